@@ -1,0 +1,190 @@
+/* plr.h - C-ABI of the MI355X-native (HIP, gfx950) backend for PlainRenderer's per-pixel frame pipeline.
+ *
+ * Drop-in boundary: the compute subset of `class RenderBackend`'s public section in the reference
+ * (Plain/src/Runtime/Rendering/Backend/RenderBackend.h:36-110) together with the plain-data pass-record
+ * structs of Plain/src/Runtime/Rendering/ResourceDescriptions.h:9-172, RenderHandles.h:4-41 and
+ * Common/ImageDescription.h:4-35. Every entry point cites the reference member it replaces.
+ * A reference-side shim (class RenderBackend implemented over these calls) is shown in INTEGRATION.md and
+ * shipped as include/plr_render_backend.hpp.
+ *
+ * Conventions: every call returns PLR_OK (0) or a negative error code (the reference prints and throws,
+ * RenderBackend.cpp:442-445; a C boundary cannot throw); plr_last_error() gives the message.
+ * All calls must come from one thread (the reference records compute passes on the main thread only).
+ * Payload pointers are copied during the call (reference: dataToCharArray, Common/Utilities/GeneralUtils.cpp:8-12).
+ * No torch types; plain pointers and sizes only.
+ */
+#ifndef PLR_H
+#define PLR_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLR_OK 0
+#define PLR_ERR_INVALID_ARGUMENT (-1)
+#define PLR_ERR_HIP (-2)
+#define PLR_ERR_UNKNOWN_SHADER (-3)
+#define PLR_ERR_BINDING (-4)
+#define PLR_ERR_NOT_INITIALISED (-5)
+#define PLR_ERR_UNSUPPORTED (-6)
+
+#define PLR_INVALID_INDEX 0xFFFFFFFFu /* RenderHandles.h:4 invalidIndex */
+
+/* Common/ImageDescription.h:4-16 (same order, same values) */
+enum plr_image_type { PLR_IMAGE_1D = 0, PLR_IMAGE_2D = 1, PLR_IMAGE_3D = 2, PLR_IMAGE_CUBE = 3 };
+enum plr_mip_count { PLR_MIP_ONE = 0, PLR_MIP_FULL_CHAIN = 1, PLR_MIP_MANUAL = 2, PLR_MIP_FULL_CHAIN_ALREADY_IN_DATA = 3 };
+enum plr_image_usage { PLR_USAGE_STORAGE = 1, PLR_USAGE_SAMPLED = 2, PLR_USAGE_ATTACHMENT = 4 };
+enum plr_image_format {
+    PLR_FORMAT_R8 = 0, PLR_FORMAT_RG8, PLR_FORMAT_RGBA8, PLR_FORMAT_R16_SFLOAT, PLR_FORMAT_RG16_SFLOAT,
+    PLR_FORMAT_RG32_SFLOAT, PLR_FORMAT_RG16_SNORM, PLR_FORMAT_RGBA16_SFLOAT, PLR_FORMAT_RGBA16_SNORM,
+    PLR_FORMAT_RGBA32_SFLOAT, PLR_FORMAT_R11G11B10_UFLOAT, PLR_FORMAT_DEPTH16, PLR_FORMAT_DEPTH32,
+    PLR_FORMAT_BC1, PLR_FORMAT_BC3, PLR_FORMAT_BC5, PLR_FORMAT_BGRA8_UNORM
+};
+
+/* RenderHandles.h:16-21 ImageHandle {type, index} */
+enum plr_image_handle_type { PLR_IMAGE_DEFAULT = 0, PLR_IMAGE_TRANSIENT = 1, PLR_IMAGE_SWAPCHAIN = 2 };
+typedef struct plr_image_handle { uint32_t type; uint32_t index; } plr_image_handle;
+typedef uint32_t plr_pass_handle;           /* RenderPassHandle.index (high bit = graphic pass, never set here) */
+typedef uint32_t plr_uniform_buffer_handle; /* UniformBufferHandle.index */
+typedef uint32_t plr_storage_buffer_handle; /* StorageBufferHandle.index */
+typedef uint32_t plr_sampler_handle;        /* SamplerHandle.index */
+
+/* ImageDescription, Common/ImageDescription.h:18-30 */
+typedef struct plr_image_desc {
+    uint32_t width, height, depth;
+    uint32_t type;             /* plr_image_type */
+    uint32_t format;           /* plr_image_format */
+    uint32_t usage_flags;      /* plr_image_usage bits */
+    uint32_t mip_count;        /* plr_mip_count */
+    uint32_t manual_mip_count; /* only if mip_count == PLR_MIP_MANUAL */
+    uint32_t auto_create_mips;
+} plr_image_desc;
+
+/* SamplerDescription, ResourceDescriptions.h:161-172 */
+typedef struct plr_sampler_desc {
+    uint32_t interpolation; /* 0 nearest, 1 linear */
+    uint32_t wrapping;      /* 0 clamp, 1 border colour, 2 repeat */
+    uint32_t use_anisotropy;
+    float max_anisotropy;
+    uint32_t border_color; /* 0 white, 1 black */
+    uint32_t max_mip;
+} plr_sampler_desc;
+
+/* ResourceDescriptions.h:9-45 */
+typedef struct plr_image_resource { plr_image_handle image; uint32_t mip_level; uint32_t binding; } plr_image_resource;
+typedef struct plr_storage_buffer_resource { plr_storage_buffer_handle buffer; uint32_t read_only; uint32_t binding; } plr_storage_buffer_resource;
+typedef struct plr_uniform_buffer_resource { plr_uniform_buffer_handle buffer; uint32_t binding; } plr_uniform_buffer_resource;
+typedef struct plr_sampler_resource { plr_sampler_handle sampler; uint32_t binding; } plr_sampler_resource;
+
+/* RenderPassResources, ResourceDescriptions.h:47-53, as flat arrays */
+typedef struct plr_pass_resources {
+    const plr_sampler_resource* samplers; uint32_t sampler_count;
+    const plr_storage_buffer_resource* storage_buffers; uint32_t storage_buffer_count;
+    const plr_uniform_buffer_resource* uniform_buffers; uint32_t uniform_buffer_count;
+    const plr_image_resource* sampled_images; uint32_t sampled_image_count;
+    const plr_image_resource* storage_images; uint32_t storage_image_count;
+} plr_pass_resources;
+
+/* ComputePassExecution, ResourceDescriptions.h:57-60,74-78 */
+typedef struct plr_compute_pass_execution {
+    plr_pass_handle handle;
+    plr_pass_resources resources;
+    const void* push_constants; uint32_t push_constant_size;
+    uint32_t dispatch_count[3];
+} plr_compute_pass_execution;
+
+/* SpecialisationConstant, ResourceDescriptions.h:112-115: raw bytes with the C++ sizeof (bool = 1 byte) */
+typedef struct plr_specialisation_constant { uint32_t location; const void* data; uint32_t size; } plr_specialisation_constant;
+
+/* ShaderDescription + ComputePassDescription, ResourceDescriptions.h:117-120,146-149 */
+typedef struct plr_compute_pass_desc {
+    const char* src_path_relative; /* e.g. "temporalFilter.comp": selects the precompiled HIP kernel */
+    const plr_specialisation_constant* specialisation_constants; uint32_t specialisation_constant_count;
+    const char* name; /* debug label, reported by plr_get_renderpass_timings */
+} plr_compute_pass_desc;
+
+/* RenderPassTime, Backend/VulkanTimestampQueries.h:17-20; name points into backend-owned storage valid until the pass is destroyed */
+typedef struct plr_renderpass_time { float time_ms; const char* name; } plr_renderpass_time;
+
+/* ---- lifetime: RenderBackend::setup / shutdown / recreateSwapchain (RenderBackend.h:36-38).
+ * There is no window: the "swapchain input image" is an off-screen BGRA8 image of the given size. */
+int plr_setup(int device_ordinal, uint32_t width, uint32_t height);
+int plr_shutdown(void);
+int plr_recreate_swapchain(uint32_t width, uint32_t height);
+const char* plr_last_error(void);
+
+/* RenderBackend::waitForGPUIdle, RenderBackend.h:41 */
+int plr_wait_for_gpu_idle(void);
+/* RenderBackend::updateShaderCode, RenderBackend.h:44: kernels are precompiled, nothing to reload */
+int plr_update_shader_code(void);
+/* RenderBackend::resizeImages, RenderBackend.h:47 */
+int plr_resize_images(const plr_image_handle* images, uint32_t count, uint32_t width, uint32_t height);
+/* RenderBackend::newFrame, RenderBackend.h:50: drops recorded executions and transient images */
+int plr_new_frame(void);
+/* RenderBackend::setComputePassExecution, RenderBackend.h:56 */
+int plr_set_compute_pass_execution(const plr_compute_pass_execution* execution);
+/* RenderBackend::prepareForDrawcallRecording, RenderBackend.h:59: resolves transient images, validates bindings */
+int plr_prepare_for_drawcall_recording(void);
+/* RenderBackend::setUniformBufferData / setStorageBufferData, RenderBackend.h:64-70:
+ * data is copied now and applied, in call order, at the start of the next plr_render_frame */
+int plr_set_uniform_buffer_data(plr_uniform_buffer_handle buffer, const void* data, size_t size);
+int plr_set_storage_buffer_data(plr_storage_buffer_handle buffer, const void* data, size_t size);
+/* RenderBackend::setGlobalDescriptorSetResources, RenderBackend.h:75: set 0 = binding 0 `global` UBO plus the
+ * eight samplers of resources/shaders/global.inc:35-42 at bindings 1..8 (sampler semantics are fixed by binding) */
+int plr_set_global_descriptor_set_resources(const plr_pass_resources* resources);
+/* RenderBackend::updateComputePassShaderDescription, RenderBackend.h:79 */
+int plr_update_compute_pass_shader_description(plr_pass_handle pass, const plr_compute_pass_desc* desc);
+/* RenderBackend::renderFrame, RenderBackend.h:82: applies deferred buffer fills, launches the recorded passes
+ * in record order on one HIP stream (in-order = the reference's barrier rule), does not block the host */
+int plr_render_frame(int present_to_screen);
+/* RenderBackend::getImageGlobalTextureArrayIndex, RenderBackend.h:84 (bindless set 2) */
+int plr_get_image_global_texture_array_index(plr_image_handle image, uint32_t* out_index);
+/* RenderBackend::createComputePass, RenderBackend.h:88 */
+int plr_create_compute_pass(const plr_compute_pass_desc* desc, plr_pass_handle* out_pass);
+/* RenderBackend::createImage, RenderBackend.h:93 */
+int plr_create_image(const plr_image_desc* desc, const void* initial_data, size_t initial_data_size, plr_image_handle* out_image);
+/* RenderBackend::createUniformBuffer / createStorageBuffer, RenderBackend.h:94-95 */
+int plr_create_uniform_buffer(size_t size, const void* initial_data, plr_uniform_buffer_handle* out_buffer);
+int plr_create_storage_buffer(size_t size, const void* initial_data, plr_storage_buffer_handle* out_buffer);
+/* RenderBackend::createSampler, RenderBackend.h:96 */
+int plr_create_sampler(const plr_sampler_desc* desc, plr_sampler_handle* out_sampler);
+/* RenderBackend::createTemporaryImage, RenderBackend.h:101: valid until the next plr_new_frame */
+int plr_create_temporary_image(const plr_image_desc* desc, plr_image_handle* out_image);
+/* RenderBackend::getSwapchainInputImage, RenderBackend.h:103 */
+int plr_get_swapchain_input_image(plr_image_handle* out_image);
+/* RenderBackend::getMemoryStats, RenderBackend.h:105 */
+int plr_get_memory_stats(uint64_t* out_allocated_size, uint64_t* out_used_size);
+/* RenderBackend::getRenderpassTimings, RenderBackend.h:107: hipEvent time of each pass of the last completed frame
+ * (enable with plr_set_pass_timing; off by default because the event pairs serialise the launch stream) */
+int plr_get_renderpass_timings(plr_renderpass_time* out_times, uint32_t* inout_count);
+/* RenderBackend::getLastFrameCPUTime, RenderBackend.h:108 */
+int plr_get_last_frame_cpu_time(float* out_ms);
+/* RenderBackend::getImageDescription, RenderBackend.h:110 */
+int plr_get_image_description(plr_image_handle image, plr_image_desc* out_desc);
+
+/* ---- additions with no reference counterpart (host <-> HBM transfer for tests and benchmarks) ---- */
+int plr_set_pass_timing(int enabled);
+/* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
+int plr_get_last_frame_gpu_time(float* out_ms);
+/* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */
+int plr_replay_frame(uint32_t count, float* out_total_gpu_ms);
+int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size);
+int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size);
+int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size);
+int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size);
+/* device address / byte size of one mip level (HBM resident; lets a caller fill inputs device-to-device) */
+int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, void** out_ptr, size_t* out_size);
+int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size);
+/* the hipStream_t all passes are launched on */
+int plr_get_stream(void** out_hip_stream);
+/* lists the shader names the backend has kernels for; returns the count */
+int plr_get_supported_shaders(const char** out_names, uint32_t capacity);
+/* detmath / codec probes on the device (same function ids as oracle/probes.cpp); pointers are host memory */
+int plr_debug_math_eval(int fn, const float* a, const float* b, float* out, int64_t n);
+int plr_debug_codec_eval(int fn, const void* in, void* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLR_H */

@@ -1,0 +1,107 @@
+"""ORACLE binding (test infrastructure): ctypes access to oracle/_build/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module. It lives under
+oracle/ on purpose: the product package (plainrenderer_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(verbose=False):
+    r = subprocess.run(["make", "-C", _HERE, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+class OrcImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("d", C.c_int32), ("format", C.c_int32)]
+
+
+class OrcGlobal(C.Structure):
+    _fields_ = [
+        ("viewProjection", C.c_float * 16), ("viewProjectionPrevious", C.c_float * 16), ("sunDirection", C.c_float * 4),
+        ("cameraPosition", C.c_float * 4), ("cameraPositionPrevious", C.c_float * 4), ("cameraRight", C.c_float * 4),
+        ("cameraUp", C.c_float * 4), ("cameraForward", C.c_float * 4), ("cameraForwardPrevious", C.c_float * 4),
+        ("noiseTextureIndices", C.c_int32 * 4), ("currentFrameCameraJitter", C.c_float * 2),
+        ("previousFrameCameraJitter", C.c_float * 2), ("screenResolution", C.c_int32 * 2), ("cameraTanFovHalf", C.c_float),
+        ("cameraAspectRatio", C.c_float), ("nearPlane", C.c_float), ("farPlane", C.c_float), ("sunStrength", C.c_float),
+        ("exposureOffset", C.c_float), ("exposureAdaptionSpeedEvPerSec", C.c_float), ("deltaTime", C.c_float), ("time", C.c_float),
+        ("mipBias", C.c_float), ("cameraCut", C.c_uint32), ("frameIndex", C.c_uint32), ("frameIndexMod2", C.c_uint32),
+        ("frameIndexMod3", C.c_uint32), ("frameIndexMod4", C.c_uint32),
+    ]
+
+
+assert C.sizeof(OrcGlobal) == 340
+
+
+class OrcLightBuffer(C.Structure):
+    _fields_ = [("sunColor", C.c_float * 3), ("previousFrameExposure", C.c_float), ("sunStrengthExposed", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+class Img:
+    """numpy-backed image: `arr` holds the packed texels (any dtype, contiguous), x fastest then y then z."""
+
+    def __init__(self, arr, w, h, fmt, d=1):
+        self.arr = np.ascontiguousarray(arr)
+        self.w, self.h, self.d, self.fmt = int(w), int(h), int(d), int(fmt)
+        self.c = OrcImage(self.arr.ctypes.data_as(C.c_void_p), self.w, self.h, self.d, self.fmt)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def new_image(w, h, fmt, bytes_per_texel, d=1):
+    return Img(np.zeros(w * h * d * bytes_per_texel, np.uint8), w, h, fmt, d)
+
+
+def global_from_bytes(b):
+    g = OrcGlobal()
+    C.memmove(C.byref(g), bytes(b), 340)
+    return g
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int32(n))
+
+
+def math_eval(fn, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+        bp = _p(b)
+    lib().orc_math_eval(C.c_int(fn), _p(a), bp, _p(out), C.c_int64(a.size))
+    return out
+
+
+def codec_eval(fn, data, n, out_dtype, out_count):
+    data = np.ascontiguousarray(data)
+    out = np.empty(out_count, out_dtype)
+    lib().orc_codec_eval(C.c_int(fn), _p(data), _p(out), C.c_int64(n))
+    return out

@@ -1,0 +1,91 @@
+"""Builds the HIP backend (libplr.so) for gfx950 with hipcc, in-tree.
+
+Every translation unit is compiled with -ffp-contract=off: the kernels' arithmetic is specified operation
+by operation (no FMA contraction) so results are reproducible against an IEEE scalar evaluation.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(CSRC, "_obj")
+LIB_PATH = os.path.join(HERE, "libplr.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
+]
+
+
+def _sources():
+    out = [os.path.join(CSRC, "backend.cpp")]
+    for sub in ("kernels", "frontend"):
+        d = os.path.join(CSRC, sub)
+        if os.path.isdir(d):
+            for f in sorted(os.listdir(d)):
+                if f.endswith((".hip", ".cpp")):
+                    out.append(os.path.join(d, f))
+    return out
+
+
+def _headers_digest():
+    h = hashlib.sha1()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for dp, _, files in os.walk(root):
+            if "_obj" in dp:
+                continue
+            for f in sorted(files):
+                if f.endswith((".h", ".hpp")):
+                    with open(os.path.join(dp, f), "rb") as fh:
+                        h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src, digest, verbose):
+    obj = os.path.join(OBJ_DIR, os.path.relpath(src, CSRC).replace(os.sep, "_") + ".o")
+    stamp = obj + ".stamp"
+    with open(src, "rb") as fh:
+        key = hashlib.sha1(fh.read() + digest.encode()).hexdigest()
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
+        return obj, False
+    cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip() and verbose:
+        print(r.stderr)
+    with open(stamp, "w") as fh:
+        fh.write(key)
+    return obj, True
+
+
+def build(verbose=False, jobs=None):
+    """Compile every HIP source for gfx950 and link libplr.so. Cross-compiles without a GPU."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    digest = _headers_digest()
+    srcs = _sources()
+    jobs = jobs or min(6, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(lambda s: _compile(s, digest, verbose), srcs))
+    objs = [o for o, _ in results]
+    changed = any(c for _, c in results)
+    if changed or not os.path.exists(LIB_PATH):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(verbose="-v" in sys.argv))

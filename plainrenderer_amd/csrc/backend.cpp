@@ -1,0 +1,790 @@
+// HIP backend runtime behind the C-ABI of include/plr.h.
+//
+// Replaces the Vulkan body of the reference's RenderBackend (Plain/src/Runtime/Rendering/Backend/
+// RenderBackend.cpp) for compute passes: images and buffers are plain HBM allocations, a "pass" is a
+// precompiled HIP kernel selected by the shader file name, and a frame is the recorded list of
+// executions launched in order on one HIP stream (in-order execution gives the reference's
+// write->read barrier rule, RenderBackend.cpp:632-767, for free).
+#include "backend.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "../../include/plr.h"
+
+namespace plr {
+
+// ---------------------------------------------------------------- registry
+struct ShaderEntry { std::string name; LaunchFn fn; };
+static std::vector<ShaderEntry>& registry() {
+    static std::vector<ShaderEntry> r;
+    return r;
+}
+ShaderRegistrar::ShaderRegistrar(const char* name, LaunchFn fn) { registry().push_back({name, fn}); }
+
+static LaunchFn findShader(const std::string& path) {
+    std::string base = path;
+    const size_t slash = base.find_last_of("/\\");
+    if (slash != std::string::npos) base = base.substr(slash + 1);
+    for (const auto& e : registry())
+        if (e.name == base) return e.fn;
+    return nullptr;
+}
+
+// ---------------------------------------------------------------- PassCtx helpers
+const SpecConstant* PassCtx::findSpec(uint32_t location) const {
+    if (!spec) return nullptr;
+    for (const auto& s : *spec)
+        if (s.location == location) return &s;
+    return nullptr;
+}
+int32_t PassCtx::specInt(uint32_t location, int32_t def) const {
+    const SpecConstant* s = findSpec(location);
+    if (!s || s->data.empty()) return def;
+    if (s->data.size() >= 4) { int32_t v; std::memcpy(&v, s->data.data(), 4); return v; }
+    return (int32_t)s->data[0];
+}
+float PassCtx::specFloat(uint32_t location, float def) const {
+    const SpecConstant* s = findSpec(location);
+    if (!s || s->data.size() < 4) return def;
+    float v; std::memcpy(&v, s->data.data(), 4); return v;
+}
+bool PassCtx::specBool(uint32_t location, bool def) const {
+    const SpecConstant* s = findSpec(location);
+    if (!s || s->data.empty()) return def;
+    // host passes sizeof(bool) == 1 byte (Backend/VulkanShader.cpp:4-23); accept 4-byte VkBool32 too
+    if (s->data.size() >= 4) { uint32_t v; std::memcpy(&v, s->data.data(), 4); return v != 0; }
+    return s->data[0] != 0;
+}
+int PassCtx::fail(int code, const std::string& msg) const {
+    if (err) *err = msg;
+    return code;
+}
+static const char* formatName(int f) {
+    static const char* names[] = {"R8", "RG8", "RGBA8", "R16_sFloat", "RG16_sFloat", "RG32_sFloat", "RG16_sNorm", "RGBA16_sFloat",
+                                  "RGBA16_sNorm", "RGBA32_sFloat", "R11G11B10_uFloat", "Depth16", "Depth32", "BC1", "BC3", "BC5", "BGRA8_uNorm"};
+    return (f >= 0 && f <= 16) ? names[f] : "?";
+}
+int PassCtx::needSampled(int b, int fmt, const char* what) const {
+    if (!hasSampled(b)) return fail(PLR_ERR_BINDING, std::string("missing sampled image at binding ") + std::to_string(b) + " (" + what + ")");
+    if (fmt >= 0 && sampled[b].fmt != fmt)
+        return fail(PLR_ERR_BINDING, std::string(what) + ": sampled binding " + std::to_string(b) + " expects " + formatName(fmt) + ", got " + formatName(sampled[b].fmt));
+    return 0;
+}
+int PassCtx::needStorage(int b, int fmt, const char* what) const {
+    if (!hasStorage(b)) return fail(PLR_ERR_BINDING, std::string("missing storage image at binding ") + std::to_string(b) + " (" + what + ")");
+    if (fmt >= 0 && storage[b].fmt != fmt)
+        return fail(PLR_ERR_BINDING, std::string(what) + ": storage binding " + std::to_string(b) + " expects " + formatName(fmt) + ", got " + formatName(storage[b].fmt));
+    return 0;
+}
+int PassCtx::needSbuf(int b, size_t minSize, const char* what) const {
+    if (!hasSbuf(b)) return fail(PLR_ERR_BINDING, std::string("missing storage buffer at binding ") + std::to_string(b) + " (" + what + ")");
+    if (sbuf[b].size < minSize)
+        return fail(PLR_ERR_BINDING, std::string(what) + ": storage buffer at binding " + std::to_string(b) + " has " + std::to_string(sbuf[b].size) + " bytes, needs " + std::to_string(minSize));
+    return 0;
+}
+int PassCtx::needUbuf(int b, size_t minSize, const char* what) const {
+    if (!hasUbuf(b)) return fail(PLR_ERR_BINDING, std::string("missing uniform buffer at binding ") + std::to_string(b) + " (" + what + ")");
+    if (ubuf[b].size < minSize)
+        return fail(PLR_ERR_BINDING, std::string(what) + ": uniform buffer at binding " + std::to_string(b) + " too small");
+    return 0;
+}
+int PassCtx::needGlobal() const {
+    if (!global) return fail(PLR_ERR_BINDING, "global uniform buffer (set 0 binding 0) not set: call plr_set_global_descriptor_set_resources");
+    return 0;
+}
+void* PassCtx::scratch(size_t bytes) const {
+    if (!scratchSlot) return nullptr;
+    if (*scratchSize < bytes) {
+        if (*scratchSlot) { hipStreamSynchronize(stream); hipFree(*scratchSlot); }
+        *scratchSlot = nullptr;
+        if (hipMalloc(scratchSlot, bytes) != hipSuccess) { *scratchSize = 0; return nullptr; }
+        hipMemsetAsync(*scratchSlot, 0, bytes, stream);
+        *scratchSize = bytes;
+    }
+    return *scratchSlot;
+}
+
+// ---------------------------------------------------------------- resources
+static int formatBytes(uint32_t f) {
+    switch (f) {
+        case PLR_FORMAT_R8: return 1; case PLR_FORMAT_RG8: return 2; case PLR_FORMAT_RGBA8: return 4;
+        case PLR_FORMAT_R16_SFLOAT: return 2; case PLR_FORMAT_RG16_SFLOAT: return 4; case PLR_FORMAT_RG32_SFLOAT: return 8;
+        case PLR_FORMAT_RG16_SNORM: return 4; case PLR_FORMAT_RGBA16_SFLOAT: return 8; case PLR_FORMAT_RGBA16_SNORM: return 8;
+        case PLR_FORMAT_RGBA32_SFLOAT: return 16; case PLR_FORMAT_R11G11B10_UFLOAT: return 4; case PLR_FORMAT_DEPTH16: return 2;
+        case PLR_FORMAT_DEPTH32: return 4; case PLR_FORMAT_BGRA8_UNORM: return 4;
+        default: return 0; // BCn: not on the hot path
+    }
+}
+
+struct MipInfo { uint32_t w, h, d; size_t offset, bytes; };
+
+struct ImageRes {
+    plr_image_desc desc{};
+    std::vector<MipInfo> mips;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    bool inUse = false; // transient pool bookkeeping
+};
+
+struct BufferRes {
+    void* dev = nullptr;
+    size_t size = 0;
+};
+
+struct PassRes {
+    std::string shader, name;
+    std::vector<SpecConstant> spec;
+    LaunchFn fn = nullptr;
+    void* scratch = nullptr;
+    size_t scratchSize = 0;
+};
+
+struct Execution {
+    uint32_t pass;
+    PassCtx ctx;
+};
+
+struct FillOrder {
+    void* dst;
+    size_t size;
+    size_t stagingOffset;
+};
+
+struct Backend {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<ImageRes> images;
+    std::vector<ImageRes> transient;
+    ImageRes swapchain;
+    std::vector<BufferRes> ubufs, sbufs;
+    std::vector<plr_sampler_desc> samplers;
+    std::vector<std::unique_ptr<PassRes>> passes;
+    std::vector<Execution> executions;
+    std::vector<FillOrder> fills;
+    std::vector<uint8_t> fillData;
+    void* pinned = nullptr;
+    size_t pinnedSize = 0;
+    hipEvent_t pinnedFree = nullptr; // signalled when the last frame's H2D copies have left the pinned buffer
+    bool pinnedBusy = false;
+    uint32_t globalUbo = PLR_INVALID_INDEX;
+    ImgView* bindlessDev = nullptr;
+    uint32_t bindlessCapacity = 0;
+    bool bindlessDirty = true;
+    uint64_t allocated = 0;
+    bool passTiming = false;
+    std::vector<hipEvent_t> passEvents; // 2 per execution
+    std::vector<plr_renderpass_time> lastTimings;
+    size_t timedExecutions = 0;
+    hipEvent_t frameStart = nullptr, frameEnd = nullptr;
+    bool frameRecorded = false;
+    float lastCpuMs = 0.f;
+};
+
+static Backend* g = nullptr;
+static thread_local std::string g_err;
+
+static int setErr(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x)                                                                                      \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) return setErr(PLR_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define NEED_INIT() \
+    if (!g) return setErr(PLR_ERR_NOT_INITIALISED, "plr_setup has not been called")
+
+static uint32_t mipCountFromResolution(uint32_t w, uint32_t h, uint32_t d) {
+    // Common/Utilities/MathUtils.cpp:17-19
+    uint32_t m = std::max(std::max(w, h), d);
+    uint32_t c = 1;
+    while (m > 1) { m >>= 1; c++; }
+    return c;
+}
+
+static int layoutImage(ImageRes& im, const plr_image_desc& d) {
+    const int bpp = formatBytes(d.format);
+    if (bpp == 0) return setErr(PLR_ERR_UNSUPPORTED, "image format not supported by the HIP backend (BCn formats are outside the hot path)");
+    if (d.width == 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "image width is 0");
+    im.desc = d;
+    const uint32_t w = d.width, h = std::max(d.height, 1u), dep = std::max(d.depth, 1u);
+    uint32_t levels = 1;
+    if (d.mip_count == PLR_MIP_FULL_CHAIN || d.mip_count == PLR_MIP_FULL_CHAIN_ALREADY_IN_DATA) levels = mipCountFromResolution(w, h, dep);
+    else if (d.mip_count == PLR_MIP_MANUAL) levels = std::max(d.manual_mip_count, 1u);
+    im.mips.clear();
+    size_t off = 0;
+    for (uint32_t m = 0; m < levels; m++) {
+        MipInfo mi;
+        mi.w = std::max(w >> m, 1u); mi.h = std::max(h >> m, 1u); mi.d = std::max(dep >> m, 1u);
+        mi.offset = off;
+        mi.bytes = (size_t)mi.w * mi.h * mi.d * bpp;
+        off += (mi.bytes + 255) & ~(size_t)255; // 256-byte aligned mip bases keep dwordx4 accesses aligned
+        im.mips.push_back(mi);
+    }
+    im.bytes = off;
+    return PLR_OK;
+}
+
+static int allocImage(ImageRes& im, const plr_image_desc& d) {
+    int rc = layoutImage(im, d);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(&im.dev, im.bytes));
+    HIP_TRY(hipMemsetAsync(im.dev, 0, im.bytes, g->stream));
+    g->allocated += im.bytes;
+    return PLR_OK;
+}
+
+static void freeImage(ImageRes& im) {
+    if (im.dev) { hipFree(im.dev); g->allocated -= im.bytes; }
+    im.dev = nullptr; im.bytes = 0; im.mips.clear();
+}
+
+static ImageRes* resolveImage(plr_image_handle h) {
+    if (h.type == PLR_IMAGE_DEFAULT) return h.index < g->images.size() && g->images[h.index].dev ? &g->images[h.index] : nullptr;
+    if (h.type == PLR_IMAGE_TRANSIENT) return h.index < g->transient.size() && g->transient[h.index].inUse ? &g->transient[h.index] : nullptr;
+    if (h.type == PLR_IMAGE_SWAPCHAIN) return g->swapchain.dev ? &g->swapchain : nullptr;
+    return nullptr;
+}
+
+static ImgView makeView(const ImageRes& im, uint32_t mip) {
+    ImgView v;
+    const MipInfo& mi = im.mips[mip];
+    v.ptr = (uint8_t*)im.dev + mi.offset;
+    v.w = (int32_t)mi.w; v.h = (int32_t)mi.h; v.d = (int32_t)mi.d;
+    v.fmt = (int32_t)im.desc.format;
+    return v;
+}
+
+static bool sameDesc(const plr_image_desc& a, const plr_image_desc& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+
+} // namespace plr
+
+using namespace plr;
+
+extern "C" {
+
+const char* plr_last_error(void) { return g_err.c_str(); }
+
+int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
+    if (g) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_setup called twice; call plr_shutdown first");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return setErr(PLR_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e) + " (this backend has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= count) return setErr(PLR_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    g = new Backend();
+    g->device = device_ordinal;
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&g->frameStart));
+    HIP_TRY(hipEventCreate(&g->frameEnd));
+    HIP_TRY(hipEventCreateWithFlags(&g->pinnedFree, hipEventDisableTiming));
+    return plr_recreate_swapchain(width, height);
+}
+
+int plr_shutdown(void) {
+    if (!g) return PLR_OK;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    for (auto& im : g->images) freeImage(im);
+    for (auto& im : g->transient) freeImage(im);
+    freeImage(g->swapchain);
+    for (auto& b : g->ubufs) if (b.dev) hipFree(b.dev);
+    for (auto& b : g->sbufs) if (b.dev) hipFree(b.dev);
+    for (auto& p : g->passes) if (p->scratch) hipFree(p->scratch);
+    for (auto ev : g->passEvents) hipEventDestroy(ev);
+    if (g->bindlessDev) hipFree(g->bindlessDev);
+    if (g->pinned) hipHostFree(g->pinned);
+    hipEventDestroy(g->frameStart); hipEventDestroy(g->frameEnd); hipEventDestroy(g->pinnedFree);
+    hipStreamDestroy(g->stream);
+    delete g;
+    g = nullptr;
+    return PLR_OK;
+}
+
+int plr_recreate_swapchain(uint32_t width, uint32_t height) {
+    NEED_INIT();
+    if (width == 0 || height == 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "swapchain size must be non-zero");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    freeImage(g->swapchain);
+    plr_image_desc d{};
+    d.width = width; d.height = height; d.depth = 1; d.type = PLR_IMAGE_2D; d.format = PLR_FORMAT_BGRA8_UNORM;
+    d.usage_flags = PLR_USAGE_STORAGE; d.mip_count = PLR_MIP_ONE; d.manual_mip_count = 1;
+    return allocImage(g->swapchain, d);
+}
+
+int plr_wait_for_gpu_idle(void) {
+    NEED_INIT();
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+
+int plr_update_shader_code(void) { NEED_INIT(); return PLR_OK; }
+
+int plr_resize_images(const plr_image_handle* images, uint32_t count, uint32_t width, uint32_t height) {
+    NEED_INIT();
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    for (uint32_t i = 0; i < count; i++) {
+        if (images[i].type != PLR_IMAGE_DEFAULT) return setErr(PLR_ERR_INVALID_ARGUMENT, "only default images can be resized");
+        ImageRes* im = resolveImage(images[i]);
+        if (!im) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_resize_images: invalid image handle");
+        plr_image_desc d = im->desc;
+        d.width = width; d.height = height;
+        freeImage(*im);
+        int rc = allocImage(*im, d);
+        if (rc) return rc;
+    }
+    g->bindlessDirty = true;
+    return PLR_OK;
+}
+
+int plr_new_frame(void) {
+    NEED_INIT();
+    g->executions.clear();
+    for (auto& t : g->transient) t.inUse = false;
+    return PLR_OK;
+}
+
+static int resolveResources(const plr_pass_resources& r, PassCtx& ctx) {
+    for (uint32_t i = 0; i < r.sampled_image_count; i++) {
+        const plr_image_resource& ir = r.sampled_images[i];
+        if (ir.binding >= (uint32_t)kMaxBindings) return setErr(PLR_ERR_BINDING, "sampled image binding index too large");
+        ImageRes* im = resolveImage(ir.image);
+        if (!im) return setErr(PLR_ERR_BINDING, "sampled image at binding " + std::to_string(ir.binding) + ": invalid image handle");
+        if (ir.mip_level >= im->mips.size()) return setErr(PLR_ERR_BINDING, "sampled image mip level out of range");
+        ctx.sampled[ir.binding] = makeView(*im, ir.mip_level);
+        ctx.sampledMask |= 1u << ir.binding;
+    }
+    for (uint32_t i = 0; i < r.storage_image_count; i++) {
+        const plr_image_resource& ir = r.storage_images[i];
+        if (ir.binding >= (uint32_t)kMaxBindings) return setErr(PLR_ERR_BINDING, "storage image binding index too large");
+        ImageRes* im = resolveImage(ir.image);
+        if (!im) return setErr(PLR_ERR_BINDING, "storage image at binding " + std::to_string(ir.binding) + ": invalid image handle");
+        if (ir.mip_level >= im->mips.size()) return setErr(PLR_ERR_BINDING, "storage image mip level out of range");
+        ctx.storage[ir.binding] = makeView(*im, ir.mip_level);
+        ctx.storageMask |= 1u << ir.binding;
+    }
+    for (uint32_t i = 0; i < r.storage_buffer_count; i++) {
+        const plr_storage_buffer_resource& br = r.storage_buffers[i];
+        if (br.binding >= (uint32_t)kMaxBindings || br.buffer >= g->sbufs.size()) return setErr(PLR_ERR_BINDING, "invalid storage buffer resource");
+        ctx.sbuf[br.binding] = {g->sbufs[br.buffer].dev, g->sbufs[br.buffer].size, br.read_only != 0};
+        ctx.sbufMask |= 1u << br.binding;
+    }
+    for (uint32_t i = 0; i < r.uniform_buffer_count; i++) {
+        const plr_uniform_buffer_resource& br = r.uniform_buffers[i];
+        if (br.binding >= (uint32_t)kMaxBindings || br.buffer >= g->ubufs.size()) return setErr(PLR_ERR_BINDING, "invalid uniform buffer resource");
+        ctx.ubuf[br.binding] = {g->ubufs[br.buffer].dev, g->ubufs[br.buffer].size, true};
+        ctx.ubufMask |= 1u << br.binding;
+    }
+    return PLR_OK;
+}
+
+int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
+    NEED_INIT();
+    if (!e) return setErr(PLR_ERR_INVALID_ARGUMENT, "execution is null");
+    if (e->handle >= g->passes.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid pass handle");
+    g->executions.emplace_back();
+    Execution& x = g->executions.back();
+    x.pass = e->handle;
+    int rc = resolveResources(e->resources, x.ctx);
+    if (rc) { g->executions.pop_back(); return rc; }
+    if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
+    for (int i = 0; i < 3; i++) x.ctx.dispatch[i] = e->dispatch_count[i];
+    return PLR_OK;
+}
+
+int plr_prepare_for_drawcall_recording(void) { NEED_INIT(); return PLR_OK; }
+
+static int queueFill(void* dst, size_t cap, const void* data, size_t size) {
+    if (!data && size) return setErr(PLR_ERR_INVALID_ARGUMENT, "buffer data is null");
+    if (size > cap) return setErr(PLR_ERR_INVALID_ARGUMENT, "buffer data (" + std::to_string(size) + " B) larger than the buffer (" + std::to_string(cap) + " B)");
+    if (size == 0) return PLR_OK;
+    const size_t off = (g->fillData.size() + 15) & ~(size_t)15;
+    g->fillData.resize(off + size);
+    std::memcpy(g->fillData.data() + off, data, size);
+    g->fills.push_back({dst, size, off});
+    return PLR_OK;
+}
+
+int plr_set_uniform_buffer_data(plr_uniform_buffer_handle buffer, const void* data, size_t size) {
+    NEED_INIT();
+    if (buffer >= g->ubufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid uniform buffer handle");
+    return queueFill(g->ubufs[buffer].dev, g->ubufs[buffer].size, data, size);
+}
+
+int plr_set_storage_buffer_data(plr_storage_buffer_handle buffer, const void* data, size_t size) {
+    NEED_INIT();
+    if (buffer >= g->sbufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid storage buffer handle");
+    return queueFill(g->sbufs[buffer].dev, g->sbufs[buffer].size, data, size);
+}
+
+int plr_set_global_descriptor_set_resources(const plr_pass_resources* r) {
+    NEED_INIT();
+    if (!r) return setErr(PLR_ERR_INVALID_ARGUMENT, "resources is null");
+    for (uint32_t i = 0; i < r->uniform_buffer_count; i++) {
+        if (r->uniform_buffers[i].binding == 0) {
+            if (r->uniform_buffers[i].buffer >= g->ubufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid global uniform buffer handle");
+            if (g->ubufs[r->uniform_buffers[i].buffer].size < sizeof(GlobalUbo)) return setErr(PLR_ERR_INVALID_ARGUMENT, "global uniform buffer smaller than 340 bytes");
+            g->globalUbo = r->uniform_buffers[i].buffer;
+        }
+    }
+    // samplers at bindings 1..8: their filter/address semantics are fixed by the binding number in every kernel,
+    // exactly as each GLSL shader names g_sampler_* explicitly (resources/shaders/global.inc:35-42)
+    return PLR_OK;
+}
+
+static int fillPass(PassRes& p, const plr_compute_pass_desc* desc) {
+    if (!desc || !desc->src_path_relative) return setErr(PLR_ERR_INVALID_ARGUMENT, "pass description / shader path is null");
+    LaunchFn fn = findShader(desc->src_path_relative);
+    if (!fn) return setErr(PLR_ERR_UNKNOWN_SHADER, std::string("no HIP kernel for shader '") + desc->src_path_relative + "'");
+    p.shader = desc->src_path_relative;
+    if (desc->name) p.name = desc->name;
+    p.fn = fn;
+    p.spec.clear();
+    for (uint32_t i = 0; i < desc->specialisation_constant_count; i++) {
+        const auto& s = desc->specialisation_constants[i];
+        SpecConstant c;
+        c.location = s.location;
+        if (s.size) c.data.assign((const uint8_t*)s.data, (const uint8_t*)s.data + s.size);
+        p.spec.push_back(std::move(c));
+    }
+    return PLR_OK;
+}
+
+int plr_update_compute_pass_shader_description(plr_pass_handle pass, const plr_compute_pass_desc* desc) {
+    NEED_INIT();
+    if (pass >= g->passes.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid pass handle");
+    plr_compute_pass_desc d = *desc;
+    std::string keepName = g->passes[pass]->name;
+    int rc = fillPass(*g->passes[pass], &d);
+    if (!desc->name) g->passes[pass]->name = keepName;
+    return rc;
+}
+
+int plr_create_compute_pass(const plr_compute_pass_desc* desc, plr_pass_handle* out_pass) {
+    NEED_INIT();
+    if (!out_pass) return setErr(PLR_ERR_INVALID_ARGUMENT, "out_pass is null");
+    auto p = std::make_unique<PassRes>();
+    int rc = fillPass(*p, desc);
+    if (rc) return rc;
+    g->passes.push_back(std::move(p));
+    *out_pass = (plr_pass_handle)(g->passes.size() - 1);
+    return PLR_OK;
+}
+
+static int flushFills() {
+    if (g->fills.empty()) return PLR_OK;
+    if (g->pinnedBusy) { HIP_TRY(hipEventSynchronize(g->pinnedFree)); g->pinnedBusy = false; }
+    if (g->pinnedSize < g->fillData.size()) {
+        if (g->pinned) hipHostFree(g->pinned);
+        g->pinnedSize = std::max<size_t>(g->fillData.size() * 2, 1 << 20);
+        HIP_TRY(hipHostMalloc(&g->pinned, g->pinnedSize, hipHostMallocDefault));
+    }
+    std::memcpy(g->pinned, g->fillData.data(), g->fillData.size());
+    for (const auto& f : g->fills)
+        HIP_TRY(hipMemcpyAsync(f.dst, (uint8_t*)g->pinned + f.stagingOffset, f.size, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipEventRecord(g->pinnedFree, g->stream));
+    g->pinnedBusy = true;
+    g->fills.clear();
+    g->fillData.clear();
+    return PLR_OK;
+}
+
+static int flushBindless() {
+    if (!g->bindlessDirty) return PLR_OK;
+    const uint32_t n = (uint32_t)g->images.size();
+    if (n == 0) { g->bindlessDirty = false; return PLR_OK; }
+    if (g->bindlessCapacity < n) {
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (g->bindlessDev) hipFree(g->bindlessDev);
+        g->bindlessCapacity = std::max(n * 2, 64u);
+        HIP_TRY(hipMalloc((void**)&g->bindlessDev, sizeof(ImgView) * g->bindlessCapacity));
+    }
+    std::vector<ImgView> table(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (g->images[i].dev) table[i] = makeView(g->images[i], 0);
+        else { table[i].ptr = nullptr; table[i].w = table[i].h = table[i].d = 0; table[i].fmt = -1; }
+    }
+    HIP_TRY(hipMemcpyAsync(g->bindlessDev, table.data(), sizeof(ImgView) * n, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->bindlessDirty = false;
+    return PLR_OK;
+}
+
+static int launchAll(bool timed) {
+    const size_t n = g->executions.size();
+    if (timed) {
+        while (g->passEvents.size() < 2 * n) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            g->passEvents.push_back(ev);
+        }
+    }
+    const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
+    for (size_t i = 0; i < n; i++) {
+        Execution& x = g->executions[i];
+        PassRes& p = *g->passes[x.pass];
+        x.ctx.stream = g->stream;
+        x.ctx.global = globalPtr;
+        x.ctx.bindless = g->bindlessDev;
+        x.ctx.bindlessCount = (uint32_t)g->images.size();
+        x.ctx.spec = &p.spec;
+        x.ctx.err = &g_err;
+        x.ctx.scratchSlot = &p.scratch;
+        x.ctx.scratchSize = &p.scratchSize;
+        if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
+        int rc = p.fn(x.ctx);
+        if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
+        if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
+    }
+    return PLR_OK;
+}
+
+int plr_render_frame(int /*present_to_screen*/) {
+    NEED_INIT();
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = flushFills();
+    if (rc) return rc;
+    rc = flushBindless();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->frameStart, g->stream));
+    rc = launchAll(g->passTiming);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->frameEnd, g->stream));
+    g->frameRecorded = true;
+    g->timedExecutions = g->passTiming ? g->executions.size() : 0;
+    if (g->passTiming) {
+        g->lastTimings.clear();
+        for (auto& x : g->executions) g->lastTimings.push_back({0.f, g->passes[x.pass]->name.c_str()});
+    }
+    g->lastCpuMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PLR_OK;
+}
+
+int plr_replay_frame(uint32_t count, float* out_total_gpu_ms) {
+    NEED_INIT();
+    int rc = flushFills();
+    if (rc) return rc;
+    rc = flushBindless();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g->frameStart, g->stream));
+    for (uint32_t i = 0; i < count; i++) {
+        rc = launchAll(false);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(g->frameEnd, g->stream));
+    HIP_TRY(hipEventSynchronize(g->frameEnd));
+    g->frameRecorded = true;
+    g->timedExecutions = 0;
+    if (out_total_gpu_ms) HIP_TRY(hipEventElapsedTime(out_total_gpu_ms, g->frameStart, g->frameEnd));
+    return PLR_OK;
+}
+
+int plr_get_image_global_texture_array_index(plr_image_handle image, uint32_t* out_index) {
+    NEED_INIT();
+    if (image.type != PLR_IMAGE_DEFAULT || !resolveImage(image)) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid image handle");
+    *out_index = image.index;
+    return PLR_OK;
+}
+
+int plr_create_image(const plr_image_desc* desc, const void* initial_data, size_t initial_data_size, plr_image_handle* out_image) {
+    NEED_INIT();
+    if (!desc || !out_image) return setErr(PLR_ERR_INVALID_ARGUMENT, "null argument");
+    ImageRes im;
+    int rc = allocImage(im, *desc);
+    if (rc) return rc;
+    if (initial_data && initial_data_size) {
+        // initial data covers mip 0 (or the whole tightly packed chain for FullChainAlreadyInData)
+        size_t consumed = 0;
+        for (size_t m = 0; m < im.mips.size() && consumed < initial_data_size; m++) {
+            const size_t nBytes = std::min(im.mips[m].bytes, initial_data_size - consumed);
+            HIP_TRY(hipMemcpyAsync((uint8_t*)im.dev + im.mips[m].offset, (const uint8_t*)initial_data + consumed, nBytes, hipMemcpyHostToDevice, g->stream));
+            consumed += nBytes;
+            if (desc->mip_count != PLR_MIP_FULL_CHAIN_ALREADY_IN_DATA) break;
+        }
+        HIP_TRY(hipStreamSynchronize(g->stream));
+    }
+    g->images.push_back(std::move(im));
+    g->bindlessDirty = true;
+    out_image->type = PLR_IMAGE_DEFAULT;
+    out_image->index = (uint32_t)(g->images.size() - 1);
+    return PLR_OK;
+}
+
+static int createBuffer(std::vector<BufferRes>& list, size_t size, const void* init, uint32_t* out) {
+    if (size == 0 || !out) return setErr(PLR_ERR_INVALID_ARGUMENT, "buffer size is 0 or out handle is null");
+    BufferRes b;
+    b.size = size;
+    HIP_TRY(hipMalloc(&b.dev, (size + 15) & ~(size_t)15));
+    HIP_TRY(hipMemsetAsync(b.dev, 0, (size + 15) & ~(size_t)15, g->stream));
+    if (init) HIP_TRY(hipMemcpyAsync(b.dev, init, size, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    g->allocated += size;
+    list.push_back(b);
+    *out = (uint32_t)(list.size() - 1);
+    return PLR_OK;
+}
+
+int plr_create_uniform_buffer(size_t size, const void* initial_data, plr_uniform_buffer_handle* out_buffer) {
+    NEED_INIT();
+    return createBuffer(g->ubufs, size, initial_data, out_buffer);
+}
+int plr_create_storage_buffer(size_t size, const void* initial_data, plr_storage_buffer_handle* out_buffer) {
+    NEED_INIT();
+    return createBuffer(g->sbufs, size, initial_data, out_buffer);
+}
+
+int plr_create_sampler(const plr_sampler_desc* desc, plr_sampler_handle* out_sampler) {
+    NEED_INIT();
+    if (!desc || !out_sampler) return setErr(PLR_ERR_INVALID_ARGUMENT, "null argument");
+    g->samplers.push_back(*desc);
+    *out_sampler = (uint32_t)(g->samplers.size() - 1);
+    return PLR_OK;
+}
+
+int plr_create_temporary_image(const plr_image_desc* desc, plr_image_handle* out_image) {
+    NEED_INIT();
+    if (!desc || !out_image) return setErr(PLR_ERR_INVALID_ARGUMENT, "null argument");
+    // pooled by description; the reference aliases by first/last use (RenderBackend.cpp:1026-1123), with 288 GB of
+    // HBM the pool simply keeps one allocation per concurrently live description
+    for (size_t i = 0; i < g->transient.size(); i++) {
+        if (!g->transient[i].inUse && g->transient[i].dev && sameDesc(g->transient[i].desc, *desc)) {
+            g->transient[i].inUse = true;
+            out_image->type = PLR_IMAGE_TRANSIENT; out_image->index = (uint32_t)i;
+            return PLR_OK;
+        }
+    }
+    ImageRes im;
+    int rc = allocImage(im, *desc);
+    if (rc) return rc;
+    im.inUse = true;
+    g->transient.push_back(std::move(im));
+    out_image->type = PLR_IMAGE_TRANSIENT; out_image->index = (uint32_t)(g->transient.size() - 1);
+    return PLR_OK;
+}
+
+int plr_get_swapchain_input_image(plr_image_handle* out_image) {
+    NEED_INIT();
+    out_image->type = PLR_IMAGE_SWAPCHAIN; out_image->index = 0;
+    return PLR_OK;
+}
+
+int plr_get_memory_stats(uint64_t* out_allocated_size, uint64_t* out_used_size) {
+    NEED_INIT();
+    if (out_allocated_size) *out_allocated_size = g->allocated;
+    if (out_used_size) *out_used_size = g->allocated;
+    return PLR_OK;
+}
+
+int plr_set_pass_timing(int enabled) { NEED_INIT(); g->passTiming = enabled != 0; return PLR_OK; }
+
+int plr_get_renderpass_timings(plr_renderpass_time* out_times, uint32_t* inout_count) {
+    NEED_INIT();
+    if (!inout_count) return setErr(PLR_ERR_INVALID_ARGUMENT, "inout_count is null");
+    const uint32_t n = (uint32_t)g->timedExecutions;
+    if (!out_times) { *inout_count = n; return PLR_OK; }
+    if (n) HIP_TRY(hipEventSynchronize(g->frameEnd));
+    const uint32_t m = std::min(n, *inout_count);
+    for (uint32_t i = 0; i < m; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g->passEvents[2 * i], g->passEvents[2 * i + 1]));
+        out_times[i].time_ms = ms;
+        out_times[i].name = g->lastTimings[i].name;
+    }
+    *inout_count = m;
+    return PLR_OK;
+}
+
+int plr_get_last_frame_cpu_time(float* out_ms) { NEED_INIT(); *out_ms = g->lastCpuMs; return PLR_OK; }
+
+int plr_get_last_frame_gpu_time(float* out_ms) {
+    NEED_INIT();
+    if (!g->frameRecorded) return setErr(PLR_ERR_INVALID_ARGUMENT, "no frame rendered yet");
+    HIP_TRY(hipEventSynchronize(g->frameEnd));
+    HIP_TRY(hipEventElapsedTime(out_ms, g->frameStart, g->frameEnd));
+    return PLR_OK;
+}
+
+int plr_get_image_description(plr_image_handle image, plr_image_desc* out_desc) {
+    NEED_INIT();
+    ImageRes* im = resolveImage(image);
+    if (!im) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid image handle");
+    *out_desc = im->desc;
+    return PLR_OK;
+}
+
+static int imageMip(plr_image_handle image, uint32_t mip, ImageRes** im, MipInfo** mi) {
+    *im = resolveImage(image);
+    if (!*im) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid image handle");
+    if (mip >= (*im)->mips.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "mip level out of range");
+    *mi = &(*im)->mips[mip];
+    return PLR_OK;
+}
+
+int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size) {
+    NEED_INIT();
+    ImageRes* im; MipInfo* mi;
+    int rc = imageMip(image, mip_level, &im, &mi);
+    if (rc) return rc;
+    if (size != mi->bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "upload size " + std::to_string(size) + " != mip size " + std::to_string(mi->bytes));
+    HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset, data, size, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+
+int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size) {
+    NEED_INIT();
+    ImageRes* im; MipInfo* mi;
+    int rc = imageMip(image, mip_level, &im, &mi);
+    if (rc) return rc;
+    if (size != mi->bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "download size " + std::to_string(size) + " != mip size " + std::to_string(mi->bytes));
+    HIP_TRY(hipMemcpyAsync(out_data, (uint8_t*)im->dev + mi->offset, size, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+
+static int downloadBuffer(std::vector<BufferRes>& list, uint32_t h, void* out, size_t offset, size_t size) {
+    if (h >= list.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid buffer handle");
+    if (offset + size > list[h].size) return setErr(PLR_ERR_INVALID_ARGUMENT, "buffer download range out of bounds");
+    HIP_TRY(hipMemcpyAsync(out, (uint8_t*)list[h].dev + offset, size, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size) {
+    NEED_INIT();
+    return downloadBuffer(g->sbufs, buffer, out_data, offset, size);
+}
+int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size) {
+    NEED_INIT();
+    return downloadBuffer(g->ubufs, buffer, out_data, offset, size);
+}
+
+int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, void** out_ptr, size_t* out_size) {
+    NEED_INIT();
+    ImageRes* im; MipInfo* mi;
+    int rc = imageMip(image, mip_level, &im, &mi);
+    if (rc) return rc;
+    *out_ptr = (uint8_t*)im->dev + mi->offset;
+    if (out_size) *out_size = mi->bytes;
+    return PLR_OK;
+}
+
+int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size) {
+    NEED_INIT();
+    if (buffer >= g->sbufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid buffer handle");
+    *out_ptr = g->sbufs[buffer].dev;
+    if (out_size) *out_size = g->sbufs[buffer].size;
+    return PLR_OK;
+}
+
+int plr_get_stream(void** out_hip_stream) { NEED_INIT(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
+
+int plr_get_supported_shaders(const char** out_names, uint32_t capacity) {
+    const auto& r = registry();
+    for (uint32_t i = 0; i < capacity && i < r.size(); i++) out_names[i] = r[i].name.c_str();
+    return (int)r.size();
+}
+
+} // extern "C"

@@ -1,0 +1,81 @@
+// Internal interface between the backend runtime (backend.cpp) and the pass kernels (kernels/*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "device/image.h"
+#include "device/types.h"
+
+namespace plr {
+
+constexpr int kMaxBindings = 32;
+
+struct SpecConstant {
+    uint32_t location;
+    std::vector<uint8_t> data;
+};
+
+struct BufferBinding {
+    void* ptr = nullptr;
+    size_t size = 0;
+    bool readOnly = false;
+};
+
+// Everything a pass launcher needs, with handles already resolved to HBM addresses.
+struct PassCtx {
+    hipStream_t stream = nullptr;
+    const GlobalUbo* global = nullptr;    // set 0 binding 0 (device memory)
+    const ImgView* bindless = nullptr;    // set 2 (device array of mip-0 views, indexed by global texture index)
+    uint32_t bindlessCount = 0;
+    ImgView sampled[kMaxBindings];
+    ImgView storage[kMaxBindings];
+    uint32_t sampledMask = 0, storageMask = 0, sbufMask = 0, ubufMask = 0;
+    BufferBinding sbuf[kMaxBindings];
+    BufferBinding ubuf[kMaxBindings];
+    std::vector<uint8_t> push;
+    uint32_t dispatch[3] = {1, 1, 1};
+    const std::vector<SpecConstant>* spec = nullptr;
+    std::string* err = nullptr;
+    void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)
+    size_t* scratchSize = nullptr;
+
+    bool hasSampled(int b) const { return (sampledMask >> b) & 1u; }
+    bool hasStorage(int b) const { return (storageMask >> b) & 1u; }
+    bool hasSbuf(int b) const { return (sbufMask >> b) & 1u; }
+    bool hasUbuf(int b) const { return (ubufMask >> b) & 1u; }
+
+    // spec constants are raw bytes with the C++ sizeof of the host type (bool = 1 byte)
+    const SpecConstant* findSpec(uint32_t location) const;
+    int32_t specInt(uint32_t location, int32_t def) const;
+    uint32_t specUint(uint32_t location, uint32_t def) const { return (uint32_t)specInt(location, (int32_t)def); }
+    float specFloat(uint32_t location, float def) const;
+    bool specBool(uint32_t location, bool def) const;
+
+    int fail(int code, const std::string& msg) const;
+    // checks presence + format of a binding; returns 0 or records an error
+    int needSampled(int binding, int fmt, const char* what) const;
+    int needStorage(int binding, int fmt, const char* what) const;
+    int needSbuf(int binding, size_t minSize, const char* what) const;
+    int needUbuf(int binding, size_t minSize, const char* what) const;
+    int needGlobal() const;
+    void* scratch(size_t bytes) const;
+};
+
+typedef int (*LaunchFn)(const PassCtx&);
+
+struct ShaderRegistrar {
+    ShaderRegistrar(const char* name, LaunchFn fn);
+};
+#define PLR_REGISTER_SHADER(name, fn) static ::plr::ShaderRegistrar plr_registrar_##fn(name, fn)
+
+inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+#define PLR_CHECK_LAUNCH(ctx)                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) return (ctx).fail(-2, std::string("kernel launch failed: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+} // namespace plr

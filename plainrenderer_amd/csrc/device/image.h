@@ -1,0 +1,193 @@
+// Linear HBM images for the HIP kernels: native packed pixel formats, tight row pitch, explicit
+// address math instead of texture units so a wave64 reads 64 consecutive texels per row segment.
+//
+// Fixed-function rules (Vulkan leaves parts of these implementation defined; DESIGN.md
+// "sampler & format contract"):
+//  * float -> half / 11-bit / 10-bit float is round-to-nearest-even; 11/10-bit: negatives -> 0,
+//    finite overflow -> max finite, NaN -> NaN, +Inf -> +Inf
+//  * UNORM8 encode round-half-even(clamp(x,0,1)*255), NaN -> 0; SNORM16 decode max(c/32767,-1)
+//  * linear filtering has 8 fractional weight bits: t = floor((u-0.5)*256+0.5), i0 = t>>8, a = (t&255)/256
+//  * texelFetch/imageLoad out of bounds = 0, imageStore out of bounds is dropped
+// Format numbering = ImageFormat in the reference (Plain/src/Common/ImageDescription.h:16).
+#pragma once
+#include "vecmath.h"
+
+namespace plr {
+
+enum Format : int32_t {
+    F_R8 = 0, F_RG8 = 1, F_RGBA8 = 2, F_R16F = 3, F_RG16F = 4, F_RG32F = 5, F_RG16SN = 6, F_RGBA16F = 7,
+    F_RGBA16SN = 8, F_RGBA32F = 9, F_R11G11B10 = 10, F_D16 = 11, F_D32 = 12, F_BC1 = 13, F_BC3 = 14, F_BC5 = 15,
+    F_BGRA8 = 16
+};
+
+struct ImgView {
+    void* ptr;
+    int32_t w, h, d;
+    int32_t fmt;
+};
+
+// ---- codecs ----
+PLR_DI float halfBitsToFloat(uint32_t h) {
+    union { uint16_t u; _Float16 f; } c;
+    c.u = (uint16_t)h;
+    return (float)c.f; // v_cvt_f32_f16, exact
+}
+PLR_DI uint32_t floatToHalfBits(float v) {
+    union { uint16_t u; _Float16 f; } c;
+    c.f = (_Float16)v; // v_cvt_f16_f32, round-to-nearest-even in the default mode
+    return c.u;
+}
+
+// an 11-bit (5e6m) / 10-bit (5e5m) unsigned float is a positive half with the low mantissa bits dropped
+PLR_DI vec3 unpackR11G11B10(uint32_t p) {
+    return vec3(halfBitsToFloat((p & 0x7ffu) << 4), halfBitsToFloat(((p >> 11) & 0x7ffu) << 4), halfBitsToFloat((p >> 22) << 5));
+}
+
+template <int M> PLR_DI uint32_t encodeUFloat(float v) {
+    constexpr uint32_t expMax = 31u << M;
+    constexpr uint32_t maxFinite = (30u << M) | ((1u << M) - 1u);
+    constexpr int shift = 23 - M;
+    const uint32_t u = f2u(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return expMax | (1u << (M - 1)); // NaN
+    if (u >> 31) return 0u;                                               // negative, -0, -inf
+    if (u == 0x7f800000u) return expMax;                                  // +inf
+    uint32_t r;
+    if (v < 6.103515625e-05f) {
+        // subnormal result: adding 2^(23-14-M) makes the fp32 adder round to the 2^-(14+M) grid (RTE)
+        constexpr float magic = (float)(1u << (9 - M));
+        r = f2u(v + magic) - f2u(magic);
+    } else {
+        const uint32_t t = u + ((1u << (shift - 1)) - 1u) + ((u >> shift) & 1u);
+        r = (t >> shift) - (112u << M);
+    }
+    return r < maxFinite ? r : maxFinite;
+}
+
+PLR_DI uint32_t packR11G11B10(vec3 c) {
+    return encodeUFloat<6>(c.x) | (encodeUFloat<6>(c.y) << 11) | (encodeUFloat<5>(c.z) << 22);
+}
+
+PLR_DI float decodeUnorm8(uint32_t c) { return (float)c / 255.0f; }
+PLR_DI uint32_t encodeUnorm8(float v) {
+    if (v != v) return 0u;
+    return (uint32_t)__float2int_rn(gclamp(v, 0.f, 1.f) * 255.0f);
+}
+PLR_DI float decodeSnorm16(int32_t c) { return gmax((float)c / 32767.0f, -1.0f); }
+PLR_DI float decodeUnorm16(uint32_t c) { return (float)c / 65535.0f; }
+
+// ---- typed texel access (idx = linear texel index) ----
+template <int FMT> struct Texel;
+template <> struct Texel<F_R11G11B10> {
+    static PLR_DI vec4 load(const void* p, size_t i) { return vec4(unpackR11G11B10(((const uint32_t*)p)[i]), 1.f); }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((uint32_t*)p)[i] = packR11G11B10(v.xyz()); }
+};
+template <> struct Texel<F_D32> {
+    static PLR_DI vec4 load(const void* p, size_t i) { return vec4(((const float*)p)[i], 0.f, 0.f, 1.f); }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((float*)p)[i] = v.x; }
+};
+template <> struct Texel<F_D16> {
+    static PLR_DI vec4 load(const void* p, size_t i) { return vec4(decodeUnorm16(((const uint16_t*)p)[i]), 0.f, 0.f, 1.f); }
+};
+template <> struct Texel<F_R16F> {
+    static PLR_DI vec4 load(const void* p, size_t i) { return vec4(halfBitsToFloat(((const uint16_t*)p)[i]), 0.f, 0.f, 1.f); }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((uint16_t*)p)[i] = (uint16_t)floatToHalfBits(v.x); }
+};
+template <> struct Texel<F_RG16F> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint32_t u = ((const uint32_t*)p)[i];
+        return vec4(halfBitsToFloat(u & 0xffffu), halfBitsToFloat(u >> 16), 0.f, 1.f);
+    }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((uint32_t*)p)[i] = floatToHalfBits(v.x) | (floatToHalfBits(v.y) << 16); }
+};
+template <> struct Texel<F_RGBA16F> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint2 u = ((const uint2*)p)[i];
+        return vec4(halfBitsToFloat(u.x & 0xffffu), halfBitsToFloat(u.x >> 16), halfBitsToFloat(u.y & 0xffffu), halfBitsToFloat(u.y >> 16));
+    }
+    static PLR_DI void store(void* p, size_t i, vec4 v) {
+        uint2 u;
+        u.x = floatToHalfBits(v.x) | (floatToHalfBits(v.y) << 16);
+        u.y = floatToHalfBits(v.z) | (floatToHalfBits(v.w) << 16);
+        ((uint2*)p)[i] = u;
+    }
+};
+template <> struct Texel<F_RG32F> {
+    static PLR_DI vec4 load(const void* p, size_t i) { const float2 u = ((const float2*)p)[i]; return vec4(u.x, u.y, 0.f, 1.f); }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((float2*)p)[i] = make_float2(v.x, v.y); }
+};
+template <> struct Texel<F_RG16SN> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint32_t u = ((const uint32_t*)p)[i];
+        return vec4(decodeSnorm16((int32_t)(int16_t)(u & 0xffffu)), decodeSnorm16((int32_t)(int16_t)(u >> 16)), 0.f, 1.f);
+    }
+};
+template <> struct Texel<F_RGBA8> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint32_t u = ((const uint32_t*)p)[i];
+        return vec4(decodeUnorm8(u & 0xffu), decodeUnorm8((u >> 8) & 0xffu), decodeUnorm8((u >> 16) & 0xffu), decodeUnorm8(u >> 24));
+    }
+    static PLR_DI void store(void* p, size_t i, vec4 v) {
+        ((uint32_t*)p)[i] = encodeUnorm8(v.x) | (encodeUnorm8(v.y) << 8) | (encodeUnorm8(v.z) << 16) | (encodeUnorm8(v.w) << 24);
+    }
+};
+template <> struct Texel<F_BGRA8> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint32_t u = ((const uint32_t*)p)[i];
+        return vec4(decodeUnorm8((u >> 16) & 0xffu), decodeUnorm8((u >> 8) & 0xffu), decodeUnorm8(u & 0xffu), decodeUnorm8(u >> 24));
+    }
+    static PLR_DI void store(void* p, size_t i, vec4 v) {
+        ((uint32_t*)p)[i] = encodeUnorm8(v.z) | (encodeUnorm8(v.y) << 8) | (encodeUnorm8(v.x) << 16) | (encodeUnorm8(v.w) << 24);
+    }
+};
+template <> struct Texel<F_RG8> {
+    static PLR_DI vec4 load(const void* p, size_t i) {
+        const uint32_t u = ((const uint16_t*)p)[i];
+        return vec4(decodeUnorm8(u & 0xffu), decodeUnorm8(u >> 8), 0.f, 1.f);
+    }
+};
+template <> struct Texel<F_R8> {
+    static PLR_DI vec4 load(const void* p, size_t i) { return vec4(decodeUnorm8(((const uint8_t*)p)[i]), 0.f, 0.f, 1.f); }
+};
+
+// ---- samplers (resources/shaders/global.inc:35-42) ----
+enum Address { CLAMP = 0, REPEAT = 1, BORDER_WHITE = 2, BORDER_BLACK = 3 };
+
+PLR_DI int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+PLR_DI int repeati(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+PLR_DI float saneCoord(float u) { return gclamp(u, -1.0e6f, 1.0e6f); }
+PLR_DI void linearCoord(float u, int* i0, float* alpha) {
+    const int ti = (int)floorf((saneCoord(u) - 0.5f) * 256.0f + 0.5f);
+    *i0 = ti >> 8;
+    *alpha = (float)(ti & 255) * (1.0f / 256.0f);
+}
+
+template <int FMT, int ADDR> PLR_DI vec4 addressedTexel2D(const ImgView& im, int x, int y) {
+    if (ADDR == CLAMP) { x = clampi(x, im.w); y = clampi(y, im.h); }
+    else if (ADDR == REPEAT) { x = repeati(x, im.w); y = repeati(y, im.h); }
+    else if (x < 0 || y < 0 || x >= im.w || y >= im.h) return ADDR == BORDER_WHITE ? vec4(1.f, 1.f, 1.f, 1.f) : vec4(0.f, 0.f, 0.f, 1.f);
+    return Texel<FMT>::load(im.ptr, (size_t)y * (size_t)im.w + (size_t)x);
+}
+
+template <int FMT, int ADDR> PLR_DI vec4 sampleNearest2D(const ImgView& im, vec2 uv) {
+    const float u = uv.x * (float)im.w, v = uv.y * (float)im.h;
+    return addressedTexel2D<FMT, ADDR>(im, (int)floorf(saneCoord(u)), (int)floorf(saneCoord(v)));
+}
+
+template <int FMT, int ADDR> PLR_DI vec4 sampleLinear2D(const ImgView& im, vec2 uv) {
+    int i0, j0; float a, b;
+    linearCoord(uv.x * (float)im.w, &i0, &a);
+    linearCoord(uv.y * (float)im.h, &j0, &b);
+    const vec4 t00 = addressedTexel2D<FMT, ADDR>(im, i0, j0);
+    const vec4 t10 = addressedTexel2D<FMT, ADDR>(im, i0 + 1, j0);
+    const vec4 t01 = addressedTexel2D<FMT, ADDR>(im, i0, j0 + 1);
+    const vec4 t11 = addressedTexel2D<FMT, ADDR>(im, i0 + 1, j0 + 1);
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    return t00 * w00 + t10 * w10 + t01 * w01 + t11 * w11;
+}
+
+template <int FMT> PLR_DI vec4 texelFetch2D(const ImgView& im, int x, int y) {
+    if (x < 0 || y < 0 || x >= im.w || y >= im.h) return vec4(0.f);
+    return Texel<FMT>::load(im.ptr, (size_t)y * (size_t)im.w + (size_t)x);
+}
+
+} // namespace plr

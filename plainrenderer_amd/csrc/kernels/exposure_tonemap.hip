@@ -1,0 +1,338 @@
+// Auto-exposure + tonemap passes for gfx950.
+//   histogramPerTile.comp / histogramReset.comp / histogramCombineTiles.comp / preExposeLights.comp / tonemapping.comp
+// (resources/shaders/, host side RenderFrontend.cpp:707-790,931-945).
+//
+// All five are HBM-streaming or tiny: no MFMA. Pixels are read 16 bytes per lane (4 packed R11G11B10 texels),
+// histograms are built in LDS with wave-level vote aggregation, and the serial exposure shader is spread over
+// one wave with the float accumulation kept in bin order so results stay bit-identical to a scalar evaluation.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+// det_logf of device/detmath.h evaluated on the host for the two specialisation constants: the same IEEE operations
+// in the same order (this file is built with -ffp-contract=off), hence the same bits as on the device.
+static float hostDetLog(float x) {
+    union { float f; uint32_t u; } cv; cv.f = x;
+    uint32_t ix = cv.u; int e = 0;
+    if (ix < 0x00800000u) { x = x * 8388608.0f; cv.f = x; ix = cv.u; e = -23; }
+    e += (int)(ix >> 23) - 127;
+    cv.u = (ix & 0x007fffffu) | 0x3f800000u;
+    float m = cv.f;
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = 0.222222224f;
+    p = p * z + 0.285714298f; p = p * z + 0.400000006f; p = p * z + 0.666666687f;
+    const float r = f - s * (f - z * p);
+    const float fe = (float)e;
+    return fe * PLR_LN2_HI + (fe * PLR_LN2_LO + r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// histogramPerTile.comp:32-65. One 256-thread block per 32x32 tile; thread t owns 4 consecutive pixels of
+// row t/8. The bin index must be bit exact, so the log is the deterministic one.
+// Unlike the reference, out-of-image invocations still reach the barriers; the observable rule is kept:
+// bin b of a tile is written back only if the reference invocation with localIndexFlat == b lies inside the image.
+__global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const LightBuffer* __restrict__ light, uint32_t* __restrict__ perTile,
+                                                              uint32_t nBins, float minLuminanceLog, float maxLuminanceLog, uint32_t tilesX) {
+    extern __shared__ uint32_t localHistogram[];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t b = t; b < nBins; b += 256u) localHistogram[b] = 0u;
+    __syncthreads();
+
+    const int x0 = (int)blockIdx.x * 32 + (int)(t & 7u) * 4;
+    const int y = (int)blockIdx.y * 32 + (int)(t >> 3);
+    const float prevExposure = light->previousFrameExposure;
+    const uint32_t maxIndex = nBins - 1u;
+    const float range = maxLuminanceLog - minLuminanceLog;
+
+    uint32_t texels[4] = {0u, 0u, 0u, 0u};
+    int nValid = 0;
+    if (y < src.h && x0 < src.w) {
+        const uint32_t* row = (const uint32_t*)src.ptr + (size_t)y * (size_t)src.w;
+        nValid = min(4, src.w - x0);
+        if (nValid == 4 && ((src.w & 3) == 0)) {
+            const uint4 v = *(const uint4*)(row + x0);
+            texels[0] = v.x; texels[1] = v.y; texels[2] = v.z; texels[3] = v.w;
+        } else {
+            for (int i = 0; i < nValid; i++) texels[i] = row[x0 + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool valid = i < nValid;
+        uint32_t bin = 0u;
+        if (valid) {
+            const vec3 c = unpackR11G11B10(texels[i]);
+            const float luminance = dot(c, vec3(0.2126f, 0.7152f, 0.0722f)) / prevExposure; // :28-30, :53
+            const float luminanceLog = det_logf(luminance);
+            bin = (uint32_t)((float)maxIndex * gclamp((luminanceLog - minLuminanceLog) / range, 0.f, 1.f));
+        }
+        // wave vote aggregation: neighbouring pixels mostly share a bin, so peel the leading bins with one LDS
+        // atomic each, then let the stragglers add individually
+        bool pending = valid;
+        for (int round = 0; round < 3; round++) {
+            const unsigned long long todo = __ballot(pending);
+            if (todo == 0ull) break;
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t leaderBin = (uint32_t)__shfl((int)bin, leader);
+            const unsigned long long same = __ballot(pending && bin == leaderBin);
+            if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&localHistogram[leaderBin], (uint32_t)__popcll(same));
+            if (bin == leaderBin) pending = false;
+        }
+        if (pending) atomicAdd(&localHistogram[bin], 1u);
+    }
+    __syncthreads();
+
+    const uint32_t tileIndex = blockIdx.x + blockIdx.y * tilesX;
+    for (uint32_t b = t; b < nBins && b < 1024u; b += 256u) {
+        const int rx = (int)blockIdx.x * 32 + (int)(b & 31u), ry = (int)blockIdx.y * 32 + (int)(b >> 5);
+        if (rx < src.w && ry < src.h) perTile[(size_t)tileIndex * nBins + b] = localHistogram[b];
+    }
+}
+
+static int launchHistogramPerTile(const PassCtx& c) {
+    if (int rc = c.needSampled(2, F_R11G11B10, "histogramPerTile srcTexture")) return rc;
+    if (int rc = c.needSbuf(3, sizeof(LightBuffer), "histogramPerTile lightBuffer")) return rc;
+    const uint32_t nBins = c.specUint(0, 64u);
+    const float minL = c.specFloat(1, 1.f), maxL = c.specFloat(2, 100.f);
+    const ImgView& src = c.sampled[2];
+    const uint32_t tilesX = divUp((unsigned)src.w, 32u), tilesY = divUp((unsigned)src.h, 32u);
+    // the reference sizes this buffer for 1920x1080 only (RenderFrontend.cpp:1069-1070); demand the real tile count
+    if (int rc = c.needSbuf(0, (size_t)tilesX * tilesY * nBins * 4u, "histogramPerTile per-tile buffer")) return rc;
+    if (nBins == 0 || nBins > 1024u) return c.fail(-6, "histogramPerTile: nBins must be in 1..1024");
+    // host-side log of the two specialisation constants with the same deterministic routine (exact same bits as device)
+    const dim3 grid(std::min(c.dispatch[0], tilesX), std::min(c.dispatch[1], tilesY));
+    if (!(minL > 0.f) || !(maxL > 0.f)) return c.fail(-1, "histogramPerTile: luminance range must be positive");
+    const float logs[2] = {hostDetLog(minL), hostDetLog(maxL)};
+    histogramPerTileKernel<<<grid, 256, nBins * sizeof(uint32_t), c.stream>>>(src, (const LightBuffer*)c.sbuf[3].ptr, (uint32_t*)c.sbuf[0].ptr,
+                                                                               nBins, logs[0], logs[1], tilesX);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("histogramPerTile.comp", launchHistogramPerTile);
+
+// ------------------------------------------------------------------------------------------------
+// histogramReset.comp:11-16
+__global__ void histogramResetKernel(uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nThreads) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nThreads && i < nBins) histogram[i] = 0u;
+}
+static int launchHistogramReset(const PassCtx& c) {
+    const uint32_t nBins = c.specUint(0, 64u);
+    if (int rc = c.needSbuf(1, (size_t)nBins * 4u, "histogramReset histogram")) return rc;
+    const uint32_t nThreads = c.dispatch[0] * 64u;
+    histogramResetKernel<<<divUp(nThreads, 64u), 64, 0, c.stream>>>((uint32_t*)c.sbuf[1].ptr, nBins, nThreads);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("histogramReset.comp", launchHistogramReset);
+
+// ------------------------------------------------------------------------------------------------
+// histogramCombineTiles.comp:27-34. The reference launches (tiles x 2) groups that each issue 64 global atomics;
+// here one block sums a slab of tiles in registers (coalesced 4*nBins-byte rows) and issues one atomic per bin.
+constexpr uint32_t kCombineTilesPerBlock = 32;
+__global__ void histogramCombineKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles, uint32_t binLimit) {
+    const uint32_t bin = threadIdx.x + blockIdx.y * blockDim.x;
+    if (bin >= nBins || bin >= binLimit) return;
+    const uint32_t t0 = blockIdx.x * kCombineTilesPerBlock;
+    const uint32_t t1 = min(t0 + kCombineTilesPerBlock, nTiles);
+    uint32_t sum = 0u;
+    for (uint32_t t = t0; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
+    if (sum) atomicAdd(&histogram[bin], sum);
+}
+static int launchHistogramCombine(const PassCtx& c) {
+    const uint32_t nBins = c.specUint(0, 64u);
+    const uint32_t nTiles = c.dispatch[0];
+    if (int rc = c.needSbuf(0, (size_t)nTiles * nBins * 4u, "histogramCombineTiles per-tile buffer")) return rc;
+    if (int rc = c.needSbuf(1, (size_t)nBins * 4u, "histogramCombineTiles histogram")) return rc;
+    const uint32_t binLimit = c.dispatch[1] * 64u; // bins covered by the recorded dispatch
+    const dim3 grid(divUp(nTiles, kCombineTilesPerBlock), divUp(std::min(nBins, binLimit), 128u));
+    if (nTiles == 0) return 0;
+    histogramCombineKernel<<<grid, 128, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (uint32_t*)c.sbuf[1].ptr, nBins, nTiles, binLimit);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("histogramCombineTiles.comp", launchHistogramCombine);
+
+// ------------------------------------------------------------------------------------------------
+// preExposeLights.comp:28-88. The reference runs one invocation over a 128-step loop; here one wave computes the
+// cumulative histogram with a shuffle scan and the exp() terms in parallel, and lane 0 replays only the float
+// accumulation in bin order (float addition is not associative, the order is part of the result).
+PLR_DI float offsetFromSceneEV(float sceneEV100) {
+    const float darkExp = 2.84f, lightExp = 12.81f, lightOffset = 1.47f, darkOffset = -3.17f;
+    const float t = gclamp((sceneEV100 - darkExp) / (lightExp - darkOffset), 0.f, 1.f); // sic: lightExp - darkOffset (:35)
+    return gmix(darkOffset, lightOffset, t);
+}
+
+constexpr int kMaxExposureBins = 1024;
+__global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restrict__ light, const uint32_t* __restrict__ histogram, ImgView transmissionLut,
+                                                            const GlobalUbo* __restrict__ g, int nBins, float minLuminanceLog, float maxLuminanceLog) {
+    __shared__ float term[kMaxExposureBins];
+    __shared__ uint32_t counted[kMaxExposureBins];
+    const int lane = threadIdx.x;
+    const uint32_t pixelCount = (uint32_t)(g->screenResolution[0] * g->screenResolution[1]);
+    uint32_t carry = 0u;
+    for (int base = 0; base < nBins; base += 64) {
+        const int i = base + lane;
+        const uint32_t h = i < nBins ? histogram[i] : 0u;
+        uint32_t incl = h;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up;
+        }
+        incl += carry;
+        carry = (uint32_t)__shfl((int)incl, 63);
+        if (i < nBins) {
+            const float percentage = (float)incl / (float)pixelCount;
+            const bool take = percentage < 0.95f && percentage >= 0.5f;
+            float tv = 0.f;
+            if (take) {
+                const float binValueLog = minLuminanceLog + (maxLuminanceLog - minLuminanceLog) * (float)i / ((float)nBins - 1.f);
+                tv = (float)h * det_expf(binValueLog);
+            }
+            term[i] = tv;
+            counted[i] = take ? h : 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    float mean = 0.f;
+    uint32_t countedPixels = 0u;
+    for (int i = 0; i < nBins; i++) {
+        if (counted[i] != 0xffffffffu) { mean += term[i]; countedPixels += counted[i]; }
+    }
+    mean /= (float)countedPixels;
+    const float sceneEV100 = det_log2f(mean * 100.f / 12.5f);
+    float exposureOffset = offsetFromSceneEV(sceneEV100);
+    exposureOffset += g->exposureOffset;
+    float targetEV100 = sceneEV100 - exposureOffset;
+    targetEV100 = gmax(targetEV100, 10.f);
+    const float previousEV100 = det_log2f(1.f / (gmax(light->previousFrameExposure, 0.000001f) * 1.2f));
+    const float evDelta = targetEV100 - previousEV100;
+    const float evMaxChange = g->exposureAdaptionSpeedEvPerSec * g->deltaTime;
+    const float evChange = gsign(evDelta) * gmin(fabsf(evDelta), fabsf(evMaxChange));
+    const float currentEV100 = previousEV100 + evChange;
+    const float exposure = 1.f / (det_powf(2.f, currentEV100) * 1.2f);
+    light->sunStrengthExposed = g->sunStrength * exposure;
+    light->previousFrameExposure = exposure;
+    const vec2 lutUV(0.f, -g->sunDirection[1] * 0.5f + 0.5f);
+    const vec4 sc = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, lutUV);
+    light->sunColor[0] = sc.x; light->sunColor[1] = sc.y; light->sunColor[2] = sc.z;
+}
+
+static int launchPreExposeLights(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSbuf(0, sizeof(LightBuffer), "preExposeLights lightBuffer")) return rc;
+    const int nBins = c.specInt(0, 64);
+    if (nBins < 1 || nBins > kMaxExposureBins) return c.fail(-6, "preExposeLights: nBins must be in 1..1024");
+    if (int rc = c.needSbuf(1, (size_t)nBins * 4u, "preExposeLights histogram")) return rc;
+    if (int rc = c.needSampled(2, F_R11G11B10, "preExposeLights transmissionLut")) return rc;
+    const float minL = c.specFloat(1, 1.f), maxL = c.specFloat(2, 100.f);
+    if (!(minL > 0.f) || !(maxL > 0.f)) return c.fail(-1, "preExposeLights: luminance range must be positive");
+    preExposeLightsKernel<<<1, 64, 0, c.stream>>>((LightBuffer*)c.sbuf[0].ptr, (const uint32_t*)c.sbuf[1].ptr, c.sampled[2], c.global, nBins,
+                                                   hostDetLog(minL), hostDetLog(maxL));
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("preExposeLights.comp", launchPreExposeLights);
+
+// ------------------------------------------------------------------------------------------------
+// tonemapping.comp:17-27 + tonemapping.inc:17-49 + colorConversion.inc:5-13 + dither.inc:6-12 + noise.inc:14-24.
+// Streaming: 4 B in, 4 B out per pixel, 4 pixels (16 B) per lane. The output is 8-bit and the stated tolerance is
+// +-1 LSB, so pow() uses the hardware v_log_f32 / v_exp_f32 pair (the det* routines would make this pass ALU bound).
+PLR_DI float fastPow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+
+PLR_DI vec3 ACESFitted(vec3 color) {
+    // the literal triples of ACESInputMat/ACESOutputMat act as rows after the transpose (tonemapping.inc:42,46)
+    vec3 v(0.59719f * color.x + 0.35458f * color.y + 0.04823f * color.z, 0.07600f * color.x + 0.90834f * color.y + 0.01566f * color.z,
+           0.02840f * color.x + 0.13383f * color.y + 0.83777f * color.z);
+    const vec3 a = v * (v + 0.0245786f) - 0.000090537f;
+    const vec3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    v = a / b;
+    vec3 o(1.60475f * v.x + -0.53108f * v.y + -0.07367f * v.z, -0.10208f * v.x + 1.10813f * v.y + -0.00605f * v.z,
+           -0.00327f * v.x + -0.07276f * v.y + 1.07602f * v.z);
+    return vclamp(o, 0.f, 1.f);
+}
+
+PLR_DI float linearTosRGB1(float l) {
+    const float lo = l * 12.92f;
+    const float hi = fastPow(fabsf(l), 1.0f / 2.4f) * 1.055f - 0.055f;
+    return l <= 0.0031308f ? lo : hi;
+}
+
+PLR_DI vec3 hash32(float qx, float qy) {
+    const uint32_t UI0 = 1597334673u, UI1 = 3812015801u, UI2 = 2798796415u;
+    uint32_t nx = (uint32_t)(int32_t)qx * UI0, ny = (uint32_t)(int32_t)qy * UI1, nz = (uint32_t)(int32_t)qx * UI2;
+    const uint32_t m = nx ^ ny ^ nz;
+    nx = m * UI0; ny = m * UI1; nz = m * UI2;
+    const float UIF = 1.0f / (float)0xffffffffu;
+    return vec3((float)nx, (float)ny, (float)nz) * UIF;
+}
+
+PLR_DI uint32_t tonemapPixel(uint32_t texel, int x, int y, float time) {
+    const vec3 linearColor = unpackR11G11B10(texel);
+    const vec3 t = ACESFitted(linearColor);
+    vec3 s(linearTosRGB1(t.x), linearTosRGB1(t.y), linearTosRGB1(t.z));
+    // ditherRGB8: hash32(uvec2(uv * g_time)) + hash32(uvec2((uv + vec2(165, 1292)) * g_time)) - 1, in 1/255 units
+    vec3 noise = hash32((float)(uint32_t)((float)x * time), (float)(uint32_t)((float)y * time));
+    noise += hash32((float)(uint32_t)(((float)x + 165.f) * time), (float)(uint32_t)(((float)y + 1292.f) * time));
+    noise = noise - 1.f;
+    noise = noise / 255.f;
+    s = s + noise;
+    // imageStore to the BGRA8 swapchain image: memory order B, G, R, A
+    return encodeUnorm8(s.z) | (encodeUnorm8(s.y) << 8) | (encodeUnorm8(s.x) << 16) | (255u << 24);
+}
+
+template <bool BGRA>
+__global__ __launch_bounds__(256) void tonemappingKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH) {
+    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (y >= coverH || x0 >= coverW) return;
+    const float time = g->time;
+    const uint32_t* srow = (const uint32_t*)src.ptr + (size_t)y * (size_t)src.w;
+    uint32_t* drow = (uint32_t*)dst.ptr + (size_t)y * (size_t)dst.w;
+    const int n = min(4, coverW - x0);
+    uint32_t in[4], out[4];
+    const bool vec = (n == 4) && ((src.w & 3) == 0) && ((dst.w & 3) == 0);
+    if (vec) {
+        const uint4 v = *(const uint4*)(srow + x0);
+        in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w;
+    } else {
+        for (int i = 0; i < n; i++) in[i] = srow[x0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < n) {
+            uint32_t p = tonemapPixel(in[i], x0 + i, y, time);
+            if (!BGRA) p = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+            out[i] = p;
+        }
+    }
+    if (vec) *(uint4*)(drow + x0) = make_uint4(out[0], out[1], out[2], out[3]);
+    else for (int i = 0; i < n; i++) drow[x0 + i] = out[i];
+}
+
+static int launchTonemapping(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "tonemapping imageIn")) return rc;
+    if (int rc = c.needStorage(0, -1, "tonemapping imageOut")) return rc;
+    const ImgView& src = c.sampled[1];
+    const ImgView& dst = c.storage[0];
+    if (dst.fmt != F_BGRA8 && dst.fmt != F_RGBA8) return c.fail(-4, "tonemapping imageOut must be BGRA8_uNorm or RGBA8");
+    // invocations exist for dispatch*8 pixels; stores outside the target are dropped, fetches outside the source are
+    // undefined in the reference, so the covered region is clipped to both images
+    const int coverW = std::min({(int)(c.dispatch[0] * 8u), dst.w, src.w});
+    const int coverH = std::min({(int)(c.dispatch[1] * 8u), dst.h, src.h});
+    if (coverW <= 0 || coverH <= 0) return 0;
+    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)coverH, 4u));
+    if (dst.fmt == F_BGRA8) tonemappingKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH);
+    else tonemappingKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("tonemapping.comp", launchTonemapping);
+
+} // namespace plr

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "oracle") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def backend():
+    """One RenderBackend per session (plr_setup is a process-wide singleton like gRenderBackend)."""
+    from plainrenderer_amd import RenderBackend
+    be = RenderBackend(1920, 1080, device=0)
+    yield be
+    be.shutdown()

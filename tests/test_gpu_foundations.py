@@ -1,0 +1,50 @@
+"""GPU: the device detmath / codec routines are bit-identical to the oracle's (the math contract both sides implement)."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.gpu
+def test_gpu_detmath_bit_identical(backend, oracle):
+    r = np.random.default_rng(21)
+    n = 400000
+    cases = {
+        0: (np.exp(r.uniform(-100, 88, n)), None), 1: (np.exp(r.uniform(-100, 88, n)), None),
+        2: (r.uniform(-110, 90, n), None), 3: (r.uniform(-155, 130, n), None),
+        4: (np.exp(r.uniform(-20, 5, n)), r.uniform(-6, 6, n)),
+        5: (r.uniform(-100, 100, n), None), 6: (r.uniform(-100, 100, n), None),
+        7: (r.uniform(-1.01, 1.01, n), None), 8: (r.uniform(-5, 5, n), r.uniform(-5, 5, n)),
+        9: (np.exp(r.uniform(-100, 88, n)), None), 10: (r.uniform(-5, 5, n), np.exp(r.uniform(-40, 40, n))),
+        11: (r.uniform(-5, 5, n), r.uniform(-5, 5, n)),
+    }
+    for fn, (a, b) in cases.items():
+        a = a.astype(np.float32)
+        b = None if b is None else b.astype(np.float32)
+        if fn in (0, 1):
+            a[:6] = [0.0, -1.0, np.inf, 1e-42, 1.0, np.nan]
+        g = backend.debugMathEval(fn, a, b)
+        o = oracle.math_eval(fn, a, b)
+        same = (g.view(np.uint32) == o.view(np.uint32)) | (np.isnan(g) & np.isnan(o))
+        assert same.all(), "fn %d: %d mismatches, first %s" % (fn, (~same).sum(), (a[~same][:3], g[~same][:3], o[~same][:3]))
+
+
+@pytest.mark.gpu
+def test_gpu_codecs_bit_identical(backend, oracle):
+    r = np.random.default_rng(22)
+    n = 300000
+    v = (np.exp(r.uniform(-30, 14, (n, 3))) * r.choice([-1.0, 1.0], (n, 3), p=[0.05, 0.95])).astype(np.float32)
+    v[0] = [np.inf, -np.inf, 0.0]
+    v[1] = [65024.0, 65280.0, 64512.0]
+    v[2] = [6.1e-5, 6.0e-5, 3e-8]
+    assert np.array_equal(backend.debugCodecEval(0, v, n, np.uint32, n), oracle.codec_eval(0, v, n, np.uint32, n))
+    packed = r.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    a = backend.debugCodecEval(1, packed, n, np.float32, 3 * n)
+    b = oracle.codec_eval(1, packed, n, np.float32, 3 * n)
+    assert np.array_equal(a.view(np.uint32)[~np.isnan(b)], b.view(np.uint32)[~np.isnan(b)])
+    f = v.reshape(-1)
+    assert np.array_equal(backend.debugCodecEval(2, f, f.size, np.uint16, f.size), oracle.codec_eval(2, f, f.size, np.uint16, f.size))
+    allh = np.arange(65536, dtype=np.uint16)
+    a = backend.debugCodecEval(3, allh, allh.size, np.float32, allh.size)
+    b = oracle.codec_eval(3, allh, allh.size, np.float32, allh.size)
+    assert np.array_equal(a[~np.isnan(b)], b[~np.isnan(b)])
+    u = r.uniform(-0.2, 1.2, n).astype(np.float32)
+    assert np.array_equal(backend.debugCodecEval(4, u, n, np.uint8, n), oracle.codec_eval(4, u, n, np.uint8, n))
