@@ -1,0 +1,183 @@
+// Min/max depth pyramid (HiZ) for gfx950: depthHiZPyramid.comp (resources/shaders/, host RenderFrontend.cpp:804-838,1770-1827).
+//
+// The reference is an SPD-style single dispatch: every 16x16 group reduces a 32x32 footprint of pyramid mip 0 through six
+// levels, then the last group (atomic counter) finishes the chain. When an intermediate level has an odd size its 3-wide
+// footprints reach into texels owned by a neighbouring group, which the reference reads with only a workgroup barrier.
+// Here the pyramid is defined level by level on completed data (min/max are exact and associative, so any evaluation order
+// gives the same bits) and computed in two launches:
+//   hizBaseKernel: one block per 32x32 tile of mip 0 produces up to six levels. Besides the texels it owns, a block computes
+//                  the few halo texels the odd-size footprints of its own next level need, in LDS, instead of racing for
+//                  its neighbour's stores. Depth is read exactly once (plus the halo), every level is written exactly once.
+//   hizTailKernel: one block finishes the (<= 64x64 texel) remainder of the chain out of LDS.
+// HBM traffic = 4 B/px depth + 8 B per pyramid texel: the algorithmic 6.67 B/px.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+constexpr int kHizMaxLevels = 11; // shader limit (depthHiZPyramid.comp:16-20)
+constexpr int kHizBaseLevels = 6;
+
+struct HizParams {
+    float2* level[kHizMaxLevels];
+    int w[kHizMaxLevels], h[kHizMaxLevels];
+    const float* depth;
+    int depthW, depthH;
+    int count;     // pyramid levels
+    int baseCount; // levels produced by hizBaseKernel
+};
+
+struct MinMax { float mn, mx; };
+
+// depthHiZPyramid.comp:52-124 for one destination texel; fetch(x, y) returns the clamped source texel as (min, max)
+// (for the depth buffer both components are the depth value).
+template <bool FROM_DEPTH, class Fetch>
+PLR_DI MinMax footprint(int ulx, int uly, int srcW, int srcH, bool extraRow, bool extraColumn, Fetch fetch) {
+    float depthMin = 1.f, depthMax = 0.f;
+    auto acc = [&](int x, int y, bool corner) {
+        const float2 t = fetch(min(x, srcW - 1), min(y, srcH - 1));
+        if (FROM_DEPTH) {
+            if (corner) depthMin = gmin(depthMin, t.x * (t.x == 0.f ? 1.f : 0.f)); // sic, :114
+            else depthMin = gmin(depthMin, t.x + (t.x == 0.f ? 1.f : 0.f));
+            depthMax = gmax(depthMax, t.x);
+        } else {
+            depthMin = gmin(depthMin, t.x + (t.y == 0.f ? 1.f : 0.f));
+            depthMax = gmax(depthMax, t.y);
+        }
+    };
+    acc(ulx, uly, false); acc(ulx + 1, uly, false); acc(ulx, uly + 1, false); acc(ulx + 1, uly + 1, false);
+    if (extraRow) { acc(ulx, uly + 2, false); acc(ulx + 1, uly + 2, false); }
+    if (extraColumn) { acc(ulx + 2, uly, false); acc(ulx + 2, uly + 1, false); }
+    if (extraRow && extraColumn) acc(ulx + 2, uly + 2, true);
+    return {depthMin, depthMax};
+}
+
+__global__ __launch_bounds__(256) void hizBaseKernel(HizParams p) {
+    __shared__ float2 bufA[64 * 64];
+    __shared__ float2 bufB[32 * 32];
+    const int K = p.baseCount;
+    // per level: owned range [lo, hi] and computed range [lo, need] (need >= hi: halo for the odd-size footprints above)
+    int lox[kHizBaseLevels], loy[kHizBaseLevels], hix[kHizBaseLevels], hiy[kHizBaseLevels], needx[kHizBaseLevels], needy[kHizBaseLevels];
+    for (int l = 0; l < K; l++) {
+        const int t = 32 >> l;
+        lox[l] = (int)blockIdx.x * t; loy[l] = (int)blockIdx.y * t;
+        hix[l] = min(lox[l] + t, p.w[l]) - 1; hiy[l] = min(loy[l] + t, p.h[l]) - 1;
+    }
+    needx[K - 1] = hix[K - 1]; needy[K - 1] = hiy[K - 1];
+    for (int l = K - 1; l >= 1; l--) {
+        const int sw = p.w[l - 1], sh = p.h[l - 1];
+        needx[l - 1] = hix[l - 1]; needy[l - 1] = hiy[l - 1];
+        if (needx[l] >= lox[l] && needy[l] >= loy[l]) {
+            needx[l - 1] = max(needx[l - 1], min(2 * needx[l] + 1 + (sw & 1), sw - 1));
+            needy[l - 1] = max(needy[l - 1], min(2 * needy[l] + 1 + (sh & 1), sh - 1));
+        }
+    }
+    const int t = threadIdx.x;
+    // ---- level 0 from the depth buffer
+    {
+        const int rw = needx[0] - lox[0] + 1, rh = needy[0] - loy[0] + 1;
+        const bool oddW = p.depthW & 1, oddH = p.depthH & 1;
+        const float* depth = p.depth;
+        const int dW = p.depthW, dH = p.depthH;
+        if (rw > 0 && rh > 0) {
+            for (int i = t; i < rw * rh; i += 256) {
+                const int rx = i % rw, ry = i / rw;
+                const int x = lox[0] + rx, y = loy[0] + ry;
+                const MinMax m = footprint<true>(2 * x, 2 * y, dW, dH, oddH, oddW, [&](int sx, int sy) {
+                    const float d = depth[(size_t)sy * dW + sx];
+                    return make_float2(d, d);
+                });
+                const float2 v = make_float2(m.mn, m.mx);
+                bufA[ry * rw + rx] = v;
+                if (x <= hix[0] && y <= hiy[0]) p.level[0][(size_t)y * p.w[0] + x] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- levels 1..K-1 out of LDS, ping-ponging between the two buffers
+    for (int l = 1; l < K; l++) {
+        const float2* src = (l & 1) ? bufA : bufB;
+        float2* dst = (l & 1) ? bufB : bufA;
+        const int srw = needx[l - 1] - lox[l - 1] + 1;
+        const int sox = lox[l - 1], soy = loy[l - 1];
+        const int sw = p.w[l - 1], sh = p.h[l - 1];
+        const int rw = needx[l] - lox[l] + 1, rh = needy[l] - loy[l] + 1;
+        if (rw > 0 && rh > 0) {
+            for (int i = t; i < rw * rh; i += 256) {
+                const int rx = i % rw, ry = i / rw;
+                const int x = lox[l] + rx, y = loy[l] + ry;
+                const MinMax m = footprint<false>(2 * x, 2 * y, sw, sh, sh & 1, sw & 1, [&](int sx, int sy) { return src[(sy - soy) * srw + (sx - sox)]; });
+                const float2 v = make_float2(m.mn, m.mx);
+                dst[ry * rw + rx] = v;
+                if (x <= hix[l] && y <= hiy[l]) p.level[l][(size_t)y * p.w[l] + x] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void hizTailKernel(HizParams p) {
+    __shared__ float2 bufA[32 * 32];
+    __shared__ float2 bufB[32 * 32];
+    const int t = threadIdx.x;
+    const int first = p.baseCount;
+    for (int l = first; l < p.count; l++) {
+        const int sw = p.w[l - 1], sh = p.h[l - 1];
+        const int w = p.w[l], h = p.h[l];
+        float2* dst = ((l - first) & 1) ? bufB : bufA;
+        const float2* srcL = ((l - first) & 1) ? bufA : bufB;
+        const float2* srcG = p.level[l - 1];
+        for (int i = t; i < w * h; i += 1024) {
+            const int x = i % w, y = i / w;
+            MinMax m;
+            if (l == first) m = footprint<false>(2 * x, 2 * y, sw, sh, sh & 1, sw & 1, [&](int sx, int sy) { return srcG[(size_t)sy * sw + sx]; });
+            else m = footprint<false>(2 * x, 2 * y, sw, sh, sh & 1, sw & 1, [&](int sx, int sy) { return srcL[sy * sw + sx]; });
+            const float2 v = make_float2(m.mn, m.mx);
+            dst[i] = v;
+            p.level[l][i] = v;
+        }
+        __syncthreads();
+    }
+}
+
+static int launchDepthHiZPyramid(const PassCtx& c) {
+    const int mipCount = c.specInt(0, 0);
+    const int resX = c.specInt(1, 0), resY = c.specInt(2, 0);
+    if (mipCount < 1) return c.fail(-1, "depthHiZPyramid: mipCount specialisation constant must be >= 1");
+    if (mipCount > kHizMaxLevels)
+        return c.fail(-6, "depthHiZPyramid: more than 11 pyramid levels (base > 2048) is unsupported, as in the reference shader; build per-tile pyramids");
+    if (int rc = c.needSampled(13, F_D32, "depthHiZPyramid depthBuffer")) return rc;
+    const ImgView& depth = c.sampled[13];
+    if (resX != depth.w || resY != depth.h) return c.fail(-1, "depthHiZPyramid: specialisation constants 1/2 must equal the depth buffer resolution");
+    HizParams p{};
+    p.depth = (const float*)depth.ptr;
+    p.depthW = depth.w; p.depthH = depth.h;
+    p.count = mipCount;
+    p.baseCount = std::min(mipCount, kHizBaseLevels);
+    // binding i is bound to pyramid mip max(i - unused, 0) (RenderFrontend.cpp:831-836)
+    const int unused = kHizMaxLevels - mipCount;
+    int sw = depth.w, sh = depth.h;
+    for (int l = 0; l < mipCount; l++) {
+        const int b = l + unused;
+        if (int rc = c.needStorage(b, F_RG32F, "depthHiZPyramid pyramid mip")) return rc;
+        const ImgView& v = c.storage[b];
+        const int w = std::max(sw / 2, 1), h = std::max(sh / 2, 1);
+        if (v.w != w || v.h != h)
+            return c.fail(-4, "depthHiZPyramid: pyramid mip " + std::to_string(l) + " is " + std::to_string(v.w) + "x" + std::to_string(v.h) + ", expected " +
+                                  std::to_string(w) + "x" + std::to_string(h));
+        p.level[l] = (float2*)v.ptr; p.w[l] = w; p.h[l] = h;
+        sw = w; sh = h;
+    }
+    if (p.baseCount < p.count && (p.w[p.baseCount] > 32 || p.h[p.baseCount] > 32)) return c.fail(-6, "depthHiZPyramid: tail level exceeds 32x32");
+    const dim3 grid(divUp((unsigned)p.w[0], 32u), divUp((unsigned)p.h[0], 32u));
+    hizBaseKernel<<<grid, 256, 0, c.stream>>>(p);
+    PLR_CHECK_LAUNCH(c);
+    if (p.count > p.baseCount) {
+        hizTailKernel<<<1, 1024, 0, c.stream>>>(p);
+        PLR_CHECK_LAUNCH(c);
+    }
+    return 0;
+}
+PLR_REGISTER_SHADER("depthHiZPyramid.comp", launchDepthHiZPyramid);
+
+} // namespace plr

@@ -139,3 +139,154 @@ def orc_tonemap(color_packed, w, h, global_packed, target_format=F.BGRA8_uNorm):
     g = orc.global_from_bytes(global_packed)
     L.orc_tonemapping(src.ref(), dst.ref(), C.byref(g))
     return dst.arr.reshape(h, w, 4).copy()
+
+
+# ------------------------------------------------------------------------------------------- HiZ
+def mip_count_from_resolution(w, h, d=1):
+    """Common/Utilities/MathUtils.cpp:17-19"""
+    return 1 + int(math.floor(math.log2(max(w, h, d))))
+
+
+def single_pass_mip_chain_dispatch(width, height, mip_count, max_mip_count=11):
+    """RenderFrontend::computeSinglePassMipChainDispatchCount, RenderFrontend.cpp:1807-1827"""
+    unused = max_mip_count - mip_count
+    if unused >= 6:
+        return 1, 1
+    extent = 32 // (2 ** unused)
+    return math.ceil(width / extent), math.ceil(height / extent)
+
+
+def hiz_mip_sizes(w, h):
+    pw, ph = w // 2, h // 2
+    n = mip_count_from_resolution(pw, ph)
+    return [(max(pw >> m, 1), max(ph >> m, 1)) for m in range(n)]
+
+
+def gpu_hiz(be, depth_f32, w, h):
+    """computeDepthPyramid, RenderFrontend.cpp:804-838; spec constants :1770-1805; pyramid image :1736-1745"""
+    pw, ph = w // 2, h // 2
+    mip_count = mip_count_from_resolution(pw, ph)
+    depth = be.createImage(image_desc_2d(w, h, F.Depth32), np.ascontiguousarray(depth_f32, np.float32))
+    pyramid = be.createImage(image_desc_2d(pw, ph, F.RG32_sFloat, MipCount.FullChain))
+    sync = be.createStorageBuffer(4, struct.pack("<I", 0))
+    dx, dy = single_pass_mip_chain_dispatch(pw, ph, mip_count)
+    p = be.createComputePass("depthHiZPyramid.comp", [spec_int(0, mip_count), spec_int(1, w), spec_int(2, h), spec_int(3, dx * dy)], "Depth min/max pyramid")
+    unused = 11 - mip_count
+    storage = [ImageResource(pyramid, (i - unused) if i >= unused else 0, i) for i in range(11)]
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(
+        storageImages=storage, sampledImages=[ImageResource(depth, 0, 13), ImageResource(pyramid, 0, 15)],
+        storageBuffers=[StorageBufferResource(sync, False, 16)]), b"", (dx, dy, 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return [be.downloadImage(pyramid, m, np.float32).reshape(s[1], s[0], 2).copy() for m, s in enumerate(hiz_mip_sizes(w, h))], pyramid, depth
+
+
+def orc_hiz(depth_f32, w, h):
+    L = orc.lib()
+    sizes = hiz_mip_sizes(w, h)
+    depth = orc.Img(np.ascontiguousarray(depth_f32, np.float32), w, h, F.Depth32)
+    mips = [orc.new_image(s[0], s[1], F.RG32_sFloat, 8) for s in sizes]
+    arr = (orc.OrcImage * len(mips))(*[m.c for m in mips])
+    L.orc_depth_hiz_pyramid(depth.ref(), arr, C.c_int32(len(mips)))
+    return [m.arr.view(np.float32).reshape(s[1], s[0], 2).copy() for m, s in zip(mips, sizes)]
+
+
+# ------------------------------------------------------------------------------------------- bloom
+BLOOM_MIPS = 6  # Techniques/Bloom.cpp:6
+
+
+def bloom_mip_size(w, h, m):
+    return max(w >> m, 1), max(h >> m, 1)
+
+
+def gpu_bloom(be, scene_packed, w, h, strength=0.05, radius=1.5):
+    """Bloom::computeBloom, Techniques/Bloom.cpp:56-143 (passes created in Bloom::init :8-40)"""
+    down_p = [be.createComputePass("bloomDownsample.comp", [], "Bloom downsample mip %d" % (i + 1)) for i in range(BLOOM_MIPS - 1)]
+    up_p = [be.createComputePass("bloomUpsample.comp", [spec_bool(0, i == 0)], "Bloom Upsample mip %d" % (BLOOM_MIPS - 2 - i)) for i in range(BLOOM_MIPS - 1)]
+    apply_p = be.createComputePass("applyBloom.comp", [], "Apply bloom")
+    target = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat), scene_packed)
+    be.newFrame()
+    desc = image_desc_2d(w, h, F.R11G11B10_uFloat, MipCount.Manual, BLOOM_MIPS)
+    down = be.createTemporaryImage(desc)
+    for i in range(BLOOM_MIPS - 1):
+        tw, th = bloom_mip_size(w, h, i + 1)
+        be.setComputePassExecution(ComputePassExecution(down_p[i], RenderPassResources(
+            storageImages=[ImageResource(down, i + 1, 0)], sampledImages=[ImageResource(target if i == 0 else down, i, 1)]), b"",
+            (math.ceil(tw / 8.0), math.ceil(th / 8.0), 1)))
+    up = be.createTemporaryImage(desc)
+    for i in range(BLOOM_MIPS - 1):
+        tm = BLOOM_MIPS - 2 - i
+        tw, th = bloom_mip_size(w, h, tm)
+        be.setComputePassExecution(ComputePassExecution(up_p[i], RenderPassResources(
+            storageImages=[ImageResource(up, tm, 0)], sampledImages=[ImageResource(up, tm + 1, 1), ImageResource(down, tm + 1, 2)]),
+            struct.pack("<f", radius), (math.ceil(tw / 8.0), math.ceil(th / 8.0), 1)))
+    be.setComputePassExecution(ComputePassExecution(apply_p, RenderPassResources(
+        storageImages=[ImageResource(target, 0, 0)], sampledImages=[ImageResource(up, 0, 1)]), struct.pack("<f", strength),
+        (math.ceil(w / 8.0), math.ceil(h / 8.0), 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    downs = [be.downloadImage(down, m, np.uint32).copy() for m in range(1, BLOOM_MIPS)]
+    ups = [be.downloadImage(up, m, np.uint32).copy() for m in range(0, BLOOM_MIPS - 1)]
+    return be.downloadImage(target, 0, np.uint32).copy(), downs, ups
+
+
+def orc_bloom(scene_packed, w, h, strength=0.05, radius=1.5):
+    L = orc.lib()
+    target = orc.Img(np.array(scene_packed, np.uint32, copy=True), w, h, F.R11G11B10_uFloat)
+    down = [None] + [orc.new_image(*bloom_mip_size(w, h, m), F.R11G11B10_uFloat, 4) for m in range(1, BLOOM_MIPS)]
+    up = [orc.new_image(*bloom_mip_size(w, h, m), F.R11G11B10_uFloat, 4) for m in range(0, BLOOM_MIPS)]
+    for i in range(BLOOM_MIPS - 1):
+        L.orc_bloom_downsample((target if i == 0 else down[i]).ref(), down[i + 1].ref())
+    for i in range(BLOOM_MIPS - 1):
+        tm = BLOOM_MIPS - 2 - i
+        L.orc_bloom_upsample(down[tm + 1].ref(), up[tm + 1].ref(), up[tm].ref(), C.c_int32(1 if i == 0 else 0), C.c_float(radius))
+    L.orc_apply_bloom(target.ref(), up[0].ref(), C.c_float(strength))
+    return (target.arr.view(np.uint32).copy(), [d.arr.view(np.uint32).copy() for d in down[1:]],
+            [u.arr.view(np.uint32).copy() for u in up[:BLOOM_MIPS - 1]])
+
+
+# ------------------------------------------------------------------------------------------- TAA
+def gpu_taa(be, current, history, motion_snorm, depth_f32, w, h, weights9, global_packed, clip=True, dilate=True, tech=4, tonemap=True):
+    """TAA::computeTemporalFilter, Techniques/TAA.cpp:139-166; spec constants :204-233"""
+    global_binding(be).set(global_packed)
+    cur = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat), current)
+    hist_src = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat), history)
+    hist_dst = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat))
+    out = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat))
+    mot = be.createImage(image_desc_2d(w, h, F.RG16_sNorm), motion_snorm)
+    dep = be.createImage(image_desc_2d(w, h, F.Depth32), np.ascontiguousarray(depth_f32, np.float32))
+    wbuf = be.createUniformBuffer(36)
+    be.setUniformBufferData(wbuf, np.asarray(weights9, np.float32).tobytes())
+    p = be.createComputePass("temporalFilter.comp", [spec_bool(0, clip), spec_bool(1, dilate), spec_int(2, tech), spec_bool(3, tonemap)], "Temporal filtering")
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(
+        storageImages=[ImageResource(out, 0, 1), ImageResource(hist_dst, 0, 2)],
+        sampledImages=[ImageResource(cur, 0, 0), ImageResource(hist_src, 0, 3), ImageResource(mot, 0, 4), ImageResource(dep, 0, 5)],
+        uniformBuffers=[UniformBufferResource(wbuf, 6)]), b"", (math.ceil(w / 8.0), math.ceil(h / 8.0), 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return be.downloadImage(out, 0, np.uint32).copy(), be.downloadImage(hist_dst, 0, np.uint32).copy()
+
+
+def orc_taa(current, history, motion_snorm, depth_f32, w, h, weights9, global_packed, clip=True, dilate=True, tech=4, tonemap=True):
+    L = orc.lib()
+    cur = orc.Img(current, w, h, F.R11G11B10_uFloat)
+    hs = orc.Img(history, w, h, F.R11G11B10_uFloat)
+    hd = orc.new_image(w, h, F.R11G11B10_uFloat, 4)
+    out = orc.new_image(w, h, F.R11G11B10_uFloat, 4)
+    mot = orc.Img(motion_snorm, w, h, F.RG16_sNorm)
+    dep = orc.Img(np.ascontiguousarray(depth_f32, np.float32), w, h, F.Depth32)
+    wts = np.ascontiguousarray(weights9, np.float32)
+    g = orc.global_from_bytes(global_packed)
+    L.orc_temporal_filter(cur.ref(), out.ref(), hd.ref(), hs.ref(), mot.ref(), dep.ref(), _p(wts), C.byref(g), C.c_int32(int(clip)), C.c_int32(int(dilate)),
+                          C.c_int32(tech), C.c_int32(int(tonemap)))
+    return out.arr.view(np.uint32).copy(), hd.arr.view(np.uint32).copy()
+
+
+def orc_taa_weights(jitter_px):
+    L = orc.lib()
+    j = np.ascontiguousarray(jitter_px, np.float32)
+    w = np.zeros(9, np.float32)
+    L.orc_taa_resolve_weights(_p(j), _p(w))
+    return w
