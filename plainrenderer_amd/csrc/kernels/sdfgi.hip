@@ -1,0 +1,472 @@
+// SDF diffuse GI for gfx950, part 1: depthDownscale.comp, sdfCameraFrustumCulling.comp, sdfCameraTileCulling.comp,
+// sdfDiffuseTrace.comp (+ SDF.inc, sdfCulling.inc, sampling.inc, sunShadowCascades.inc, sky.inc, SphericalHarmonics.inc);
+// host side Techniques/SDFGI.cpp:380-419,538-630 and RenderFrontend.cpp:873-892.
+//
+// Mapping to CDNA4: one wave64 is one 8x8 reference workgroup (the shared-memory ray exchange of resolveColor becomes a
+// per-wave LDS slab), four waves of a block share one 32x32-px culling tile so the culled instance list and the 96-byte
+// SDFInstance records are wave-uniform scalar loads. SDF volumes (64^3 half floats, 512 KiB each) are fetched with explicit
+// trilinear address math; 256 of them (134 MB) sit in the 256 MB Infinity Cache after the first touch.
+// Culling is rewritten as ordered wave compaction, which makes the reference's atomic-append order deterministic
+// (ascending instance index) without changing which instances survive.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+// ------------------------------------------------------------------------------------------------
+// depthDownscale.comp:12-20: half-res R16F depth = nearest full-res texel at (2*iUV + 0.5) / res
+__global__ __launch_bounds__(256) void depthDownscaleKernel(ImgView src, ImgView dst, int coverW, int coverH) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= coverW || y >= coverH) return;
+    const vec2 texelSize(1.f / (float)src.w, 1.f / (float)src.h);
+    const vec2 uv(((float)(x * 2) + 0.5f) * texelSize.x, ((float)(y * 2) + 0.5f) * texelSize.y);
+    const float depth = sampleNearest2D<F_D32, CLAMP>(src, uv).x;
+    ((uint16_t*)dst.ptr)[(size_t)y * (size_t)dst.w + x] = (uint16_t)floatToHalfBits(depth);
+}
+static int launchDepthDownscale(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R16F, "depthDownscale halfResDst")) return rc;
+    if (int rc = c.needSampled(1, F_D32, "depthDownscale fullResSrc")) return rc;
+    const ImgView& dst = c.storage[0];
+    const int w = std::min((int)(c.dispatch[0] * 8u), dst.w), h = std::min((int)(c.dispatch[1] * 8u), dst.h);
+    if (w <= 0 || h <= 0) return 0;
+    depthDownscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.sampled[1], dst, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("depthDownscale.comp", launchDepthDownscale);
+
+// ------------------------------------------------------------------------------------------------
+// sdfCameraFrustumCulling.comp:36-62 as one block doing an ordered stream compaction.
+struct FrustumUbo { float points[6][4]; float normals[6][4]; };
+struct CulledList { uint32_t count; uint32_t indices[1]; };
+
+__global__ __launch_bounds__(1024) void frustumCullingKernel(const uint32_t* __restrict__ instanceBuffer, const FrustumUbo* __restrict__ frustum,
+                                                             uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs,
+                                                             const float* __restrict__ influenceRangeP, uint32_t threadLimit, uint32_t capacity) {
+    __shared__ uint32_t waveTotals[16];
+    __shared__ uint32_t base;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t instanceCount = min(instanceBuffer[0], threadLimit);
+    const float influenceRange = *influenceRangeP;
+    if (t == 0) base = culled[0];
+    __syncthreads();
+    for (uint32_t chunk = 0; chunk < instanceCount; chunk += 1024u) {
+        const uint32_t instanceIndex = chunk + t;
+        bool inside = false;
+        if (instanceIndex < instanceCount) {
+            const BoundingBox bb = bbs[instanceIndex];
+            const vec3 bbMin = ld3(bb.bbMin), bbMax = ld3(bb.bbMax);
+            const vec3 center = (bbMax + bbMin) * 0.5f;
+            const vec3 ext = bbMax - bbMin;
+            float radius = gmax(gmax(ext.x, ext.y), ext.z) * 0.5f;
+            radius += influenceRange;
+            inside = true;
+            for (int i = 0; i < 6; i++) {
+                const bool outsidePlane = dot(center - ld3(frustum->points[i]), ld3(frustum->normals[i])) > radius;
+                inside = inside && !outsidePlane;
+            }
+        }
+        const unsigned long long mask = __ballot(inside);
+        const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) waveTotals[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t waveBase = base, total = 0;
+        for (uint32_t w = 0; w < 16u; w++) {
+            if (w < wave) waveBase += waveTotals[w];
+            total += waveTotals[w];
+        }
+        if (inside && waveBase + before < capacity) culled[1 + waveBase + before] = instanceIndex;
+        __syncthreads();
+        if (t == 0) base += total;
+        __syncthreads();
+    }
+    if (t == 0) culled[0] = base;
+}
+
+static int launchFrustumCulling(const PassCtx& c) {
+    if (int rc = c.needSbuf(0, 16, "sdfCameraFrustumCulling instance buffer")) return rc;
+    if (int rc = c.needUbuf(1, sizeof(FrustumUbo), "sdfCameraFrustumCulling frustum buffer")) return rc;
+    if (int rc = c.needSbuf(2, 8, "sdfCameraFrustumCulling culled instance buffer")) return rc;
+    if (int rc = c.needSbuf(3, sizeof(BoundingBox), "sdfCameraFrustumCulling world bounding boxes")) return rc;
+    if (int rc = c.needUbuf(4, 4, "sdfCameraFrustumCulling influence range")) return rc;
+    const uint32_t capacity = (uint32_t)(c.sbuf[2].size / 4u) - 1u;
+    const uint32_t bbCapacity = (uint32_t)(c.sbuf[3].size / sizeof(BoundingBox));
+    // invocations exist for dispatch*64 instances (instanceIndex >= instanceCount return early)
+    const uint32_t threadLimit = std::min(c.dispatch[0] * 64u, bbCapacity);
+    frustumCullingKernel<<<1, 1024, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const FrustumUbo*)c.ubuf[1].ptr, (uint32_t*)c.sbuf[2].ptr,
+                                                   (const BoundingBox*)c.sbuf[3].ptr, (const float*)c.ubuf[4].ptr, threadLimit, capacity);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("sdfCameraFrustumCulling.comp", launchFrustumCulling);
+
+// ------------------------------------------------------------------------------------------------
+// sdfCulling.inc:17-20: tile stride from the FULL screen resolution (reproduced as is)
+PLR_DI uint32_t tileIndexFromTileUV(int tx, int ty, const GlobalUbo* g) {
+    const uint32_t tileCountX = (uint32_t)ceilf((float)g->screenResolution[0] / (float)kCullingTileSize);
+    return (uint32_t)tx + (uint32_t)ty * tileCountX;
+}
+
+PLR_DI vec3 VFromiUV(int x, int y, const GlobalUbo* g) {
+    const vec2 pixelCoor(((float)x / (float)g->screenResolution[0] - 0.5f) * 2.f, ((float)y / (float)g->screenResolution[1] - 0.5f) * 2.f);
+    return calculateViewDirectionFromPixel(pixelCoor, ld3(g->cameraForward), ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
+}
+
+// sdfCameraTileCulling.comp:42-99, one wave per tile: 64 instances are tested per step and appended in list order.
+template <bool USE_HIZ>
+__global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
+                                                         const float* __restrict__ influenceRangeP, ImgView depthMinMax, const GlobalUbo* __restrict__ g,
+                                                         uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX, uint32_t domainY, uint32_t tileCapacity,
+                                                         uint32_t listCapacity) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tileLinear = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tileLinear >= domainX * domainY) return;
+    const int tx = (int)(tileLinear % domainX), ty = (int)(tileLinear / domainX);
+    const uint32_t tileIndex = tileIndexFromTileUV(tx, ty, g);
+    if (tileIndex >= tileCapacity) return;
+    CulledInstancesPerTile* tile = tiles + tileIndex;
+    const int ts = (int)kCullingTileSize;
+    const vec3 cameraToPixel = -VFromiUV(tx * ts + ts / 2, ty * ts + ts / 2, g);
+    vec3 V_ll = -VFromiUV(tx * ts, ty * ts, g);
+    vec3 V_ur = -VFromiUV(tx * ts + ts, ty * ts + ts, g);
+    V_ll /= dot(cameraToPixel, V_ll);
+    V_ur /= dot(cameraToPixel, V_ur);
+    const float coneRadiusPerMeter = distance(V_ll, V_ur) * 0.5f;
+    float depthMin = g->nearPlane, depthMax = g->farPlane;
+    if (USE_HIZ) {
+        const vec2 uv((float)tx / (float)tileCountX, (float)ty / (float)tileCountY);
+        const vec4 mm = sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv);
+        depthMin = linearizeDepth(mm.y, g->nearPlane, g->farPlane);
+        depthMax = linearizeDepth(mm.x, g->nearPlane, g->farPlane);
+    }
+    const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
+    depthMin *= dot(cameraToPixel, camFwd);
+    depthMax *= dot(cameraToPixel, camFwd);
+    const float influenceRange = *influenceRangeP;
+    const uint32_t culledInstanceCount = min(culled[0], listCapacity);
+    uint32_t count = 0;
+    for (uint32_t chunk = 0; chunk < culledInstanceCount && count < kMaxObjectsPerTile; chunk += 64u) {
+        const uint32_t i = chunk + lane;
+        bool pass = false;
+        uint32_t inst = 0;
+        if (i < culledInstanceCount) {
+            inst = culled[1 + i];
+            const BoundingBox bb = bbs[inst];
+            const vec3 bbMin = ld3(bb.bbMin), bbMax = ld3(bb.bbMax);
+            const vec3 center = (bbMax + bbMin) * 0.5f;
+            const vec3 ext = (bbMax - bbMin) * 0.5f;
+            float radius = gmax(gmax(ext.x, ext.y), ext.z);
+            radius += influenceRange;
+            float projection = dot(center - camPos, cameraToPixel);
+            projection = gclamp(projection, depthMin, depthMax);
+            const float d = distance(center, projection * cameraToPixel + camPos);
+            pass = d < radius + coneRadiusPerMeter * projection;
+        }
+        const unsigned long long mask = __ballot(pass);
+        const uint32_t pos = count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pass && pos < kMaxObjectsPerTile) tile->indices[pos] = inst;
+        count = min(count + (uint32_t)__popcll(mask), kMaxObjectsPerTile);
+    }
+    if (lane == 0) tile->objectCount = count;
+}
+
+static int launchTileCulling(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSbuf(0, 8, "sdfCameraTileCulling culled instance buffer")) return rc;
+    if (int rc = c.needSbuf(1, sizeof(BoundingBox), "sdfCameraTileCulling world bounding boxes")) return rc;
+    if (int rc = c.needSbuf(2, sizeof(CulledInstancesPerTile), "sdfCameraTileCulling per tile buffer")) return rc;
+    if (int rc = c.needUbuf(3, 4, "sdfCameraTileCulling influence range")) return rc;
+    const bool useHiZ = c.specBool(0, false);
+    if (useHiZ) if (int rc = c.needSampled(4, F_RG32F, "sdfCameraTileCulling depthMinMaxTexture")) return rc;
+    if (c.push.size() < 8) return c.fail(-1, "sdfCameraTileCulling: push constant cameraTileCount missing");
+    uint32_t tileCount[2];
+    std::memcpy(tileCount, c.push.data(), 8);
+    // invocations exist for dispatch*8 tiles per axis; tiles beyond cameraTileCount return early
+    const uint32_t tcx = std::min(tileCount[0], c.dispatch[0] * 8u), tcy = std::min(tileCount[1], c.dispatch[1] * 8u);
+    if (tcx == 0 || tcy == 0) return 0;
+    const uint32_t tileCapacity = (uint32_t)(c.sbuf[2].size / sizeof(CulledInstancesPerTile));
+    const uint32_t listCapacity = (uint32_t)(c.sbuf[0].size / 4u) - 1u;
+    const dim3 grid(divUp(tcx * tcy, 4u));
+    const ImgView hiz = useHiZ ? c.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
+    // the uv of the HiZ fetch divides by the push-constant tile count; the dispatch only bounds which tiles run
+    if (useHiZ) tileCullingKernel<true><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
+                                                                   (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileCapacity, listCapacity);
+    else tileCullingKernel<false><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
+                                                             (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileCapacity, listCapacity);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("sdfCameraTileCulling.comp", launchTileCulling);
+
+// ------------------------------------------------------------------------------------------------ trace
+// trilinear, clamp-to-edge sample of an R16F volume (sampler contract: 8-bit sub-texel weights)
+PLR_DI float sampleSDF(const ImgView& v, vec3 uvw) {
+    int i0, j0, k0; float a, b, c;
+    linearCoord(uvw.x * (float)v.w, &i0, &a);
+    linearCoord(uvw.y * (float)v.h, &j0, &b);
+    linearCoord(uvw.z * (float)v.d, &k0, &c);
+    const int x0 = clampi(i0, v.w), x1 = clampi(i0 + 1, v.w);
+    const int y0 = clampi(j0, v.h) * v.w, y1 = clampi(j0 + 1, v.h) * v.w;
+    const int sl = v.w * v.h;
+    const int z0 = clampi(k0, v.d) * sl, z1 = clampi(k0 + 1, v.d) * sl;
+    const uint16_t* p = (const uint16_t*)v.ptr;
+    const float t000 = halfBitsToFloat(p[z0 + y0 + x0]), t100 = halfBitsToFloat(p[z0 + y0 + x1]);
+    const float t010 = halfBitsToFloat(p[z0 + y1 + x0]), t110 = halfBitsToFloat(p[z0 + y1 + x1]);
+    const float t001 = halfBitsToFloat(p[z1 + y0 + x0]), t101 = halfBitsToFloat(p[z1 + y0 + x1]);
+    const float t011 = halfBitsToFloat(p[z1 + y1 + x0]), t111 = halfBitsToFloat(p[z1 + y1 + x1]);
+    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
+    float r = t000 * ((a0 * b0) * c0);
+    r = r + t100 * ((a * b0) * c0);
+    r = r + t010 * ((a0 * b) * c0);
+    r = r + t110 * ((a * b) * c0);
+    r = r + t001 * ((a0 * b0) * c);
+    r = r + t101 * ((a * b0) * c);
+    r = r + t011 * ((a0 * b) * c);
+    r = r + t111 * ((a * b) * c);
+    return r;
+}
+
+// SDF.inc:16-25
+PLR_DI vec3 normalFromSDF(vec3 uv, vec3 extends, const ImgView& sdf) {
+    const float extendsMax = gmax(extends.x, gmax(extends.y, extends.z));
+    const vec3 extendsNormalized = extends / extendsMax;
+    const vec3 epsilon = vec3(0.15f) / vec3((float)sdf.w, (float)sdf.h, (float)sdf.d) / extendsNormalized;
+    return normalize(vec3(sampleSDF(sdf, uv + vec3(epsilon.x, 0.f, 0.f)) - sampleSDF(sdf, uv - vec3(epsilon.x, 0.f, 0.f)),
+                          sampleSDF(sdf, uv + vec3(0.f, epsilon.y, 0.f)) - sampleSDF(sdf, uv - vec3(0.f, epsilon.y, 0.f)),
+                          sampleSDF(sdf, uv + vec3(0.f, 0.f, epsilon.z)) - sampleSDF(sdf, uv - vec3(0.f, 0.f, epsilon.z))));
+}
+
+struct TraceResult {
+    bool hit;
+    float closestHitDistance;
+    vec3 hitPos;
+    vec3 albedo;
+};
+
+// SDF.inc:42-86
+PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mn, vec3 mx, float* tOut) {
+    bool hit = false;
+    float t = 100000.f;
+    float intersection = o.x < 0.f ? mn.x : mx.x;
+    const float tx = (intersection - o.x) / dir.x;
+    vec3 p = o + tx * dir;
+    if (tx > 0.f && p.y >= mn.y && p.y <= mx.y && p.z >= mn.z && p.z <= mx.z) { t = gmin(t, tx); hit = true; }
+    intersection = o.y < 0.f ? mn.y : mx.y;
+    const float ty = (intersection - o.y) / dir.y;
+    p = o + ty * dir;
+    if (ty > 0.f && p.x >= mn.x && p.x <= mx.x && p.z >= mn.z && p.z <= mx.z) { t = gmin(t, ty); hit = true; }
+    intersection = o.z < 0.f ? mn.z : mx.z;
+    const float tz = (intersection - o.z) / dir.z;
+    p = o + tz * dir;
+    if (tz > 0.f && p.x >= mn.x && p.x <= mx.x && p.y >= mn.y && p.y <= mx.y) { t = gmin(t, tz); hit = true; }
+    *tOut = t;
+    return hit;
+}
+
+// SDF.inc:101-184. `inst` and `sdf` are wave uniform.
+PLR_DI void traceRayTroughSDFInstance(const SDFInstance& inst, vec3 rayStartWorld, const ImgView& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
+    const float* m = inst.worldToLocal;
+    const vec3 localExtends = ld3(inst.localExtends);
+    vec3 rayStartLocal = mulMat4(m, vec4(rayStartWorld, 1.f)).xyz();
+    const vec3 rayEndLocal = mulMat4(m, vec4(rayStartWorld + rayDirectionWorld, 1.f)).xyz();
+    vec3 rayDirection = rayEndLocal - rayStartLocal;
+    rayDirection /= length(rayDirection);
+    const vec3 sdfMaxLocal = localExtends * 0.5f;
+    const vec3 sdfMinLocal = -sdfMaxLocal;
+    float hitDistanceLocal = 0.f;
+    const bool inside = rayStartLocal.x >= sdfMinLocal.x && rayStartLocal.y >= sdfMinLocal.y && rayStartLocal.z >= sdfMinLocal.z &&
+                        rayStartLocal.x <= sdfMaxLocal.x && rayStartLocal.y <= sdfMaxLocal.y && rayStartLocal.z <= sdfMaxLocal.z;
+    if (!inside) {
+        float t;
+        if (rayAABBIntersection(rayStartLocal, rayDirection, sdfMinLocal, sdfMaxLocal, &t)) {
+            rayStartLocal += t * rayDirection;
+            hitDistanceLocal = t;
+        } else return;
+    }
+    vec3 localSamplePos = rayStartLocal;
+    const float distanceThreshold = length(localExtends / vec3((float)sdf.w, (float)sdf.h, (float)sdf.d)) * 0.25f;
+    float dLast = 0.f, d = 0.f;
+    const float localToGlobalScale = 1.f / length(vec3(m[0], m[1], m[2]));
+    if (localToGlobalScale * hitDistanceLocal > tr.closestHitDistance) return;
+    vec3 localExtendsHalf = localExtends * 0.5f;
+    localExtendsHalf = localExtendsHalf + 0.01f;
+    for (int i = 0; i < 128; i++) {
+        if (localSamplePos.x > localExtendsHalf.x || localSamplePos.y > localExtendsHalf.y || localSamplePos.z > localExtendsHalf.z ||
+            localSamplePos.x < -localExtendsHalf.x || localSamplePos.y < -localExtendsHalf.y || localSamplePos.z < -localExtendsHalf.z)
+            break;
+        vec3 sampleUV = localSamplePos / localExtends + 0.5f;
+        dLast = d;
+        d = sampleSDF(sdf, sampleUV);
+        if (d < distanceThreshold) {
+            tr.hit = true;
+            const float distanceGlobal = hitDistanceLocal * localToGlobalScale;
+            if (distanceGlobal < tr.closestHitDistance) {
+                tr.closestHitDistance = distanceGlobal;
+                const float lastStepSizeLocal = d / (1.f - (d - dLast));
+                localSamplePos += rayDirection * lastStepSizeLocal;
+                // the reference also evaluates normalFromSDF and the transformed normal here; neither reaches an output of
+                // sdfDiffuseTrace.comp (only the debug visualisation reads traceResult.N), so they are not computed
+                tr.albedo = vpow(ld3(inst.meanAlbedo), 2.2f);
+                const float lastStepSizeGlobal = lastStepSizeLocal * localToGlobalScale;
+                tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeGlobal);
+            }
+            break;
+        }
+        localSamplePos += rayDirection * fabsf(d);
+        hitDistanceLocal += fabsf(d);
+    }
+}
+
+// sunShadowCascades.inc:13-20 with the nearest / white-border sampler and a D16 map
+PLR_DI float simpleShadow(vec3 posWorld, const float* lightMatrix, const ImgView& shadowMap) {
+    vec4 p = mulMat4(lightMatrix, vec4(posWorld, 1.f));
+    p = p / p.w;
+    const vec2 xy(p.x * 0.5f + 0.5f, p.y * 0.5f + 0.5f);
+    const float actualDepth = gclamp(p.z, 0.f, 1.f);
+    const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_WHITE>(shadowMap, xy).x;
+    return actualDepth > shadowMapDepth ? 1.f : 0.f;
+}
+
+struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
+struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
+
+template <bool STRICT_CUTOFF>
+__global__ __launch_bounds__(256) void sdfDiffuseTraceKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
+                                                             const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
+                                                             const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
+                                                             const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
+                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY,
+                                                             uint32_t tileCapacity, uint32_t instanceCapacity) {
+    __shared__ RayInfo sharedRays[4][64];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    // one wave = one 8x8 reference workgroup; the four waves of a block are a 2x2 arrangement inside one culling tile
+    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = (int)blockIdx.y * 2 + (wave >> 1);
+    const bool active = gx < groupsX && gy < groupsY;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int px = gx * 8 + lx, py = gy * 8 + ly;
+    vec3 L(0.f, 0.f, 1.f);
+    RayInfo mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const vec2 uv((float)px / (float)outYSH.w, (float)py / (float)outYSH.h);
+        const float depth = sampleNearest2D<F_D32, CLAMP>(depthTexture, uv).x;
+        const float depthLinear = linearizeDepth(depth, g->nearPlane, g->farPlane);
+        const vec2 pixelNDC(uv.x * 2.f - 1.f, uv.y * 2.f - 1.f);
+        const vec3 camFwd = ld3(g->cameraForward);
+        const vec3 V = -calculateViewDirectionFromPixel(pixelNDC, camFwd, ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
+        const vec3 pWorld = ld3(g->cameraPosition) + V / dot(V, camFwd) * depthLinear;
+
+        const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
+        const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
+        const vec2 noiseUV((float)px / (float)noiseTex.w, (float)py / (float)noiseTex.h);
+        const vec4 nz = sampleNearest2D<F_RG8, REPEAT>(noiseTex, noiseUV);
+        const vec2 xi(nz.x, nz.y);
+        const vec3 normalTexel = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, uv).xyz();
+        const vec3 N = normalTexel * 2.f - 1.f;
+        mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
+        const vec3 rayOrigin = pWorld + N * 0.2f;
+        L = importanceSampleCosine(xi, N);
+
+        TraceResult tr;
+        tr.hit = false;
+        tr.closestHitDistance = 10000.f;
+        tr.hitPos = vec3(0.f);
+        tr.albedo = vec3(0.f);
+        // tileUV = gl_WorkGroupID.xy / (cullingTileSize / 8); wave uniform
+        const uint32_t tileIndex = min(tileIndexFromTileUV(gx / (int)(kCullingTileSize / 8u), gy / (int)(kCullingTileSize / 8u), g), tileCapacity - 1u);
+        const CulledInstancesPerTile* tile = tiles + tileIndex;
+        const int objectCount = (int)min(tile->objectCount, kMaxObjectsPerTile);
+        for (int i = 0; i < objectCount; i++) {
+            const uint32_t instIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tile->indices[i]), instanceCapacity - 1u);
+            const SDFInstance& inst = instanceBuffer->instances[instIndex];
+            const uint32_t texIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)inst.sdfTextureIndex), bindlessCount - 1u);
+            const ImgView sdf = bindless[texIndex];
+            traceRayTroughSDFInstance(inst, rayOrigin, sdf, L, tr);
+        }
+        vec3 hitColor;
+        if (tr.hit) {
+            const float shadow = simpleShadow(tr.hitPos, shadowInfo->lightMatrices[shadowCascadeIndex], shadowMap);
+            const vec3 sunLight = shadow * light->sunStrengthExposed * ld3(light->sunColor);
+            hitColor = tr.albedo * sunLight;
+            bool hitInRange = tr.closestHitDistance < *influenceRangeP;
+            hitInRange = hitInRange || !STRICT_CUTOFF;
+            const bool selfIntersection = tr.closestHitDistance < 0.0001f;
+            if (!hitInRange || selfIntersection) hitColor = vec3(0.f);
+        } else {
+            hitColor = sampleSkyLut(L, skyLut);
+        }
+        mine.cr = hitColor.x; mine.cg = hitColor.y; mine.cb = hitColor.z;
+    }
+    sharedRays[wave][lane] = mine;
+    __syncthreads();
+    if (!active) return;
+
+    // resolveColor (:70-116); sharedRays[x][y] of the reference = slab[y * 8 + x]
+    float weightTotal = 1.f;
+    vec3 color(mine.cr, mine.cg, mine.cb);
+    const vec3 myN(mine.nx, mine.ny, mine.nz);
+    for (int x = -1; x <= 1; x++)
+        for (int y = -1; y <= 1; y++) {
+            if (x == 0 && y == 0) continue;
+            const int rx = lx + x, ry = ly + y;
+            const bool isValidIndex = (rx > 0 && ry > 0) && (rx < 8 && ry < 8); // sic: > 0 (:88)
+            if (!isValidIndex) continue;
+            const RayInfo nb = sharedRays[wave][ry * 8 + rx];
+            const float NoN = gclamp(dot(myN, vec3(nb.nx, nb.ny, nb.nz)), 0.f, 1.f);
+            const bool normalsMatch = NoN > 0.9f;
+            const bool depthMatch = fabsf(mine.depth - nb.depth) < 0.5f;
+            if (normalsMatch && depthMatch) {
+                const float weight = (x == 0 ? 1.f : 0.5f) * (y == 0 ? 1.f : 0.5f);
+                color += weight * vec3(nb.cr, nb.cg, nb.cb);
+                weightTotal += weight;
+            }
+        }
+    color /= weightTotal;
+    const vec3 YCoCg = linearToYCoCg(color);
+    if (px < outYSH.w && py < outYSH.h) {
+        const vec4 sh = directionToSH_L1(L);
+        // result_Y_SH = vec4(0) + YCoCg.x * SH
+        const vec4 ysh = vec4(0.f) + YCoCg.x * sh;
+        const size_t idx = (size_t)py * (size_t)outYSH.w + px;
+        Texel<F_RGBA16F>::store(outYSH.ptr, idx, ysh);
+        Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(0.f + YCoCg.y, 0.f + YCoCg.z, 0.f, 0.f));
+    }
+}
+
+static int launchSdfDiffuseTrace(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "sdfDiffuseTrace imageOut_Y_SH")) return rc;
+    if (int rc = c.needStorage(1, F_RG16F, "sdfDiffuseTrace imageOut_CoCg")) return rc;
+    if (int rc = c.needSampled(2, F_D32, "sdfDiffuseTrace depthTexture")) return rc;
+    if (int rc = c.needSampled(3, F_RGBA8, "sdfDiffuseTrace normalTexture")) return rc;
+    if (int rc = c.needSampled(4, F_R11G11B10, "sdfDiffuseTrace skyLut")) return rc;
+    if (int rc = c.needSbuf(5, sizeof(LightBuffer), "sdfDiffuseTrace lightBuffer")) return rc;
+    if (int rc = c.needSbuf(6, 16 + sizeof(SDFInstance), "sdfDiffuseTrace sdfInstanceBuffer")) return rc;
+    if (int rc = c.needSbuf(7, sizeof(CulledInstancesPerTile), "sdfDiffuseTrace cameraCulledTileBuffer")) return rc;
+    if (int rc = c.needUbuf(8, 4, "sdfDiffuseTrace influenceRangeBuffer")) return rc;
+    if (int rc = c.needSbuf(9, sizeof(ShadowCascadeInfo), "sdfDiffuseTrace sunShadowInfo")) return rc;
+    if (int rc = c.needSampled(10, F_D16, "sdfDiffuseTrace shadowMap")) return rc;
+    if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "sdfDiffuseTrace: global texture array (set 2) is empty");
+    const bool strict = c.specBool(0, false);
+    const int cascade = c.specInt(1, 3);
+    if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
+    const ImgView& out = c.storage[0];
+    if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
+    const int groupsX = (int)c.dispatch[0], groupsY = (int)c.dispatch[1];
+    if (groupsX <= 0 || groupsY <= 0) return 0;
+    const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
+    const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
+    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)groupsY, 2u));
+#define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
+                       (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY,      \
+                       tileCapacity, instanceCapacity
+    if (strict) sdfDiffuseTraceKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    else sdfDiffuseTraceKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+#undef PLR_TRACE_ARGS
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("sdfDiffuseTrace.comp", launchSdfDiffuseTrace);
+
+} // namespace plr
