@@ -551,3 +551,77 @@ def orc_gi_upscale(ysh, cocg, tw, th, depth_f32, half_depth_u16, w, h, global_pa
     g = orc.global_from_bytes(global_packed)
     L.orc_indirect_light_upscale(d_y.ref(), d_c.ref(), s_y.ref(), s_c.ref(), fd.ref(), hd.ref(), C.byref(g))
     return d_y.arr.view(np.uint16).copy(), d_c.arr.view(np.uint16).copy()
+
+
+# ------------------------------------------------------------------------------------------- shading
+def gpu_brdf_lut(be, res, diffuse_brdf=2):
+    """RenderFrontend::computeBRDFLut, RenderFrontend.cpp:1031-1042 (512^2 RGBA16F in the reference)"""
+    lut = be.createImage(image_desc_2d(res, res, F.RGBA16_sFloat))
+    p = be.createComputePass("brdfLut.comp", [spec_int(0, diffuse_brdf)], "BRDF Lut creation")
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(lut, 0, 0)]), b"", (math.ceil(res / 8.0), math.ceil(res / 8.0), 1)))
+    be.renderFrame()
+    return be.downloadImage(lut, 0, np.uint16).copy(), lut
+
+
+def orc_brdf_lut(res, diffuse_brdf=2):
+    L = orc.lib()
+    lut = orc.new_image(res, res, F.RGBA16_sFloat, 8)
+    L.orc_brdf_lut(lut.ref(), C.c_int32(diffuse_brdf))
+    return lut.arr.view(np.uint16).copy()
+
+
+def gpu_deferred_shading(be, gb, w, h, brdf_lut_u16, lut_res, light_bytes, shadow_info, shadow_maps, shadow_res, ysh_u16, cocg_u16, froxel_u16, froxel_dims,
+                         vol_settings, sky_packed, global_packed, diffuse_brdf=2, multiscatter=0, geometric_aa=True, indirect_tech=0, cascades=3):
+    """deferred re-expression of renderForwardShading, RenderFrontend.cpp:894-929; spec constants :1093-1131"""
+    from plainrenderer_amd.backend import ImageDescription, ImageType, ImageUsageFlags
+    global_binding(be).set(global_packed)
+    mk = lambda fmt, data, ww=w, hh=h: be.createImage(image_desc_2d(ww, hh, fmt), np.ascontiguousarray(data))
+    color = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat))
+    depth, normal = mk(F.Depth32, gb["depth"]), mk(F.RGBA8, gb["normal"])
+    albedo, spec = mk(F.RGBA8, gb["albedo"]), mk(F.RGBA8, gb["specular"])
+    lut = mk(F.RGBA16_sFloat, brdf_lut_u16, lut_res, lut_res)
+    smaps = [mk(F.Depth16, m, shadow_res, shadow_res) for m in shadow_maps]
+    ysh, cocg = mk(F.RGBA16_sFloat, ysh_u16), mk(F.RG16_sFloat, cocg_u16)
+    fw, fh, fd = froxel_dims
+    vol = be.createImage(ImageDescription(width=fw, height=fh, depth=fd, type=ImageType.Type3D, format=F.RGBA16_sFloat, usageFlags=int(ImageUsageFlags.Sampled)),
+                         np.ascontiguousarray(froxel_u16))
+    sky = mk(F.R11G11B10_uFloat, sky_packed, 200, 100)
+    light = be.createStorageBuffer(20, light_bytes)
+    sinfo = be.createStorageBuffer(304, shadow_info)
+    vset = be.createUniformBuffer(64, vol_settings)
+    p = be.createComputePass("deferredShading.comp", [spec_int(0, diffuse_brdf), spec_int(1, multiscatter), spec_bool(2, geometric_aa), spec_int(3, indirect_tech),
+                                                      spec_uint(4, cascades)], "Forward shading (deferred)")
+    be.newFrame()
+    sampled = [ImageResource(lut, 0, 3), ImageResource(ysh, 0, 15), ImageResource(cocg, 0, 16), ImageResource(vol, 0, 18), ImageResource(depth, 0, 20),
+               ImageResource(normal, 0, 21), ImageResource(albedo, 0, 22), ImageResource(spec, 0, 23), ImageResource(sky, 0, 24)]
+    sampled += [ImageResource(smaps[i], 0, 9 + i) for i in range(4)]
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(
+        storageImages=[ImageResource(color, 0, 0)], sampledImages=sampled,
+        storageBuffers=[StorageBufferResource(light, True, 7), StorageBufferResource(sinfo, True, 8)],
+        uniformBuffers=[UniformBufferResource(vset, 19)]), b"", (math.ceil(w / 8.0), math.ceil(h / 8.0), 1)))
+    be.renderFrame()
+    return be.downloadImage(color, 0, np.uint32).copy()
+
+
+def orc_deferred_shading(gb, w, h, brdf_lut_u16, lut_res, light_bytes, shadow_info, shadow_maps, shadow_res, ysh_u16, cocg_u16, froxel_u16, froxel_dims, vol_settings,
+                         sky_packed, global_packed, bindless_arr, n_bindless, diffuse_brdf=2, multiscatter=0, geometric_aa=True, indirect_tech=0, cascades=3):
+    L = orc.lib()
+    I = lambda a, fmt, ww=w, hh=h, d=1: orc.Img(np.ascontiguousarray(a), ww, hh, fmt, d)
+    color = orc.new_image(w, h, F.R11G11B10_uFloat, 4)
+    depth, normal, albedo, spec = I(gb["depth"], F.Depth32), I(gb["normal"], F.RGBA8), I(gb["albedo"], F.RGBA8), I(gb["specular"], F.RGBA8)
+    lut = I(brdf_lut_u16, F.RGBA16_sFloat, lut_res, lut_res)
+    smaps = [I(m, F.Depth16, shadow_res, shadow_res) for m in shadow_maps]
+    sm_arr = (orc.OrcImage * 4)(*[m.c for m in smaps])
+    ysh, cocg = I(ysh_u16, F.RGBA16_sFloat), I(cocg_u16, F.RG16_sFloat)
+    fw, fh, fd = froxel_dims
+    vol = I(froxel_u16, F.RGBA16_sFloat, fw, fh, fd)
+    sky = I(sky_packed, F.R11G11B10_uFloat, 200, 100)
+    light = C.create_string_buffer(light_bytes, 20)
+    sinfo = C.create_string_buffer(shadow_info, 304)
+    vset = C.create_string_buffer(vol_settings, 64)
+    g = orc.global_from_bytes(global_packed)
+    L.orc_deferred_shading(color.ref(), depth.ref(), normal.ref(), albedo.ref(), spec.ref(), lut.ref(), light, sinfo, sm_arr, ysh.ref(), cocg.ref(), vol.ref(), vset,
+                           sky.ref(), bindless_arr, C.c_int32(n_bindless), C.byref(g), C.c_int32(diffuse_brdf), C.c_int32(multiscatter), C.c_int32(int(geometric_aa)),
+                           C.c_int32(indirect_tech), C.c_uint32(cascades))
+    return color.arr.view(np.uint32).copy()
