@@ -1,0 +1,95 @@
+// C entry points of the frame pipeline (include/plr_frame.h).
+#include <cstring>
+#include <string>
+
+#include "../../../include/plr_frame.h"
+#include "frame_pipeline.h"
+
+using namespace plrhost;
+
+static thread_local std::string g_ferr;
+static int fail(const std::exception& e) { g_ferr = e.what(); return PLR_ERR_INVALID_ARGUMENT; }
+#define PLRF_TRY(...) try { __VA_ARGS__; return PLR_OK; } catch (const std::exception& e) { return fail(e); }
+
+extern "C" {
+
+const char* plrf_last_error(void) { return g_ferr.c_str(); }
+
+int plrf_default_settings(plrf_settings* o, uint32_t width, uint32_t height) {
+    if (!o) return PLR_ERR_INVALID_ARGUMENT;
+    const FramePipelineSettings d;
+    std::memset(o, 0, sizeof(*o));
+    o->width = width; o->height = height;
+    o->shadow_map_res = d.shadowMapRes; o->brdf_lut_res = d.brdfLutRes; o->max_sdf_instances = d.maxSdfInstances; o->froxel_depth = d.froxelDepth;
+    o->taa_enabled = d.taa.enabled; o->taa_use_clipping = d.taa.useClipping; o->taa_use_motion_vector_dilation = d.taa.useMotionVectorDilation;
+    o->taa_history_sampling_tech = (uint32_t)d.taa.historySamplingTech; o->taa_filter_use_tonemapping = d.taa.filterUseTonemapping;
+    o->bloom_enabled = d.bloom.enabled; o->bloom_strength = d.bloom.strength; o->bloom_radius = d.bloom.radius;
+    o->sdf_half_res_trace = d.sdfTrace.halfResTrace; o->sdf_strict_influence_radius_cutoff = d.sdfTrace.strictInfluenceRadiusCutoff;
+    o->sdf_trace_influence_radius = d.sdfTrace.traceInfluenceRadius;
+    o->diffuse_brdf = (uint32_t)d.shading.diffuseBRDF; o->direct_multiscatter = (uint32_t)d.shading.directMultiscatter;
+    o->indirect_lighting_tech = (uint32_t)d.shading.indirectLightingTech; o->use_geometry_aa = d.shading.useGeometryAA;
+    o->sun_shadow_cascade_count = (uint32_t)d.shading.sunShadowCascadeCount;
+    o->run_exposure = o->run_hiz = o->run_gi = o->run_shading = o->run_taa = o->run_bloom = o->run_tonemap = 1;
+    return PLR_OK;
+}
+
+int plrf_create(const plrf_settings* s, void** out) {
+    if (!s || !out) return PLR_ERR_INVALID_ARGUMENT;
+    PLRF_TRY({
+        FramePipelineSettings f;
+        f.width = s->width; f.height = s->height; f.shadowMapRes = s->shadow_map_res; f.brdfLutRes = s->brdf_lut_res; f.maxSdfInstances = s->max_sdf_instances;
+        f.froxelDepth = s->froxel_depth;
+        f.taa.enabled = s->taa_enabled; f.taa.useClipping = s->taa_use_clipping; f.taa.useMotionVectorDilation = s->taa_use_motion_vector_dilation;
+        f.taa.historySamplingTech = (HistorySamplingTech)s->taa_history_sampling_tech; f.taa.filterUseTonemapping = s->taa_filter_use_tonemapping;
+        f.bloom.enabled = s->bloom_enabled; f.bloom.strength = s->bloom_strength; f.bloom.radius = s->bloom_radius;
+        f.sdfTrace.halfResTrace = s->sdf_half_res_trace; f.sdfTrace.strictInfluenceRadiusCutoff = s->sdf_strict_influence_radius_cutoff;
+        f.sdfTrace.traceInfluenceRadius = s->sdf_trace_influence_radius;
+        f.shading.diffuseBRDF = (DiffuseBRDF)s->diffuse_brdf; f.shading.directMultiscatter = (DirectSpecularMultiscattering)s->direct_multiscatter;
+        f.shading.indirectLightingTech = (IndirectLightingTech)s->indirect_lighting_tech; f.shading.useGeometryAA = s->use_geometry_aa;
+        f.shading.sunShadowCascadeCount = (int)s->sun_shadow_cascade_count;
+        f.runExposure = s->run_exposure; f.runHiZ = s->run_hiz; f.runGI = s->run_gi; f.runShading = s->run_shading; f.runTAA = s->run_taa;
+        f.runBloom = s->run_bloom; f.runTonemap = s->run_tonemap;
+        *out = new FramePipeline(f);
+    })
+}
+
+int plrf_destroy(void* p) { delete (FramePipeline*)p; return PLR_OK; }
+
+int plrf_get_image(void* p, const char* name, plr_image_handle* out) {
+    const ImageHandle h = ((FramePipeline*)p)->image(name);
+    if (h.index == invalidIndex) { g_ferr = std::string("unknown image '") + name + "'"; return PLR_ERR_INVALID_ARGUMENT; }
+    *out = RenderBackend::toC(h);
+    return PLR_OK;
+}
+int plrf_get_storage_buffer(void* p, const char* name, plr_storage_buffer_handle* out) {
+    StorageBufferHandle h;
+    if (!((FramePipeline*)p)->storageBuffer(name, &h)) { g_ferr = std::string("unknown storage buffer '") + name + "'"; return PLR_ERR_INVALID_ARGUMENT; }
+    *out = h.index;
+    return PLR_OK;
+}
+int plrf_get_uniform_buffer(void* p, const char* name, plr_uniform_buffer_handle* out) {
+    UniformBufferHandle h;
+    if (!((FramePipeline*)p)->uniformBuffer(name, &h)) { g_ferr = std::string("unknown uniform buffer '") + name + "'"; return PLR_ERR_INVALID_ARGUMENT; }
+    *out = h.index;
+    return PLR_OK;
+}
+int plrf_add_sdf_volume(void* p, uint32_t res, const void* data, size_t bytes, uint32_t* out) { PLRF_TRY(*out = ((FramePipeline*)p)->addSdfVolume(res, data, bytes)) }
+int plrf_set_sdf_scene(void* p, const void* inst, size_t ib, const void* bb, size_t bbb) { PLRF_TRY(((FramePipeline*)p)->setSdfScene(inst, ib, bb, bbb)) }
+int plrf_set_sun_direction(void* p, const float d[3]) { PLRF_TRY(((FramePipeline*)p)->setSunDirection(d)) }
+int plrf_set_camera_intrinsic(void* p, float fov, float n, float f) { PLRF_TRY(((FramePipeline*)p)->setCameraIntrinsic(fov, n, f)) }
+int plrf_set_camera_cut(void* p) { PLRF_TRY(((FramePipeline*)p)->setCameraCut()) }
+int plrf_frame(void* p, const plrf_camera* c, float dt, float time) {
+    PLRF_TRY({
+        CameraExtrinsic e;
+        e.position = {c->position[0], c->position[1], c->position[2]};
+        e.forward = {c->forward[0], c->forward[1], c->forward[2]};
+        e.up = {c->up[0], c->up[1], c->up[2]};
+        e.right = {c->right[0], c->right[1], c->right[2]};
+        ((FramePipeline*)p)->frame(e, dt, time);
+    })
+}
+int plrf_get_submitted_globals(void* p, void* out) { std::memcpy(out, &((FramePipeline*)p)->lastSubmittedGlobals(), 340); return PLR_OK; }
+int plrf_get_resolve_weights(void* p, float* out) { std::memcpy(out, ((FramePipeline*)p)->lastResolveWeights(), 36); return PLR_OK; }
+int plrf_get_cpu_frame_index(void* p, uint64_t* out) { *out = ((FramePipeline*)p)->cpuFrameIndex(); return PLR_OK; }
+
+} // extern "C"

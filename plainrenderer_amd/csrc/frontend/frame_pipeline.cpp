@@ -1,0 +1,837 @@
+// See frame_pipeline.h. Pass order, bindings, specialisation constants and dispatch counts follow the cited reference code.
+#include "frame_pipeline.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace plrhost {
+
+// ------------------------------------------------------------------ small math (the reference uses glm)
+static Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static Vec3 operator*(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+static Vec3 normalize(Vec3 a) { const float l = std::sqrt(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+static Mat4 mul(const Mat4& a, const Mat4& b) {
+    Mat4 r{};
+    for (int c = 0; c < 4; c++)
+        for (int row = 0; row < 4; row++) {
+            float s = 0.f;
+            for (int k = 0; k < 4; k++) s += a.m[k * 4 + row] * b.m[c * 4 + k];
+            r.m[c * 4 + row] = s;
+        }
+    return r;
+}
+static Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f; return r; }
+
+// Camera.cpp:4-12
+static Mat4 viewMatrixFromCameraExtrinsic(const CameraExtrinsic& e) {
+    Mat4 rot = identity(); // rows = right, up, -forward
+    rot.m[0] = e.right.x; rot.m[4] = e.right.y; rot.m[8] = e.right.z;
+    rot.m[1] = e.up.x; rot.m[5] = e.up.y; rot.m[9] = e.up.z;
+    rot.m[2] = -e.forward.x; rot.m[6] = -e.forward.y; rot.m[10] = -e.forward.z;
+    Mat4 t = identity();
+    t.m[12] = -e.position.x; t.m[13] = -e.position.y; t.m[14] = -e.position.z;
+    return mul(rot, t);
+}
+// Camera.cpp:14-27: glm::perspective (RH, -1..1) then the Vulkan Y flip / reverse-Z correction
+static Mat4 projectionMatrixFromCameraIntrinsic(const CameraIntrinsic& in) {
+    const float f = 1.f / std::tan(in.fov * 3.14159265358979f / 180.f * 0.5f);
+    Mat4 p{};
+    p.m[0] = f / in.aspectRatio;
+    p.m[5] = f;
+    p.m[10] = -(in.far + in.near) / (in.far - in.near);
+    p.m[11] = -1.f;
+    p.m[14] = -(2.f * in.far * in.near) / (in.far - in.near);
+    Mat4 corr{};
+    corr.m[0] = 1.f; corr.m[5] = -1.f; corr.m[10] = -0.5f; corr.m[14] = 0.5f; corr.m[15] = 1.f;
+    return mul(corr, p);
+}
+
+// Common/Utilities/MathUtils.cpp:17-23
+static uint32_t mipCountFromResolution(uint32_t w, uint32_t h, uint32_t d) { return 1 + (uint32_t)std::floor(std::log2((float)std::max(std::max(w, h), d))); }
+static void resolutionFromMip(int w, int h, int mip, int* ow, int* oh) { *ow = std::max(w / (1 << mip), 1); *oh = std::max(h / (1 << mip), 1); }
+// MathUtils.cpp:25-60
+static float radicalInverseBase2(uint32_t in) {
+    uint32_t out = (in << 16) | (in >> 16);
+    out = ((out & 0x00ff00ff) << 8) | ((out & 0xff00ff00) >> 8);
+    out = ((out & 0x0f0f0f0f) << 4) | ((out & 0xf0f0f0f0) >> 4);
+    out = ((out & 0x33333333) << 2) | ((out & 0xcccccccc) >> 2);
+    out = ((out & 0x55555555) << 1) | ((out & 0xaaaaaaaa) >> 1);
+    return float(out) * (float)2.3283064365386963e-10;
+}
+static float radicalInverseBase3(uint32_t in) {
+    const uint32_t base = 3;
+    const float inverseBase = 1.f / (float)base;
+    uint32_t reversedDigits = 0, current = in;
+    float inverseBasePowerN = 1;
+    while (current) {
+        const uint32_t next = current / base;
+        const uint32_t digit = current - next * base;
+        reversedDigits = reversedDigits * base + digit;
+        inverseBasePowerN *= inverseBase;
+        current = next;
+    }
+    return reversedDigits * inverseBasePowerN;
+}
+
+template <class T> static SpecialisationConstant spec(uint32_t location, const T& v) { return {location, dataToCharArray(&v, sizeof(T))}; }
+
+static ImageDescription desc2D(uint32_t w, uint32_t h, ImageFormat f, ImageUsageFlags usage = ImageUsageFlags::Storage | ImageUsageFlags::Sampled,
+                               MipCount mips = MipCount::One, uint32_t manual = 1) {
+    ImageDescription d;
+    d.width = w; d.height = h; d.depth = 1; d.type = ImageType::Type2D; d.format = f; d.usageFlags = usage; d.mipCount = mips; d.manualMipCount = manual;
+    return d;
+}
+static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h) {
+    exe.dispatchCount[0] = (uint32_t)std::ceil(w / 8.f);
+    exe.dispatchCount[1] = (uint32_t)std::ceil(h / 8.f);
+    exe.dispatchCount[2] = 1;
+}
+
+// ------------------------------------------------------------------ TAA (Techniques/TAA.cpp)
+static ShaderDescription temporalFilterShaderDescription(const TAASettings& s) { // TAA.cpp:204-233
+    ShaderDescription d;
+    d.srcPathRelative = "temporalFilter.comp";
+    d.specialisationConstants = {spec(0, s.useClipping), spec(1, s.useMotionVectorDilation), spec(2, s.historySamplingTech), spec(3, s.filterUseTonemapping)};
+    return d;
+}
+void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { // TAA.cpp:7-67
+    ComputePassDescription d;
+    d.name = "Temporal filtering";
+    d.shaderDescription = temporalFilterShaderDescription(settings);
+    m_temporalFilterPass = be.createComputePass(d);
+    for (int i = 0; i < 2; i++) m_historyBuffers[i] = be.createImage(desc2D(w, h, ImageFormat::R11G11B10_uFloat), nullptr, 0);
+    UniformBufferDescription ub;
+    ub.size = sizeof(float) * 9;
+    m_taaResolveWeightBuffer = be.createUniformBuffer(ub);
+}
+void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target) const {
+    // TAA.cpp:139-166
+    const size_t frameIndexMod2 = fi.mod2();
+    const ImageHandle historySrc = m_historyBuffers[frameIndexMod2];
+    const ImageHandle historyDst = m_historyBuffers[(frameIndexMod2 + 1) % 2];
+    const ImageDescription td = be.getImageDescription(target);
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_temporalFilterPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(target, 0, 1), ImageResource(historyDst, 0, 2)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(colorSrc, 0, 0), ImageResource(historySrc, 0, 3), ImageResource(currentFrame.motionBuffer, 0, 4),
+                                               ImageResource(currentFrame.depthBuffer, 0, 5)};
+    exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_taaResolveWeightBuffer, 6)};
+    dispatch8(exe, td.width, td.height);
+    be.setComputePassExecution(exe);
+}
+void TAA::jitterInPixels(const FrameIndexCounter& fi, float out[2]) const { // TAA.cpp:168-170
+    const uint32_t i = (uint32_t)fi.mod8();
+    out[0] = 2.f * radicalInverseBase2(i) - 1.f;
+    out[1] = 2.f * radicalInverseBase3(i) - 1.f;
+}
+void TAA::updateTaaResolveWeights(RenderBackend& be, const float j[2]) { // TAA.cpp:181-202
+    std::array<float, 9> weights = {};
+    int index = 0;
+    float totalWeight = 0.f;
+    for (int y = -1; y <= 1; y++)
+        for (int x = -1; x <= 1; x++) {
+            const float dx = j[0] - (float)x, dy = j[1] - (float)y;
+            const float d = std::sqrt(dx * dx + dy * dy);
+            const float w = std::exp(-2.29f * d * d);
+            weights[index++] = w;
+            totalWeight += w;
+        }
+    for (float& w : weights) w /= totalWeight;
+    be.setUniformBufferData(m_taaResolveWeightBuffer, &weights[0], sizeof(float) * 9);
+}
+
+// ------------------------------------------------------------------ Bloom (Techniques/Bloom.cpp)
+static const int bloomMipCount = 6; // Bloom.cpp:6
+void Bloom::init(RenderBackend& be) { // Bloom.cpp:8-40
+    for (int i = 0; i < bloomMipCount - 1; i++) {
+        ComputePassDescription d;
+        d.name = "Bloom downsample mip " + std::to_string(i + 1);
+        d.shaderDescription.srcPathRelative = "bloomDownsample.comp";
+        m_bloomDownsamplePasses.push_back(be.createComputePass(d));
+    }
+    for (int i = 0; i < bloomMipCount - 1; i++) {
+        ComputePassDescription d;
+        d.name = "Bloom Upsample mip " + std::to_string(bloomMipCount - 2 - i);
+        d.shaderDescription.srcPathRelative = "bloomUpsample.comp";
+        const bool isLowestMip = i == 0;
+        d.shaderDescription.specialisationConstants = {spec(0, isLowestMip)};
+        m_bloomUpsamplePasses.push_back(be.createComputePass(d));
+    }
+    ComputePassDescription d;
+    d.name = "Apply bloom";
+    d.shaderDescription.srcPathRelative = "applyBloom.comp";
+    m_applyBloomPass = be.createComputePass(d);
+}
+void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings) const { // Bloom.cpp:56-143
+    const ImageDescription td = be.getImageDescription(targetImage);
+    const int width = (int)td.width, height = (int)td.height;
+    const ImageDescription desc = desc2D(width, height, ImageFormat::R11G11B10_uFloat, ImageUsageFlags::Sampled | ImageUsageFlags::Storage, MipCount::Manual, bloomMipCount);
+    const ImageHandle downscaleTexture = be.createTemporaryImage(desc);
+    for (int i = 0; i < (int)m_bloomDownsamplePasses.size(); i++) {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_bloomDownsamplePasses[i];
+        const int sourceMip = i, targetMip = i + 1;
+        exe.genericInfo.resources.storageImages = {ImageResource(downscaleTexture, targetMip, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(i == 0 ? targetImage : downscaleTexture, sourceMip, 1)};
+        int tw, th;
+        resolutionFromMip(width, height, targetMip, &tw, &th);
+        dispatch8(exe, tw, th);
+        be.setComputePassExecution(exe);
+    }
+    const ImageHandle upscaleTexture = be.createTemporaryImage(desc);
+    for (int i = 0; i < (int)m_bloomUpsamplePasses.size(); i++) {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_bloomUpsamplePasses[i];
+        const int targetMip = bloomMipCount - 2 - i, sourceMip = targetMip + 1;
+        exe.genericInfo.resources.storageImages = {ImageResource(upscaleTexture, targetMip, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, sourceMip, 1), ImageResource(downscaleTexture, sourceMip, 2)};
+        int tw, th;
+        resolutionFromMip(width, height, targetMip, &tw, &th);
+        dispatch8(exe, tw, th);
+        exe.pushConstants = dataToCharArray(&settings.radius, sizeof(settings.radius));
+        be.setComputePassExecution(exe);
+    }
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_applyBloomPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(targetImage, 0, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, 0, 1)};
+    dispatch8(exe, width, height);
+    exe.pushConstants = dataToCharArray(&settings.strength, sizeof(settings.strength));
+    be.setComputePassExecution(exe);
+}
+
+// ------------------------------------------------------------------ SDFGI (Techniques/SDFGI.cpp)
+static const size_t sdfCameraCullingTileSize = 32; // SDFGI.cpp:10
+static const size_t maxSdfObjectsPerTile = 100;    // SDFGI.cpp:11
+static const size_t sdfInstanceSize = 96;          // sizeof(SDFInstance), SDFGI.h:31-37
+
+void SDFGI::init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& ts, int sunShadowCascadeIndex, uint32_t maxInstances) { // SDFGI.cpp:48-258
+    const uint32_t tw = ts.halfResTrace ? screenW / 2 : screenW, th = ts.halfResTrace ? screenH / 2 : screenH;
+    for (int i = 0; i < 2; i++) {
+        m_indirectDiffuse_Y_SH[i] = be.createImage(desc2D(tw, th, ImageFormat::RGBA16_sFloat), nullptr, 0);
+        m_indirectDiffuse_CoCg[i] = be.createImage(desc2D(tw, th, ImageFormat::RG16_sFloat), nullptr, 0);
+        m_indirectDiffuseHistory_Y_SH[i] = be.createImage(desc2D(tw, th, ImageFormat::RGBA16_sFloat), nullptr, 0);
+        m_indirectDiffuseHistory_CoCg[i] = be.createImage(desc2D(tw, th, ImageFormat::RG16_sFloat), nullptr, 0);
+    }
+    m_indirectLightingFullRes_Y_SH = be.createImage(desc2D(screenW, screenH, ImageFormat::RGBA16_sFloat), nullptr, 0);
+    m_indirectLightingFullRes_CoCg = be.createImage(desc2D(screenW, screenH, ImageFormat::RG16_sFloat), nullptr, 0);
+    StorageBufferDescription sb;
+    sb.size = maxInstances * sdfInstanceSize + sizeof(uint32_t) * 4;
+    m_sdfInstanceBuffer = be.createStorageBuffer(sb);
+    sb.size = maxInstances * sizeof(uint32_t) + sizeof(uint32_t);
+    m_sdfCameraFrustumCulledInstances = be.createStorageBuffer(sb);
+    UniformBufferDescription ub;
+    ub.size = 12 * 4 * sizeof(float);
+    m_cameraFrustumBuffer = be.createUniformBuffer(ub);
+    sb.size = maxInstances * 2 * 4 * sizeof(float);
+    m_sdfInstanceWorldBBBuffer = be.createStorageBuffer(sb);
+    {
+        // the reference sizes this for 1920x1080 only (SDFGI.cpp:145-151); sized here for the tile-index range the shaders
+        // produce: stride = ceil(screenW / 32) (full-res, sdfCulling.inc:17-20) times the trace image's tile rows
+        const size_t strideX = (size_t)std::ceil(screenW / float(sdfCameraCullingTileSize));
+        const size_t rows = (size_t)std::ceil(th / float(sdfCameraCullingTileSize));
+        const size_t tileSize = maxSdfObjectsPerTile * sizeof(uint32_t) + sizeof(uint32_t);
+        sb.size = strideX * std::max<size_t>(rows, 1) * tileSize;
+        m_sdfCameraCulledTiles = be.createStorageBuffer(sb);
+    }
+    ub.size = sizeof(float);
+    m_sdfTraceInfluenceRangeBuffer = be.createUniformBuffer(ub);
+    {
+        ComputePassDescription d;
+        d.name = "Indirect diffuse SDF trace";
+        d.shaderDescription.srcPathRelative = "sdfDiffuseTrace.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, ts.strictInfluenceRadiusCutoff), spec(1, sunShadowCascadeIndex)};
+        m_diffuseSDFTracePass = be.createComputePass(d);
+    }
+    for (int i = 0; i < 2; i++) {
+        ComputePassDescription d;
+        d.name = "Indirect diffuse spatial filter";
+        d.shaderDescription.srcPathRelative = "filterIndirectDiffuseSpatial.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, i)};
+        m_indirectDiffuseFilterSpatialPass[i] = be.createComputePass(d);
+    }
+    {
+        ComputePassDescription d;
+        d.name = "Indirect diffuse temporal filter";
+        d.shaderDescription.srcPathRelative = "filterIndirectDiffuseTemporal.comp";
+        m_indirectDiffuseFilterTemporalPass = be.createComputePass(d);
+        d.name = "Indirect lighting upscale";
+        d.shaderDescription.srcPathRelative = "indirectLightUpscale.comp";
+        m_indirectLightingUpscale = be.createComputePass(d);
+        d.name = "SDF camera frustum culling";
+        d.shaderDescription.srcPathRelative = "sdfCameraFrustumCulling.comp";
+        m_sdfCameraFrustumCulling = be.createComputePass(d);
+    }
+    for (int hiz = 0; hiz < 2; hiz++) {
+        ComputePassDescription d;
+        d.name = "SDF camera tile culling";
+        d.shaderDescription.srcPathRelative = "sdfCameraTileCulling.comp";
+        const bool useHiZ = hiz == 1;
+        d.shaderDescription.specialisationConstants = {spec(0, useHiZ)};
+        (useHiZ ? m_sdfCameraTileCullingHiZ : m_sdfCameraTileCulling) = be.createComputePass(d);
+    }
+}
+
+void SDFGI::updateSDFScene(RenderBackend& be, const void* instanceData, size_t instanceBytes, const void* bbData, size_t bbBytes) { // SDFGI.cpp:260-313
+    if (instanceBytes >= 4) std::memcpy(&m_sdfInstanceCount, instanceData, 4);
+    be.setStorageBufferData(m_sdfInstanceBuffer, instanceData, instanceBytes);
+    be.setStorageBufferData(m_sdfInstanceWorldBBBuffer, bbData, bbBytes);
+}
+
+SDFGI::IndirectLightingImages SDFGI::getIndirectLightingResults(bool tracedHalfRes) const { // SDFGI.cpp:315-326
+    if (tracedHalfRes) return {m_indirectLightingFullRes_Y_SH, m_indirectLightingFullRes_CoCg};
+    return {m_indirectDiffuseHistory_Y_SH[0], m_indirectDiffuseHistory_CoCg[0]};
+}
+
+void SDFGI::computeIndirectLighting(RenderBackend& be, const FrameIndexCounter&, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const {
+    diffuseSDFTrace(be, deps, s);
+    filterIndirectDiffuse(be, deps, s);
+}
+
+void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling) const {
+    // SDFGI.cpp:538-630
+    {
+        struct GPUFrustumData { float points[6][4]; float normal[6][4]; } frustumData;
+        std::memcpy(frustumData.points, deps.frustumPoints, sizeof(frustumData.points));
+        std::memcpy(frustumData.normal, deps.frustumNormals, sizeof(frustumData.normal));
+        be.setUniformBufferData(m_cameraFrustumBuffer, &frustumData, sizeof(frustumData));
+        uint32_t zero = 0;
+        be.setStorageBufferData(m_sdfCameraFrustumCulledInstances, &zero, sizeof(zero));
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_sdfCameraFrustumCulling;
+        exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sdfInstanceBuffer, true, 0), StorageBufferResource(m_sdfCameraFrustumCulledInstances, false, 2),
+                                                    StorageBufferResource(m_sdfInstanceWorldBBBuffer, true, 3)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_cameraFrustumBuffer, 1), UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 4)};
+        exe.dispatchCount[0] = uint32_t(std::ceil(m_sdfInstanceCount / 64.f));
+        exe.dispatchCount[1] = 1;
+        exe.dispatchCount[2] = 1;
+        be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = hiZCulling ? m_sdfCameraTileCullingHiZ : m_sdfCameraTileCulling;
+        const uint32_t tileCount[2] = {(uint32_t)std::ceil(targetW / float(sdfCameraCullingTileSize)), (uint32_t)std::ceil(targetH / float(sdfCameraCullingTileSize))};
+        const uint32_t localGroupSize = 8;
+        exe.dispatchCount[0] = uint32_t(std::ceil(tileCount[0] / float(localGroupSize)));
+        exe.dispatchCount[1] = uint32_t(std::ceil(tileCount[1] / float(localGroupSize)));
+        exe.dispatchCount[2] = 1;
+        exe.pushConstants = dataToCharArray(&tileCount, sizeof(tileCount));
+        exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sdfCameraFrustumCulledInstances, true, 0), StorageBufferResource(m_sdfInstanceWorldBBBuffer, true, 1),
+                                                    StorageBufferResource(m_sdfCameraCulledTiles, false, 2)};
+        be.setUniformBufferData(m_sdfTraceInfluenceRangeBuffer, &influenceRadius, sizeof(influenceRadius));
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 3)};
+        const int depthPyramidMipLevel = (int)std::log2(std::ceil(float(sdfCameraCullingTileSize))) - 1; // = 4
+        exe.genericInfo.resources.sampledImages = {ImageResource(deps.depthMinMaxPyramid, depthPyramidMipLevel, 4)};
+        be.setComputePassExecution(exe);
+    }
+}
+
+void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const { // SDFGI.cpp:380-419
+    const ImageDescription td = be.getImageDescription(m_indirectDiffuse_CoCg[0]);
+    sdfInstanceCulling(be, deps, td.width, td.height, s.traceInfluenceRadius, true);
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_diffuseSDFTracePass;
+    exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuse_CoCg[0], 0, 1)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(deps.currentFrame.depthBuffer, 0, 2), ImageResource(deps.worldSpaceNormals, 0, 3), ImageResource(deps.skyLut, 0, 4),
+                                               ImageResource(deps.shadowMap, 0, 10)};
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
+                                                StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
+    exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
+    dispatch8(exe, td.width, td.height);
+    be.setComputePassExecution(exe);
+}
+
+void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const { // SDFGI.cpp:421-536
+    const ImageHandle depthSrc = s.halfResTrace ? deps.depthHalfRes : deps.currentFrame.depthBuffer;
+    const ImageDescription td = be.getImageDescription(m_indirectDiffuse_Y_SH[1]);
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[0];
+        exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 0), ImageResource(m_indirectDiffuse_CoCg[1], 0, 1)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuse_CoCg[0], 0, 3), ImageResource(depthSrc, 0, 4),
+                                                   ImageResource(deps.worldSpaceNormals, 0, 5)};
+        dispatch8(exe, td.width, td.height);
+        be.setComputePassExecution(exe);
+    }
+    {
+        // always History[0] -> History[1]; the reference computes historySrc/DstIndex but never uses them (SDFGI.cpp:457-458)
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_indirectDiffuseFilterTemporalPass;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuse_CoCg[0], 0, 1),
+                                                   ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
+                                                   ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
+                                                   ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
+        dispatch8(exe, td.width, td.height);
+        be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[1];
+        exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 1)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
+                                                   ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
+        dispatch8(exe, td.width, td.height);
+        be.setComputePassExecution(exe);
+    }
+    if (s.halfResTrace) {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_indirectLightingUpscale;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_indirectLightingFullRes_Y_SH, 0, 0), ImageResource(m_indirectLightingFullRes_CoCg, 0, 1)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 3),
+                                                   ImageResource(deps.currentFrame.depthBuffer, 0, 4), ImageResource(deps.depthHalfRes, 0, 5)};
+        const ImageDescription fd = be.getImageDescription(m_indirectLightingFullRes_Y_SH);
+        dispatch8(exe, fd.width, fd.height);
+        be.setComputePassExecution(exe);
+    }
+}
+
+// ------------------------------------------------------------------ FramePipeline (RenderFrontend.cpp)
+static const uint32_t nHistogramBins = 128;       // RenderFrontend.cpp:46
+static const uint32_t histogramTileSizeX = 32, histogramTileSizeY = 32;
+static const float histogramMinValue = 0.001f, histogramMaxValue = 200000.f; // RenderFrontend.cpp:1066-1067
+static const uint32_t noiseTextureWidth = 32, noiseTextureHeight = 32;       // RenderFrontend.cpp:52-54
+static const int maxSunShadowCascadeCount = 4;
+
+// RenderFrontend::computeSinglePassMipChainDispatchCount, RenderFrontend.cpp:1807-1827
+static void singlePassMipChainDispatchCount(uint32_t width, uint32_t height, uint32_t mipCount, uint32_t maxMipCount, uint32_t out[2]) {
+    const uint32_t unusedMips = maxMipCount - mipCount;
+    if (unusedMips >= 6) { out[0] = out[1] = 1; return; }
+    const uint32_t localThreadGroupExtent = 32 / (uint32_t)std::pow((uint32_t)2, unusedMips);
+    out[0] = (uint32_t)std::ceil(float(width) / localThreadGroupExtent);
+    out[1] = (uint32_t)std::ceil(float(height) / localThreadGroupExtent);
+}
+
+FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
+    const uint32_t W = s.width, H = s.height;
+    // the backend is set up by the caller (plr_setup), like gRenderBackend.setup in the reference's main(); match the swapchain
+    const ImageDescription sw = m_be.getImageDescription(m_be.getSwapchainInputImage());
+    if (sw.width != W || sw.height != H) m_be.recreateSwapchain(W, H);
+    m_cameraIntrinsic.aspectRatio = (float)W / (float)H;
+
+    // ---- initBuffers (RenderFrontend.cpp:1449-1500)
+    StorageBufferDescription sb;
+    sb.size = nHistogramBins * sizeof(uint32_t);
+    m_histogramBuffer = m_be.createStorageBuffer(sb);
+    float lightInit[5] = {0, 0, 0, 0, 0};
+    sb.size = sizeof(lightInit); sb.initialData = lightInit;
+    m_lightBuffer = m_be.createStorageBuffer(sb);
+    sb.initialData = nullptr;
+    const uint32_t tileCount = (uint32_t)std::ceil(W / float(histogramTileSizeX)) * (uint32_t)std::ceil(H / float(histogramTileSizeY));
+    sb.size = (size_t)tileCount * nHistogramBins * sizeof(uint32_t); // the reference allocates for 1920x1080 only (:1069-1070)
+    m_histogramPerTileBuffer = m_be.createStorageBuffer(sb);
+    sb.size = sizeof(uint32_t);
+    m_depthPyramidSyncBuffer = m_be.createStorageBuffer(sb);
+    sb.size = 16 + 64 * maxSunShadowCascadeCount + 8 * maxSunShadowCascadeCount;
+    m_sunShadowInfoBuffer = m_be.createStorageBuffer(sb);
+    UniformBufferDescription ub;
+    ub.size = sizeof(GlobalShaderInfo);
+    m_globalUniformBuffer = m_be.createUniformBuffer(ub);
+    ub.size = 64;
+    m_volumetricsInfoBuffer = m_be.createUniformBuffer(ub);
+    RenderPassResources globalResources;
+    globalResources.uniformBuffers = {UniformBufferResource(m_globalUniformBuffer, 0)};
+    m_be.setGlobalDescriptorSetResources(globalResources);
+
+    // ---- initImages (RenderFrontend.cpp:1186-1447): G-buffer + colour targets, two sets
+    for (int i = 0; i < 2; i++) {
+        m_postProcessBuffers[i] = m_be.createImage(desc2D(W, H, ImageFormat::R11G11B10_uFloat), nullptr, 0);
+        m_frameRenderTargets[i].colorBuffer = m_be.createImage(desc2D(W, H, ImageFormat::R11G11B10_uFloat), nullptr, 0);
+        m_frameRenderTargets[i].motionBuffer = m_be.createImage(desc2D(W, H, ImageFormat::RG16_sNorm), nullptr, 0);
+        m_frameRenderTargets[i].depthBuffer = m_be.createImage(desc2D(W, H, ImageFormat::Depth32), nullptr, 0);
+    }
+    m_worldSpaceNormalImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
+    m_albedoImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
+    m_specularImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
+    m_minMaxDepthPyramid = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::FullChain), nullptr, 0);
+    m_depthHalfRes = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::R16_sFloat), nullptr, 0);
+    m_brdfLut = m_be.createImage(desc2D(s.brdfLutRes, s.brdfLutRes, ImageFormat::RGBA16_sFloat), nullptr, 0);
+    m_skyLut = m_be.createImage(desc2D(200, 100, ImageFormat::R11G11B10_uFloat), nullptr, 0);          // Sky.cpp sky LUT
+    m_transmissionLut = m_be.createImage(desc2D(128, 128, ImageFormat::R11G11B10_uFloat), nullptr, 0); // Sky.cpp transmission LUT
+    {
+        ImageDescription d; // Volumetrics.cpp:8-16
+        d.width = (uint32_t)std::ceil(W / 8.f); d.height = (uint32_t)std::ceil(H / 8.f); d.depth = s.froxelDepth;
+        d.type = ImageType::Type3D; d.format = ImageFormat::RGBA16_sFloat; d.usageFlags = ImageUsageFlags::Storage | ImageUsageFlags::Sampled;
+        m_volumetricIntegrationVolume = m_be.createImage(d, nullptr, 0);
+    }
+    for (int i = 0; i < maxSunShadowCascadeCount; i++)
+        m_shadowMaps[i] = m_be.createImage(desc2D(s.shadowMapRes, s.shadowMapRes, ImageFormat::Depth16, ImageUsageFlags::Sampled), nullptr, 0);
+    for (int i = 0; i < 4; i++) {
+        m_noiseTextures[i] = m_be.createImage(desc2D(noiseTextureWidth, noiseTextureHeight, ImageFormat::RG8, ImageUsageFlags::Sampled), nullptr, 0);
+        m_globalShaderInfo.noiseTextureIndices[i] = (int32_t)m_be.getImageGlobalTextureArrayIndex(m_noiseTextures[i]);
+    }
+
+    // ---- initRenderpasses (RenderFrontend.cpp:1618-1760)
+    {
+        ComputePassDescription d;
+        const int nTiles = (int)tileCount;
+        d.name = "Histogram per tile";
+        d.shaderDescription.srcPathRelative = "histogramPerTile.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, nHistogramBins), spec(1, histogramMinValue), spec(2, histogramMaxValue), spec(3, nTiles)};
+        m_histogramPerTilePass = m_be.createComputePass(d);
+        d.name = "Histogram reset";
+        d.shaderDescription.srcPathRelative = "histogramReset.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, nHistogramBins)};
+        m_histogramResetPass = m_be.createComputePass(d);
+        d.name = "Histogram combine tiles";
+        d.shaderDescription.srcPathRelative = "histogramCombineTiles.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, nHistogramBins), spec(1, nTiles)};
+        m_histogramCombinePass = m_be.createComputePass(d);
+        d.name = "Pre-expose lights";
+        d.shaderDescription.srcPathRelative = "preExposeLights.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, (int)nHistogramBins), spec(1, histogramMinValue), spec(2, histogramMaxValue)};
+        m_preExposeLightsPass = m_be.createComputePass(d);
+        d.name = "Tonemap";
+        d.shaderDescription.srcPathRelative = "tonemapping.comp";
+        d.shaderDescription.specialisationConstants = {};
+        m_tonemappingPass = m_be.createComputePass(d);
+        d.name = "Depth downscale";
+        d.shaderDescription.srcPathRelative = "depthDownscale.comp";
+        m_depthDownscalePass = m_be.createComputePass(d);
+        d.name = "BRDF Lut creation";
+        d.shaderDescription.srcPathRelative = "brdfLut.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, s.shading.diffuseBRDF)};
+        m_brdfLutPass = m_be.createComputePass(d);
+    }
+    {
+        // createDepthPyramidShaderDescription, RenderFrontend.cpp:1770-1805
+        ComputePassDescription d;
+        d.name = "Depth min/max pyramid";
+        d.shaderDescription.srcPathRelative = "depthHiZPyramid.comp";
+        const uint32_t pw = W / 2, ph = H / 2;
+        const uint32_t depthMipCount = mipCountFromResolution(pw, ph, 1);
+        uint32_t dc[2];
+        singlePassMipChainDispatchCount(pw, ph, depthMipCount, 11, dc);
+        m_depthPyramidThreadgroupCount = dc[0] * dc[1];
+        d.shaderDescription.specialisationConstants = {spec(0, depthMipCount), spec(1, W), spec(2, H), spec(3, m_depthPyramidThreadgroupCount)};
+        m_depthPyramidPass = m_be.createComputePass(d);
+    }
+    {
+        // createForwardPassShaderDescription, RenderFrontend.cpp:1093-1131, as the deferred compute pass
+        ComputePassDescription d;
+        d.name = "Forward shading (deferred)";
+        d.shaderDescription.srcPathRelative = "deferredShading.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, s.shading.diffuseBRDF), spec(1, s.shading.directMultiscatter), spec(2, s.shading.useGeometryAA),
+                                                       spec(3, s.shading.indirectLightingTech), spec(4, s.shading.sunShadowCascadeCount)};
+        m_deferredShadingPass = m_be.createComputePass(d);
+    }
+    m_taa.init(m_be, W, H, s.taa);
+    m_bloom.init(m_be);
+    m_sdfGi.init(m_be, W, H, s.sdfTrace, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
+    const float influence = s.sdfTrace.traceInfluenceRadius;
+    (void)influence;
+}
+
+ImageHandle FramePipeline::image(const std::string& n) const {
+    if (n == "color0") return m_frameRenderTargets[0].colorBuffer;
+    if (n == "color1") return m_frameRenderTargets[1].colorBuffer;
+    if (n == "motion0") return m_frameRenderTargets[0].motionBuffer;
+    if (n == "motion1") return m_frameRenderTargets[1].motionBuffer;
+    if (n == "depth0") return m_frameRenderTargets[0].depthBuffer;
+    if (n == "depth1") return m_frameRenderTargets[1].depthBuffer;
+    if (n == "post0") return m_postProcessBuffers[0];
+    if (n == "post1") return m_postProcessBuffers[1];
+    if (n == "normal") return m_worldSpaceNormalImage;
+    if (n == "albedo") return m_albedoImage;
+    if (n == "specular") return m_specularImage;
+    if (n == "pyramid") return m_minMaxDepthPyramid;
+    if (n == "depthHalfRes") return m_depthHalfRes;
+    if (n == "brdfLut") return m_brdfLut;
+    if (n == "skyLut") return m_skyLut;
+    if (n == "transmissionLut") return m_transmissionLut;
+    if (n == "volumetricIntegrationVolume") return m_volumetricIntegrationVolume;
+    if (n.size() == 7 && n.compare(0, 6, "shadow") == 0) return m_shadowMaps[(n[6] - '0') & 3];
+    if (n.size() == 6 && n.compare(0, 5, "noise") == 0) return m_noiseTextures[(n[5] - '0') & 3];
+    if (n == "taaHistory0") return m_taa.m_historyBuffers[0];
+    if (n == "taaHistory1") return m_taa.m_historyBuffers[1];
+    if (n == "giYSH0") return m_sdfGi.m_indirectDiffuse_Y_SH[0];
+    if (n == "giYSH1") return m_sdfGi.m_indirectDiffuse_Y_SH[1];
+    if (n == "giCoCg0") return m_sdfGi.m_indirectDiffuse_CoCg[0];
+    if (n == "giCoCg1") return m_sdfGi.m_indirectDiffuse_CoCg[1];
+    if (n == "giHistoryYSH0") return m_sdfGi.m_indirectDiffuseHistory_Y_SH[0];
+    if (n == "giHistoryYSH1") return m_sdfGi.m_indirectDiffuseHistory_Y_SH[1];
+    if (n == "giHistoryCoCg0") return m_sdfGi.m_indirectDiffuseHistory_CoCg[0];
+    if (n == "giHistoryCoCg1") return m_sdfGi.m_indirectDiffuseHistory_CoCg[1];
+    if (n == "giFullResYSH") return m_sdfGi.m_indirectLightingFullRes_Y_SH;
+    if (n == "giFullResCoCg") return m_sdfGi.m_indirectLightingFullRes_CoCg;
+    if (n == "swapchain") return const_cast<RenderBackend&>(m_be).getSwapchainInputImage();
+    return ImageHandle{};
+}
+
+bool FramePipeline::storageBuffer(const std::string& n, StorageBufferHandle* out) const {
+    if (n == "histogram") *out = m_histogramBuffer;
+    else if (n == "histogramPerTile") *out = m_histogramPerTileBuffer;
+    else if (n == "light") *out = m_lightBuffer;
+    else if (n == "sunShadowInfo") *out = m_sunShadowInfoBuffer;
+    else if (n == "sdfInstances") *out = m_sdfGi.m_sdfInstanceBuffer;
+    else if (n == "sdfCulledInstances") *out = m_sdfGi.m_sdfCameraFrustumCulledInstances;
+    else if (n == "sdfCulledTiles") *out = m_sdfGi.m_sdfCameraCulledTiles;
+    else if (n == "sdfWorldBBs") *out = m_sdfGi.m_sdfInstanceWorldBBBuffer;
+    else return false;
+    return true;
+}
+
+bool FramePipeline::uniformBuffer(const std::string& n, UniformBufferHandle* out) const {
+    if (n == "global") *out = m_globalUniformBuffer;
+    else if (n == "volumetricSettings") *out = m_volumetricsInfoBuffer;
+    else if (n == "taaResolveWeights") *out = m_taa.m_taaResolveWeightBuffer;
+    else if (n == "sdfCameraFrustum") *out = m_sdfGi.m_cameraFrustumBuffer;
+    else if (n == "sdfInfluenceRange") *out = m_sdfGi.m_sdfTraceInfluenceRangeBuffer;
+    else return false;
+    return true;
+}
+
+uint32_t FramePipeline::addSdfVolume(uint32_t res, const void* halfData, size_t bytes) {
+    ImageDescription d;
+    d.width = d.height = d.depth = res;
+    d.type = ImageType::Type3D; d.format = ImageFormat::R16_sFloat; d.usageFlags = ImageUsageFlags::Sampled;
+    const ImageHandle h = m_be.createImage(d, halfData, bytes);
+    m_sdfVolumes.push_back(h);
+    return m_be.getImageGlobalTextureArrayIndex(h);
+}
+
+void FramePipeline::setSdfScene(const void* inst, size_t instBytes, const void* bb, size_t bbBytes) { m_sdfGi.updateSDFScene(m_be, inst, instBytes, bb, bbBytes); }
+void FramePipeline::setSunDirection(const float d[3]) { m_globalShaderInfo.sunDirection[0] = d[0]; m_globalShaderInfo.sunDirection[1] = d[1]; m_globalShaderInfo.sunDirection[2] = d[2]; m_globalShaderInfo.sunDirection[3] = 0.f; }
+void FramePipeline::setCameraIntrinsic(float fov, float n, float f) { m_cameraIntrinsic.fov = fov; m_cameraIntrinsic.near = n; m_cameraIntrinsic.far = f; }
+
+void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { // RenderFrontend.cpp:707-754
+    const StorageBufferResource histogramPerTileResource(m_histogramPerTileBuffer, false, 0);
+    const StorageBufferResource histogramResource(m_histogramBuffer, false, 1);
+    const uint32_t W = settings.width, H = settings.height;
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_histogramPerTilePass;
+        exe.genericInfo.resources.storageBuffers = {histogramPerTileResource, StorageBufferResource(m_lightBuffer, true, 3)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(lastFrameColor, 0, 2)};
+        exe.dispatchCount[0] = uint32_t(std::ceil((float)W / float(histogramTileSizeX)));
+        exe.dispatchCount[1] = uint32_t(std::ceil((float)H / float(histogramTileSizeY)));
+        exe.dispatchCount[2] = 1;
+        m_be.setComputePassExecution(exe);
+    }
+    const float binsPerDispatch = 64.f;
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_histogramResetPass;
+        exe.genericInfo.resources.storageBuffers = {histogramResource};
+        exe.dispatchCount[0] = uint32_t(std::ceil(float(nHistogramBins) / binsPerDispatch));
+        m_be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_histogramCombinePass;
+        exe.genericInfo.resources.storageBuffers = {histogramPerTileResource, histogramResource};
+        exe.dispatchCount[0] = (uint32_t)std::ceil(W / float(histogramTileSizeX)) * (uint32_t)std::ceil(H / float(histogramTileSizeY));
+        exe.dispatchCount[1] = uint32_t(std::ceil(float(nHistogramBins) / binsPerDispatch));
+        m_be.setComputePassExecution(exe);
+    }
+}
+
+void FramePipeline::computeExposure() { // RenderFrontend.cpp:776-790
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_preExposeLightsPass;
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_histogramBuffer, false, 1), StorageBufferResource(m_lightBuffer, false, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(m_transmissionLut, 0, 2)};
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::computeDepthPyramid(ImageHandle depthBuffer) { // RenderFrontend.cpp:804-838
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_depthPyramidPass;
+    const uint32_t width = settings.width / 2, height = settings.height / 2, maxMipCount = 11;
+    const uint32_t mipCount = mipCountFromResolution(width, height, 1);
+    uint32_t dc[2];
+    singlePassMipChainDispatchCount(width, height, mipCount, maxMipCount, dc);
+    exe.dispatchCount[0] = dc[0]; exe.dispatchCount[1] = dc[1]; exe.dispatchCount[2] = 1;
+    exe.genericInfo.resources.sampledImages = {ImageResource(depthBuffer, 0, 13), ImageResource(m_minMaxDepthPyramid, 0, 15)};
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_depthPyramidSyncBuffer, false, 16)};
+    const uint32_t unusedMipCount = maxMipCount - mipCount;
+    for (uint32_t i = 0; i < maxMipCount; i++) {
+        const uint32_t mipLevel = i >= unusedMipCount ? i - unusedMipCount : 0;
+        exe.genericInfo.resources.storageImages.push_back(ImageResource(m_minMaxDepthPyramid, mipLevel, i));
+    }
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::downscaleDepth(const FrameRenderTargets& currentTarget) { // RenderFrontend.cpp:873-892
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_depthDownscalePass;
+    dispatch8(exe, settings.width / 2, settings.height / 2);
+    exe.genericInfo.resources.storageImages = {ImageResource(m_depthHalfRes, 0, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(currentTarget.depthBuffer, 0, 1)};
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::computeDeferredShading(ImageHandle colorTarget, const FrameRenderTargets& current) { // renderForwardShading, RenderFrontend.cpp:894-929
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_deferredShadingPass;
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_lightBuffer, true, 7), StorageBufferResource(m_sunShadowInfoBuffer, true, 8)};
+    const SDFGI::IndirectLightingImages indirectLight = m_sdfGi.getIndirectLightingResults(settings.sdfTrace.halfResTrace);
+    exe.genericInfo.resources.storageImages = {ImageResource(colorTarget, 0, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(m_brdfLut, 0, 3), ImageResource(indirectLight.Y_SH, 0, 15), ImageResource(indirectLight.CoCg, 0, 16),
+                                               ImageResource(m_volumetricIntegrationVolume, 0, 18),
+                                               ImageResource(current.depthBuffer, 0, 20), ImageResource(m_worldSpaceNormalImage, 0, 21),
+                                               ImageResource(m_albedoImage, 0, 22), ImageResource(m_specularImage, 0, 23), ImageResource(m_skyLut, 0, 24)};
+    for (uint32_t i = 0; i < (uint32_t)maxSunShadowCascadeCount; i++) exe.genericInfo.resources.sampledImages.push_back(ImageResource(m_shadowMaps[i], 0, 9 + i));
+    exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 19)};
+    dispatch8(exe, settings.width, settings.height);
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:931-945
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_tonemappingPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(m_be.getSwapchainInputImage(), 0, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(src, 0, 1)};
+    dispatch8(exe, settings.width, settings.height);
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::computeBRDFLut() { // RenderFrontend.cpp:1031-1042
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_brdfLutPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(m_brdfLut, 0, 0)};
+    dispatch8(exe, settings.brdfLutRes, settings.brdfLutRes);
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
+    const FrameRenderTargets previousRenderTarget = m_frameRenderTargets[m_sceneRenderTargetIndex];
+    m_sceneRenderTargetIndex = (m_sceneRenderTargetIndex + 1) % 2;
+    const FrameRenderTargets currentRenderTarget = m_frameRenderTargets[m_sceneRenderTargetIndex];
+
+    if (m_isBRDFLutShaderDescriptionStale) {
+        computeBRDFLut();
+        m_isBRDFLutShaderDescriptionStale = false;
+    }
+    if (settings.runExposure) {
+        computeColorBufferHistogram(previousRenderTarget.colorBuffer);
+        // [m_sky.updateTransmissionLut: input]
+        computeExposure();
+    }
+    // [m_sky.updateSkyLut, renderDepthPrepass: inputs]
+    if (settings.runHiZ) computeDepthPyramid(currentRenderTarget.depthBuffer);
+    // [computeSunLightMatrices, renderSunShadowCascades: inputs]
+    if (settings.runGI && settings.shading.indirectLightingTech == IndirectLightingTech::SDFTrace) {
+        if (settings.sdfTrace.halfResTrace) downscaleDepth(currentRenderTarget);
+        SDFTraceDependencies deps = m_frustumScratch; // frustum points/normals from setCameraExtrinsic (fillOutSdfGiDependencies, :1073-1090)
+        deps.currentFrame = currentRenderTarget;
+        deps.previousFrame = previousRenderTarget;
+        deps.depthHalfRes = m_depthHalfRes;
+        deps.worldSpaceNormals = m_worldSpaceNormalImage;
+        deps.skyLut = m_skyLut;
+        deps.shadowMap = m_shadowMaps[settings.shading.sunShadowCascadeCount - 1];
+        deps.lightBuffer = m_lightBuffer;
+        deps.sunShadowInfoBuffer = m_sunShadowInfoBuffer;
+        deps.depthMinMaxPyramid = m_minMaxDepthPyramid;
+        m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace);
+    }
+    // [volumetrics: input]
+    if (settings.runShading) computeDeferredShading(currentRenderTarget.colorBuffer, currentRenderTarget);
+    // [sky: folded into the deferred pass' sky stand-in]
+    ImageHandle currentSrc = currentRenderTarget.colorBuffer;
+    if (settings.runTAA && settings.taa.enabled) {
+        m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1]);
+        currentSrc = m_postProcessBuffers[1];
+    }
+    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom);
+    if (settings.runTonemap) computeTonemapping(currentSrc);
+}
+
+// ViewFrustum.cpp:4-52 + the packing of SDFGI.cpp:543-566 (top, bot, near, far, left, right)
+static void computeFrustum(const CameraExtrinsic& e, const CameraIntrinsic& in, float points[6][4], float normals[6][4]) {
+    const Vec3 nearC = e.position + e.forward * in.near, farC = e.position + e.forward * in.far;
+    const float tanFoV = std::tan(in.fov * 3.14159265358979f / 180.f * 0.5f);
+    const float hn = tanFoV * in.near, hf = tanFoV * in.far, wn = hn * in.aspectRatio, wf = hf * in.aspectRatio;
+    const Vec3 r_u_f = farC + e.up * hf + e.right * wf, l_u_f = farC + e.up * hf - e.right * wf, r_l_f = farC - e.up * hf + e.right * wf, l_l_f = farC - e.up * hf - e.right * wf;
+    const Vec3 r_u_n = nearC + e.up * hn + e.right * wn, l_u_n = nearC + e.up * hn - e.right * wn, r_l_n = nearC - e.up * hn + e.right * wn, l_l_n = nearC - e.up * hn - e.right * wn;
+    const Vec3 top = normalize(cross(r_u_f - r_u_n, r_u_n - l_u_n)), bot = normalize(cross(r_l_n - l_l_n, r_l_f - r_l_n));
+    const Vec3 right = normalize(cross(r_u_n - r_l_n, r_l_f - r_l_n)), left = normalize(cross(l_l_f - l_l_n, l_u_n - l_l_n));
+    const Vec3 nearN = normalize(cross(r_u_n - r_l_n, r_l_n - l_l_n)), farN = normalize(cross(r_l_f - l_l_f, r_u_f - r_l_f));
+    const Vec3 P[6] = {l_u_f, l_l_f, l_l_n, l_l_f, l_l_f, r_l_f};
+    const Vec3 N[6] = {top, bot, nearN, farN, left, right};
+    for (int i = 0; i < 6; i++) {
+        points[i][0] = P[i].x; points[i][1] = P[i].y; points[i][2] = P[i].z; points[i][3] = 0.f;
+        normals[i][0] = N[i].x; normals[i][1] = N[i].y; normals[i][2] = N[i].z; normals[i][3] = 0.f;
+    }
+}
+
+void FramePipeline::setCameraExtrinsic(const CameraExtrinsic& extrinsic) { // RenderFrontend.cpp:423-454
+    m_globalShaderInfo.previousFrameCameraJitter[0] = m_globalShaderInfo.currentFrameCameraJitter[0];
+    m_globalShaderInfo.previousFrameCameraJitter[1] = m_globalShaderInfo.currentFrameCameraJitter[1];
+    m_cameraExtrinsic = extrinsic;
+    const Mat4 viewMatrix = viewMatrixFromCameraExtrinsic(extrinsic);
+    Mat4 projectionMatrix = projectionMatrixFromCameraIntrinsic(m_cameraIntrinsic);
+    if (settings.taa.enabled) {
+        float jitterInPixels[2];
+        m_taa.jitterInPixels(m_frameIndex, jitterInPixels);
+        m_taa.updateTaaResolveWeights(m_be, jitterInPixels);
+        // keep a copy for tests: same arithmetic as updateTaaResolveWeights
+        {
+            int index = 0; float total = 0.f;
+            for (int y = -1; y <= 1; y++)
+                for (int x = -1; x <= 1; x++) {
+                    const float dx = jitterInPixels[0] - (float)x, dy = jitterInPixels[1] - (float)y;
+                    const float d = std::sqrt(dx * dx + dy * dy);
+                    m_lastWeights[index] = std::exp(-2.29f * d * d);
+                    total += m_lastWeights[index++];
+                }
+            for (float& w : m_lastWeights) w /= total;
+        }
+        m_globalShaderInfo.currentFrameCameraJitter[0] = jitterInPixels[0] * (1.f / settings.width);
+        m_globalShaderInfo.currentFrameCameraJitter[1] = jitterInPixels[1] * (1.f / settings.height);
+        // TAA::applyProjectionMatrixJitter: projection[2][0..1] = offset (TAA.cpp:172-179)
+        projectionMatrix.m[2 * 4 + 0] = m_globalShaderInfo.currentFrameCameraJitter[0];
+        projectionMatrix.m[2 * 4 + 1] = m_globalShaderInfo.currentFrameCameraJitter[1];
+    } else {
+        m_globalShaderInfo.currentFrameCameraJitter[0] = m_globalShaderInfo.currentFrameCameraJitter[1] = 0.f;
+    }
+    m_globalShaderInfo.viewProjectionPrevious = m_globalShaderInfo.viewProjection;
+    m_globalShaderInfo.viewProjection = mul(projectionMatrix, viewMatrix);
+    computeFrustum(extrinsic, m_cameraIntrinsic, m_frustumScratch.frustumPoints, m_frustumScratch.frustumNormals); // updateCameraFrustum
+}
+
+void FramePipeline::updateGlobalShaderInfo(float deltaTime, float time) { // RenderFrontend.cpp:1158-1184
+    GlobalShaderInfo& g = m_globalShaderInfo;
+    std::memcpy(g.cameraPosPrevious, g.cameraPos, sizeof(g.cameraPos));
+    g.cameraPos[0] = m_cameraExtrinsic.position.x; g.cameraPos[1] = m_cameraExtrinsic.position.y; g.cameraPos[2] = m_cameraExtrinsic.position.z; g.cameraPos[3] = 1.f;
+    g.deltaTime = deltaTime;
+    g.time = time;
+    g.nearPlane = m_cameraIntrinsic.near;
+    g.farPlane = m_cameraIntrinsic.far;
+    const Vec3 r = m_cameraExtrinsic.right, u = m_cameraExtrinsic.up, f = m_cameraExtrinsic.forward;
+    g.cameraRight[0] = r.x; g.cameraRight[1] = r.y; g.cameraRight[2] = r.z; g.cameraRight[3] = 0.f;
+    g.cameraUp[0] = u.x; g.cameraUp[1] = u.y; g.cameraUp[2] = u.z; g.cameraUp[3] = 0.f;
+    std::memcpy(g.cameraForwardPrevious, g.cameraForward, sizeof(g.cameraForward));
+    g.cameraForward[0] = f.x; g.cameraForward[1] = f.y; g.cameraForward[2] = f.z; g.cameraForward[3] = 0.f;
+    g.cameraTanFovHalf = std::tan(m_cameraIntrinsic.fov * 3.14159265358979f / 180.f * 0.5f);
+    g.cameraAspectRatio = m_cameraIntrinsic.aspectRatio;
+    g.screenResolution[0] = (int32_t)settings.width; g.screenResolution[1] = (int32_t)settings.height;
+    const float lodBiasSampleRadius = 0.5f;
+    g.mipBias = settings.taa.enabled && settings.taa.useMipBias ? std::log2(lodBiasSampleRadius) : 0.f;
+    m_be.setUniformBufferData(m_globalUniformBuffer, &g, sizeof(g));
+    m_submittedGlobals = g;
+}
+
+void FramePipeline::frame(const CameraExtrinsic& camera, float deltaTime, float time) { // Runtime/main.cpp:79-90
+    m_frameIndex.markNewFrame();
+    // RenderFrontend::prepareNewFrame, RenderFrontend.cpp:198-278
+    m_be.updateShaderCode();
+    m_be.newFrame();
+    prepareRenderpasses();
+    m_be.prepareForDrawcallRecording();
+    // App::runUpdate, App.cpp:64-74
+    setCameraExtrinsic(camera);
+    updateGlobalShaderInfo(deltaTime, time);
+    // RenderFrontend::renderFrame, RenderFrontend.cpp:685-705: the GPU-visible frame index lags the CPU one
+    m_globalShaderInfo.frameIndex++;
+    m_globalShaderInfo.frameIndexMod2 = m_globalShaderInfo.frameIndex % 2;
+    m_globalShaderInfo.frameIndexMod3 = m_globalShaderInfo.frameIndex % 3;
+    m_globalShaderInfo.frameIndexMod4 = m_globalShaderInfo.frameIndex % 4;
+    m_be.renderFrame(true);
+    m_globalShaderInfo.cameraCut = 0;
+}
+
+} // namespace plrhost

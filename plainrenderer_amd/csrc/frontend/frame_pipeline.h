@@ -1,0 +1,216 @@
+// Host-side frame graph author for the hot path: the compute part of the reference's RenderFrontend
+// (Plain/src/Runtime/Rendering/RenderFrontend.cpp:313-406 prepareRenderpasses and the compute*/init* helpers) and of its
+// technique classes (Techniques/TAA.cpp, Bloom.cpp, SDFGI.cpp), written against the RenderBackend shim in
+// include/plr_render_backend.hpp. Rasterised passes (depth prepass, shadow cascades, forward shading, sky) are inputs:
+// their outputs (G-buffer, shadow maps, LUTs) are uploaded by the caller; forward shading is replaced by the deferred
+// compute pass. Pass order, bindings, specialisation constants and dispatch counts are the reference's.
+#pragma once
+#include <array>
+#include <string>
+#include <vector>
+
+#include "../../../include/plr_render_backend.hpp"
+
+namespace plrhost {
+
+struct Vec3 { float x = 0, y = 0, z = 0; };
+struct Mat4 { float m[16]; }; // column major: m[col * 4 + row]
+
+// GPU image of GlobalShaderInfo (ResourceDescriptions.h:174-203 / global.inc:4-33); the bool is 4 bytes at offset 320
+struct GlobalShaderInfo {
+    Mat4 viewProjection{};
+    Mat4 viewProjectionPrevious{};
+    float sunDirection[4] = {0.f, -1.f, 0.f, 0.f};
+    float cameraPos[4] = {0, 0, 0, 0};
+    float cameraPosPrevious[4] = {0, 0, 0, 0};
+    float cameraRight[4] = {1.f, 0.f, 0.f, 0.f};
+    float cameraUp[4] = {0.f, -1.f, 0.f, 0.f};
+    float cameraForward[4] = {0.f, 0.f, -1.f, 0.f};
+    float cameraForwardPrevious[4] = {0.f, 0.f, -1.f, 0.f};
+    int32_t noiseTextureIndices[4] = {0, 0, 0, 0};
+    float currentFrameCameraJitter[2] = {0, 0};
+    float previousFrameCameraJitter[2] = {0, 0};
+    int32_t screenResolution[2] = {0, 0};
+    float cameraTanFovHalf = 1.f;
+    float cameraAspectRatio = 1.f;
+    float nearPlane = 0.1f;
+    float farPlane = 100.f;
+    float sunIlluminanceLux = 128000.f;
+    float exposureOffset = 1.f;
+    float exposureAdaptionSpeedEvPerSec = 2.f;
+    float deltaTime = 0.016f;
+    float time = 0.f;
+    float mipBias = 0.f;
+    uint32_t cameraCut = 0;
+    uint32_t frameIndex = 0;
+    uint32_t frameIndexMod2 = 0;
+    uint32_t frameIndexMod3 = 0;
+    uint32_t frameIndexMod4 = 0;
+};
+static_assert(sizeof(GlobalShaderInfo) == 340, "GlobalShaderInfo layout");
+
+struct CameraExtrinsic { Vec3 position; Vec3 forward{0, 0, -1}; Vec3 up{0, -1, 0}; Vec3 right{1, 0, 0}; };
+struct CameraIntrinsic { float fov = 35.f; float aspectRatio = 1.f; float near = 0.1f; float far = 300.f; }; // Camera.h:11-16
+
+struct FrameRenderTargets { ImageHandle colorBuffer, motionBuffer, depthBuffer; };
+
+// ---- Techniques/TAA.h
+enum class HistorySamplingTech : int { Bilinear = 0, Bicubic16Tap = 1, Bicubic9Tap = 2, Bicubic5Tap = 3, Bicubic1Tap = 4 };
+struct TAASettings {
+    bool enabled = true;
+    bool useSeparateSupersampling = false;
+    bool useClipping = true;
+    bool useMotionVectorDilation = true;
+    HistorySamplingTech historySamplingTech = HistorySamplingTech::Bicubic1Tap;
+    bool supersampleUseTonemapping = true;
+    bool filterUseTonemapping = true;
+    bool useMipBias = true;
+};
+struct BloomSettings { bool enabled = true; float strength = 0.05f; float radius = 1.5f; };
+struct SDFTraceSettings {
+    bool halfResTrace = true;
+    bool strictInfluenceRadiusCutoff = true;
+    float traceInfluenceRadius = 5.f;
+    float additionalSunShadowMapPadding = 3.f;
+};
+enum class DiffuseBRDF : int { Lambert = 0, Disney = 1, CoDWWII = 2, Titanfall2 = 3 };
+enum class DirectSpecularMultiscattering : int { McAuley = 0, Simplified = 1, ScaledGGX = 2, None = 3 };
+enum class IndirectLightingTech : int { SDFTrace, ConstantAmbient };
+struct ShadingConfig {
+    DiffuseBRDF diffuseBRDF = DiffuseBRDF::CoDWWII;
+    DirectSpecularMultiscattering directMultiscatter = DirectSpecularMultiscattering::McAuley;
+    IndirectLightingTech indirectLightingTech = IndirectLightingTech::SDFTrace;
+    bool useGeometryAA = true;
+    int sunShadowCascadeCount = 3;
+};
+
+struct FrameIndexCounter { // Runtime/FrameIndex.cpp
+    size_t frameIndex = 0;
+    void markNewFrame() { frameIndex++; }
+    size_t mod2() const { return frameIndex % 2; }
+    size_t mod8() const { return frameIndex % 8; }
+};
+
+class TAA {
+public:
+    void init(RenderBackend& be, int imageWidth, int imageHeight, const TAASettings& settings);
+    void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target) const;
+    void jitterInPixels(const FrameIndexCounter& fi, float out[2]) const;
+    void updateTaaResolveWeights(RenderBackend& be, const float cameraJitterInPixels[2]);
+    ImageHandle m_historyBuffers[2];
+    UniformBufferHandle m_taaResolveWeightBuffer;
+private:
+    RenderPassHandle m_temporalFilterPass;
+};
+
+class Bloom {
+public:
+    void init(RenderBackend& be);
+    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings) const;
+private:
+    std::vector<RenderPassHandle> m_bloomDownsamplePasses, m_bloomUpsamplePasses;
+    RenderPassHandle m_applyBloomPass;
+};
+
+struct SDFTraceDependencies {
+    FrameRenderTargets currentFrame, previousFrame;
+    float frustumPoints[6][4], frustumNormals[6][4];
+    ImageHandle depthHalfRes, worldSpaceNormals, skyLut, shadowMap, depthMinMaxPyramid;
+    StorageBufferHandle lightBuffer, sunShadowInfoBuffer;
+};
+
+class SDFGI {
+public:
+    void init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& traceSettings, int sunShadowCascadeIndex, uint32_t maxInstances);
+    // packed { uint count; uint pad[3]; SDFInstance[] } and { vec3 min; pad; vec3 max; pad }[] as SDFGI::updateSDFScene builds them
+    void updateSDFScene(RenderBackend& be, const void* instanceBufferData, size_t instanceBytes, const void* worldBBData, size_t bbBytes);
+    void computeIndirectLighting(RenderBackend& be, const FrameIndexCounter& fi, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
+    struct IndirectLightingImages { ImageHandle Y_SH, CoCg; };
+    IndirectLightingImages getIndirectLightingResults(bool tracedHalfRes) const;
+    ImageHandle m_indirectDiffuse_Y_SH[2], m_indirectDiffuse_CoCg[2], m_indirectDiffuseHistory_Y_SH[2], m_indirectDiffuseHistory_CoCg[2];
+    ImageHandle m_indirectLightingFullRes_Y_SH, m_indirectLightingFullRes_CoCg;
+    StorageBufferHandle m_sdfInstanceBuffer, m_sdfCameraFrustumCulledInstances, m_sdfInstanceWorldBBBuffer, m_sdfCameraCulledTiles;
+private:
+    void sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling) const;
+    void diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
+    void filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
+public:
+    UniformBufferHandle m_cameraFrustumBuffer, m_sdfTraceInfluenceRangeBuffer;
+private:
+    uint32_t m_sdfInstanceCount = 0;
+    RenderPassHandle m_diffuseSDFTracePass, m_indirectDiffuseFilterSpatialPass[2], m_indirectDiffuseFilterTemporalPass, m_indirectLightingUpscale,
+        m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ;
+};
+
+struct FramePipelineSettings {
+    uint32_t width = 1920, height = 1080;
+    uint32_t shadowMapRes = 2048;  // RenderFrontend.cpp:40
+    uint32_t brdfLutRes = 512;     // RenderFrontend.cpp:45
+    uint32_t maxSdfInstances = 1200; // SceneConfig.h:3 maxObjectCountMainScene
+    uint32_t froxelDepth = 64;
+    TAASettings taa;
+    BloomSettings bloom;
+    SDFTraceSettings sdfTrace;
+    ShadingConfig shading;
+    // which groups of prepareRenderpasses are recorded (all on = the full frame)
+    bool runExposure = true, runHiZ = true, runGI = true, runShading = true, runTAA = true, runBloom = true, runTonemap = true;
+};
+
+class FramePipeline {
+public:
+    explicit FramePipeline(const FramePipelineSettings& s);
+    // one iteration of the reference main loop (Runtime/main.cpp:79-90): markNewFrame, prepareNewFrame, update, renderFrame
+    void frame(const CameraExtrinsic& camera, float deltaTime, float time);
+    // only re-record + submit with the current state (used by benchmarks that replay one frame)
+    ImageHandle image(const std::string& name) const;
+    bool storageBuffer(const std::string& name, StorageBufferHandle* out) const;
+    bool uniformBuffer(const std::string& name, UniformBufferHandle* out) const;
+    uint32_t addSdfVolume(uint32_t res, const void* halfData, size_t bytes);
+    void setSdfScene(const void* instanceBufferData, size_t instanceBytes, const void* worldBBData, size_t bbBytes);
+    void setSunDirection(const float dir[3]);
+    void setCameraIntrinsic(float fovDegrees, float nearPlane, float farPlane);
+    void setCameraCut() { m_globalShaderInfo.cameraCut = 1; }
+    const GlobalShaderInfo& lastSubmittedGlobals() const { return m_submittedGlobals; }
+    const float* lastResolveWeights() const { return m_lastWeights; }
+    size_t cpuFrameIndex() const { return m_frameIndex.frameIndex; }
+    RenderBackend& backend() { return m_be; }
+    FramePipelineSettings settings;
+
+private:
+    void prepareRenderpasses();
+    void computeColorBufferHistogram(ImageHandle lastFrameColor);
+    void computeExposure();
+    void computeDepthPyramid(ImageHandle depthBuffer);
+    void downscaleDepth(const FrameRenderTargets& currentTarget);
+    void computeDeferredShading(ImageHandle colorTarget, const FrameRenderTargets& current);
+    void computeTonemapping(ImageHandle src);
+    void computeBRDFLut();
+    void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
+    void updateGlobalShaderInfo(float deltaTime, float time);
+
+    RenderBackend m_be;
+    FrameIndexCounter m_frameIndex;
+    GlobalShaderInfo m_globalShaderInfo, m_submittedGlobals;
+    float m_lastWeights[9] = {};
+    CameraExtrinsic m_cameraExtrinsic;
+    CameraIntrinsic m_cameraIntrinsic;
+    SDFTraceDependencies m_frustumScratch;
+    int m_sceneRenderTargetIndex = 0;
+    bool m_isBRDFLutShaderDescriptionStale = true;
+    uint32_t m_depthPyramidThreadgroupCount = 0;
+
+    UniformBufferHandle m_globalUniformBuffer, m_volumetricsInfoBuffer;
+    FrameRenderTargets m_frameRenderTargets[2];
+    ImageHandle m_postProcessBuffers[2], m_worldSpaceNormalImage, m_albedoImage, m_specularImage, m_minMaxDepthPyramid, m_depthHalfRes, m_brdfLut, m_skyLut,
+        m_transmissionLut, m_volumetricIntegrationVolume;
+    ImageHandle m_shadowMaps[4], m_noiseTextures[4];
+    std::vector<ImageHandle> m_sdfVolumes;
+    StorageBufferHandle m_histogramPerTileBuffer, m_histogramBuffer, m_lightBuffer, m_sunShadowInfoBuffer, m_depthPyramidSyncBuffer;
+    RenderPassHandle m_histogramPerTilePass, m_histogramResetPass, m_histogramCombinePass, m_preExposeLightsPass, m_depthPyramidPass, m_depthDownscalePass,
+        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass;
+    TAA m_taa;
+    Bloom m_bloom;
+    SDFGI m_sdfGi;
+};
+
+} // namespace plrhost

@@ -1,0 +1,153 @@
+"""ctypes binding of the C++ frame pipeline (include/plr_frame.h) and the upload of one synthetic scene into it.
+
+The pipeline (plainrenderer_amd/csrc/frontend/frame_pipeline.cpp) is the host-side mirror of the reference's
+RenderFrontend::prepareRenderpasses + technique classes; this module only drives it for tests and benchmarks.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import synth
+from .backend import ImageHandle, PlrError, RenderBackend, _ImageHandle
+from .scene import Camera
+
+
+class PlrfSettings(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "shadow_map_res", "brdf_lut_res", "max_sdf_instances", "froxel_depth", "taa_enabled",
+                                          "taa_use_clipping", "taa_use_motion_vector_dilation", "taa_history_sampling_tech", "taa_filter_use_tonemapping",
+                                          "bloom_enabled")] + \
+               [("bloom_strength", C.c_float), ("bloom_radius", C.c_float), ("sdf_half_res_trace", C.c_uint32), ("sdf_strict_influence_radius_cutoff", C.c_uint32),
+                ("sdf_trace_influence_radius", C.c_float)] + \
+               [(n, C.c_uint32) for n in ("diffuse_brdf", "direct_multiscatter", "indirect_lighting_tech", "use_geometry_aa", "sun_shadow_cascade_count",
+                                          "run_exposure", "run_hiz", "run_gi", "run_shading", "run_taa", "run_bloom", "run_tonemap")]
+
+
+class PlrfCamera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3)]
+
+
+class FramePipeline:
+    def __init__(self, be: RenderBackend, width, height, **overrides):
+        self.be, self.lib = be, be.lib
+        self.lib.plrf_last_error.restype = C.c_char_p
+        s = PlrfSettings()
+        self._check(self.lib.plrf_default_settings(C.byref(s), C.c_uint32(width), C.c_uint32(height)))
+        for k, v in overrides.items():
+            if not hasattr(s, k):
+                raise KeyError(k)
+            setattr(s, k, v)
+        self.settings = s
+        self.handle = C.c_void_p()
+        self._check(self.lib.plrf_create(C.byref(s), C.byref(self.handle)))
+        self.width, self.height = width, height
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.plrf_last_error().decode() or self.lib.plr_last_error().decode()
+            raise PlrError("plrf error %d: %s" % (rc, msg))
+
+    def destroy(self):
+        if self.handle:
+            self.lib.plrf_destroy(self.handle)
+            self.handle = None
+
+    def image(self, name):
+        h = _ImageHandle()
+        self._check(self.lib.plrf_get_image(self.handle, name.encode(), C.byref(h)))
+        return ImageHandle(h.type, h.index)
+
+    def storage_buffer(self, name):
+        h = C.c_uint32()
+        self._check(self.lib.plrf_get_storage_buffer(self.handle, name.encode(), C.byref(h)))
+        return h.value
+
+    def uniform_buffer(self, name):
+        h = C.c_uint32()
+        self._check(self.lib.plrf_get_uniform_buffer(self.handle, name.encode(), C.byref(h)))
+        return h.value
+
+    def add_sdf_volume(self, res, half_data):
+        a = np.ascontiguousarray(half_data)
+        out = C.c_uint32()
+        self._check(self.lib.plrf_add_sdf_volume(self.handle, C.c_uint32(res), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), C.byref(out)))
+        return out.value
+
+    def set_sdf_scene(self, instance_bytes, bb_bytes):
+        self._check(self.lib.plrf_set_sdf_scene(self.handle, instance_bytes, C.c_size_t(len(instance_bytes)), bb_bytes, C.c_size_t(len(bb_bytes))))
+
+    def set_sun_direction(self, d):
+        self._check(self.lib.plrf_set_sun_direction(self.handle, (C.c_float * 3)(*[float(x) for x in d])))
+
+    def set_camera_intrinsic(self, fov, near, far):
+        self._check(self.lib.plrf_set_camera_intrinsic(self.handle, C.c_float(fov), C.c_float(near), C.c_float(far)))
+
+    def set_camera_cut(self):
+        self._check(self.lib.plrf_set_camera_cut(self.handle))
+
+    def frame(self, cam: Camera, delta_time=1.0 / 60.0, time=0.0):
+        c = PlrfCamera()
+        for name in ("position", "forward", "up", "right"):
+            setattr(c, name, (C.c_float * 3)(*[float(x) for x in getattr(cam, name)]))
+        self._check(self.lib.plrf_frame(self.handle, C.byref(c), C.c_float(delta_time), C.c_float(time)))
+
+    def submitted_globals(self):
+        buf = C.create_string_buffer(340)
+        self._check(self.lib.plrf_get_submitted_globals(self.handle, buf))
+        return buf.raw
+
+    def resolve_weights(self):
+        w = np.zeros(9, np.float32)
+        self._check(self.lib.plrf_get_resolve_weights(self.handle, w.ctypes.data_as(C.c_void_p)))
+        return w
+
+    def cpu_frame_index(self):
+        v = C.c_uint64()
+        self._check(self.lib.plrf_get_cpu_frame_index(self.handle, C.byref(v)))
+        return v.value
+
+
+class SyntheticInputs:
+    """everything the rasterised / out-of-scope passes would have produced, generated once per scene + camera"""
+
+    def __init__(self, scene: synth.SynthScene, cam: Camera, cam_prev: Camera, width, height, sdf_res, shadow_res, froxel_depth, sun_direction, cascades=3):
+        self.width, self.height, self.sdf_res, self.shadow_res = width, height, sdf_res, shadow_res
+        self.gb = scene.gbuffer(cam, width, height, cam_prev)
+        self.instance_bytes, self.bb_bytes, self.volumes = scene.sdf_instances(sdf_res)
+        self.noise = synth.blue_noise_standins()
+        self.sky = synth.sky_lut()
+        self.transmission = synth.transmission_lut()
+        sun = np.asarray(sun_direction, np.float64)
+        self.sun = sun / np.linalg.norm(sun)
+        depth = self.gb["depth"]
+        n, f = cam.near, cam.far
+        vis = depth[depth > 0]
+        lin = n * f / (f + (1.0 - vis.astype(np.float64)) * (n - f)) if vis.size else np.array([1.0, 50.0])
+        self.shadow_info, self.shadow_maps = scene.shadow_cascades(cam, self.sun, float(lin.min()), float(lin.max()), shadow_res, cascade_count=cascades)
+        self.froxel, self.froxel_dims = synth.froxel_volume(width, height, froxel_depth)
+        self.vol_settings = synth.volumetric_settings_bytes(30.0)
+
+    def upload(self, fp: FramePipeline):
+        be = fp.be
+        gb = self.gb
+        for i in (0, 1):
+            be.uploadImage(fp.image("depth%d" % i), gb["depth"])
+            be.uploadImage(fp.image("motion%d" % i), gb["motion"])
+        be.uploadImage(fp.image("normal"), gb["normal"])
+        be.uploadImage(fp.image("albedo"), gb["albedo"])
+        be.uploadImage(fp.image("specular"), gb["specular"])
+        be.uploadImage(fp.image("skyLut"), self.sky)
+        be.uploadImage(fp.image("transmissionLut"), self.transmission)
+        be.uploadImage(fp.image("volumetricIntegrationVolume"), self.froxel)
+        for i in range(4):
+            be.uploadImage(fp.image("shadow%d" % i), self.shadow_maps[i])
+            be.uploadImage(fp.image("noise%d" % i), self.noise[i])
+        be.setStorageBufferData(fp.storage_buffer("sunShadowInfo"), self.shadow_info)
+        be.setUniformBufferData(fp.uniform_buffer("volumetricSettings"), self.vol_settings)
+        self.volume_indices = [fp.add_sdf_volume(self.sdf_res, v) for v in self.volumes]
+        inst = bytearray(self.instance_bytes)
+        for i, ti in enumerate(self.volume_indices):
+            struct.pack_into("<I", inst, 16 + i * 96 + 12, ti)
+        self.instance_bytes_patched = bytes(inst)
+        fp.set_sdf_scene(self.instance_bytes_patched, self.bb_bytes)
+        fp.set_sun_direction(self.sun)
