@@ -22,9 +22,11 @@ namespace orc {
 static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-// GLSL 4.60 spec 8.3: min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x
-static inline float gmin(float x, float y) { return (y < x) ? y : x; }
-static inline float gmax(float x, float y) { return (x < y) ? y : x; }
+// GLSL 4.60 spec 8.3: min(x,y) = y < x ? y : x ; max(x,y) = x < y ? y : x, "undefined" if an operand is NaN.
+// NaN case fixed the way GPU hardware (v_min_f32 / v_max_f32, IEEE minNum / maxNum) resolves it: the non-NaN operand wins.
+// The reference relies on this to recover from the 0/0 of its first frames (preExposeLights.comp:64,72).
+static inline float gmin(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((y < x) ? y : x)); }
+static inline float gmax(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((x < y) ? y : x)); }
 static inline float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 static inline float gsign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 static inline float gfract(float x) { return x - std::floor(x); }

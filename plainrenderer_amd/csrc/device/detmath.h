@@ -16,9 +16,10 @@ namespace plr {
 PLR_DI uint32_t f2u(float f) { return __float_as_uint(f); }
 PLR_DI float u2f(uint32_t u) { return __uint_as_float(u); }
 
-// GLSL 4.60 8.3 definitions (NaN and signed-zero behaviour follows from the comparison)
-PLR_DI float gmin(float x, float y) { return (y < x) ? y : x; }
-PLR_DI float gmax(float x, float y) { return (x < y) ? y : x; }
+// GLSL 4.60 8.3 definitions; a NaN operand loses (IEEE minNum / maxNum, what v_min_f32 / v_max_f32 do), signed zeros
+// follow from the comparison. The reference relies on the NaN rule to recover from the 0/0 of its first frames.
+PLR_DI float gmin(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((y < x) ? y : x)); }
+PLR_DI float gmax(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((x < y) ? y : x)); }
 PLR_DI float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 PLR_DI float gsign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 PLR_DI float gmix(float a, float b, float t) { return a * (1.f - t) + b * t; }

@@ -69,10 +69,13 @@ def test_kat_exposure_ev_floor_and_slew():
     ev_prev = math.log2(1.0 / (1e-2 * 1.2))
     ev_now = math.log2(1.0 / (lb2[3] * 1.2))
     assert ev_now - ev_prev == pytest.approx(2.0 / 60.0, rel=1e-3)
-    # reference quirk: if no bin qualifies the mean is 0/0
+    # reference quirk: if no bin qualifies the mean is 0/0; max(NaN, 10) then resolves to 10 as on GPU hardware
+    # (IEEE maxNum), which is how the reference recovers from its all-black first frames
     one = np.zeros(128, np.uint32)
     one[40] = n
-    assert np.isnan(passes.orc_pre_expose(one, light_buffer_bytes(), lut, 4, 4, g)[3])
+    g = _global(640, 360, exposureAdaptionSpeedEvPerSec=1e6)
+    lb3 = passes.orc_pre_expose(one, light_buffer_bytes(), lut, 4, 4, g)
+    assert math.log2(1.0 / (lb3[3] * 1.2)) == pytest.approx(10.0, abs=1e-3)
 
 
 # ------------------------------------------------------------------ GPU parity
