@@ -120,8 +120,11 @@ static inline float det_exp2f(float x) {
     return det_exp_poly_scale(r, (int)fk);
 }
 
-// GLSL pow(x,y): undefined for x<0 (NaN here); exp2(y*log2(x)) otherwise
+// GLSL pow(x,y) = exp2(y*log2(x)), "undefined" for x < 0. A negative base is treated as 0 here: the only negative bases
+// the hot path produces are roundoff (1 - VoH with VoH = dot of two unit vectors = 1 + 1ulp, brdf.inc:35 via
+// triangle.frag:315-317 when the irradiance SH is exactly zero), where hardware log2 would poison the frame with NaN.
 static inline float det_powf(float x, float y) {
+    if (x < 0.f) x = 0.f;
     if (x == 0.f) return (y > 0.f) ? 0.f : ((y == 0.f) ? 1.f : u2f(0x7f800000u));
     return det_exp2f(y * det_log2f(x));
 }

@@ -110,7 +110,9 @@ PLR_DI float det_exp2f(float x) {
     return det_exp_poly_scale(r, (int)fk);
 }
 
+// pow(x, y) = exp2(y * log2(x)); GLSL leaves x < 0 undefined, a negative base (roundoff of 1 - cos) is treated as 0
 PLR_DI float det_powf(float x, float y) {
+    if (x < 0.f) x = 0.f;
     if (x == 0.f) return (y > 0.f) ? 0.f : ((y == 0.f) ? 1.f : u2f(0x7f800000u));
     return det_exp2f(y * det_log2f(x));
 }

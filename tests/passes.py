@@ -30,6 +30,8 @@ class GlobalBinding:
         be.setGlobalDescriptorSetResources(RenderPassResources(uniformBuffers=[UniformBufferResource(self.ubo, 0)]))
 
     def set(self, packed340):
+        # re-bind every time: a FramePipeline created in between installs its own global uniform buffer
+        self.be.setGlobalDescriptorSetResources(RenderPassResources(uniformBuffers=[UniformBufferResource(self.ubo, 0)]))
         self.be.setUniformBufferData(self.ubo, packed340)
 
 
