@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of the full GI + shade + post frame at 3840x2160 on MI355X (BASELINE.json).
+
+One step = one frame of the hot path recorded by the C++ FramePipeline (reference pass order: histogram x3, pre-expose, HiZ,
+depth downscale, SDF frustum+tile culling, diffuse trace, spatial/temporal/spatial denoise, upscale, deferred shade, TAA,
+bloom x11, tonemap) on synthetic inputs that are resident in HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+N > 1 (this round): replicas only, weak scaling - every rank renders its own 3840x2160 view of the scene (own camera), no
+data-path collective; ranks meet only at the timing barriers. Screen-tiling one 8K frame with RCCL halo exchange
+needs tile offsets in the per-pixel ray set-up and is the documented next step (DESIGN.md "multi-GPU").
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_depth):
+    """Compulsory HBM bytes per pass launch: every input read once, every output written once."""
+    N = w * h
+    M = (w // 2) * (h // 2)
+    tiles = math.ceil(w / 32) * math.ceil(h / 32)
+    sdf = n_instances * sdf_res ** 3 * 2
+    lut = brdf_res * brdf_res * 8 + 3 * shadow_res * shadow_res * 2 + math.ceil(w / 8) * math.ceil(h / 8) * froxel_depth * 8
+    b = {
+        "Histogram per tile": 4 * N + tiles * 512,
+        "Histogram reset": 512,
+        "Histogram combine tiles": tiles * 512 + 512,
+        "Pre-expose lights": 512 + 20 + 4,
+        "Depth min/max pyramid": 4 * N + 8 * (N / 4) * 4.0 / 3.0,
+        "Depth downscale": 6 * M,
+        "SDF camera frustum culling": n_instances * 36,
+        "SDF camera tile culling": n_instances * 36 + tiles * 404 / 4,
+        "Indirect diffuse SDF trace": 20 * M + sdf + (tiles / 4) * 404,
+        "Indirect diffuse spatial filter": 30 * M,
+        "Indirect diffuse temporal filter": 56 * M,
+        "Indirect lighting upscale": 14 * M + 16 * N,
+        "Forward shading (deferred)": 32 * N + lut,
+        "Temporal filtering": 24 * N,
+        "Apply bloom": 12 * N,
+        "Tonemap": 8 * N,
+    }
+    for m in range(1, 6):  # down: read mip m-1, write mip m; up (target t): read down t+1, up t+1, write t
+        b["Bloom downsample mip %d" % m] = 4 * N / 4 ** (m - 1) + 4 * N / 4 ** m
+    for t in range(4, -1, -1):
+        b["Bloom Upsample mip %d" % t] = 4 * N / 4 ** (t + 1) * (1 if t == 4 else 2) + 4 * N / 4 ** t
+    frame = 157.3 * N + sdf + lut
+    return b, frame
+
+
+def build_scene(args, device, rank):
+    from plainrenderer_amd import synth
+    from plainrenderer_amd.frame import SyntheticInputs
+    from plainrenderer_amd.scene import Camera
+    w, h = args.width, args.height
+    scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
+    span = args.grid * 8.0
+    # every rank looks at the field from its own position (weak scaling: one 4K view per GPU)
+    x0 = span * (0.35 + 0.3 * ((rank * 0.37) % 1.0))
+    cams = [Camera.look((x0 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(args.steps + args.warmup + args.profile_frames + 4)]
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=args.shadow_res, froxel_depth=64, sun_direction=(0.35, -0.8, 0.45))
+    return scene, cams, inputs
+
+
+def cpu_baseline(args, cores):
+    """oracle frames (scalar C++ restatement, rows split over `cores` std::threads) on a 1/64-area version of the same
+    workload; reported as 4K-equivalent frames/s (time scaled by the pixel ratio)."""
+    import pyoracle
+    from oracle_frame import OracleFrame
+    from plainrenderer_amd import synth
+    from plainrenderer_amd.frame import PlrfSettings, SyntheticInputs
+    from plainrenderer_amd.scene import Camera, GlobalShaderInfo, taa_jitter_pixels, taa_resolve_weights
+    scale = 8
+    w, h = args.width // scale, args.height // scale
+    pyoracle.set_threads(cores)
+    scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device="cpu")
+    span = args.grid * 8.0
+    cams = [Camera.look((span * 0.35 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(4)]
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+    inputs.volume_indices = list(range(len(inputs.volumes)))
+    inputs.instance_bytes_patched = inputs.instance_bytes
+    s = PlrfSettings()
+    s.taa_enabled = s.taa_use_clipping = s.taa_use_motion_vector_dilation = s.taa_filter_use_tonemapping = 1
+    s.taa_history_sampling_tech = 4
+    s.bloom_enabled, s.bloom_strength, s.bloom_radius = 1, 0.05, 1.5
+    s.sdf_half_res_trace, s.sdf_strict_influence_radius_cutoff, s.sdf_trace_influence_radius = 1, 1, 5.0
+    s.diffuse_brdf, s.direct_multiscatter, s.indirect_lighting_tech, s.use_geometry_aa, s.sun_shadow_cascade_count = 2, 0, 0, 1, 3
+    s.run_exposure = s.run_hiz = s.run_gi = s.run_shading = s.run_taa = s.run_bloom = s.run_tonemap = 1
+    ora = OracleFrame(inputs, w, h, 32, s)
+    n_vol = len(inputs.volumes)
+    times = []
+    for f in range(3):
+        g = GlobalShaderInfo(frameIndex=f, sunDirection=(*inputs.sun.tolist(), 0.0), time=0.5 + f / 60.0, deltaTime=1 / 60.0)
+        g.noiseTextureIndices = (n_vol, n_vol + 1, n_vol + 2, n_vol + 3)
+        cams[f + 1].fill_global(g, w, h)
+        fp_, fn_ = cams[f].frustum_points_normals()
+        frustum = np.concatenate([fp_.reshape(-1), fn_.reshape(-1)]).astype(np.float32).tobytes()
+        t0 = time.perf_counter()
+        ora.frame(g.pack(), taa_resolve_weights(taa_jitter_pixels((f + 1) % 8)), frustum, 5.0)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))  # frame 0 bakes the BRDF LUT
+    return {"value": 1.0 / (t * scale * scale), "unit": "frames/s (3840x2160-equivalent)", "cores": cores, "kind": "port",
+            "sample": "full frame at %dx%d (1/%d of the pixels, %d instances x %d^3 SDF), median of 2 frames = %.2f s each, scaled by the pixel ratio" % (
+                w, h, scale * scale, args.grid ** 2, args.sdf_res, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--grid", type=int, default=16, help="SDF instances = grid^2 (16 -> 256)")
+    ap.add_argument("--sdf-res", type=int, default=64)
+    ap.add_argument("--shadow-res", type=int, default=2048)
+    ap.add_argument("--profile-frames", type=int, default=20, help="extra frames with per-pass hipEvent timing for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = "cuda:%d" % local_rank
+
+    from plainrenderer_amd import RenderBackend
+    from plainrenderer_amd.frame import FramePipeline
+    w, h = args.width, args.height
+    be = RenderBackend(w, h, device=local_rank)
+    fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res)
+    scene, cams, inputs = build_scene(args, device, rank)
+    inputs.upload(fp)
+    be.waitForGPUIdle()
+
+    frame_no = [0]
+
+    def step():
+        fp.frame(cams[frame_no[0] + 1], 1.0 / 60.0, 0.5 + frame_no[0] / 60.0)
+        frame_no[0] += 1
+
+    for _ in range(args.warmup):
+        step()
+    be.waitForGPUIdle()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    be.waitForGPUIdle()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1000.0 / args.steps
+
+    # ---- per-pass hipEvent timings (events recorded on the backend's launch stream) for the roofline object
+    pass_ms = {}
+    if args.profile_frames > 0:
+        be.setPassTiming(True)
+        for _ in range(args.profile_frames):
+            step()
+            for name, ms in be.getRenderpassTimings():
+                pass_ms.setdefault(name, []).append(ms)
+        be.setPassTiming(False)
+    bytes_per_pass, frame_bytes = algorithmic_bytes(w, h, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
+    table = []
+    for name, v in pass_ms.items():
+        launches = len(v) / args.profile_frames
+        avg = float(np.mean(v))
+        table.append((name, avg, launches, bytes_per_pass.get(name, 0.0)))
+    table.sort(key=lambda r: -r[1] * r[2])
+    roofline = None
+    if table:
+        name, avg_ms, launches, nbytes = table[0]
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+    if args.pass_table and rank == 0:
+        tot = sum(r[1] * r[2] for r in table)
+        sys.stderr.write("%-36s %9s %7s %9s %8s\n" % ("pass", "avg ms", "launch", "GB/s", "% frame"))
+        for name, avg, launches, nbytes in table:
+            sys.stderr.write("%-36s %9.4f %7.1f %9.1f %8.1f\n" % (name, avg, launches, nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0, 100 * avg * launches / tot))
+        sys.stderr.write("sum of pass times %.3f ms; frame (wall) %.3f ms\n" % (tot, ms_per_step))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, os.cpu_count() or 1)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec full GI+shade+post @4K; %HBM roofline; 1/2/4/8-GPU scaling",
+            "value": round(world * 1000.0 / ms_per_step, 3),
+            "unit": "frames/s (3840x2160 frames, summed over GPUs)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d per GPU, %d SDF instances x %d^3, "
+                                   "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
+                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "parallelism": "replicas: 1 independent view per GPU" if world > 1 else "single GPU"},
+            "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                               "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "passes_ms": {name: round(avg * launches, 4) for name, avg, launches, _ in table},
+        }
+        print(json.dumps(out))
+    fp.destroy()
+    be.shutdown()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
