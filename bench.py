@@ -76,18 +76,18 @@ def build_scene(args, device, rank):
     return scene, cams, inputs
 
 
-def cpu_baseline(args, cores):
-    """oracle frames (scalar C++ restatement, rows split over `cores` std::threads) on a 1/64-area version of the same
-    workload; reported as 4K-equivalent frames/s (time scaled by the pixel ratio)."""
+def cpu_baseline(args, cores, device):
+    """oracle frames (scalar C++ restatement, rows split over `cores` std::threads) on a quarter-area (1920x1080) version of the
+    same workload; reported as 4K-equivalent frames/s (time scaled by the pixel ratio). Inputs are generated on `device`."""
     import pyoracle
     from oracle_frame import OracleFrame
     from plainrenderer_amd import synth
     from plainrenderer_amd.frame import PlrfSettings, SyntheticInputs
     from plainrenderer_amd.scene import Camera, GlobalShaderInfo, taa_jitter_pixels, taa_resolve_weights
-    scale = 8
+    scale = 2
     w, h = args.width // scale, args.height // scale
     pyoracle.set_threads(cores)
-    scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device="cpu")
+    scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
     span = args.grid * 8.0
     cams = [Camera.look((span * 0.35 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(4)]
     inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
@@ -213,7 +213,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, os.cpu_count() or 1)
+        cpu = cpu_baseline(args, os.cpu_count() or 1, device)
 
     if rank == 0:
         out = {
