@@ -164,6 +164,14 @@ int plr_get_last_frame_cpu_time(float* out_ms);
 int plr_get_image_description(plr_image_handle image, plr_image_desc* out_desc);
 
 /* ---- additions with no reference counterpart (host <-> HBM transfer for tests and benchmarks) ---- */
+/* Kernel arithmetic mode. PLR_MATH_EXACT: every pass evaluates the shader's operations in source order with IEEE divide/sqrt,
+ * software transcendentals and no FMA contraction (bit-identical to a scalar IEEE evaluation). PLR_MATH_FAST (default): passes
+ * that have a restructured kernel (FMA, v_rcp/v_rsq/v_exp/v_log, LDS tiling, algebraic simplification) use it; results stay
+ * within the per-pass tolerances stated in DESIGN.md. Integer/bit-exact outputs (histogram, HiZ, culling) are identical in both. */
+#define PLR_MATH_EXACT 0
+#define PLR_MATH_FAST 1
+int plr_set_math_mode(int mode);
+int plr_get_math_mode(int* out_mode);
 int plr_set_pass_timing(int enabled);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
 int plr_get_last_frame_gpu_time(float* out_ms);

@@ -15,6 +15,10 @@ OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(HERE, "libplr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+# kernels_fast/*.hip: restructured kernels for PLR_MATH_FAST. FMA contraction on, divide/sqrt may use the v_rcp/v_rsq based
+# sequences; still no -ffast-math (NaN guards and comparisons keep IEEE semantics).
+FAST_FLAGS_REPLACE = {"-ffp-contract=off": "-ffp-contract=fast", "-fhip-fp32-correctly-rounded-divide-sqrt": "-fno-hip-fp32-correctly-rounded-divide-sqrt"}
+
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
@@ -24,7 +28,7 @@ FLAGS = [
 
 def _sources():
     out = [os.path.join(CSRC, "backend.cpp")]
-    for sub in ("kernels", "frontend"):
+    for sub in ("kernels", "kernels_fast", "frontend"):
         d = os.path.join(CSRC, sub)
         if os.path.isdir(d):
             for f in sorted(os.listdir(d)):
@@ -43,7 +47,7 @@ def _headers_digest():
                 if f.endswith((".h", ".hpp")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + sorted(FAST_FLAGS_REPLACE.values())).encode())
     return h.hexdigest()
 
 
@@ -54,7 +58,10 @@ def _compile(src, digest, verbose):
         key = hashlib.sha1(fh.read() + digest.encode()).hexdigest()
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == key:
         return obj, False
-    cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+    flags = FLAGS
+    if os.sep + "kernels_fast" + os.sep in src:
+        flags = [FAST_FLAGS_REPLACE.get(f, f) for f in FLAGS]
+    cmd = [HIPCC, "-x", "hip"] + flags + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -18,19 +18,26 @@
 namespace plr {
 
 // ---------------------------------------------------------------- registry
-struct ShaderEntry { std::string name; LaunchFn fn; };
+struct ShaderEntry { std::string name; LaunchFn fn = nullptr; LaunchFn fast = nullptr; };
 static std::vector<ShaderEntry>& registry() {
     static std::vector<ShaderEntry> r;
     return r;
 }
-ShaderRegistrar::ShaderRegistrar(const char* name, LaunchFn fn) { registry().push_back({name, fn}); }
+ShaderRegistrar::ShaderRegistrar(const char* name, LaunchFn fn, bool fast) {
+    for (auto& e : registry())
+        if (e.name == name) { (fast ? e.fast : e.fn) = fn; return; }
+    ShaderEntry e;
+    e.name = name;
+    (fast ? e.fast : e.fn) = fn;
+    registry().push_back(e);
+}
 
-static LaunchFn findShader(const std::string& path) {
+static const ShaderEntry* findShader(const std::string& path) {
     std::string base = path;
     const size_t slash = base.find_last_of("/\\");
     if (slash != std::string::npos) base = base.substr(slash + 1);
     for (const auto& e : registry())
-        if (e.name == base) return e.fn;
+        if (e.name == base && e.fn) return &e;
     return nullptr;
 }
 
@@ -138,7 +145,7 @@ struct BufferRes {
 struct PassRes {
     std::string shader, name;
     std::vector<SpecConstant> spec;
-    LaunchFn fn = nullptr;
+    LaunchFn fn = nullptr, fast = nullptr;
     void* scratch = nullptr;
     size_t scratchSize = 0;
 };
@@ -176,6 +183,7 @@ struct Backend {
     bool bindlessDirty = true;
     uint64_t allocated = 0;
     bool passTiming = false;
+    int mathMode = PLR_MATH_FAST;
     std::vector<hipEvent_t> passEvents; // 2 per execution
     std::vector<plr_renderpass_time> lastTimings;
     size_t timedExecutions = 0;
@@ -437,11 +445,12 @@ int plr_set_global_descriptor_set_resources(const plr_pass_resources* r) {
 
 static int fillPass(PassRes& p, const plr_compute_pass_desc* desc) {
     if (!desc || !desc->src_path_relative) return setErr(PLR_ERR_INVALID_ARGUMENT, "pass description / shader path is null");
-    LaunchFn fn = findShader(desc->src_path_relative);
-    if (!fn) return setErr(PLR_ERR_UNKNOWN_SHADER, std::string("no HIP kernel for shader '") + desc->src_path_relative + "'");
+    const ShaderEntry* entry = findShader(desc->src_path_relative);
+    if (!entry) return setErr(PLR_ERR_UNKNOWN_SHADER, std::string("no HIP kernel for shader '") + desc->src_path_relative + "'");
     p.shader = desc->src_path_relative;
     if (desc->name) p.name = desc->name;
-    p.fn = fn;
+    p.fn = entry->fn;
+    p.fast = entry->fast;
     p.spec.clear();
     for (uint32_t i = 0; i < desc->specialisation_constant_count; i++) {
         const auto& s = desc->specialisation_constants[i];
@@ -535,7 +544,7 @@ static int launchAll(bool timed) {
         x.ctx.scratchSlot = &p.scratch;
         x.ctx.scratchSize = &p.scratchSize;
         if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
-        int rc = p.fn(x.ctx);
+        int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : p.fn(x.ctx);
         if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
         if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
     }
@@ -677,6 +686,14 @@ int plr_get_memory_stats(uint64_t* out_allocated_size, uint64_t* out_used_size) 
     if (out_used_size) *out_used_size = g->allocated;
     return PLR_OK;
 }
+
+int plr_set_math_mode(int mode) {
+    NEED_INIT();
+    if (mode != PLR_MATH_EXACT && mode != PLR_MATH_FAST) return setErr(PLR_ERR_INVALID_ARGUMENT, "math mode must be PLR_MATH_EXACT or PLR_MATH_FAST");
+    g->mathMode = mode;
+    return PLR_OK;
+}
+int plr_get_math_mode(int* out_mode) { NEED_INIT(); *out_mode = g->mathMode; return PLR_OK; }
 
 int plr_set_pass_timing(int enabled) { NEED_INIT(); g->passTiming = enabled != 0; return PLR_OK; }
 

@@ -67,9 +67,11 @@ struct PassCtx {
 typedef int (*LaunchFn)(const PassCtx&);
 
 struct ShaderRegistrar {
-    ShaderRegistrar(const char* name, LaunchFn fn);
+    ShaderRegistrar(const char* name, LaunchFn fn, bool fast = false);
 };
 #define PLR_REGISTER_SHADER(name, fn) static ::plr::ShaderRegistrar plr_registrar_##fn(name, fn)
+// restructured / fast-math variant of a shader, used when the math mode is PLR_MATH_FAST (kernels_fast/*.hip)
+#define PLR_REGISTER_SHADER_FAST(name, fn) static ::plr::ShaderRegistrar plr_registrar_fast_##fn(name, fn, true)
 
 inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 

@@ -1,0 +1,155 @@
+// PLR_MATH_FAST variant of filterIndirectDiffuseSpatial.comp:30-135 (exact variant: kernels/gi_filters.hip).
+//
+// Same samples, same weights, same accumulation order; what changes is how each quantity is computed:
+//  * pixelToWorld(uv) = camPos + cameraToPixel / dot(cameraToPixel, forward) * depthLinear. cameraToPixel is the normalised
+//    vector forward - tan*ndc.y*up + tan*aspect*ndc.x*right; with an orthonormal camera basis the normalisation cancels against
+//    the dot product, so the position is camPos + (forward - tan*ndc.y*up + tan*aspect*ndc.x*right) * depthLinear: no sqrt, no
+//    divide per sample.
+//  * the sample's clip position is affine in the disc offset: clip = VP*pCenter + ox*(VP*R*tangent) + oy*(VP*R*bitangent); the three
+//    projected vectors are computed once per pixel (only x, y, w rows are needed).
+//  * distance to the tangent plane |dot(N, pixelWorld - pCenter)| = |dot(N, camPos - pCenter) + depthLinear * dot(N, ray)| with
+//    dot(N, ray) affine in the sample's NDC.
+//  * divisions are v_rcp_f32 multiplies, FMA contraction is on.
+// Per sample this is ~45 VALU operations + 3 gathers instead of ~180 + 3. Results differ from the exact kernel by float
+// rounding only (stated tolerance in tests/test_fast_kernels.py); nearest-texel selection and the off-screen test are the
+// discontinuities where a last-bit difference can pick a neighbouring texel.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+
+template <int DEPTH_FMT>
+__global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
+                                                               const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH) {
+    __shared__ float sqrtRand[32], cosA[32], sinA[32];
+    if (threadIdx.x < 32) {
+        uint32_t rngState = wang_hash(g->frameIndexMod4 + (uint32_t)filterIndex);
+        const int i = (int)threadIdx.x;
+        float r0 = 0.f, r1 = 0.f;
+        for (int k = 0; k <= i; k++) { r0 = rand01(rngState); r1 = rand01(rngState); }
+        sqrtRand[i] = sqrtf(r0);
+        float s, c;
+        det_sincosf(2.f * PLR_GLSL_PI * r1, &s, &c);
+        cosA[i] = c; sinA[i] = s;
+    }
+    __syncthreads();
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+
+    const float nearP = g->nearPlane, farP = g->farPlane;
+    const float nf = nearP * farP, nmf = nearP - farP;
+    const vec3 fwd = ld3(g->cameraForward), up = ld3(g->cameraUp), right = ld3(g->cameraRight), camPos = ld3(g->cameraPosition);
+    const float tanH = g->cameraTanFovHalf, tanA = g->cameraTanFovHalf * g->cameraAspectRatio;
+    const float dW = (float)depthTexture.w, dH = (float)depthTexture.h;
+    const int dwi = depthTexture.w, dhi = depthTexture.h;
+
+    auto depthLinearAt = [&](float u, float v) -> float {
+        const int x = min(max((int)floorf(u * dW), 0), dwi - 1), y = min(max((int)floorf(v * dH), 0), dhi - 1);
+        const float d = Texel<DEPTH_FMT>::load(depthTexture.ptr, (size_t)y * (size_t)dwi + (size_t)x).x;
+        return nf * rcpf(farP + (1.f - d) * nmf);
+    };
+    auto worldAt = [&](float u, float v) -> vec3 {
+        const float lin = depthLinearAt(u, v);
+        const float nx = u * 2.f - 1.f, ny = v * 2.f - 1.f;
+        const vec3 ray = fwd + (-tanH * ny) * up + (tanA * nx) * right;
+        return camPos + ray * lin;
+    };
+
+    const float tsx = 1.f / (float)outYSH.w, tsy = 1.f / (float)outYSH.h;
+    const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
+    const vec3 pCenter = worldAt(u0, v0);
+    const vec3 pRight = worldAt(u0 + tsx, v0);
+    const vec3 pUp = worldAt(u0, v0 + tsy);
+    const vec3 dT = pCenter - pRight, dB = pCenter - pUp;
+    const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
+    const vec3 T = dT * (radiusWorld * __builtin_amdgcn_rsqf(dot(dT, dT)));
+    const vec3 B = dB * (radiusWorld * __builtin_amdgcn_rsqf(dot(dB, dB)));
+    const int nwi = normalTexture.w, nhi = normalTexture.h;
+    vec3 N;
+    {
+        const int x = min(max((int)floorf(u0 * (float)nwi), 0), nwi - 1), y = min(max((int)floorf(v0 * (float)nhi), 0), nhi - 1);
+        N = 2.f * Texel<F_RGBA8>::load(normalTexture.ptr, (size_t)y * (size_t)nwi + (size_t)x).xyz() - 1.f;
+    }
+    // clip.xyw = P0 + ox * PT + oy * PB
+    const float* vp = g->viewProjection;
+    auto projXYW = [&](vec3 p, float w) -> vec3 {
+        return vec3(vp[0] * p.x + vp[4] * p.y + vp[8] * p.z + vp[12] * w, vp[1] * p.x + vp[5] * p.y + vp[9] * p.z + vp[13] * w,
+                    vp[3] * p.x + vp[7] * p.y + vp[11] * p.z + vp[15] * w);
+    };
+    const vec3 P0 = projXYW(pCenter, 1.f), PT = projXYW(T, 0.f), PB = projXYW(B, 0.f);
+    // dot(N, pixelWorld - pCenter) = c0 + lin * (nF + ndcY * nU + ndcX * nR)
+    const float c0 = dot(N, camPos - pCenter);
+    const float nF = dot(N, fwd), nU = -tanH * dot(N, up), nR = tanA * dot(N, right);
+
+    vec4 result_Y_SH(0.f);
+    float resCo = 0.f, resCg = 0.f;
+    float weightTotal = 0.f;
+    float lengthModifier = 1.f;
+    const int ywi = inYSH.w, yhi = inYSH.h;
+    const float yW = (float)ywi, yH = (float)yhi;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        const float d = sqrtRand[i] * lengthModifier;
+        const float ox = cosA[i] * d, oy = sinA[i] * d;
+        const vec3 clip = P0 + ox * PT + oy * PB;
+        const float invW = rcpf(clip.z);
+        float su = clip.x * invW * 0.5f + 0.5f, sv = clip.y * invW * 0.5f + 0.5f;
+        su = su < 0.f ? u0 - ox : su;
+        sv = sv < 0.f ? v0 - oy : sv;
+        su = su > 1.f ? u0 - ox : su;
+        sv = sv > 1.f ? v0 - oy : sv;
+        const float lin = depthLinearAt(su, sv);
+        const float dist = fabsf(c0 + lin * (nF + (sv * 2.f - 1.f) * nU + (su * 2.f - 1.f) * nR));
+        float weight = gclamp(0.25f * rcpf(gmax(dist, 0.0001f)), 0.f, 1.f);
+        weight *= weight;
+        if (su < 0.f || sv < 0.f || su > 1.f || sv > 1.f) {
+            weight = 0.f;
+            lengthModifier *= 0.98f;
+        }
+        if (weight > 0.f) {
+            const int x = min(max((int)floorf(su * yW), 0), ywi - 1), y = min(max((int)floorf(sv * yH), 0), yhi - 1);
+            const size_t ti = (size_t)y * (size_t)ywi + (size_t)x;
+            const vec4 s = Texel<F_RGBA16F>::load(inYSH.ptr, ti);
+            const vec4 cc = Texel<F_RG16F>::load(inCoCg.ptr, ti);
+            if (!(anyNan(s) || cc.x != cc.x || cc.y != cc.y)) {
+                result_Y_SH = result_Y_SH + weight * s;
+                resCo += weight * cc.x;
+                resCg += weight * cc.y;
+                weightTotal += weight;
+            }
+        }
+    }
+    const float inv = rcpf(gmax(weightTotal, 0.00001f));
+    const size_t idx = (size_t)py * (size_t)outYSH.w + px;
+    Texel<F_RGBA16F>::store(outYSH.ptr, idx, result_Y_SH * inv);
+    Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(resCo * inv, resCg * inv, 0.f, 0.f));
+}
+
+static int launchSpatialFilterFast(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "filterIndirectDiffuseSpatial imageOut_Y_SH")) return rc;
+    if (int rc = c.needStorage(1, F_RG16F, "filterIndirectDiffuseSpatial imageOut_CoCg")) return rc;
+    if (int rc = c.needSampled(2, F_RGBA16F, "filterIndirectDiffuseSpatial texture_Y_SH")) return rc;
+    if (int rc = c.needSampled(3, F_RG16F, "filterIndirectDiffuseSpatial texture_CoCg")) return rc;
+    if (int rc = c.needSampled(4, -1, "filterIndirectDiffuseSpatial depthTexture")) return rc;
+    if (int rc = c.needSampled(5, F_RGBA8, "filterIndirectDiffuseSpatial normalTexture")) return rc;
+    if (c.sampled[3].w != c.sampled[2].w || c.sampled[3].h != c.sampled[2].h) return c.fail(-4, "filterIndirectDiffuseSpatial: Y_SH and CoCg inputs differ in size");
+    const int filterIndex = c.specInt(0, 0);
+    const ImgView& out = c.storage[0];
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u));
+    if (c.sampled[4].fmt == F_R16F)
+        spatialFilterFastKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h);
+    else if (c.sampled[4].fmt == F_D32)
+        spatialFilterFastKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h);
+    else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseSpatial.comp", launchSpatialFilterFast);
+
+} // namespace plr

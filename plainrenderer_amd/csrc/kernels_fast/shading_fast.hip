@@ -1,0 +1,338 @@
+// PLR_MATH_FAST variant of the deferred shade (exact variant and the description of the re-expression: kernels/shading.hip).
+//
+// Same lighting model term by term; the arithmetic is restructured for the VALU:
+//  * (1-x)^5 Fresnel / CoD terms are x2*x2*x instead of exp2(5*log2(x)); the remaining pow/log/exp use v_log_f32 / v_exp_f32
+//  * world position = camPos + (forward - tan*ndc.y*up + tan*aspect*ndc.x*right) * depthLinear (the normalisation of the view ray
+//    cancels against the division by dot(ray, forward)); normalisations use v_rsq_f32, divisions v_rcp_f32, FMA contraction is on
+//  * the 12 PCF tap directions are one hardware sin/cos of the per-pixel noise angle rotated by a constant 12-entry table
+//  * directionToSH_L1 of a unit vector has a constant norm, so its normalize() is two constants
+// Output is R11G11B10 (6/5-bit mantissas); stated tolerance in tests/test_fast_kernels.py. A PCF tap whose depth comparison sits
+// within rounding of equality can flip (1/12 of the sun term for that pixel).
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+namespace fastshade {
+
+PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
+PLR_DI float log2h(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (base 2)
+PLR_DI float exp2h(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (base 2)
+PLR_DI vec3 nrm(vec3 v) { return v * rsqf(dot(v, v)); }
+PLR_DI float pow5(float x) { x = gmax(x, 0.f); const float x2 = x * x; return x2 * x2 * x; }
+PLR_DI float fpow(float x, float y) { return x <= 0.f ? 0.f : exp2h(y * log2h(x)); }
+
+PLR_DI float D_GGX(float NoH, float r) {
+    const float a = NoH * r;
+    const float k = r * rcpf(1.0f - NoH * NoH + a * a);
+    return k * k * (1.0f / PLR_GLSL_PI);
+}
+PLR_DI float Visibility(float NoV, float NoL, float r) {
+    const float r_2 = r * r;
+    const float v1 = NoL * sqrtf(NoV * NoV * (1.f - r_2) + r_2);
+    const float v2 = NoV * sqrtf(NoL * NoL * (1.f - r_2) + r_2);
+    return 0.5f * rcpf(v1 + v2);
+}
+PLR_DI vec3 F_Schlick(vec3 f0, vec3 f90, float VoH) { return f0 + (f90 - f0) * pow5(1.f - VoH); }
+PLR_DI vec3 DisneyDiffuse(vec3 diffuseColor, float NoL, float VoH, float NoV, float r) {
+    const float energyBias = 0.5f * r;
+    const float energyFactor = gmix(1.f, 1.f / 1.51f, r);
+    const float f90 = energyBias + 2.f * VoH * VoH * r;
+    const float fl = 1.f + (f90 - 1.f) * pow5(1.f - NoL), fv = 1.f + (f90 - 1.f) * pow5(1.f - NoV);
+    return diffuseColor * ((1.f / PLR_GLSL_PI) * fl * fv * energyFactor);
+}
+PLR_DI vec3 CoDWWIIDiffuse(vec3 diffuseColor, float NoL, float VoH, float NoV, float NoH, float r) {
+    const float f0Diffuse = VoH + pow5(1.f - VoH);
+    const float f1 = (1.f - 0.75f * pow5(1.f - NoL)) * (1.f - 0.75f * pow5(1.f - NoV));
+    const float g = log2h(2.f * rcpf(r * r) - 1.f) * (1.f / 18.f);
+    const float t = gclamp(2.2f * g - 0.5f, 0.f, 1.f);
+    const float fd = f0Diffuse + (f1 - f0Diffuse) * t;
+    const float fb = (34.5f * g * g - 59.f * g + 24.5f) * VoH * exp2h(-gmax(73.2f * g - 21.2f, 8.9f) * sqrtf(NoH));
+    return diffuseColor * ((1.f / PLR_GLSL_PI) * (fd + fb));
+}
+PLR_DI float Titanfall2DiffuseSingleComponent(float NoL, float LoV, float NoV, float NoH, float r) {
+    const float facing = 0.5f + 0.5f * LoV;
+    const float rough = facing * (0.9f - 0.4f * facing) * (0.5f + NoH) * rcpf(gmax(NoH, 0.03f));
+    const float smoothDiffuse = 1.05f * (1.f - pow5(1.f - NoL)) * (1.f - pow5(1.f - NoV));
+    return (1.f / PLR_GLSL_PI) * gmix(smoothDiffuse, rough, r);
+}
+PLR_DI vec3 GGXSingleScattering(float r, vec3 f0, float NoH, float NoV, float VoH, float NoL) {
+    return (D_GGX(NoH, r) * Visibility(NoV, NoL, r)) * F_Schlick(f0, vec3(1.f), VoH);
+}
+PLR_DI float ReflectedEnergyAverage(float roughness) {
+    const float smoothness = 1.f - sqrtf(roughness);
+    float r = -0.0761947f - 0.383026f * smoothness;
+    r = 1.04997f + smoothness * r;
+    r = 0.409255f + smoothness * r;
+    return gmin(0.999f, r);
+}
+PLR_DI float sRGBToLinear1(float c) { return c <= 0.004045f ? c * (1.f / 12.92f) : fpow((c + 0.055f) * (1.f / 1.055f), 2.4f); }
+
+struct ShadeParams {
+    ImgView color, depth, normal, albedo, specular, brdfLut, shadowMaps[4], ysh, cocg, volumetricLut, skyLut;
+    const LightBuffer* light;
+    const ShadowCascadeInfo* shadowInfo;
+    const VolumetricLightingSettings* vol;
+    const GlobalUbo* g;
+    const ImgView* bindless;
+    uint32_t bindlessCount;
+    uint32_t cascadeCount;
+    int coverW, coverH;
+};
+
+PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
+    x = clampi(x, normalTexture.w);
+    y = clampi(y, normalTexture.h);
+    const vec3 raw = Texel<F_RGBA8>::load(normalTexture.ptr, (size_t)y * (size_t)normalTexture.w + x).xyz() * 2.f - 1.f;
+    const vec3 N = nrm(raw);
+    return anyNan(N) ? raw : N;
+}
+
+// cos / sin of 2*pi*i/12
+__constant__ const float kTapCos[12] = {1.f, 0.8660254f, 0.5f, 0.f, -0.5f, -0.8660254f, -1.f, -0.8660254f, -0.5f, 0.f, 0.5f, 0.8660254f};
+__constant__ const float kTapSin[12] = {0.f, 0.5f, 0.8660254f, 1.f, 0.8660254f, 0.5f, 0.f, -0.5f, -0.8660254f, -1.f, -0.8660254f, -0.5f};
+
+PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMatrix, vec2 lightSpaceScale, float noise) {
+    vec4 p = mulMat4(lightMatrix, vec4(pos, 1.f));
+    const float iw = rcpf(p.w);
+    const float bx = p.x * iw * 0.5f + 0.5f, by = p.y * iw * 0.5f + 0.5f;
+    const float actualDepth = gclamp(p.z * iw, 0.f, 1.f);
+    const float sx = 0.03f * lightSpaceScale.x, sy = 0.03f * lightSpaceScale.y;
+    const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
+    const float fw = (float)shadowMap.w, fh = (float)shadowMap.h;
+    const uint16_t* sm = (const uint16_t*)shadowMap.ptr;
+    float shadow = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const float d = sqrtf(((float)i + 0.5f * noise) * (1.f / 12.f));
+        const float ca = c0 * kTapCos[i] - s0 * kTapSin[i], sa = s0 * kTapCos[i] + c0 * kTapSin[i];
+        const float u = bx + ca * (sx * d), v = by + sa * (sy * d);
+        const int x = (int)floorf(u * fw), y = (int)floorf(v * fh);
+        float depthTexel = 0.f; // nearest, black border
+        if (x >= 0 && y >= 0 && x < shadowMap.w && y < shadowMap.h) depthTexel = (float)sm[(size_t)y * (size_t)shadowMap.w + x] * (1.f / 65535.f);
+        shadow += (actualDepth >= depthTexel) ? 1.f : 0.f;
+    }
+    return shadow * (1.f / 12.f);
+}
+
+template <int MULTISCATTER>
+PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, float NoL, vec3 f0, vec3 singleScatteringLobe, vec3 brdfLut) {
+    const float energyOutgoing = brdfLut.y;
+    const vec3 fresnelAverage = f0 + (1.f - f0) * (1.f / 21.f);
+    if (MULTISCATTER == 0) {
+        const float energyAverage = ReflectedEnergyAverage(r);
+        const float energyIncoming = sampleLinear2D<F_RGBA16F, CLAMP>(brdfLutTex, vec2(r, NoL)).y;
+        const float unscaled = (1.f - energyIncoming) * (1.f - energyOutgoing) * rcpf(3.1415f * (1.f - energyAverage));
+        const vec3 den = 1.f - fresnelAverage * (1.f - energyAverage);
+        const vec3 scaling = (fresnelAverage * fresnelAverage * energyAverage) * vec3(rcpf(den.x), rcpf(den.y), rcpf(den.z));
+        return unscaled * scaling;
+    } else if (MULTISCATTER == 1) {
+        const float lobe = (1.f - energyOutgoing) * (1.f / PLR_GLSL_PI);
+        const vec3 den = 1.f - fresnelAverage * (1.f - energyOutgoing);
+        return (fresnelAverage * fresnelAverage * (energyOutgoing * lobe)) * vec3(rcpf(den.x), rcpf(den.y), rcpf(den.z));
+    } else if (MULTISCATTER == 2) {
+        return f0 * (rcpf(energyOutgoing) - 1.f) * singleScatteringLobe;
+    }
+    return vec3(0.f);
+}
+
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
+__global__ __launch_bounds__(256) void deferredShadingFastKernel(ShadeParams P) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= P.coverW || py >= P.coverH) return;
+    const GlobalUbo* g = P.g;
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const float su = fx * rcpf((float)g->screenResolution[0]), sv = fy * rcpf((float)g->screenResolution[1]);
+    const size_t idx = (size_t)py * (size_t)P.color.w + px;
+    const float depth = texelFetch2D<F_D32>(P.depth, px, py).x;
+    const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
+    const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
+    const vec3 ray = camFwd + (-g->cameraTanFovHalf * ndy) * ld3(g->cameraUp) + (g->cameraTanFovHalf * g->cameraAspectRatio * ndx) * ld3(g->cameraRight);
+    if (depth == 0.f) {
+        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(sampleSkyLut(nrm(ray), P.skyLut));
+        return;
+    }
+    const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
+    const vec3 toPixel = ray * depthLinear; // passPos - camPos
+    const vec3 passPos = camPos + toPixel;
+
+    const vec3 albedoTexel = texelFetch2D<F_RGBA8>(P.albedo, px, py).xyz();
+    const vec3 specularTexel = texelFetch2D<F_RGBA8>(P.specular, px, py).xyz();
+    const float metalic = specularTexel.z;
+    float r = specularTexel.y;
+    r = gmax(r * r, 0.0045f);
+    const vec3 albedo(sRGBToLinear1(albedoTexel.x), sRGBToLinear1(albedoTexel.y), sRGBToLinear1(albedoTexel.z));
+    const vec3 diffuseColor = (1.f - metalic) * albedo;
+    const vec3 N = gbufferNormal(P.normal, px, py);
+    const vec3 L = nrm(ld3(g->sunDirection));
+    const float pixelDepth = depthLinear; // dot(camPos - passPos, -forward) = depthLinear * dot(ray, forward) = depthLinear
+    const vec3 V = -nrm(ray);
+    const vec3 H = nrm(V + L);
+    if (GEOMETRIC_AA) {
+        const int xl = px & ~1, yl = py & ~1;
+        const vec3 Nn = (px & 1) ? gbufferNormal(P.normal, xl, py) : gbufferNormal(P.normal, xl + 1, py);
+        const vec3 Nm = (py & 1) ? gbufferNormal(P.normal, px, yl) : gbufferNormal(P.normal, px, yl + 1);
+        const vec3 N_U = Nn - N, N_V = Nm - N; // sign is irrelevant: only squared lengths are used
+        const float variance = 0.25f * (dot(N_V, N_V) + dot(N_U, N_U));
+        const float kernelRoughness2 = gmin(2.f * variance, 0.18f);
+        r = gclamp(sqrtf(r * r + kernelRoughness2), 0.f, 1.f);
+    }
+    const float NoH = gmax(dot(N, H), 0.f);
+    const float NdotL = dot(N, L);
+    const float NoL = gclamp(NdotL, 0.f, 1.f);
+    const float VoH = fabsf(dot(V, H));
+    const float LoV = gmax(dot(L, V), 0.f);
+    const float NoV = gmax(fabsf(dot(N, V)), 0.0001f);
+    const vec3 f0 = vmix(vec3(0.04f), albedo, metalic);
+
+    const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
+    const ImgView noiseTex = P.bindless[min(noiseSlot, P.bindlessCount - 1u)];
+    const vec4 noiseTexel = Texel<F_RG8>::load(noiseTex.ptr, (size_t)repeati(py, noiseTex.h) * (size_t)noiseTex.w + (size_t)repeati(px, noiseTex.w));
+
+    int cascadeIndex = 0;
+    for (int cascade = 0; cascade < (int)P.cascadeCount - 1; cascade++) cascadeIndex += (pixelDepth >= P.shadowInfo->splits[cascade]) ? 1 : 0;
+    cascadeIndex = min(cascadeIndex, 3);
+    const vec2 lss(P.shadowInfo->lightSpaceScale[cascadeIndex][0], P.shadowInfo->lightSpaceScale[cascadeIndex][1]);
+    float sunShadow;
+    if (cascadeIndex == 0) sunShadow = calcShadow(passPos, P.shadowMaps[0], P.shadowInfo->lightMatrices[0], lss, noiseTexel.x);
+    else if (cascadeIndex == 1) sunShadow = calcShadow(passPos, P.shadowMaps[1], P.shadowInfo->lightMatrices[1], lss, noiseTexel.x);
+    else if (cascadeIndex == 2) sunShadow = calcShadow(passPos, P.shadowMaps[2], P.shadowInfo->lightMatrices[2], lss, noiseTexel.x);
+    else sunShadow = calcShadow(passPos, P.shadowMaps[3], P.shadowInfo->lightMatrices[3], lss, noiseTexel.x);
+    const vec3 directLighting = (gmax(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
+    const vec3 brdfLut = sampleLinear2D<F_RGBA16F, CLAMP>(P.brdfLut, vec2(r, NoV)).xyz();
+
+    vec3 diffuseDirect;
+    vec3 diffuseBRDFIntegral(brdfLut.z);
+    if (DIFFUSE_BRDF == 0) diffuseDirect = diffuseColor * (1.f / PLR_GLSL_PI) * directLighting;
+    else if (DIFFUSE_BRDF == 1) diffuseDirect = DisneyDiffuse(diffuseColor, NoL, VoH, NoV, r) * directLighting;
+    else if (DIFFUSE_BRDF == 2) diffuseDirect = CoDWWIIDiffuse(diffuseColor, NoL, VoH, NoV, NoH, r) * directLighting;
+    else {
+        const float single = Titanfall2DiffuseSingleComponent(NoL, LoV, NoV, NoH, r);
+        diffuseDirect = diffuseColor * (single + diffuseColor * (0.1159f * r)) * directLighting;
+        float multiIntegral = 0.1159f * r * PLR_GLSL_PI * 2.f;
+        multiIntegral *= (1.f - (0.04f + 0.96f * pow5(1.f - NoV)));
+        multiIntegral *= 0.94291f;
+        diffuseBRDFIntegral = vmin(vec3(brdfLut.z) + diffuseColor * multiIntegral, vec3(1.f));
+    }
+    diffuseDirect = diffuseDirect * ((1.f - F_Schlick(f0, vec3(1.f), NoV)) * (1.f - F_Schlick(f0, vec3(1.f), NoL)));
+
+    const vec3 singleScatteringLobe = GGXSingleScattering(r, f0, NoH, NoV, VoH, NoL);
+    const vec3 multiScatteringLobe = specularMultiscatteringLobe<MULTISCATTER>(P.brdfLut, r, NoL, f0, singleScatteringLobe, brdfLut);
+    const vec3 specularDirect = directLighting * (singleScatteringLobe + multiScatteringLobe);
+
+    vec3 lightingIndirect;
+    if (INDIRECT_TECH == 0) {
+        const int ix = min(max((int)floorf(su * (float)P.ysh.w), 0), P.ysh.w - 1), iy = min(max((int)floorf(sv * (float)P.ysh.h), 0), P.ysh.h - 1);
+        const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, (size_t)iy * (size_t)P.ysh.w + ix);
+        const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, (size_t)iy * (size_t)P.cocg.w + ix);
+        // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
+        const vec4 shN(0.5f, -0.8660254f * N.y, 0.8660254f * N.z, -0.8660254f * N.x);
+        const float irradiance_Y = dot(irradiance_Y_SH, shN);
+        const vec3 irradiance = YCoCgToLinear(vec3(irradiance_Y, cc.x, cc.y));
+        const vec3 diffuseIndirect = irradiance * diffuseColor * diffuseBRDFIntegral;
+        const vec3 dominantDirection = dominantDirectionFromSH_L1(irradiance_Y_SH);
+        const float dominantDirectionLength = gclamp(sqrtf(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
+        const float r_indirect = gmix(1.f, r, sqrtf(dominantDirectionLength));
+        const vec3 L_indirect = dominantDirection * rcpf(dominantDirectionLength);
+        const vec3 H_indirect = nrm(L_indirect + V);
+        const float NoH_indirect = gmax(dot(N, H_indirect), 0.f);
+        const float NoL_indirect = gmax(dot(N, L_indirect), 0.f);
+        const float VoH_indirect = gmax(dot(V, H_indirect), 0.f);
+        const vec3 single_i = GGXSingleScattering(r_indirect, f0, NoH_indirect, NoV, VoH_indirect, NoL_indirect);
+        const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P.brdfLut, r_indirect, NoL_indirect, f0, single_i, brdfLut);
+        const vec3 specularIndirect = (single_i + multi_i) * YCoCgToLinear(vec3(irradiance_Y_SH.x, cc.x, cc.y));
+        lightingIndirect = diffuseIndirect + specularIndirect;
+    } else {
+        const float amb = 0.003f * P.light->sunStrengthExposed;
+        const vec3 singleScattering = vmix(vec3(brdfLut.x), vec3(brdfLut.y), f0);
+        lightingIndirect = (amb * diffuseColor) * diffuseBRDFIntegral + singleScattering * amb;
+    }
+    vec3 outColor = (diffuseDirect + specularDirect) * P.light->sunStrengthExposed + lightingIndirect;
+    {
+        // applyVolumetricLighting: froxel z = log(linear * (e^3 - 1) + 1) / 3
+        const float nu = su + (noiseTexel.x - 0.5f) * 0.013f, nv = sv + (noiseTexel.y - 0.5f) * 0.013f;
+        const float linear = pixelDepth * rcpf(P.vol->maxDistance);
+        const float z = log2h(linear * 19.0855369f + 1.f) * (0.693147181f / 3.f);
+        const ImgView& vol = P.volumetricLut;
+        int i0, j0, k0; float a, b, c;
+        linearCoord(nu * (float)vol.w, &i0, &a);
+        linearCoord(nv * (float)vol.h, &j0, &b);
+        linearCoord(z * (float)vol.d, &k0, &c);
+        const int x0 = clampi(i0, vol.w), x1 = clampi(i0 + 1, vol.w);
+        const size_t y0 = (size_t)clampi(j0, vol.h) * vol.w, y1 = (size_t)clampi(j0 + 1, vol.h) * vol.w;
+        const size_t sl = (size_t)vol.w * vol.h;
+        const size_t z0 = (size_t)clampi(k0, vol.d) * sl, z1 = (size_t)clampi(k0 + 1, vol.d) * sl;
+        auto T = [&](size_t i) { return Texel<F_RGBA16F>::load(vol.ptr, i); };
+        const vec4 lo = vmix(vmix(T(z0 + y0 + x0), T(z0 + y0 + x1), a), vmix(T(z0 + y1 + x0), T(z0 + y1 + x1), a), b);
+        const vec4 hi = vmix(vmix(T(z1 + y0 + x0), T(z1 + y0 + x1), a), vmix(T(z1 + y1 + x0), T(z1 + y1 + x1), a), b);
+        const vec4 it = vmix(lo, hi, c);
+        outColor = outColor * it.w + it.xyz();
+    }
+    ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(outColor);
+}
+
+typedef void (*ShadeKernel)(ShadeParams);
+template <int D, int M, bool G> static ShadeKernel pickIndirect(int tech) {
+    return tech == 0 ? (ShadeKernel)deferredShadingFastKernel<D, M, G, 0> : (ShadeKernel)deferredShadingFastKernel<D, M, G, 1>;
+}
+template <int D, int M> static ShadeKernel pickAA(bool aa, int tech) { return aa ? pickIndirect<D, M, true>(tech) : pickIndirect<D, M, false>(tech); }
+template <int D> static ShadeKernel pickMulti(int m, bool aa, int tech) {
+    switch (m) {
+        case 0: return pickAA<D, 0>(aa, tech);
+        case 1: return pickAA<D, 1>(aa, tech);
+        case 2: return pickAA<D, 2>(aa, tech);
+        default: return pickAA<D, 3>(aa, tech);
+    }
+}
+
+static int launchDeferredShadingFast(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_R11G11B10, "deferredShading colour target")) return rc;
+    if (int rc = c.needSampled(3, F_RGBA16F, "deferredShading brdfLutTexture")) return rc;
+    if (int rc = c.needSbuf(7, sizeof(LightBuffer), "deferredShading lightBuffer")) return rc;
+    if (int rc = c.needSbuf(8, sizeof(ShadowCascadeInfo), "deferredShading sunShadowInfo")) return rc;
+    for (int i = 0; i < 4; i++) if (int rc = c.needSampled(9 + i, F_D16, "deferredShading shadowMapCascade")) return rc;
+    if (int rc = c.needSampled(15, F_RGBA16F, "deferredShading indirectDiffuse_Y_SH")) return rc;
+    if (int rc = c.needSampled(16, F_RG16F, "deferredShading indirectDiffuse_CoCg")) return rc;
+    if (int rc = c.needSampled(18, F_RGBA16F, "deferredShading volumetricLightingLUT")) return rc;
+    if (int rc = c.needUbuf(19, 52, "deferredShading volumetric settings")) return rc;
+    if (int rc = c.needSampled(20, F_D32, "deferredShading depth")) return rc;
+    if (int rc = c.needSampled(21, F_RGBA8, "deferredShading world normals")) return rc;
+    if (int rc = c.needSampled(22, F_RGBA8, "deferredShading albedo")) return rc;
+    if (int rc = c.needSampled(23, F_RGBA8, "deferredShading specular")) return rc;
+    if (int rc = c.needSampled(24, F_R11G11B10, "deferredShading skyLut")) return rc;
+    if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "deferredShading: global texture array (set 2) is empty");
+    if (c.sampled[16].w != c.sampled[15].w || c.sampled[16].h != c.sampled[15].h) return c.fail(-4, "deferredShading: Y_SH and CoCg differ in size");
+    const int diffuseBRDF = c.specInt(0, 0), multi = c.specInt(1, 0), tech = c.specInt(3, 0);
+    const bool aa = c.specBool(2, false);
+    const uint32_t cascades = c.specUint(4, 4u);
+    if (diffuseBRDF < 0 || diffuseBRDF > 3 || multi < 0 || multi > 3 || cascades < 1 || cascades > 4) return c.fail(-1, "deferredShading: specialisation constant out of range");
+    ShadeKernel k = nullptr;
+    switch (diffuseBRDF) {
+        case 0: k = pickMulti<0>(multi, aa, tech); break;
+        case 1: k = pickMulti<1>(multi, aa, tech); break;
+        case 2: k = pickMulti<2>(multi, aa, tech); break;
+        default: k = pickMulti<3>(multi, aa, tech); break;
+    }
+    ShadeParams P{};
+    P.color = c.storage[0]; P.depth = c.sampled[20]; P.normal = c.sampled[21]; P.albedo = c.sampled[22]; P.specular = c.sampled[23];
+    P.brdfLut = c.sampled[3];
+    for (int i = 0; i < 4; i++) P.shadowMaps[i] = c.sampled[9 + i];
+    P.ysh = c.sampled[15]; P.cocg = c.sampled[16]; P.volumetricLut = c.sampled[18]; P.skyLut = c.sampled[24];
+    P.light = (const LightBuffer*)c.sbuf[7].ptr; P.shadowInfo = (const ShadowCascadeInfo*)c.sbuf[8].ptr;
+    P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
+    P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
+    P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = std::min((int)(c.dispatch[1] * 8u), P.color.h);
+    if (P.coverW <= 0 || P.coverH <= 0) return 0;
+    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)P.coverH, 4u)), 256, 0, c.stream>>>(P);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace fastshade
+
+static int fastshade_launch(const PassCtx& c) { return fastshade::launchDeferredShadingFast(c); }
+PLR_REGISTER_SHADER_FAST("deferredShading.comp", fastshade_launch);
+} // namespace plr

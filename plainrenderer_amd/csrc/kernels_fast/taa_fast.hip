@@ -1,0 +1,249 @@
+// PLR_MATH_FAST variant of temporalFilter.comp (exact variant: kernels/taa.hip).
+//
+// Same algorithm; restructured where the shader repeats work:
+//  * tonemap(c) = c / (1 + lum(c)) is one v_rcp_f32 and three multiplies instead of three IEEE divisions
+//  * the contrast term only needs luminances, and luminance is linear: lum(tonemap(c)) = lum(c) / (1 + lum(c)) and
+//    lum(bilinear(texels)) = bilinear(lum(texels)). The nine bilinear history taps of sampleNeighbourhood(historyBufferSrc, uv + motion)
+//    sit one texel apart, so they share one 4x4 texel footprint and one pair of sub-texel weights: 16 texel decodes and 27 scalar
+//    lerps replace 36 decodes and 108 vector multiply-adds
+//  * clipAABB uses reciprocals; FMA contraction is on
+// A tap whose 8-bit sub-texel weight sits on a quantisation boundary can differ by 1/256 between neighbouring taps in the exact
+// kernel; here all nine use the centre tap's weights. Stated tolerance: tests/test_fast_kernels.py.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+namespace fasttaa {
+
+PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+PLR_DI float lum(vec3 c) { return c.x * 0.21f + c.y * 0.72f + c.z * 0.07f; }
+PLR_DI vec3 tonemapF(vec3 c) { return c * rcpf(1.f + lum(c)); }
+PLR_DI vec3 tonemapReverseF(vec3 c) { return c * rcpf(1.f - lum(c)); }
+
+PLR_DI vec3 historyTap(const ImgView& im, float u, float v) {
+    int i0, j0; float a, b;
+    linearCoord(u * (float)im.w, &i0, &a);
+    linearCoord(v * (float)im.h, &j0, &b);
+    const uint32_t* base = (const uint32_t*)im.ptr;
+    const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w);
+    const size_t r0 = (size_t)clampi(j0, im.h) * (size_t)im.w, r1 = (size_t)clampi(j0 + 1, im.h) * (size_t)im.w;
+    const vec3 t00 = unpackR11G11B10(base[r0 + x0]), t10 = unpackR11G11B10(base[r0 + x1]);
+    const vec3 t01 = unpackR11G11B10(base[r1 + x0]), t11 = unpackR11G11B10(base[r1 + x1]);
+    const vec3 top = t00 + (t10 - t00) * a, bot = t01 + (t11 - t01) * a;
+    return top + (bot - top) * b;
+}
+
+PLR_DI vec3 clipAABB(vec3 target, vec3 bbMin, vec3 bbMax) {
+    const vec3 center = 0.5f * (bbMax + bbMin);
+    const vec3 extend = 0.5f * (bbMax - bbMin) + vec3(0.0001f);
+    const vec3 toTarget = target - center;
+    const vec3 n(fabsf(toTarget.x) * rcpf(extend.x), fabsf(toTarget.y) * rcpf(extend.y), fabsf(toTarget.z) * rcpf(extend.z));
+    const float maxComponent = gmax(n.x, gmax(n.y, n.z));
+    if (maxComponent < 1.f) return target;
+    return center + toTarget * rcpf(maxComponent);
+}
+
+PLR_DI float catmullRomWeight1D(float d) {
+    const float d1 = fabsf(d), d2 = d1 * d1, d3 = d2 * d1;
+    if (d1 <= 1.f) return (1.f / 6.f) * (9.f * d3 - 15.f * d2 + 6.f);
+    if (d1 <= 2.f) return (1.f / 6.f) * (-3.f * d3 + 15.f * d2 - 24.f * d + 12.f);
+    return 0.f;
+}
+
+struct ResolveWeights { float w[9]; };
+
+template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
+__global__ __launch_bounds__(256) void temporalFilterFastKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
+                                                                ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
+                                                                int coverW, int coverH) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const float tsx = 1.f / (float)output.w, tsy = 1.f / (float)output.h;
+    const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
+
+    // current 3x3 (texel centres -> plain fetches), tonemapped; n[x+1][y+1]
+    vec3 n[3][3];
+    float nl[3][3]; // luminance of the (tonemapped) neighbourhood
+    const uint32_t* cur = (const uint32_t*)current.ptr;
+#pragma unroll
+    for (int x = -1; x <= 1; x++)
+#pragma unroll
+        for (int y = -1; y <= 1; y++) {
+            const vec3 c = unpackR11G11B10(cur[(size_t)clampi(py + y, current.h) * (size_t)current.w + clampi(px + x, current.w)]);
+            const float l = lum(c);
+            if (TONEMAP) {
+                const float s = rcpf(1.f + l);
+                n[x + 1][y + 1] = c * s;
+                nl[x + 1][y + 1] = l * s;
+            } else {
+                n[x + 1][y + 1] = c;
+                nl[x + 1][y + 1] = l;
+            }
+        }
+    vec3 mn = n[0][0], mx = n[0][0];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { mn = vmin(mn, n[i][j]); mx = vmax(mx, n[i][j]); }
+    const ResolveWeights rw = *rwp;
+    vec3 currentColor = n[0][0] * rw.w[0] + n[1][0] * rw.w[1] + n[2][0] * rw.w[2] + n[0][1] * rw.w[3] + n[1][1] * rw.w[4] + n[2][1] * rw.w[5] +
+                        n[0][2] * rw.w[6] + n[1][2] * rw.w[7] + n[2][2] * rw.w[8];
+
+    vec2 motion;
+    {
+        int ox = 0, oy = 0;
+        if (DILATE) {
+            float closest = 0.f;
+#pragma unroll
+            for (int x = -1; x <= 1; x++)
+#pragma unroll
+                for (int y = -1; y <= 1; y++) {
+                    const float d = texelFetch2D<F_D32>(depthBuffer, px + x, py + y).x;
+                    if (d > closest) { closest = d; ox = x; oy = y; }
+                }
+        }
+        const vec4 m = texelFetch2D<F_RG16SN>(motionBuffer, px + ox, py + oy);
+        motion = vec2(m.x, m.y);
+    }
+    const float rpx = u0 + motion.x, rpy = v0 + motion.y;
+
+    vec3 historySample;
+    if (TECH == 0) historySample = historyTap(historySrc, rpx, rpy);
+    else {
+        const float ix = (float)px + 0.5f + motion.x * (float)g->screenResolution[0], iy = (float)py + 0.5f + motion.y * (float)g->screenResolution[1];
+        const float tx = floorf(ix - 0.5f) + 0.5f, ty = floorf(iy - 0.5f) + 0.5f;
+        const float fx = ix - tx, fy = iy - ty;
+        if (TECH == 1) {
+            const float wx[4] = {catmullRomWeight1D(fx + 1.f), catmullRomWeight1D(fx), catmullRomWeight1D(1.f - fx), catmullRomWeight1D(2.f - fx)};
+            const float wy[4] = {catmullRomWeight1D(fy + 1.f), catmullRomWeight1D(fy), catmullRomWeight1D(1.f - fy), catmullRomWeight1D(2.f - fy)};
+            vec3 r(0.f);
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++) r = r + historyTap(historySrc, (tx + (float)(i - 1)) * tsx, (ty + (float)(j - 1)) * tsy) * (wx[i] * wy[j]);
+            historySample = r;
+        } else {
+            const float fx2 = fx * fx, fx3 = fx2 * fx, fy2 = fy * fy, fy3 = fy2 * fy;
+            const float w0x = -0.5f * fx3 + fx2 - 0.5f * fx, w1x = 1.5f * fx3 - 2.5f * fx2 + 1.f, w2x = -1.5f * fx3 + 2.f * fx2 + 0.5f * fx, w3x = 0.5f * fx3 - 0.5f * fx2;
+            const float w0y = -0.5f * fy3 + fy2 - 0.5f * fy, w1y = 1.5f * fy3 - 2.5f * fy2 + 1.f, w2y = -1.5f * fy3 + 2.f * fy2 + 0.5f * fy, w3y = 0.5f * fy3 - 0.5f * fy2;
+            const float wBx = w1x + w2x, wBy = w1y + w2y;
+            const float u0c = (tx - 1.f) * tsx, uT = (tx + w2x * rcpf(wBx)) * tsx, u3 = (tx + 2.f) * tsx;
+            const float v0c = (ty - 1.f) * tsy, vT = (ty + w2y * rcpf(wBy)) * tsy, v3 = (ty + 2.f) * tsy;
+            if (TECH == 2) {
+                historySample = historyTap(historySrc, u0c, v0c) * (w0x * w0y) + historyTap(historySrc, u0c, vT) * (w0x * wBy) + historyTap(historySrc, u0c, v3) * (w0x * w3y) +
+                                historyTap(historySrc, uT, v0c) * (wBx * w0y) + historyTap(historySrc, uT, vT) * (wBx * wBy) + historyTap(historySrc, uT, v3) * (wBx * w3y) +
+                                historyTap(historySrc, u3, v0c) * (w3x * w0y) + historyTap(historySrc, u3, vT) * (w3x * wBy) + historyTap(historySrc, u3, v3) * (w3x * w3y);
+            } else if (TECH == 3) {
+                const float wa = w0x * wBy, wb = wBx * w0y, wc = wBx * wBy, wd = wBx * w3y, we = w3x * wBy;
+                const vec3 r = historyTap(historySrc, u0c, vT) * wa + historyTap(historySrc, uT, v0c) * wb + historyTap(historySrc, uT, vT) * wc +
+                               historyTap(historySrc, uT, v3) * wd + historyTap(historySrc, u3, vT) * we;
+                historySample = r * rcpf(wa + wb + wc + wd + we);
+            } else {
+                // Bicubic1Tap: sum_k w_k (h + d_k) / sum_k w_k = h + (sum_k w_k d_k) / sum_k w_k, with d = neighbour - centre of the
+                // (tonemapped) current frame; the history tap itself is not tonemapped yet (bicubicSampling.inc:169-176)
+                const vec3 h = historyTap(historySrc, uT, vT);
+                const float wa = w0x * wBy, wb = wBx * w0y, wc = wBx * wBy, wd = wBx * w3y, we = w3x * wBy;
+                const vec3 c = n[1][1];
+                const vec3 acc = (n[0][1] - c) * wa + (n[1][0] - c) * wb + (n[1][2] - c) * wd + (n[2][1] - c) * we;
+                historySample = h + acc * rcpf(wa + wb + wc + wd + we);
+            }
+        }
+    }
+    if (TONEMAP) historySample = tonemapF(historySample);
+    if (CLIP) historySample = clipAABB(historySample, mn, mx);
+    else historySample = vclamp(historySample, mn, mx);
+    if (anyNan(historySample)) historySample = currentColor;
+
+    const float cc = nl[1][1];
+    const float currentContrast = fabsf(nl[0][0] - cc) + fabsf(nl[1][0] - cc) + fabsf(nl[2][0] - cc) + fabsf(nl[0][2] - cc) + fabsf(nl[1][2] - cc) + fabsf(nl[2][2] - cc) +
+                                  fabsf(nl[0][1] - cc) + fabsf(nl[2][1] - cc);
+    // history neighbourhood luminances from one shared 4x4 footprint
+    float lastContrast;
+    {
+        int i0, j0; float a, b;
+        linearCoord(rpx * (float)historySrc.w, &i0, &a);
+        linearCoord(rpy * (float)historySrc.h, &j0, &b);
+        const uint32_t* hist = (const uint32_t*)historySrc.ptr;
+        float tl[4][4]; // [row][col] luminance of texels (i0-1 .. i0+2, j0-1 .. j0+2)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t row = (size_t)clampi(j0 - 1 + r, historySrc.h) * (size_t)historySrc.w;
+#pragma unroll
+            for (int c = 0; c < 4; c++) tl[r][c] = lum(unpackR11G11B10(hist[row + clampi(i0 - 1 + c, historySrc.w)]));
+        }
+        float hl[3][3]; // [x+1][y+1]
+#pragma unroll
+        for (int y = 0; y < 3; y++) {
+            float rowLerp[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) rowLerp[c] = tl[y][c] + (tl[y + 1][c] - tl[y][c]) * b;
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                const float l = rowLerp[x] + (rowLerp[x + 1] - rowLerp[x]) * a;
+                hl[x][y] = TONEMAP ? l * rcpf(1.f + l) : l;
+            }
+        }
+        const float hc = hl[1][1];
+        lastContrast = fabsf(hl[0][0] - hc) + fabsf(hl[1][0] - hc) + fabsf(hl[2][0] - hc) + fabsf(hl[0][2] - hc) + fabsf(hl[1][2] - hc) + fabsf(hl[2][2] - hc) +
+                       fabsf(hl[0][1] - hc) + fabsf(hl[2][1] - hc);
+    }
+    const float contrastChange = gclamp(fabsf(currentContrast - lastContrast), 0.f, 1.f);
+    float blendFactor = gmix(0.13f, 0.03f, contrastChange);
+    if (g->cameraCut) blendFactor = 1.f;
+    if (rpx < 0.f || rpy < 0.f || rpx > 1.f || rpy > 1.f) {
+        blendFactor = 1.f;
+        currentColor = (n[0][0] + n[0][2] + n[2][0] + n[2][2]) * 0.0625f + (n[1][0] + n[0][1] + n[1][2] + n[2][1]) * 0.125f + n[1][1] * 0.25f;
+    }
+    vec3 color = historySample + (currentColor - historySample) * blendFactor;
+    if (TONEMAP) color = tonemapReverseF(color);
+    const uint32_t packed = packR11G11B10(color);
+    if (px < historyDst.w && py < historyDst.h) ((uint32_t*)historyDst.ptr)[(size_t)py * (size_t)historyDst.w + px] = packed;
+    ((uint32_t*)output.ptr)[(size_t)py * (size_t)output.w + px] = packed;
+}
+
+typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int);
+template <bool CLIP, bool DILATE, bool TONEMAP> static TaaKernel pickTech(int tech) {
+    switch (tech) {
+        case 0: return temporalFilterFastKernel<CLIP, DILATE, 0, TONEMAP>;
+        case 1: return temporalFilterFastKernel<CLIP, DILATE, 1, TONEMAP>;
+        case 2: return temporalFilterFastKernel<CLIP, DILATE, 2, TONEMAP>;
+        case 3: return temporalFilterFastKernel<CLIP, DILATE, 3, TONEMAP>;
+        case 4: return temporalFilterFastKernel<CLIP, DILATE, 4, TONEMAP>;
+        default: return nullptr;
+    }
+}
+
+static int launch(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSampled(0, F_R11G11B10, "temporalFilter currentFrame")) return rc;
+    if (int rc = c.needStorage(1, F_R11G11B10, "temporalFilter outputImage")) return rc;
+    if (int rc = c.needStorage(2, F_R11G11B10, "temporalFilter historyBufferDst")) return rc;
+    if (int rc = c.needSampled(3, F_R11G11B10, "temporalFilter historyBufferSrc")) return rc;
+    if (int rc = c.needSampled(4, F_RG16SN, "temporalFilter motionBuffer")) return rc;
+    if (int rc = c.needSampled(5, F_D32, "temporalFilter depthBuffer")) return rc;
+    if (int rc = c.needUbuf(6, 36, "temporalFilter resolveWeightBuffer")) return rc;
+    const bool clip = c.specBool(0, false), dilate = c.specBool(1, false), tonemap = c.specBool(3, false);
+    const int tech = c.specInt(2, 0);
+    TaaKernel k = nullptr;
+    if (clip) {
+        if (dilate) k = tonemap ? pickTech<true, true, true>(tech) : pickTech<true, true, false>(tech);
+        else k = tonemap ? pickTech<true, false, true>(tech) : pickTech<true, false, false>(tech);
+    } else {
+        if (dilate) k = tonemap ? pickTech<false, true, true>(tech) : pickTech<false, true, false>(tech);
+        else k = tonemap ? pickTech<false, false, true>(tech) : pickTech<false, false, false>(tech);
+    }
+    if (!k) return c.fail(-6, "temporalFilter: historySampleTech must be 0..4");
+    const ImgView& out = c.storage[1];
+    const int w = std::min({(int)(c.dispatch[0] * 8u), out.w, c.sampled[0].w});
+    const int h = std::min({(int)(c.dispatch[1] * 8u), out.h, c.sampled[0].h});
+    if (w <= 0 || h <= 0) return 0;
+    k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
+                                                                                   (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace fasttaa
+
+static int fasttaa_launch(const PassCtx& c) { return fasttaa::launch(c); }
+PLR_REGISTER_SHADER_FAST("temporalFilter.comp", fasttaa_launch);
+} // namespace plr

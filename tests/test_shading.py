@@ -13,8 +13,7 @@ W, H = 192, 108
 LUT_RES = 32
 
 
-@pytest.fixture(scope="module")
-def scene():
+def build_scene():
     class S:
         pass
     s = S()
@@ -39,6 +38,11 @@ def scene():
     s.light = light_buffer_bytes(sun_color=(1.0, 0.92, 0.8), prev_exposure=8e-5, sun_strength_exposed=128000 * 8e-5)
     s.lut = passes.orc_brdf_lut(LUT_RES, 2)
     return s
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return build_scene()
 
 
 def test_kat_brdf_lut_properties(scene):
