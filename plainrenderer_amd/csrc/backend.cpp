@@ -544,7 +544,8 @@ static int launchAll(bool timed) {
         x.ctx.scratchSlot = &p.scratch;
         x.ctx.scratchSize = &p.scratchSize;
         if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
-        int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : p.fn(x.ctx);
+        int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
+        if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
         if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
         if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
     }

@@ -65,6 +65,9 @@ struct PassCtx {
 };
 
 typedef int (*LaunchFn)(const PassCtx&);
+// a PLR_MATH_FAST launcher returns this when the recorded execution is outside the configuration its kernel was built for;
+// the backend then runs the general (exact-order) kernel of the same shader
+constexpr int kUseGeneralKernel = 1;
 
 struct ShaderRegistrar {
     ShaderRegistrar(const char* name, LaunchFn fn, bool fast = false);

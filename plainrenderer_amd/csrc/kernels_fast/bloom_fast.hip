@@ -1,0 +1,134 @@
+// PLR_MATH_FAST variant of bloomUpsample.comp:19-57 (exact variant: kernels/bloom.hip).
+//
+// The 9-tap tent (weights .25/.125/.0625 at 0, +-blurRadius texels) is the outer product of the 1D tent (.5, .25, .25), the
+// 4-tap box of the previous mip (4 x .25 at +-0.5 texel) is the outer product of (.5, .5), and bilinear filtering is itself
+// separable. So   target = sum_rows wy(r) * [ sum_cols wx(c) * source(c, r) ]  +  the same for the previous mip:
+// a block first builds the horizontally filtered rows it needs in LDS (6 + 4 texel decodes per row entry), then every output
+// combines 6 + 4 LDS rows vertically. 64x16 outputs per block read ~7 texels per output instead of 52 and the vector work drops
+// from 52 to ~10 multiply-adds per output. Tap positions, 8-bit sub-texel weights and clamp-to-edge addressing are evaluated
+// per tap exactly as in the sampler contract; only the association order of the weighted sum differs from the exact kernel.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+namespace fastbloom {
+
+constexpr int TW = 64, TH = 16;
+constexpr int ROWS_A = 16, ROWS_B = 12; // rows of the source / previous mip one 16-row output tile can touch (8 + 2*ceil(radius) + 2 / 8 + 3)
+
+struct Tap { int i0, i1; float w0, w1; };
+
+// bilinear footprint of one 1D tap at normalised coordinate u (size n), scaled by the tap's filter weight h
+PLR_DI Tap tap1D(float u, int n, float h) {
+    int i0; float a;
+    linearCoord(u * (float)n, &i0, &a);
+    Tap t;
+    t.i0 = clampi(i0, n); t.i1 = clampi(i0 + 1, n);
+    t.w0 = (1.f - a) * h; t.w1 = a * h;
+    return t;
+}
+
+template <bool LOWEST>
+__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH) {
+    __shared__ float HA[ROWS_A][3][TW];
+    __shared__ float HB[ROWS_B][3][TW];
+    const int t = (int)threadIdx.x;
+    const int lx = t & 63, lyBase = t >> 6;
+    const int x = (int)blockIdx.x * TW + lx;
+    const int y0 = (int)blockIdx.y * TH;
+    const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
+    const float sx = blurRadius * tsx, sy = blurRadius * tsy;
+    const float invTW = 1.f / (float)target.w, invTH = 1.f / (float)target.h;
+    const int yLast = min(y0 + TH, coverH) - 1;
+
+    // row ranges touched by this tile (tap positions are monotonic in y)
+    const float vFirst = ((float)y0 + 0.5f) * invTH, vLast = ((float)yLast + 0.5f) * invTH;
+    const int rowA0 = tap1D(vFirst + sy * -1.f, source.h, 1.f).i0;
+    const int rowA1 = tap1D(vLast + sy * 1.f, source.h, 1.f).i1;
+    const int nRowsA = min(rowA1 - rowA0 + 1, ROWS_A);
+    int rowB0 = 0, nRowsB = 0;
+    if (!LOWEST) {
+        rowB0 = tap1D(vFirst + tsy * -0.5f, previous.h, 1.f).i0;
+        const int rowB1 = tap1D(vLast + tsy * 0.5f, previous.h, 1.f).i1;
+        nRowsB = min(rowB1 - rowB0 + 1, ROWS_B);
+    }
+
+    // ---- horizontal pass: this lane's column taps, then one LDS entry per (row, column)
+    if (x < coverW) {
+        const float u = ((float)x + 0.5f) * invTW;
+        const Tap a0 = tap1D(u, source.w, 0.5f), a1 = tap1D(u + sx * 1.f, source.w, 0.25f), a2 = tap1D(u + sx * -1.f, source.w, 0.25f);
+        const uint32_t* src = (const uint32_t*)source.ptr;
+        for (int r = lyBase; r < nRowsA; r += 4) {
+            const uint32_t* row = src + (size_t)(rowA0 + r) * (size_t)source.w;
+            vec3 acc = unpackR11G11B10(row[a0.i0]) * a0.w0 + unpackR11G11B10(row[a0.i1]) * a0.w1;
+            acc = acc + unpackR11G11B10(row[a1.i0]) * a1.w0 + unpackR11G11B10(row[a1.i1]) * a1.w1;
+            acc = acc + unpackR11G11B10(row[a2.i0]) * a2.w0 + unpackR11G11B10(row[a2.i1]) * a2.w1;
+            HA[r][0][lx] = acc.x; HA[r][1][lx] = acc.y; HA[r][2][lx] = acc.z;
+        }
+        if (!LOWEST) {
+            const Tap b0 = tap1D(u + tsx * 0.5f, previous.w, 0.5f), b1 = tap1D(u + tsx * -0.5f, previous.w, 0.5f);
+            const uint32_t* prv = (const uint32_t*)previous.ptr;
+            for (int r = lyBase; r < nRowsB; r += 4) {
+                const uint32_t* row = prv + (size_t)(rowB0 + r) * (size_t)previous.w;
+                const vec3 acc = unpackR11G11B10(row[b0.i0]) * b0.w0 + unpackR11G11B10(row[b0.i1]) * b0.w1 + unpackR11G11B10(row[b1.i0]) * b1.w0 +
+                                 unpackR11G11B10(row[b1.i1]) * b1.w1;
+                HB[r][0][lx] = acc.x; HB[r][1][lx] = acc.y; HB[r][2][lx] = acc.z;
+            }
+        }
+    }
+    __syncthreads();
+    if (x >= coverW) return;
+
+    // ---- vertical pass
+#pragma unroll
+    for (int k = 0; k < TH / 4; k++) {
+        const int y = y0 + lyBase + 4 * k;
+        if (y >= coverH) break;
+        const float v = ((float)y + 0.5f) * invTH;
+        const Tap c0 = tap1D(v, source.h, 0.5f), c1 = tap1D(v + sy * 1.f, source.h, 0.25f), c2 = tap1D(v + sy * -1.f, source.h, 0.25f);
+        vec3 color(0.f);
+        auto rowA = [&](int r, float w) {
+            r = min(max(r - rowA0, 0), ROWS_A - 1);
+            color = color + vec3(HA[r][0][lx], HA[r][1][lx], HA[r][2][lx]) * w;
+        };
+        rowA(c0.i0, c0.w0); rowA(c0.i1, c0.w1); rowA(c1.i0, c1.w0); rowA(c1.i1, c1.w1); rowA(c2.i0, c2.w0); rowA(c2.i1, c2.w1);
+        if (!LOWEST) {
+            const Tap d0 = tap1D(v + tsy * 0.5f, previous.h, 0.5f), d1 = tap1D(v + tsy * -0.5f, previous.h, 0.5f);
+            auto rowB = [&](int r, float w) {
+                r = min(max(r - rowB0, 0), ROWS_B - 1);
+                color = color + vec3(HB[r][0][lx], HB[r][1][lx], HB[r][2][lx]) * w;
+            };
+            rowB(d0.i0, d0.w0); rowB(d0.i1, d0.w1); rowB(d1.i0, d1.w0); rowB(d1.i1, d1.w1);
+        }
+        ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
+    }
+}
+
+static int launch(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R11G11B10, "bloomUpsample target")) return rc;
+    if (int rc = c.needSampled(2, F_R11G11B10, "bloomUpsample source")) return rc;
+    const bool lowest = c.specBool(0, false);
+    if (!lowest) if (int rc = c.needSampled(1, F_R11G11B10, "bloomUpsample targetPreviousMip")) return rc;
+    if (c.push.size() < 4) return c.fail(-1, "bloomUpsample: push constant blurRadius missing");
+    float blurRadius;
+    std::memcpy(&blurRadius, c.push.data(), 4);
+    const ImgView& target = c.storage[0];
+    const ImgView& source = c.sampled[2];
+    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = std::min((int)(c.dispatch[1] * 8u), target.h);
+    if (w <= 0 || h <= 0) return 0;
+    // the LDS row budget assumes the reference's configuration: source = next smaller mip (>= half the target height) and a
+    // blur radius of at most 3 source texels; anything else takes the general (exact-order) kernel
+    const bool fits = blurRadius >= 0.f && blurRadius <= 3.f && source.h * 2 + 1 >= target.h && (lowest || c.sampled[1].h * 2 + 1 >= target.h);
+    if (!fits) return kUseGeneralKernel;
+    const dim3 grid(divUp((unsigned)w, (unsigned)TW), divUp((unsigned)h, (unsigned)TH));
+    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h);
+    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace fastbloom
+
+static int fastbloom_up_launch(const PassCtx& c) { return fastbloom::launch(c); }
+PLR_REGISTER_SHADER_FAST("bloomUpsample.comp", fastbloom_up_launch);
+} // namespace plr

@@ -103,3 +103,26 @@ def test_gpu_fast_taa(fast, clip, dilate, tech, tonemap):
     assert np.array_equal(og, hg)
     assert_close(pixfmt.unpack_r11g11b10(og), pixfmt.unpack_r11g11b10(oo), rel=2.0 ** -5, abs_floor_frac=2e-4, outlier_frac=0.005, outlier_max_frac=0.1, mean_rel=2e-3,
                  what="TAA output")
+
+
+# ------------------------------------------------------------------ bloom
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1920, 1080), (270, 136), (97, 61)])
+def test_gpu_fast_bloom(fast, w, h):
+    from util import hdr_image
+    scene_img = hdr_image(w, h, buffer_id=31)
+    out_g, downs_g, ups_g = passes.gpu_bloom(fast, scene_img, w, h)
+    out_o, downs_o, ups_o = passes.orc_bloom(scene_img, w, h)
+    for i, (a, b) in enumerate(zip(ups_g, ups_o)):
+        # each level re-quantises to R11G11B10; a one-quantum flip at a coarse level is carried (attenuated) into the finer ones
+        assert_close(pixfmt.unpack_r11g11b10(a), pixfmt.unpack_r11g11b10(b), rel=2.0 ** -5, abs_floor_frac=1e-4, outlier_frac=0.0, mean_rel=2e-3, what="up mip %d" % i)
+    assert_close(pixfmt.unpack_r11g11b10(out_g), pixfmt.unpack_r11g11b10(out_o), rel=2.0 ** -5, abs_floor_frac=1e-4, outlier_frac=0.0, mean_rel=2e-3, what="applied")
+
+
+@pytest.mark.gpu
+def test_gpu_fast_bloom_constant_energy(fast):
+    w, h = 3840, 2160
+    scene_img = pixfmt.pack_r11g11b10(np.full((h, w, 3), 0.5, np.float32))
+    out, downs, ups = passes.gpu_bloom(fast, scene_img, w, h, strength=0.25)
+    assert np.all(pixfmt.unpack_r11g11b10(ups[0]) == 2.5)
+    assert np.all(pixfmt.unpack_r11g11b10(out) == 0.5 * (1 + 4 * 0.25))
