@@ -14,6 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(HERE, "libplr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, e.g. -DPLR_SHADE_WAVES=5
 
 # kernels_fast/*.hip: restructured kernels for PLR_MATH_FAST. FMA contraction on, divide/sqrt may use the v_rcp/v_rsq based
 # sequences; still no -ffast-math (NaN guards and comparisons keep IEEE semantics).
@@ -47,7 +48,7 @@ def _headers_digest():
                 if f.endswith((".h", ".hpp")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(fh.read())
-    h.update(" ".join(FLAGS + sorted(FAST_FLAGS_REPLACE.values())).encode())
+    h.update(" ".join(FLAGS + sorted(FAST_FLAGS_REPLACE.values()) + EXTRA_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -61,7 +62,7 @@ def _compile(src, digest, verbose):
     flags = FLAGS
     if os.sep + "kernels_fast" + os.sep in src:
         flags = [FAST_FLAGS_REPLACE.get(f, f) for f in FLAGS]
-    cmd = [HIPCC, "-x", "hip"] + flags + ["-c", src, "-o", obj]
+    cmd = [HIPCC, "-x", "hip"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,278 @@
+// PLR_MATH_FAST variant of sdfDiffuseTrace.comp (exact variant and the wave / tile mapping: kernels/sdfgi.hip).
+//
+// Same sphere trace, same culling tiles, same LDS ray exchange. Arithmetic changes:
+//  * the per-step uv = localPos / localExtends + 0.5 is a multiply-add with the precomputed reciprocal extents (three IEEE
+//    divisions per step in the exact kernel); other divisions are v_rcp_f32, normalisations v_rsq_f32, FMA contraction is on
+//  * the two x-neighbours of every trilinear corner pair are fetched with one 32-bit load when they are adjacent in memory
+//  * the world position uses the un-normalised view ray (normalisation cancels), the cosine sample uses v_sin/v_cos,
+//    directionToSH_L1 of a unit vector is two constants
+// A ray whose closest SDF sample sits within rounding of the hit threshold (or of an AABB face) can resolve differently than in
+// the exact kernel; such a pixel and the neighbours that share its ray in the 3x3 resolve change visibly. Stated tolerance:
+// tests/test_fast_kernels.py.
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+namespace fasttrace {
+
+PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
+
+struct Volume {
+    const uint16_t* p;
+    int w, h, d;
+    float fw, fh, fd;
+};
+
+PLR_DI float sampleSDF(const Volume& v, float u, float vv, float ww) {
+    int i0, j0, k0; float a, b, c;
+    linearCoord(u * v.fw, &i0, &a);
+    linearCoord(vv * v.fh, &j0, &b);
+    linearCoord(ww * v.fd, &k0, &c);
+    const int y0 = clampi(j0, v.h) * v.w, y1 = clampi(j0 + 1, v.h) * v.w;
+    const int sl = v.w * v.h;
+    const int z0 = clampi(k0, v.d) * sl, z1 = clampi(k0 + 1, v.d) * sl;
+    float t000, t100, t010, t110, t001, t101, t011, t111;
+    if (i0 >= 0 && i0 + 1 < v.w) {
+        // both x texels in range: adjacent halves, one (possibly unaligned) dword load per row
+        auto pair = [&](int off, float& lo, float& hi) {
+            uint32_t u32;
+            __builtin_memcpy(&u32, v.p + off + i0, 4);
+            lo = halfBitsToFloat(u32 & 0xffffu); hi = halfBitsToFloat(u32 >> 16);
+        };
+        pair(z0 + y0, t000, t100); pair(z0 + y1, t010, t110); pair(z1 + y0, t001, t101); pair(z1 + y1, t011, t111);
+    } else {
+        const int x0 = clampi(i0, v.w), x1 = clampi(i0 + 1, v.w);
+        t000 = halfBitsToFloat(v.p[z0 + y0 + x0]); t100 = halfBitsToFloat(v.p[z0 + y0 + x1]);
+        t010 = halfBitsToFloat(v.p[z0 + y1 + x0]); t110 = halfBitsToFloat(v.p[z0 + y1 + x1]);
+        t001 = halfBitsToFloat(v.p[z1 + y0 + x0]); t101 = halfBitsToFloat(v.p[z1 + y0 + x1]);
+        t011 = halfBitsToFloat(v.p[z1 + y1 + x0]); t111 = halfBitsToFloat(v.p[z1 + y1 + x1]);
+    }
+    const float x00 = t000 + (t100 - t000) * a, x10 = t010 + (t110 - t010) * a, x01 = t001 + (t101 - t001) * a, x11 = t011 + (t111 - t011) * a;
+    const float y0v = x00 + (x10 - x00) * b, y1v = x01 + (x11 - x01) * b;
+    return y0v + (y1v - y0v) * c;
+}
+
+struct TraceResult {
+    bool hit;
+    float closestHitDistance;
+    vec3 hitPos;
+    vec3 albedoSrgb; // meanAlbedo of the closest hit; linearised once after the loop
+};
+
+PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mx, float* tOut) {
+    bool hit = false;
+    float t = 100000.f;
+    const float tx = ((o.x < 0.f ? -mx.x : mx.x) - o.x) * rcpf(dir.x);
+    vec3 p = o + tx * dir;
+    if (tx > 0.f && fabsf(p.y) <= mx.y && fabsf(p.z) <= mx.z) { t = gmin(t, tx); hit = true; }
+    const float ty = ((o.y < 0.f ? -mx.y : mx.y) - o.y) * rcpf(dir.y);
+    p = o + ty * dir;
+    if (ty > 0.f && fabsf(p.x) <= mx.x && fabsf(p.z) <= mx.z) { t = gmin(t, ty); hit = true; }
+    const float tz = ((o.z < 0.f ? -mx.z : mx.z) - o.z) * rcpf(dir.z);
+    p = o + tz * dir;
+    if (tz > 0.f && fabsf(p.x) <= mx.x && fabsf(p.y) <= mx.y) { t = gmin(t, tz); hit = true; }
+    *tOut = t;
+    return hit;
+}
+
+PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Volume& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
+    const float* m = inst.worldToLocal;
+    const vec3 localExtends = ld3(inst.localExtends);
+    vec3 rayStartLocal(m[0] * rayStartWorld.x + m[4] * rayStartWorld.y + m[8] * rayStartWorld.z + m[12],
+                       m[1] * rayStartWorld.x + m[5] * rayStartWorld.y + m[9] * rayStartWorld.z + m[13],
+                       m[2] * rayStartWorld.x + m[6] * rayStartWorld.y + m[10] * rayStartWorld.z + m[14]);
+    // (M * (start + dir)) - (M * start) = linear part of M applied to dir
+    vec3 rayDirection(m[0] * rayDirectionWorld.x + m[4] * rayDirectionWorld.y + m[8] * rayDirectionWorld.z,
+                      m[1] * rayDirectionWorld.x + m[5] * rayDirectionWorld.y + m[9] * rayDirectionWorld.z,
+                      m[2] * rayDirectionWorld.x + m[6] * rayDirectionWorld.y + m[10] * rayDirectionWorld.z);
+    rayDirection = rayDirection * rsqf(dot(rayDirection, rayDirection));
+    const vec3 sdfMaxLocal = localExtends * 0.5f;
+    float hitDistanceLocal = 0.f;
+    const bool inside = fabsf(rayStartLocal.x) <= sdfMaxLocal.x && fabsf(rayStartLocal.y) <= sdfMaxLocal.y && fabsf(rayStartLocal.z) <= sdfMaxLocal.z;
+    if (!inside) {
+        float t;
+        if (rayAABBIntersection(rayStartLocal, rayDirection, sdfMaxLocal, &t)) {
+            rayStartLocal += t * rayDirection;
+            hitDistanceLocal = t;
+        } else return;
+    }
+    const float localToGlobalScale = rsqf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    if (localToGlobalScale * hitDistanceLocal > tr.closestHitDistance) return;
+    const vec3 invExt(rcpf(localExtends.x), rcpf(localExtends.y), rcpf(localExtends.z));
+    const vec3 voxel(localExtends.x * rcpf(sdf.fw), localExtends.y * rcpf(sdf.fh), localExtends.z * rcpf(sdf.fd));
+    const float distanceThreshold = sqrtf(dot(voxel, voxel)) * 0.25f;
+    const vec3 lim = sdfMaxLocal + 0.01f;
+    vec3 pos = rayStartLocal;
+    float dLast = 0.f, d = 0.f;
+    for (int i = 0; i < 128; i++) {
+        if (fabsf(pos.x) > lim.x || fabsf(pos.y) > lim.y || fabsf(pos.z) > lim.z) break;
+        dLast = d;
+        d = sampleSDF(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f);
+        if (d < distanceThreshold) {
+            tr.hit = true;
+            const float distanceGlobal = hitDistanceLocal * localToGlobalScale;
+            if (distanceGlobal < tr.closestHitDistance) {
+                tr.closestHitDistance = distanceGlobal;
+                const float lastStepSizeLocal = d * rcpf(1.f - (d - dLast));
+                tr.albedoSrgb = ld3(inst.meanAlbedo);
+                tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeLocal * localToGlobalScale);
+            }
+            break;
+        }
+        const float step = fabsf(d);
+        pos = pos + rayDirection * step;
+        hitDistanceLocal += step;
+    }
+}
+
+struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
+struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
+
+template <bool STRICT_CUTOFF>
+__global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
+                                                                 const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
+                                                                 const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
+                                                                 const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
+                                                                 uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY,
+                                                                 uint32_t tileCapacity, uint32_t instanceCapacity) {
+    __shared__ RayInfo sharedRays[4][64];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = (int)blockIdx.y * 2 + (wave >> 1);
+    const bool active = gx < groupsX && gy < groupsY;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int px = gx * 8 + lx, py = gy * 8 + ly;
+    vec3 L(0.f, 0.f, 1.f);
+    RayInfo mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const float u = (float)px / (float)outYSH.w, v = (float)py / (float)outYSH.h;
+        const float depth = sampleNearest2D<F_D32, CLAMP>(depthTexture, vec2(u, v)).x;
+        const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
+        const vec3 ray = ld3(g->cameraForward) + (-g->cameraTanFovHalf * (v * 2.f - 1.f)) * ld3(g->cameraUp) +
+                         (g->cameraTanFovHalf * g->cameraAspectRatio * (u * 2.f - 1.f)) * ld3(g->cameraRight);
+        const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
+        const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
+        const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
+        const vec4 nz = Texel<F_RG8>::load(noiseTex.ptr, (size_t)repeati(py, noiseTex.h) * (size_t)noiseTex.w + (size_t)repeati(px, noiseTex.w));
+        const vec3 N = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, vec2(u, v)).xyz() * 2.f - 1.f;
+        mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
+        const vec3 rayOrigin = pWorld + N * 0.2f;
+        {
+            // importanceSampleCosine (sampling.inc:25-45): phi = 2 pi xi.y, v_sin/v_cos take revolutions
+            const float cosTheta = sqrtf(nz.x), sinTheta = sqrtf(1.f - nz.x);
+            const float sp = __builtin_amdgcn_sinf(nz.y), cp = __builtin_amdgcn_cosf(nz.y);
+            const vec3 up = fabsf(N.z) < 0.999f ? vec3(0.f, 0.f, 1.f) : vec3(1.f, 0.f, 0.f);
+            vec3 tangent = cross(up, N);
+            tangent = tangent * rsqf(dot(tangent, tangent));
+            const vec3 bitangent = cross(N, tangent);
+            L = (cp * sinTheta) * tangent + (sp * sinTheta) * bitangent + cosTheta * N;
+        }
+        TraceResult tr;
+        tr.hit = false;
+        tr.closestHitDistance = 10000.f;
+        tr.hitPos = vec3(0.f);
+        tr.albedoSrgb = vec3(0.f);
+        const uint32_t tileIndex = min((uint32_t)(gx / 4) + (uint32_t)(gy / 4) * (uint32_t)ceilf((float)g->screenResolution[0] / 32.f), tileCapacity - 1u);
+        const CulledInstancesPerTile* tile = tiles + tileIndex;
+        const int objectCount = (int)min(tile->objectCount, kMaxObjectsPerTile);
+        for (int i = 0; i < objectCount; i++) {
+            const uint32_t instIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tile->indices[i]), instanceCapacity - 1u);
+            const SDFInstance& inst = instanceBuffer->instances[instIndex];
+            const uint32_t texIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)inst.sdfTextureIndex), bindlessCount - 1u);
+            const ImgView view = bindless[texIndex];
+            Volume vol;
+            vol.p = (const uint16_t*)view.ptr; vol.w = view.w; vol.h = view.h; vol.d = view.d;
+            vol.fw = (float)view.w; vol.fh = (float)view.h; vol.fd = (float)view.d;
+            traceInstance(inst, rayOrigin, vol, L, tr);
+        }
+        vec3 hitColor;
+        if (tr.hit) {
+            const float* lm = shadowInfo->lightMatrices[shadowCascadeIndex];
+            const vec4 p = mulMat4(lm, vec4(tr.hitPos, 1.f));
+            const float iw = rcpf(p.w);
+            const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_WHITE>(shadowMap, vec2(p.x * iw * 0.5f + 0.5f, p.y * iw * 0.5f + 0.5f)).x;
+            const float shadow = gclamp(p.z * iw, 0.f, 1.f) > shadowMapDepth ? 1.f : 0.f;
+            const vec3 a = tr.albedoSrgb;
+            const vec3 albedo(a.x <= 0.f ? 0.f : __builtin_amdgcn_exp2f(2.2f * __builtin_amdgcn_logf(a.x)), a.y <= 0.f ? 0.f : __builtin_amdgcn_exp2f(2.2f * __builtin_amdgcn_logf(a.y)),
+                              a.z <= 0.f ? 0.f : __builtin_amdgcn_exp2f(2.2f * __builtin_amdgcn_logf(a.z)));
+            hitColor = albedo * ((shadow * light->sunStrengthExposed) * ld3(light->sunColor));
+            const bool hitInRange = (tr.closestHitDistance < *influenceRangeP) || !STRICT_CUTOFF;
+            if (!hitInRange || tr.closestHitDistance < 0.0001f) hitColor = vec3(0.f);
+        } else {
+            hitColor = sampleSkyLut(L, skyLut);
+        }
+        mine.cr = hitColor.x; mine.cg = hitColor.y; mine.cb = hitColor.z;
+    }
+    sharedRays[wave][lane] = mine;
+    __syncthreads();
+    if (!active) return;
+
+    float weightTotal = 1.f;
+    vec3 color(mine.cr, mine.cg, mine.cb);
+    const vec3 myN(mine.nx, mine.ny, mine.nz);
+#pragma unroll
+    for (int x = -1; x <= 1; x++)
+#pragma unroll
+        for (int y = -1; y <= 1; y++) {
+            if (x == 0 && y == 0) continue;
+            const int rx = lx + x, ry = ly + y;
+            if (!((rx > 0 && ry > 0) && (rx < 8 && ry < 8))) continue; // sic: > 0 (:88)
+            const RayInfo nb = sharedRays[wave][ry * 8 + rx];
+            const float NoN = gclamp(dot(myN, vec3(nb.nx, nb.ny, nb.nz)), 0.f, 1.f);
+            if (NoN > 0.9f && fabsf(mine.depth - nb.depth) < 0.5f) {
+                const float weight = (x == 0 ? 1.f : 0.5f) * (y == 0 ? 1.f : 0.5f);
+                color = color + weight * vec3(nb.cr, nb.cg, nb.cb);
+                weightTotal += weight;
+            }
+        }
+    color = color * rcpf(weightTotal);
+    const vec3 YCoCg = linearToYCoCg(color);
+    if (px < outYSH.w && py < outYSH.h) {
+        // directionToSH_L1(L), |L| = 1: (0.5, -0.86603 L.y, 0.86603 L.z, -0.86603 L.x)
+        const vec4 ysh(YCoCg.x * 0.5f, YCoCg.x * (-0.8660254f * L.y), YCoCg.x * (0.8660254f * L.z), YCoCg.x * (-0.8660254f * L.x));
+        const size_t idx = (size_t)py * (size_t)outYSH.w + px;
+        Texel<F_RGBA16F>::store(outYSH.ptr, idx, ysh);
+        Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(YCoCg.y, YCoCg.z, 0.f, 0.f));
+    }
+}
+
+static int launch(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "sdfDiffuseTrace imageOut_Y_SH")) return rc;
+    if (int rc = c.needStorage(1, F_RG16F, "sdfDiffuseTrace imageOut_CoCg")) return rc;
+    if (int rc = c.needSampled(2, F_D32, "sdfDiffuseTrace depthTexture")) return rc;
+    if (int rc = c.needSampled(3, F_RGBA8, "sdfDiffuseTrace normalTexture")) return rc;
+    if (int rc = c.needSampled(4, F_R11G11B10, "sdfDiffuseTrace skyLut")) return rc;
+    if (int rc = c.needSbuf(5, sizeof(LightBuffer), "sdfDiffuseTrace lightBuffer")) return rc;
+    if (int rc = c.needSbuf(6, 16 + sizeof(SDFInstance), "sdfDiffuseTrace sdfInstanceBuffer")) return rc;
+    if (int rc = c.needSbuf(7, sizeof(CulledInstancesPerTile), "sdfDiffuseTrace cameraCulledTileBuffer")) return rc;
+    if (int rc = c.needUbuf(8, 4, "sdfDiffuseTrace influenceRangeBuffer")) return rc;
+    if (int rc = c.needSbuf(9, sizeof(ShadowCascadeInfo), "sdfDiffuseTrace sunShadowInfo")) return rc;
+    if (int rc = c.needSampled(10, F_D16, "sdfDiffuseTrace shadowMap")) return rc;
+    if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "sdfDiffuseTrace: global texture array (set 2) is empty");
+    const bool strict = c.specBool(0, false);
+    const int cascade = c.specInt(1, 3);
+    if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
+    const ImgView& out = c.storage[0];
+    if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
+    const int groupsX = (int)c.dispatch[0], groupsY = (int)c.dispatch[1];
+    if (groupsX <= 0 || groupsY <= 0) return 0;
+    const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
+    const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
+    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)groupsY, 2u));
+#define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
+                       (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY,      \
+                       tileCapacity, instanceCapacity
+    if (strict) sdfDiffuseTraceFastKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    else sdfDiffuseTraceFastKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+#undef PLR_TRACE_ARGS
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace fasttrace
+
+static int fasttrace_launch(const PassCtx& c) { return fasttrace::launch(c); }
+PLR_REGISTER_SHADER_FAST("sdfDiffuseTrace.comp", fasttrace_launch);
+} // namespace plr

@@ -15,6 +15,10 @@ namespace plr {
 
 namespace fastshade {
 
+#ifndef PLR_SHADE_WAVES
+#define PLR_SHADE_WAVES 5 // 88 VGPRs, no scratch: 319 -> 284 us at 4K (6 waves spills: 389 us)
+#endif
+
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
 PLR_DI float log2h(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (base 2)
@@ -138,7 +142,7 @@ PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, floa
 }
 
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
-__global__ __launch_bounds__(256) void deferredShadingFastKernel(ShadeParams P) {
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= P.coverW || py >= P.coverH) return;

@@ -126,3 +126,19 @@ def test_gpu_fast_bloom_constant_energy(fast):
     out, downs, ups = passes.gpu_bloom(fast, scene_img, w, h, strength=0.25)
     assert np.all(pixfmt.unpack_r11g11b10(ups[0]) == 2.5)
     assert np.all(pixfmt.unpack_r11g11b10(out) == 0.5 * (1 + 4 * 0.25))
+
+
+# ------------------------------------------------------------------ SDF trace
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [True, False])
+def test_gpu_fast_trace(fast, scene, strict):
+    c, inst_bytes, arr, n, keep = _trace_inputs(fast, scene)
+    gp = scene.g.pack()
+    args = (scene.gb["depth"], scene.gb["normal"], W, H, TW, TH, scene.sky, 200, 100, scene.light, inst_bytes, c["tiles"], INFLUENCE, scene.shadow_info,
+            scene.shadow_maps[2], 256, gp)
+    y_g, c_g = passes.gpu_sdf_trace(fast, *args, strict=strict, cascade=2)
+    y_o, c_o = passes.orc_sdf_trace(*args, arr, n, strict=strict, cascade=2)
+    # a ray on the edge of the hit threshold / an AABB face may resolve differently; it then changes its own texel and the (up to 8)
+    # neighbours sharing it through the 3x3 resolve. Everything else agrees to half-float precision.
+    assert_close(pixfmt.unpack_half(y_g), pixfmt.unpack_half(y_o), rel=2.0 ** -8, abs_floor_frac=2e-4, outlier_frac=0.03, outlier_max_frac=1.0, mean_rel=2e-2, what="trace Y_SH")
+    assert_close(pixfmt.unpack_half(c_g), pixfmt.unpack_half(c_o), rel=2.0 ** -8, abs_floor_frac=2e-4, outlier_frac=0.03, outlier_max_frac=2.0, mean_rel=2e-2, what="trace CoCg")
