@@ -158,9 +158,13 @@ void orc_deferred_shading(const orc_image* color, const orc_image* depth, const 
                           int32_t indirectLightingTech, uint32_t sunShadowCascadeCount);
 
 /* ---- config 1: CPU SDF bake (AssetPipeline/SceneSDF.cpp) ---- */
-int32_t orc_sdf_bake(const float* positions /* nVerts x 3 */, const float* normals /* nVerts x 3 */, int64_t nVerts,
-                     const uint32_t* indices, int64_t nIndices, const float* bbMin3, const float* bbMax3,
-                     int32_t resX, int32_t resY, int32_t resZ, uint16_t* outHalf);
+/* positions: nVerts x 3 floats, indices: triangle list. Triangle normal = normalize(cross(v0 - v2, v0 - v1)) (SceneSDF.cpp:273).
+ * outHalf: resX*resY*resZ half floats, x fastest. Returns 0, -1 (bad sizes) or -2 (index out of range). */
+int32_t orc_sdf_bake(const float* positions, int64_t nVerts, const uint32_t* indices, int64_t nIndices, const float* bbMin3,
+                     const float* bbMax3, int32_t resX, int32_t resY, int32_t resZ, uint16_t* outHalf);
+void orc_sdf_resolution(const float* bbMin3, const float* bbMax3, int32_t* res3);                     /* SceneSDF.cpp:116-131 */
+void orc_sdf_padded_box(const float* bbMin3, const float* bbMax3, float* outMin3, float* outMax3);    /* sdfUtilities.cpp:5-19 */
+uint16_t orc_pack_half_glm(float v);                                                                  /* glm::packHalf as used at SceneSDF.cpp:506 */
 
 /* row range variants used by the multi-threaded cpu_baseline (rows [y0,y1) of the dispatch domain) */
 void orc_set_threads(int32_t n);

@@ -105,3 +105,38 @@ def codec_eval(fn, data, n, out_dtype, out_count):
     out = np.empty(out_count, out_dtype)
     lib().orc_codec_eval(C.c_int(fn), _p(data), _p(out), C.c_int64(n))
     return out
+
+
+# ---- config 1: SDF bake (AssetPipeline/SceneSDF.cpp)
+def sdf_resolution(bb_min, bb_max):
+    mn = np.ascontiguousarray(bb_min, np.float32); mx = np.ascontiguousarray(bb_max, np.float32)
+    res = np.zeros(3, np.int32)
+    lib().orc_sdf_resolution(_p(mn), _p(mx), _p(res))
+    return tuple(int(r) for r in res)
+
+
+def sdf_padded_box(bb_min, bb_max):
+    mn = np.ascontiguousarray(bb_min, np.float32); mx = np.ascontiguousarray(bb_max, np.float32)
+    omn = np.zeros(3, np.float32); omx = np.zeros(3, np.float32)
+    lib().orc_sdf_padded_box(_p(mn), _p(mx), _p(omn), _p(omx))
+    return omn, omx
+
+
+def pack_half_glm(values):
+    f = lib().orc_pack_half_glm
+    f.restype = C.c_uint16
+    return np.array([f(C.c_float(float(v))) for v in np.asarray(values, np.float32).ravel()], np.uint16)
+
+
+def sdf_bake(positions, indices, bb_min, bb_max, res):
+    """-> uint16 array [resZ, resY, resX] of half-float bits."""
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).ravel()
+    mn = np.ascontiguousarray(bb_min, np.float32); mx = np.ascontiguousarray(bb_max, np.float32)
+    out = np.zeros(res[0] * res[1] * res[2], np.uint16)
+    f = lib().orc_sdf_bake
+    f.restype = C.c_int32
+    rc = f(_p(pos), C.c_int64(pos.shape[0]), _p(idx), C.c_int64(idx.size), _p(mn), _p(mx), C.c_int32(res[0]), C.c_int32(res[1]), C.c_int32(res[2]), _p(out))
+    if rc != 0:
+        raise ValueError("orc_sdf_bake failed: %d" % rc)
+    return out.reshape(res[2], res[1], res[0])

@@ -196,6 +196,7 @@ static Backend* g = nullptr;
 static thread_local std::string g_err;
 
 static int setErr(int code, const std::string& msg) { g_err = msg; return code; }
+int setLastError(int code, const std::string& msg) { return setErr(code, msg); }
 #define HIP_TRY(x)                                                                                      \
     do {                                                                                                \
         hipError_t e_ = (x);                                                                            \

@@ -78,6 +78,9 @@ struct ShaderRegistrar {
 
 inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// records the message plr_last_error() returns on this thread; returns code
+int setLastError(int code, const std::string& msg);
+
 #define PLR_CHECK_LAUNCH(ctx)                                                                   \
     do {                                                                                        \
         hipError_t e_ = hipGetLastError();                                                      \
