@@ -194,7 +194,7 @@ private:
     float m_lastWeights[9] = {};
     CameraExtrinsic m_cameraExtrinsic;
     CameraIntrinsic m_cameraIntrinsic;
-    SDFTraceDependencies m_frustumScratch;
+    SDFTraceDependencies m_frustumScratch{}; // zero until the first setCameraExtrinsic: the reference frontend is a zero-initialised global (RenderFrontend.h)
     int m_sceneRenderTargetIndex = 0;
     bool m_isBRDFLutShaderDescriptionStale = true;
     uint32_t m_depthPyramidThreadgroupCount = 0;

@@ -127,6 +127,37 @@ class SyntheticInputs:
         self.froxel, self.froxel_dims = synth.froxel_volume(width, height, froxel_depth)
         self.vol_settings = synth.volumetric_settings_bytes(30.0)
 
+    # ---- fixtures: the generated arrays as a flat dict of numpy arrays and back (tests/golden)
+    def to_arrays(self):
+        d = {"dims": np.array([self.width, self.height, self.sdf_res, self.shadow_res], np.int64), "sun": np.asarray(self.sun, np.float64),
+             "instance_bytes": np.frombuffer(self.instance_bytes, np.uint8), "bb_bytes": np.frombuffer(self.bb_bytes, np.uint8),
+             "shadow_info": np.frombuffer(bytes(self.shadow_info), np.uint8), "vol_settings": np.frombuffer(bytes(self.vol_settings), np.uint8),
+             "sky": self.sky, "transmission": self.transmission, "froxel": self.froxel, "froxel_dims": np.asarray(self.froxel_dims, np.int64),
+             "n_volumes": np.array([len(self.volumes)], np.int64)}
+        for k, v in self.gb.items():
+            d["gb_" + k] = v
+        for i, v in enumerate(self.volumes):
+            d["volume_%d" % i] = v
+        for i in range(4):
+            d["shadow_map_%d" % i] = self.shadow_maps[i]
+            d["noise_%d" % i] = self.noise[i]
+        return d
+
+    @classmethod
+    def from_arrays(cls, d):
+        self = cls.__new__(cls)
+        self.width, self.height, self.sdf_res, self.shadow_res = (int(v) for v in d["dims"])
+        self.sun = np.asarray(d["sun"], np.float64)
+        self.instance_bytes, self.bb_bytes = d["instance_bytes"].tobytes(), d["bb_bytes"].tobytes()
+        self.shadow_info, self.vol_settings = d["shadow_info"].tobytes(), d["vol_settings"].tobytes()
+        self.sky, self.transmission, self.froxel = d["sky"], d["transmission"], d["froxel"]
+        self.froxel_dims = tuple(int(v) for v in d["froxel_dims"])
+        self.gb = {k[3:]: d[k] for k in d if k.startswith("gb_")}
+        self.volumes = [d["volume_%d" % i] for i in range(int(d["n_volumes"][0]))]
+        self.shadow_maps = [d["shadow_map_%d" % i] for i in range(4)]
+        self.noise = [d["noise_%d" % i] for i in range(4)]
+        return self
+
     def upload(self, fp: FramePipeline):
         be = fp.be
         gb = self.gb

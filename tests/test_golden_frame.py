@@ -1,0 +1,80 @@
+"""Committed golden fixture of the whole hot path (tests/golden/frame_96x54.npz, made by tests/golden/make_frame_golden.py).
+
+CPU: the oracle, replayed from the stored inputs and the stored per-frame global UBO bytes, reproduces the stored outputs
+(pins the oracle over time). GPU: the C++ host mirror, driven with the same cameras, submits the very same UBO bytes / TAA
+weights / frustum (pins the host logic), and the HIP passes reproduce the stored images bit for bit (exact math mode)."""
+import os
+
+import numpy as np
+import pytest
+
+import passes
+from golden import make_frame_golden as gen
+from plainrenderer_amd import pixfmt
+from plainrenderer_amd.frame import PlrfSettings, SyntheticInputs
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_96x54.npz")
+
+
+def load():
+    d = dict(np.load(PATH))
+    inputs = SyntheticInputs.from_arrays({k[3:]: v for k, v in d.items() if k.startswith("in_")})
+    inputs.volume_indices = [int(v) for v in d["volume_indices"]]
+    inst = bytearray(inputs.instance_bytes)
+    import struct
+    for i, ti in enumerate(inputs.volume_indices):
+        struct.pack_into("<I", inst, 16 + i * 96 + 12, ti)
+    inputs.instance_bytes_patched = bytes(inst)
+    settings = PlrfSettings.from_buffer_copy(d["settings"].tobytes())
+    return d, inputs, settings
+
+
+def test_oracle_replays_golden_frames():
+    from oracle_frame import OracleFrame
+    d, inputs, settings = load()
+    ora = OracleFrame(inputs, gen.W, gen.H, gen.LUT, settings)
+    for f in range(gen.N_FRAMES):
+        ora.frame(d["f%d_globals" % f].tobytes(), d["f%d_weights" % f], d["f%d_frustum" % f].tobytes(), float(d["f%d_influence" % f][0]))
+        assert ora.light == d["f%d_light" % f].tobytes(), "light buffer, frame %d" % f
+        assert np.array_equal(ora.hist, d["f%d_hist" % f]) and int(ora.hist.sum()) == gen.W * gen.H
+        assert np.array_equal(np.asarray(ora.hiz[4]).view(np.uint32), d["f%d_hiz4" % f].view(np.uint32))
+        assert np.array_equal(ora.tiles, d["f%d_tiles" % f])
+        assert np.array_equal(ora.full_y, d["f%d_gi_full_y" % f])
+        assert np.array_equal(ora.color[ora.rt_index], d["f%d_color" % f])
+        assert np.array_equal(ora.post1, d["f%d_post1" % f])
+        assert np.array_equal(ora.swapchain, d["f%d_swapchain" % f])
+    lit = pixfmt.unpack_r11g11b10(ora.post1)
+    assert np.isfinite(lit).all() and lit.max() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_frame_matches_golden(backend):
+    from plainrenderer_amd.frame import FramePipeline
+    d, inputs, settings = load()
+    be = backend
+    fp = FramePipeline(be, gen.W, gen.H, **gen.FP_ARGS)
+    assert bytes(fp.settings) == bytes(settings)
+    inputs.upload(fp)
+    # slots in the global texture array depend on what the shared test backend registered before: the four noise-texture
+    # indices (last 16 bytes of the UBO) and the instances' sdfTextureIndex are the only bytes allowed to differ
+    cams = gen.cameras()
+    for f in range(gen.N_FRAMES):
+        dt, t = gen.frame_times(f)
+        fp.frame(cams[f + 1], dt, t)
+        # host logic: identical bytes leave the C++ mirror
+        assert bytes(fp.submitted_globals())[:324] == d["f%d_globals" % f].tobytes()[:324], "global UBO, frame %d" % f
+        assert np.array_equal(np.asarray(fp.resolve_weights(), np.float32).view(np.uint32), d["f%d_weights" % f].view(np.uint32))
+        assert be.downloadUniformBuffer(fp.uniform_buffer("sdfCameraFrustum"), 192).tobytes() == d["f%d_frustum" % f].tobytes()
+        # kernels: identical images
+        assert be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes() == d["f%d_light" % f].tobytes()
+        assert np.array_equal(be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32), d["f%d_hist" % f])
+        exp_tiles = d["f%d_tiles" % f]
+        tiles = be.downloadStorageBuffer(fp.storage_buffer("sdfCulledTiles"), exp_tiles.nbytes, dtype=np.uint32)
+        assert np.array_equal(tiles.reshape(-1, passes.TILE_UINTS)[:, 0], exp_tiles.reshape(-1, passes.TILE_UINTS)[:, 0])
+        assert np.array_equal(be.downloadImage(fp.image("giFullResYSH"), 0, np.uint16), d["f%d_gi_full_y" % f])
+        cur = (f + 1) % 2
+        assert np.array_equal(be.downloadImage(fp.image("color%d" % cur), 0, np.uint32), d["f%d_color" % f].reshape(-1))
+        assert np.array_equal(be.downloadImage(fp.image("post1"), 0, np.uint32), d["f%d_post1" % f].reshape(-1))
+        sw = be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(gen.H, gen.W, 4).astype(int)
+        assert np.abs(sw - d["f%d_swapchain" % f].astype(int)).max() <= 1  # tonemap uses hardware log2/exp2: +-1 LSB of 8 bit
+    fp.destroy()
