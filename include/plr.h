@@ -92,7 +92,16 @@ typedef struct plr_compute_pass_execution {
     plr_pass_resources resources;
     const void* push_constants; uint32_t push_constant_size;
     uint32_t dispatch_count[3];
+    /* extension (no reference counterpart): first workgroup of the dispatch, vkCmdDispatchBase semantics. Zero for the
+     * reference's recorder code. A band renderer (one GPU per range of screen rows) sets [1] so a pass covers only its rows;
+     * [0] is honoured by histogramCombineTiles (first tile), [2] must be 0. */
+    uint32_t dispatch_base[3];
 } plr_compute_pass_execution;
+
+/* extension: host function executed in recording order while plr_render_frame launches the recorded passes; it may enqueue
+ * work (copies, collectives) on the launch stream it is handed. Non-zero return aborts the frame. Used for the halo exchange
+ * between passes when the frame is partitioned over GPUs. */
+typedef int (*plr_host_callback)(void* user, void* hip_stream);
 
 /* SpecialisationConstant, ResourceDescriptions.h:112-115: raw bytes with the C++ sizeof (bool = 1 byte) */
 typedef struct plr_specialisation_constant { uint32_t location; const void* data; uint32_t size; } plr_specialisation_constant;
@@ -124,6 +133,8 @@ int plr_resize_images(const plr_image_handle* images, uint32_t count, uint32_t w
 int plr_new_frame(void);
 /* RenderBackend::setComputePassExecution, RenderBackend.h:56 */
 int plr_set_compute_pass_execution(const plr_compute_pass_execution* execution);
+/* extension: see plr_host_callback; name is the label reported by plr_get_renderpass_timings */
+int plr_set_host_callback_execution(plr_host_callback callback, void* user, const char* name);
 /* RenderBackend::prepareForDrawcallRecording, RenderBackend.h:59: resolves transient images, validates bindings */
 int plr_prepare_for_drawcall_recording(void);
 /* RenderBackend::setUniformBufferData / setStorageBufferData, RenderBackend.h:64-70:

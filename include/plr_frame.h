@@ -28,7 +28,32 @@ typedef struct plrf_settings {
     uint32_t diffuse_brdf, direct_multiscatter, indirect_lighting_tech, use_geometry_aa, sun_shadow_cascade_count;
     /* which pass groups of the frame are recorded (all 1 = full frame) */
     uint32_t run_exposure, run_hiz, run_gi, run_shading, run_taa, run_bloom, run_tonemap;
+    /* band rendering (multi-GPU partition by screen rows; no reference counterpart). width/height stay the whole frame's; this
+     * instance renders full-resolution rows [band_row_begin, band_row_end) (multiples of 64, or the last row). band_row_end == 0:
+     * off. Halos: rows exchanged / recomputed around the band, see BandSettings in csrc/frontend/frame_pipeline.h */
+    uint32_t band_row_begin, band_row_end, band_gi_halo, band_gi_history_halo, band_color_halo, band_post_halo;
 } plrf_settings;
+
+/* ---- band rendering: halo exchange hooks ----
+ * While plrf_frame launches the passes it calls the exchange callback, in pass order, at the points where rows produced by
+ * neighbouring bands are needed. The callback moves the rows (RCCL send/recv on the stream it is handed, or any other transport)
+ * of every item plrf_get_exchange_items reports for that exchange id; PLRF_EXCHANGE_HISTOGRAM instead sums the 128-bin luminance
+ * histogram over all bands in place (plrf_get_histogram_exchange). */
+enum plrf_exchange_id { PLRF_EXCHANGE_HISTOGRAM = 0, PLRF_EXCHANGE_GI_TRACE = 1, PLRF_EXCHANGE_GI_TEMPORAL = 2, PLRF_EXCHANGE_GI_HISTORY = 3,
+                        PLRF_EXCHANGE_POST = 4, PLRF_EXCHANGE_COUNT = 5 };
+typedef int (*plrf_exchange_callback)(void* user, int exchange_id, void* hip_stream);
+/* an image of image_rows rows of row_bytes bytes at device_ptr; this band owns rows [row_begin, row_end): it sends its first
+ * halo_rows owned rows to the band above and its last halo_rows to the band below, and receives rows
+ * [row_begin - halo_rows, row_begin) from above and [row_end, row_end + halo_rows) from below (clipped to the image) */
+typedef struct plrf_exchange_item {
+    plr_image_handle image;
+    void* device_ptr;
+    uint32_t row_begin, row_end, halo_rows, row_bytes, image_rows;
+} plrf_exchange_item;
+int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, void* user);
+/* items of the frame being launched (valid inside the callback and until the next plrf_frame); *inout_count = capacity in, count out */
+int plrf_get_exchange_items(void* pipeline, int exchange_id, plrf_exchange_item* out_items, uint32_t* inout_count);
+int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes);
 
 typedef struct plrf_camera { float position[3], forward[3], up[3], right[3]; } plrf_camera;
 

@@ -82,6 +82,7 @@ struct ComputePassExecution {
     RenderPassExecution genericInfo;
     std::vector<char> pushConstants;
     uint32_t dispatchCount[3] = {1, 1, 1};
+    uint32_t dispatchBase[3] = {0, 0, 0}; // extension: first workgroup (band rendering), see plr.h
 };
 struct SpecialisationConstant {
     uint32_t location;
@@ -149,9 +150,11 @@ public:
         e.resources.storage_images = st.data(); e.resources.storage_image_count = (uint32_t)st.size();
         e.push_constants = execution.pushConstants.data();
         e.push_constant_size = (uint32_t)execution.pushConstants.size();
-        for (int i = 0; i < 3; i++) e.dispatch_count[i] = execution.dispatchCount[i];
+        for (int i = 0; i < 3; i++) { e.dispatch_count[i] = execution.dispatchCount[i]; e.dispatch_base[i] = execution.dispatchBase[i]; }
         check(plr_set_compute_pass_execution(&e));
     }
+    void setHostCallbackExecution(plr_host_callback callback, void* user, const char* name) { check(plr_set_host_callback_execution(callback, user, name)); }
+    void getImageDevicePointer(const ImageHandle image, uint32_t mipLevel, void** outPtr, size_t* outSize) { check(plr_get_image_device_pointer(toC(image), mipLevel, outPtr, outSize)); }
     void prepareForDrawcallRecording() { check(plr_prepare_for_drawcall_recording()); }
     void setUniformBufferData(const UniformBufferHandle buffer, const void* data, const size_t size) { check(plr_set_uniform_buffer_data(buffer.index, data, size)); }
     void setStorageBufferData(const StorageBufferHandle buffer, const void* data, const size_t size) { check(plr_set_storage_buffer_data(buffer.index, data, size)); }

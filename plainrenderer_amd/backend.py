@@ -110,7 +110,7 @@ class _PassResources(C.Structure):
 
 class _ComputePassExecution(C.Structure):
     _fields_ = [("handle", C.c_uint32), ("resources", _PassResources), ("push_constants", C.c_void_p),
-                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3)]
+                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3)]
 
 
 class _SpecConstant(C.Structure):
@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_host_callback_execution",
 ]
 
 
@@ -297,6 +297,7 @@ class RenderBackend:
         e.push_constants = C.cast(buf, C.c_void_p) if buf is not None else None
         e.push_constant_size = len(pc)
         e.dispatch_count = (C.c_uint32 * 3)(*[int(x) for x in exe.dispatchCount])
+        e.dispatch_base = (C.c_uint32 * 3)(*[int(x) for x in getattr(exe, "dispatchBase", (0, 0, 0))])
         self._check(self.lib.plr_set_compute_pass_execution(C.byref(e)))
 
     def prepareForDrawcallRecording(self):

@@ -8,6 +8,7 @@
 #include "backend.h"
 
 #include <chrono>
+#include <set>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -153,6 +154,9 @@ struct PassRes {
 struct Execution {
     uint32_t pass;
     PassCtx ctx;
+    plr_host_callback callback = nullptr; // host callback execution (pass is unused)
+    void* callbackUser = nullptr;
+    const char* callbackName = ""; // interned in Backend::callbackNames
 };
 
 struct FillOrder {
@@ -186,13 +190,16 @@ struct Backend {
     int mathMode = PLR_MATH_FAST;
     std::vector<hipEvent_t> passEvents; // 2 per execution
     std::vector<plr_renderpass_time> lastTimings;
+    std::set<std::string> callbackNames; // stable storage for the labels of host callback executions
     size_t timedExecutions = 0;
     hipEvent_t frameStart = nullptr, frameEnd = nullptr;
     bool frameRecorded = false;
     float lastCpuMs = 0.f;
 };
 
-static Backend* g = nullptr;
+// one backend per host thread: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
+// uses one thread per backend
+static thread_local Backend* g = nullptr;
 static thread_local std::string g_err;
 
 static int setErr(int code, const std::string& msg) { g_err = msg; return code; }
@@ -400,7 +407,20 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
     int rc = resolveResources(e->resources, x.ctx);
     if (rc) { g->executions.pop_back(); return rc; }
     if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
-    for (int i = 0; i < 3; i++) x.ctx.dispatch[i] = e->dispatch_count[i];
+    for (int i = 0; i < 3; i++) { x.ctx.dispatch[i] = e->dispatch_count[i]; x.ctx.base[i] = e->dispatch_base[i]; }
+    if (e->dispatch_base[2] != 0) { g->executions.pop_back(); return setErr(PLR_ERR_INVALID_ARGUMENT, "dispatch_base[2] must be 0"); }
+    return PLR_OK;
+}
+
+int plr_set_host_callback_execution(plr_host_callback callback, void* user, const char* name) {
+    NEED_INIT();
+    if (!callback) return setErr(PLR_ERR_INVALID_ARGUMENT, "callback is null");
+    g->executions.emplace_back();
+    Execution& x = g->executions.back();
+    x.pass = PLR_INVALID_INDEX;
+    x.callback = callback;
+    x.callbackUser = user;
+    x.callbackName = g->callbackNames.insert(name ? name : "host callback").first->c_str();
     return PLR_OK;
 }
 
@@ -535,6 +555,13 @@ static int launchAll(bool timed) {
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
     for (size_t i = 0; i < n; i++) {
         Execution& x = g->executions[i];
+        if (x.callback) {
+            if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
+            const int crc = x.callback(x.callbackUser, (void*)g->stream);
+            if (crc) return setErr(crc, "host callback '" + std::string(x.callbackName) + "' failed with code " + std::to_string(crc));
+            if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
+            continue;
+        }
         PassRes& p = *g->passes[x.pass];
         x.ctx.stream = g->stream;
         x.ctx.global = globalPtr;
@@ -568,7 +595,7 @@ int plr_render_frame(int /*present_to_screen*/) {
     g->timedExecutions = g->passTiming ? g->executions.size() : 0;
     if (g->passTiming) {
         g->lastTimings.clear();
-        for (auto& x : g->executions) g->lastTimings.push_back({0.f, g->passes[x.pass]->name.c_str()});
+        for (auto& x : g->executions) g->lastTimings.push_back({0.f, x.callback ? x.callbackName : g->passes[x.pass]->name.c_str()});
     }
     g->lastCpuMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PLR_OK;

@@ -37,6 +37,7 @@ struct PassCtx {
     BufferBinding ubuf[kMaxBindings];
     std::vector<uint8_t> push;
     uint32_t dispatch[3] = {1, 1, 1};
+    uint32_t base[3] = {0, 0, 0};         // first workgroup of the dispatch (vkCmdDispatchBase semantics; band rendering, plr.h)
     const std::vector<SpecConstant>* spec = nullptr;
     std::string* err = nullptr;
     void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)
@@ -53,6 +54,16 @@ struct PassCtx {
     uint32_t specUint(uint32_t location, uint32_t def) const { return (uint32_t)specInt(location, (int32_t)def); }
     float specFloat(uint32_t location, float def) const;
     bool specBool(uint32_t location, bool def) const;
+
+    // pixel rows [y0, y1) covered by the recorded dispatch for workgroups of wgRows rows, clipped to an image of imageH rows
+    struct RowSpan { int y0, y1; };
+    RowSpan rowSpan(int imageH, int wgRows = 8) const {
+        const long long a = (long long)base[1] * wgRows, b = a + (long long)dispatch[1] * wgRows;
+        RowSpan r;
+        r.y0 = (int)(a < imageH ? a : imageH);
+        r.y1 = (int)(b < imageH ? b : imageH);
+        return r;
+    }
 
     int fail(int code, const std::string& msg) const;
     // checks presence + format of a binding; returns 0 or records an error

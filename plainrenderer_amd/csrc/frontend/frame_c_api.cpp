@@ -1,5 +1,7 @@
 // C entry points of the frame pipeline (include/plr_frame.h).
+#include <algorithm>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 
 #include "../../../include/plr_frame.h"
@@ -30,6 +32,7 @@ int plrf_default_settings(plrf_settings* o, uint32_t width, uint32_t height) {
     o->indirect_lighting_tech = (uint32_t)d.shading.indirectLightingTech; o->use_geometry_aa = d.shading.useGeometryAA;
     o->sun_shadow_cascade_count = (uint32_t)d.shading.sunShadowCascadeCount;
     o->run_exposure = o->run_hiz = o->run_gi = o->run_shading = o->run_taa = o->run_bloom = o->run_tonemap = 1;
+    o->band_gi_halo = d.band.giHalo; o->band_gi_history_halo = d.band.giHistoryHalo; o->band_color_halo = d.band.colorHalo; o->band_post_halo = d.band.postHalo;
     return PLR_OK;
 }
 
@@ -49,6 +52,8 @@ int plrf_create(const plrf_settings* s, void** out) {
         f.shading.sunShadowCascadeCount = (int)s->sun_shadow_cascade_count;
         f.runExposure = s->run_exposure; f.runHiZ = s->run_hiz; f.runGI = s->run_gi; f.runShading = s->run_shading; f.runTAA = s->run_taa;
         f.runBloom = s->run_bloom; f.runTonemap = s->run_tonemap;
+        f.band.rowBegin = s->band_row_begin; f.band.rowEnd = s->band_row_end; f.band.giHalo = s->band_gi_halo; f.band.giHistoryHalo = s->band_gi_history_halo;
+        f.band.colorHalo = s->band_color_halo; f.band.postHalo = s->band_post_halo;
         *out = new FramePipeline(f);
     })
 }
@@ -91,5 +96,31 @@ int plrf_frame(void* p, const plrf_camera* c, float dt, float time) {
 int plrf_get_submitted_globals(void* p, void* out) { std::memcpy(out, &((FramePipeline*)p)->lastSubmittedGlobals(), 340); return PLR_OK; }
 int plrf_get_resolve_weights(void* p, float* out) { std::memcpy(out, ((FramePipeline*)p)->lastResolveWeights(), 36); return PLR_OK; }
 int plrf_get_cpu_frame_index(void* p, uint64_t* out) { *out = ((FramePipeline*)p)->cpuFrameIndex(); return PLR_OK; }
+
+int plrf_set_exchange_callback(void* p, plrf_exchange_callback cb, void* user) { PLRF_TRY(((FramePipeline*)p)->setExchangeCallback(cb, user)) }
+int plrf_get_exchange_items(void* p, int id, plrf_exchange_item* out, uint32_t* inoutCount) {
+    if (id < 0 || id >= ExchangeCount || !inoutCount) { g_ferr = "invalid exchange id"; return PLR_ERR_INVALID_ARGUMENT; }
+    PLRF_TRY({
+        FramePipeline* fp = (FramePipeline*)p;
+        const std::vector<ExchangeItem>& items = fp->exchangeItems(id);
+        const uint32_t n = std::min<uint32_t>((uint32_t)items.size(), out ? *inoutCount : 0u);
+        for (uint32_t i = 0; i < n; i++) {
+            const ExchangeItem& it = items[i];
+            size_t bytes = 0;
+            out[i].image = RenderBackend::toC(it.image);
+            fp->backend().getImageDevicePointer(it.image, it.mip, &out[i].device_ptr, &bytes);
+            out[i].row_begin = it.rowBegin; out[i].row_end = it.rowEnd; out[i].halo_rows = it.haloRows; out[i].row_bytes = it.rowBytes; out[i].image_rows = it.imageRows;
+        }
+        *inoutCount = (uint32_t)items.size();
+    })
+}
+int plrf_get_histogram_exchange(void* p, void** outPtr, size_t* outBytes) {
+    PLRF_TRY({
+        FramePipeline* fp = (FramePipeline*)p;
+        size_t size = 0;
+        if (plr_get_storage_buffer_device_pointer(fp->histogramBuffer().index, outPtr, &size) != PLR_OK) throw std::runtime_error(plr_last_error());
+        *outBytes = 128 * sizeof(uint32_t);
+    })
+}
 
 } // extern "C"

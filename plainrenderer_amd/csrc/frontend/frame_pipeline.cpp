@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <stdexcept>
 
 namespace plrhost {
 
@@ -84,10 +85,17 @@ static ImageDescription desc2D(uint32_t w, uint32_t h, ImageFormat f, ImageUsage
     d.width = w; d.height = h; d.depth = 1; d.type = ImageType::Type2D; d.format = f; d.usageFlags = usage; d.mipCount = mips; d.manualMipCount = manual;
     return d;
 }
-static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h) {
+// 8x8 workgroups over a w x h image; rows restricts the dispatch to the workgroup rows touching [rows.begin, rows.end)
+static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows = {}) {
+    const uint32_t lo = std::min(rows.begin, h), hi = std::min(rows.end, h);
     exe.dispatchCount[0] = (uint32_t)std::ceil(w / 8.f);
-    exe.dispatchCount[1] = (uint32_t)std::ceil(h / 8.f);
+    exe.dispatchBase[1] = lo / 8;
+    exe.dispatchCount[1] = hi > lo ? (hi + 7) / 8 - lo / 8 : 0;
     exe.dispatchCount[2] = 1;
+}
+static RowRange scaleRows(RowRange r, uint32_t divisor) { // the rows of a 1/divisor resolution image that cover r
+    if (r.end == 0xffffffffu && r.begin == 0) return r;
+    return {r.begin / divisor, (r.end + divisor - 1) / divisor};
 }
 
 // ------------------------------------------------------------------ TAA (Techniques/TAA.cpp)
@@ -107,7 +115,8 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     ub.size = sizeof(float) * 9;
     m_taaResolveWeightBuffer = be.createUniformBuffer(ub);
 }
-void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target) const {
+void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
+                                RowRange rows) const {
     // TAA.cpp:139-166
     const size_t frameIndexMod2 = fi.mod2();
     const ImageHandle historySrc = m_historyBuffers[frameIndexMod2];
@@ -119,7 +128,7 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     exe.genericInfo.resources.sampledImages = {ImageResource(colorSrc, 0, 0), ImageResource(historySrc, 0, 3), ImageResource(currentFrame.motionBuffer, 0, 4),
                                                ImageResource(currentFrame.depthBuffer, 0, 5)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_taaResolveWeightBuffer, 6)};
-    dispatch8(exe, td.width, td.height);
+    dispatch8(exe, td.width, td.height, rows);
     be.setComputePassExecution(exe);
 }
 void TAA::jitterInPixels(const FrameIndexCounter& fi, float out[2]) const { // TAA.cpp:168-170
@@ -165,7 +174,7 @@ void Bloom::init(RenderBackend& be) { // Bloom.cpp:8-40
     d.shaderDescription.srcPathRelative = "applyBloom.comp";
     m_applyBloomPass = be.createComputePass(d);
 }
-void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings) const { // Bloom.cpp:56-143
+void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows) const { // Bloom.cpp:56-143
     const ImageDescription td = be.getImageDescription(targetImage);
     const int width = (int)td.width, height = (int)td.height;
     const ImageDescription desc = desc2D(width, height, ImageFormat::R11G11B10_uFloat, ImageUsageFlags::Sampled | ImageUsageFlags::Storage, MipCount::Manual, bloomMipCount);
@@ -178,7 +187,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(i == 0 ? targetImage : downscaleTexture, sourceMip, 1)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th);
+        dispatch8(exe, tw, th, scaleRows(chainRows, 1u << targetMip));
         be.setComputePassExecution(exe);
     }
     const ImageHandle upscaleTexture = be.createTemporaryImage(desc);
@@ -190,7 +199,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, sourceMip, 1), ImageResource(downscaleTexture, sourceMip, 2)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th);
+        dispatch8(exe, tw, th, scaleRows(chainRows, 1u << targetMip));
         exe.pushConstants = dataToCharArray(&settings.radius, sizeof(settings.radius));
         be.setComputePassExecution(exe);
     }
@@ -198,7 +207,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
     exe.genericInfo.handle = m_applyBloomPass;
     exe.genericInfo.resources.storageImages = {ImageResource(targetImage, 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, 0, 1)};
-    dispatch8(exe, width, height);
+    dispatch8(exe, width, height, applyRows);
     exe.pushConstants = dataToCharArray(&settings.strength, sizeof(settings.strength));
     be.setComputePassExecution(exe);
 }
@@ -286,12 +295,12 @@ SDFGI::IndirectLightingImages SDFGI::getIndirectLightingResults(bool tracedHalfR
     return {m_indirectDiffuseHistory_Y_SH[0], m_indirectDiffuseHistory_CoCg[0]};
 }
 
-void SDFGI::computeIndirectLighting(RenderBackend& be, const FrameIndexCounter&, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const {
-    diffuseSDFTrace(be, deps, s);
-    filterIndirectDiffuse(be, deps, s);
+void SDFGI::computeIndirectLighting(RenderBackend& be, const FrameIndexCounter&, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const {
+    diffuseSDFTrace(be, deps, s, band);
+    filterIndirectDiffuse(be, deps, s, band);
 }
 
-void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling) const {
+void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling, const GiBand* band) const {
     // SDFGI.cpp:538-630
     {
         struct GPUFrustumData { float points[6][4]; float normal[6][4]; } frustumData;
@@ -318,6 +327,12 @@ void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& de
         exe.dispatchCount[0] = uint32_t(std::ceil(tileCount[0] / float(localGroupSize)));
         exe.dispatchCount[1] = uint32_t(std::ceil(tileCount[1] / float(localGroupSize)));
         exe.dispatchCount[2] = 1;
+        if (band) { // only the workgroups (8 tile rows each) that hold tiles of the band's trace rows
+            const uint32_t tileRows = (uint32_t)sdfCameraCullingTileSize * localGroupSize;
+            const uint32_t lo = std::min(band->traceRows.begin, (uint32_t)targetH), hi = std::min(band->traceRows.end, (uint32_t)targetH);
+            exe.dispatchBase[1] = lo / tileRows;
+            exe.dispatchCount[1] = hi > lo ? (hi + tileRows - 1) / tileRows - lo / tileRows : 0;
+        }
         exe.pushConstants = dataToCharArray(&tileCount, sizeof(tileCount));
         exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sdfCameraFrustumCulledInstances, true, 0), StorageBufferResource(m_sdfInstanceWorldBBBuffer, true, 1),
                                                     StorageBufferResource(m_sdfCameraCulledTiles, false, 2)};
@@ -329,9 +344,9 @@ void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& de
     }
 }
 
-void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const { // SDFGI.cpp:380-419
+void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const { // SDFGI.cpp:380-419
     const ImageDescription td = be.getImageDescription(m_indirectDiffuse_CoCg[0]);
-    sdfInstanceCulling(be, deps, td.width, td.height, s.traceInfluenceRadius, true);
+    sdfInstanceCulling(be, deps, td.width, td.height, s.traceInfluenceRadius, true, band);
     ComputePassExecution exe;
     exe.genericInfo.handle = m_diffuseSDFTracePass;
     exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuse_CoCg[0], 0, 1)};
@@ -340,20 +355,22 @@ void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps,
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
                                                 StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
-    dispatch8(exe, td.width, td.height);
+    dispatch8(exe, td.width, td.height, band ? band->traceRows : RowRange{});
     be.setComputePassExecution(exe);
+    if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTrace); // spatial pass 0 reads neighbouring bands' rays
 }
 
-void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const { // SDFGI.cpp:421-536
+void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const { // SDFGI.cpp:421-536
     const ImageHandle depthSrc = s.halfResTrace ? deps.depthHalfRes : deps.currentFrame.depthBuffer;
     const ImageDescription td = be.getImageDescription(m_indirectDiffuse_Y_SH[1]);
+    const RowRange rows = band ? band->traceRows : RowRange{};
     {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[0];
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 0), ImageResource(m_indirectDiffuse_CoCg[1], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuse_CoCg[0], 0, 3), ImageResource(depthSrc, 0, 4),
                                                    ImageResource(deps.worldSpaceNormals, 0, 5)};
-        dispatch8(exe, td.width, td.height);
+        dispatch8(exe, td.width, td.height, rows);
         be.setComputePassExecution(exe);
     }
     {
@@ -365,18 +382,20 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
                                                    ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
                                                    ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
-        dispatch8(exe, td.width, td.height);
+        dispatch8(exe, td.width, td.height, rows);
         be.setComputePassExecution(exe);
     }
+    if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
     {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[1];
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
-        dispatch8(exe, td.width, td.height);
+        dispatch8(exe, td.width, td.height, rows);
         be.setComputePassExecution(exe);
     }
+    if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiHistory); // upscale + next frame's reprojection read History[0]
     if (s.halfResTrace) {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectLightingUpscale;
@@ -384,7 +403,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 3),
                                                    ImageResource(deps.currentFrame.depthBuffer, 0, 4), ImageResource(deps.depthHalfRes, 0, 5)};
         const ImageDescription fd = be.getImageDescription(m_indirectLightingFullRes_Y_SH);
-        dispatch8(exe, fd.width, fd.height);
+        dispatch8(exe, fd.width, fd.height, band ? band->upscaleRows : RowRange{});
         be.setComputePassExecution(exe);
     }
 }
@@ -405,8 +424,17 @@ static void singlePassMipChainDispatchCount(uint32_t width, uint32_t height, uin
     out[1] = (uint32_t)std::ceil(float(height) / localThreadGroupExtent);
 }
 
+static const uint32_t bandAlignment = 64;      // HiZ tile (64 px), culling tile (32 trace px), histogram tile (32 px), 2^5 bloom texel
+static const uint32_t bandPyramidMipCount = 6; // per-tile levels of the HiZ kernel; the hot path reads mip 4 (SDFGI.cpp:567)
+
 FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     const uint32_t W = s.width, H = s.height;
+    if (s.band.enabled()) {
+        const BandSettings& b = s.band;
+        if (b.rowEnd > H || b.rowBegin % bandAlignment != 0 || (b.rowEnd % bandAlignment != 0 && b.rowEnd != H))
+            throw std::runtime_error("band rows must lie inside the frame and start/end on multiples of 64 (or at the last row)");
+    }
+    for (int i = 0; i < ExchangeCount; i++) m_exchangeCtx[i] = {this, i};
     // the backend is set up by the caller (plr_setup), like gRenderBackend.setup in the reference's main(); match the swapchain
     const ImageDescription sw = m_be.getImageDescription(m_be.getSwapchainInputImage());
     if (sw.width != W || sw.height != H) m_be.recreateSwapchain(W, H);
@@ -446,7 +474,10 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     m_worldSpaceNormalImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
     m_albedoImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
     m_specularImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
-    m_minMaxDepthPyramid = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::FullChain), nullptr, 0);
+    // a band builds only the levels one 64x64-pixel tile yields (the rest of the chain needs every band and has no consumer on this path)
+    m_minMaxDepthPyramid = s.band.enabled()
+        ? m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::Manual, bandPyramidMipCount), nullptr, 0)
+        : m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::FullChain), nullptr, 0);
     m_depthHalfRes = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::R16_sFloat), nullptr, 0);
     m_brdfLut = m_be.createImage(desc2D(s.brdfLutRes, s.brdfLutRes, ImageFormat::RGBA16_sFloat), nullptr, 0);
     m_skyLut = m_be.createImage(desc2D(200, 100, ImageFormat::R11G11B10_uFloat), nullptr, 0);          // Sky.cpp sky LUT
@@ -502,7 +533,7 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         d.name = "Depth min/max pyramid";
         d.shaderDescription.srcPathRelative = "depthHiZPyramid.comp";
         const uint32_t pw = W / 2, ph = H / 2;
-        const uint32_t depthMipCount = mipCountFromResolution(pw, ph, 1);
+        const uint32_t depthMipCount = s.band.enabled() ? bandPyramidMipCount : mipCountFromResolution(pw, ph, 1);
         uint32_t dc[2];
         singlePassMipChainDispatchCount(pw, ph, depthMipCount, 11, dc);
         m_depthPyramidThreadgroupCount = dc[0] * dc[1];
@@ -601,6 +632,7 @@ void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { //
     const StorageBufferResource histogramPerTileResource(m_histogramPerTileBuffer, false, 0);
     const StorageBufferResource histogramResource(m_histogramBuffer, false, 1);
     const uint32_t W = settings.width, H = settings.height;
+    const RowRange tileRows = scaleRows(bandRows(0), histogramTileSizeY);
     {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_histogramPerTilePass;
@@ -609,6 +641,10 @@ void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { //
         exe.dispatchCount[0] = uint32_t(std::ceil((float)W / float(histogramTileSizeX)));
         exe.dispatchCount[1] = uint32_t(std::ceil((float)H / float(histogramTileSizeY)));
         exe.dispatchCount[2] = 1;
+        if (settings.band.enabled()) { // the band's tile rows; the global histogram is the sum over bands (ExchangeHistogram)
+            exe.dispatchBase[1] = tileRows.begin;
+            exe.dispatchCount[1] = tileRows.end - tileRows.begin;
+        }
         m_be.setComputePassExecution(exe);
     }
     const float binsPerDispatch = 64.f;
@@ -625,6 +661,11 @@ void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { //
         exe.genericInfo.resources.storageBuffers = {histogramPerTileResource, histogramResource};
         exe.dispatchCount[0] = (uint32_t)std::ceil(W / float(histogramTileSizeX)) * (uint32_t)std::ceil(H / float(histogramTileSizeY));
         exe.dispatchCount[1] = uint32_t(std::ceil(float(nHistogramBins) / binsPerDispatch));
+        if (settings.band.enabled()) {
+            const uint32_t tilesX = (uint32_t)std::ceil(W / float(histogramTileSizeX));
+            exe.dispatchBase[0] = tileRows.begin * tilesX;
+            exe.dispatchCount[0] = (tileRows.end - tileRows.begin) * tilesX;
+        }
         m_be.setComputePassExecution(exe);
     }
 }
@@ -641,10 +682,16 @@ void FramePipeline::computeDepthPyramid(ImageHandle depthBuffer) { // RenderFron
     ComputePassExecution exe;
     exe.genericInfo.handle = m_depthPyramidPass;
     const uint32_t width = settings.width / 2, height = settings.height / 2, maxMipCount = 11;
-    const uint32_t mipCount = mipCountFromResolution(width, height, 1);
+    const uint32_t mipCount = settings.band.enabled() ? bandPyramidMipCount : mipCountFromResolution(width, height, 1);
     uint32_t dc[2];
     singlePassMipChainDispatchCount(width, height, mipCount, maxMipCount, dc);
     exe.dispatchCount[0] = dc[0]; exe.dispatchCount[1] = dc[1]; exe.dispatchCount[2] = 1;
+    if (settings.band.enabled()) { // one workgroup per 32x32 texels of pyramid mip 0 = 64 full-resolution rows
+        const RowRange groups = scaleRows(bandRows(0), 64);
+        exe.dispatchCount[0] = (width + 31) / 32;
+        exe.dispatchBase[1] = groups.begin;
+        exe.dispatchCount[1] = groups.end - groups.begin;
+    }
     exe.genericInfo.resources.sampledImages = {ImageResource(depthBuffer, 0, 13), ImageResource(m_minMaxDepthPyramid, 0, 15)};
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_depthPyramidSyncBuffer, false, 16)};
     const uint32_t unusedMipCount = maxMipCount - mipCount;
@@ -658,7 +705,8 @@ void FramePipeline::computeDepthPyramid(ImageHandle depthBuffer) { // RenderFron
 void FramePipeline::downscaleDepth(const FrameRenderTargets& currentTarget) { // RenderFrontend.cpp:873-892
     ComputePassExecution exe;
     exe.genericInfo.handle = m_depthDownscalePass;
-    dispatch8(exe, settings.width / 2, settings.height / 2);
+    // band: the spatial filters sample half-res depth up to giHalo trace rows away, the upscale one more
+    dispatch8(exe, settings.width / 2, settings.height / 2, bandRows(2 * (settings.band.giHalo + settings.band.giHistoryHalo) + 16, 2));
     exe.genericInfo.resources.storageImages = {ImageResource(m_depthHalfRes, 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(currentTarget.depthBuffer, 0, 1)};
     m_be.setComputePassExecution(exe);
@@ -676,7 +724,7 @@ void FramePipeline::computeDeferredShading(ImageHandle colorTarget, const FrameR
                                                ImageResource(m_albedoImage, 0, 22), ImageResource(m_specularImage, 0, 23), ImageResource(m_skyLut, 0, 24)};
     for (uint32_t i = 0; i < (uint32_t)maxSunShadowCascadeCount; i++) exe.genericInfo.resources.sampledImages.push_back(ImageResource(m_shadowMaps[i], 0, 9 + i));
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 19)};
-    dispatch8(exe, settings.width, settings.height);
+    dispatch8(exe, settings.width, settings.height, bandRows(settings.band.colorHalo));
     m_be.setComputePassExecution(exe);
 }
 
@@ -685,7 +733,7 @@ void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:
     exe.genericInfo.handle = m_tonemappingPass;
     exe.genericInfo.resources.storageImages = {ImageResource(m_be.getSwapchainInputImage(), 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(src, 0, 1)};
-    dispatch8(exe, settings.width, settings.height);
+    dispatch8(exe, settings.width, settings.height, bandRows(0));
     m_be.setComputePassExecution(exe);
 }
 
@@ -697,6 +745,37 @@ void FramePipeline::computeBRDFLut() { // RenderFrontend.cpp:1031-1042
     m_be.setComputePassExecution(exe);
 }
 
+RowRange FramePipeline::bandRows(uint32_t halo, uint32_t divisor) const {
+    if (!settings.band.enabled()) return {};
+    const uint32_t lo = settings.band.rowBegin > halo ? settings.band.rowBegin - halo : 0;
+    const uint32_t hi = std::min(settings.band.rowEnd + halo, settings.height);
+    return {lo / divisor, (hi + divisor - 1) / divisor};
+}
+
+void FramePipeline::addExchangeItem(int id, ImageHandle image, uint32_t divisor, uint32_t haloRows) {
+    const ImageDescription d = m_be.getImageDescription(image);
+    ExchangeItem it;
+    it.image = image;
+    it.rowBegin = settings.band.rowBegin / divisor;
+    it.rowEnd = std::min((settings.band.rowEnd + divisor - 1) / divisor, d.height);
+    it.haloRows = haloRows;
+    it.imageRows = d.height;
+    size_t bytes = 0;
+    void* ptr = nullptr;
+    m_be.getImageDevicePointer(image, 0, &ptr, &bytes);
+    it.rowBytes = (uint32_t)(bytes / d.height);
+    m_exchangeItems[id].push_back(it);
+}
+
+int FramePipeline::exchangeTrampoline(void* user, void* stream) {
+    const ExchangeCtx* ctx = (const ExchangeCtx*)user;
+    return ctx->self->m_exchangeFn ? ctx->self->m_exchangeFn(ctx->self->m_exchangeUser, ctx->id, stream) : 0;
+}
+
+void FramePipeline::exchangePoint(int id, const char* label) {
+    if (m_exchangeFn) m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[id], label);
+}
+
 void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     const FrameRenderTargets previousRenderTarget = m_frameRenderTargets[m_sceneRenderTargetIndex];
     m_sceneRenderTargetIndex = (m_sceneRenderTargetIndex + 1) % 2;
@@ -706,8 +785,11 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
         computeBRDFLut();
         m_isBRDFLutShaderDescriptionStale = false;
     }
+    const bool band = settings.band.enabled();
+    for (auto& items : m_exchangeItems) items.clear();
     if (settings.runExposure) {
         computeColorBufferHistogram(previousRenderTarget.colorBuffer);
+        if (band) exchangePoint(ExchangeHistogram, "Exchange: histogram all-reduce");
         // [m_sky.updateTransmissionLut: input]
         computeExposure();
     }
@@ -726,17 +808,49 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
         deps.lightBuffer = m_lightBuffer;
         deps.sunShadowInfoBuffer = m_sunShadowInfoBuffer;
         deps.depthMinMaxPyramid = m_minMaxDepthPyramid;
-        m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace);
+        if (band) {
+            const uint32_t div = settings.sdfTrace.halfResTrace ? 2 : 1;
+            GiBand gb;
+            gb.traceRows = bandRows(0, div);
+            gb.upscaleRows = bandRows(settings.band.colorHalo);
+            gb.user = this;
+            gb.exchangePoint = [](void* user, int id) {
+                FramePipeline* self = (FramePipeline*)user;
+                const SDFGI& gi = self->m_sdfGi;
+                const uint32_t d = self->settings.sdfTrace.halfResTrace ? 2 : 1;
+                const BandSettings& b = self->settings.band;
+                if (id == ExchangeGiTrace) {
+                    self->addExchangeItem(id, gi.m_indirectDiffuse_Y_SH[0], d, b.giHalo);
+                    self->addExchangeItem(id, gi.m_indirectDiffuse_CoCg[0], d, b.giHalo);
+                    self->exchangePoint(id, "Exchange: traced GI halo rows");
+                } else if (id == ExchangeGiTemporal) {
+                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[1], d, b.giHalo);
+                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[1], d, b.giHalo);
+                    self->exchangePoint(id, "Exchange: temporally filtered GI halo rows");
+                } else {
+                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[0], d, b.giHistoryHalo);
+                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[0], d, b.giHistoryHalo);
+                    self->exchangePoint(id, "Exchange: GI history halo rows");
+                }
+            };
+            m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace, &gb);
+        } else m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace);
     }
     // [volumetrics: input]
     if (settings.runShading) computeDeferredShading(currentRenderTarget.colorBuffer, currentRenderTarget);
     // [sky: folded into the deferred pass' sky stand-in]
     ImageHandle currentSrc = currentRenderTarget.colorBuffer;
     if (settings.runTAA && settings.taa.enabled) {
-        m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1]);
+        m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
         currentSrc = m_postProcessBuffers[1];
     }
-    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom);
+    if (band) {
+        // the bloom chain reads postHalo rows around the band; next frame's temporal filter reprojects into the history image
+        if (settings.runBloom && settings.bloom.enabled) addExchangeItem(ExchangePost, currentSrc, 1, settings.band.postHalo);
+        if (settings.runTAA && settings.taa.enabled) addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.postHalo);
+        if (!m_exchangeItems[ExchangePost].empty()) exchangePoint(ExchangePost, "Exchange: resolved colour halo rows");
+    }
+    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0));
     if (settings.runTonemap) computeTonemapping(currentSrc);
 }
 

@@ -54,6 +54,25 @@ struct CameraIntrinsic { float fov = 35.f; float aspectRatio = 1.f; float near =
 
 struct FrameRenderTargets { ImageHandle colorBuffer, motionBuffer, depthBuffer; };
 
+// ---- band rendering (no reference counterpart): the frame is partitioned over GPUs by screen rows.
+// Every instance allocates the images of the WHOLE frame (HBM is not the constraint: ~80 B/px) and uses full-frame coordinates,
+// but records dispatches (ComputePassExecution::dispatchBase) only for the rows it owns plus the halo a later pass reads, and
+// calls the exchange callback where a pass reads rows a neighbouring band produced (DESIGN.md "Multi-GPU").
+struct RowRange { uint32_t begin = 0, end = 0xffffffffu; }; // pixel rows of a pass's output image; default = all rows
+struct BandSettings {
+    uint32_t rowBegin = 0, rowEnd = 0;  // owned full-resolution rows [rowBegin, rowEnd); rowEnd == 0: band rendering off
+    uint32_t giHalo = 64;               // trace-resolution rows of the GI images exchanged before each spatial filter pass
+    uint32_t giHistoryHalo = 16;        // trace-resolution rows of the filtered GI exchanged for the upscale / next frame's reprojection
+    uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
+    uint32_t postHalo = 320;            // full-resolution rows of the temporal filter's result exchanged (bloom chain, TAA history)
+    bool enabled() const { return rowEnd > rowBegin; }
+};
+enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeCount = 5 };
+// one image whose rows next to the band must be refreshed from the neighbours: this band sends its first / last haloRows owned
+// rows up / down and receives [rowBegin - haloRows, rowBegin) and [rowEnd, rowEnd + haloRows) (clipped to the image)
+struct ExchangeItem { ImageHandle image; uint32_t mip = 0; uint32_t rowBegin = 0, rowEnd = 0, haloRows = 0, rowBytes = 0, imageRows = 0; };
+typedef int (*ExchangeCallback)(void* user, int exchangeId, void* hipStream);
+
 // ---- Techniques/TAA.h
 enum class HistorySamplingTech : int { Bilinear = 0, Bicubic16Tap = 1, Bicubic9Tap = 2, Bicubic5Tap = 3, Bicubic1Tap = 4 };
 struct TAASettings {
@@ -94,7 +113,9 @@ struct FrameIndexCounter { // Runtime/FrameIndex.cpp
 class TAA {
 public:
     void init(RenderBackend& be, int imageWidth, int imageHeight, const TAASettings& settings);
-    void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target) const;
+    void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
+                               RowRange rows = {}) const;
+    ImageHandle historyDst(const FrameIndexCounter& fi) const { return m_historyBuffers[(fi.mod2() + 1) % 2]; }
     void jitterInPixels(const FrameIndexCounter& fi, float out[2]) const;
     void updateTaaResolveWeights(RenderBackend& be, const float cameraJitterInPixels[2]);
     ImageHandle m_historyBuffers[2];
@@ -106,10 +127,19 @@ private:
 class Bloom {
 public:
     void init(RenderBackend& be);
-    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings) const;
+    // chainRows: rows of the target image the down/upsample chain is evaluated for (scaled per mip); applyRows: rows bloom is applied to
+    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}) const;
 private:
     std::vector<RenderPassHandle> m_bloomDownsamplePasses, m_bloomUpsamplePasses;
     RenderPassHandle m_applyBloomPass;
+};
+
+// row ranges of one band for the GI passes + where the recorder asks for a halo exchange (band rendering only)
+struct GiBand {
+    RowRange traceRows;    // trace-resolution rows traced and filtered
+    RowRange upscaleRows;  // full-resolution rows of the upscale
+    void* user = nullptr;
+    void (*exchangePoint)(void* user, int exchangeId) = nullptr; // records the exchange as a host callback execution
 };
 
 struct SDFTraceDependencies {
@@ -124,16 +154,16 @@ public:
     void init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& traceSettings, int sunShadowCascadeIndex, uint32_t maxInstances);
     // packed { uint count; uint pad[3]; SDFInstance[] } and { vec3 min; pad; vec3 max; pad }[] as SDFGI::updateSDFScene builds them
     void updateSDFScene(RenderBackend& be, const void* instanceBufferData, size_t instanceBytes, const void* worldBBData, size_t bbBytes);
-    void computeIndirectLighting(RenderBackend& be, const FrameIndexCounter& fi, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
+    void computeIndirectLighting(RenderBackend& be, const FrameIndexCounter& fi, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band = nullptr) const;
     struct IndirectLightingImages { ImageHandle Y_SH, CoCg; };
     IndirectLightingImages getIndirectLightingResults(bool tracedHalfRes) const;
     ImageHandle m_indirectDiffuse_Y_SH[2], m_indirectDiffuse_CoCg[2], m_indirectDiffuseHistory_Y_SH[2], m_indirectDiffuseHistory_CoCg[2];
     ImageHandle m_indirectLightingFullRes_Y_SH, m_indirectLightingFullRes_CoCg;
     StorageBufferHandle m_sdfInstanceBuffer, m_sdfCameraFrustumCulledInstances, m_sdfInstanceWorldBBBuffer, m_sdfCameraCulledTiles;
 private:
-    void sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling) const;
-    void diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
-    void filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s) const;
+    void sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling, const GiBand* band) const;
+    void diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const;
+    void filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const;
 public:
     UniformBufferHandle m_cameraFrustumBuffer, m_sdfTraceInfluenceRangeBuffer;
 private:
@@ -154,6 +184,7 @@ struct FramePipelineSettings {
     ShadingConfig shading;
     // which groups of prepareRenderpasses are recorded (all on = the full frame)
     bool runExposure = true, runHiZ = true, runGI = true, runShading = true, runTAA = true, runBloom = true, runTonemap = true;
+    BandSettings band; // width/height stay the WHOLE frame's
 };
 
 class FramePipeline {
@@ -173,6 +204,10 @@ public:
     const GlobalShaderInfo& lastSubmittedGlobals() const { return m_submittedGlobals; }
     const float* lastResolveWeights() const { return m_lastWeights; }
     size_t cpuFrameIndex() const { return m_frameIndex.frameIndex; }
+    // band rendering: called (from inside renderFrame, in pass order) where rows of neighbouring bands are needed
+    void setExchangeCallback(ExchangeCallback fn, void* user) { m_exchangeFn = fn; m_exchangeUser = user; }
+    const std::vector<ExchangeItem>& exchangeItems(int exchangeId) const { return m_exchangeItems[exchangeId]; }
+    StorageBufferHandle histogramBuffer() const { return m_histogramBuffer; }
     RenderBackend& backend() { return m_be; }
     FramePipelineSettings settings;
 
@@ -187,6 +222,10 @@ private:
     void computeBRDFLut();
     void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
     void updateGlobalShaderInfo(float deltaTime, float time);
+    RowRange bandRows(uint32_t halo, uint32_t divisor = 1) const;
+    void exchangePoint(int exchangeId, const char* label);
+    void addExchangeItem(int exchangeId, ImageHandle image, uint32_t divisor, uint32_t haloRows);
+    static int exchangeTrampoline(void* user, void* stream);
 
     RenderBackend m_be;
     FrameIndexCounter m_frameIndex;
@@ -211,6 +250,11 @@ private:
     TAA m_taa;
     Bloom m_bloom;
     SDFGI m_sdfGi;
+
+    ExchangeCallback m_exchangeFn = nullptr;
+    void* m_exchangeUser = nullptr;
+    struct ExchangeCtx { FramePipeline* self; int id; } m_exchangeCtx[ExchangeCount];
+    std::vector<ExchangeItem> m_exchangeItems[ExchangeCount];
 };
 
 } // namespace plrhost

@@ -29,9 +29,9 @@ PLR_DI vec3 bloomTap(const ImgView& im, float u, float v) {
 }
 
 // bloomDownsample.comp:12-49
-__global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, ImgView target, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
     const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float uvx = ((float)x + 0.5f) / (float)target.w, uvy = ((float)y + 0.5f) / (float)target.h;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
@@ -52,18 +52,20 @@ __global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, Img
     ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
 }
 
-static int coverage(const PassCtx& c, const ImgView& target, int* w, int* h) {
+// columns [0, w) and rows [y0, h) of the target covered by the recorded dispatch
+static int coverage(const PassCtx& c, const ImgView& target, int* w, int* h, int* y0) {
     *w = std::min((int)(c.dispatch[0] * 8u), target.w);
-    *h = std::min((int)(c.dispatch[1] * 8u), target.h);
-    return (*w > 0 && *h > 0) ? 1 : 0;
+    const PassCtx::RowSpan rs = c.rowSpan(target.h);
+    *h = rs.y1; *y0 = rs.y0;
+    return (*w > 0 && *h > *y0) ? 1 : 0;
 }
 
 static int launchBloomDownsample(const PassCtx& c) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomDownsample target")) return rc;
     if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
-    int w, h;
-    if (!coverage(c, c.storage[0], &w, &h)) return 0;
-    bloomDownsampleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.sampled[1], c.storage[0], w, h);
+    int w, h, y0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
+    bloomDownsampleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], c.storage[0], w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -71,9 +73,9 @@ PLR_REGISTER_SHADER("bloomDownsample.comp", launchBloomDownsample);
 
 // bloomUpsample.comp:19-57
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void bloomUpsampleKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase) {
     const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
     const float sx = blurRadius * tsx, sy = blurRadius * tsy;
@@ -105,11 +107,11 @@ static int launchBloomUpsample(const PassCtx& c) {
     if (c.push.size() < 4) return c.fail(-1, "bloomUpsample: push constant blurRadius missing");
     float blurRadius;
     std::memcpy(&blurRadius, c.push.data(), 4);
-    int w, h;
-    if (!coverage(c, c.storage[0], &w, &h)) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u));
-    if (lowest) bloomUpsampleKernel<true><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[2], c.storage[0], blurRadius, w, h);
-    else bloomUpsampleKernel<false><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[1], c.storage[0], blurRadius, w, h);
+    int w, h, y0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+    if (lowest) bloomUpsampleKernel<true><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[2], c.storage[0], blurRadius, w, h, y0);
+    else bloomUpsampleKernel<false><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[1], c.storage[0], blurRadius, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -117,9 +119,9 @@ PLR_REGISTER_SHADER("bloomUpsample.comp", launchBloomUpsample);
 
 // applyBloom.comp:16-30: target = mix(scene, bloom, strength), in place. The bloom image has the target's size, so the
 // bilinear tap sits on a texel centre; it is still evaluated through the sampler path for exactness.
-__global__ __launch_bounds__(256) void applyBloomKernel(ImgView target, ImgView bloom, float bloomStrength, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void applyBloomKernel(ImgView target, ImgView bloom, float bloomStrength, int coverW, int coverH, int yBase) {
     const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float uvx = ((float)x + 0.5f) / (float)target.w, uvy = ((float)y + 0.5f) / (float)target.h;
     const vec3 b = bloomTap(bloom, uvx, uvy);
@@ -134,9 +136,9 @@ static int launchApplyBloom(const PassCtx& c) {
     if (c.push.size() < 4) return c.fail(-1, "applyBloom: push constant bloomStrength missing");
     float strength;
     std::memcpy(&strength, c.push.data(), 4);
-    int w, h;
-    if (!coverage(c, c.storage[0], &w, &h)) return 0;
-    applyBloomKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], strength, w, h);
+    int w, h, y0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
+    applyBloomKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], strength, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -36,14 +36,15 @@ static float hostDetLog(float x) {
 // Unlike the reference, out-of-image invocations still reach the barriers; the observable rule is kept:
 // bin b of a tile is written back only if the reference invocation with localIndexFlat == b lies inside the image.
 __global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const LightBuffer* __restrict__ light, uint32_t* __restrict__ perTile,
-                                                              uint32_t nBins, float minLuminanceLog, float maxLuminanceLog, uint32_t tilesX) {
+                                                              uint32_t nBins, float minLuminanceLog, float maxLuminanceLog, uint32_t tilesX, uint32_t tileY0) {
     extern __shared__ uint32_t localHistogram[];
     const uint32_t t = threadIdx.x;
+    const uint32_t tileY = blockIdx.y + tileY0;
     for (uint32_t b = t; b < nBins; b += 256u) localHistogram[b] = 0u;
     __syncthreads();
 
     const int x0 = (int)blockIdx.x * 32 + (int)(t & 7u) * 4;
-    const int y = (int)blockIdx.y * 32 + (int)(t >> 3);
+    const int y = (int)tileY * 32 + (int)(t >> 3);
     const float prevExposure = light->previousFrameExposure;
     const uint32_t maxIndex = nBins - 1u;
     const float range = maxLuminanceLog - minLuminanceLog;
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const
     }
     __syncthreads();
 
-    const uint32_t tileIndex = blockIdx.x + blockIdx.y * tilesX;
+    const uint32_t tileIndex = blockIdx.x + tileY * tilesX;
     for (uint32_t b = t; b < nBins && b < 1024u; b += 256u) {
-        const int rx = (int)blockIdx.x * 32 + (int)(b & 31u), ry = (int)blockIdx.y * 32 + (int)(b >> 5);
+        const int rx = (int)blockIdx.x * 32 + (int)(b & 31u), ry = (int)tileY * 32 + (int)(b >> 5);
         if (rx < src.w && ry < src.h) perTile[(size_t)tileIndex * nBins + b] = localHistogram[b];
     }
 }
@@ -104,11 +105,13 @@ static int launchHistogramPerTile(const PassCtx& c) {
     if (int rc = c.needSbuf(0, (size_t)tilesX * tilesY * nBins * 4u, "histogramPerTile per-tile buffer")) return rc;
     if (nBins == 0 || nBins > 1024u) return c.fail(-6, "histogramPerTile: nBins must be in 1..1024");
     // host-side log of the two specialisation constants with the same deterministic routine (exact same bits as device)
-    const dim3 grid(std::min(c.dispatch[0], tilesX), std::min(c.dispatch[1], tilesY));
+    const PassCtx::RowSpan rs = c.rowSpan((int)tilesY, 1); // tile rows [y0, y1) of the recorded dispatch (one workgroup per tile)
+    if (rs.y1 <= rs.y0) return 0;
+    const dim3 grid(std::min(c.dispatch[0], tilesX), (unsigned)(rs.y1 - rs.y0));
     if (!(minL > 0.f) || !(maxL > 0.f)) return c.fail(-1, "histogramPerTile: luminance range must be positive");
     const float logs[2] = {hostDetLog(minL), hostDetLog(maxL)};
     histogramPerTileKernel<<<grid, 256, nBins * sizeof(uint32_t), c.stream>>>(src, (const LightBuffer*)c.sbuf[3].ptr, (uint32_t*)c.sbuf[0].ptr,
-                                                                               nBins, logs[0], logs[1], tilesX);
+                                                                               nBins, logs[0], logs[1], tilesX, (uint32_t)rs.y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -134,24 +137,24 @@ PLR_REGISTER_SHADER("histogramReset.comp", launchHistogramReset);
 // histogramCombineTiles.comp:27-34. The reference launches (tiles x 2) groups that each issue 64 global atomics;
 // here one block sums a slab of tiles in registers (coalesced 4*nBins-byte rows) and issues one atomic per bin.
 constexpr uint32_t kCombineTilesPerBlock = 32;
-__global__ void histogramCombineKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles, uint32_t binLimit) {
+__global__ void histogramCombineKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t tile0, uint32_t nTiles, uint32_t binLimit) {
     const uint32_t bin = threadIdx.x + blockIdx.y * blockDim.x;
     if (bin >= nBins || bin >= binLimit) return;
-    const uint32_t t0 = blockIdx.x * kCombineTilesPerBlock;
-    const uint32_t t1 = min(t0 + kCombineTilesPerBlock, nTiles);
+    const uint32_t t0 = tile0 + blockIdx.x * kCombineTilesPerBlock;
+    const uint32_t t1 = min(t0 + kCombineTilesPerBlock, tile0 + nTiles);
     uint32_t sum = 0u;
     for (uint32_t t = t0; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
     if (sum) atomicAdd(&histogram[bin], sum);
 }
 static int launchHistogramCombine(const PassCtx& c) {
     const uint32_t nBins = c.specUint(0, 64u);
-    const uint32_t nTiles = c.dispatch[0];
-    if (int rc = c.needSbuf(0, (size_t)nTiles * nBins * 4u, "histogramCombineTiles per-tile buffer")) return rc;
+    const uint32_t tile0 = c.base[0], nTiles = c.dispatch[0]; // tiles [tile0, tile0 + nTiles)
+    if (int rc = c.needSbuf(0, (size_t)(tile0 + nTiles) * nBins * 4u, "histogramCombineTiles per-tile buffer")) return rc;
     if (int rc = c.needSbuf(1, (size_t)nBins * 4u, "histogramCombineTiles histogram")) return rc;
     const uint32_t binLimit = c.dispatch[1] * 64u; // bins covered by the recorded dispatch
     const dim3 grid(divUp(nTiles, kCombineTilesPerBlock), divUp(std::min(nBins, binLimit), 128u));
     if (nTiles == 0) return 0;
-    histogramCombineKernel<<<grid, 128, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (uint32_t*)c.sbuf[1].ptr, nBins, nTiles, binLimit);
+    histogramCombineKernel<<<grid, 128, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (uint32_t*)c.sbuf[1].ptr, nBins, tile0, nTiles, binLimit);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -287,9 +290,9 @@ PLR_DI uint32_t tonemapPixel(uint32_t texel, int x, int y, float time) {
 }
 
 template <bool BGRA>
-__global__ __launch_bounds__(256) void tonemappingKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void tonemappingKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
     const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
-    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (y >= coverH || x0 >= coverW) return;
     const float time = g->time;
     const uint32_t* srow = (const uint32_t*)src.ptr + (size_t)y * (size_t)src.w;
@@ -325,11 +328,12 @@ static int launchTonemapping(const PassCtx& c) {
     // invocations exist for dispatch*8 pixels; stores outside the target are dropped, fetches outside the source are
     // undefined in the reference, so the covered region is clipped to both images
     const int coverW = std::min({(int)(c.dispatch[0] * 8u), dst.w, src.w});
-    const int coverH = std::min({(int)(c.dispatch[1] * 8u), dst.h, src.h});
-    if (coverW <= 0 || coverH <= 0) return 0;
-    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)coverH, 4u));
-    if (dst.fmt == F_BGRA8) tonemappingKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH);
-    else tonemappingKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH);
+    const PassCtx::RowSpan rs = c.rowSpan(std::min(dst.h, src.h));
+    const int coverH = rs.y1, y0 = rs.y0; // rows [y0, coverH)
+    if (coverW <= 0 || coverH <= y0) return 0;
+    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)(coverH - y0), 4u));
+    if (dst.fmt == F_BGRA8) tonemappingKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
+    else tonemappingKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -22,7 +22,7 @@ PLR_DI vec3 pixelToWorld(vec2 uv, const ImgView& depthTexture, const GlobalUbo* 
 // filterIndirectDiffuseSpatial.comp:30-135
 template <int DEPTH_FMT>
 __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
-                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH) {
+                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase) {
     __shared__ float sqrtRand[32], cosA[32], sinA[32];
     if (threadIdx.x < 64) {
         // lane i replays the xorshift sequence up to its own pair of draws (2*i + 2 steps at most 64: negligible)
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgVi
     }
     __syncthreads();
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 texelSize(1.f / (float)outYSH.w, 1.f / (float)outYSH.h);
     const vec2 uv(((float)px + 0.5f) * texelSize.x, ((float)py + 0.5f) * texelSize.y);
@@ -104,14 +104,15 @@ static int launchSpatialFilter(const PassCtx& c) {
     if (int rc = c.needSampled(5, F_RGBA8, "filterIndirectDiffuseSpatial normalTexture")) return rc;
     const int filterIndex = c.specInt(0, 0);
     const ImgView& out = c.storage[0];
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
-    if (w <= 0 || h <= 0) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u));
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
+    if (w <= 0 || h <= y0) return 0;
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
     // depth is the half-res R16F copy for a half-res trace, the D32 depth buffer otherwise (Techniques/SDFGI.cpp:423)
     if (c.sampled[4].fmt == F_R16F)
-        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h);
+        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0);
     else if (c.sampled[4].fmt == F_D32)
-        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h);
+        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0);
     else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
     PLR_CHECK_LAUNCH(c);
     return 0;
@@ -122,9 +123,9 @@ PLR_REGISTER_SHADER("filterIndirectDiffuseSpatial.comp", launchSpatialFilter);
 // filterIndirectDiffuseTemporal.comp:20-86
 __global__ __launch_bounds__(256) void temporalGiFilterKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                               ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
-                                                              ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH) {
+                                                              ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 texelSize(1.f / (float)targetYSH.w, 1.f / (float)targetYSH.h);
     const vec2 uv(((float)px + 0.5f) * texelSize.x, ((float)py + 0.5f) * texelSize.y);
@@ -184,10 +185,11 @@ static int launchTemporalGiFilter(const PassCtx& c) {
     if (int rc = c.needSampled(8, F_RG16SN, "filterIndirectDiffuseTemporal velocityCurrent")) return rc;
     if (int rc = c.needSampled(9, F_RG16SN, "filterIndirectDiffuseTemporal velocityLastFrame")) return rc;
     const ImgView& out = c.storage[0];
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
-    if (w <= 0 || h <= 0) return 0;
-    temporalGiFilterKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(
-        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h);
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
+    if (w <= 0 || h <= y0) return 0;
+    temporalGiFilterKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(
+        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -196,9 +198,9 @@ PLR_REGISTER_SHADER("filterIndirectDiffuseTemporal.comp", launchTemporalGiFilter
 // ------------------------------------------------------------------------------------------------
 // indirectLightUpscale.comp:17-71
 __global__ __launch_bounds__(256) void indirectLightUpscaleKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                  ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH) {
+                                                                  ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 uv(((float)px + 0.5f) / (float)g->screenResolution[0], ((float)py + 0.5f) / (float)g->screenResolution[1]);
     float fullResDepth = sampleNearest2D<F_D32, CLAMP>(fullResDepthT, uv).x;
@@ -247,10 +249,11 @@ static int launchIndirectLightUpscale(const PassCtx& c) {
     if (int rc = c.needSampled(4, F_D32, "indirectLightUpscale fullResDepth")) return rc;
     if (int rc = c.needSampled(5, F_R16F, "indirectLightUpscale halfResDepth")) return rc;
     const ImgView& out = c.storage[0];
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
-    if (w <= 0 || h <= 0) return 0;
-    indirectLightUpscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
-                                                                                                          c.sampled[4], c.sampled[5], c.global, w, h);
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
+    if (w <= 0 || h <= y0) return 0;
+    indirectLightUpscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
+                                                                                                          c.sampled[4], c.sampled[5], c.global, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

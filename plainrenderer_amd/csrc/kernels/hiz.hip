@@ -24,6 +24,7 @@ struct HizParams {
     const float* depth;
     int depthW, depthH;
     int count;     // pyramid levels
+    int tileY0;    // first 32x32 mip-0 tile row of the launch (dispatch base)
     int baseCount; // levels produced by hizBaseKernel
 };
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void hizBaseKernel(HizParams p) {
     int lox[kHizBaseLevels], loy[kHizBaseLevels], hix[kHizBaseLevels], hiy[kHizBaseLevels], needx[kHizBaseLevels], needy[kHizBaseLevels];
     for (int l = 0; l < K; l++) {
         const int t = 32 >> l;
-        lox[l] = (int)blockIdx.x * t; loy[l] = (int)blockIdx.y * t;
+        lox[l] = (int)blockIdx.x * t; loy[l] = ((int)blockIdx.y + p.tileY0) * t;
         hix[l] = min(lox[l] + t, p.w[l]) - 1; hiy[l] = min(loy[l] + t, p.h[l]) - 1;
     }
     needx[K - 1] = hix[K - 1]; needy[K - 1] = hiy[K - 1];
@@ -169,10 +170,17 @@ static int launchDepthHiZPyramid(const PassCtx& c) {
         sw = w; sh = h;
     }
     if (p.baseCount < p.count && (p.w[p.baseCount] > 32 || p.h[p.baseCount] > 32)) return c.fail(-6, "depthHiZPyramid: tail level exceeds 32x32");
-    const dim3 grid(divUp((unsigned)p.w[0], 32u), divUp((unsigned)p.h[0], 32u));
+    // a dispatch base / count that covers only part of the tile rows (band rendering) builds the per-tile levels of those rows;
+    // the tail of the chain needs every tile and is skipped for a partial dispatch
+    const int tileRows = (int)divUp((unsigned)p.h[0], 32u);
+    const PassCtx::RowSpan rs = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows ? PassCtx::RowSpan{0, tileRows} : c.rowSpan(tileRows, 1);
+    if (rs.y1 <= rs.y0) return 0;
+    p.tileY0 = rs.y0;
+    const bool wholePyramid = rs.y0 == 0 && rs.y1 == tileRows;
+    const dim3 grid(divUp((unsigned)p.w[0], 32u), (unsigned)(rs.y1 - rs.y0));
     hizBaseKernel<<<grid, 256, 0, c.stream>>>(p);
     PLR_CHECK_LAUNCH(c);
-    if (p.count > p.baseCount) {
+    if (p.count > p.baseCount && wholePyramid) {
         hizTailKernel<<<1, 1024, 0, c.stream>>>(p);
         PLR_CHECK_LAUNCH(c);
     }

@@ -15,9 +15,9 @@ namespace plr {
 
 // ------------------------------------------------------------------------------------------------
 // depthDownscale.comp:12-20: half-res R16F depth = nearest full-res texel at (2*iUV + 0.5) / res
-__global__ __launch_bounds__(256) void depthDownscaleKernel(ImgView src, ImgView dst, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void depthDownscaleKernel(ImgView src, ImgView dst, int coverW, int coverH, int yBase) {
     const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const vec2 texelSize(1.f / (float)src.w, 1.f / (float)src.h);
     const vec2 uv(((float)(x * 2) + 0.5f) * texelSize.x, ((float)(y * 2) + 0.5f) * texelSize.y);
@@ -28,9 +28,10 @@ static int launchDepthDownscale(const PassCtx& c) {
     if (int rc = c.needStorage(0, F_R16F, "depthDownscale halfResDst")) return rc;
     if (int rc = c.needSampled(1, F_D32, "depthDownscale fullResSrc")) return rc;
     const ImgView& dst = c.storage[0];
-    const int w = std::min((int)(c.dispatch[0] * 8u), dst.w), h = std::min((int)(c.dispatch[1] * 8u), dst.h);
-    if (w <= 0 || h <= 0) return 0;
-    depthDownscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)h, 4u)), 256, 0, c.stream>>>(c.sampled[1], dst, w, h);
+    const PassCtx::RowSpan rs = c.rowSpan(dst.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), dst.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
+    if (w <= 0 || h <= y0) return 0;
+    depthDownscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], dst, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -117,12 +118,12 @@ PLR_DI vec3 VFromiUV(int x, int y, const GlobalUbo* g) {
 template <bool USE_HIZ>
 __global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
                                                          const float* __restrict__ influenceRangeP, ImgView depthMinMax, const GlobalUbo* __restrict__ g,
-                                                         uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX, uint32_t domainY, uint32_t tileCapacity,
-                                                         uint32_t listCapacity) {
+                                                         uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX, uint32_t domainY, uint32_t tileRow0,
+                                                         uint32_t tileCapacity, uint32_t listCapacity) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tileLinear = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tileLinear >= domainX * domainY) return;
-    const int tx = (int)(tileLinear % domainX), ty = (int)(tileLinear / domainX);
+    const int tx = (int)(tileLinear % domainX), ty = (int)(tileRow0 + tileLinear / domainX);
     const uint32_t tileIndex = tileIndexFromTileUV(tx, ty, g);
     if (tileIndex >= tileCapacity) return;
     CulledInstancesPerTile* tile = tiles + tileIndex;
@@ -183,17 +184,18 @@ static int launchTileCulling(const PassCtx& c) {
     uint32_t tileCount[2];
     std::memcpy(tileCount, c.push.data(), 8);
     // invocations exist for dispatch*8 tiles per axis; tiles beyond cameraTileCount return early
-    const uint32_t tcx = std::min(tileCount[0], c.dispatch[0] * 8u), tcy = std::min(tileCount[1], c.dispatch[1] * 8u);
-    if (tcx == 0 || tcy == 0) return 0;
+    const PassCtx::RowSpan rs = c.rowSpan((int)tileCount[1]); // tile rows [y0, y1) of the recorded dispatch (8x8 tiles per workgroup)
+    const uint32_t tcx = std::min(tileCount[0], c.dispatch[0] * 8u), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0;
+    if (tcx == 0 || rs.y1 <= rs.y0) return 0;
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[2].size / sizeof(CulledInstancesPerTile));
     const uint32_t listCapacity = (uint32_t)(c.sbuf[0].size / 4u) - 1u;
     const dim3 grid(divUp(tcx * tcy, 4u));
     const ImgView hiz = useHiZ ? c.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
     // the uv of the HiZ fetch divides by the push-constant tile count; the dispatch only bounds which tiles run
     if (useHiZ) tileCullingKernel<true><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
-                                                                   (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileCapacity, listCapacity);
+                                                                   (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity);
     else tileCullingKernel<false><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
-                                                             (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileCapacity, listCapacity);
+                                                             (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -336,12 +338,12 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceKernel(ImgView outYSH, Img
                                                              const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                              const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                              const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
-                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY,
+                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
                                                              uint32_t tileCapacity, uint32_t instanceCapacity) {
     __shared__ RayInfo sharedRays[4][64];
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
     // one wave = one 8x8 reference workgroup; the four waves of a block are a 2x2 arrangement inside one culling tile
-    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = (int)blockIdx.y * 2 + (wave >> 1);
+    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
@@ -452,14 +454,16 @@ static int launchSdfDiffuseTrace(const PassCtx& c) {
     if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
     const ImgView& out = c.storage[0];
     if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
-    const int groupsX = (int)c.dispatch[0], groupsY = (int)c.dispatch[1];
-    if (groupsX <= 0 || groupsY <= 0) return 0;
+    // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
+    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
+    if (groupsX <= 0 || groupsY <= groupY0) return 0;
+    if (groupY0 & 1) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)groupsY, 2u));
+    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)(groupsY - groupY0), 2u));
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
-                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY,      \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
                        tileCapacity, instanceCapacity
     if (strict) sdfDiffuseTraceKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
     else sdfDiffuseTraceKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);

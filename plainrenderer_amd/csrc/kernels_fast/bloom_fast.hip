@@ -29,13 +29,13 @@ PLR_DI Tap tap1D(float u, int n, float h) {
 }
 
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH) {
+__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase) {
     __shared__ float HA[ROWS_A][3][TW];
     __shared__ float HB[ROWS_B][3][TW];
     const int t = (int)threadIdx.x;
     const int lx = t & 63, lyBase = t >> 6;
     const int x = (int)blockIdx.x * TW + lx;
-    const int y0 = (int)blockIdx.y * TH;
+    const int y0 = yBase + (int)blockIdx.y * TH;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
     const float sx = blurRadius * tsx, sy = blurRadius * tsy;
     const float invTW = 1.f / (float)target.w, invTH = 1.f / (float)target.h;
@@ -114,15 +114,16 @@ static int launch(const PassCtx& c) {
     std::memcpy(&blurRadius, c.push.data(), 4);
     const ImgView& target = c.storage[0];
     const ImgView& source = c.sampled[2];
-    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = std::min((int)(c.dispatch[1] * 8u), target.h);
-    if (w <= 0 || h <= 0) return 0;
+    const PassCtx::RowSpan rs = c.rowSpan(target.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, yBase = rs.y0; // columns [0, w), rows [yBase, h)
+    if (w <= 0 || h <= yBase) return 0;
     // the LDS row budget assumes the reference's configuration: source = next smaller mip (>= half the target height) and a
     // blur radius of at most 3 source texels; anything else takes the general (exact-order) kernel
     const bool fits = blurRadius >= 0.f && blurRadius <= 3.f && source.h * 2 + 1 >= target.h && (lowest || c.sampled[1].h * 2 + 1 >= target.h);
     if (!fits) return kUseGeneralKernel;
-    const dim3 grid(divUp((unsigned)w, (unsigned)TW), divUp((unsigned)h, (unsigned)TH));
-    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h);
-    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h);
+    const dim3 grid(divUp((unsigned)w, (unsigned)TW), divUp((unsigned)(h - yBase), (unsigned)TH));
+    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h, yBase);
+    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h, yBase);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

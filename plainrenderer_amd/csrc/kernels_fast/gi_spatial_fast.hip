@@ -27,7 +27,7 @@ PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 // contiguous horizontal band of tiles, so a band's sliding window stays resident in that XCD's L2.
 template <int DEPTH_FMT, int TX>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
-                                                               const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int tilesX, int numTiles,
+                                                               const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase, int tilesX, int numTiles,
                                                                int chunk) {
     __shared__ float sqrtRand[32], cosA[32], sinA[32];
     if (threadIdx.x < 32) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
     if (tile >= numTiles) return;
     const int px = (tile % tilesX) * TX + (int)(threadIdx.x % TX);
-    const int py = (tile / tilesX) * TY + (int)(threadIdx.x / TX);
+    const int py = yBase + (tile / tilesX) * TY + (int)(threadIdx.x / TX);
     if (px >= coverW || py >= coverH) return;
 
     const float nearP = g->nearPlane, farP = g->farPlane;
@@ -160,15 +160,16 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     if (c.sampled[3].w != c.sampled[2].w || c.sampled[3].h != c.sampled[2].h) return c.fail(-4, "filterIndirectDiffuseSpatial: Y_SH and CoCg inputs differ in size");
     const int filterIndex = c.specInt(0, 0);
     const ImgView& out = c.storage[0];
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
-    if (w <= 0 || h <= 0) return 0;
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
+    if (w <= 0 || h <= y0) return 0;
     const int tileX = 64; // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
     const int TXv = tileX == 64 ? 64 : (tileX == 16 ? 16 : 32), TYv = 256 / TXv;
-    const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)h, (unsigned)TYv);
+    const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     const int numTiles = tilesX * tilesY, chunk = (numTiles + 7) / 8;
     const dim3 grid((unsigned)chunk * 8u);
 #define PLR_SPATIAL_LAUNCH(FMT, TXC) spatialFilterFastKernel<FMT, TXC><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], \
-                                                                                              c.global, filterIndex, w, h, tilesX, numTiles, chunk)
+                                                                                              c.global, filterIndex, w, h, y0, tilesX, numTiles, chunk)
     if (c.sampled[4].fmt == F_R16F) {
         if (TXv == 64) PLR_SPATIAL_LAUNCH(F_R16F, 64); else if (TXv == 16) PLR_SPATIAL_LAUNCH(F_R16F, 16); else PLR_SPATIAL_LAUNCH(F_R16F, 32);
     } else if (c.sampled[4].fmt == F_D32) {

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
-                                                                 uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY,
+                                                                 uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
                                                                  uint32_t tileCapacity, uint32_t instanceCapacity) {
     __shared__ RayInfo sharedRays[4][64];
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = (int)blockIdx.y * 2 + (wave >> 1);
+    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
@@ -255,14 +255,16 @@ static int launch(const PassCtx& c) {
     if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
     const ImgView& out = c.storage[0];
     if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
-    const int groupsX = (int)c.dispatch[0], groupsY = (int)c.dispatch[1];
-    if (groupsX <= 0 || groupsY <= 0) return 0;
+    // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
+    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
+    if (groupsX <= 0 || groupsY <= groupY0) return 0;
+    if (groupY0 & 1) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)groupsY, 2u));
+    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)(groupsY - groupY0), 2u));
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
-                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY,      \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
                        tileCapacity, instanceCapacity
     if (strict) sdfDiffuseTraceFastKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
     else sdfDiffuseTraceFastKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);

@@ -82,7 +82,7 @@ struct ShadeParams {
     const ImgView* bindless;
     uint32_t bindlessCount;
     uint32_t cascadeCount;
-    int coverW, coverH;
+    int coverW, coverH, yBase;
 };
 
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
@@ -144,7 +144,7 @@ PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, floa
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
 __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= P.coverW || py >= P.coverH) return;
     const GlobalUbo* g = P.g;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
@@ -328,9 +328,10 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     P.light = (const LightBuffer*)c.sbuf[7].ptr; P.shadowInfo = (const ShadowCascadeInfo*)c.sbuf[8].ptr;
     P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
-    P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = std::min((int)(c.dispatch[1] * 8u), P.color.h);
-    if (P.coverW <= 0 || P.coverH <= 0) return 0;
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)P.coverH, 4u)), 256, 0, c.stream>>>(P);
+    const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
+    P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
+    if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
+    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

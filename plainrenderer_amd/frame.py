@@ -20,7 +20,17 @@ class PlrfSettings(C.Structure):
                [("bloom_strength", C.c_float), ("bloom_radius", C.c_float), ("sdf_half_res_trace", C.c_uint32), ("sdf_strict_influence_radius_cutoff", C.c_uint32),
                 ("sdf_trace_influence_radius", C.c_float)] + \
                [(n, C.c_uint32) for n in ("diffuse_brdf", "direct_multiscatter", "indirect_lighting_tech", "use_geometry_aa", "sun_shadow_cascade_count",
-                                          "run_exposure", "run_hiz", "run_gi", "run_shading", "run_taa", "run_bloom", "run_tonemap")]
+                                          "run_exposure", "run_hiz", "run_gi", "run_shading", "run_taa", "run_bloom", "run_tonemap",
+                                          "band_row_begin", "band_row_end", "band_gi_halo", "band_gi_history_halo", "band_color_halo", "band_post_halo")]
+
+
+class PlrfExchangeItem(C.Structure):
+    _fields_ = [("image", _ImageHandle), ("device_ptr", C.c_void_p), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("halo_rows", C.c_uint32),
+                ("row_bytes", C.c_uint32), ("image_rows", C.c_uint32)]
+
+
+EXCHANGE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+EXCHANGE_HISTOGRAM, EXCHANGE_GI_TRACE, EXCHANGE_GI_TEMPORAL, EXCHANGE_GI_HISTORY, EXCHANGE_POST = range(5)
 
 
 class PlrfCamera(C.Structure):
@@ -90,6 +100,31 @@ class FramePipeline:
         for name in ("position", "forward", "up", "right"):
             setattr(c, name, (C.c_float * 3)(*[float(x) for x in getattr(cam, name)]))
         self._check(self.lib.plrf_frame(self.handle, C.byref(c), C.c_float(delta_time), C.c_float(time)))
+
+    # ---- band rendering (include/plr_frame.h)
+    def set_exchange_callback(self, fn):
+        """fn(exchange_id, hip_stream_ptr) -> None; called in pass order from inside frame() where neighbouring bands' rows are needed."""
+        def tramp(_user, exchange_id, stream):
+            try:
+                fn(int(exchange_id), stream)
+                return 0
+            except Exception:  # an exception cannot cross the C frames; report and fail the frame
+                import traceback
+                traceback.print_exc()
+                return -7
+        self._exchange_cb = EXCHANGE_CALLBACK(tramp)  # keep alive
+        self._check(self.lib.plrf_set_exchange_callback(self.handle, self._exchange_cb, None))
+
+    def exchange_items(self, exchange_id):
+        n = C.c_uint32(16)
+        items = (PlrfExchangeItem * 16)()
+        self._check(self.lib.plrf_get_exchange_items(self.handle, C.c_int(exchange_id), items, C.byref(n)))
+        return [items[i] for i in range(n.value)]
+
+    def histogram_exchange(self):
+        ptr, size = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.plrf_get_histogram_exchange(self.handle, C.byref(ptr), C.byref(size)))
+        return ptr.value, size.value
 
     def submitted_globals(self):
         buf = C.create_string_buffer(340)

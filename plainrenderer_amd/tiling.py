@@ -1,0 +1,205 @@
+"""Multi-GPU partition of the frame by screen rows ("bands") and the halo exchange between neighbouring bands.
+
+One process (or, in the single-GPU partition tests, one thread) per band. Every band holds whole-frame images and renders only its
+rows (csrc/frontend/frame_pipeline.h BandSettings); where a pass reads rows of a neighbouring band the C++ host calls back into
+`Exchange.run`, which moves the rows named by plrf_get_exchange_items:
+
+  * DistTransport: torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+    A band only talks to the band above and the band below; the single collective is the 512-byte histogram all-reduce.
+  * LocalTransport: all bands live in one process on one GPU (threads); rows are copied device-to-device. Used to prove the
+    partition bit-exact against the unpartitioned frame without a multi-GPU box.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+BAND_ALIGNMENT = 64
+
+
+def band_rows(height, n_bands, index):
+    """Rows [begin, end) of band `index`: multiples of 64 rows (the last band ends at `height`), sizes differing by at most 64."""
+    tiles = (height + BAND_ALIGNMENT - 1) // BAND_ALIGNMENT
+    if n_bands > tiles:
+        raise ValueError("more bands (%d) than 64-row tiles (%d)" % (n_bands, tiles))
+    base, extra = divmod(tiles, n_bands)
+    begin = index * base + min(index, extra)
+    end = begin + base + (1 if index < extra else 0)
+    return begin * BAND_ALIGNMENT, min(end * BAND_ALIGNMENT, height)
+
+
+class Rows:
+    """what one exchange item asks for, in plain integers (mirrors plrf_exchange_item)"""
+
+    def __init__(self, ptr, row_begin, row_end, halo_rows, row_bytes, image_rows):
+        self.ptr, self.row_begin, self.row_end, self.halo_rows, self.row_bytes, self.image_rows = ptr, row_begin, row_end, halo_rows, row_bytes, image_rows
+
+    @classmethod
+    def from_item(cls, it):
+        return cls(int(it.device_ptr), int(it.row_begin), int(it.row_end), int(it.halo_rows), int(it.row_bytes), int(it.image_rows))
+
+    # rows this band sends up / down, and the rows it receives from above / below (clipped to the image and to what exists)
+    def send_up(self):
+        return self.row_begin, min(self.row_begin + self.halo_rows, self.row_end)
+
+    def send_down(self):
+        return max(self.row_end - self.halo_rows, self.row_begin), self.row_end
+
+    def recv_from_above(self):
+        return max(self.row_begin - self.halo_rows, 0), self.row_begin
+
+    def recv_from_below(self):
+        return self.row_end, min(self.row_end + self.halo_rows, self.image_rows)
+
+
+def neighbour_plan(rows_of_band, index, n_bands):
+    """[(peer, 'send'|'recv', row0, row1)] for one item. A halo wider than the neighbouring band is clipped to that band: rows
+    further away belong to the band after it and are not exchanged (stated limit: halo <= height of the neighbouring band)."""
+    ops = []
+    me = rows_of_band[index]
+    if index > 0:
+        up = rows_of_band[index - 1]
+        a, b = me.send_up()
+        ops.append((index - 1, "send", a, b))
+        a, b = me.recv_from_above()
+        a = max(a, up.row_begin)
+        ops.append((index - 1, "recv", a, b))
+    if index + 1 < n_bands:
+        dn = rows_of_band[index + 1]
+        a, b = me.send_down()
+        ops.append((index + 1, "send", a, b))
+        a, b = me.recv_from_below()
+        b = min(b, dn.row_end)
+        ops.append((index + 1, "recv", a, b))
+    return [o for o in ops if o[3] > o[2]]
+
+
+# ------------------------------------------------------------------ transports
+class _DevMem:
+    """exposes a raw device address range to torch through the CUDA array interface"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class DistTransport:
+    """torch.distributed transport. device=None: the pointers are host memory (gloo CPU tests)."""
+
+    def __init__(self, rank, world, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+
+    def _tensor(self, ptr, nbytes):
+        if self.device is None:
+            buf = (C.c_uint8 * nbytes).from_address(ptr)
+            return self.torch.from_numpy(np.ctypeslib.as_array(buf))
+        return self.torch.as_tensor(_DevMem(ptr, nbytes), device=self.device)
+
+    def _on_stream(self, stream_ptr):
+        if self.device is None or not stream_ptr:
+            import contextlib
+            return contextlib.nullcontext()
+        return self.torch.cuda.stream(self.torch.cuda.ExternalStream(stream_ptr, device=self.device))
+
+    def exchange(self, items, stream_ptr, band_meta):
+        """items: [Rows] of this band; band_meta(i) -> (row_begin, row_end) scaled like items[i] for any band index."""
+        dist, ops = self.dist, []
+        with self._on_stream(stream_ptr):
+            for i, r in enumerate(items):
+                bands = [Rows(0, *band_meta(i, b), r.halo_rows, r.row_bytes, r.image_rows) for b in range(self.world)]
+                bands[self.rank] = r
+                for peer, kind, a, b in neighbour_plan(bands, self.rank, self.world):
+                    t = self._tensor(r.ptr + a * r.row_bytes, (b - a) * r.row_bytes)
+                    ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+
+    def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
+        with self._on_stream(stream_ptr):
+            t = self._tensor(ptr, nbytes).view(self.torch.int32)  # bin counts < 2^31: the int32 sum is the uint32 sum
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+
+class LocalGroup:
+    """shared state of the bands of one process (LocalTransport)"""
+
+    def __init__(self, n_bands, lib):
+        self.n, self.lib = n_bands, lib
+        self.barrier = threading.Barrier(n_bands)
+        self.slots = [None] * n_bands
+        self.hip = C.CDLL("libamdhip64.so")
+
+
+class LocalTransport:
+    def __init__(self, group, index):
+        self.g, self.rank, self.world = group, index, group.n
+
+    def _sync(self, stream_ptr):
+        rc = self.g.hip.hipStreamSynchronize(C.c_void_p(stream_ptr))
+        if rc != 0:
+            raise RuntimeError("hipStreamSynchronize failed: %d" % rc)
+
+    def _publish(self, payload, stream_ptr):
+        self._sync(stream_ptr)            # my rows are complete in HBM
+        self.g.slots[self.rank] = payload
+        self.g.barrier.wait()             # everybody's rows are complete and published
+
+    def _retire(self, stream_ptr):
+        self._sync(stream_ptr)            # my copies are done
+        self.g.barrier.wait()             # nobody still reads my rows
+
+    def exchange(self, items, stream_ptr, band_meta):
+        self._publish(items, stream_ptr)
+        for i, r in enumerate(items):
+            bands = [self.g.slots[b][i] for b in range(self.world)]
+            for peer, kind, a, b in neighbour_plan(bands, self.rank, self.world):
+                if kind != "recv":
+                    continue
+                src = bands[peer].ptr + a * r.row_bytes
+                rc = self.g.hip.hipMemcpyAsync(C.c_void_p(r.ptr + a * r.row_bytes), C.c_void_p(src), C.c_size_t((b - a) * r.row_bytes), C.c_int(3), C.c_void_p(stream_ptr))
+                if rc != 0:
+                    raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
+        self._retire(stream_ptr)
+
+    def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
+        self._sync(stream_ptr)
+        host = np.zeros(nbytes // 4, np.uint32)
+        rc = self.g.hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed: %d" % rc)
+        self.g.slots[self.rank] = host
+        self.g.barrier.wait()
+        total = np.sum(np.stack(self.g.slots), axis=0, dtype=np.uint64).astype(np.uint32)
+        self.g.barrier.wait()
+        rc = self.g.hip.hipMemcpy(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), C.c_int(1))
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed: %d" % rc)
+
+
+class Exchange:
+    """the exchange callback of one band: glue between the C++ host's exchange points and a transport"""
+
+    def __init__(self, fp, transport, height, n_bands, index):
+        from .frame import EXCHANGE_HISTOGRAM
+        self.fp, self.t, self.height, self.n, self.index = fp, transport, height, n_bands, index
+        self._hist_id = EXCHANGE_HISTOGRAM
+        self.calls = []
+        fp.set_exchange_callback(self.run)
+
+    def run(self, exchange_id, stream_ptr):
+        self.calls.append(exchange_id)
+        if exchange_id == self._hist_id:
+            ptr, nbytes = self.fp.histogram_exchange()
+            self.t.all_reduce_histogram(ptr, nbytes, stream_ptr)
+            return
+        items = [Rows.from_item(it) for it in self.fp.exchange_items(exchange_id)]
+
+        def band_meta(i, b):
+            # rows of band b in item i's image: the full-resolution band scaled by the item's resolution divisor
+            div = max(1, round(self.height / items[i].image_rows))
+            b0, b1 = band_rows(self.height, self.n, b)
+            return b0 // div, min((b1 + div - 1) // div, items[i].image_rows)
+
+        self.t.exchange(items, stream_ptr, band_meta)

@@ -1,0 +1,243 @@
+"""Row-band partition of the frame (multi-GPU path, DESIGN.md "Multi-GPU").
+
+CPU: partition arithmetic, the neighbour exchange plan and the torch.distributed transport over gloo with world_size 2.
+GPU: all bands run on ONE GPU (one host thread + one backend per band, LocalTransport) and must reproduce the unpartitioned
+frame bit for bit over several frames, which exercises every dispatch base, every halo and every exchange point."""
+import copy
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from plainrenderer_amd import tiling
+
+
+# ------------------------------------------------------------------ CPU: arithmetic
+def test_band_rows_partition():
+    for height, n in ((4320, 4), (2160, 2), (8640, 8), (1080, 3), (192, 2), (64, 1)):
+        rows = [tiling.band_rows(height, n, i) for i in range(n)]
+        assert rows[0][0] == 0 and rows[-1][1] == height
+        for (a0, a1), (b0, b1) in zip(rows, rows[1:]):
+            assert a1 == b0
+        assert all(b % 64 == 0 for b, _ in rows) and all(e % 64 == 0 for _, e in rows[:-1])
+        sizes = [e - b for b, e in rows]
+        assert max(sizes) - min(sizes) <= 64 + (64 - height % 64) % 64
+    with pytest.raises(ValueError):
+        tiling.band_rows(128, 3, 0)
+
+
+def test_neighbour_plan_rows():
+    mk = lambda b0, b1: tiling.Rows(0, b0, b1, 16, 8, 300)
+    bands = [mk(0, 100), mk(100, 200), mk(200, 300)]
+    assert tiling.neighbour_plan(bands, 0, 3) == [(1, "send", 84, 100), (1, "recv", 100, 116)]
+    assert tiling.neighbour_plan(bands, 1, 3) == [(0, "send", 100, 116), (0, "recv", 84, 100), (2, "send", 184, 200), (2, "recv", 200, 216)]
+    assert tiling.neighbour_plan(bands, 2, 3) == [(1, "send", 200, 216), (1, "recv", 184, 200)]
+    # a halo wider than the neighbouring band is clipped to that band
+    wide = [tiling.Rows(0, 0, 10, 64, 8, 40), tiling.Rows(0, 10, 20, 64, 8, 40), tiling.Rows(0, 20, 40, 64, 8, 40)]
+    assert tiling.neighbour_plan(wide, 2, 3) == [(1, "send", 20, 40), (1, "recv", 10, 20)]
+    # every send has the matching receive on the peer
+    for bs in (bands, wide):
+        for i in range(3):
+            for peer, kind, a, b in tiling.neighbour_plan(bs, i, 3):
+                other = "recv" if kind == "send" else "send"
+                assert (i, other, a, b) in tiling.neighbour_plan(bs, peer, 3)
+
+
+# ------------------------------------------------------------------ CPU: gloo world_size 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, height, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = tiling.DistTransport(rank, world, device=None)
+        # two "images" (full and half resolution) holding rank-stamped rows only inside the band, garbage (0xEE) elsewhere
+        items, arrays = [], []
+        for div, row_bytes, halo in ((1, 24, 16), (2, 12, 8)):
+            rows = height // div
+            b0, b1 = tiling.band_rows(height, world, rank)
+            b0, b1 = b0 // div, min((b1 + div - 1) // div, rows)
+            img = np.full((rows, row_bytes), 0xEE, np.uint8)
+            img[b0:b1] = (np.arange(b0, b1, dtype=np.uint8)[:, None] * 3 + np.arange(row_bytes, dtype=np.uint8)[None, :]) ^ 0x5A
+            arrays.append(img)
+            items.append(tiling.Rows(img.ctypes.data, b0, b1, halo, row_bytes, rows))
+
+        def band_meta(i, b):
+            div = (1, 2)[i]
+            a0, a1 = tiling.band_rows(height, world, b)
+            return a0 // div, min((a1 + div - 1) // div, height // div)
+
+        t.exchange(items, None, band_meta)
+        hist = np.arange(128, dtype=np.uint32) * (rank + 1)
+        t.all_reduce_histogram(hist.ctypes.data, hist.nbytes, None)
+        out.put((rank, [a.copy() for a in arrays], hist.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_transport_gloo_world2():
+    import torch.multiprocessing as mp
+    height, world = 192, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, height, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, arrays, hist = q.get(timeout=120)
+        got[rank] = (arrays, hist)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        arrays, hist = got[rank]
+        assert np.array_equal(hist, np.arange(128, dtype=np.uint32) * 3)  # (0+1) + (1+1)
+        for (div, row_bytes, halo), img in zip(((1, 24, 16), (2, 12, 8)), arrays):
+            rows = height // div
+            b0, b1 = tiling.band_rows(height, world, rank)
+            b0, b1 = b0 // div, min((b1 + div - 1) // div, rows)
+            expect = (np.arange(rows, dtype=np.uint8)[:, None] * 3 + np.arange(row_bytes, dtype=np.uint8)[None, :]) ^ 0x5A
+            lo, hi = max(b0 - halo, 0), min(b1 + halo, rows)
+            assert np.array_equal(img[lo:hi], expect[lo:hi]), "band + halo rows hold the owners' data"
+            assert (img[:lo] == 0xEE).all() and (img[hi:] == 0xEE).all(), "rows beyond the halo are untouched"
+
+
+# ------------------------------------------------------------------ GPU: bands on one GPU vs the unpartitioned frame
+W, H, LUT = 256, 192, 16
+N_FRAMES = 3
+FP_ARGS = dict(shadow_map_res=128, brdf_lut_res=LUT, froxel_depth=8, max_sdf_instances=64)
+
+
+def _cams():
+    from plainrenderer_amd.scene import Camera
+    return [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=W / H) for i in range(N_FRAMES + 1)]
+
+
+def _make_inputs():
+    from plainrenderer_amd import synth
+    from plainrenderer_amd.frame import SyntheticInputs
+    cams = _cams()
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=800)
+    return SyntheticInputs(scene, cams[1], cams[0], W, H, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
+
+
+def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1):
+    """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame"""
+    from plainrenderer_amd import RenderBackend
+    from plainrenderer_amd.frame import FramePipeline
+    try:
+        be = RenderBackend(W, H, device=0)
+        be.setMathMode(not exact)
+        kw = dict(FP_ARGS, sdf_half_res_trace=half_res)
+        if band is not None:
+            b0, b1 = tiling.band_rows(H, band[1], band[0])
+            kw.update(band_row_begin=b0, band_row_end=b1, **(halos or {}))
+        fp = FramePipeline(be, W, H, **kw)
+        inp = copy.copy(inputs)
+        inp.upload(fp)
+        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band[0]), H, band[1], band[0]) if band is not None else None
+        cams = _cams()
+        frames = []
+        for f in range(N_FRAMES):
+            fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+            cur = (f + 1) % 2
+            frames.append(dict(post=be.downloadImage(fp.image("post1"), 0, np.uint32).reshape(H, W).copy(),
+                               color=be.downloadImage(fp.image("color%d" % cur), 0, np.uint32).reshape(H, W).copy(),
+                               swap=be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(H, W, 4).copy(),
+                               hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
+                               light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes()))
+        res = dict(frames=frames, calls=list(ex.calls) if ex else [])
+        fp.destroy()
+        be.shutdown()
+        out[band[0] if band is not None else "full"] = res
+    except BaseException as e:  # surface failures of worker threads (and unblock the others)
+        out[band[0] if band is not None else "full"] = e
+        if group is not None:
+            group.barrier.abort()
+        raise
+
+
+def _run_bands(inputs, n, exact, halos, half_res=1):
+    from plainrenderer_amd import backend
+    group = tiling.LocalGroup(n, backend._load())
+    out = {}
+    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    for i in range(n):
+        assert i in out, "band %d did not finish" % i
+        if isinstance(out[i], BaseException):
+            raise out[i]
+    return out
+
+
+def _compare(full, bands, n, what=("post", "color", "swap")):
+    mism = {}
+    for f in range(N_FRAMES):
+        for i in range(n):
+            b0, b1 = tiling.band_rows(H, n, i)
+            fr, bf = full["frames"][f], bands[i]["frames"][f]
+            assert np.array_equal(fr["hist"], bf["hist"]) and int(bf["hist"].sum()) == W * H, "histogram frame %d band %d" % (f, i)
+            assert fr["light"] == bf["light"], "exposure frame %d band %d" % (f, i)
+            for k in what:
+                d = fr[k][b0:b1] != bf[k][b0:b1]
+                mism[(f, i, k)] = float(d.mean())
+    return mism
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half_res", [1, 0])
+def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
+    # n = 2: the neighbour is the rest of the frame, so halos as tall as the image make every pass's inputs complete and the
+    # partitioned frame must equal the unpartitioned one in every bit, over 3 frames of temporal feedback
+    inputs = _make_inputs()
+    out = {}
+    _run(inputs, True, out=out, half_res=half_res)
+    full = out["full"]
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
+    bands = _run_bands(inputs, 2, True, halos, half_res)
+    mism = _compare(full, bands, 2)
+    bad = {k: v for k, v in mism.items() if v != 0.0}
+    assert not bad, bad
+    assert bands[0]["calls"][:5] == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+def test_gpu_three_bands_default_halos():
+    # default halos (64 trace rows GI, 16 history, 320 post): bands of 64 rows here, so halos are clipped to the neighbouring
+    # band; pixels whose 1.5 m denoiser disc or bloom footprint reaches past the neighbouring band may differ - they must be few
+    inputs = _make_inputs()
+    out = {}
+    _run(inputs, True, out=out)
+    bands = _run_bands(inputs, 3, True, None)
+    mism = _compare(out["full"], bands, 3)
+    assert max(v for (f, i, k), v in mism.items() if k == "color") < 0.05, mism
+    assert max(mism.values()) < 0.6, mism
+
+
+@pytest.mark.gpu
+def test_gpu_two_bands_fast_math_matches_full_frame():
+    # the default (PLR_MATH_FAST) kernel set through the same partition: fast kernels are deterministic too
+    inputs = _make_inputs()
+    out = {}
+    _run(inputs, False, out=out)
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
+    bands = _run_bands(inputs, 2, False, halos)
+    mism = _compare(out["full"], bands, 2)
+    bad = {k: v for k, v in mism.items() if v != 0.0}
+    assert not bad, bad
