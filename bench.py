@@ -62,17 +62,29 @@ def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_d
     return b, frame
 
 
-def build_scene(args, device, rank):
+INPUT_HALO = 256  # full-res rows of G-buffer a band needs beyond its own: 2 * (giHalo + giHistoryHalo) + 16 = 176 for the half-res depth
+
+
+def build_scene(args, device, w, h, band=None):
+    """band = (row_begin, row_end) of this rank in the w x h frame, or None for the whole frame"""
     from plainrenderer_amd import synth
     from plainrenderer_amd.frame import SyntheticInputs
     from plainrenderer_amd.scene import Camera
-    w, h = args.width, args.height
     scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
     span = args.grid * 8.0
-    # every rank looks at the field from its own position (weak scaling: one 4K view per GPU)
-    x0 = span * (0.35 + 0.3 * ((rank * 0.37) % 1.0))
+    x0 = span * 0.35
     cams = [Camera.look((x0 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(args.steps + args.warmup + args.profile_frames + 4)]
-    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=args.shadow_res, froxel_depth=64, sun_direction=(0.35, -0.8, 0.45))
+    rows = depth_range = None
+    if band is not None:
+        # every band must fit the same shadow cascades: depth range of the whole frame from a 1/8-resolution G-buffer (same on all ranks)
+        coarse = scene.gbuffer(cams[1], w // 8, h // 8)["depth"]
+        vis = coarse[coarse > 0].astype(np.float64)
+        n, f = cams[1].near, cams[1].far
+        lin = n * f / (f + (1.0 - vis) * (n - f)) if vis.size else np.array([1.0, 50.0])
+        depth_range = (float(lin.min()), float(lin.max()))
+        rows = (max(band[0] - INPUT_HALO, 0), min(band[1] + INPUT_HALO, h))
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=args.shadow_res, froxel_depth=64, sun_direction=(0.35, -0.8, 0.45),
+                             rows=rows, depth_range=depth_range)
     return scene, cams, inputs
 
 
@@ -131,6 +143,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20, help="extra frames with per-pass hipEvent timing for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
+    ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     args = ap.parse_args()
 
     import torch
@@ -141,18 +154,31 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_bands:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     device = "cuda:%d" % local_rank
 
-    from plainrenderer_amd import RenderBackend
+    from plainrenderer_amd import RenderBackend, tiling
     from plainrenderer_amd.frame import FramePipeline
     w, h = args.width, args.height
+    band = exchange = None
+    if world > 1:
+        # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
+        # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
+        w, h = 2 * args.width, (args.height // 2) * world
+        band = tiling.band_rows(h, world, rank)
+    elif args.force_bands:
+        band = (0, h)
     be = RenderBackend(w, h, device=local_rank)
-    fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res)
-    scene, cams, inputs = build_scene(args, device, rank)
+    if band is not None:
+        fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res, band_row_begin=band[0], band_row_end=band[1])
+        exchange = tiling.Exchange(fp, tiling.DistTransport(rank, world, device=device), h, world, rank)
+    else:
+        fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res)
+    scene, cams, inputs = build_scene(args, device, w, h, band)
     inputs.upload(fp)
     be.waitForGPUIdle()
 
@@ -191,7 +217,9 @@ def main():
             for name, ms in be.getRenderpassTimings():
                 pass_ms.setdefault(name, []).append(ms)
         be.setPassTiming(False)
-    bytes_per_pass, frame_bytes = algorithmic_bytes(w, h, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
+    # per-GPU pixels: the band's rows (a band renders w x rows of the frame)
+    bh = h if band is None else band[1] - band[0]
+    bytes_per_pass, frame_bytes = algorithmic_bytes(w, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
     table = []
     for name, v in pass_ms.items():
         launches = len(v) / args.profile_frames
@@ -218,13 +246,15 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec full GI+shade+post @4K; %HBM roofline; 1/2/4/8-GPU scaling",
-            "value": round(world * 1000.0 / ms_per_step, 3),
-            "unit": "frames/s (3840x2160 frames, summed over GPUs)",
+            "value": round(1000.0 / ms_per_step * (w * h) / float(args.width * args.height), 3),
+            "unit": "frames/s (3840x2160-equivalent: frames/s x frame pixels / 8294400)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d per GPU, %d SDF instances x %d^3, "
+            "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d, %d SDF instances x %d^3, "
                                    "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
-                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "parallelism": "replicas: 1 independent view per GPU" if world > 1 else "single GPU"},
+                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res,
+                       "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point "
+                                       "%d times per frame + one 512 B histogram all-reduce" % (w, h, world, h // world, 4)) if world > 1 else "single GPU"},
             "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roofline,

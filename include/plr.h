@@ -189,6 +189,8 @@ int plr_get_last_frame_gpu_time(float* out_ms);
 /* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */
 int plr_replay_frame(uint32_t count, float* out_total_gpu_ms);
 int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size);
+/* rows [row_begin, row_begin + row_count) of a 2D mip level (band rendering: a GPU only needs the inputs of its rows) */
+int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t row_begin, uint32_t row_count, const void* data, size_t size);
 int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size);
 int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size);
 int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size);

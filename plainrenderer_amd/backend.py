@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_host_callback_execution",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -431,6 +431,12 @@ class RenderBackend:
     def uploadImage(self, image, data, mip=0):
         b = np.ascontiguousarray(data)
         self._check(self.lib.plr_upload_image(self._h(image), C.c_uint32(mip), b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes)))
+
+    def uploadImageRows(self, image, row_begin, data, mip=0):
+        """data: the rows [row_begin, row_begin + data.shape[0]) of a 2D image"""
+        b = np.ascontiguousarray(data)
+        self._check(self.lib.plr_upload_image_rows(self._h(image), C.c_uint32(mip), C.c_uint32(row_begin), C.c_uint32(b.shape[0]), b.ctypes.data_as(C.c_void_p),
+                                                   C.c_size_t(b.nbytes)))
 
     def downloadImage(self, image, mip=0, dtype=np.uint8):
         w, h, dep, bpp = self.mipSize(image, mip)

@@ -780,6 +780,21 @@ int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* dat
     return PLR_OK;
 }
 
+int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t row_begin, uint32_t row_count, const void* data, size_t size) {
+    NEED_INIT();
+    ImageRes* im; MipInfo* mi;
+    int rc = imageMip(image, mip_level, &im, &mi);
+    if (rc) return rc;
+    if (mi->d != 1) return setErr(PLR_ERR_INVALID_ARGUMENT, "row upload needs a 2D image");
+    if ((uint64_t)row_begin + row_count > mi->h) return setErr(PLR_ERR_INVALID_ARGUMENT, "rows outside the image");
+    const size_t rowBytes = mi->bytes / mi->h;
+    if (size != rowBytes * row_count) return setErr(PLR_ERR_INVALID_ARGUMENT, "upload size " + std::to_string(size) + " != rows * " + std::to_string(rowBytes));
+    if (size == 0) return PLR_OK;
+    HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset + rowBytes * row_begin, data, size, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+
 int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size) {
     NEED_INIT();
     ImageRes* im; MipInfo* mi;

@@ -145,9 +145,13 @@ class FramePipeline:
 class SyntheticInputs:
     """everything the rasterised / out-of-scope passes would have produced, generated once per scene + camera"""
 
-    def __init__(self, scene: synth.SynthScene, cam: Camera, cam_prev: Camera, width, height, sdf_res, shadow_res, froxel_depth, sun_direction, cascades=3):
+    def __init__(self, scene: synth.SynthScene, cam: Camera, cam_prev: Camera, width, height, sdf_res, shadow_res, froxel_depth, sun_direction, cascades=3,
+                 rows=None, depth_range=None):
+        """rows=(r0, r1): generate the per-pixel inputs for these rows only (band rendering); depth_range=(min, max) linear depth of
+        the WHOLE frame then has to be given so that every band fits the same shadow cascades"""
         self.width, self.height, self.sdf_res, self.shadow_res = width, height, sdf_res, shadow_res
-        self.gb = scene.gbuffer(cam, width, height, cam_prev)
+        self.rows = rows
+        self.gb = scene.gbuffer(cam, width, height, cam_prev, rows=rows)
         self.instance_bytes, self.bb_bytes, self.volumes = scene.sdf_instances(sdf_res)
         self.noise = synth.blue_noise_standins()
         self.sky = synth.sky_lut()
@@ -158,7 +162,8 @@ class SyntheticInputs:
         n, f = cam.near, cam.far
         vis = depth[depth > 0]
         lin = n * f / (f + (1.0 - vis.astype(np.float64)) * (n - f)) if vis.size else np.array([1.0, 50.0])
-        self.shadow_info, self.shadow_maps = scene.shadow_cascades(cam, self.sun, float(lin.min()), float(lin.max()), shadow_res, cascade_count=cascades)
+        self.depth_range = depth_range if depth_range is not None else (float(lin.min()), float(lin.max()))
+        self.shadow_info, self.shadow_maps = scene.shadow_cascades(cam, self.sun, self.depth_range[0], self.depth_range[1], shadow_res, cascade_count=cascades)
         self.froxel, self.froxel_dims = synth.froxel_volume(width, height, froxel_depth)
         self.vol_settings = synth.volumetric_settings_bytes(30.0)
 
@@ -196,12 +201,14 @@ class SyntheticInputs:
     def upload(self, fp: FramePipeline):
         be = fp.be
         gb = self.gb
+        r0 = self.rows[0] if getattr(self, "rows", None) is not None else None
+        up = (lambda img, a: be.uploadImageRows(img, r0, a)) if r0 is not None else be.uploadImage
         for i in (0, 1):
-            be.uploadImage(fp.image("depth%d" % i), gb["depth"])
-            be.uploadImage(fp.image("motion%d" % i), gb["motion"])
-        be.uploadImage(fp.image("normal"), gb["normal"])
-        be.uploadImage(fp.image("albedo"), gb["albedo"])
-        be.uploadImage(fp.image("specular"), gb["specular"])
+            up(fp.image("depth%d" % i), gb["depth"])
+            up(fp.image("motion%d" % i), gb["motion"])
+        up(fp.image("normal"), gb["normal"])
+        up(fp.image("albedo"), gb["albedo"])
+        up(fp.image("specular"), gb["specular"])
         be.uploadImage(fp.image("skyLut"), self.sky)
         be.uploadImage(fp.image("transmissionLut"), self.transmission)
         be.uploadImage(fp.image("volumetricIntegrationVolume"), self.froxel)

@@ -113,11 +113,14 @@ class SynthScene:
         return n / torch.clamp(torch.linalg.norm(n, dim=-1, keepdim=True), min=1e-12)
 
     # ---------------------------------------------------------------- G-buffer
-    def gbuffer(self, cam: Camera, w, h, cam_prev: Camera = None):
+    def gbuffer(self, cam: Camera, w, h, cam_prev: Camera = None, rows=None):
+        """rows=(r0, r1): only these rows of the w x h frame (arrays of r1 - r0 rows); the frame's coordinates stay global"""
         dev = self.device
-        ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        r0, r1 = rows if rows is not None else (0, h)
+        ys, xs = torch.meshgrid(torch.arange(r0, r1, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+        full_h, h = h, r1 - r0
         ndc_x = (xs + 0.5) / w * 2 - 1
-        ndc_y = (ys + 0.5) / h * 2 - 1
+        ndc_y = (ys + 0.5) / full_h * 2 - 1
         tv = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
         fwd, up, right, pos = tv(cam.forward), tv(cam.up), tv(cam.right), tv(cam.position)
         tan = cam.tan_fov_half()

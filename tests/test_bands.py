@@ -241,3 +241,20 @@ def test_gpu_two_bands_fast_math_matches_full_frame():
     mism = _compare(out["full"], bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_gpu_bench_band_path_over_rccl_group_of_one():
+    """bench.py's multi-GPU code path (band pipeline + torch.distributed "nccl" = RCCL transport on the backend's stream) with a
+    process group of size 1: device pointers wrapped as tensors, the histogram all-reduce and the exchange callbacks all run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-bands", "--steps", "3", "--warmup", "1", "--profile-frames", "2", "--no-cpu-baseline",
+           "--width", "512", "--height", "256", "--grid", "4", "--sdf-res", "16", "--shadow-res", "256"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["value"] > 0 and any(k.startswith("Exchange:") for k in out["passes_ms"]), out["passes_ms"]
