@@ -65,6 +65,28 @@ def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_d
 INPUT_HALO = 256  # full-res rows of G-buffer a band needs beyond its own: 2 * (giHalo + giHistoryHalo) + 16 = 176 for the half-res depth
 
 
+PASS_KERNEL = {  # pass label -> kernel name prefix in the rocprofv3 summaries under profiles/
+    "Indirect diffuse spatial filter": "plr::spatialFilter", "Forward shading (deferred)": "plr::fastshade::deferredShading",
+    "Temporal filtering": "plr::fasttaa::temporalFilter", "Indirect diffuse SDF trace": "plr::fasttrace::sdfDiffuseTrace",
+    "Indirect lighting upscale": "plr::indirectLightUpscale", "Indirect diffuse temporal filter": "plr::temporalGiFilter",
+    "Depth min/max pyramid": "plr::hizBase", "Tonemap": "plr::tonemapping", "Apply bloom": "plr::applyBloom", "Histogram per tile": "plr::histogramPerTile",
+}
+
+
+def pmc_traffic(pass_name):
+    """HBM-side bytes per launch of the pass's kernel from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command at the default workload, gfx950 x2 fetch correction applied)."""
+    import glob
+    prefix = PASS_KERNEL.get(pass_name)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    if not prefix or not files:
+        return None, None
+    for line in open(files[-1]):
+        if line.startswith(prefix):
+            return int(line.strip().split(",")[-1]), os.path.basename(files[-1])
+    return None, None
+
+
 def build_scene(args, device, w, h, band=None):
     """band = (row_begin, row_end) of this rank in the w x h frame, or None for the whole frame"""
     from plainrenderer_amd import synth
@@ -230,8 +252,10 @@ def main():
     if table:
         name, avg_ms, launches, nbytes = table[0]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        default_workload = (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None
+        traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
     if args.pass_table and rank == 0:
         tot = sum(r[1] * r[2] for r in table)
         sys.stderr.write("%-36s %9s %7s %9s %8s\n" % ("pass", "avg ms", "launch", "GB/s", "% frame"))

@@ -25,22 +25,50 @@ PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 // from a ~100-pixel disc around every pixel, so neighbouring tiles share most of their footprint: with the natural mapping the
 // eight L2s each fetch their own copy (measured 364 MB of L2 fills for 62 MB of inputs). The remap below hands every XCD one
 // contiguous horizontal band of tiles, so a band's sliding window stays resident in that XCD's L2.
-template <int DEPTH_FMT, int TX>
+// The 32 disc samples are the same for every pixel: the shader seeds its RNG with wang_hash(frameIndexMod4 + filterIndex)
+// (:53), so there are only five distinct tables. They are derived once (first launch of a pass) into the pass's scratch memory:
+// table[key][0..31] = sqrt(r0), [32..63] = cos(2 pi r1), [64..95] = sin(2 pi r1). The filter kernel reads them with uniform
+// (scalar) loads instead of every block re-deriving them.
+constexpr int kSampleKeys = 5, kSampleTableFloats = 96;
+__global__ void spatialSampleTableKernel(float* __restrict__ table) {
+    const int key = (int)threadIdx.x / 32, i = (int)threadIdx.x % 32;
+    if (key >= kSampleKeys) return;
+    uint32_t rngState = wang_hash((uint32_t)key);
+    float r0 = 0.f, r1 = 0.f;
+    for (int k = 0; k <= i; k++) { r0 = rand01(rngState); r1 = rand01(rngState); }
+    float sn, cs;
+    det_sincosf(2.f * PLR_GLSL_PI * r1, &sn, &cs);
+    float* t = table + key * kSampleTableFloats;
+    t[i] = sqrtf(r0); t[32 + i] = cs; t[64 + i] = sn;
+}
+
+// Vector memory instructions, not bytes, are what this filter runs out of: a CU's texture addresser retires one wave-wide load
+// per ~16-22 cycles whatever its width (measured: TA busy 75 % of the kernel with three 2/4/8-byte gathers per sample). When depth
+// and GI images share the texel grid, a pre-pass packs {Y_SH (8 B), CoCg (4 B), linear-depth denominator (4 B float)} into one
+// 16-byte texel, so a sample is ONE dwordx4 gather. The pre-pass also resolves the shader's NaN guard (:118): a texel with a NaN
+// component is stored as zeros with a negative denominator (= "skip").
+template <int DEPTH_FMT>
+__global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
+                                                         int rowBegin, int rowEnd) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int y = rowBegin + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= inYSH.w || y >= rowEnd) return;
+    const size_t idx = (size_t)y * (size_t)inYSH.w + (size_t)x;
+    uint2 yt = ((const uint2*)inYSH.ptr)[idx];
+    uint32_t ct = ((const uint32_t*)inCoCg.ptr)[idx];
+    const float dep = Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x;
+    float den = g->farPlane + (1.f - dep) * (g->nearPlane - g->farPlane);
+    const float probe = ((halfBitsToFloat(yt.x & 0xffffu) + halfBitsToFloat(yt.x >> 16)) + (halfBitsToFloat(yt.y & 0xffffu) + halfBitsToFloat(yt.y >> 16))) +
+                        (halfBitsToFloat(ct & 0xffffu) + halfBitsToFloat(ct >> 16));
+    if (probe != probe || !(den > 0.f)) { yt = make_uint2(0u, 0u); ct = 0u; den = -1.f; }
+    packed[idx] = make_uint4(yt.x, yt.y, ct, f2u(den));
+}
+
+template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
-                                                               const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase, int tilesX, int numTiles,
-                                                               int chunk) {
-    __shared__ float sqrtRand[32], cosA[32], sinA[32];
-    if (threadIdx.x < 32) {
-        uint32_t rngState = wang_hash(g->frameIndexMod4 + (uint32_t)filterIndex);
-        const int i = (int)threadIdx.x;
-        float r0 = 0.f, r1 = 0.f;
-        for (int k = 0; k <= i; k++) { r0 = rand01(rngState); r1 = rand01(rngState); }
-        sqrtRand[i] = sqrtf(r0);
-        float s, c;
-        det_sincosf(2.f * PLR_GLSL_PI * r1, &s, &c);
-        cosA[i] = c; sinA[i] = s;
-    }
-    __syncthreads();
+                                                               const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
+                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk) {
+    const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
     if (tile >= numTiles) return;
@@ -101,46 +129,83 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     float lengthModifier = 1.f;
     const uint32_t ywi = (uint32_t)inYSH.w;
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
-    const bool sameGrid = depthTexture.w == inYSH.w && depthTexture.h == inYSH.h; // half-res trace: depth and GI images share the texel grid
     const uint2* yshTexels = (const uint2*)inYSH.ptr;
     const uint32_t* cocgTexels = (const uint32_t*)inCoCg.ptr;
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        const float d = sqrtRand[i] * lengthModifier;
-        const float ox = cosA[i] * d, oy = sinA[i] * d;
-        const vec3 clip = P0 + ox * PT + oy * PB;
-        const float invW = rcpf(clip.z) * 0.5f;
-        float su = clip.x * invW + 0.5f, sv = clip.y * invW + 0.5f;
-        // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
-        su = fabsf(su - 0.5f) > 0.5f ? u0 - ox : su;
-        sv = fabsf(sv - 0.5f) > 0.5f ? v0 - oy : sv;
-        // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
-        const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(su * yW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(sv * yH, 0.f, yHm1);
-        const uint32_t ti = ty * ywi + tx;
-        uint32_t di = ti;
-        if (!sameGrid) di = (uint32_t)(int)__builtin_amdgcn_fmed3f(sv * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(su * dW, 0.f, dWm1);
-        // all three gathers are issued together (the Y_SH / CoCg texels are needed unless the sample is off-screen), so a sample
-        // costs one memory round trip instead of two dependent ones
-        const float dep = Texel<DEPTH_FMT>::load(depthTexture.ptr, di).x;
-        const uint2 yt = yshTexels[ti];
-        const uint32_t ct = cocgTexels[ti];
-        const float lin = nf * rcpf(farP + (1.f - dep) * nmf);
-        const float dist = fabsf(c0 + lin * (k0 + sv * k1 + su * k2));
-        float weight = gclamp(0.25f * rcpf(gmax(dist, 0.0001f)), 0.f, 1.f);
-        weight *= weight;
-        if (fabsf(su - 0.5f) > 0.5f || fabsf(sv - 0.5f) > 0.5f) {
-            weight = 0.f;
-            lengthModifier *= 0.98f;
+    // The kernel is bound by memory latency, not by issue: samples are processed four at a time, branch-free, so that the twelve
+    // gathers of a group are in flight together (a per-sample branch makes the compiler wait for each sample's loads in turn).
+    // Only lengthModifier chains the samples, and it depends on coordinates alone.
+    for (int i0 = 0; i0 < 32; i0 += 4) {
+        float su[4], sv[4];
+        uint32_t ti[4], di[4];
+        bool off[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float d = samples[i0 + k] * lengthModifier;
+            const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
+            const vec3 clip = P0 + ox * PT + oy * PB;
+            const float invW = rcpf(clip.z) * 0.5f;
+            float u = clip.x * invW + 0.5f, v = clip.y * invW + 0.5f;
+            // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
+            u = fabsf(u - 0.5f) > 0.5f ? u0 - ox : u;
+            v = fabsf(v - 0.5f) > 0.5f ? v0 - oy : v;
+            su[k] = u; sv[k] = v;
+            off[k] = fabsf(u - 0.5f) > 0.5f || fabsf(v - 0.5f) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
+            lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
+            // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
+            const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(u * yW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(v * yH, 0.f, yHm1);
+            ti[k] = ty * ywi + tx;
+            di[k] = SAME_GRID ? ti[k]
+                              : (uint32_t)(int)__builtin_amdgcn_fmed3f(v * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(u * dW, 0.f, dWm1);
         }
-        const vec4 s(halfBitsToFloat(yt.x & 0xffffu), halfBitsToFloat(yt.x >> 16), halfBitsToFloat(yt.y & 0xffffu), halfBitsToFloat(yt.y >> 16));
-        const float co = halfBitsToFloat(ct & 0xffffu), cg = halfBitsToFloat(ct >> 16);
-        // NaN guard (:118): finite half inputs cannot overflow this sum, so it is NaN exactly when a component is NaN
-        const float nanProbe = ((s.x + s.y) + (s.z + s.w)) + (co + cg);
-        if (weight > 0.f && nanProbe == nanProbe) {
-            result_Y_SH = result_Y_SH + weight * s;
+        if (PACKED) {
+            uint4 t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t4[k] = packed[ti[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float den = u2f(t4[k].w); // <= 0: texel had a NaN component (skip)
+                const float q = k0 + sv[k] * k1 + su[k] * k2;
+                const float num = fabsf(c0 * den + nf * q);
+                float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
+                weight *= weight;
+                weight = (!off[k] && den > 0.f) ? weight : 0.f;
+                const vec4 sY(halfBitsToFloat(t4[k].x & 0xffffu), halfBitsToFloat(t4[k].x >> 16), halfBitsToFloat(t4[k].y & 0xffffu), halfBitsToFloat(t4[k].y >> 16));
+                result_Y_SH = result_Y_SH + weight * sY;
+                resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
+                resCg += weight * halfBitsToFloat(t4[k].z >> 16);
+                weightTotal += weight;
+            }
+        } else {
+        float dep[4];
+        uint2 yt[4];
+        uint32_t ct[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dep[k] = Texel<DEPTH_FMT>::load(depthTexture.ptr, di[k]).x;
+            yt[k] = yshTexels[ti[k]];
+            ct[k] = cocgTexels[ti[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // depthLinear = nf / den with den = far + (1 - depth) * (near - far) > 0; the distance to the tangent plane is
+            // |c0 + depthLinear * q| = |c0 * den + nf * q| / den, so weight = clamp(0.25 * den / max(|c0 * den + nf * q|, 1e-4 * den))^2: one reciprocal
+            const float den = farP + (1.f - dep[k]) * nmf;
+            const float q = k0 + sv[k] * k1 + su[k] * k2;
+            const float num = fabsf(c0 * den + nf * q);
+            float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
+            weight *= weight;
+            vec4 sY(halfBitsToFloat(yt[k].x & 0xffffu), halfBitsToFloat(yt[k].x >> 16), halfBitsToFloat(yt[k].y & 0xffffu), halfBitsToFloat(yt[k].y >> 16));
+            float co = halfBitsToFloat(ct[k] & 0xffffu), cg = halfBitsToFloat(ct[k] >> 16);
+            // NaN guard (:118): finite half inputs cannot overflow this sum, so it is NaN exactly when a component is NaN
+            const float nanProbe = ((sY.x + sY.y) + (sY.z + sY.w)) + (co + cg);
+            const bool use = !off[k] && weight > 0.f && nanProbe == nanProbe;
+            weight = use ? weight : 0.f;
+            if (nanProbe != nanProbe) { sY = vec4(0.f); co = 0.f; cg = 0.f; } // 0 * NaN would poison the sums
+            result_Y_SH = result_Y_SH + weight * sY;
             resCo += weight * co;
             resCg += weight * cg;
             weightTotal += weight;
+        }
         }
     }
     const float inv = rcpf(gmax(weightTotal, 0.00001f));
@@ -163,17 +228,42 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
     const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
     if (w <= 0 || h <= y0) return 0;
-    const int tileX = 64; // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
-    const int TXv = tileX == 64 ? 64 : (tileX == 16 ? 16 : 32), TYv = 256 / TXv;
+    // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
+    constexpr int TXv = 64, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     const int numTiles = tilesX * tilesY, chunk = (numTiles + 7) / 8;
     const dim3 grid((unsigned)chunk * 8u);
-#define PLR_SPATIAL_LAUNCH(FMT, TXC) spatialFilterFastKernel<FMT, TXC><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], \
-                                                                                              c.global, filterIndex, w, h, y0, tilesX, numTiles, chunk)
+    // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
+    const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h;
+    // per-pass scratch: [sample tables | packed texels of the whole trace image]
+    const size_t tableBytes = 2048, packedBytes = sameGrid ? (size_t)c.sampled[2].w * (size_t)c.sampled[2].h * 16u : 0u;
+    static_assert(sizeof(float) * kSampleKeys * kSampleTableFloats <= 2048, "sample tables");
+    const bool freshScratch = c.scratchSize && *c.scratchSize < tableBytes + packedBytes;
+    uint8_t* scratch = (uint8_t*)c.scratch(tableBytes + packedBytes);
+    if (!scratch) return c.fail(-2, "filterIndirectDiffuseSpatial: cannot allocate scratch memory");
+    float* tables = (float*)scratch;
+    uint4* packed = (uint4*)(scratch + tableBytes);
+    if (freshScratch) {
+        spatialSampleTableKernel<<<1, 256, 0, c.stream>>>(tables);
+        PLR_CHECK_LAUNCH(c);
+    }
+    if (sameGrid) {
+        // rows the filter can read: the dispatched rows and a margin (a band renderer exchanges 64 halo rows; samples further away
+        // read whatever an earlier frame packed there, exactly like the stale image rows they would read unpacked)
+        const int margin = 128;
+        const int p0 = std::max(y0 - margin, 0), p1 = std::min(h + margin, c.sampled[2].h);
+        const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)(p1 - p0), 4u));
+        if (c.sampled[4].fmt == F_R16F) spatialPackKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, p0, p1);
+        else if (c.sampled[4].fmt == F_D32) spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, p0, p1);
+        else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
+        PLR_CHECK_LAUNCH(c);
+    }
+#define PLR_SPATIAL_LAUNCH(FMT, SG, PK) spatialFilterFastKernel<FMT, TXv, SG, PK><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], \
+                                                                                              c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk)
     if (c.sampled[4].fmt == F_R16F) {
-        if (TXv == 64) PLR_SPATIAL_LAUNCH(F_R16F, 64); else if (TXv == 16) PLR_SPATIAL_LAUNCH(F_R16F, 16); else PLR_SPATIAL_LAUNCH(F_R16F, 32);
+        if (sameGrid) PLR_SPATIAL_LAUNCH(F_R16F, true, true); else PLR_SPATIAL_LAUNCH(F_R16F, false, false);
     } else if (c.sampled[4].fmt == F_D32) {
-        if (TXv == 64) PLR_SPATIAL_LAUNCH(F_D32, 64); else if (TXv == 16) PLR_SPATIAL_LAUNCH(F_D32, 16); else PLR_SPATIAL_LAUNCH(F_D32, 32);
+        if (sameGrid) PLR_SPATIAL_LAUNCH(F_D32, true, true); else PLR_SPATIAL_LAUNCH(F_D32, false, false);
     } else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
 #undef PLR_SPATIAL_LAUNCH
     PLR_CHECK_LAUNCH(c);

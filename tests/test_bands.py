@@ -170,6 +170,18 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1)
         raise
 
 
+def _run_full(inputs, exact, half_res=1):
+    # on its own thread = its own backend: the session-wide test backend may already live on the main thread
+    out = {}
+    t = threading.Thread(target=_run, args=(inputs, exact), kwargs=dict(out=out, half_res=half_res))
+    t.start()
+    t.join(timeout=600)
+    assert "full" in out, "the unpartitioned frame did not finish"
+    if isinstance(out["full"], BaseException):
+        raise out["full"]
+    return out["full"]
+
+
 def _run_bands(inputs, n, exact, halos, half_res=1):
     from plainrenderer_amd import backend
     group = tiling.LocalGroup(n, backend._load())
@@ -206,9 +218,7 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
     # n = 2: the neighbour is the rest of the frame, so halos as tall as the image make every pass's inputs complete and the
     # partitioned frame must equal the unpartitioned one in every bit, over 3 frames of temporal feedback
     inputs = _make_inputs()
-    out = {}
-    _run(inputs, True, out=out, half_res=half_res)
-    full = out["full"]
+    full = _run_full(inputs, True, half_res)
     halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
     bands = _run_bands(inputs, 2, True, halos, half_res)
     mism = _compare(full, bands, 2)
@@ -222,10 +232,9 @@ def test_gpu_three_bands_default_halos():
     # default halos (64 trace rows GI, 16 history, 320 post): bands of 64 rows here, so halos are clipped to the neighbouring
     # band; pixels whose 1.5 m denoiser disc or bloom footprint reaches past the neighbouring band may differ - they must be few
     inputs = _make_inputs()
-    out = {}
-    _run(inputs, True, out=out)
+    full = _run_full(inputs, True)
     bands = _run_bands(inputs, 3, True, None)
-    mism = _compare(out["full"], bands, 3)
+    mism = _compare(full, bands, 3)
     assert max(v for (f, i, k), v in mism.items() if k == "color") < 0.05, mism
     assert max(mism.values()) < 0.6, mism
 
@@ -234,11 +243,10 @@ def test_gpu_three_bands_default_halos():
 def test_gpu_two_bands_fast_math_matches_full_frame():
     # the default (PLR_MATH_FAST) kernel set through the same partition: fast kernels are deterministic too
     inputs = _make_inputs()
-    out = {}
-    _run(inputs, False, out=out)
+    full = _run_full(inputs, False)
     halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
     bands = _run_bands(inputs, 2, False, halos)
-    mism = _compare(out["full"], bands, 2)
+    mism = _compare(full, bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
     assert not bad, bad
 
