@@ -200,6 +200,220 @@ __global__ __launch_bounds__(256) void temporalFilterFastKernel(ImgView current,
     ((uint32_t*)output.ptr)[(size_t)py * (size_t)output.w + px] = packed;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Strip kernel (history sampling Bilinear and Bicubic1Tap, the default).
+//
+// A CU's texture addresser retires roughly one wave-wide load per 16-22 cycles whatever its width, and the kernel above issues
+// ~40 of them per pixel row segment (9 colour + 9 depth + 16 + 4 history texels ...): it is bound by load-instruction count.
+// Here a wave owns a 62-pixel wide, 4-row tall strip: lane L holds column x0 - 1 + L, so the left and right neighbour columns of
+// the 3x3 neighbourhood arrive by DPP wave shifts instead of loads (lanes 0 and 63 only feed their neighbours), and the wave walks
+// down its rows with a three-row window in registers, loading each colour / depth row once. The 4x4 history footprint of the
+// nine neighbourhood taps is four unaligned 16-byte row loads and also contains the bilinear history tap. Per output row a wave
+// issues ~9 loads instead of ~40.
+PLR_DI float fromLeft(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false)); }  // wave_shr:1
+PLR_DI float fromRight(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false)); } // wave_shl:1
+PLR_DI float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+PLR_DI float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+struct Column { float r, g, b, l, d; }; // (tonemapped) colour, its luminance, raw depth (0 outside the image, as texelFetch)
+PLR_DI Column shiftFromLeft(const Column& c) { return {fromLeft(c.r), fromLeft(c.g), fromLeft(c.b), fromLeft(c.l), fromLeft(c.d)}; }
+PLR_DI Column shiftFromRight(const Column& c) { return {fromRight(c.r), fromRight(c.g), fromRight(c.b), fromRight(c.l), fromRight(c.d)}; }
+
+constexpr int kStripW = 62, kStripRows = 4;
+
+template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
+__global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
+                                                                 ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
+                                                                 int coverW, int coverH, int yBase) {
+    static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
+    const int rowFirst = yBase + ((int)blockIdx.y * 4 + wave) * kStripRows;
+    if (rowFirst >= coverH) return; // wave-uniform
+    const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
+    const int xc = clampi(px, current.w);
+    const bool xInDepth = px >= 0 && px < depthBuffer.w;
+    const uint32_t* cur = (const uint32_t*)current.ptr;
+    const float* dep = (const float*)depthBuffer.ptr;
+
+    auto loadRow = [&](int y) -> Column {
+        const vec3 c = unpackR11G11B10(cur[(size_t)clampi(y, current.h) * (size_t)current.w + xc]);
+        const float l = lum(c);
+        Column o;
+        if (TONEMAP) { const float s = rcpf(1.f + l); o.r = c.x * s; o.g = c.y * s; o.b = c.z * s; o.l = l * s; }
+        else { o.r = c.x; o.g = c.y; o.b = c.z; o.l = l; }
+        o.d = 0.f;
+        if (DILATE) {
+            const float dv = dep[(size_t)clampi(y, depthBuffer.h) * (size_t)depthBuffer.w + clampi(px, depthBuffer.w)];
+            o.d = (xInDepth && y >= 0 && y < depthBuffer.h) ? dv : 0.f;
+        }
+        return o;
+    };
+
+    const ResolveWeights rw = *rwp;
+    const float tsx = 1.f / (float)output.w, tsy = 1.f / (float)output.h;
+    const float resX = (float)g->screenResolution[0], resY = (float)g->screenResolution[1];
+    const bool cameraCut = g->cameraCut != 0u;
+    const uint32_t* hist = (const uint32_t*)historySrc.ptr;
+    const int hw = historySrc.w, hh = historySrc.h;
+
+    // three-row window: C[0] = row y-1, C[1] = row y, C[2] = row y+1; L / R = the neighbour lanes' columns
+    Column C[3], L[3], R[3];
+    C[0] = loadRow(rowFirst - 1); C[1] = loadRow(rowFirst);
+    L[0] = shiftFromLeft(C[0]); R[0] = shiftFromRight(C[0]);
+    L[1] = shiftFromLeft(C[1]); R[1] = shiftFromRight(C[1]);
+
+#pragma unroll
+    for (int j = 0; j < kStripRows; j++) {
+        const int py = rowFirst + j;
+        if (py >= coverH) break; // wave-uniform
+        C[2] = loadRow(py + 1);
+        L[2] = shiftFromLeft(C[2]); R[2] = shiftFromRight(C[2]);
+
+        // n[x+1][y+1] of the reference: x = -1 -> L, 0 -> C, +1 -> R; y = -1..1 -> window row 0..2
+        const vec3 mn(min3f(min3f(L[0].r, C[0].r, R[0].r), min3f(L[1].r, C[1].r, R[1].r), min3f(L[2].r, C[2].r, R[2].r)),
+                      min3f(min3f(L[0].g, C[0].g, R[0].g), min3f(L[1].g, C[1].g, R[1].g), min3f(L[2].g, C[2].g, R[2].g)),
+                      min3f(min3f(L[0].b, C[0].b, R[0].b), min3f(L[1].b, C[1].b, R[1].b), min3f(L[2].b, C[2].b, R[2].b)));
+        const vec3 mx(max3f(max3f(L[0].r, C[0].r, R[0].r), max3f(L[1].r, C[1].r, R[1].r), max3f(L[2].r, C[2].r, R[2].r)),
+                      max3f(max3f(L[0].g, C[0].g, R[0].g), max3f(L[1].g, C[1].g, R[1].g), max3f(L[2].g, C[2].g, R[2].g)),
+                      max3f(max3f(L[0].b, C[0].b, R[0].b), max3f(L[1].b, C[1].b, R[1].b), max3f(L[2].b, C[2].b, R[2].b)));
+        // weights: index = (x+1) + 3 * (y+1) (temporalFilter.comp resolve loop, y outer)
+        auto wsum = [&](float l0, float c0, float r0, float l1, float c1, float r1, float l2, float c2, float r2) {
+            return l0 * rw.w[0] + c0 * rw.w[1] + r0 * rw.w[2] + l1 * rw.w[3] + c1 * rw.w[4] + r1 * rw.w[5] + l2 * rw.w[6] + c2 * rw.w[7] + r2 * rw.w[8];
+        };
+        vec3 currentColor(wsum(L[0].r, C[0].r, R[0].r, L[1].r, C[1].r, R[1].r, L[2].r, C[2].r, R[2].r),
+                          wsum(L[0].g, C[0].g, R[0].g, L[1].g, C[1].g, R[1].g, L[2].g, C[2].g, R[2].g),
+                          wsum(L[0].b, C[0].b, R[0].b, L[1].b, C[1].b, R[1].b, L[2].b, C[2].b, R[2].b));
+
+        // closest (largest reverse-Z) depth of the 3x3, scanned x outer / y inner like the reference loop, first maximum wins
+        int ox = 0, oy = 0;
+        if (DILATE) {
+            float closest = 0.f;
+            const Column* cols[3] = {L, C, R};
+#pragma unroll
+            for (int x = 0; x < 3; x++)
+#pragma unroll
+                for (int y = 0; y < 3; y++) {
+                    const float d = cols[x][y].d;
+                    if (d > closest) { closest = d; ox = x - 1; oy = y - 1; }
+                }
+        }
+        const vec4 m = texelFetch2D<F_RG16SN>(motionBuffer, px + ox, py + oy);
+        const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
+        const float rpx = u0 + m.x, rpy = v0 + m.y;
+
+        // ---- history: the 4x4 texel footprint of the nine bilinear neighbourhood taps around uv + motion
+        int i0, j0; float a, b;
+        linearCoord(rpx * (float)hw, &i0, &a);
+        linearCoord(rpy * (float)hh, &j0, &b);
+        uint32_t t[4][4]; // [row][col] = texel (i0 - 1 + col, j0 - 1 + row), clamped to the edge
+        const bool interior = i0 >= 1 && i0 + 2 < hw;
+        if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint4 v;
+                __builtin_memcpy(&v, hist + (size_t)clampi(j0 - 1 + r, hh) * (size_t)hw + (size_t)(i0 - 1), 16);
+                t[r][0] = v.x; t[r][1] = v.y; t[r][2] = v.z; t[r][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const size_t row = (size_t)clampi(j0 - 1 + r, hh) * (size_t)hw;
+#pragma unroll
+                for (int c = 0; c < 4; c++) t[r][c] = hist[row + clampi(i0 - 1 + c, hw)];
+            }
+        }
+        float tl[4][4];
+        vec3 tc[2][2]; // colours of the centre 2x2 = footprint of the bilinear tap at uv + motion
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const vec3 col = unpackR11G11B10(t[r][c]);
+                tl[r][c] = lum(col);
+                if (r >= 1 && r <= 2 && c >= 1 && c <= 2) tc[r - 1][c - 1] = col;
+            }
+
+        vec3 historySample;
+        {
+            const vec3 top = tc[0][0] + (tc[0][1] - tc[0][0]) * a, bot = tc[1][0] + (tc[1][1] - tc[1][0]) * a;
+            const vec3 bilinear = top + (bot - top) * b; // = historyTap(historySrc, rpx, rpy)
+            if (TECH == 0) historySample = bilinear;
+            else {
+                // Bicubic1Tap (bicubicSampling.inc:147-181): one bilinear tap at the bicubic-adjusted position plus the current frame's
+                // neighbourhood differences
+                const float ix = (float)px + 0.5f + m.x * resX, iy = (float)py + 0.5f + m.y * resY;
+                const float tx = floorf(ix - 0.5f) + 0.5f, ty = floorf(iy - 0.5f) + 0.5f;
+                const float fx = ix - tx, fy = iy - ty;
+                const float fx2 = fx * fx, fx3 = fx2 * fx, fy2 = fy * fy, fy3 = fy2 * fy;
+                const float w0x = -0.5f * fx3 + fx2 - 0.5f * fx, w1x = 1.5f * fx3 - 2.5f * fx2 + 1.f, w2x = -1.5f * fx3 + 2.f * fx2 + 0.5f * fx, w3x = 0.5f * fx3 - 0.5f * fx2;
+                const float w0y = -0.5f * fy3 + fy2 - 0.5f * fy, w1y = 1.5f * fy3 - 2.5f * fy2 + 1.f, w2y = -1.5f * fy3 + 2.f * fy2 + 0.5f * fy, w3y = 0.5f * fy3 - 0.5f * fy2;
+                const float wBx = w1x + w2x, wBy = w1y + w2y;
+                const float uT = (tx + w2x * rcpf(wBx)) * tsx, vT = (ty + w2y * rcpf(wBy)) * tsy;
+                int i1, j1; float a1, b1;
+                linearCoord(uT * (float)hw, &i1, &a1);
+                linearCoord(vT * (float)hh, &j1, &b1);
+                vec3 h;
+                if (i1 == i0 && j1 == j0) {
+                    const vec3 tp = tc[0][0] + (tc[0][1] - tc[0][0]) * a1, bt = tc[1][0] + (tc[1][1] - tc[1][0]) * a1;
+                    h = tp + (bt - tp) * b1;
+                } else h = historyTap(historySrc, uT, vT); // the adjusted tap fell into a neighbouring texel quad (rounding at a texel border)
+                const float wa = w0x * wBy, wb = wBx * w0y, wc = wBx * wBy, wd = wBx * w3y, we = w3x * wBy;
+                const vec3 cC(C[1].r, C[1].g, C[1].b);
+                const vec3 acc = (vec3(L[1].r, L[1].g, L[1].b) - cC) * wa + (vec3(C[0].r, C[0].g, C[0].b) - cC) * wb + (vec3(C[2].r, C[2].g, C[2].b) - cC) * wd +
+                                 (vec3(R[1].r, R[1].g, R[1].b) - cC) * we;
+                historySample = h + acc * rcpf(wa + wb + wc + wd + we);
+            }
+        }
+        if (TONEMAP) historySample = tonemapF(historySample);
+        if (CLIP) historySample = clipAABB(historySample, mn, mx);
+        else historySample = vec3(__builtin_fminf(__builtin_fmaxf(historySample.x, mn.x), mx.x), __builtin_fminf(__builtin_fmaxf(historySample.y, mn.y), mx.y),
+                                  __builtin_fminf(__builtin_fmaxf(historySample.z, mn.z), mx.z));
+        if (anyNan(historySample)) historySample = currentColor;
+
+        const float cc = C[1].l;
+        const float currentContrast = fabsf(L[0].l - cc) + fabsf(C[0].l - cc) + fabsf(R[0].l - cc) + fabsf(L[2].l - cc) + fabsf(C[2].l - cc) + fabsf(R[2].l - cc) +
+                                      fabsf(L[1].l - cc) + fabsf(R[1].l - cc);
+        float lastContrast;
+        {
+            float hl[3][3]; // [x+1][y+1]
+#pragma unroll
+            for (int y = 0; y < 3; y++) {
+                float rowLerp[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) rowLerp[c] = tl[y][c] + (tl[y + 1][c] - tl[y][c]) * b;
+#pragma unroll
+                for (int x = 0; x < 3; x++) {
+                    const float l = rowLerp[x] + (rowLerp[x + 1] - rowLerp[x]) * a;
+                    hl[x][y] = TONEMAP ? l * rcpf(1.f + l) : l;
+                }
+            }
+            const float hc = hl[1][1];
+            lastContrast = fabsf(hl[0][0] - hc) + fabsf(hl[1][0] - hc) + fabsf(hl[2][0] - hc) + fabsf(hl[0][2] - hc) + fabsf(hl[1][2] - hc) + fabsf(hl[2][2] - hc) +
+                           fabsf(hl[0][1] - hc) + fabsf(hl[2][1] - hc);
+        }
+        const float contrastChange = __builtin_amdgcn_fmed3f(fabsf(currentContrast - lastContrast), 0.f, 1.f);
+        float blendFactor = 0.13f + (0.03f - 0.13f) * contrastChange;
+        if (cameraCut) blendFactor = 1.f;
+        if (rpx < 0.f || rpy < 0.f || rpx > 1.f || rpy > 1.f) {
+            blendFactor = 1.f;
+            currentColor = (vec3(L[0].r, L[0].g, L[0].b) + vec3(L[2].r, L[2].g, L[2].b) + vec3(R[0].r, R[0].g, R[0].b) + vec3(R[2].r, R[2].g, R[2].b)) * 0.0625f +
+                           (vec3(C[0].r, C[0].g, C[0].b) + vec3(L[1].r, L[1].g, L[1].b) + vec3(C[2].r, C[2].g, C[2].b) + vec3(R[1].r, R[1].g, R[1].b)) * 0.125f +
+                           vec3(C[1].r, C[1].g, C[1].b) * 0.25f;
+        }
+        vec3 color = historySample + (currentColor - historySample) * blendFactor;
+        if (TONEMAP) color = tonemapReverseF(color);
+        const uint32_t packed = packR11G11B10(color);
+        if (isOutputLane) {
+            if (px < historyDst.w && py < historyDst.h) ((uint32_t*)historyDst.ptr)[(size_t)py * (size_t)historyDst.w + px] = packed;
+            ((uint32_t*)output.ptr)[(size_t)py * (size_t)output.w + px] = packed;
+        }
+        // slide the window down one row
+        C[0] = C[1]; L[0] = L[1]; R[0] = R[1];
+        C[1] = C[2]; L[1] = L[2]; R[1] = R[2];
+    }
+}
+
 typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
 template <bool CLIP, bool DILATE, bool TONEMAP> static TaaKernel pickTech(int tech) {
     switch (tech) {
@@ -232,13 +446,29 @@ static int launch(const PassCtx& c) {
         else k = tonemap ? pickTech<false, false, true>(tech) : pickTech<false, false, false>(tech);
     }
     if (!k) return c.fail(-6, "temporalFilter: historySampleTech must be 0..4");
+    TaaKernel strip = nullptr;
+    if (tech == 0 || tech == 4) {
+#define PLR_STRIP(T) (clip ? (dilate ? (tonemap ? temporalFilterStripKernel<true, true, T, true> : temporalFilterStripKernel<true, true, T, false>)   \
+                                     : (tonemap ? temporalFilterStripKernel<true, false, T, true> : temporalFilterStripKernel<true, false, T, false>)) \
+                           : (dilate ? (tonemap ? temporalFilterStripKernel<false, true, T, true> : temporalFilterStripKernel<false, true, T, false>)  \
+                                     : (tonemap ? temporalFilterStripKernel<false, false, T, true> : temporalFilterStripKernel<false, false, T, false>)))
+        strip = tech == 0 ? PLR_STRIP(0) : PLR_STRIP(4);
+#undef PLR_STRIP
+    }
     const ImgView& out = c.storage[1];
     const int w = std::min({(int)(c.dispatch[0] * 8u), out.w, c.sampled[0].w});
     const PassCtx::RowSpan rs = c.rowSpan(std::min(out.h, c.sampled[0].h));
     const int h = rs.y1, y0 = rs.y0; // rows [y0, h)
     if (w <= 0 || h <= y0) return 0;
-    k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
-                                                                                   (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
+    // the strip kernel indexes all per-pixel images with one coordinate: it needs them to be the same size
+    const bool sameSize = c.sampled[0].w == out.w && c.sampled[0].h == out.h && c.sampled[3].w == out.w && c.sampled[3].h == out.h && c.sampled[5].w == out.w &&
+                          c.sampled[5].h == out.h && out.w >= 4;
+    if (strip && sameSize)
+        strip<<<dim3(divUp((unsigned)w, (unsigned)kStripW), divUp((unsigned)(h - y0), 4u * kStripRows)), 256, 0, c.stream>>>(
+            c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
+    else
+        k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
+                                                                                       (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
