@@ -432,6 +432,12 @@ class RenderBackend:
         b = np.ascontiguousarray(data)
         self._check(self.lib.plr_upload_image(self._h(image), C.c_uint32(mip), b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes)))
 
+    def getLastFrameCPUTime(self):
+        """RenderBackend::getLastFrameCPUTime: host milliseconds spent inside the last renderFrame (flush + launches)"""
+        ms = C.c_float()
+        self._check(self.lib.plr_get_last_frame_cpu_time(C.byref(ms)))
+        return ms.value
+
     def uploadImageRows(self, image, row_begin, data, mip=0):
         """data: the rows [row_begin, row_begin + data.shape[0]) of a 2D image"""
         b = np.ascontiguousarray(data)

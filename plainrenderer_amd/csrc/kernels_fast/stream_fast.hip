@@ -1,0 +1,346 @@
+// PLR_MATH_FAST variants of the streaming passes: applyBloom.comp, tonemapping.comp, indirectLightUpscale.comp,
+// filterIndirectDiffuseTemporal.comp (exact variants: kernels/bloom.hip, exposure_tonemap.hip, gi_filters.hip).
+//
+// Every pass of this pipeline is bound by VALU issue on gfx950 (a wave64 FP32 instruction occupies a SIMD for 4 cycles; PMC:
+// SQ_INSTS_VALU x 4 cycles / 4 SIMDs accounts for each kernel's time), not by HBM. These variants keep the algorithms and cut the
+// instruction count: v_rcp instead of IEEE division sequences, hardware min/max/med3 instead of the NaN-ordered software forms,
+// texel-centre taps as plain fetches, values that are constant along a row or shared by the four pixels of a lane computed once,
+// and adjacent texels fetched with one wide load (a load instruction costs a CU's texture addresser ~16 cycles whatever its width).
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+namespace faststream {
+
+PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+PLR_DI float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+
+// ------------------------------------------------------------------------------------------------ applyBloom.comp:16-30
+// target = mix(scene, bloom, strength) in place. The bloom image has the target's size, so the bilinear tap at the pixel centre
+// is the texel itself. Four pixels (16 B) per lane.
+__global__ __launch_bounds__(256) void applyBloomFastKernel(ImgView target, ImgView bloom, float strength, int coverW, int coverH, int yBase) {
+    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (y >= coverH || x0 >= coverW) return;
+    uint32_t* trow = (uint32_t*)target.ptr + (size_t)y * (size_t)target.w;
+    const uint32_t* brow = (const uint32_t*)bloom.ptr + (size_t)y * (size_t)bloom.w;
+    const int n = min(4, coverW - x0);
+    uint32_t s[4] = {0u, 0u, 0u, 0u}, b[4] = {0u, 0u, 0u, 0u};
+    const bool wide = n == 4 && (target.w & 3) == 0;
+    if (wide) {
+        const uint4 sv = *(const uint4*)(trow + x0), bv = *(const uint4*)(brow + x0);
+        s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w; b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+    } else for (int i = 0; i < n; i++) { s[i] = trow[x0 + i]; b[i] = brow[x0 + i]; }
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const vec3 sc = unpackR11G11B10(s[i]), bc = unpackR11G11B10(b[i]);
+        o[i] = packR11G11B10(sc + (bc - sc) * strength);
+    }
+    if (wide) *(uint4*)(trow + x0) = make_uint4(o[0], o[1], o[2], o[3]);
+    else for (int i = 0; i < n; i++) trow[x0 + i] = o[i];
+}
+
+static int launchApplyBloom(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R11G11B10, "applyBloom target")) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "applyBloom bloomTexture")) return rc;
+    if (c.push.size() < 4) return c.fail(-1, "applyBloom: push constant bloomStrength missing");
+    const ImgView& target = c.storage[0];
+    if (c.sampled[1].w != target.w || c.sampled[1].h != target.h) return kUseGeneralKernel; // a real bilinear tap: general kernel
+    float strength;
+    std::memcpy(&strength, c.push.data(), 4);
+    const PassCtx::RowSpan rs = c.rowSpan(target.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    applyBloomFastKernel<<<dim3(divUp((unsigned)w, 256u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(target, c.sampled[1], strength, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ tonemapping.comp:17-27
+PLR_DI float srgb(float l) {
+    const float hi = __builtin_amdgcn_exp2f((1.0f / 2.4f) * __builtin_amdgcn_logf(fabsf(l))) * 1.055f - 0.055f;
+    return l <= 0.0031308f ? l * 12.92f : hi;
+}
+PLR_DI uint32_t unorm8(float v) { return (uint32_t)__float2int_rn(clamp01(v) * 255.0f); } // the inputs here are never NaN after the clamps of ACESFitted
+
+template <bool BGRA>
+__global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (y >= coverH || x0 >= coverW) return;
+    const float time = g->time;
+    const uint32_t* srow = (const uint32_t*)src.ptr + (size_t)y * (size_t)src.w;
+    uint32_t* drow = (uint32_t*)dst.ptr + (size_t)y * (size_t)dst.w;
+    const int n = min(4, coverW - x0);
+    uint32_t in[4] = {0u, 0u, 0u, 0u}, out[4];
+    const bool wide = n == 4 && (src.w & 3) == 0 && (dst.w & 3) == 0;
+    if (wide) { const uint4 v = *(const uint4*)(srow + x0); in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w; }
+    else for (int i = 0; i < n; i++) in[i] = srow[x0 + i];
+    // dither.inc:6-12 / noise.inc:19-24: hash32(q) = fract-free integer hash of uvec2 q; the y terms are shared by the lane's four pixels
+    const uint32_t UI0 = 1597334673u, UI1 = 3812015801u, UI2 = 2798796415u;
+    const uint32_t qyA = (uint32_t)(int32_t)(float)(uint32_t)((float)y * time), qyB = (uint32_t)(int32_t)(float)(uint32_t)(((float)y + 1292.f) * time);
+    const uint32_t nyA = qyA * UI1, nyB = qyB * UI1;
+    const float UIF = 1.0f / (float)0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const vec3 c = unpackR11G11B10(in[i]);
+        // ACESFitted (tonemapping.inc:40-49)
+        vec3 v(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z, 0.02840f * c.x + 0.13383f * c.y + 0.83777f * c.z);
+        const vec3 a = v * (v + 0.0245786f) - 0.000090537f;
+        const vec3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+        v = vec3(a.x * rcpf(b.x), a.y * rcpf(b.y), a.z * rcpf(b.z));
+        const vec3 o(clamp01(1.60475f * v.x + -0.53108f * v.y + -0.07367f * v.z), clamp01(-0.10208f * v.x + 1.10813f * v.y + -0.00605f * v.z),
+                     clamp01(-0.00327f * v.x + -0.07276f * v.y + 1.07602f * v.z));
+        const int x = x0 + i;
+        const uint32_t qxA = (uint32_t)(int32_t)(float)(uint32_t)((float)x * time), qxB = (uint32_t)(int32_t)(float)(uint32_t)(((float)x + 165.f) * time);
+        const uint32_t mA = (qxA * UI0) ^ nyA ^ (qxA * UI2), mB = (qxB * UI0) ^ nyB ^ (qxB * UI2);
+        const vec3 noise = (vec3((float)(mA * UI0), (float)(mA * UI1), (float)(mA * UI2)) + vec3((float)(mB * UI0), (float)(mB * UI1), (float)(mB * UI2))) * UIF - 1.f;
+        const vec3 s = vec3(srgb(o.x), srgb(o.y), srgb(o.z)) + noise * (1.f / 255.f);
+        uint32_t p = unorm8(s.z) | (unorm8(s.y) << 8) | (unorm8(s.x) << 16) | (255u << 24);
+        if (!BGRA) p = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+        out[i] = p;
+    }
+    if (wide) *(uint4*)(drow + x0) = make_uint4(out[0], out[1], out[2], out[3]);
+    else for (int i = 0; i < n; i++) drow[x0 + i] = out[i];
+}
+
+static int launchTonemapping(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "tonemapping imageIn")) return rc;
+    if (int rc = c.needStorage(0, -1, "tonemapping imageOut")) return rc;
+    const ImgView& src = c.sampled[1];
+    const ImgView& dst = c.storage[0];
+    if (dst.fmt != F_BGRA8 && dst.fmt != F_RGBA8) return c.fail(-4, "tonemapping imageOut must be BGRA8_uNorm or RGBA8");
+    const int coverW = std::min({(int)(c.dispatch[0] * 8u), dst.w, src.w});
+    const PassCtx::RowSpan rs = c.rowSpan(std::min(dst.h, src.h));
+    const int coverH = rs.y1, y0 = rs.y0;
+    if (coverW <= 0 || coverH <= y0) return 0;
+    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)(coverH - y0), 4u));
+    if (dst.fmt == F_BGRA8) tonemappingFastKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
+    else tonemappingFastKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ indirectLightUpscale.comp:17-71
+// bilinear footprint of an RGBA16F / RG16F / R16F image at (i0..i0+1, j0..j0+1) with clamp-to-edge, the two texels of a row in one load
+struct Pair8 { uint2 a, b; };
+PLR_DI Pair8 loadPairRGBA16F(const ImgView& im, int x0, int x1, int y) {
+    const uint2* row = (const uint2*)im.ptr + (size_t)y * (size_t)im.w;
+    Pair8 p;
+    if (im.w >= 2) {
+        const int xb = min(x0, im.w - 2);
+        uint4 v;
+        __builtin_memcpy(&v, row + xb, 16);
+        const uint2 lo = make_uint2(v.x, v.y), hi = make_uint2(v.z, v.w);
+        p.a = x0 == xb ? lo : hi;
+        p.b = x1 == xb ? lo : hi;
+    } else { p.a = row[x0]; p.b = row[x1]; }
+    return p;
+}
+PLR_DI void loadPairRG16F(const ImgView& im, int x0, int x1, int y, uint32_t* a, uint32_t* b) {
+    const uint32_t* row = (const uint32_t*)im.ptr + (size_t)y * (size_t)im.w;
+    if (im.w >= 2) {
+        const int xb = min(x0, im.w - 2);
+        uint2 v;
+        __builtin_memcpy(&v, row + xb, 8);
+        *a = x0 == xb ? v.x : v.y;
+        *b = x1 == xb ? v.x : v.y;
+    } else { *a = row[x0]; *b = row[x1]; }
+}
+PLR_DI vec4 halves4(uint2 t) { return vec4(halfBitsToFloat(t.x & 0xffffu), halfBitsToFloat(t.x >> 16), halfBitsToFloat(t.y & 0xffffu), halfBitsToFloat(t.y >> 16)); }
+PLR_DI vec2 halves2(uint32_t t) { return vec2(halfBitsToFloat(t & 0xffffu), halfBitsToFloat(t >> 16)); }
+
+struct Bilinear { int x0, x1, y0, y1; float a, b; };
+PLR_DI Bilinear bilinearCoords(const ImgView& im, float u, float v) {
+    Bilinear q;
+    int i0, j0;
+    linearCoord(u * (float)im.w, &i0, &q.a);
+    linearCoord(v * (float)im.h, &j0, &q.b);
+    q.x0 = clampi(i0, im.w); q.x1 = clampi(i0 + 1, im.w); q.y0 = clampi(j0, im.h); q.y1 = clampi(j0 + 1, im.h);
+    return q;
+}
+PLR_DI vec4 bilinearRGBA16F(const ImgView& im, const Bilinear& q) {
+    const Pair8 r0 = loadPairRGBA16F(im, q.x0, q.x1, q.y0), r1 = loadPairRGBA16F(im, q.x0, q.x1, q.y1);
+    const vec4 t00 = halves4(r0.a), t10 = halves4(r0.b), t01 = halves4(r1.a), t11 = halves4(r1.b);
+    const float w00 = (1.f - q.a) * (1.f - q.b), w10 = q.a * (1.f - q.b), w01 = (1.f - q.a) * q.b, w11 = q.a * q.b;
+    return t00 * w00 + t10 * w10 + t01 * w01 + t11 * w11;
+}
+PLR_DI vec2 bilinearRG16F(const ImgView& im, const Bilinear& q) {
+    uint32_t a0, b0, a1, b1;
+    loadPairRG16F(im, q.x0, q.x1, q.y0, &a0, &b0);
+    loadPairRG16F(im, q.x0, q.x1, q.y1, &a1, &b1);
+    const float w00 = (1.f - q.a) * (1.f - q.b), w10 = q.a * (1.f - q.b), w01 = (1.f - q.a) * q.b, w11 = q.a * q.b;
+    return halves2(a0) * w00 + halves2(b0) * w10 + halves2(a1) * w01 + halves2(b1) * w11;
+}
+
+__global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
+                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const float u = ((float)px + 0.5f) * rcpf((float)g->screenResolution[0]), v = ((float)py + 0.5f) * rcpf((float)g->screenResolution[1]);
+    const float nearP = g->nearPlane, farP = g->farPlane, nf = nearP * farP, nmf = nearP - farP;
+    auto linearize = [&](float d) { return nf * rcpf(farP + (1.f - d) * nmf); };
+    const int fx = min(max((int)floorf(u * (float)fullResDepthT.w), 0), fullResDepthT.w - 1), fy = min(max((int)floorf(v * (float)fullResDepthT.h), 0), fullResDepthT.h - 1);
+    const float fullResDepth = linearize(((const float*)fullResDepthT.ptr)[(size_t)fy * (size_t)fullResDepthT.w + fx]);
+    // textureGather footprint of the half-res depth: (i0,j1), (i1,j1), (i1,j0), (i0,j0); a row's two texels in one 4-byte load
+    const Bilinear q = bilinearCoords(halfResDepthT, u, v);
+    float d00, d10, d01, d11;
+    {
+        const uint16_t* hd = (const uint16_t*)halfResDepthT.ptr;
+        auto pair = [&](int y, float* a, float* b) {
+            const uint16_t* row = hd + (size_t)y * (size_t)halfResDepthT.w;
+            if (halfResDepthT.w >= 2) {
+                const int xb = min(q.x0, halfResDepthT.w - 2);
+                uint32_t w2;
+                __builtin_memcpy(&w2, row + xb, 4);
+                const float lo = halfBitsToFloat(w2 & 0xffffu), hi = halfBitsToFloat(w2 >> 16);
+                *a = q.x0 == xb ? lo : hi;
+                *b = q.x1 == xb ? lo : hi;
+            } else { *a = halfBitsToFloat(row[q.x0]); *b = halfBitsToFloat(row[q.x1]); }
+        };
+        pair(q.y0, &d00, &d10);
+        pair(q.y1, &d01, &d11);
+    }
+    const float depthSamples[4] = {d01, d11, d10, d00};
+    const float offx[4] = {0.f, 1.f, 1.f, 0.f}, offy[4] = {1.f, 1.f, 0.f, 0.f};
+    float minDepthDiff = 1000.f, cx = 0.f, cy = 0.f;
+    bool isEdge = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float depthDiff = fabsf(linearize(depthSamples[i]) - fullResDepth);
+        isEdge = isEdge || depthDiff > 0.5f;
+        if (depthDiff < minDepthDiff) { minDepthDiff = depthDiff; cx = offx[i]; cy = offy[i]; }
+    }
+    vec4 ysh;
+    vec2 cc;
+    if (isEdge) {
+        // nearest texel at uv + offset * halfResTexelSize (:60-64); this can be a texel outside the gather footprint
+        const float uc = u + cx * rcpf((float)halfResDepthT.w), vc = v + cy * rcpf((float)halfResDepthT.h);
+        const int nx = min(max((int)floorf(uc * (float)srcYSH.w), 0), srcYSH.w - 1), ny = min(max((int)floorf(vc * (float)srcYSH.h), 0), srcYSH.h - 1);
+        ysh = halves4(((const uint2*)srcYSH.ptr)[(size_t)ny * (size_t)srcYSH.w + nx]);
+        const int mx = min(max((int)floorf(uc * (float)srcCoCg.w), 0), srcCoCg.w - 1), my = min(max((int)floorf(vc * (float)srcCoCg.h), 0), srcCoCg.h - 1);
+        cc = halves2(((const uint32_t*)srcCoCg.ptr)[(size_t)my * (size_t)srcCoCg.w + mx]);
+    } else {
+        ysh = bilinearRGBA16F(srcYSH, bilinearCoords(srcYSH, u, v));
+        cc = bilinearRG16F(srcCoCg, bilinearCoords(srcCoCg, u, v));
+    }
+    const size_t idx = (size_t)py * (size_t)dstYSH.w + px;
+    Texel<F_RGBA16F>::store(dstYSH.ptr, idx, ysh);
+    Texel<F_RG16F>::store(dstCoCg.ptr, idx, vec4(cc.x, cc.y, 0.f, 0.f));
+}
+
+static int launchUpscale(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "indirectLightUpscale fullResDst_Y_SH")) return rc;
+    if (int rc = c.needStorage(1, F_RG16F, "indirectLightUpscale fullResDst_CoCg")) return rc;
+    if (int rc = c.needSampled(2, F_RGBA16F, "indirectLightUpscale halfResSrc_Y_SH")) return rc;
+    if (int rc = c.needSampled(3, F_RG16F, "indirectLightUpscale halfResSrc_CoCg")) return rc;
+    if (int rc = c.needSampled(4, F_D32, "indirectLightUpscale fullResDepth")) return rc;
+    if (int rc = c.needSampled(5, F_R16F, "indirectLightUpscale halfResDepth")) return rc;
+    const ImgView& out = c.storage[0];
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    indirectLightUpscaleFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
+                                                                                                              c.sampled[4], c.sampled[5], c.global, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ filterIndirectDiffuseTemporal.comp:20-86
+PLR_DI vec2 bilinearRG16SN(const ImgView& im, float u, float v, bool repeat) {
+    int i0, j0; float a, b;
+    linearCoord(u * (float)im.w, &i0, &a);
+    linearCoord(v * (float)im.h, &j0, &b);
+    int x0, x1, y0, y1;
+    if (repeat) { x0 = repeati(i0, im.w); x1 = repeati(i0 + 1, im.w); y0 = repeati(j0, im.h); y1 = repeati(j0 + 1, im.h); }
+    else { x0 = clampi(i0, im.w); x1 = clampi(i0 + 1, im.w); y0 = clampi(j0, im.h); y1 = clampi(j0 + 1, im.h); }
+    const uint32_t* base = (const uint32_t*)im.ptr;
+    auto tx = [&](int x, int y) {
+        const uint32_t t = base[(size_t)y * (size_t)im.w + x];
+        return vec2(fmaxf((float)(int16_t)(t & 0xffffu) * (1.f / 32767.f), -1.f), fmaxf((float)(int16_t)(t >> 16) * (1.f / 32767.f), -1.f));
+    };
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    return tx(x0, y0) * w00 + tx(x1, y0) * w10 + tx(x0, y1) * w01 + tx(x1, y1) * w11;
+}
+
+__global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
+                                                                  ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
+                                                                  ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const float u = ((float)px + 0.5f) * rcpf((float)targetYSH.w), v = ((float)py + 0.5f) * rcpf((float)targetYSH.h);
+    // the input images have the target's size: the tap at the pixel centre is the texel itself (weights 1,0,0,0)
+    const size_t idx = (size_t)py * (size_t)targetYSH.w + px;
+    const vec4 current_Y_SH = halves4(((const uint2*)inYSH.ptr)[idx]);
+    const vec2 current_CoCg = halves2(((const uint32_t*)inCoCg.ptr)[idx]);
+    const vec2 motion = bilinearRG16SN(velocityCurrent, u, v, false);
+    const float ru = u + motion.x, rv = v + motion.y;
+    vec4 history_Y_SH = bilinearRGBA16F(historyInYSH, bilinearCoords(historyInYSH, ru, rv));
+    vec2 history_CoCg = bilinearRG16F(historyInCoCg, bilinearCoords(historyInCoCg, ru, rv));
+    const vec2 motionLast = bilinearRG16SN(velocityLast, ru, rv, true); // sic: linearRepeat (:36)
+    const float motionDifference = __builtin_amdgcn_sqrtf(fabsf(__builtin_amdgcn_sqrtf(dot(motion, motion)) - __builtin_amdgcn_sqrtf(dot(motionLast, motionLast))));
+    const float motionDifferenceFactor = clamp01(motionDifference * 10.f);
+    float alphaMin = 0.6f - 0.3f * fabsf(__builtin_amdgcn_sqrtf(dot(current_Y_SH, current_Y_SH)) - __builtin_amdgcn_sqrtf(dot(history_Y_SH, history_Y_SH)));
+    alphaMin = fmaxf(alphaMin, 0.f);
+    float alpha = 0.8f + (alphaMin - 0.8f) * motionDifferenceFactor;
+    const float resX = (float)g->screenResolution[0], resY = (float)g->screenResolution[1];
+    if (fmaxf(fmaxf(fabsf(motion.x), fabsf(motionLast.x)) * resX, fmaxf(fabsf(motion.y), fabsf(motionLast.y)) * resY) > 3.f) alpha = alphaMin;
+    if (ru < 0.f || rv < 0.f || ru > 1.f || rv > 1.f) alpha = 0.f;
+    if (g->cameraCut) alpha = 0.f;
+    if (anyNan(current_Y_SH) || anyNan(current_CoCg)) {
+        alpha = 1.f;
+        if (anyNan(history_Y_SH)) history_Y_SH = vec4(0.f);
+        if (anyNan(history_CoCg)) history_CoCg = vec2(0.f);
+    }
+    const vec4 result_Y_SH = current_Y_SH * (1.f - alpha) + history_Y_SH * alpha;
+    const vec2 result_CoCg = current_CoCg * (1.f - alpha) + history_CoCg * alpha;
+    const uint2 py4 = make_uint2(floatToHalfBits(result_Y_SH.x) | (floatToHalfBits(result_Y_SH.y) << 16), floatToHalfBits(result_Y_SH.z) | (floatToHalfBits(result_Y_SH.w) << 16));
+    const uint32_t pc = floatToHalfBits(result_CoCg.x) | (floatToHalfBits(result_CoCg.y) << 16);
+    ((uint2*)targetYSH.ptr)[idx] = py4;
+    ((uint32_t*)targetCoCg.ptr)[idx] = pc;
+    ((uint2*)historyOutYSH.ptr)[idx] = py4;
+    ((uint32_t*)historyOutCoCg.ptr)[idx] = pc;
+}
+
+static int launchTemporalGi(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    const int ysh[4] = {0, 2, 4, 6}, cocg[4] = {1, 3, 5, 7};
+    for (int i = 0; i < 2; i++) {
+        if (int rc = c.needStorage(ysh[i], F_RGBA16F, "filterIndirectDiffuseTemporal Y_SH output")) return rc;
+        if (int rc = c.needStorage(cocg[i], F_RG16F, "filterIndirectDiffuseTemporal CoCg output")) return rc;
+    }
+    for (int i = 2; i < 4; i++) {
+        if (int rc = c.needSampled(ysh[i], F_RGBA16F, "filterIndirectDiffuseTemporal Y_SH input")) return rc;
+        if (int rc = c.needSampled(cocg[i], F_RG16F, "filterIndirectDiffuseTemporal CoCg input")) return rc;
+    }
+    if (int rc = c.needSampled(8, F_RG16SN, "filterIndirectDiffuseTemporal velocityCurrent")) return rc;
+    if (int rc = c.needSampled(9, F_RG16SN, "filterIndirectDiffuseTemporal velocityLastFrame")) return rc;
+    const ImgView& out = c.storage[0];
+    // the centre-tap shortcut and the shared store index need all trace-resolution images to have one size
+    for (int b : {1, 2, 3}) if (c.storage[b].w != out.w || c.storage[b].h != out.h) return kUseGeneralKernel;
+    for (int b : {4, 5, 6, 7}) if (c.sampled[b].w != out.w || c.sampled[b].h != out.h) return kUseGeneralKernel;
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    temporalGiFilterFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(
+        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace faststream
+
+static int faststream_apply_bloom(const PassCtx& c) { return faststream::launchApplyBloom(c); }
+static int faststream_tonemapping(const PassCtx& c) { return faststream::launchTonemapping(c); }
+static int faststream_upscale(const PassCtx& c) { return faststream::launchUpscale(c); }
+static int faststream_temporal_gi(const PassCtx& c) { return faststream::launchTemporalGi(c); }
+PLR_REGISTER_SHADER_FAST("applyBloom.comp", faststream_apply_bloom);
+PLR_REGISTER_SHADER_FAST("tonemapping.comp", faststream_tonemapping);
+PLR_REGISTER_SHADER_FAST("indirectLightUpscale.comp", faststream_upscale);
+PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseTemporal.comp", faststream_temporal_gi);
+} // namespace plr

@@ -142,3 +142,47 @@ def test_gpu_fast_trace(fast, scene, strict):
     # neighbours sharing it through the 3x3 resolve. Everything else agrees to half-float precision.
     assert_close(pixfmt.unpack_half(y_g), pixfmt.unpack_half(y_o), rel=2.0 ** -8, abs_floor_frac=2e-4, outlier_frac=0.03, outlier_max_frac=1.0, mean_rel=2e-2, what="trace Y_SH")
     assert_close(pixfmt.unpack_half(c_g), pixfmt.unpack_half(c_o), rel=2.0 ** -8, abs_floor_frac=2e-4, outlier_frac=0.03, outlier_max_frac=2.0, mean_rel=2e-2, what="trace CoCg")
+
+
+# ------------------------------------------------------------------ streaming passes (kernels_fast/stream_fast.hip)
+@pytest.mark.gpu
+def test_gpu_fast_temporal_gi_and_upscale(fast, scene):
+    c, inst_bytes, arr, n, keep = _trace_inputs(fast, scene)
+    gp = scene.g.pack()
+    if "trace" not in c:
+        c["trace"] = passes.orc_sdf_trace(scene.gb["depth"], scene.gb["normal"], W, H, TW, TH, scene.sky, 200, 100, scene.light, inst_bytes, c["tiles"], INFLUENCE,
+                                          scene.shadow_info, scene.shadow_maps[2], 256, gp, arr, n, strict=True, cascade=2)
+    y0, c0 = c["trace"]
+    r = np.random.default_rng(5)
+    hy = pixfmt.pack_half(pixfmt.unpack_half(y0) * r.uniform(0.7, 1.3, y0.shape).astype(np.float32))
+    hc = pixfmt.pack_half(pixfmt.unpack_half(c0) * r.uniform(0.7, 1.3, c0.shape).astype(np.float32))
+    motion_last = np.roll(scene.gb["motion"], 3, axis=1)
+    ta = (y0, c0, hy, hc, TW, TH, scene.gb["motion"], motion_last, W, H, gp)
+    tg = passes.gpu_gi_temporal(fast, *ta)
+    to = passes.orc_gi_temporal(*ta)
+    # half-float outputs; alpha switches between branches at thresholds (3 px motion, off-screen), where a rounding difference
+    # in the reprojected coordinate changes a pixel visibly
+    for a, b, what in zip(tg, to, ("Y_SH", "CoCg", "history Y_SH", "history CoCg")):
+        assert_close(pixfmt.unpack_half(a), pixfmt.unpack_half(b), rel=2.0 ** -9, outlier_frac=0.005, outlier_max_frac=0.5, mean_rel=3e-3, what="temporal " + what)
+    assert np.array_equal(tg[0], tg[2]) and np.array_equal(tg[1], tg[3])
+    ua = (to[2], to[3], TW, TH, scene.gb["depth"], c["half_depth"], W, H, gp)
+    yug, cug = passes.gpu_gi_upscale(fast, *ua)
+    yuo, cuo = passes.orc_gi_upscale(*ua)
+    # the edge test (|depth difference| > 0.5 m) and the closest-texel choice flip for a few pixels on a depth discontinuity
+    assert_close(pixfmt.unpack_half(yug), pixfmt.unpack_half(yuo), rel=2.0 ** -9, outlier_frac=0.005, outlier_max_frac=1.0, mean_rel=3e-3, what="upscale Y_SH")
+    assert_close(pixfmt.unpack_half(cug), pixfmt.unpack_half(cuo), rel=2.0 ** -9, outlier_frac=0.005, outlier_max_frac=2.0, mean_rel=3e-3, what="upscale CoCg")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1920, 1080), (97, 61)])
+def test_gpu_fast_tonemap_within_one_lsb(fast, w, h):
+    from util import hdr_image
+    from test_exposure_tonemap import _global
+    img = hdr_image(w, h, buffer_id=4, pre_exposure=1e-3)
+    g = _global(w, h, time=37.25)
+    a = passes.gpu_tonemap(fast, img, w, h, g, F.BGRA8_uNorm).astype(int)
+    b = passes.orc_tonemap(img, w, h, g).astype(int)
+    d = np.abs(a - b)
+    assert d.max() <= 1  # stated tolerance: +-1/255
+    assert (d != 0).mean() < 0.03
+    assert np.all(a[..., 3] == 255)
