@@ -11,6 +11,7 @@
 // tests/test_fast_kernels.py.
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../device/fastmath.h"
 
 namespace plr {
 namespace fasttrace {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
         const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
         const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
         const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
-        const vec4 nz = Texel<F_RG8>::load(noiseTex.ptr, (size_t)repeati(py, noiseTex.h) * (size_t)noiseTex.w + (size_t)repeati(px, noiseTex.w));
+        const vec2 nz = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
         const vec3 N = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, vec2(u, v)).xyz() * 2.f - 1.f;
         mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
         const vec3 rayOrigin = pWorld + N * 0.2f;

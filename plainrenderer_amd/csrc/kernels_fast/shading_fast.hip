@@ -10,21 +10,28 @@
 // within rounding of equality can flip (1/12 of the sun term for that pixel).
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../device/fastmath.h"
 
 namespace plr {
 
 namespace fastshade {
 
 #ifndef PLR_SHADE_WAVES
-#define PLR_SHADE_WAVES 5 // 88 VGPRs, no scratch: 319 -> 284 us at 4K (6 waves spills: 389 us)
+#define PLR_SHADE_WAVES 4 // 128 VGPRs, no scratch (5 waves = 96 VGPRs spills after the load-pairing rewrite)
 #endif
 
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
+PLR_DI float sqrth(float x) { return __builtin_amdgcn_sqrth(x); } // v_sqrt_f32 (1 ulp) without the denormal-range rescue sequence of sqrth()
+// v_min / v_max / v_med3: a NaN operand loses, as in the software forms of detmath.h, in one instruction
+PLR_DI float fmin1(float a, float b) { return __builtin_fminf(a, b); }
+PLR_DI float fmax1(float a, float b) { return __builtin_fmaxf(a, b); }
+PLR_DI float fclamp(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+PLR_DI float fmix(float a, float b, float t) { return a + (b - a) * t; }
 PLR_DI float log2h(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32 (base 2)
 PLR_DI float exp2h(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (base 2)
 PLR_DI vec3 nrm(vec3 v) { return v * rsqf(dot(v, v)); }
-PLR_DI float pow5(float x) { x = gmax(x, 0.f); const float x2 = x * x; return x2 * x2 * x; }
+PLR_DI float pow5(float x) { x = fmax1(x, 0.f); const float x2 = x * x; return x2 * x2 * x; }
 PLR_DI float fpow(float x, float y) { return x <= 0.f ? 0.f : exp2h(y * log2h(x)); }
 
 PLR_DI float D_GGX(float NoH, float r) {
@@ -34,14 +41,14 @@ PLR_DI float D_GGX(float NoH, float r) {
 }
 PLR_DI float Visibility(float NoV, float NoL, float r) {
     const float r_2 = r * r;
-    const float v1 = NoL * sqrtf(NoV * NoV * (1.f - r_2) + r_2);
-    const float v2 = NoV * sqrtf(NoL * NoL * (1.f - r_2) + r_2);
+    const float v1 = NoL * sqrth(NoV * NoV * (1.f - r_2) + r_2);
+    const float v2 = NoV * sqrth(NoL * NoL * (1.f - r_2) + r_2);
     return 0.5f * rcpf(v1 + v2);
 }
 PLR_DI vec3 F_Schlick(vec3 f0, vec3 f90, float VoH) { return f0 + (f90 - f0) * pow5(1.f - VoH); }
 PLR_DI vec3 DisneyDiffuse(vec3 diffuseColor, float NoL, float VoH, float NoV, float r) {
     const float energyBias = 0.5f * r;
-    const float energyFactor = gmix(1.f, 1.f / 1.51f, r);
+    const float energyFactor = fmix(1.f, 1.f / 1.51f, r);
     const float f90 = energyBias + 2.f * VoH * VoH * r;
     const float fl = 1.f + (f90 - 1.f) * pow5(1.f - NoL), fv = 1.f + (f90 - 1.f) * pow5(1.f - NoV);
     return diffuseColor * ((1.f / PLR_GLSL_PI) * fl * fv * energyFactor);
@@ -50,28 +57,55 @@ PLR_DI vec3 CoDWWIIDiffuse(vec3 diffuseColor, float NoL, float VoH, float NoV, f
     const float f0Diffuse = VoH + pow5(1.f - VoH);
     const float f1 = (1.f - 0.75f * pow5(1.f - NoL)) * (1.f - 0.75f * pow5(1.f - NoV));
     const float g = log2h(2.f * rcpf(r * r) - 1.f) * (1.f / 18.f);
-    const float t = gclamp(2.2f * g - 0.5f, 0.f, 1.f);
+    const float t = fclamp(2.2f * g - 0.5f, 0.f, 1.f);
     const float fd = f0Diffuse + (f1 - f0Diffuse) * t;
-    const float fb = (34.5f * g * g - 59.f * g + 24.5f) * VoH * exp2h(-gmax(73.2f * g - 21.2f, 8.9f) * sqrtf(NoH));
+    const float fb = (34.5f * g * g - 59.f * g + 24.5f) * VoH * exp2h(-fmax1(73.2f * g - 21.2f, 8.9f) * sqrth(NoH));
     return diffuseColor * ((1.f / PLR_GLSL_PI) * (fd + fb));
 }
 PLR_DI float Titanfall2DiffuseSingleComponent(float NoL, float LoV, float NoV, float NoH, float r) {
     const float facing = 0.5f + 0.5f * LoV;
-    const float rough = facing * (0.9f - 0.4f * facing) * (0.5f + NoH) * rcpf(gmax(NoH, 0.03f));
+    const float rough = facing * (0.9f - 0.4f * facing) * (0.5f + NoH) * rcpf(fmax1(NoH, 0.03f));
     const float smoothDiffuse = 1.05f * (1.f - pow5(1.f - NoL)) * (1.f - pow5(1.f - NoV));
-    return (1.f / PLR_GLSL_PI) * gmix(smoothDiffuse, rough, r);
+    return (1.f / PLR_GLSL_PI) * fmix(smoothDiffuse, rough, r);
 }
 PLR_DI vec3 GGXSingleScattering(float r, vec3 f0, float NoH, float NoV, float VoH, float NoL) {
     return (D_GGX(NoH, r) * Visibility(NoV, NoL, r)) * F_Schlick(f0, vec3(1.f), VoH);
 }
 PLR_DI float ReflectedEnergyAverage(float roughness) {
-    const float smoothness = 1.f - sqrtf(roughness);
+    const float smoothness = 1.f - sqrth(roughness);
     float r = -0.0761947f - 0.383026f * smoothness;
     r = 1.04997f + smoothness * r;
     r = 0.409255f + smoothness * r;
-    return gmin(0.999f, r);
+    return fmin1(0.999f, r);
 }
 PLR_DI float sRGBToLinear1(float c) { return c <= 0.004045f ? c * (1.f / 12.92f) : fpow((c + 0.055f) * (1.f / 1.055f), 2.4f); }
+
+// bilinear RGBA16F fetch with clamp-to-edge; the two texels of a row come from one 16-byte load (a load instruction costs the
+// texture addresser the same whatever its width)
+PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
+    int i0, j0; float a, b;
+    linearCoord(u * (float)im.w, &i0, &a);
+    linearCoord(v * (float)im.h, &j0, &b);
+    const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w), y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
+    const int xb = max(min(x0, im.w - 2), 0);
+    auto rowPair = [&](int y, vec4* t0, vec4* t1) {
+        const uint2* row = (const uint2*)im.ptr + (size_t)y * (size_t)im.w;
+        uint2 lo, hi;
+        if (im.w >= 2) {
+            uint4 q;
+            __builtin_memcpy(&q, row + xb, 16);
+            lo = make_uint2(q.x, q.y); hi = make_uint2(q.z, q.w);
+        } else { lo = row[0]; hi = lo; }
+        const uint2 e0 = x0 == xb ? lo : hi, e1 = x1 == xb ? lo : hi;
+        *t0 = vec4(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
+        *t1 = vec4(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
+    };
+    vec4 t00, t10, t01, t11;
+    rowPair(y0, &t00, &t10);
+    rowPair(y1, &t01, &t11);
+    const vec4 top = t00 + (t10 - t00) * a, bot = t01 + (t11 - t01) * a;
+    return top + (bot - top) * b;
+}
 
 struct ShadeParams {
     ImgView color, depth, normal, albedo, specular, brdfLut, shadowMaps[4], ysh, cocg, volumetricLut, skyLut;
@@ -88,7 +122,7 @@ struct ShadeParams {
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
     x = clampi(x, normalTexture.w);
     y = clampi(y, normalTexture.h);
-    const vec3 raw = Texel<F_RGBA8>::load(normalTexture.ptr, (size_t)y * (size_t)normalTexture.w + x).xyz() * 2.f - 1.f;
+    const vec3 raw = fastm::unorm8x4(((const uint32_t*)normalTexture.ptr)[fastm::texelIndex((uint32_t)x, (uint32_t)y, (uint32_t)normalTexture.w)]).xyz() * 2.f - 1.f;
     const vec3 N = nrm(raw);
     return anyNan(N) ? raw : N;
 }
@@ -101,7 +135,7 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
     vec4 p = mulMat4(lightMatrix, vec4(pos, 1.f));
     const float iw = rcpf(p.w);
     const float bx = p.x * iw * 0.5f + 0.5f, by = p.y * iw * 0.5f + 0.5f;
-    const float actualDepth = gclamp(p.z * iw, 0.f, 1.f);
+    const float actualDepth = fclamp(p.z * iw, 0.f, 1.f);
     const float sx = 0.03f * lightSpaceScale.x, sy = 0.03f * lightSpaceScale.y;
     const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
     const float fw = (float)shadowMap.w, fh = (float)shadowMap.h;
@@ -109,12 +143,15 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
     float shadow = 0.f;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        const float d = sqrtf(((float)i + 0.5f * noise) * (1.f / 12.f));
+        const float d = sqrth(((float)i + 0.5f * noise) * (1.f / 12.f));
         const float ca = c0 * kTapCos[i] - s0 * kTapSin[i], sa = s0 * kTapCos[i] + c0 * kTapSin[i];
         const float u = bx + ca * (sx * d), v = by + sa * (sy * d);
-        const int x = (int)floorf(u * fw), y = (int)floorf(v * fh);
-        float depthTexel = 0.f; // nearest, black border
-        if (x >= 0 && y >= 0 && x < shadowMap.w && y < shadowMap.h) depthTexel = (float)sm[(size_t)y * (size_t)shadowMap.w + x] * (1.f / 65535.f);
+        // nearest tap with a black border: fetch the clamped texel unconditionally, select 0 outside (no branch per tap)
+        const float tu = u * fw, tv = v * fh;
+        const bool inside = tu >= 0.f && tv >= 0.f && tu < fw && tv < fh;
+        const uint32_t x = (uint32_t)(int)__builtin_amdgcn_fmed3f(tu, 0.f, fw - 1.f), y = (uint32_t)(int)__builtin_amdgcn_fmed3f(tv, 0.f, fh - 1.f);
+        const float texel = (float)sm[fastm::texelIndex(x, y, (uint32_t)shadowMap.w)] * (1.f / 65535.f);
+        const float depthTexel = inside ? texel : 0.f;
         shadow += (actualDepth >= depthTexel) ? 1.f : 0.f;
     }
     return shadow * (1.f / 12.f);
@@ -126,7 +163,7 @@ PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, floa
     const vec3 fresnelAverage = f0 + (1.f - f0) * (1.f / 21.f);
     if (MULTISCATTER == 0) {
         const float energyAverage = ReflectedEnergyAverage(r);
-        const float energyIncoming = sampleLinear2D<F_RGBA16F, CLAMP>(brdfLutTex, vec2(r, NoL)).y;
+        const float energyIncoming = bilinearLut(brdfLutTex, r, NoL).y;
         const float unscaled = (1.f - energyIncoming) * (1.f - energyOutgoing) * rcpf(3.1415f * (1.f - energyAverage));
         const vec3 den = 1.f - fresnelAverage * (1.f - energyAverage);
         const vec3 scaling = (fresnelAverage * fresnelAverage * energyAverage) * vec3(rcpf(den.x), rcpf(den.y), rcpf(den.z));
@@ -150,7 +187,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const float su = fx * rcpf((float)g->screenResolution[0]), sv = fy * rcpf((float)g->screenResolution[1]);
     const size_t idx = (size_t)py * (size_t)P.color.w + px;
-    const float depth = texelFetch2D<F_D32>(P.depth, px, py).x;
+    const float depth = ((const float*)P.depth.ptr)[idx];
     const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
     const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
     const vec3 ray = camFwd + (-g->cameraTanFovHalf * ndy) * ld3(g->cameraUp) + (g->cameraTanFovHalf * g->cameraAspectRatio * ndx) * ld3(g->cameraRight);
@@ -162,11 +199,12 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const vec3 toPixel = ray * depthLinear; // passPos - camPos
     const vec3 passPos = camPos + toPixel;
 
-    const vec3 albedoTexel = texelFetch2D<F_RGBA8>(P.albedo, px, py).xyz();
-    const vec3 specularTexel = texelFetch2D<F_RGBA8>(P.specular, px, py).xyz();
+    // the launcher guarantees that the G-buffer images have the colour target's size: one texel index serves all of them
+    const vec3 albedoTexel = fastm::unorm8x4(((const uint32_t*)P.albedo.ptr)[idx]).xyz();
+    const vec3 specularTexel = fastm::unorm8x4(((const uint32_t*)P.specular.ptr)[idx]).xyz();
     const float metalic = specularTexel.z;
     float r = specularTexel.y;
-    r = gmax(r * r, 0.0045f);
+    r = fmax1(r * r, 0.0045f);
     const vec3 albedo(sRGBToLinear1(albedoTexel.x), sRGBToLinear1(albedoTexel.y), sRGBToLinear1(albedoTexel.z));
     const vec3 diffuseColor = (1.f - metalic) * albedo;
     const vec3 N = gbufferNormal(P.normal, px, py);
@@ -180,32 +218,33 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const vec3 Nm = (py & 1) ? gbufferNormal(P.normal, px, yl) : gbufferNormal(P.normal, px, yl + 1);
         const vec3 N_U = Nn - N, N_V = Nm - N; // sign is irrelevant: only squared lengths are used
         const float variance = 0.25f * (dot(N_V, N_V) + dot(N_U, N_U));
-        const float kernelRoughness2 = gmin(2.f * variance, 0.18f);
-        r = gclamp(sqrtf(r * r + kernelRoughness2), 0.f, 1.f);
+        const float kernelRoughness2 = fmin1(2.f * variance, 0.18f);
+        r = fclamp(sqrth(r * r + kernelRoughness2), 0.f, 1.f);
     }
-    const float NoH = gmax(dot(N, H), 0.f);
+    const float NoH = fmax1(dot(N, H), 0.f);
     const float NdotL = dot(N, L);
-    const float NoL = gclamp(NdotL, 0.f, 1.f);
+    const float NoL = fclamp(NdotL, 0.f, 1.f);
     const float VoH = fabsf(dot(V, H));
-    const float LoV = gmax(dot(L, V), 0.f);
-    const float NoV = gmax(fabsf(dot(N, V)), 0.0001f);
+    const float LoV = fmax1(dot(L, V), 0.f);
+    const float NoV = fmax1(fabsf(dot(N, V)), 0.0001f);
     const vec3 f0 = vmix(vec3(0.04f), albedo, metalic);
 
     const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
     const ImgView noiseTex = P.bindless[min(noiseSlot, P.bindlessCount - 1u)];
-    const vec4 noiseTexel = Texel<F_RG8>::load(noiseTex.ptr, (size_t)repeati(py, noiseTex.h) * (size_t)noiseTex.w + (size_t)repeati(px, noiseTex.w));
+    const vec2 noiseTexel = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
 
     int cascadeIndex = 0;
     for (int cascade = 0; cascade < (int)P.cascadeCount - 1; cascade++) cascadeIndex += (pixelDepth >= P.shadowInfo->splits[cascade]) ? 1 : 0;
     cascadeIndex = min(cascadeIndex, 3);
     const vec2 lss(P.shadowInfo->lightSpaceScale[cascadeIndex][0], P.shadowInfo->lightSpaceScale[cascadeIndex][1]);
-    float sunShadow;
-    if (cascadeIndex == 0) sunShadow = calcShadow(passPos, P.shadowMaps[0], P.shadowInfo->lightMatrices[0], lss, noiseTexel.x);
-    else if (cascadeIndex == 1) sunShadow = calcShadow(passPos, P.shadowMaps[1], P.shadowInfo->lightMatrices[1], lss, noiseTexel.x);
-    else if (cascadeIndex == 2) sunShadow = calcShadow(passPos, P.shadowMaps[2], P.shadowInfo->lightMatrices[2], lss, noiseTexel.x);
-    else sunShadow = calcShadow(passPos, P.shadowMaps[3], P.shadowInfo->lightMatrices[3], lss, noiseTexel.x);
-    const vec3 directLighting = (gmax(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
-    const vec3 brdfLut = sampleLinear2D<F_RGBA16F, CLAMP>(P.brdfLut, vec2(r, NoV)).xyz();
+    // one instance of the PCF loop: the cascade only selects which image view and matrix it reads
+    ImgView shadowMap = P.shadowMaps[0];
+    if (cascadeIndex == 1) shadowMap = P.shadowMaps[1];
+    else if (cascadeIndex == 2) shadowMap = P.shadowMaps[2];
+    else if (cascadeIndex == 3) shadowMap = P.shadowMaps[3];
+    const float sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[cascadeIndex], lss, noiseTexel.x);
+    const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
+    const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
 
     vec3 diffuseDirect;
     vec3 diffuseBRDFIntegral(brdfLut.z);
@@ -237,13 +276,13 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const vec3 irradiance = YCoCgToLinear(vec3(irradiance_Y, cc.x, cc.y));
         const vec3 diffuseIndirect = irradiance * diffuseColor * diffuseBRDFIntegral;
         const vec3 dominantDirection = dominantDirectionFromSH_L1(irradiance_Y_SH);
-        const float dominantDirectionLength = gclamp(sqrtf(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
-        const float r_indirect = gmix(1.f, r, sqrtf(dominantDirectionLength));
+        const float dominantDirectionLength = fclamp(sqrth(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
+        const float r_indirect = fmix(1.f, r, sqrth(dominantDirectionLength));
         const vec3 L_indirect = dominantDirection * rcpf(dominantDirectionLength);
         const vec3 H_indirect = nrm(L_indirect + V);
-        const float NoH_indirect = gmax(dot(N, H_indirect), 0.f);
-        const float NoL_indirect = gmax(dot(N, L_indirect), 0.f);
-        const float VoH_indirect = gmax(dot(V, H_indirect), 0.f);
+        const float NoH_indirect = fmax1(dot(N, H_indirect), 0.f);
+        const float NoL_indirect = fmax1(dot(N, L_indirect), 0.f);
+        const float VoH_indirect = fmax1(dot(V, H_indirect), 0.f);
         const vec3 single_i = GGXSingleScattering(r_indirect, f0, NoH_indirect, NoV, VoH_indirect, NoL_indirect);
         const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P.brdfLut, r_indirect, NoL_indirect, f0, single_i, brdfLut);
         const vec3 specularIndirect = (single_i + multi_i) * YCoCgToLinear(vec3(irradiance_Y_SH.x, cc.x, cc.y));
@@ -268,10 +307,20 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const size_t y0 = (size_t)clampi(j0, vol.h) * vol.w, y1 = (size_t)clampi(j0 + 1, vol.h) * vol.w;
         const size_t sl = (size_t)vol.w * vol.h;
         const size_t z0 = (size_t)clampi(k0, vol.d) * sl, z1 = (size_t)clampi(k0 + 1, vol.d) * sl;
-        auto T = [&](size_t i) { return Texel<F_RGBA16F>::load(vol.ptr, i); };
-        const vec4 lo = vmix(vmix(T(z0 + y0 + x0), T(z0 + y0 + x1), a), vmix(T(z0 + y1 + x0), T(z0 + y1 + x1), a), b);
-        const vec4 hi = vmix(vmix(T(z1 + y0 + x0), T(z1 + y0 + x1), a), vmix(T(z1 + y1 + x0), T(z1 + y1 + x1), a), b);
-        const vec4 it = vmix(lo, hi, c);
+        const int xb = max(min(x0, vol.w - 2), 0);
+        auto rowLerp = [&](size_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
+            const uint2* row = (const uint2*)vol.ptr + rowBase;
+            uint2 tl, th;
+            if (vol.w >= 2) { uint4 q; __builtin_memcpy(&q, row + xb, 16); tl = make_uint2(q.x, q.y); th = make_uint2(q.z, q.w); }
+            else { tl = row[0]; th = tl; }
+            const uint2 e0 = x0 == xb ? tl : th, e1 = x1 == xb ? tl : th;
+            const vec4 t0(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
+            const vec4 t1(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
+            return t0 + (t1 - t0) * a;
+        };
+        const vec4 l0 = rowLerp(z0 + y0), l1 = rowLerp(z0 + y1), h0 = rowLerp(z1 + y0), h1 = rowLerp(z1 + y1);
+        const vec4 lo = l0 + (l1 - l0) * b, hi = h0 + (h1 - h0) * b;
+        const vec4 it = lo + (hi - lo) * c;
         outColor = outColor * it.w + it.xyz();
     }
     ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(outColor);
@@ -309,6 +358,8 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     if (int rc = c.needSampled(24, F_R11G11B10, "deferredShading skyLut")) return rc;
     if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "deferredShading: global texture array (set 2) is empty");
     if (c.sampled[16].w != c.sampled[15].w || c.sampled[16].h != c.sampled[15].h) return c.fail(-4, "deferredShading: Y_SH and CoCg differ in size");
+    // this kernel addresses depth / albedo / specular with the colour target's texel index: other layouts take the general kernel
+    for (int b : {20, 22, 23}) if (c.sampled[b].w != c.storage[0].w || c.sampled[b].h != c.storage[0].h) return kUseGeneralKernel;
     const int diffuseBRDF = c.specInt(0, 0), multi = c.specInt(1, 0), tech = c.specInt(3, 0);
     const bool aa = c.specBool(2, false);
     const uint32_t cascades = c.specUint(4, 4u);
