@@ -128,8 +128,52 @@ static int launch(const PassCtx& c) {
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ bloomDownsample.comp:12-49
+// When the source is exactly twice the target in both dimensions, every one of the 13 bilinear taps lands on a texel centre or
+// half way between two / four texels, so the filter is a fixed 4x4 stencil over source texels (2x-1 .. 2x+2) x (2y-1 .. 2y+2):
+//   the four centre texels weigh 0.125 (the +-0.5 taps) + 0.03125 (a quarter of the centre tap) = 0.15625, the other twelve 0.03125.
+// Four 16-byte row loads replace up to 36 texel fetches. (The exact kernel's sub-texel weights are quantised to 1/256 from a
+// float coordinate; where that rounding lands one step off the ideal 0.5 the two kernels differ by 1/256 of a texel difference.)
+__global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= coverW || y >= coverH) return;
+    const uint32_t* src = (const uint32_t*)source.ptr;
+    const int sx = 2 * x - 1;
+    const bool interior = sx >= 0 && sx + 3 < source.w;
+    vec3 centre(0.f), border(0.f);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t* row = src + (size_t)clampi(2 * y - 1 + r, source.h) * (size_t)source.w;
+        uint32_t t[4];
+        if (interior) { uint4 v; __builtin_memcpy(&v, row + sx, 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; }
+        else { for (int c = 0; c < 4; c++) t[c] = row[clampi(sx + c, source.w)]; }
+        const vec3 c0 = unpackR11G11B10(t[0]), c1 = unpackR11G11B10(t[1]), c2 = unpackR11G11B10(t[2]), c3 = unpackR11G11B10(t[3]);
+        if (r == 1 || r == 2) { centre = centre + (c1 + c2); border = border + (c0 + c3); }
+        else border = border + ((c0 + c1) + (c2 + c3));
+    }
+    ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(centre * 0.15625f + border * 0.03125f);
+}
+
+static int launchDown(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R11G11B10, "bloomDownsample target")) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
+    const ImgView& target = c.storage[0];
+    const ImgView& source = c.sampled[1];
+    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 4) return kUseGeneralKernel; // odd sizes: taps are not on texel centres
+    const PassCtx::RowSpan rs = c.rowSpan(target.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    bloomDownsampleFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
 } // namespace fastbloom
 
 static int fastbloom_up_launch(const PassCtx& c) { return fastbloom::launch(c); }
 PLR_REGISTER_SHADER_FAST("bloomUpsample.comp", fastbloom_up_launch);
+static int fastbloom_down_launch(const PassCtx& c) { return fastbloom::launchDown(c); }
+PLR_REGISTER_SHADER_FAST("bloomDownsample.comp", fastbloom_down_launch);
 } // namespace plr
