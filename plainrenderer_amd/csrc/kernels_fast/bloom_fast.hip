@@ -104,6 +104,101 @@ __global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, I
     }
 }
 
+// ---- 2x2 outputs per thread for the regular case (target = exactly twice the source and the previous mip; footprint within +-2)
+// An output pixel X = 2k + p samples the half-resolution images at k + 0.25 + 0.5 p (texel units), so the three tent taps and the
+// two box taps have the same sub-texel weights for every pixel of one parity: per axis the filter is a 5-entry (tent, texels
+// k-2 .. k+2) and a 3-entry (box, texels k-1 .. k+1) weight vector per parity, computed once on the host with the sampler's 8-bit
+// weight rule. A thread filters a 5x5 / 3x3 texel footprint horizontally for both x parities, then vertically for both y
+// parities: 34 texel decodes and 13 loads per four outputs (the LDS kernel above: ~7 decodes per output plus the per-pixel tap
+// set-up, ~400 VALU instructions per output; this one ~175).
+struct ParityWeights { float tent[2][5]; float box[2][3]; };
+
+__global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
+                                                               int yBase) {
+    // thread -> 2x2 output quad; a wave covers 128 x 2 outputs, a block 128 x 8
+    const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int X = 2 * k, Y = 2 * m;
+    if (X >= coverW || Y >= coverH) return;
+    const int sw = source.w, sh = source.h;
+    const uint32_t* src = (const uint32_t*)source.ptr;
+    const bool interiorX = k >= 2 && k + 2 < sw;
+    // horizontally filtered rows: hT[row][parity] for source rows m-2 .. m+2
+    vec3 acc[2][2] = {{vec3(0.f), vec3(0.f)}, {vec3(0.f), vec3(0.f)}}; // [y parity][x parity]
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t* row = src + (size_t)clampi(m - 2 + r, sh) * (size_t)sw;
+        uint32_t t[5];
+        if (interiorX) { uint4 v; __builtin_memcpy(&v, row + (k - 2), 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; t[4] = row[k + 2]; }
+        else { for (int c = 0; c < 5; c++) t[c] = row[clampi(k - 2 + c, sw)]; }
+        vec3 h0(0.f), h1(0.f);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const vec3 col = unpackR11G11B10(t[c]);
+            h0 = h0 + col * pw.tent[0][c];
+            h1 = h1 + col * pw.tent[1][c];
+        }
+        acc[0][0] = acc[0][0] + h0 * pw.tent[0][r]; acc[0][1] = acc[0][1] + h1 * pw.tent[0][r];
+        acc[1][0] = acc[1][0] + h0 * pw.tent[1][r]; acc[1][1] = acc[1][1] + h1 * pw.tent[1][r];
+    }
+    if (!lowest) {
+        const int pwid = previous.w, phei = previous.h;
+        const uint32_t* prv = (const uint32_t*)previous.ptr;
+        const bool interiorP = k >= 1 && k + 2 < pwid;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t* row = prv + (size_t)clampi(m - 1 + r, phei) * (size_t)pwid;
+            uint32_t t[3];
+            if (interiorP) { uint4 v; __builtin_memcpy(&v, row + (k - 1), 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; }
+            else { for (int c = 0; c < 3; c++) t[c] = row[clampi(k - 1 + c, pwid)]; }
+            vec3 h0(0.f), h1(0.f);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const vec3 col = unpackR11G11B10(t[c]);
+                h0 = h0 + col * pw.box[0][c];
+                h1 = h1 + col * pw.box[1][c];
+            }
+            acc[0][0] = acc[0][0] + h0 * pw.box[0][r]; acc[0][1] = acc[0][1] + h1 * pw.box[0][r];
+            acc[1][0] = acc[1][0] + h0 * pw.box[1][r]; acc[1][1] = acc[1][1] + h1 * pw.box[1][r];
+        }
+    }
+    uint32_t* out = (uint32_t*)target.ptr;
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        if (Y + py >= coverH || Y + py < yBase) continue;
+        uint32_t* orow = out + (size_t)(Y + py) * (size_t)target.w + X;
+        const uint32_t p0 = packR11G11B10(acc[py][0]), p1 = packR11G11B10(acc[py][1]);
+        if (X + 1 < coverW) *(uint2*)orow = make_uint2(p0, p1); // X is even and the row pitch is even: 8-byte aligned
+        else orow[0] = p0;
+    }
+}
+
+// the 1D footprint of one tap (sampler rule of image.h:linearCoord) accumulated into weights over texels base .. base + n - 1
+static bool accumulateTap(float position, float weight, int base, int n, float* w) {
+    const float sane = std::min(std::max(position, -1.0e6f), 1.0e6f);
+    const int ti = (int)std::floor((sane - 0.5f) * 256.0f + 0.5f);
+    const int i0 = ti >> 8;
+    const float a = (float)(ti & 255) * (1.0f / 256.0f);
+    const int j0 = i0 - base, j1 = i0 + 1 - base;
+    if ((1.f - a) != 0.f) { if (j0 < 0 || j0 >= n) return false; w[j0] += weight * (1.f - a); }
+    if (a != 0.f) { if (j1 < 0 || j1 >= n) return false; w[j1] += weight * a; }
+    return true;
+}
+
+static bool makeParityWeights(float blurRadius, ParityWeights* pw) {
+    const int k = 8; // any interior texel: the weights do not depend on it
+    for (int p = 0; p < 2; p++) {
+        const float s = (float)k + 0.25f + 0.5f * (float)p;
+        for (float& v : pw->tent[p]) v = 0.f;
+        for (float& v : pw->box[p]) v = 0.f;
+        bool ok = accumulateTap(s, 0.5f, k - 2, 5, pw->tent[p]) && accumulateTap(s + blurRadius, 0.25f, k - 2, 5, pw->tent[p]) &&
+                  accumulateTap(s - blurRadius, 0.25f, k - 2, 5, pw->tent[p]) && accumulateTap(s + 0.5f, 0.5f, k - 1, 3, pw->box[p]) &&
+                  accumulateTap(s - 0.5f, 0.5f, k - 1, 3, pw->box[p]);
+        if (!ok) return false;
+    }
+    return true;
+}
+
 static int launch(const PassCtx& c) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomUpsample target")) return rc;
     if (int rc = c.needSampled(2, F_R11G11B10, "bloomUpsample source")) return rc;
@@ -121,6 +216,18 @@ static int launch(const PassCtx& c) {
     // blur radius of at most 3 source texels; anything else takes the general (exact-order) kernel
     const bool fits = blurRadius >= 0.f && blurRadius <= 3.f && source.h * 2 + 1 >= target.h && (lowest || c.sampled[1].h * 2 + 1 >= target.h);
     if (!fits) return kUseGeneralKernel;
+    {
+        // regular case: one thread per 2x2 outputs with per-parity weight vectors (needs even row base so quads do not straddle the dispatch)
+        ParityWeights pw;
+        const bool regular = target.w == 2 * source.w && target.h == 2 * source.h && (lowest || (c.sampled[1].w == source.w && c.sampled[1].h == source.h)) &&
+                             source.w >= 5 && (yBase & 1) == 0 && (target.w & 1) == 0 && makeParityWeights(blurRadius, &pw);
+        if (regular) {
+            const dim3 qgrid(divUp((unsigned)divUp((unsigned)w, 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u));
+            bloomUpsampleQuadKernel<<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase);
+            PLR_CHECK_LAUNCH(c);
+            return 0;
+        }
+    }
     const dim3 grid(divUp((unsigned)w, (unsigned)TW), divUp((unsigned)(h - yBase), (unsigned)TH));
     if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h, yBase);
     else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h, yBase);
