@@ -65,26 +65,29 @@ def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_d
 INPUT_HALO = 256  # full-res rows of G-buffer a band needs beyond its own: 2 * (giHalo + giHistoryHalo) + 16 = 176 for the half-res depth
 
 
-PASS_KERNEL = {  # pass label -> kernel name prefix in the rocprofv3 summaries under profiles/
-    "Indirect diffuse spatial filter": "plr::spatialFilter", "Forward shading (deferred)": "plr::fastshade::deferredShading",
-    "Temporal filtering": "plr::fasttaa::temporalFilter", "Indirect diffuse SDF trace": "plr::fasttrace::sdfDiffuseTrace",
-    "Indirect lighting upscale": "plr::indirectLightUpscale", "Indirect diffuse temporal filter": "plr::temporalGiFilter",
-    "Depth min/max pyramid": "plr::hizBase", "Tonemap": "plr::tonemapping", "Apply bloom": "plr::applyBloom", "Histogram per tile": "plr::histogramPerTile",
+PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries under profiles/ (a pass may launch more than one kernel)
+    "Indirect diffuse spatial filter": ["plr::spatialFilter", "plr::spatialPack"], "Forward shading (deferred)": ["plr::fastshade::deferredShading"],
+    "Temporal filtering": ["plr::fasttaa::temporalFilter"], "Indirect diffuse SDF trace": ["plr::fasttrace::sdfDiffuseTrace"],
+    "Indirect lighting upscale": ["plr::faststream::indirectLightUpscale"], "Indirect diffuse temporal filter": ["plr::faststream::temporalGiFilter"],
+    "Depth min/max pyramid": ["plr::hizBase", "plr::hizTail"], "Tonemap": ["plr::faststream::tonemapping"], "Apply bloom": ["plr::faststream::applyBloom"],
+    "Histogram per tile": ["plr::histogramPerTile"],
 }
 
 
 def pmc_traffic(pass_name):
-    """HBM-side bytes per launch of the pass's kernel from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
+    """HBM-side bytes per launch of the pass (all its kernels) from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
     FETCH_SIZE / WRITE_SIZE passes of this same command at the default workload, gfx950 x2 fetch correction applied)."""
     import glob
-    prefix = PASS_KERNEL.get(pass_name)
+    prefixes = PASS_KERNEL.get(pass_name)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
-    if not prefix or not files:
+    if not prefixes or not files:
         return None, None
+    total, found = 0, False
     for line in open(files[-1]):
-        if line.startswith(prefix):
-            return int(line.strip().split(",")[-1]), os.path.basename(files[-1])
-    return None, None
+        if any(line.startswith(p) for p in prefixes):
+            total += int(line.strip().split(",")[-1])
+            found = True
+    return (total, os.path.basename(files[-1])) if found else (None, None)
 
 
 def build_scene(args, device, w, h, band=None):
