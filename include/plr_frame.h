@@ -67,6 +67,8 @@ int plrf_get_storage_buffer(void* pipeline, const char* name, plr_storage_buffer
 int plrf_get_uniform_buffer(void* pipeline, const char* name, plr_uniform_buffer_handle* out);
 /* registers one R16F res^3 SDF volume, returns its global texture array index (SDFInstance.sdfTextureIndex) */
 int plrf_add_sdf_volume(void* pipeline, uint32_t res, const void* half_data, size_t bytes, uint32_t* out_texture_index);
+/* the same from a DDS file written by the asset pipeline (plr_write_dds_file / the reference's writeDDSFile): any width x height x depth */
+int plrf_add_sdf_volume_dds(void* pipeline, const char* path, uint32_t* out_texture_index, uint32_t out_size[3]);
 /* {uint count; uint pad[3]; SDFInstance[count]} and {vec3 min; float; vec3 max; float}[count] (SDFGI::updateSDFScene) */
 int plrf_set_sdf_scene(void* pipeline, const void* instance_buffer, size_t instance_bytes, const void* world_bbs, size_t bb_bytes);
 int plrf_set_sun_direction(void* pipeline, const float direction[3]);

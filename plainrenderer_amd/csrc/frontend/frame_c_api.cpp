@@ -79,6 +79,13 @@ int plrf_get_uniform_buffer(void* p, const char* name, plr_uniform_buffer_handle
     return PLR_OK;
 }
 int plrf_add_sdf_volume(void* p, uint32_t res, const void* data, size_t bytes, uint32_t* out) { PLRF_TRY(*out = ((FramePipeline*)p)->addSdfVolume(res, data, bytes)) }
+int plrf_add_sdf_volume_dds(void* p, const char* path, uint32_t* out, uint32_t outSize[3]) {
+    PLRF_TRY({
+        ImageDescription d;
+        *out = ((FramePipeline*)p)->addSdfVolumeFromDds(path, &d);
+        if (outSize) { outSize[0] = d.width; outSize[1] = d.height; outSize[2] = d.depth; }
+    })
+}
 int plrf_set_sdf_scene(void* p, const void* inst, size_t ib, const void* bb, size_t bbb) { PLRF_TRY(((FramePipeline*)p)->setSdfScene(inst, ib, bb, bbb)) }
 int plrf_set_sun_direction(void* p, const float d[3]) { PLRF_TRY(((FramePipeline*)p)->setSunDirection(d)) }
 int plrf_set_camera_intrinsic(void* p, float fov, float n, float f) { PLRF_TRY(((FramePipeline*)p)->setCameraIntrinsic(fov, n, f)) }

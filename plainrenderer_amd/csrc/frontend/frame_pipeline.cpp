@@ -1,6 +1,8 @@
 // See frame_pipeline.h. Pass order, bindings, specialisation constants and dispatch counts follow the cited reference code.
 #include "frame_pipeline.h"
 
+#include "../../../include/plr_image_io.h"
+
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -621,6 +623,24 @@ uint32_t FramePipeline::addSdfVolume(uint32_t res, const void* halfData, size_t 
     d.type = ImageType::Type3D; d.format = ImageFormat::R16_sFloat; d.usageFlags = ImageUsageFlags::Sampled;
     const ImageHandle h = m_be.createImage(d, halfData, bytes);
     m_sdfVolumes.push_back(h);
+    return m_be.getImageGlobalTextureArrayIndex(h);
+}
+
+uint32_t FramePipeline::addSdfVolumeFromDds(const std::string& path, ImageDescription* outDesc) {
+    plr_image_desc cd{};
+    size_t size = 0;
+    if (plr_load_dds_file(path.c_str(), &cd, nullptr, 0, &size) != PLR_OK) throw std::runtime_error(plr_last_error());
+    if (cd.format != PLR_FORMAT_R16_SFLOAT || cd.type != PLR_IMAGE_3D) throw std::runtime_error("SDF texture must be a 3D R16_sFloat DDS: " + path);
+    std::vector<uint8_t> data(size);
+    if (plr_load_dds_file(path.c_str(), &cd, data.data(), data.size(), &size) != PLR_OK) throw std::runtime_error(plr_last_error());
+    ImageDescription d;
+    d.width = cd.width; d.height = cd.height; d.depth = cd.depth;
+    d.type = ImageType::Type3D; d.format = ImageFormat::R16_sFloat; d.usageFlags = ImageUsageFlags::Sampled;
+    d.mipCount = cd.manual_mip_count > 1 ? MipCount::Manual : MipCount::One; d.manualMipCount = cd.manual_mip_count;
+    if ((size_t)d.width * d.height * d.depth * 2 > size) throw std::runtime_error("DDS file holds fewer texels than its header declares: " + path);
+    const ImageHandle h = m_be.createImage(d, data.data(), data.size());
+    m_sdfVolumes.push_back(h);
+    if (outDesc) *outDesc = d;
     return m_be.getImageGlobalTextureArrayIndex(h);
 }
 

@@ -197,6 +197,9 @@ public:
     bool storageBuffer(const std::string& name, StorageBufferHandle* out) const;
     bool uniformBuffer(const std::string& name, UniformBufferHandle* out) const;
     uint32_t addSdfVolume(uint32_t res, const void* halfData, size_t bytes);
+    // loads a baked SDF volume from a DDS file (what registerMeshes / loadImagesFromPaths do with MeshBinary::texturePaths.sdfTexturePath,
+    // RenderFrontend.cpp:456-521) and returns its global texture array index; outDesc (optional) receives the file's description
+    uint32_t addSdfVolumeFromDds(const std::string& path, ImageDescription* outDesc = nullptr);
     void setSdfScene(const void* instanceBufferData, size_t instanceBytes, const void* worldBBData, size_t bbBytes);
     void setSunDirection(const float dir[3]);
     void setCameraIntrinsic(float fovDegrees, float nearPlane, float farPlane);

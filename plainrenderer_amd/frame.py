@@ -83,6 +83,13 @@ class FramePipeline:
         self._check(self.lib.plrf_add_sdf_volume(self.handle, C.c_uint32(res), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), C.byref(out)))
         return out.value
 
+    def add_sdf_volume_dds(self, path):
+        """-> (global texture array index, (width, height, depth)) of a baked SDF volume stored as DDS"""
+        out = C.c_uint32()
+        size = (C.c_uint32 * 3)()
+        self._check(self.lib.plrf_add_sdf_volume_dds(self.handle, str(path).encode(), C.byref(out), size))
+        return out.value, tuple(int(v) for v in size)
+
     def set_sdf_scene(self, instance_bytes, bb_bytes):
         self._check(self.lib.plrf_set_sdf_scene(self.handle, instance_bytes, C.c_size_t(len(instance_bytes)), bb_bytes, C.c_size_t(len(bb_bytes))))
 
