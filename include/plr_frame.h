@@ -32,6 +32,8 @@ typedef struct plrf_settings {
      * instance renders full-resolution rows [band_row_begin, band_row_end) (multiples of 64, or the last row). band_row_end == 0:
      * off. Halos: rows exchanged / recomputed around the band, see BandSettings in csrc/frontend/frame_pipeline.h */
     uint32_t band_row_begin, band_row_end, band_gi_halo, band_gi_history_halo, band_color_halo, band_post_halo;
+    /* input producers recorded as compute passes instead of uploaded (0 = uploaded): lightMatrix.comp after the depth pyramid */
+    uint32_t run_light_matrix; float volumetrics_max_distance;
 } plrf_settings;
 
 /* ---- band rendering: halo exchange hooks ----

@@ -157,6 +157,11 @@ void orc_deferred_shading(const orc_image* color, const orc_image* depth, const 
                           int32_t diffuseBRDF, int32_t directMultiscatterBRDF, int32_t geometricAA,
                           int32_t indirectLightingTech, uint32_t sunShadowCascadeCount);
 
+/* ---- input producers ---- */
+/* lightMatrix.comp: fits the sun shadow cascades to the HiZ apex (min, max depth); updates splits, lightMatrices, lightSpaceScale in place */
+void orc_light_matrix(orc_shadow_cascade_info* info, const float* apexMinMax2, const orc_global* g, uint32_t sunShadowCascadeCount,
+                      float highestCascadeExtraPadding, float highestCascadeMinFarPlane);
+
 /* ---- config 1: CPU SDF bake (AssetPipeline/SceneSDF.cpp) ---- */
 /* positions: nVerts x 3 floats, indices: triangle list. Triangle normal = normalize(cross(v0 - v2, v0 - v1)) (SceneSDF.cpp:273).
  * outHalf: resX*resY*resZ half floats, x fastest. Returns 0, -1 (bad sizes) or -2 (index out of range). */

@@ -551,6 +551,13 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
                                                        spec(3, s.shading.indirectLightingTech), spec(4, s.shading.sunShadowCascadeCount)};
         m_deferredShadingPass = m_be.createComputePass(d);
     }
+    {
+        ComputePassDescription d; // RenderFrontend.cpp:1730-1740
+        d.name = "Compute light matrix";
+        d.shaderDescription.srcPathRelative = "lightMatrix.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, (uint32_t)s.shading.sunShadowCascadeCount)};
+        m_lightMatrixPass = m_be.createComputePass(d);
+    }
     m_taa.init(m_be, W, H, s.taa);
     m_bloom.init(m_be);
     m_sdfGi.init(m_be, W, H, s.sdfTrace, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
@@ -757,6 +764,22 @@ void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:
     m_be.setComputePassExecution(exe);
 }
 
+void FramePipeline::computeSunLightMatrices() { // RenderFrontend.cpp:840-872
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_lightMatrixPass;
+    exe.dispatchCount[0] = exe.dispatchCount[1] = exe.dispatchCount[2] = 1;
+    const uint32_t depthPyramidMipCount = mipCountFromResolution(settings.width / 2, settings.height / 2, 1);
+    exe.genericInfo.resources.storageImages = {ImageResource(m_minMaxDepthPyramid, depthPyramidMipCount - 1, 1)};
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sunShadowInfoBuffer, false, 0)};
+    struct LightMatrixPushConstants { float highestCascadePaddingSize; float highestCascadeMinFarPlane; } pc;
+    pc.highestCascadePaddingSize = settings.sdfTrace.traceInfluenceRadius;
+    pc.highestCascadeMinFarPlane = settings.volumetricsMaxDistance;
+    // if strict cutoff enabled all hits outside influence radius are discarded anyways
+    if (!settings.sdfTrace.strictInfluenceRadiusCutoff) pc.highestCascadePaddingSize += settings.sdfTrace.additionalSunShadowMapPadding;
+    exe.pushConstants = dataToCharArray(&pc, sizeof(pc));
+    m_be.setComputePassExecution(exe);
+}
+
 void FramePipeline::computeBRDFLut() { // RenderFrontend.cpp:1031-1042
     ComputePassExecution exe;
     exe.genericInfo.handle = m_brdfLutPass;
@@ -815,7 +838,8 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     }
     // [m_sky.updateSkyLut, renderDepthPrepass: inputs]
     if (settings.runHiZ) computeDepthPyramid(currentRenderTarget.depthBuffer);
-    // [computeSunLightMatrices, renderSunShadowCascades: inputs]
+    if (settings.runLightMatrix && settings.runHiZ && !band) computeSunLightMatrices();
+    // [renderSunShadowCascades: input]
     if (settings.runGI && settings.shading.indirectLightingTech == IndirectLightingTech::SDFTrace) {
         if (settings.sdfTrace.halfResTrace) downscaleDepth(currentRenderTarget);
         SDFTraceDependencies deps = m_frustumScratch; // frustum points/normals from setCameraExtrinsic (fillOutSdfGiDependencies, :1073-1090)

@@ -185,6 +185,9 @@ struct FramePipelineSettings {
     // which groups of prepareRenderpasses are recorded (all on = the full frame)
     bool runExposure = true, runHiZ = true, runGI = true, runShading = true, runTAA = true, runBloom = true, runTonemap = true;
     BandSettings band; // width/height stay the WHOLE frame's
+    // input producers recorded as compute passes instead of being uploaded by the caller
+    bool runLightMatrix = false; // lightMatrix.comp after the depth pyramid (RenderFrontend.cpp:353, 840-872); needs the pyramid apex: not in band mode
+    float volumetricsMaxDistance = 30.f; // VolumetricsSettings::maxDistance, the last cascade's minimum far plane
 };
 
 class FramePipeline {
@@ -223,6 +226,7 @@ private:
     void computeDeferredShading(ImageHandle colorTarget, const FrameRenderTargets& current);
     void computeTonemapping(ImageHandle src);
     void computeBRDFLut();
+    void computeSunLightMatrices();
     void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
     void updateGlobalShaderInfo(float deltaTime, float time);
     RowRange bandRows(uint32_t halo, uint32_t divisor = 1) const;
@@ -249,7 +253,7 @@ private:
     std::vector<ImageHandle> m_sdfVolumes;
     StorageBufferHandle m_histogramPerTileBuffer, m_histogramBuffer, m_lightBuffer, m_sunShadowInfoBuffer, m_depthPyramidSyncBuffer;
     RenderPassHandle m_histogramPerTilePass, m_histogramResetPass, m_histogramCombinePass, m_preExposeLightsPass, m_depthPyramidPass, m_depthDownscalePass,
-        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass;
+        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass;
     TAA m_taa;
     Bloom m_bloom;
     SDFGI m_sdfGi;

@@ -228,7 +228,9 @@ class SynthScene:
                 ww = hh * cam.aspect
                 pts += [c + cup * hh + cright * ww, c + cup * hh - cright * ww, c - cup * hh + cright * ww, c - cup * hh - cright * ww]
             pv = (V[:3, :3] @ np.array(pts).T).T
-            mn, mx = pv.min(0), pv.max(0)
+            # lightMatrix.comp:88-89 starts the maximum at FLOAT_MIN (the smallest positive float), not at -FLOAT_MAX: a cascade that lies
+            # entirely on the negative side of a light-space axis is fitted as if it reached 0
+            mn, mx = pv.min(0), np.maximum(pv.max(0), 1.175494351e-38)
             if i == cascade_count - 1:
                 mn, mx = mn - extra_padding, mx + extra_padding
             mn, mx = mn - sample_radius * 2, mx + sample_radius * 2

@@ -627,3 +627,28 @@ def orc_deferred_shading(gb, w, h, brdf_lut_u16, lut_res, light_bytes, shadow_in
                            sky.ref(), bindless_arr, C.c_int32(n_bindless), C.byref(g), C.c_int32(diffuse_brdf), C.c_int32(multiscatter), C.c_int32(int(geometric_aa)),
                            C.c_int32(indirect_tech), C.c_uint32(cascades))
     return color.arr.view(np.uint32).copy()
+
+
+# ------------------------------------------------------------------ input producers
+def gpu_light_matrix(be, info_bytes, apex_min_max, global_packed, cascade_count, padding, min_far):
+    """lightMatrix.comp: binding 0 = sunShadowInfo (std430, 304 B), storage image 1 = lowest HiZ mip (1x1 RG32F); push = 2 floats"""
+    info = be.createStorageBuffer(304, info_bytes)
+    apex = be.createImage(image_desc_2d(1, 1, F.RG32_sFloat), np.asarray(apex_min_max, np.float32))
+    p = be.createComputePass("lightMatrix.comp", [spec_uint(0, cascade_count)], "Compute light matrix")
+    gb = global_binding(be)
+    gb.set(global_packed)
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(storageBuffers=[StorageBufferResource(info, False, 0)],
+                                                                           storageImages=[ImageResource(apex, 0, 1)]), struct.pack("<2f", padding, min_far), (1, 1, 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return be.downloadStorageBuffer(info, 304).tobytes()
+
+
+def orc_light_matrix(info_bytes, apex_min_max, global_packed, cascade_count, padding, min_far):
+    L = orc.lib()
+    info = (C.c_uint8 * 304).from_buffer_copy(info_bytes)
+    apex = np.asarray(apex_min_max, np.float32)
+    g = orc.global_from_bytes(global_packed)
+    L.orc_light_matrix(C.byref(info), _p(apex), C.byref(g), C.c_uint32(cascade_count), C.c_float(padding), C.c_float(min_far))
+    return bytes(info)

