@@ -162,6 +162,12 @@ void orc_deferred_shading(const orc_image* color, const orc_image* depth, const 
 void orc_light_matrix(orc_shadow_cascade_info* info, const float* apexMinMax2, const orc_global* g, uint32_t sunShadowCascadeCount,
                       float highestCascadeExtraPadding, float highestCascadeMinFarPlane);
 
+/* sky LUTs (skyTransmissionLut.comp, skyMultiscatterLut.comp, skyLut.comp); atmosphereSettings = the 56-byte std140 AtmosphereSettings block */
+void orc_sky_transmission_lut(const orc_image* lut, const void* atmosphereSettings56);
+void orc_sky_multiscatter_lut(const orc_image* lut, const orc_image* transmissionLut, const void* atmosphereSettings56);
+void orc_sky_lut(const orc_image* lut, const orc_image* transmissionLut, const orc_image* multiscatterLut, const void* atmosphereSettings56,
+                 const orc_light_buffer* light, const orc_global* g);
+
 /* ---- config 1: CPU SDF bake (AssetPipeline/SceneSDF.cpp) ---- */
 /* positions: nVerts x 3 floats, indices: triangle list. Triangle normal = normalize(cross(v0 - v2, v0 - v1)) (SceneSDF.cpp:273).
  * outHalf: resX*resY*resZ half floats, x fastest. Returns 0, -1 (bad sizes) or -2 (index out of range). */

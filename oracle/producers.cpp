@@ -88,3 +88,228 @@ extern "C" void orc_light_matrix(orc_shadow_cascade_info* info, const float* ape
         info->lightSpaceScale[i][1] = scale.y;
     }
 }
+
+// ====================================================================================================================
+// Sky LUTs: resources/shaders/sky.inc, volumeShading.inc, skyTransmissionLut.comp, skyMultiscatterLut.comp, skyLut.comp.
+// exp / pow / sin / cos are the detmath contract functions; max / min / clamp resolve NaN like v_max / v_min (detmath.h).
+namespace {
+
+struct Atmosphere { // sky.inc:1-10, std140 (vec3 + float packs into 16 bytes): 56 bytes
+    float scatteringRayleighGround[3], earthRadius;
+    float extinctionRayleighGround[3], atmosphereHeight;
+    float ozoneExtinction[3], scatteringMieGround;
+    float extinctionMieGround, mieScatteringExponent;
+};
+
+struct Coefficients { vec3 scatterRayleigh, scatterMie, extinction; };
+
+Coefficients calculateCoefficients(float height, const Atmosphere& a) { // sky.inc:30-45
+    const float rayleighFactor = det_expf(-height * (1.f / 8));
+    const float mieFactor = det_expf(-height * (1.f / 1.2f));
+    const float ozoneFactor = gmax(0.f, 1.f - std::fabs(height - 25.f) / 15.f);
+    Coefficients c;
+    c.scatterRayleigh = rayleighFactor * vec3(a.scatteringRayleighGround[0], a.scatteringRayleighGround[1], a.scatteringRayleighGround[2]);
+    c.scatterMie = vec3(mieFactor) * a.scatteringMieGround;
+    c.extinction = rayleighFactor * vec3(a.extinctionRayleighGround[0], a.extinctionRayleighGround[1], a.extinctionRayleighGround[2]) + vec3(mieFactor * a.extinctionMieGround) +
+                   ozoneFactor * vec3(a.ozoneExtinction[0], a.ozoneExtinction[1], a.ozoneExtinction[2]);
+    return c;
+}
+
+struct Intersection { vec3 pos; float distance; bool hitEarth; };
+
+Intersection rayEarthIntersection(vec3 P, vec3 D, vec3 C, float earthRadius, float atmosphere) { // sky.inc:63-84
+    const vec3 L = C - P;
+    const float t_ca = dot(L, D);
+    const float d = std::sqrt(dot(L, L) - t_ca * t_ca);
+    const float t_hc_earth = std::sqrt(earthRadius * earthRadius - d * d);
+    const float t_earth = t_ca - t_hc_earth;
+    const float r = earthRadius + atmosphere;
+    const float t_hc_atmosphere = std::sqrt(r * r - d * d);
+    const float t_atmosphere = t_ca + std::fabs(t_hc_atmosphere);
+    Intersection result;
+    result.hitEarth = t_earth >= 0.f; // false when the ray misses the earth (sqrt of a negative number is NaN)
+    const float t = result.hitEarth ? t_earth : t_atmosphere;
+    result.distance = t;
+    result.pos = P + t * D;
+    return result;
+}
+
+vec3 expv(vec3 v) { return vec3(det_expf(v.x), det_expf(v.y), det_expf(v.z)); }
+
+vec3 integrateInscattering(vec3 inscattering, vec3 ext, float length) { // volumeShading.inc:27-29
+    const vec3 e = expv(-ext * length);
+    const vec3 num = inscattering - inscattering * e;
+    return vec3(num.x / gmax(ext.x, 0.00001f), num.y / gmax(ext.y, 0.00001f), num.z / gmax(ext.z, 0.00001f));
+}
+
+vec2 computeLutUV(float height, float atmosphereHeight, vec3 up, vec3 direction) { return vec2(height / atmosphereHeight, dot(up, direction) * 0.5f + 0.5f); } // sky.inc:105-110
+
+const float kPi = 3.1415926535f; // global.inc:44
+
+} // namespace
+
+// skyTransmissionLut.comp:17-47
+extern "C" void orc_sky_transmission_lut(const orc_image* lutP, const void* atmosphereSettings56) {
+    const Image& lut = img(lutP);
+    Atmosphere a;
+    std::memcpy(&a, atmosphereSettings56, sizeof(a));
+    parallelFor(lut.h, [&](int r0, int r1) {
+        for (int uy = r0; uy < r1; uy++)
+            for (int ux = 0; ux < lut.w; ux++) {
+                const float x = (float)ux / (float)(lut.w - 1), y = (float)uy / (float)(lut.h - 1);
+                const float height = 0.f * (1.f - x) + a.atmosphereHeight * x; // mix(0, H, x)
+                float upDot = y * 2.f - 1.f;
+                upDot = gmax(upDot, -0.999f);
+                const vec3 V(0.f, -upDot, std::sqrt(1.f - (upDot * upDot)));
+                const vec3 P(0.f, -height - a.earthRadius, 0.f);
+                const vec3 earthCenter(0.f);
+                const Intersection is = rayEarthIntersection(P - 0.01f, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+                const float pathLength = gmax(distance(is.pos, P), 0.01f);
+                const int sampleCount = 40;
+                const float stepLength = pathLength / (float)sampleCount;
+                vec3 currentPos = is.pos;
+                vec3 absorption(1.f);
+                const vec3 step = V * stepLength;
+                for (int i = 0; i < sampleCount; i++) {
+                    currentPos = currentPos - step;
+                    const float currentHeight = gmax(distance(earthCenter, currentPos) - a.earthRadius, 0.f);
+                    const Coefficients c = calculateCoefficients(currentHeight, a);
+                    absorption = absorption * expv(-c.extinction * stepLength);
+                }
+                absorption = is.hitEarth ? vec3(0.f) : absorption;
+                imageStore(lut, ivec2(ux, uy), vec4(absorption, 0.f));
+            }
+    });
+}
+
+// skyMultiscatterLut.comp:19-123
+extern "C" void orc_sky_multiscatter_lut(const orc_image* lutP, const orc_image* transmissionP, const void* atmosphereSettings56) {
+    const Image& lut = img(lutP);
+    const Image& transmissionLut = img(transmissionP);
+    Atmosphere a;
+    std::memcpy(&a, atmosphereSettings56, sizeof(a));
+    parallelFor(lut.h, [&](int r0, int r1) {
+        for (int uy = r0; uy < r1; uy++)
+            for (int ux = 0; ux < lut.w; ux++) {
+                const float x = (float)ux / (float)lut.w, y = (float)uy / (float)lut.h;
+                const float height = 0.f * (1.f - x) + a.atmosphereHeight * x;
+                const vec3 P(0.f, -height - a.earthRadius, 0.f);
+                const vec3 earthCenter(0.f);
+                const float upDot = y * 2.f - 1.f;
+                const vec3 L(0.f, -upDot, std::sqrt(1.f - (upDot * upDot)));
+                vec3 L_2nd(0.f), f_ms(0.f);
+                const float isotropicPhase = 1.f / (4.f * kPi);
+                const int sampleCountSqrt = 8;
+                const float sampleCountSqrtRcp = 1.f / (float)sampleCountSqrt;
+                for (int i = 0; i < sampleCountSqrt; i++)
+                    for (int j = 0; j < sampleCountSqrt; j++) {
+                        const float theta = kPi * (float)i * sampleCountSqrtRcp; // phi is computed by the shader but never used (:42)
+                        const float sinTheta = det_sinf(theta), cosTheta = det_cosf(theta);
+                        vec3 V(sinTheta * cosTheta, -cosTheta, sinTheta * sinTheta); // sic (:46)
+                        const int innerSampleCount = 20;
+                        vec3 inscattered(0.f);
+                        const Intersection is = rayEarthIntersection(P, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+                        vec3 currentPosition = P;
+                        const float stepSize = is.distance / (float)innerSampleCount;
+                        V = V * stepSize;
+                        vec3 L_f(0.f);
+                        const vec3 earthAlbedo(0.3f);
+                        const vec3 earthHitNormal = normalize(is.pos - earthCenter);
+                        const float earthNoL = gclamp(dot(earthHitNormal, L), 0.f, 1.f);
+                        const vec3 up0 = normalize(currentPosition - earthCenter);
+                        const vec2 lutUV0 = computeLutUV(0.f, a.atmosphereHeight, up0, L);
+                        const vec3 incomingLight = texture2D(transmissionLut, LINEAR, CLAMP, lutUV0).xyz();
+                        const vec3 earthLit = earthAlbedo / kPi * incomingLight * earthNoL;
+                        vec3 direct = is.hitEarth ? earthLit : vec3(0.f);
+                        vec3 transmission(1.f);
+                        const float currentHeight = -currentPosition.y - a.earthRadius; // "approximation" branch (:73-77)
+                        for (int k = 0; k < innerSampleCount; k++) {
+                            currentPosition = currentPosition + V;
+                            const vec3 up(0.f, -1.f, 0.f);
+                            const Coefficients c = calculateCoefficients(height, a); // sic: height, not currentHeight (:94)
+                            const vec3 scatteringCo = c.scatterRayleigh + c.scatterMie;
+                            const vec2 lutUV = computeLutUV(currentHeight, a.atmosphereHeight, up, L);
+                            const vec3 transmissionSun = texture2D(transmissionLut, LINEAR, CLAMP, lutUV).xyz();
+                            const vec3 coefficientIntegral = integrateInscattering(scatteringCo, c.extinction, stepSize);
+                            L_f = L_f + coefficientIntegral * transmission;
+                            const vec3 scatterIntegral = coefficientIntegral * transmissionSun * isotropicPhase;
+                            inscattered = inscattered + scatterIntegral * transmission;
+                            transmission = transmission * expv(-c.extinction * stepSize);
+                        }
+                        direct = direct * transmission;
+                        f_ms = f_ms + L_f * sinTheta;
+                        L_2nd = L_2nd + (direct * transmission + inscattered) * sinTheta;
+                    }
+                const float sampleCountInverse = 1.f / (float)(sampleCountSqrt * sampleCountSqrt);
+                f_ms = f_ms * sampleCountInverse;
+                L_2nd = L_2nd * sampleCountInverse;
+                const vec3 F_ms(1.f / (1.f - f_ms.x), 1.f / (1.f - f_ms.y), 1.f / (1.f - f_ms.z));
+                imageStore(lut, ivec2(ux, uy), vec4(L_2nd * F_ms, 0.f));
+            }
+    });
+}
+
+// skyLut.comp:25-96
+extern "C" void orc_sky_lut(const orc_image* lutP, const orc_image* transmissionP, const orc_image* multiscatterP, const void* atmosphereSettings56,
+                            const orc_light_buffer* light, const orc_global* g) {
+    const Image& lut = img(lutP);
+    const Image& transmissionLut = img(transmissionP);
+    const Image& multiscatterLut = img(multiscatterP);
+    Atmosphere a;
+    std::memcpy(&a, atmosphereSettings56, sizeof(a));
+    parallelFor(lut.h, [&](int r0, int r1) {
+        for (int uy = r0; uy < r1; uy++)
+            for (int ux = 0; ux < lut.w; ux++) {
+                const float x = (float)ux / (float)lut.w, y = (float)uy / (float)lut.h;
+                // fromSkyLut (sky.inc:96-103)
+                float theta = (1.f - y) - 0.5f;
+                theta = gsign(theta) * theta * theta * 2.f;
+                theta *= kPi;
+                theta += kPi * 0.5f;
+                const float phi = (-x + 0.5f) * 2.f * kPi;
+                const vec3 V(det_sinf(theta) * det_cosf(phi), det_cosf(theta), det_sinf(theta) * det_sinf(phi));
+                const vec3 earthCenter(0.f);
+                const float bias = 0.002f;
+                const vec3 P(0.f, -a.earthRadius - bias, 0.f);
+                const Intersection is = rayEarthIntersection(P, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+                const int sampleCount = 30;
+                const float stepSize = is.distance / (float)sampleCount;
+                const vec3 L(g->sunDirection[0], g->sunDirection[1], g->sunDirection[2]);
+                const float VoL = dot(V, L);
+                const float phaseRayleigh = 3.f / (16.f * kPi) * (1.f + VoL * VoL);
+                const float gM = a.mieScatteringExponent;
+                const float nominator = 3.f / (8.f * kPi) * (1.f - gM * gM) * (1.f + VoL * VoL);
+                const float denominator = (2.f + gM * gM) * det_powf(1.f + gM * gM - 2.f * gM * VoL, 1.5f);
+                const float phaseMie = nominator / denominator;
+                vec3 currentPosition = P;
+                vec3 absorption(1.f), color(0.f);
+                const vec3 step = V * stepSize;
+                for (int i = 0; i < sampleCount; i++) {
+                    currentPosition = currentPosition + step;
+                    vec3 up = currentPosition - earthCenter;
+                    const float upLength = length(up);
+                    const float currentHeight = upLength - a.earthRadius;
+                    up = up / upLength;
+                    const vec2 lutUV = computeLutUV(currentHeight, a.atmosphereHeight, up, L);
+                    const vec3 transmission = texture2D(transmissionLut, LINEAR, CLAMP, lutUV).xyz();
+                    vec3 incomingLight = light->sunStrengthExposed * transmission;
+                    {   // shadowRay (:25-35)
+                        const vec3 Lc = earthCenter - currentPosition;
+                        const float t_ca = dot(Lc, L);
+                        const float d = std::sqrt(dot(Lc, Lc) - t_ca * t_ca);
+                        const float t_hc_earth = std::sqrt(a.earthRadius * a.earthRadius - d * d);
+                        const float t_earth = t_ca - t_hc_earth;
+                        incomingLight = incomingLight * (t_earth > 0.f ? 0.f : 1.f);
+                    }
+                    const Coefficients c = calculateCoefficients(currentHeight, a);
+                    const vec3 inscattering = c.scatterRayleigh * incomingLight * phaseRayleigh + c.scatterMie * incomingLight * phaseMie;
+                    const vec3 scatterIntegral = integrateInscattering(inscattering, c.extinction, stepSize);
+                    color = color + scatterIntegral * absorption;
+                    absorption = absorption * expv(-c.extinction * stepSize);
+                    const vec3 multiscattering = texture2D(multiscatterLut, LINEAR, CLAMP, lutUV).xyz();
+                    color = color + multiscattering * incomingLight * (c.scatterRayleigh + c.scatterMie) * stepSize * transmission;
+                }
+                imageStore(lut, ivec2(ux, uy), vec4(color, 0.f));
+            }
+    });
+}

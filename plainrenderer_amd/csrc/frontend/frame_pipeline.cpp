@@ -558,6 +558,24 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         d.shaderDescription.specialisationConstants = {spec(0, (uint32_t)s.shading.sunShadowCascadeCount)};
         m_lightMatrixPass = m_be.createComputePass(d);
     }
+    {
+        // Sky::init (Techniques/Sky.cpp:5-64, 196-258): LUT sizes 128^2, 32^2, 200x100; the transmission and sky LUT images are the ones the
+        // shade / trace / exposure passes already read
+        m_skyMultiscatterLut = m_be.createImage(desc2D(32, 32, ImageFormat::R11G11B10_uFloat), nullptr, 0);
+        UniformBufferDescription aub;
+        aub.size = sizeof(AtmosphereSettings);
+        m_atmosphereSettingsBuffer = m_be.createUniformBuffer(aub);
+        ComputePassDescription d;
+        d.name = "Sky transmission lut";
+        d.shaderDescription.srcPathRelative = "skyTransmissionLut.comp";
+        m_skyTransmissionLutPass = m_be.createComputePass(d);
+        d.name = "Sky multiscatter lut";
+        d.shaderDescription.srcPathRelative = "skyMultiscatterLut.comp";
+        m_skyMultiscatterLutPass = m_be.createComputePass(d);
+        d.name = "Sky lut";
+        d.shaderDescription.srcPathRelative = "skyLut.comp";
+        m_skyLutPass = m_be.createComputePass(d);
+    }
     m_taa.init(m_be, W, H, s.taa);
     m_bloom.init(m_be);
     m_sdfGi.init(m_be, W, H, s.sdfTrace, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
@@ -581,6 +599,7 @@ ImageHandle FramePipeline::image(const std::string& n) const {
     if (n == "depthHalfRes") return m_depthHalfRes;
     if (n == "brdfLut") return m_brdfLut;
     if (n == "skyLut") return m_skyLut;
+    if (n == "skyMultiscatterLut") return m_skyMultiscatterLut;
     if (n == "transmissionLut") return m_transmissionLut;
     if (n == "volumetricIntegrationVolume") return m_volumetricIntegrationVolume;
     if (n.size() == 7 && n.compare(0, 6, "shadow") == 0) return m_shadowMaps[(n[6] - '0') & 3];
@@ -780,6 +799,41 @@ void FramePipeline::computeSunLightMatrices() { // RenderFrontend.cpp:840-872
     m_be.setComputePassExecution(exe);
 }
 
+void FramePipeline::updateTransmissionLut() { // Sky::updateTransmissionLut, Techniques/Sky.cpp:260-272
+    const uint32_t res = 128;
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_skyTransmissionLutPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(m_transmissionLut, 0, 0)};
+    exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_atmosphereSettingsBuffer, 1)};
+    exe.dispatchCount[0] = res / 8; exe.dispatchCount[1] = res / 8; exe.dispatchCount[2] = 1;
+    m_be.setComputePassExecution(exe);
+}
+
+void FramePipeline::updateSkyLut() { // Sky::updateSkyLut, Techniques/Sky.cpp:274-316
+    m_be.setUniformBufferData(m_atmosphereSettingsBuffer, &atmosphereSettings, sizeof(atmosphereSettings));
+    {
+        const uint32_t res = 32;
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_skyMultiscatterLutPass;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_skyMultiscatterLut, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_transmissionLut, 0, 1)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_atmosphereSettingsBuffer, 3)};
+        exe.dispatchCount[0] = res / 8; exe.dispatchCount[1] = res / 8; exe.dispatchCount[2] = 1;
+        m_be.setComputePassExecution(exe);
+    }
+    {
+        const uint32_t w = 200, h = 100; // sic: 100 / 8 = 12 workgroups, the last four rows of the LUT are never written (Sky.cpp:311-312)
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_skyLutPass;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_skyLut, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_transmissionLut, 0, 1), ImageResource(m_skyMultiscatterLut, 0, 2)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_atmosphereSettingsBuffer, 4)};
+        exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_lightBuffer, true, 5)};
+        exe.dispatchCount[0] = w / 8; exe.dispatchCount[1] = h / 8; exe.dispatchCount[2] = 1;
+        m_be.setComputePassExecution(exe);
+    }
+}
+
 void FramePipeline::computeBRDFLut() { // RenderFrontend.cpp:1031-1042
     ComputePassExecution exe;
     exe.genericInfo.handle = m_brdfLutPass;
@@ -833,10 +887,11 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     if (settings.runExposure) {
         computeColorBufferHistogram(previousRenderTarget.colorBuffer);
         if (band) exchangePoint(ExchangeHistogram, "Exchange: histogram all-reduce");
-        // [m_sky.updateTransmissionLut: input]
+        if (settings.runSkyLuts) updateTransmissionLut(); // separate from the sky LUT: the exposure pass reads it, the other LUTs depend on the exposure
         computeExposure();
-    }
-    // [m_sky.updateSkyLut, renderDepthPrepass: inputs]
+    } else if (settings.runSkyLuts) updateTransmissionLut();
+    if (settings.runSkyLuts) updateSkyLut();
+    // [renderDepthPrepass: input]
     if (settings.runHiZ) computeDepthPyramid(currentRenderTarget.depthBuffer);
     if (settings.runLightMatrix && settings.runHiZ && !band) computeSunLightMatrices();
     // [renderSunShadowCascades: input]

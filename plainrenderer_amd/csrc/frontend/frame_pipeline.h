@@ -172,6 +172,19 @@ private:
         m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ;
 };
 
+// Techniques/Sky.h:6-15 (everything in km); laid out as the std140 block of sky.inc:1-10 (56 bytes)
+struct AtmosphereSettings {
+    float scatteringRayleighGround[3] = {0.0058f, 0.0135f, 0.0331f};
+    float earthRadius = 6371.f;
+    float extinctionRayleighGround[3] = {0.0058f, 0.0135f, 0.0331f};
+    float atmosphereHeight = 100.f;
+    float ozoneExtinction[3] = {0.000650f, 0.001881f, 0.000085f};
+    float scatteringMieGround = 0.006f;
+    float extinctionMieGround = 1.11f * 0.006f;
+    float mieScatteringExponent = 0.76f;
+};
+static_assert(sizeof(AtmosphereSettings) == 56, "AtmosphereSettings layout");
+
 struct FramePipelineSettings {
     uint32_t width = 1920, height = 1080;
     uint32_t shadowMapRes = 2048;  // RenderFrontend.cpp:40
@@ -187,6 +200,7 @@ struct FramePipelineSettings {
     BandSettings band; // width/height stay the WHOLE frame's
     // input producers recorded as compute passes instead of being uploaded by the caller
     bool runLightMatrix = false; // lightMatrix.comp after the depth pyramid (RenderFrontend.cpp:353, 840-872); needs the pyramid apex: not in band mode
+    bool runSkyLuts = false;     // skyTransmissionLut / skyMultiscatterLut / skyLut.comp (Techniques/Sky.cpp:260-316) instead of uploaded LUTs
     float volumetricsMaxDistance = 30.f; // VolumetricsSettings::maxDistance, the last cascade's minimum far plane
 };
 
@@ -227,6 +241,8 @@ private:
     void computeTonemapping(ImageHandle src);
     void computeBRDFLut();
     void computeSunLightMatrices();
+    void updateTransmissionLut();
+    void updateSkyLut();
     void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
     void updateGlobalShaderInfo(float deltaTime, float time);
     RowRange bandRows(uint32_t halo, uint32_t divisor = 1) const;
@@ -253,7 +269,12 @@ private:
     std::vector<ImageHandle> m_sdfVolumes;
     StorageBufferHandle m_histogramPerTileBuffer, m_histogramBuffer, m_lightBuffer, m_sunShadowInfoBuffer, m_depthPyramidSyncBuffer;
     RenderPassHandle m_histogramPerTilePass, m_histogramResetPass, m_histogramCombinePass, m_preExposeLightsPass, m_depthPyramidPass, m_depthDownscalePass,
-        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass;
+        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass, m_skyTransmissionLutPass, m_skyMultiscatterLutPass, m_skyLutPass;
+    ImageHandle m_skyMultiscatterLut;
+    UniformBufferHandle m_atmosphereSettingsBuffer;
+public:
+    AtmosphereSettings atmosphereSettings;
+private:
     TAA m_taa;
     Bloom m_bloom;
     SDFGI m_sdfGi;

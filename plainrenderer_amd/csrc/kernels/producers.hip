@@ -95,4 +95,251 @@ static int launchLightMatrix(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("lightMatrix.comp", launchLightMatrix);
 
+
+// ====================================================================================================================
+// Sky LUTs: sky.inc, volumeShading.inc, skyTransmissionLut.comp, skyMultiscatterLut.comp, skyLut.comp (oracle/producers.cpp has the
+// same functions in the same operation order). 8x8 workgroups of the shaders = one 64-lane wave each.
+namespace sky {
+
+struct Atmosphere { // sky.inc:1-10, std140: 56 bytes
+    float scatteringRayleighGround[3], earthRadius;
+    float extinctionRayleighGround[3], atmosphereHeight;
+    float ozoneExtinction[3], scatteringMieGround;
+    float extinctionMieGround, mieScatteringExponent;
+};
+struct Coefficients { vec3 scatterRayleigh, scatterMie, extinction; };
+
+PLR_DI Coefficients calculateCoefficients(float height, const Atmosphere& a) {
+    const float rayleighFactor = det_expf(-height * (1.f / 8));
+    const float mieFactor = det_expf(-height * (1.f / 1.2f));
+    const float ozoneFactor = gmax(0.f, 1.f - fabsf(height - 25.f) / 15.f);
+    Coefficients c;
+    c.scatterRayleigh = rayleighFactor * ld3(a.scatteringRayleighGround);
+    c.scatterMie = vec3(mieFactor) * a.scatteringMieGround;
+    c.extinction = rayleighFactor * ld3(a.extinctionRayleighGround) + vec3(mieFactor * a.extinctionMieGround) + ozoneFactor * ld3(a.ozoneExtinction);
+    return c;
+}
+
+struct Intersection { vec3 pos; float distance; bool hitEarth; };
+PLR_DI Intersection rayEarthIntersection(vec3 P, vec3 D, vec3 C, float earthRadius, float atmosphere) {
+    const vec3 L = C - P;
+    const float t_ca = dot(L, D);
+    const float d = sqrtf(dot(L, L) - t_ca * t_ca);
+    const float t_hc_earth = sqrtf(earthRadius * earthRadius - d * d);
+    const float t_earth = t_ca - t_hc_earth;
+    const float r = earthRadius + atmosphere;
+    const float t_hc_atmosphere = sqrtf(r * r - d * d);
+    const float t_atmosphere = t_ca + fabsf(t_hc_atmosphere);
+    Intersection result;
+    result.hitEarth = t_earth >= 0.f;
+    const float t = result.hitEarth ? t_earth : t_atmosphere;
+    result.distance = t;
+    result.pos = P + t * D;
+    return result;
+}
+PLR_DI vec3 expv(vec3 v) { return vec3(det_expf(v.x), det_expf(v.y), det_expf(v.z)); }
+PLR_DI vec3 integrateInscattering(vec3 inscattering, vec3 ext, float length) {
+    const vec3 e = expv(-ext * length);
+    const vec3 num = inscattering - inscattering * e;
+    return vec3(num.x / gmax(ext.x, 0.00001f), num.y / gmax(ext.y, 0.00001f), num.z / gmax(ext.z, 0.00001f));
+}
+PLR_DI vec2 computeLutUV(float height, float atmosphereHeight, vec3 up, vec3 direction) { return vec2(height / atmosphereHeight, dot(up, direction) * 0.5f + 0.5f); }
+
+__global__ __launch_bounds__(64) void skyTransmissionLutKernel(ImgView lut, const Atmosphere* __restrict__ ap, int coverW, int coverH) {
+    const int ux = (int)(blockIdx.x * 8u + (threadIdx.x & 7u)), uy = (int)(blockIdx.y * 8u + (threadIdx.x >> 3));
+    if (ux >= coverW || uy >= coverH) return;
+    const Atmosphere a = *ap;
+    const float x = (float)ux / (float)(lut.w - 1), y = (float)uy / (float)(lut.h - 1);
+    const float height = 0.f * (1.f - x) + a.atmosphereHeight * x;
+    float upDot = y * 2.f - 1.f;
+    upDot = gmax(upDot, -0.999f);
+    const vec3 V(0.f, -upDot, sqrtf(1.f - (upDot * upDot)));
+    const vec3 P(0.f, -height - a.earthRadius, 0.f);
+    const vec3 earthCenter(0.f);
+    const Intersection is = rayEarthIntersection(P - 0.01f, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+    const float pathLength = gmax(distance(is.pos, P), 0.01f);
+    const int sampleCount = 40;
+    const float stepLength = pathLength / (float)sampleCount;
+    vec3 currentPos = is.pos;
+    vec3 absorption(1.f);
+    const vec3 step = V * stepLength;
+    for (int i = 0; i < sampleCount; i++) {
+        currentPos = currentPos - step;
+        const float currentHeight = gmax(distance(earthCenter, currentPos) - a.earthRadius, 0.f);
+        const Coefficients c = calculateCoefficients(currentHeight, a);
+        absorption = absorption * expv(-c.extinction * stepLength);
+    }
+    absorption = is.hitEarth ? vec3(0.f) : absorption;
+    Texel<F_R11G11B10>::store(lut.ptr, (size_t)uy * (size_t)lut.w + ux, vec4(absorption, 0.f));
+}
+
+__global__ __launch_bounds__(64) void skyMultiscatterLutKernel(ImgView lut, ImgView transmissionLut, const Atmosphere* __restrict__ ap, int coverW, int coverH) {
+    const int ux = (int)(blockIdx.x * 8u + (threadIdx.x & 7u)), uy = (int)(blockIdx.y * 8u + (threadIdx.x >> 3));
+    if (ux >= coverW || uy >= coverH) return;
+    const Atmosphere a = *ap;
+    const float kPi = PLR_GLSL_PI;
+    const float x = (float)ux / (float)lut.w, y = (float)uy / (float)lut.h;
+    const float height = 0.f * (1.f - x) + a.atmosphereHeight * x;
+    const vec3 P(0.f, -height - a.earthRadius, 0.f);
+    const vec3 earthCenter(0.f);
+    const float upDot = y * 2.f - 1.f;
+    const vec3 L(0.f, -upDot, sqrtf(1.f - (upDot * upDot)));
+    vec3 L_2nd(0.f), f_ms(0.f);
+    const float isotropicPhase = 1.f / (4.f * kPi);
+    const int sampleCountSqrt = 8;
+    const float sampleCountSqrtRcp = 1.f / (float)sampleCountSqrt;
+    for (int i = 0; i < sampleCountSqrt; i++)
+        for (int j = 0; j < sampleCountSqrt; j++) {
+            const float theta = kPi * (float)i * sampleCountSqrtRcp;
+            const float sinTheta = det_sinf(theta), cosTheta = det_cosf(theta);
+            vec3 V(sinTheta * cosTheta, -cosTheta, sinTheta * sinTheta); // sic (:46)
+            const int innerSampleCount = 20;
+            vec3 inscattered(0.f);
+            const Intersection is = rayEarthIntersection(P, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+            vec3 currentPosition = P;
+            const float stepSize = is.distance / (float)innerSampleCount;
+            V = V * stepSize;
+            vec3 L_f(0.f);
+            const vec3 earthAlbedo(0.3f);
+            const vec3 earthHitNormal = normalize(is.pos - earthCenter);
+            const float earthNoL = gclamp(dot(earthHitNormal, L), 0.f, 1.f);
+            const vec3 up0 = normalize(currentPosition - earthCenter);
+            const vec2 lutUV0 = computeLutUV(0.f, a.atmosphereHeight, up0, L);
+            const vec3 incomingLight = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, lutUV0).xyz();
+            const vec3 earthLit = earthAlbedo / kPi * incomingLight * earthNoL;
+            vec3 direct = is.hitEarth ? earthLit : vec3(0.f);
+            vec3 transmission(1.f);
+            const float currentHeight = -currentPosition.y - a.earthRadius;
+            for (int k = 0; k < innerSampleCount; k++) {
+                currentPosition = currentPosition + V;
+                const vec3 up(0.f, -1.f, 0.f);
+                const Coefficients c = calculateCoefficients(height, a); // sic (:94)
+                const vec3 scatteringCo = c.scatterRayleigh + c.scatterMie;
+                const vec2 lutUV = computeLutUV(currentHeight, a.atmosphereHeight, up, L);
+                const vec3 transmissionSun = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, lutUV).xyz();
+                const vec3 coefficientIntegral = integrateInscattering(scatteringCo, c.extinction, stepSize);
+                L_f = L_f + coefficientIntegral * transmission;
+                const vec3 scatterIntegral = coefficientIntegral * transmissionSun * isotropicPhase;
+                inscattered = inscattered + scatterIntegral * transmission;
+                transmission = transmission * expv(-c.extinction * stepSize);
+            }
+            direct = direct * transmission;
+            f_ms = f_ms + L_f * sinTheta;
+            L_2nd = L_2nd + (direct * transmission + inscattered) * sinTheta;
+        }
+    const float sampleCountInverse = 1.f / (float)(sampleCountSqrt * sampleCountSqrt);
+    f_ms = f_ms * sampleCountInverse;
+    L_2nd = L_2nd * sampleCountInverse;
+    const vec3 F_ms(1.f / (1.f - f_ms.x), 1.f / (1.f - f_ms.y), 1.f / (1.f - f_ms.z));
+    Texel<F_R11G11B10>::store(lut.ptr, (size_t)uy * (size_t)lut.w + ux, vec4(L_2nd * F_ms, 0.f));
+}
+
+__global__ __launch_bounds__(64) void skyLutKernel(ImgView lut, ImgView transmissionLut, ImgView multiscatterLut, const Atmosphere* __restrict__ ap,
+                                                  const LightBuffer* __restrict__ light, const GlobalUbo* __restrict__ g, int coverW, int coverH) {
+    const int ux = (int)(blockIdx.x * 8u + (threadIdx.x & 7u)), uy = (int)(blockIdx.y * 8u + (threadIdx.x >> 3));
+    if (ux >= coverW || uy >= coverH) return;
+    const Atmosphere a = *ap;
+    const float kPi = PLR_GLSL_PI;
+    const float x = (float)ux / (float)lut.w, y = (float)uy / (float)lut.h;
+    float theta = (1.f - y) - 0.5f;
+    theta = gsign(theta) * theta * theta * 2.f;
+    theta *= kPi;
+    theta += kPi * 0.5f;
+    const float phi = (-x + 0.5f) * 2.f * kPi;
+    const vec3 V(det_sinf(theta) * det_cosf(phi), det_cosf(theta), det_sinf(theta) * det_sinf(phi));
+    const vec3 earthCenter(0.f);
+    const float bias = 0.002f;
+    const vec3 P(0.f, -a.earthRadius - bias, 0.f);
+    const Intersection is = rayEarthIntersection(P, V, earthCenter, a.earthRadius, a.atmosphereHeight);
+    const int sampleCount = 30;
+    const float stepSize = is.distance / (float)sampleCount;
+    const vec3 L = ld3(g->sunDirection);
+    const float VoL = dot(V, L);
+    const float phaseRayleigh = 3.f / (16.f * kPi) * (1.f + VoL * VoL);
+    const float gM = a.mieScatteringExponent;
+    const float nominator = 3.f / (8.f * kPi) * (1.f - gM * gM) * (1.f + VoL * VoL);
+    const float denominator = (2.f + gM * gM) * det_powf(1.f + gM * gM - 2.f * gM * VoL, 1.5f);
+    const float phaseMie = nominator / denominator;
+    vec3 currentPosition = P;
+    vec3 absorption(1.f), color(0.f);
+    const vec3 step = V * stepSize;
+    const float sunStrengthExposed = light->sunStrengthExposed;
+    for (int i = 0; i < sampleCount; i++) {
+        currentPosition = currentPosition + step;
+        vec3 up = currentPosition - earthCenter;
+        const float upLength = length(up);
+        const float currentHeight = upLength - a.earthRadius;
+        up = up / upLength;
+        const vec2 lutUV = computeLutUV(currentHeight, a.atmosphereHeight, up, L);
+        const vec3 transmission = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, lutUV).xyz();
+        vec3 incomingLight = sunStrengthExposed * transmission;
+        {
+            const vec3 Lc = earthCenter - currentPosition;
+            const float t_ca = dot(Lc, L);
+            const float d = sqrtf(dot(Lc, Lc) - t_ca * t_ca);
+            const float t_hc_earth = sqrtf(a.earthRadius * a.earthRadius - d * d);
+            const float t_earth = t_ca - t_hc_earth;
+            incomingLight = incomingLight * (t_earth > 0.f ? 0.f : 1.f);
+        }
+        const Coefficients c = calculateCoefficients(currentHeight, a);
+        const vec3 inscattering = c.scatterRayleigh * incomingLight * phaseRayleigh + c.scatterMie * incomingLight * phaseMie;
+        const vec3 scatterIntegral = integrateInscattering(inscattering, c.extinction, stepSize);
+        color = color + scatterIntegral * absorption;
+        absorption = absorption * expv(-c.extinction * stepSize);
+        const vec3 multiscattering = sampleLinear2D<F_R11G11B10, CLAMP>(multiscatterLut, lutUV).xyz();
+        color = color + multiscattering * incomingLight * (c.scatterRayleigh + c.scatterMie) * stepSize * transmission;
+    }
+    Texel<F_R11G11B10>::store(lut.ptr, (size_t)uy * (size_t)lut.w + ux, vec4(color, 0.f));
+}
+
+static int cover(const PassCtx& c, const ImgView& lut, int* w, int* h) {
+    *w = std::min((int)(c.dispatch[0] * 8u), lut.w);
+    *h = std::min((int)(c.dispatch[1] * 8u), lut.h);
+    return *w > 0 && *h > 0;
+}
+
+static int launchTransmission(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R11G11B10, "skyTransmissionLut lut")) return rc;
+    if (int rc = c.needUbuf(1, sizeof(Atmosphere), "skyTransmissionLut atmosphereSettingsBuffer")) return rc;
+    int w, h;
+    if (!cover(c, c.storage[0], &w, &h)) return 0;
+    if (c.storage[0].w < 2 || c.storage[0].h < 2) return c.fail(-4, "skyTransmissionLut: the lut needs at least 2x2 texels (coordinates divide by size - 1)");
+    skyTransmissionLutKernel<<<dim3(divUp((unsigned)w, 8u), divUp((unsigned)h, 8u)), 64, 0, c.stream>>>(c.storage[0], (const Atmosphere*)c.ubuf[1].ptr, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+static int launchMultiscatter(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_R11G11B10, "skyMultiscatterLut multiscatterLut")) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "skyMultiscatterLut transmissionLut")) return rc;
+    if (int rc = c.needUbuf(3, sizeof(Atmosphere), "skyMultiscatterLut atmosphereSettingsBuffer")) return rc;
+    int w, h;
+    if (!cover(c, c.storage[0], &w, &h)) return 0;
+    skyMultiscatterLutKernel<<<dim3(divUp((unsigned)w, 8u), divUp((unsigned)h, 8u)), 64, 0, c.stream>>>(c.storage[0], c.sampled[1], (const Atmosphere*)c.ubuf[3].ptr, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+static int launchSkyLut(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_R11G11B10, "skyLut skyLut")) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "skyLut transmissionLut")) return rc;
+    if (int rc = c.needSampled(2, F_R11G11B10, "skyLut multiscatterLut")) return rc;
+    if (int rc = c.needUbuf(4, sizeof(Atmosphere), "skyLut atmosphereSettingsBuffer")) return rc;
+    if (int rc = c.needSbuf(5, sizeof(LightBuffer), "skyLut lightStorageBuffer")) return rc;
+    int w, h;
+    if (!cover(c, c.storage[0], &w, &h)) return 0;
+    skyLutKernel<<<dim3(divUp((unsigned)w, 8u), divUp((unsigned)h, 8u)), 64, 0, c.stream>>>(c.storage[0], c.sampled[1], c.sampled[2], (const Atmosphere*)c.ubuf[4].ptr,
+                                                                                             (const LightBuffer*)c.sbuf[5].ptr, c.global, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace sky
+
+static int sky_transmission_launch(const PassCtx& c) { return sky::launchTransmission(c); }
+static int sky_multiscatter_launch(const PassCtx& c) { return sky::launchMultiscatter(c); }
+static int sky_lut_launch(const PassCtx& c) { return sky::launchSkyLut(c); }
+PLR_REGISTER_SHADER("skyTransmissionLut.comp", sky_transmission_launch);
+PLR_REGISTER_SHADER("skyMultiscatterLut.comp", sky_multiscatter_launch);
+PLR_REGISTER_SHADER("skyLut.comp", sky_lut_launch);
+
 } // namespace plr

@@ -652,3 +652,52 @@ def orc_light_matrix(info_bytes, apex_min_max, global_packed, cascade_count, pad
     g = orc.global_from_bytes(global_packed)
     L.orc_light_matrix(C.byref(info), _p(apex), C.byref(g), C.c_uint32(cascade_count), C.c_float(padding), C.c_float(min_far))
     return bytes(info)
+
+
+ATMOSPHERE_DEFAULT = struct.pack("<14f", 0.0058, 0.0135, 0.0331, 6371.0, 0.0058, 0.0135, 0.0331, 100.0, 0.000650, 0.001881, 0.000085, 0.006, 1.11 * 0.006, 0.76)  # Sky.h:6-15
+
+
+def gpu_sky_luts(be, atmosphere_bytes, light_bytes, global_packed, t_res=128, m_res=32, sky_w=200, sky_h=100):
+    """Sky::updateTransmissionLut + Sky::updateSkyLut (Techniques/Sky.cpp:260-316): bindings as recorded there"""
+    t = be.createImage(image_desc_2d(t_res, t_res, F.R11G11B10_uFloat))
+    m = be.createImage(image_desc_2d(m_res, m_res, F.R11G11B10_uFloat))
+    s = be.createImage(image_desc_2d(sky_w, sky_h, F.R11G11B10_uFloat))
+    atm = be.createUniformBuffer(64, atmosphere_bytes)
+    light = be.createStorageBuffer(20, light_bytes)
+    pt = be.createComputePass("skyTransmissionLut.comp", [], "Sky transmission lut")
+    pm = be.createComputePass("skyMultiscatterLut.comp", [], "Sky multiscatter lut")
+    ps = be.createComputePass("skyLut.comp", [], "Sky lut")
+    gb = global_binding(be)
+    gb.set(global_packed)
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(pt, RenderPassResources(storageImages=[ImageResource(t, 0, 0)], uniformBuffers=[UniformBufferResource(atm, 1)]), b"",
+                                                    (t_res // 8, t_res // 8, 1)))
+    be.setComputePassExecution(ComputePassExecution(pm, RenderPassResources(storageImages=[ImageResource(m, 0, 0)], sampledImages=[ImageResource(t, 0, 1)],
+                                                                            uniformBuffers=[UniformBufferResource(atm, 3)]), b"", (m_res // 8, m_res // 8, 1)))
+    be.setComputePassExecution(ComputePassExecution(ps, RenderPassResources(storageImages=[ImageResource(s, 0, 0)], sampledImages=[ImageResource(t, 0, 1), ImageResource(m, 0, 2)],
+                                                                            uniformBuffers=[UniformBufferResource(atm, 4)], storageBuffers=[StorageBufferResource(light, True, 5)]),
+                                                    b"", (sky_w // 8, sky_h // 8, 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return (be.downloadImage(t, 0, np.uint32).reshape(t_res, t_res).copy(), be.downloadImage(m, 0, np.uint32).reshape(m_res, m_res).copy(),
+            be.downloadImage(s, 0, np.uint32).reshape(sky_h, sky_w).copy())
+
+
+def orc_sky_luts(atmosphere_bytes, light_bytes, global_packed, t_res=128, m_res=32, sky_w=200, sky_h=100):
+    L = orc.lib()
+    t = orc.new_image(t_res, t_res, F.R11G11B10_uFloat, 4)
+    m = orc.new_image(m_res, m_res, F.R11G11B10_uFloat, 4)
+    s = orc.new_image(sky_w, sky_h, F.R11G11B10_uFloat, 4)
+    atm = (C.c_uint8 * 56).from_buffer_copy(atmosphere_bytes[:56])
+    light = (C.c_uint8 * 20).from_buffer_copy(light_bytes)
+    g = orc.global_from_bytes(global_packed)
+    L.orc_sky_transmission_lut(t.ref(), C.byref(atm))
+    L.orc_sky_multiscatter_lut(m.ref(), t.ref(), C.byref(atm))
+    L.orc_sky_lut(s.ref(), t.ref(), m.ref(), C.byref(atm), C.byref(light), C.byref(g))
+    out = [t.arr.view(np.uint32).reshape(t_res, t_res).copy(), m.arr.view(np.uint32).reshape(m_res, m_res).copy(), s.arr.view(np.uint32).reshape(sky_h, sky_w).copy()]
+    # the recorded dispatches are size / 8 workgroups (integer division, Sky.cpp:268-313): 100 / 8 = 12 groups leave the last 4 rows of the
+    # sky LUT unwritten (still the zeros the image was created with)
+    for img, (w_, h_) in zip(out, ((t_res, t_res), (m_res, m_res), (sky_w, sky_h))):
+        img[(h_ // 8) * 8:, :] = 0
+        img[:, (w_ // 8) * 8:] = 0
+    return tuple(out)

@@ -108,3 +108,73 @@ def test_gpu_frame_with_compute_light_matrices(backend):
     s1, m1, _ = _parse(got)
     assert np.allclose(s1[:2], s0[:2], rtol=1e-3) and np.allclose(m1[:3], m0[:3], rtol=5e-3, atol=1e-3)
     fp.destroy()
+
+
+# ------------------------------------------------------------------ sky LUTs
+def _sky_inputs(sun=(0.35, -0.8, 0.45)):
+    from util import light_buffer_bytes
+    cam = Camera.look((0.0, -5.0, 0.0), (0.0, 0.0, 1.0), aspect=W / H)
+    sun = np.array(sun, np.float64); sun /= np.linalg.norm(sun)
+    return passes.ATMOSPHERE_DEFAULT, light_buffer_bytes(sun_strength_exposed=12.8), _global(cam, sun)
+
+
+def test_oracle_sky_luts_known_answers():
+    from plainrenderer_amd import pixfmt
+    atm, light, gp = _sky_inputs()
+    t, m, s = passes.orc_sky_luts(atm, light, gp)
+    T = pixfmt.unpack_r11g11b10(t.reshape(-1)).reshape(128, 128, 3)
+    # x = height (0 .. 100 km), y = cos of the angle to the zenith (-1 .. 1)
+    assert np.isfinite(T).all() and T.min() >= 0 and T.max() <= 1.0
+    assert (T[127, 127] > 0.99).all()                   # top of the atmosphere looking up: nothing left to absorb
+    assert (T[0, :40] == 0).all()                       # looking straight down from any height below 30 km: the earth blocks the ray
+    assert (np.diff(T[100, :, 2]) >= -1e-3).all()       # transmission grows with the height of the observer
+    assert (np.diff(T[64:, 0, 2]) >= -1e-3).all()       # from the ground: grows from the horizon towards the zenith
+    assert T[127, 0, 2] < T[127, 0, 0]                  # Rayleigh: blue is absorbed/scattered most
+    M = pixfmt.unpack_r11g11b10(m.reshape(-1)).reshape(32, 32, 3)
+    assert np.isfinite(M).all() and M.min() >= 0 and M.max() < 1.0 and M.max() > 1e-3
+    S = pixfmt.unpack_r11g11b10(s.reshape(-1)).reshape(100, 200, 3)
+    assert np.isfinite(S).all() and S.max() > 0
+    # a blue sky: away from the sun, above the horizon, blue > red
+    sky_rows = S[10:40]
+    assert (sky_rows[..., 2].mean() > sky_rows[..., 0].mean())
+    # the Mie forward peak: looking at the sun is brighter than looking at the same elevation in the opposite azimuth
+    def lut_texel(V):  # toSkyLut (sky.inc:86-94)
+        th = np.arccos(-V[1]); y = th / np.pi; yl = y * 2 - 1; y = np.sign(yl) * np.sqrt(abs(yl)) * 0.5 + 0.5
+        x = -np.arctan2(V[2], V[0]) / (2 * 3.1415) + 0.5
+        return S[min(int(y * 100), 99), int(x * 200) % 200]
+    sun = np.array([0.35, -0.8, 0.45]); sun /= np.linalg.norm(sun)
+    anti = sun * np.array([-1.0, 1.0, -1.0])
+    assert lut_texel(sun).sum() > 1.5 * lut_texel(anti).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sun", [(0.35, -0.8, 0.45), (0.9, -0.05, 0.1)])
+def test_gpu_sky_luts_bit_exact(backend, sun):
+    atm, light, gp = _sky_inputs(sun)
+    a = passes.gpu_sky_luts(backend, atm, light, gp)
+    b = passes.orc_sky_luts(atm, light, gp)
+    for x, y, what in zip(a, b, ("transmission", "multiscatter", "sky")):
+        assert np.array_equal(x, y), what
+
+
+@pytest.mark.gpu
+def test_gpu_frame_with_compute_sky_luts(backend):
+    """the frame graph with the three sky LUT passes recorded where Sky::updateTransmissionLut / updateSkyLut sit (RenderFrontend.cpp:348-350):
+    the LUTs the exposure, trace and shade passes read are this frame's compute results (the sky LUT uses this frame's exposure)"""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h = 256, 144
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(3)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=952)
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=8, max_sdf_instances=64, run_sky_luts=1)
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
+    inputs.upload(fp)  # uploads stand-in LUTs too; the compute passes overwrite them
+    for f in range(2):
+        fp.frame(cams[f + 1], 1 / 60.0, 0.5 + f / 60.0)
+    light = backend.downloadStorageBuffer(fp.storage_buffer("light"), 20).tobytes()
+    t, m, s = passes.orc_sky_luts(passes.ATMOSPHERE_DEFAULT, light, bytes(fp.submitted_globals()))
+    assert np.array_equal(backend.downloadImage(fp.image("transmissionLut"), 0, np.uint32).reshape(128, 128), t)
+    assert np.array_equal(backend.downloadImage(fp.image("skyMultiscatterLut"), 0, np.uint32).reshape(32, 32), m)
+    got = backend.downloadImage(fp.image("skyLut"), 0, np.uint32).reshape(100, 200)
+    assert np.array_equal(got[:96], s[:96])  # rows 96..99 are never dispatched: they keep what was uploaded
+    assert np.array_equal(got[96:], inputs.sky.reshape(100, 200)[96:])
+    fp.destroy()
