@@ -34,6 +34,7 @@ typedef struct plrf_settings {
     uint32_t band_row_begin, band_row_end, band_gi_halo, band_gi_history_halo, band_color_halo, band_post_halo;
     /* input producers recorded as compute passes instead of uploaded (0 = uploaded): lightMatrix.comp after the depth pyramid */
     uint32_t run_light_matrix; float volumetrics_max_distance;
+    uint32_t taa_use_separate_supersampling, taa_supersample_use_tonemapping; /* TAASettings::useSeparateSupersampling (off), supersampleUseTonemapping */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
 } plrf_settings;
 

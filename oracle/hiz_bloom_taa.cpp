@@ -342,3 +342,69 @@ extern "C" void orc_taa_resolve_weights(const float* jitter, float* weights) {
         }
     for (int i = 0; i < 9; i++) weights[i] /= totalWeight;
 }
+
+
+// ====================================================================================================================
+// Optional TAA stage (TAASettings::useSeparateSupersampling, off by default): colorToLuminance.comp + temporalSupersampling.comp.
+// Host: Techniques/TAA.cpp:85-137.
+
+// colorToLuminance.comp:14-21 (dst is R8: the store converts to UNORM8)
+extern "C" void orc_color_to_luminance(const orc_image* srcP, const orc_image* dstP) {
+    const Image& src = img(srcP);
+    const Image& dst = img(dstP);
+    parallelFor(dst.h, [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < dst.w; x++) {
+                const vec3 color = texelFetch(src, ivec2(x, y)).xyz();
+                imageStore(dst, ivec2(x, y), vec4(computeLuminance(color), 0.f, 0.f, 0.f));
+            }
+    });
+}
+
+namespace {
+// temporalSupersampling.comp:23-29
+float minAbsoluteDifference(float s, vec4 v) {
+    return gmin(std::fabs(s) - std::fabs(v.x), gmin(std::fabs(s) - std::fabs(v.y), gmin(std::fabs(s) - std::fabs(v.z), std::fabs(s) - std::fabs(v.w))));
+}
+// temporalSupersampling.comp:39-55
+float getClosestNeighbourhoodDepth(const Image& depthBuffer, vec2 uv, const orc_global* g) {
+    const vec2 texelSize(1.f / (float)g->screenResolution[0], 1.f / (float)g->screenResolution[1]);
+    const int ox[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1}, oy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1};
+    float closestDepth = texture2D(depthBuffer, NEAREST, CLAMP, uv + vec2((float)ox[0], (float)oy[0]) * texelSize).x;
+    for (int i = 1; i < 9; i++) closestDepth = gmax(texture2D(depthBuffer, NEAREST, CLAMP, uv + vec2((float)ox[i], (float)oy[i]) * texelSize).x, closestDepth);
+    return linearizeDepth(closestDepth, g->nearPlane, g->farPlane);
+}
+} // namespace
+
+// temporalSupersampling.comp:57-110
+extern "C" void orc_temporal_supersampling(const orc_image* currentP, const orc_image* lastP, const orc_image* targetP, const orc_image* velocityP,
+                                           const orc_image* currentDepthP, const orc_image* lastDepthP, const orc_image* currentLumP, const orc_image* lastLumP,
+                                           const orc_global* g, int32_t useTonemap) {
+    const Image &currentFrame = img(currentP), &lastFrame = img(lastP), &target = img(targetP), &velocity = img(velocityP), &currentDepth = img(currentDepthP),
+                &lastDepth = img(lastDepthP), &currentLum = img(currentLumP), &lastLum = img(lastLumP);
+    parallelFor(target.h, [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < target.w; x++) {
+                const ivec2 iUV(x, y);
+                const vec2 texelSize(1.f / (float)g->screenResolution[0], 1.f / (float)g->screenResolution[1]);
+                const vec2 uvCurrent = (vec2((float)x, (float)y) + vec2(0.5f)) * texelSize;
+                const vec2 motion = getClosestFragmentMotion(iUV, currentDepth, velocity);
+                const vec2 uvLast = uvCurrent + motion;
+                vec3 currentSample = texture2D(currentFrame, LINEAR, CLAMP, uvCurrent).xyz();
+                vec3 lastSample = texture2D(lastFrame, LINEAR, CLAMP, uvLast).xyz();
+                if (useTonemap) { currentSample = tonemap(currentSample); lastSample = tonemap(lastSample); }
+                // acceptLastFrameSample (:57-84)
+                const vec4 cl = textureGatherR(currentLum, CLAMP, uvCurrent), ll = textureGatherR(lastLum, CLAMP, uvLast);
+                const float contrast = minAbsoluteDifference(cl.x, ll) + minAbsoluteDifference(cl.y, ll) + minAbsoluteDifference(cl.z, ll) + minAbsoluteDifference(cl.w, ll);
+                const bool contrastTest = contrast < 0.5f;
+                const float cd = getClosestNeighbourhoodDepth(currentDepth, uvCurrent, g), ld = getClosestNeighbourhoodDepth(lastDepth, uvLast, g);
+                const bool depthTest = std::fabs(cd - ld) < 1.f;
+                const bool outOfScreen = uvLast.x < 0.f || uvLast.y < 0.f || uvLast.x > 1.f || uvLast.y > 1.f;
+                const bool acceptSample = contrastTest && depthTest && !outOfScreen;
+                const float blendFactor = acceptSample ? 0.5f : 0.f;
+                vec3 color = currentSample * (1.f - blendFactor) + lastSample * blendFactor; // mix
+                if (useTonemap) color = tonemapReverse(color);
+                imageStore(target, iUV, vec4(color, 1.f));
+            }
+    });
+}

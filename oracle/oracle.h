@@ -157,6 +157,12 @@ void orc_deferred_shading(const orc_image* color, const orc_image* depth, const 
                           int32_t diffuseBRDF, int32_t directMultiscatterBRDF, int32_t geometricAA,
                           int32_t indirectLightingTech, uint32_t sunShadowCascadeCount);
 
+/* optional TAA stage: colorToLuminance.comp, temporalSupersampling.comp */
+void orc_color_to_luminance(const orc_image* src, const orc_image* dstR8);
+void orc_temporal_supersampling(const orc_image* currentFrame, const orc_image* lastFrame, const orc_image* target, const orc_image* velocity,
+                                const orc_image* currentDepth, const orc_image* lastDepth, const orc_image* currentLuminance, const orc_image* lastLuminance,
+                                const orc_global* g, int32_t useTonemap);
+
 /* ---- input producers ---- */
 /* lightMatrix.comp: fits the sun shadow cascades to the HiZ apex (min, max depth); updates splits, lightMatrices, lightSpaceScale in place */
 void orc_light_matrix(orc_shadow_cascade_info* info, const float* apexMinMax2, const orc_global* g, uint32_t sunShadowCascadeCount,

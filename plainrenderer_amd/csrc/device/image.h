@@ -147,6 +147,7 @@ template <> struct Texel<F_RG8> {
 };
 template <> struct Texel<F_R8> {
     static PLR_DI vec4 load(const void* p, size_t i) { return vec4(decodeUnorm8(((const uint8_t*)p)[i]), 0.f, 0.f, 1.f); }
+    static PLR_DI void store(void* p, size_t i, vec4 v) { ((uint8_t*)p)[i] = (uint8_t)encodeUnorm8(v.x); }
 };
 
 // ---- samplers (resources/shaders/global.inc:35-42) ----

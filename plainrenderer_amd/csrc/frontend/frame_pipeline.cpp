@@ -113,6 +113,18 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     d.shaderDescription = temporalFilterShaderDescription(settings);
     m_temporalFilterPass = be.createComputePass(d);
     for (int i = 0; i < 2; i++) m_historyBuffers[i] = be.createImage(desc2D(w, h, ImageFormat::R11G11B10_uFloat), nullptr, 0);
+    for (int i = 0; i < 2; i++) m_sceneLuminance[i] = be.createImage(desc2D(w, h, ImageFormat::R8), nullptr, 0); // TAA.cpp:38-53
+    {
+        ComputePassDescription sd; // TAA.cpp:20-36, 235-245
+        sd.name = "Temporal supersampling";
+        sd.shaderDescription.srcPathRelative = "temporalSupersampling.comp";
+        sd.shaderDescription.specialisationConstants = {spec(0, settings.supersampleUseTonemapping)};
+        m_temporalSupersamplingPass = be.createComputePass(sd);
+        ComputePassDescription ld;
+        ld.name = "Color to Luminance";
+        ld.shaderDescription.srcPathRelative = "colorToLuminance.comp";
+        m_colorToLuminancePass = be.createComputePass(ld);
+    }
     UniformBufferDescription ub;
     ub.size = sizeof(float) * 9;
     m_taaResolveWeightBuffer = be.createUniformBuffer(ub);
@@ -132,6 +144,31 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_taaResolveWeightBuffer, 6)};
     dispatch8(exe, td.width, td.height, rows);
     be.setComputePassExecution(exe);
+}
+void TAA::computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
+                                       ImageHandle target, RowRange rows) const { // TAA.cpp:85-137
+    const ImageDescription td = be.getImageDescription(target);
+    const size_t frameIndexMod2 = fi.mod2();
+    const ImageHandle currentLuminance = m_sceneLuminance[frameIndexMod2];
+    const ImageHandle historyLuminance = m_sceneLuminance[(frameIndexMod2 + 1) % 2];
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_colorToLuminancePass;
+        exe.genericInfo.resources.storageImages = {ImageResource(currentLuminance, 0, 1)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(currentFrame.colorBuffer, 0, 0)};
+        dispatch8(exe, td.width, td.height, rows);
+        be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_temporalSupersamplingPass;
+        exe.genericInfo.resources.storageImages = {ImageResource(target, 0, 3)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(currentFrame.colorBuffer, 0, 1), ImageResource(lastFrame.colorBuffer, 0, 2), ImageResource(currentFrame.motionBuffer, 0, 4),
+                                                   ImageResource(currentFrame.depthBuffer, 0, 5), ImageResource(lastFrame.depthBuffer, 0, 6), ImageResource(currentLuminance, 0, 7),
+                                                   ImageResource(historyLuminance, 0, 8)};
+        dispatch8(exe, td.width, td.height, rows);
+        be.setComputePassExecution(exe);
+    }
 }
 void TAA::jitterInPixels(const FrameIndexCounter& fi, float out[2]) const { // TAA.cpp:168-170
     const uint32_t i = (uint32_t)fi.mod8();
@@ -606,6 +643,8 @@ ImageHandle FramePipeline::image(const std::string& n) const {
     if (n.size() == 6 && n.compare(0, 5, "noise") == 0) return m_noiseTextures[(n[5] - '0') & 3];
     if (n == "taaHistory0") return m_taa.m_historyBuffers[0];
     if (n == "taaHistory1") return m_taa.m_historyBuffers[1];
+    if (n == "sceneLuminance0") return m_taa.m_sceneLuminance[0];
+    if (n == "sceneLuminance1") return m_taa.m_sceneLuminance[1];
     if (n == "giYSH0") return m_sdfGi.m_indirectDiffuse_Y_SH[0];
     if (n == "giYSH1") return m_sdfGi.m_indirectDiffuse_Y_SH[1];
     if (n == "giCoCg0") return m_sdfGi.m_indirectDiffuse_CoCg[0];
@@ -940,6 +979,11 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     // [sky: folded into the deferred pass' sky stand-in]
     ImageHandle currentSrc = currentRenderTarget.colorBuffer;
     if (settings.runTAA && settings.taa.enabled) {
+        if (settings.taa.useSeparateSupersampling) { // RenderFrontend.cpp:391-395 (whole-frame only: the stage has no halo plan for band rendering)
+            if (band) throw std::runtime_error("useSeparateSupersampling is not supported in band rendering");
+            m_taa.computeTemporalSuperSampling(m_be, m_frameIndex, currentRenderTarget, previousRenderTarget, m_postProcessBuffers[0]);
+            currentSrc = m_postProcessBuffers[0];
+        }
         m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
         currentSrc = m_postProcessBuffers[1];
     }

@@ -116,12 +116,16 @@ public:
     void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
                                RowRange rows = {}) const;
     ImageHandle historyDst(const FrameIndexCounter& fi) const { return m_historyBuffers[(fi.mod2() + 1) % 2]; }
+    // TAASettings::useSeparateSupersampling (TAA.cpp:85-137): luminance of the current frame, then a 2-frame blend with contrast / depth rejection
+    void computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
+                                      ImageHandle target, RowRange rows = {}) const;
+    ImageHandle m_sceneLuminance[2];
     void jitterInPixels(const FrameIndexCounter& fi, float out[2]) const;
     void updateTaaResolveWeights(RenderBackend& be, const float cameraJitterInPixels[2]);
     ImageHandle m_historyBuffers[2];
     UniformBufferHandle m_taaResolveWeightBuffer;
 private:
-    RenderPassHandle m_temporalFilterPass;
+    RenderPassHandle m_temporalFilterPass, m_temporalSupersamplingPass, m_colorToLuminancePass;
 };
 
 class Bloom {

@@ -236,4 +236,113 @@ static int launchTemporalFilter(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("temporalFilter.comp", launchTemporalFilter);
 
+
+// ====================================================================================================================
+// Optional TAA stage (TAASettings::useSeparateSupersampling): colorToLuminance.comp + temporalSupersampling.comp (Techniques/TAA.cpp:85-137)
+
+// colorToLuminance.comp:14-21
+__global__ __launch_bounds__(256) void colorToLuminanceKernel(ImgView src, ImgView dst, int coverW, int coverH, int yBase) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const vec3 color = texelFetch2D<F_R11G11B10>(src, px, py).xyz();
+    Texel<F_R8>::store(dst.ptr, (size_t)py * (size_t)dst.w + px, vec4(computeLuminance(color), 0.f, 0.f, 0.f));
+}
+static int launchColorToLuminance(const PassCtx& c) {
+    if (int rc = c.needSampled(0, F_R11G11B10, "colorToLuminance srcTexture")) return rc;
+    if (int rc = c.needStorage(1, F_R8, "colorToLuminance dstImage")) return rc;
+    const ImgView& dst = c.storage[1];
+    const PassCtx::RowSpan rs = c.rowSpan(dst.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), dst.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    colorToLuminanceKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], dst, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("colorToLuminance.comp", launchColorToLuminance);
+
+// temporalSupersampling.comp:23-29
+PLR_DI float minAbsoluteDifference(float s, vec4 v) {
+    return gmin(fabsf(s) - fabsf(v.x), gmin(fabsf(s) - fabsf(v.y), gmin(fabsf(s) - fabsf(v.z), fabsf(s) - fabsf(v.w))));
+}
+// textureGather component 0 of an R8 image with clamp-to-edge: (i0,j1), (i1,j1), (i1,j0), (i0,j0)
+PLR_DI vec4 gatherR8(const ImgView& im, vec2 uv) {
+    int i0, j0; float a, b;
+    linearCoord(uv.x * (float)im.w, &i0, &a);
+    linearCoord(uv.y * (float)im.h, &j0, &b);
+    return vec4(addressedTexel2D<F_R8, CLAMP>(im, i0, j0 + 1).x, addressedTexel2D<F_R8, CLAMP>(im, i0 + 1, j0 + 1).x, addressedTexel2D<F_R8, CLAMP>(im, i0 + 1, j0).x,
+                addressedTexel2D<F_R8, CLAMP>(im, i0, j0).x);
+}
+// temporalSupersampling.comp:39-55
+PLR_DI float closestNeighbourhoodDepth(const ImgView& depthBuffer, vec2 uv, const GlobalUbo* g) {
+    const vec2 texelSize(1.f / (float)g->screenResolution[0], 1.f / (float)g->screenResolution[1]);
+    const int ox[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1}, oy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1};
+    float closestDepth = sampleNearest2D<F_D32, CLAMP>(depthBuffer, uv + vec2((float)ox[0], (float)oy[0]) * texelSize).x;
+#pragma unroll
+    for (int i = 1; i < 9; i++) closestDepth = gmax(sampleNearest2D<F_D32, CLAMP>(depthBuffer, uv + vec2((float)ox[i], (float)oy[i]) * texelSize).x, closestDepth);
+    return linearizeDepth(closestDepth, g->nearPlane, g->farPlane);
+}
+
+// temporalSupersampling.comp:57-110
+template <bool TONEMAP>
+__global__ __launch_bounds__(256) void temporalSupersamplingKernel(ImgView currentFrame, ImgView lastFrame, ImgView target, ImgView velocityBuffer, ImgView currentDepth,
+                                                                   ImgView lastDepth, ImgView currentLum, ImgView lastLum, const GlobalUbo* __restrict__ g, int coverW,
+                                                                   int coverH, int yBase) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const vec2 texelSize(1.f / (float)g->screenResolution[0], 1.f / (float)g->screenResolution[1]);
+    const vec2 uvCurrent = (vec2((float)px, (float)py) + vec2(0.5f)) * texelSize;
+    vec2 motion;
+    {   // getClosestFragmentMotion (temporalReprojection.inc:67-83)
+        float closest = 0.f;
+        int ox = 0, oy = 0;
+#pragma unroll
+        for (int x = -1; x <= 1; x++)
+#pragma unroll
+            for (int y = -1; y <= 1; y++) {
+                const float d = texelFetch2D<F_D32>(currentDepth, px + x, py + y).x;
+                if (d > closest) { closest = d; ox = x; oy = y; }
+            }
+        const vec4 m = texelFetch2D<F_RG16SN>(velocityBuffer, px + ox, py + oy);
+        motion = vec2(m.x, m.y);
+    }
+    const vec2 uvLast = uvCurrent + motion;
+    vec3 currentSample = sampleLinear2D<F_R11G11B10, CLAMP>(currentFrame, uvCurrent).xyz();
+    vec3 lastSample = sampleLinear2D<F_R11G11B10, CLAMP>(lastFrame, uvLast).xyz();
+    if (TONEMAP) { currentSample = taaTonemap(currentSample); lastSample = taaTonemap(lastSample); }
+    const vec4 cl = gatherR8(currentLum, uvCurrent), ll = gatherR8(lastLum, uvLast);
+    const float contrast = minAbsoluteDifference(cl.x, ll) + minAbsoluteDifference(cl.y, ll) + minAbsoluteDifference(cl.z, ll) + minAbsoluteDifference(cl.w, ll);
+    const bool contrastTest = contrast < 0.5f;
+    const float cd = closestNeighbourhoodDepth(currentDepth, uvCurrent, g), ld = closestNeighbourhoodDepth(lastDepth, uvLast, g);
+    const bool depthTest = fabsf(cd - ld) < 1.f;
+    const bool outOfScreen = uvLast.x < 0.f || uvLast.y < 0.f || uvLast.x > 1.f || uvLast.y > 1.f;
+    const float blendFactor = (contrastTest && depthTest && !outOfScreen) ? 0.5f : 0.f;
+    vec3 color = currentSample * (1.f - blendFactor) + lastSample * blendFactor;
+    if (TONEMAP) color = taaTonemapReverse(color);
+    Texel<F_R11G11B10>::store(target.ptr, (size_t)py * (size_t)target.w + px, vec4(color, 1.f));
+}
+static int launchTemporalSupersampling(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSampled(1, F_R11G11B10, "temporalSupersampling currentFrame")) return rc;
+    if (int rc = c.needSampled(2, F_R11G11B10, "temporalSupersampling lastFrame")) return rc;
+    if (int rc = c.needStorage(3, F_R11G11B10, "temporalSupersampling targetImage")) return rc;
+    if (int rc = c.needSampled(4, F_RG16SN, "temporalSupersampling velocityBuffer")) return rc;
+    if (int rc = c.needSampled(5, F_D32, "temporalSupersampling currentDepthBuffer")) return rc;
+    if (int rc = c.needSampled(6, F_D32, "temporalSupersampling lastDepthBuffer")) return rc;
+    if (int rc = c.needSampled(7, F_R8, "temporalSupersampling currentLuminanceTexture")) return rc;
+    if (int rc = c.needSampled(8, F_R8, "temporalSupersampling lastLuminanceTexture")) return rc;
+    const bool tonemap = c.specBool(0, false);
+    const ImgView& out = c.storage[3];
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+    if (tonemap) temporalSupersamplingKernel<true><<<grid, 256, 0, c.stream>>>(c.sampled[1], c.sampled[2], out, c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.global, w, h, y0);
+    else temporalSupersamplingKernel<false><<<grid, 256, 0, c.stream>>>(c.sampled[1], c.sampled[2], out, c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.global, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("temporalSupersampling.comp", launchTemporalSupersampling);
+
 } // namespace plr

@@ -90,6 +90,15 @@ class OracleFrame:
                                                           int(s.direct_multiscatter), bool(s.use_geometry_aa), int(s.indirect_lighting_tech),
                                                           int(s.sun_shadow_cascade_count))
         src = self.color[cur]
+        if s.run_taa and s.taa_enabled and getattr(s, "taa_use_separate_supersampling", 0):
+            # TAA::computeTemporalSuperSampling (TAA.cpp:85-137): luminance of this frame, 2-frame blend into postProcessBuffers[0]
+            m2 = self.cpu_frame % 2
+            if not hasattr(self, "scene_lum"):
+                self.scene_lum = [np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)]
+            self.scene_lum[m2] = passes.orc_color_to_luminance(self.color[cur], w, h)
+            self.post0 = passes.orc_temporal_supersampling(self.color[cur], self.color[prev], inp.gb["motion"], depth, depth, self.scene_lum[m2], self.scene_lum[(m2 + 1) % 2],
+                                                           w, h, global_bytes, bool(s.taa_supersample_use_tonemapping))
+            src = self.post0
         if s.run_taa and s.taa_enabled:
             m2 = self.cpu_frame % 2
             out, hist = passes.orc_taa(src, self.taa_hist[m2], inp.gb["motion"], depth, w, h, weights9, global_bytes, bool(s.taa_use_clipping),

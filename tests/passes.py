@@ -701,3 +701,53 @@ def orc_sky_luts(atmosphere_bytes, light_bytes, global_packed, t_res=128, m_res=
         img[(h_ // 8) * 8:, :] = 0
         img[:, (w_ // 8) * 8:] = 0
     return tuple(out)
+
+
+# ------------------------------------------------------------------ optional TAA stage
+def gpu_color_to_luminance(be, color_packed, w, h):
+    src = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat), color_packed)
+    dst = be.createImage(image_desc_2d(w, h, F.R8))
+    p = be.createComputePass("colorToLuminance.comp", [], "Color to Luminance")
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(dst, 0, 1)], sampledImages=[ImageResource(src, 0, 0)]), b"",
+                                                    (div_up(w, 8), div_up(h, 8), 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return be.downloadImage(dst, 0, np.uint8).reshape(h, w).copy()
+
+
+def orc_color_to_luminance(color_packed, w, h):
+    src = orc.Img(np.ascontiguousarray(color_packed, np.uint32), w, h, F.R11G11B10_uFloat)
+    dst = orc.new_image(w, h, F.R8, 1)
+    orc.lib().orc_color_to_luminance(src.ref(), dst.ref())
+    return dst.arr.reshape(h, w).copy()
+
+
+def gpu_temporal_supersampling(be, current, last, motion_snorm, depth_cur, depth_last, lum_cur, lum_last, w, h, global_packed, tonemap=True):
+    """TAA::computeTemporalSuperSampling bindings (TAA.cpp:106-136)"""
+    mk = lambda fmt, data: be.createImage(image_desc_2d(w, h, fmt), data)
+    cur, lst, tgt = mk(F.R11G11B10_uFloat, current), mk(F.R11G11B10_uFloat, last), mk(F.R11G11B10_uFloat, None)
+    vel, dc, dl = mk(F.RG16_sNorm, motion_snorm), mk(F.Depth32, depth_cur), mk(F.Depth32, depth_last)
+    lc, ll = mk(F.R8, lum_cur), mk(F.R8, lum_last)
+    p = be.createComputePass("temporalSupersampling.comp", [spec_bool(0, tonemap)], "Temporal supersampling")
+    gb = global_binding(be)
+    gb.set(global_packed)
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(
+        storageImages=[ImageResource(tgt, 0, 3)],
+        sampledImages=[ImageResource(cur, 0, 1), ImageResource(lst, 0, 2), ImageResource(vel, 0, 4), ImageResource(dc, 0, 5), ImageResource(dl, 0, 6), ImageResource(lc, 0, 7),
+                       ImageResource(ll, 0, 8)]), b"", (div_up(w, 8), div_up(h, 8), 1)))
+    be.prepareForDrawcallRecording()
+    be.renderFrame()
+    return be.downloadImage(tgt, 0, np.uint32).reshape(h, w).copy()
+
+
+def orc_temporal_supersampling(current, last, motion_snorm, depth_cur, depth_last, lum_cur, lum_last, w, h, global_packed, tonemap=True):
+    I = lambda a, dt, fmt: orc.Img(np.ascontiguousarray(a, dt), w, h, fmt)
+    cur, lst = I(current, np.uint32, F.R11G11B10_uFloat), I(last, np.uint32, F.R11G11B10_uFloat)
+    tgt = orc.new_image(w, h, F.R11G11B10_uFloat, 4)
+    vel, dc, dl = I(motion_snorm, np.int16, F.RG16_sNorm), I(depth_cur, np.float32, F.Depth32), I(depth_last, np.float32, F.Depth32)
+    lc, ll = I(lum_cur, np.uint8, F.R8), I(lum_last, np.uint8, F.R8)
+    g = orc.global_from_bytes(global_packed)
+    orc.lib().orc_temporal_supersampling(cur.ref(), lst.ref(), tgt.ref(), vel.ref(), dc.ref(), dl.ref(), lc.ref(), ll.ref(), C.byref(g), C.c_int32(int(tonemap)))
+    return tgt.arr.view(np.uint32).reshape(h, w).copy()

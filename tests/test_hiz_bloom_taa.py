@@ -218,3 +218,45 @@ def test_gpu_taa_4k_static_scene_is_identity(backend):
     v = pixfmt.unpack_r11g11b10(out)
     assert np.abs(v - 0.75).max() <= 0.75 * 2.0 ** -5
     assert np.array_equal(out, hist)
+
+
+# ------------------------------------------------------------------ optional TAA stage
+def _supersampling_inputs(w, h, seed=31):
+    from util import hdr_image
+    r = np.random.default_rng(0x504C4149 + seed)
+    cur = hdr_image(w, h, buffer_id=seed, pre_exposure=1.0)
+    last = hdr_image(w, h, buffer_id=seed + 1, pre_exposure=1.0)
+    # mostly similar frames with a band of strong change (contrast rejection) and a depth discontinuity (depth rejection)
+    last = np.where(r.random((h, w)) < 0.7, cur.reshape(h, w), last.reshape(h, w)).astype(np.uint32)
+    depth = np.full((h, w), 0.02, np.float32)
+    depth[:, w // 2:] = 0.2
+    depth_last = depth.copy()
+    depth_last[h // 3: h // 2] = 0.004
+    motion = np.zeros((h, w, 2), np.float32)
+    motion[..., 0] = 1.3 / w
+    motion[: h // 8] = 0.9  # reprojects off screen
+    return cur.reshape(h, w), last, pixfmt.pack_snorm16(motion), depth, depth_last
+
+
+def test_kat_color_to_luminance_weights():
+    px = pixfmt.pack_r11g11b10(np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.25, 0.25, 0.25], [4.0, 4.0, 4.0]], np.float32))
+    lum = passes.orc_color_to_luminance(px.reshape(1, 5), 5, 1).reshape(-1)
+    assert lum.tolist() == [round(0.21 * 255), round(0.72 * 255), round(0.07 * 255), round(0.25 * 255), 255]  # luminance.inc weights, R8 store saturates
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tonemap", [(256, 144, True), (97, 61, False)])
+def test_gpu_temporal_supersampling_bit_exact(backend, w, h, tonemap):
+    from test_exposure_tonemap import _global
+    cur, last, motion, depth, depth_last = _supersampling_inputs(w, h)
+    lc_g = passes.gpu_color_to_luminance(backend, cur, w, h)
+    lc_o = passes.orc_color_to_luminance(cur, w, h)
+    assert np.array_equal(lc_g, lc_o)
+    ll = passes.orc_color_to_luminance(last, w, h)
+    g = _global(w, h, time=1.0)
+    a = passes.gpu_temporal_supersampling(backend, cur, last, motion, depth, depth_last, lc_o, ll, w, h, g, tonemap)
+    b = passes.orc_temporal_supersampling(cur, last, motion, depth, depth_last, lc_o, ll, w, h, g, tonemap)
+    assert np.array_equal(a, b)
+    # the test data exercises both outcomes of every rejection test
+    same = a == cur
+    assert 0.05 < same.mean() < 0.95
