@@ -35,6 +35,7 @@ typedef struct plrf_settings {
     /* input producers recorded as compute passes instead of uploaded (0 = uploaded): lightMatrix.comp after the depth pyramid */
     uint32_t run_light_matrix; float volumetrics_max_distance;
     uint32_t taa_use_separate_supersampling, taa_supersample_use_tonemapping; /* TAASettings::useSeparateSupersampling (off), supersampleUseTonemapping */
+    uint32_t sdf_debug_mode, sdf_debug_tile_usage_with_hiz, sdf_debug_use_influence_radius; /* SDFDebugSettings (SDFGI.h:9-15): mode != 0 replaces the frame by the debug view */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
 } plrf_settings;
 

@@ -157,6 +157,11 @@ void orc_deferred_shading(const orc_image* color, const orc_image* depth, const 
                           int32_t diffuseBRDF, int32_t directMultiscatterBRDF, int32_t geometricAA,
                           int32_t indirectLightingTech, uint32_t sunShadowCascadeCount);
 
+/* sdfDebugVisualisation.comp: instances = sdfInstances[] (without the 16-byte count header), tiles = cameraCulledTiles[] */
+void orc_sdf_debug_visualisation(const orc_image* imageOut, const orc_light_buffer* light, const orc_image* skyLut, const orc_sdf_instance* instances,
+                                 const uint32_t* tiles, const orc_shadow_cascade_info* shadowInfo, const orc_image* shadowMap, const orc_image* bindless,
+                                 int32_t nBindless, const orc_global* g, int32_t debugMode, int32_t shadowCascadeIndex);
+
 /* optional TAA stage: colorToLuminance.comp, temporalSupersampling.comp */
 void orc_color_to_luminance(const orc_image* src, const orc_image* dstR8);
 void orc_temporal_supersampling(const orc_image* currentFrame, const orc_image* lastFrame, const orc_image* target, const orc_image* velocity,

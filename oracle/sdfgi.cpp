@@ -498,3 +498,54 @@ extern "C" void orc_indirect_light_upscale(const orc_image* dstYSHP, const orc_i
             }
     });
 }
+
+// sdfDebugVisualisation.comp:73-133. debugMode: 1 lit SDF, 2 camera tile usage, 3 normals, 4 raymarching steps.
+// Fields of TraceResult the shader leaves uninitialised without a hit start at zero here (they reach no output in that case).
+extern "C" void orc_sdf_debug_visualisation(const orc_image* outP, const orc_light_buffer* light, const orc_image* skyLutP, const orc_sdf_instance* instances,
+                                            const uint32_t* tiles, const orc_shadow_cascade_info* shadowInfo, const orc_image* shadowMapP, const orc_image* bindless,
+                                            int32_t nBindless, const orc_global* g, int32_t debugMode, int32_t shadowCascadeIndex) {
+    (void)nBindless;
+    const Image &imageOut = img(outP), &skyLut = img(skyLutP), &shadowMap = img(shadowMapP);
+    const mat4 lightMatrix = toMat4(shadowInfo->lightMatrices[shadowCascadeIndex]);
+    parallelFor(imageOut.h, [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < imageOut.w; x++) {
+                const ivec2 uv(x, y);
+                const vec3 cameraToPixel = -VFromiUV(uv, g);
+                const ivec2 tileUV(x / (int)cullingTileSize, y / (int)cullingTileSize);
+                const uint32_t tileIndex = tileIndexFromTileUV(tileUV, g);
+                const vec3 rayStart = v3(g->cameraPosition) + g->nearPlane * cameraToPixel;
+                TraceResult tr;
+                tr.hit = false;
+                tr.closestHitDistance = 10000.f;
+                tr.hitPos = vec3(0.f); tr.N = vec3(0.f); tr.albedo = vec3(0.f); tr.hitCount = 0;
+                const uint32_t* cullingTile = tiles + (size_t)tileIndex * tileStrideUints;
+                const int objectCount = (int)cullingTile[0];
+                for (int i = 0; i < objectCount; i++) {
+                    const orc_sdf_instance& instance = instances[cullingTile[1 + i]];
+                    traceRayTroughSDFInstance(instance, rayStart, img(&bindless[instance.sdfTextureIndex]), cameraToPixel, tr);
+                }
+                const float shadow = simpleShadow(tr.hitPos, lightMatrix, shadowMap, BORDER_BLACK);
+                vec3 color(0.f);
+                if (tr.hit || debugMode == 2) {
+                    if (debugMode == 1) {
+                        vec3 sunLight = light->sunStrengthExposed * vec3(light->sunColor[0], light->sunColor[1], light->sunColor[2]);
+                        sunLight = sunLight * shadow;
+                        const vec3 ambient(0.15f);
+                        const float NoL = gclamp(dot(tr.N, vec3(g->sunDirection[0], g->sunDirection[1], g->sunDirection[2])), 0.f, 1.f);
+                        color = tr.albedo * (ambient + sunLight * NoL);
+                    } else if (debugMode == 2) {
+                        const float percentage = (float)cullingTile[0] / (float)maxObjectsPerTile;
+                        color = percentage >= 1.f ? vec3(1.f, 0.f, 0.f) : vec3(percentage);
+                    } else if (debugMode == 3) {
+                        color = tr.N * 0.5f + 0.5f;
+                    } else if (debugMode == 4) {
+                        color = vec3((float)tr.hitCount / 128.f);
+                    }
+                } else {
+                    color = sampleSkyLut(cameraToPixel, skyLut);
+                }
+                imageStore(imageOut, uv, vec4(color, 1.f));
+            }
+    });
+}

@@ -256,7 +256,7 @@ static const size_t sdfCameraCullingTileSize = 32; // SDFGI.cpp:10
 static const size_t maxSdfObjectsPerTile = 100;    // SDFGI.cpp:11
 static const size_t sdfInstanceSize = 96;          // sizeof(SDFInstance), SDFGI.h:31-37
 
-void SDFGI::init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& ts, int sunShadowCascadeIndex, uint32_t maxInstances) { // SDFGI.cpp:48-258
+void SDFGI::init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& ts, const SDFDebugSettings& ds, int sunShadowCascadeIndex, uint32_t maxInstances) { // SDFGI.cpp:48-258
     const uint32_t tw = ts.halfResTrace ? screenW / 2 : screenW, th = ts.halfResTrace ? screenH / 2 : screenH;
     for (int i = 0; i < 2; i++) {
         m_indirectDiffuse_Y_SH[i] = be.createImage(desc2D(tw, th, ImageFormat::RGBA16_sFloat), nullptr, 0);
@@ -280,13 +280,21 @@ void SDFGI::init(RenderBackend& be, int screenW, int screenH, const SDFTraceSett
         // the reference sizes this for 1920x1080 only (SDFGI.cpp:145-151); sized here for the tile-index range the shaders
         // produce: stride = ceil(screenW / 32) (full-res, sdfCulling.inc:17-20) times the trace image's tile rows
         const size_t strideX = (size_t)std::ceil(screenW / float(sdfCameraCullingTileSize));
-        const size_t rows = (size_t)std::ceil(th / float(sdfCameraCullingTileSize));
+        // (the debug visualisation culls at full resolution, SDFGI.cpp:340-350: rows for the full screen height)
+        const size_t rows = (size_t)std::ceil(std::max<uint32_t>(th, (uint32_t)screenH) / float(sdfCameraCullingTileSize));
         const size_t tileSize = maxSdfObjectsPerTile * sizeof(uint32_t) + sizeof(uint32_t);
         sb.size = strideX * std::max<size_t>(rows, 1) * tileSize;
         m_sdfCameraCulledTiles = be.createStorageBuffer(sb);
     }
     ub.size = sizeof(float);
     m_sdfTraceInfluenceRangeBuffer = be.createUniformBuffer(ub);
+    {
+        ComputePassDescription d; // createSDFDebugShaderDescription, SDFGI.cpp:13-28
+        d.name = "Visualize SDF";
+        d.shaderDescription.srcPathRelative = "sdfDebugVisualisation.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, ds.visualisationMode), spec(1, sunShadowCascadeIndex)};
+        m_sdfDebugVisualisationPass = be.createComputePass(d);
+    }
     {
         ComputePassDescription d;
         d.name = "Indirect diffuse SDF trace";
@@ -337,6 +345,23 @@ SDFGI::IndirectLightingImages SDFGI::getIndirectLightingResults(bool tracedHalfR
 void SDFGI::computeIndirectLighting(RenderBackend& be, const FrameIndexCounter&, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const {
     diffuseSDFTrace(be, deps, s, band);
     filterIndirectDiffuse(be, deps, s, band);
+}
+
+void SDFGI::renderSDFVisualization(RenderBackend& be, ImageHandle target, const SDFTraceDependencies& deps, const SDFDebugSettings& ds, const SDFTraceSettings& ts) const {
+    // SDFGI.cpp:334-369
+    const float sdfInfluenceRadius = ds.useInfluenceRadiusForDebug ? ts.traceInfluenceRadius : 0.f;
+    const ImageDescription td = be.getImageDescription(m_indirectLightingFullRes_CoCg);
+    const bool useHiZCulling = ds.visualisationMode == SDFVisualisationMode::CameraTileUsage && ds.showCameraTileUsageWithHiZ;
+    sdfInstanceCulling(be, deps, (int)td.width, (int)td.height, sdfInfluenceRadius, useHiZCulling, nullptr);
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_sdfDebugVisualisationPass;
+    exe.genericInfo.resources.storageImages = {ImageResource(target, 0, 0)};
+    exe.genericInfo.resources.sampledImages = {ImageResource(deps.skyLut, 0, 2), ImageResource(deps.shadowMap, 0, 7)};
+    exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 1), StorageBufferResource(m_sdfInstanceBuffer, true, 3),
+                                                StorageBufferResource(m_sdfCameraCulledTiles, true, 4), StorageBufferResource(m_sdfCameraFrustumCulledInstances, true, 5),
+                                                StorageBufferResource(deps.sunShadowInfoBuffer, true, 6)};
+    dispatch8(exe, td.width, td.height);
+    be.setComputePassExecution(exe);
 }
 
 void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling, const GiBand* band) const {
@@ -615,7 +640,7 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     }
     m_taa.init(m_be, W, H, s.taa);
     m_bloom.init(m_be);
-    m_sdfGi.init(m_be, W, H, s.sdfTrace, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
+    m_sdfGi.init(m_be, W, H, s.sdfTrace, s.sdfDebug, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
     const float influence = s.sdfTrace.traceInfluenceRadius;
     (void)influence;
 }
@@ -917,6 +942,32 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     m_sceneRenderTargetIndex = (m_sceneRenderTargetIndex + 1) % 2;
     const FrameRenderTargets currentRenderTarget = m_frameRenderTargets[m_sceneRenderTargetIndex];
 
+    const bool bandMode = settings.band.enabled();
+    if (settings.sdfDebug.visualisationMode != SDFVisualisationMode::None) { // RenderFrontend.cpp:321-340
+        if (bandMode) throw std::runtime_error("the SDF debug visualisation is not supported in band rendering");
+        for (auto& items : m_exchangeItems) items.clear();
+        // [renderDepthPrepass: input]
+        computeDepthPyramid(currentRenderTarget.depthBuffer);
+        computeColorBufferHistogram(m_postProcessBuffers[0]);
+        if (settings.runSkyLuts) updateTransmissionLut();
+        computeExposure();
+        if (settings.runSkyLuts) updateSkyLut();
+        if (settings.runLightMatrix) computeSunLightMatrices();
+        // [renderSunShadowCascades: input]
+        SDFTraceDependencies deps = m_frustumScratch;
+        deps.currentFrame = currentRenderTarget;
+        deps.previousFrame = previousRenderTarget;
+        deps.depthHalfRes = m_depthHalfRes;
+        deps.worldSpaceNormals = m_worldSpaceNormalImage;
+        deps.skyLut = m_skyLut;
+        deps.shadowMap = m_shadowMaps[settings.shading.sunShadowCascadeCount - 1];
+        deps.lightBuffer = m_lightBuffer;
+        deps.sunShadowInfoBuffer = m_sunShadowInfoBuffer;
+        deps.depthMinMaxPyramid = m_minMaxDepthPyramid;
+        m_sdfGi.renderSDFVisualization(m_be, m_postProcessBuffers[0], deps, settings.sdfDebug, settings.sdfTrace);
+        computeTonemapping(m_postProcessBuffers[0]);
+        return;
+    }
     if (m_isBRDFLutShaderDescriptionStale) {
         computeBRDFLut();
         m_isBRDFLutShaderDescriptionStale = false;

@@ -86,6 +86,13 @@ struct TAASettings {
     bool useMipBias = true;
 };
 struct BloomSettings { bool enabled = true; float strength = 0.05f; float radius = 1.5f; };
+// Techniques/SDFGI.h:9-15
+enum class SDFVisualisationMode : int { None = 0, VisualizeSDF = 1, CameraTileUsage = 2, SDFNormals = 3, RaymarchingSteps = 4 };
+struct SDFDebugSettings {
+    SDFVisualisationMode visualisationMode = SDFVisualisationMode::None;
+    bool showCameraTileUsageWithHiZ = true;
+    bool useInfluenceRadiusForDebug = false;
+};
 struct SDFTraceSettings {
     bool halfResTrace = true;
     bool strictInfluenceRadiusCutoff = true;
@@ -155,7 +162,11 @@ struct SDFTraceDependencies {
 
 class SDFGI {
 public:
-    void init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& traceSettings, int sunShadowCascadeIndex, uint32_t maxInstances);
+    void init(RenderBackend& be, int screenW, int screenH, const SDFTraceSettings& traceSettings, const SDFDebugSettings& debugSettings, int sunShadowCascadeIndex,
+              uint32_t maxInstances);
+    // SDFGI::renderSDFVisualization, Techniques/SDFGI.cpp:334-369
+    void renderSDFVisualization(RenderBackend& be, ImageHandle target, const SDFTraceDependencies& deps, const SDFDebugSettings& debugSettings,
+                                const SDFTraceSettings& traceSettings) const;
     // packed { uint count; uint pad[3]; SDFInstance[] } and { vec3 min; pad; vec3 max; pad }[] as SDFGI::updateSDFScene builds them
     void updateSDFScene(RenderBackend& be, const void* instanceBufferData, size_t instanceBytes, const void* worldBBData, size_t bbBytes);
     void computeIndirectLighting(RenderBackend& be, const FrameIndexCounter& fi, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band = nullptr) const;
@@ -173,7 +184,7 @@ public:
 private:
     uint32_t m_sdfInstanceCount = 0;
     RenderPassHandle m_diffuseSDFTracePass, m_indirectDiffuseFilterSpatialPass[2], m_indirectDiffuseFilterTemporalPass, m_indirectLightingUpscale,
-        m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ;
+        m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ, m_sdfDebugVisualisationPass;
 };
 
 // Techniques/Sky.h:6-15 (everything in km); laid out as the std140 block of sky.inc:1-10 (56 bytes)
@@ -198,6 +209,7 @@ struct FramePipelineSettings {
     TAASettings taa;
     BloomSettings bloom;
     SDFTraceSettings sdfTrace;
+    SDFDebugSettings sdfDebug; // visualisationMode != None replaces the frame by the debug view (RenderFrontend.cpp:321-340)
     ShadingConfig shading;
     // which groups of prepareRenderpasses are recorded (all on = the full frame)
     bool runExposure = true, runHiZ = true, runGI = true, runShading = true, runTAA = true, runBloom = true, runTonemap = true;

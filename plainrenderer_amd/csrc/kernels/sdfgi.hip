@@ -244,6 +244,8 @@ struct TraceResult {
     float closestHitDistance;
     vec3 hitPos;
     vec3 albedo;
+    vec3 N;       // only written by the WITH_NORMAL instantiation (sdfDebugVisualisation.comp)
+    int hitCount; // "
 };
 
 // SDF.inc:42-86
@@ -266,7 +268,8 @@ PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mn, vec3 mx, float* tOut)
     return hit;
 }
 
-// SDF.inc:101-184. `inst` and `sdf` are wave uniform.
+// SDF.inc:101-184. `inst` and `sdf` are wave uniform (diffuse trace) or per lane (debug visualisation).
+template <bool WITH_NORMAL = false>
 PLR_DI void traceRayTroughSDFInstance(const SDFInstance& inst, vec3 rayStartWorld, const ImgView& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
     const float* m = inst.worldToLocal;
     const vec3 localExtends = ld3(inst.localExtends);
@@ -308,7 +311,14 @@ PLR_DI void traceRayTroughSDFInstance(const SDFInstance& inst, vec3 rayStartWorl
                 const float lastStepSizeLocal = d / (1.f - (d - dLast));
                 localSamplePos += rayDirection * lastStepSizeLocal;
                 // the reference also evaluates normalFromSDF and the transformed normal here; neither reaches an output of
-                // sdfDiffuseTrace.comp (only the debug visualisation reads traceResult.N), so they are not computed
+                // sdfDiffuseTrace.comp (only the debug visualisation reads traceResult.N and hitCount), so they are computed on request
+                if (WITH_NORMAL) {
+                    tr.hitCount = i;
+                    const vec3 nUV = localSamplePos / localExtends + 0.5f;
+                    const vec3 nl = normalFromSDF(nUV, localExtends, sdf);
+                    // transpose(mat3(worldToLocal)) * N
+                    tr.N = vec3(m[0] * nl.x + m[1] * nl.y + m[2] * nl.z, m[4] * nl.x + m[5] * nl.y + m[6] * nl.z, m[8] * nl.x + m[9] * nl.y + m[10] * nl.z);
+                }
                 tr.albedo = vpow(ld3(inst.meanAlbedo), 2.2f);
                 const float lastStepSizeGlobal = lastStepSizeLocal * localToGlobalScale;
                 tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeGlobal);
@@ -472,5 +482,97 @@ static int launchSdfDiffuseTrace(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("sdfDiffuseTrace.comp", launchSdfDiffuseTrace);
+
+
+// ------------------------------------------------------------------------------------------------
+// sdfDebugVisualisation.comp:73-133 (host Techniques/SDFGI.cpp:334-369): primary rays from the camera through the tile's
+// instance list. debugMode 1 lit SDF, 2 camera tile usage, 3 normals, 4 raymarching steps.
+template <int MODE>
+__global__ __launch_bounds__(256) void sdfDebugVisualisationKernel(ImgView imageOut, const LightBuffer* __restrict__ light, ImgView skyLut,
+                                                                   const SdfInstanceBuffer* __restrict__ instanceBuffer, const CulledInstancesPerTile* __restrict__ tiles,
+                                                                   const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
+                                                                   uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int coverW, int coverH,
+                                                                   int yBase, uint32_t tileCapacity, uint32_t instanceCapacity) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= coverW || py >= coverH) return;
+    const vec3 cameraToPixel = -VFromiUV(px, py, g);
+    const uint32_t tileIndex = min(tileIndexFromTileUV(px / (int)kCullingTileSize, py / (int)kCullingTileSize, g), tileCapacity - 1u);
+    const vec3 rayStart = ld3(g->cameraPosition) + g->nearPlane * cameraToPixel;
+    TraceResult tr;
+    tr.hit = false;
+    tr.closestHitDistance = 10000.f;
+    tr.hitPos = vec3(0.f); tr.N = vec3(0.f); tr.albedo = vec3(0.f); tr.hitCount = 0;
+    const CulledInstancesPerTile* tile = tiles + tileIndex;
+    const uint32_t objectCountRaw = tile->objectCount;
+    const int objectCount = (int)min(objectCountRaw, kMaxObjectsPerTile);
+    for (int i = 0; i < objectCount; i++) {
+        const uint32_t instIndex = min(tile->indices[i], instanceCapacity - 1u);
+        const SDFInstance& inst = instanceBuffer->instances[instIndex];
+        const ImgView view = bindless[min(inst.sdfTextureIndex, bindlessCount - 1u)];
+        traceRayTroughSDFInstance<true>(inst, rayStart, view, cameraToPixel, tr);
+    }
+    vec3 color(0.f);
+    if (tr.hit || MODE == 2) {
+        if (MODE == 1) {
+            // simpleShadow with the nearest / BLACK-border sampler (sdfDebugVisualisation.comp:101)
+            vec4 p = mulMat4(shadowInfo->lightMatrices[shadowCascadeIndex], vec4(tr.hitPos, 1.f));
+            p = p / p.w;
+            const vec2 xy(p.x * 0.5f + 0.5f, p.y * 0.5f + 0.5f);
+            const float actualDepth = gclamp(p.z, 0.f, 1.f);
+            const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_BLACK>(shadowMap, xy).x;
+            const float shadow = actualDepth > shadowMapDepth ? 1.f : 0.f;
+            vec3 sunLight = light->sunStrengthExposed * ld3(light->sunColor);
+            sunLight = sunLight * shadow;
+            const vec3 ambient(0.15f);
+            const float NoL = gclamp(dot(tr.N, ld3(g->sunDirection)), 0.f, 1.f);
+            color = tr.albedo * (ambient + sunLight * NoL);
+        } else if (MODE == 2) {
+            const float percentage = (float)objectCountRaw / (float)kMaxObjectsPerTile;
+            color = percentage >= 1.f ? vec3(1.f, 0.f, 0.f) : vec3(percentage);
+        } else if (MODE == 3) {
+            color = tr.N * 0.5f + 0.5f;
+        } else if (MODE == 4) {
+            color = vec3((float)tr.hitCount / 128.f);
+        }
+    } else {
+        color = sampleSkyLut(cameraToPixel, skyLut);
+    }
+    Texel<F_R11G11B10>::store(imageOut.ptr, (size_t)py * (size_t)imageOut.w + px, vec4(color, 1.f));
+}
+
+static int launchSdfDebugVisualisation(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_R11G11B10, "sdfDebugVisualisation imageOut")) return rc;
+    if (int rc = c.needSbuf(1, sizeof(LightBuffer), "sdfDebugVisualisation lightStorageBuffer")) return rc;
+    if (int rc = c.needSampled(2, F_R11G11B10, "sdfDebugVisualisation skyLut")) return rc;
+    if (int rc = c.needSbuf(3, 16 + sizeof(SDFInstance), "sdfDebugVisualisation sdfInstanceBuffer")) return rc;
+    if (int rc = c.needSbuf(4, sizeof(CulledInstancesPerTile), "sdfDebugVisualisation cameraCulledTileBuffer")) return rc;
+    if (int rc = c.needSbuf(6, sizeof(ShadowCascadeInfo), "sdfDebugVisualisation sunShadowInfo")) return rc;
+    if (int rc = c.needSampled(7, F_D16, "sdfDebugVisualisation shadowMap")) return rc;
+    if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "sdfDebugVisualisation: global texture array (set 2) is empty");
+    const int mode = c.specInt(0, 0), cascade = c.specInt(1, 3);
+    if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDebugVisualisation: shadowCascadeIndex must be 0..3");
+    const ImgView& out = c.storage[0];
+    const PassCtx::RowSpan rs = c.rowSpan(out.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    const uint32_t tileCapacity = (uint32_t)(c.sbuf[4].size / sizeof(CulledInstancesPerTile));
+    const uint32_t instanceCapacity = (uint32_t)((c.sbuf[3].size - 16u) / sizeof(SDFInstance));
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+#define PLR_DBG_ARGS out, (const LightBuffer*)c.sbuf[1].ptr, c.sampled[2], (const SdfInstanceBuffer*)c.sbuf[3].ptr, (const CulledInstancesPerTile*)c.sbuf[4].ptr, \
+                     (const ShadowCascadeInfo*)c.sbuf[6].ptr, c.sampled[7], c.bindless, c.bindlessCount, c.global, cascade, w, h, y0, tileCapacity, instanceCapacity
+    switch (mode) {
+        case 1: sdfDebugVisualisationKernel<1><<<grid, 256, 0, c.stream>>>(PLR_DBG_ARGS); break;
+        case 2: sdfDebugVisualisationKernel<2><<<grid, 256, 0, c.stream>>>(PLR_DBG_ARGS); break;
+        case 3: sdfDebugVisualisationKernel<3><<<grid, 256, 0, c.stream>>>(PLR_DBG_ARGS); break;
+        case 4: sdfDebugVisualisationKernel<4><<<grid, 256, 0, c.stream>>>(PLR_DBG_ARGS); break;
+        default: sdfDebugVisualisationKernel<0><<<grid, 256, 0, c.stream>>>(PLR_DBG_ARGS); break; // None: hits stay black, misses show the sky
+    }
+#undef PLR_DBG_ARGS
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("sdfDebugVisualisation.comp", launchSdfDebugVisualisation);
 
 } // namespace plr

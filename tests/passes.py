@@ -751,3 +751,39 @@ def orc_temporal_supersampling(current, last, motion_snorm, depth_cur, depth_las
     g = orc.global_from_bytes(global_packed)
     orc.lib().orc_temporal_supersampling(cur.ref(), lst.ref(), tgt.ref(), vel.ref(), dc.ref(), dl.ref(), lc.ref(), ll.ref(), C.byref(g), C.c_int32(int(tonemap)))
     return tgt.arr.view(np.uint32).reshape(h, w).copy()
+
+
+def gpu_sdf_debug(be, w, h, sky_packed, sky_w, sky_h, light_bytes, instance_bytes, tiles_u32, shadow_info, shadow_map_u16, shadow_res, global_packed, mode, cascade=2):
+    """SDFGI::renderSDFVisualization's visualisation pass, Techniques/SDFGI.cpp:351-369 (the culling passes before it are gpu_sdf_culling)"""
+    global_binding(be).set(global_packed)
+    out = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat))
+    sky = be.createImage(image_desc_2d(sky_w, sky_h, F.R11G11B10_uFloat), sky_packed)
+    shadow = be.createImage(image_desc_2d(shadow_res, shadow_res, F.Depth16), np.ascontiguousarray(shadow_map_u16))
+    light = be.createStorageBuffer(20, light_bytes)
+    inst = be.createStorageBuffer(len(instance_bytes), instance_bytes)
+    tiles = be.createStorageBuffer(tiles_u32.nbytes, tiles_u32.tobytes())
+    culled = be.createStorageBuffer(16)
+    sinfo = be.createStorageBuffer(304, shadow_info)
+    p = be.createComputePass("sdfDebugVisualisation.comp", [spec_int(0, mode), spec_int(1, cascade)], "Visualize SDF")
+    be.newFrame()
+    be.setComputePassExecution(ComputePassExecution(p, RenderPassResources(
+        storageImages=[ImageResource(out, 0, 0)], sampledImages=[ImageResource(sky, 0, 2), ImageResource(shadow, 0, 7)],
+        storageBuffers=[StorageBufferResource(light, True, 1), StorageBufferResource(inst, True, 3), StorageBufferResource(tiles, True, 4), StorageBufferResource(culled, True, 5),
+                        StorageBufferResource(sinfo, True, 6)]), b"", (math.ceil(w / 8.0), math.ceil(h / 8.0), 1)))
+    be.renderFrame()
+    return be.downloadImage(out, 0, np.uint32).reshape(h, w).copy()
+
+
+def orc_sdf_debug(w, h, sky_packed, sky_w, sky_h, light_bytes, instance_bytes, tiles_u32, shadow_info, shadow_map_u16, shadow_res, global_packed, bindless_arr, n_bindless,
+                  mode, cascade=2):
+    out = orc.new_image(w, h, F.R11G11B10_uFloat, 4)
+    sky = orc.Img(sky_packed, sky_w, sky_h, F.R11G11B10_uFloat)
+    shadow = orc.Img(np.ascontiguousarray(shadow_map_u16), shadow_res, shadow_res, F.Depth16)
+    light = C.create_string_buffer(light_bytes, 20)
+    inst = C.create_string_buffer(instance_bytes[16:], len(instance_bytes) - 16)
+    tiles = np.ascontiguousarray(tiles_u32, np.uint32)
+    sinfo = C.create_string_buffer(shadow_info, 304)
+    g = orc.global_from_bytes(global_packed)
+    orc.lib().orc_sdf_debug_visualisation(out.ref(), light, sky.ref(), inst, _p(tiles), sinfo, shadow.ref(), bindless_arr, C.c_int32(n_bindless), C.byref(g), C.c_int32(mode),
+                                          C.c_int32(cascade))
+    return out.arr.view(np.uint32).reshape(h, w).copy()
