@@ -179,6 +179,14 @@ void orc_sky_multiscatter_lut(const orc_image* lut, const orc_image* transmissio
 void orc_sky_lut(const orc_image* lut, const orc_image* transmissionLut, const orc_image* multiscatterLut, const void* atmosphereSettings56,
                  const orc_light_buffer* light, const orc_global* g);
 
+/* volumetric froxel lighting (froxelVolumeMaterial, froxelLightScattering, volumeLightingReprojection, volumetricLightingIntegration .comp);
+ * settings52 = the 52-byte std140 VolumetricLightingSettings block */
+void orc_froxel_volume_material(const orc_image* materialVolume, const orc_image* noiseTexture, const void* settings52, const orc_global* g);
+void orc_froxel_light_scattering(const orc_image* scatteringTransmittanceVolume, const orc_image* sunShadowMap, const orc_image* materialVolume,
+                                 const orc_shadow_cascade_info* shadowInfo, const orc_light_buffer* light, const void* settings52, const orc_global* g);
+void orc_volume_lighting_reprojection(const orc_image* target, const orc_image* inputVolume, const orc_image* historyVolume, const void* settings52, const orc_global* g);
+void orc_volumetric_lighting_integration(const orc_image* integrationVolume, const orc_image* scatteringTransmittanceVolume, const void* settings52);
+
 /* ---- config 1: CPU SDF bake (AssetPipeline/SceneSDF.cpp) ---- */
 /* positions: nVerts x 3 floats, indices: triangle list. Triangle normal = normalize(cross(v0 - v2, v0 - v1)) (SceneSDF.cpp:273).
  * outHalf: resX*resY*resZ half floats, x fastest. Returns 0, -1 (bad sizes) or -2 (index out of range). */

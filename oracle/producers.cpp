@@ -313,3 +313,169 @@ extern "C" void orc_sky_lut(const orc_image* lutP, const orc_image* transmission
             }
     });
 }
+
+// ====================================================================================================================
+// Volumetric froxel lighting: froxelVolumeMaterial.comp, froxelLightScattering.comp, volumeLightingReprojection.comp,
+// volumetricLightingIntegration.comp with volumetricFroxelLighting.inc, volume shading helpers. Host: Techniques/Volumetrics.cpp:119-243.
+namespace {
+
+struct VolSettings { // volumetricFroxelLighting.inc:6-16 (std140, 52 bytes) == orc_volumetric_settings
+    float windSampleOffset[3], sampleOffset;
+    float scatteringCoefficients[3], maxDistance;
+    float absorptionCoefficient, baseDensity, densityNoiseRange, densityNoiseScale, phaseFunctionG;
+};
+
+const float kFroxelK = 3.f; // volumetricFroxelLighting.inc:20
+float froxelUVToDepth(float uvZ, float maxDistance) { // :23-31
+    const float remaped = (det_expf(kFroxelK * uvZ) - 1.f) / (det_expf(kFroxelK) - 1.f);
+    return remaped * maxDistance;
+}
+float depthToFroxelUVZ(float depth, float maxDistance) { // :33-41
+    const float linear = depth / maxDistance;
+    return det_logf(linear * (det_expf(kFroxelK) - 1.f) + 1.f) / kFroxelK;
+}
+
+// the froxel centre's world position as the three producers compute it (:25-29 of each shader); jitter = settings.sampleOffset or 0
+vec3 froxelWorldPosition(int x, int y, int z, const Image& vol, float jitter, const orc_global* g, float maxDistance, vec3* Vout, vec3* uvOut, bool ndcForm2) {
+    const vec3 uv(((float)x + 0.5f + jitter) / (float)vol.w, ((float)y + 0.5f + jitter) / (float)vol.h, ((float)z + 0.5f + jitter) / (float)vol.d);
+    // froxelVolumeMaterial / reprojection: 2 * (uv - 0.5); froxelLightScattering: 2 * uv - 1
+    const vec2 ndc = ndcForm2 ? vec2(2.f * uv.x - 1.f, 2.f * uv.y - 1.f) : vec2(2.f * (uv.x - 0.5f), 2.f * (uv.y - 0.5f));
+    const vec3 fwd(g->cameraForward[0], g->cameraForward[1], g->cameraForward[2]);
+    const vec3 V = calculateViewDirectionFromPixel(ndc, fwd, vec3(g->cameraUp[0], g->cameraUp[1], g->cameraUp[2]), vec3(g->cameraRight[0], g->cameraRight[1], g->cameraRight[2]),
+                                                   g->cameraTanFovHalf, g->cameraAspectRatio);
+    const vec3 posWorld = vec3(g->cameraPosition[0], g->cameraPosition[1], g->cameraPosition[2]) - V / dot(-V, fwd) * froxelUVToDepth(uv.z, maxDistance);
+    if (Vout) *Vout = V;
+    if (uvOut) *uvOut = uv;
+    return posWorld;
+}
+
+void store3D(const Image& im, int x, int y, int z, vec4 v) {
+    if (x < 0 || y < 0 || z < 0 || x >= im.w || y >= im.h || z >= im.d) return; // imageStore out of bounds is dropped
+    storeTexel(im, x, y, z, v);
+}
+vec4 fetch3D(const Image& im, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= im.w || y >= im.h || z >= im.d) return vec4(0.f); // texelFetch out of bounds reads 0
+    return loadTexel(im, x, y, z);
+}
+
+} // namespace
+
+// froxelVolumeMaterial.comp:17-43
+extern "C" void orc_froxel_volume_material(const orc_image* materialP, const orc_image* noiseP, const void* settings52, const orc_global* g) {
+    const Image &material = img(materialP), &noiseTexture = img(noiseP);
+    VolSettings s;
+    std::memcpy(&s, settings52, sizeof(s));
+    parallelFor(material.d * material.h, [&](int r0, int r1) {
+        for (int r = r0; r < r1; r++) {
+            const int z = r / material.h, y = r % material.h;
+            for (int x = 0; x < material.w; x++) {
+                const vec3 posWorld = froxelWorldPosition(x, y, z, material, s.sampleOffset, g, s.maxDistance, nullptr, nullptr, false);
+                const float noiseScale = 0.5f;
+                const vec3 noiseSample = posWorld * noiseScale + vec3(s.windSampleOffset[0], s.windSampleOffset[1], s.windSampleOffset[2]);
+                const float noise = texture3D(noiseTexture, LINEAR, REPEAT, noiseSample).x;
+                vec3 scatteringCoefficient(s.scatteringCoefficients[0], s.scatteringCoefficients[1], s.scatteringCoefficients[2]);
+                float absorptionCoefficient = s.absorptionCoefficient;
+                float densityMultiplier = s.baseDensity;
+                densityMultiplier += s.densityNoiseRange * (noise - 0.5f);
+                densityMultiplier = gmax(densityMultiplier, 0.f);
+                scatteringCoefficient = scatteringCoefficient * densityMultiplier;
+                absorptionCoefficient *= densityMultiplier;
+                store3D(material, x, y, z, vec4(scatteringCoefficient, absorptionCoefficient));
+            }
+        }
+    });
+}
+
+// froxelLightScattering.comp:31-63 (the sun shadow cascade is hard-wired to index 2, :43)
+extern "C" void orc_froxel_light_scattering(const orc_image* outP, const orc_image* shadowMapP, const orc_image* materialP, const orc_shadow_cascade_info* shadowInfo,
+                                            const orc_light_buffer* light, const void* settings52, const orc_global* g) {
+    const Image &out = img(outP), &shadowMap = img(shadowMapP), &material = img(materialP);
+    VolSettings s;
+    std::memcpy(&s, settings52, sizeof(s));
+    mat4 lightMatrix;
+    std::memcpy(lightMatrix.c, shadowInfo->lightMatrices[2], 64);
+    parallelFor(out.d * out.h, [&](int r0, int r1) {
+        for (int r = r0; r < r1; r++) {
+            const int z = r / out.h, y = r % out.h;
+            for (int x = 0; x < out.w; x++) {
+                vec3 V;
+                const vec3 posWorld = froxelWorldPosition(x, y, z, out, s.sampleOffset, g, s.maxDistance, &V, nullptr, true);
+                // simpleShadow with the nearest / black-border sampler
+                vec4 p = lightMatrix * vec4(posWorld, 1.f);
+                p = p / p.w;
+                const float actualDepth = gclamp(p.z, 0.f, 1.f);
+                const float shadowMapDepth = texture2D(shadowMap, NEAREST, BORDER_BLACK, vec2(p.x, p.y) * 0.5f + 0.5f).x;
+                const float shadow = actualDepth > shadowMapDepth ? 1.f : 0.f;
+                const float sunStrength = shadow * light->sunStrengthExposed;
+                const vec3 L(g->sunDirection[0], g->sunDirection[1], g->sunDirection[2]);
+                const float VoL = dot(-V, L);
+                const float gg = s.phaseFunctionG;
+                const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f)); // phaseGreenstein
+                const vec4 sa = fetch3D(material, x, y, z);
+                const vec3 scatteringCoefficient = sa.xyz();
+                const float absorptionCoefficient = sa.w;
+                const vec3 constantAmbientLighting(0.02f);
+                const vec3 inscattering = (sunStrength * phase * vec3(light->sunColor[0], light->sunColor[1], light->sunColor[2]) + constantAmbientLighting) * scatteringCoefficient;
+                const vec3 extinctionCoefficient = scatteringCoefficient + absorptionCoefficient;
+                const float transmittance = computeLuminance(extinctionCoefficient);
+                store3D(out, x, y, z, vec4(inscattering, transmittance));
+            }
+        }
+    });
+}
+
+// volumeLightingReprojection.comp:18-61
+extern "C" void orc_volume_lighting_reprojection(const orc_image* targetP, const orc_image* inputP, const orc_image* historyP, const void* settings52, const orc_global* g) {
+    const Image &target = img(targetP), &inputVolume = img(inputP), &historyVolume = img(historyP);
+    VolSettings s;
+    std::memcpy(&s, settings52, sizeof(s));
+    mat4 vpPrev;
+    std::memcpy(vpPrev.c, g->viewProjectionPrevious, 64);
+    parallelFor(target.d * target.h, [&](int r0, int r1) {
+        for (int r = r0; r < r1; r++) {
+            const int z = r / target.h, y = r % target.h;
+            for (int x = 0; x < target.w; x++) {
+                const vec4 current = fetch3D(inputVolume, x, y, z);
+                const vec3 posWorld = froxelWorldPosition(x, y, z, target, 0.f, g, s.maxDistance, nullptr, nullptr, false);
+                vec4 ndcPrevious = vpPrev * vec4(posWorld, 1.f);
+                ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
+                const vec3 camPrev(g->cameraPositionPrevious[0], g->cameraPositionPrevious[1], g->cameraPositionPrevious[2]);
+                const vec3 V_history = normalize(camPrev - posWorld);
+                const float historyDistance = distance(posWorld, camPrev);
+                const float historyDepth = historyDistance * dot(-V_history, vec3(g->cameraForwardPrevious[0], g->cameraForwardPrevious[1], g->cameraForwardPrevious[2]));
+                const vec3 historyUV(ndcPrevious.x * 0.5f + 0.5f, ndcPrevious.y * 0.5f + 0.5f, depthToFroxelUVZ(historyDepth, s.maxDistance));
+                vec4 history = texture3D(historyVolume, LINEAR, CLAMP, historyUV);
+                float alpha = 0.95f;
+                if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
+                if (g->cameraCut) history = current;
+                const vec4 result = current * (1.f - alpha) + history * alpha; // mix
+                store3D(target, x, y, z, result);
+            }
+        }
+    });
+}
+
+// volumetricLightingIntegration.comp:17-42
+extern "C" void orc_volumetric_lighting_integration(const orc_image* outP, const orc_image* inP, const void* settings52) {
+    const Image &integrationVolume = img(outP), &scatteringTransmittanceVolume = img(inP);
+    VolSettings s;
+    std::memcpy(&s, settings52, sizeof(s));
+    parallelFor(integrationVolume.h, [&](int y0, int y1) {
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < integrationVolume.w; x++) {
+                vec3 inscatteringTotal(0.f);
+                float transmittance = 1.f;
+                const int resZ = integrationVolume.d;
+                for (int z = 0; z <= resZ; z++) { // sic: one slice past the volume (the fetch reads 0, the store is dropped)
+                    const vec4 it = fetch3D(scatteringTransmittanceVolume, x, y, z);
+                    const float depthStart = froxelUVToDepth((float)z / (float)resZ, s.maxDistance);
+                    const float depthEnd = froxelUVToDepth((float)(z + 1) / (float)resZ, s.maxDistance);
+                    const float segmentLength = depthEnd - depthStart;
+                    const vec3 inscattering = integrateInscattering(it.xyz(), vec3(it.w), segmentLength);
+                    inscatteringTotal = inscatteringTotal + inscattering;
+                    transmittance *= det_expf(-it.w * segmentLength);
+                    store3D(integrationVolume, x, y, z, vec4(inscatteringTotal, transmittance));
+                }
+            }
+    });
+}

@@ -638,6 +638,27 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         d.shaderDescription.srcPathRelative = "skyLut.comp";
         m_skyLutPass = m_be.createComputePass(d);
     }
+    {
+        // Volumetrics::init (Techniques/Volumetrics.cpp:19-117): froxel volumes of the integration volume's size; the 32^3 R8 Perlin noise is an
+        // input (generate3DPerlinNoise is asset code), uploaded by the caller into "perlinNoise3D"
+        ImageDescription fd = m_be.getImageDescription(m_volumetricIntegrationVolume);
+        m_scatteringTransmittanceVolume = m_be.createImage(fd, nullptr, 0);
+        m_volumetricLightingHistory[0] = m_be.createImage(fd, nullptr, 0);
+        m_volumetricLightingHistory[1] = m_be.createImage(fd, nullptr, 0);
+        m_volumeMaterialVolume = m_be.createImage(fd, nullptr, 0);
+        ImageDescription nd;
+        nd.width = nd.height = nd.depth = 32; nd.type = ImageType::Type3D; nd.format = ImageFormat::R8; nd.usageFlags = ImageUsageFlags::Sampled;
+        m_perlinNoise3D = m_be.createImage(nd, nullptr, 0);
+        ComputePassDescription d;
+        d.name = "Froxel volume material"; d.shaderDescription.srcPathRelative = "froxelVolumeMaterial.comp";
+        m_froxelVolumeMaterialPass = m_be.createComputePass(d);
+        d.name = "Froxel light scattering"; d.shaderDescription.srcPathRelative = "froxelLightScattering.comp";
+        m_froxelScatteringTransmittancePass = m_be.createComputePass(d);
+        d.name = "Volumetric light integration"; d.shaderDescription.srcPathRelative = "volumetricLightingIntegration.comp";
+        m_volumetricLightingIntegration = m_be.createComputePass(d);
+        d.name = "Volumetric lighting reprojection"; d.shaderDescription.srcPathRelative = "volumeLightingReprojection.comp";
+        m_volumetricLightingReprojection = m_be.createComputePass(d);
+    }
     m_taa.init(m_be, W, H, s.taa);
     m_bloom.init(m_be);
     m_sdfGi.init(m_be, W, H, s.sdfTrace, s.sdfDebug, s.shading.sunShadowCascadeCount - 1, s.maxSdfInstances);
@@ -662,6 +683,11 @@ ImageHandle FramePipeline::image(const std::string& n) const {
     if (n == "brdfLut") return m_brdfLut;
     if (n == "skyLut") return m_skyLut;
     if (n == "skyMultiscatterLut") return m_skyMultiscatterLut;
+    if (n == "perlinNoise3D") return m_perlinNoise3D;
+    if (n == "volumetricHistory0") return m_volumetricLightingHistory[0];
+    if (n == "volumetricHistory1") return m_volumetricLightingHistory[1];
+    if (n == "scatteringTransmittanceVolume") return m_scatteringTransmittanceVolume;
+    if (n == "volumeMaterialVolume") return m_volumeMaterialVolume;
     if (n == "transmissionLut") return m_transmissionLut;
     if (n == "volumetricIntegrationVolume") return m_volumetricIntegrationVolume;
     if (n.size() == 7 && n.compare(0, 6, "shadow") == 0) return m_shadowMaps[(n[6] - '0') & 3];
@@ -863,6 +889,61 @@ void FramePipeline::computeSunLightMatrices() { // RenderFrontend.cpp:840-872
     m_be.setComputePassExecution(exe);
 }
 
+void FramePipeline::computeVolumetricLighting(float deltaTime) { // Volumetrics::computeVolumetricLighting, Techniques/Volumetrics.cpp:119-243
+    m_volumetricsState.sampleOffset = radicalInverseBase2((uint32_t)m_frameIndex.mod8()) - 0.5f; // hammersley2D(frameIndexMod8).x - 0.5
+    for (int i = 0; i < 3; i++) m_volumetricsState.windSampleOffset[i] += windSettings.vector[i] * windSettings.speed * deltaTime;
+    VolumetricsBufferContents contents;
+    contents.state = m_volumetricsState;
+    contents.settings = volumetricsSettings;
+    m_be.setUniformBufferData(m_volumetricsInfoBuffer, &contents, sizeof(contents));
+    const ImageDescription md = m_be.getImageDescription(m_volumeMaterialVolume);
+    auto groups = [&](ComputePassExecution& exe, float groupSize, bool flat) {
+        exe.dispatchCount[0] = (uint32_t)std::ceil(md.width / groupSize);
+        exe.dispatchCount[1] = (uint32_t)std::ceil(md.height / groupSize);
+        exe.dispatchCount[2] = flat ? 1u : (uint32_t)std::ceil(md.depth / groupSize);
+    };
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_froxelVolumeMaterialPass;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_volumeMaterialVolume, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_perlinNoise3D, 0, 1)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 2)};
+        groups(exe, 4.f, false);
+        m_be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_froxelScatteringTransmittancePass;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_scatteringTransmittanceVolume, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_shadowMaps[settings.shading.sunShadowCascadeCount - 1], 0, 1), ImageResource(m_volumeMaterialVolume, 0, 2)};
+        exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sunShadowInfoBuffer, true, 3), StorageBufferResource(m_lightBuffer, true, 4)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 5)};
+        groups(exe, 4.f, false);
+        m_be.setComputePassExecution(exe);
+    }
+    const size_t frameIndexMod2 = m_frameIndex.mod2();
+    const ImageHandle reprojectionTarget = m_volumetricLightingHistory[frameIndexMod2];
+    const ImageHandle reprojectionHistory = m_volumetricLightingHistory[(frameIndexMod2 + 1) % 2];
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_volumetricLightingReprojection;
+        exe.genericInfo.resources.storageImages = {ImageResource(reprojectionTarget, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(m_scatteringTransmittanceVolume, 0, 1), ImageResource(reprojectionHistory, 0, 2)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 3)};
+        groups(exe, 4.f, false);
+        m_be.setComputePassExecution(exe);
+    }
+    {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_volumetricLightingIntegration;
+        exe.genericInfo.resources.storageImages = {ImageResource(m_volumetricIntegrationVolume, 0, 0)};
+        exe.genericInfo.resources.sampledImages = {ImageResource(reprojectionTarget, 0, 1)};
+        exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 2)};
+        groups(exe, 8.f, true);
+        m_be.setComputePassExecution(exe);
+    }
+}
+
 void FramePipeline::updateTransmissionLut() { // Sky::updateTransmissionLut, Techniques/Sky.cpp:260-272
     const uint32_t res = 128;
     ComputePassExecution exe;
@@ -1025,7 +1106,10 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace, &gb);
         } else m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace);
     }
-    // [volumetrics: input]
+    if (settings.runVolumetrics) {
+        if (band) throw std::runtime_error("the volumetric froxel passes are not supported in band rendering");
+        computeVolumetricLighting(m_lastDeltaTime);
+    }
     if (settings.runShading) computeDeferredShading(currentRenderTarget.colorBuffer, currentRenderTarget);
     // [sky: folded into the deferred pass' sky stand-in]
     ImageHandle currentSrc = currentRenderTarget.colorBuffer;
@@ -1125,6 +1209,7 @@ void FramePipeline::updateGlobalShaderInfo(float deltaTime, float time) { // Ren
 
 void FramePipeline::frame(const CameraExtrinsic& camera, float deltaTime, float time) { // Runtime/main.cpp:79-90
     m_frameIndex.markNewFrame();
+    m_lastDeltaTime = deltaTime; // Timer::getDeltaTimeFloat() of this frame (Volumetrics.cpp:124)
     // RenderFrontend::prepareNewFrame, RenderFrontend.cpp:198-278
     m_be.updateShaderCode();
     m_be.newFrame();

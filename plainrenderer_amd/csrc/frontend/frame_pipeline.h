@@ -200,6 +200,21 @@ struct AtmosphereSettings {
 };
 static_assert(sizeof(AtmosphereSettings) == 56, "AtmosphereSettings layout");
 
+// Techniques/Volumetrics.h:5-18 and the std140 block of volumetricFroxelLighting.inc:6-16 (state first, then settings: 52 bytes)
+struct VolumetricsSettings {
+    float scatteringCoefficients[3] = {1.f, 1.f, 1.f};
+    float maxDistance = 30.f;
+    float absorptionCoefficient = 1.f;
+    float baseDensity = 0.003f;
+    float densityNoiseRange = 0.008f;
+    float densityNoiseScale = 0.5f;
+    float phaseFunctionG = 0.2f;
+};
+struct WindSettings { float vector[3] = {0.f, 0.f, 0.f}; float speed = 0.15f; };
+struct VolumetricsState { float windSampleOffset[3] = {0.f, 0.f, 0.f}; float sampleOffset = 0.f; };
+struct VolumetricsBufferContents { VolumetricsState state; VolumetricsSettings settings; };
+static_assert(sizeof(VolumetricsBufferContents) == 52, "VolumetricLightingSettings layout");
+
 struct FramePipelineSettings {
     uint32_t width = 1920, height = 1080;
     uint32_t shadowMapRes = 2048;  // RenderFrontend.cpp:40
@@ -216,6 +231,7 @@ struct FramePipelineSettings {
     BandSettings band; // width/height stay the WHOLE frame's
     // input producers recorded as compute passes instead of being uploaded by the caller
     bool runLightMatrix = false; // lightMatrix.comp after the depth pyramid (RenderFrontend.cpp:353, 840-872); needs the pyramid apex: not in band mode
+    bool runVolumetrics = false; // froxelVolumeMaterial / froxelLightScattering / volumeLightingReprojection / volumetricLightingIntegration (Volumetrics.cpp:119-243)
     bool runSkyLuts = false;     // skyTransmissionLut / skyMultiscatterLut / skyLut.comp (Techniques/Sky.cpp:260-316) instead of uploaded LUTs
     float volumetricsMaxDistance = 30.f; // VolumetricsSettings::maxDistance, the last cascade's minimum far plane
 };
@@ -258,6 +274,7 @@ private:
     void computeBRDFLut();
     void computeSunLightMatrices();
     void updateTransmissionLut();
+    void computeVolumetricLighting(float deltaTime);
     void updateSkyLut();
     void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
     void updateGlobalShaderInfo(float deltaTime, float time);
@@ -286,10 +303,15 @@ private:
     StorageBufferHandle m_histogramPerTileBuffer, m_histogramBuffer, m_lightBuffer, m_sunShadowInfoBuffer, m_depthPyramidSyncBuffer;
     RenderPassHandle m_histogramPerTilePass, m_histogramResetPass, m_histogramCombinePass, m_preExposeLightsPass, m_depthPyramidPass, m_depthDownscalePass,
         m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass, m_skyTransmissionLutPass, m_skyMultiscatterLutPass, m_skyLutPass;
-    ImageHandle m_skyMultiscatterLut;
+    ImageHandle m_skyMultiscatterLut, m_scatteringTransmittanceVolume, m_volumetricLightingHistory[2], m_volumeMaterialVolume, m_perlinNoise3D;
+    RenderPassHandle m_froxelVolumeMaterialPass, m_froxelScatteringTransmittancePass, m_volumetricLightingIntegration, m_volumetricLightingReprojection;
+    VolumetricsState m_volumetricsState;
+    float m_lastDeltaTime = 0.f;
     UniformBufferHandle m_atmosphereSettingsBuffer;
 public:
     AtmosphereSettings atmosphereSettings;
+    VolumetricsSettings volumetricsSettings;
+    WindSettings windSettings;
 private:
     TAA m_taa;
     Bloom m_bloom;

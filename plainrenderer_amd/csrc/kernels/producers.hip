@@ -342,4 +342,236 @@ PLR_REGISTER_SHADER("skyTransmissionLut.comp", sky_transmission_launch);
 PLR_REGISTER_SHADER("skyMultiscatterLut.comp", sky_multiscatter_launch);
 PLR_REGISTER_SHADER("skyLut.comp", sky_lut_launch);
 
+
+// ====================================================================================================================
+// Volumetric froxel lighting (oracle/producers.cpp has the same functions in the same operation order): froxelVolumeMaterial.comp,
+// froxelLightScattering.comp, volumeLightingReprojection.comp (4x4x4 workgroups = one 64-lane wave), volumetricLightingIntegration.comp.
+namespace froxel {
+
+struct VolSettings { // volumetricFroxelLighting.inc:6-16, 52 bytes
+    float windSampleOffset[3], sampleOffset;
+    float scatteringCoefficients[3], maxDistance;
+    float absorptionCoefficient, baseDensity, densityNoiseRange, densityNoiseScale, phaseFunctionG;
+};
+
+constexpr float kFroxelK = 3.f;
+PLR_DI float froxelUVToDepth(float uvZ, float maxDistance) {
+    const float remaped = (det_expf(kFroxelK * uvZ) - 1.f) / (det_expf(kFroxelK) - 1.f);
+    return remaped * maxDistance;
+}
+PLR_DI float depthToFroxelUVZ(float depth, float maxDistance) {
+    const float linear = depth / maxDistance;
+    return det_logf(linear * (det_expf(kFroxelK) - 1.f) + 1.f) / kFroxelK;
+}
+
+PLR_DI vec3 froxelWorldPosition(int x, int y, int z, const ImgView& vol, float jitter, const GlobalUbo* g, float maxDistance, vec3* Vout, bool ndcForm2) {
+    const vec3 uv(((float)x + 0.5f + jitter) / (float)vol.w, ((float)y + 0.5f + jitter) / (float)vol.h, ((float)z + 0.5f + jitter) / (float)vol.d);
+    const vec2 ndc = ndcForm2 ? vec2(2.f * uv.x - 1.f, 2.f * uv.y - 1.f) : vec2(2.f * (uv.x - 0.5f), 2.f * (uv.y - 0.5f));
+    const vec3 fwd = ld3(g->cameraForward);
+    const vec3 V = calculateViewDirectionFromPixel(ndc, fwd, ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
+    const vec3 posWorld = ld3(g->cameraPosition) - V / dot(-V, fwd) * froxelUVToDepth(uv.z, maxDistance);
+    if (Vout) *Vout = V;
+    return posWorld;
+}
+
+// trilinear sample with the sampler contract of image.h (8-bit sub-texel weights); ADDR = CLAMP or REPEAT; same term order as oracle/image.h texture3D
+template <int FMT, int ADDR> PLR_DI vec4 sampleLinear3D(const ImgView& im, vec3 uvw) {
+    int i0, j0, k0; float a, b, c;
+    linearCoord(uvw.x * (float)im.w, &i0, &a);
+    linearCoord(uvw.y * (float)im.h, &j0, &b);
+    linearCoord(uvw.z * (float)im.d, &k0, &c);
+    auto wrap = [](int i, int n) { return ADDR == REPEAT ? repeati(i, n) : clampi(i, n); };
+    const int x0 = wrap(i0, im.w), x1 = wrap(i0 + 1, im.w), y0 = wrap(j0, im.h), y1 = wrap(j0 + 1, im.h), z0 = wrap(k0, im.d), z1 = wrap(k0 + 1, im.d);
+    auto T = [&](int x, int y, int z) { return Texel<FMT>::load(im.ptr, ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x); };
+    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
+    vec4 r(0.f); // the sum starts from +0 like the oracle's loop (keeps the sign of an all-zero result)
+    r = r + T(x0, y0, z0) * ((a0 * b0) * c0);
+    r = r + T(x1, y0, z0) * ((a * b0) * c0);
+    r = r + T(x0, y1, z0) * ((a0 * b) * c0);
+    r = r + T(x1, y1, z0) * ((a * b) * c0);
+    r = r + T(x0, y0, z1) * ((a0 * b0) * c);
+    r = r + T(x1, y0, z1) * ((a * b0) * c);
+    r = r + T(x0, y1, z1) * ((a0 * b) * c);
+    r = r + T(x1, y1, z1) * ((a * b) * c);
+    return r;
+}
+
+PLR_DI size_t idx3(const ImgView& im, int x, int y, int z) { return ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x; }
+
+// thread -> froxel for the 4x4x4-workgroup passes: blocks of 64 lanes walk x fastest
+PLR_DI bool froxelOfThread(const ImgView& vol, int coverX, int coverY, int coverZ, int* x, int* y, int* z) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)coverX * coverY * coverZ;
+    if (i >= n) return false;
+    *x = (int)(i % coverX); *y = (int)((i / coverX) % coverY); *z = (int)(i / ((long long)coverX * coverY));
+    return true;
+}
+
+__global__ __launch_bounds__(256) void froxelVolumeMaterialKernel(ImgView material, ImgView noiseTexture, const VolSettings* __restrict__ sp, const GlobalUbo* __restrict__ g,
+                                                                  int cx, int cy, int cz) {
+    int x, y, z;
+    if (!froxelOfThread(material, cx, cy, cz, &x, &y, &z)) return;
+    const VolSettings s = *sp;
+    const vec3 posWorld = froxelWorldPosition(x, y, z, material, s.sampleOffset, g, s.maxDistance, nullptr, false);
+    const float noiseScale = 0.5f;
+    const vec3 noiseSample = posWorld * noiseScale + ld3(s.windSampleOffset);
+    const float noise = sampleLinear3D<F_R8, REPEAT>(noiseTexture, noiseSample).x;
+    vec3 scatteringCoefficient = ld3(s.scatteringCoefficients);
+    float absorptionCoefficient = s.absorptionCoefficient;
+    float densityMultiplier = s.baseDensity;
+    densityMultiplier += s.densityNoiseRange * (noise - 0.5f);
+    densityMultiplier = gmax(densityMultiplier, 0.f);
+    scatteringCoefficient = scatteringCoefficient * densityMultiplier;
+    absorptionCoefficient *= densityMultiplier;
+    Texel<F_RGBA16F>::store(material.ptr, idx3(material, x, y, z), vec4(scatteringCoefficient, absorptionCoefficient));
+}
+
+__global__ __launch_bounds__(256) void froxelLightScatteringKernel(ImgView out, ImgView shadowMap, ImgView material, const ShadowCascadeInfo* __restrict__ shadowInfo,
+                                                                   const LightBuffer* __restrict__ light, const VolSettings* __restrict__ sp, const GlobalUbo* __restrict__ g,
+                                                                   int cx, int cy, int cz) {
+    int x, y, z;
+    if (!froxelOfThread(out, cx, cy, cz, &x, &y, &z)) return;
+    const VolSettings s = *sp;
+    const float kPi = PLR_GLSL_PI;
+    vec3 V;
+    const vec3 posWorld = froxelWorldPosition(x, y, z, out, s.sampleOffset, g, s.maxDistance, &V, true);
+    vec4 p = mulMat4(shadowInfo->lightMatrices[2], vec4(posWorld, 1.f)); // sic: cascade 2 (:43)
+    p = p / p.w;
+    const float actualDepth = gclamp(p.z, 0.f, 1.f);
+    const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_BLACK>(shadowMap, vec2(p.x, p.y) * 0.5f + 0.5f).x;
+    const float shadow = actualDepth > shadowMapDepth ? 1.f : 0.f;
+    const float sunStrength = shadow * light->sunStrengthExposed;
+    const vec3 L = ld3(g->sunDirection);
+    const float VoL = dot(-V, L);
+    const float gg = s.phaseFunctionG;
+    const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
+    const bool inMaterial = x < material.w && y < material.h && z < material.d;
+    const vec4 sa = inMaterial ? Texel<F_RGBA16F>::load(material.ptr, idx3(material, x, y, z)) : vec4(0.f);
+    const vec3 scatteringCoefficient = sa.xyz();
+    const float absorptionCoefficient = sa.w;
+    const vec3 constantAmbientLighting(0.02f);
+    const vec3 inscattering = (sunStrength * phase * ld3(light->sunColor) + constantAmbientLighting) * scatteringCoefficient;
+    const vec3 extinctionCoefficient = scatteringCoefficient + absorptionCoefficient;
+    const float transmittance = computeLuminance(extinctionCoefficient);
+    Texel<F_RGBA16F>::store(out.ptr, idx3(out, x, y, z), vec4(inscattering, transmittance));
+}
+
+__global__ __launch_bounds__(256) void volumeLightingReprojectionKernel(ImgView target, ImgView inputVolume, ImgView historyVolume, const VolSettings* __restrict__ sp,
+                                                                        const GlobalUbo* __restrict__ g, int cx, int cy, int cz) {
+    int x, y, z;
+    if (!froxelOfThread(target, cx, cy, cz, &x, &y, &z)) return;
+    const VolSettings s = *sp;
+    const bool inInput = x < inputVolume.w && y < inputVolume.h && z < inputVolume.d;
+    const vec4 current = inInput ? Texel<F_RGBA16F>::load(inputVolume.ptr, idx3(inputVolume, x, y, z)) : vec4(0.f);
+    const vec3 posWorld = froxelWorldPosition(x, y, z, target, 0.f, g, s.maxDistance, nullptr, false);
+    vec4 ndcPrevious = mulMat4(g->viewProjectionPrevious, vec4(posWorld, 1.f));
+    ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
+    const vec3 camPrev = ld3(g->cameraPositionPrevious);
+    const vec3 V_history = normalize(camPrev - posWorld);
+    const float historyDistance = distance(posWorld, camPrev);
+    const float historyDepth = historyDistance * dot(-V_history, ld3(g->cameraForwardPrevious));
+    const vec3 historyUV(ndcPrevious.x * 0.5f + 0.5f, ndcPrevious.y * 0.5f + 0.5f, depthToFroxelUVZ(historyDepth, s.maxDistance));
+    vec4 history = sampleLinear3D<F_RGBA16F, CLAMP>(historyVolume, historyUV);
+    float alpha = 0.95f;
+    if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
+    if (g->cameraCut) history = current;
+    const vec4 result = current * (1.f - alpha) + history * alpha;
+    Texel<F_RGBA16F>::store(target.ptr, idx3(target, x, y, z), result);
+}
+
+PLR_DI vec3 integrateInscattering(vec3 inscattering, vec3 ext, float length) {
+    const vec3 e(det_expf(-ext.x * length), det_expf(-ext.y * length), det_expf(-ext.z * length));
+    const vec3 num = inscattering - inscattering * e;
+    return vec3(num.x / gmax(ext.x, 0.00001f), num.y / gmax(ext.y, 0.00001f), num.z / gmax(ext.z, 0.00001f));
+}
+
+__global__ __launch_bounds__(64) void volumetricLightingIntegrationKernel(ImgView integrationVolume, ImgView inVolume, const VolSettings* __restrict__ sp, int coverW, int coverH) {
+    const int x = (int)(blockIdx.x * 8u + (threadIdx.x & 7u)), y = (int)(blockIdx.y * 8u + (threadIdx.x >> 3));
+    if (x >= coverW || y >= coverH) return;
+    const VolSettings s = *sp;
+    vec3 inscatteringTotal(0.f);
+    float transmittance = 1.f;
+    const int resZ = integrationVolume.d;
+    for (int z = 0; z <= resZ; z++) { // sic: one slice past the volume (the fetch reads 0, the store is dropped)
+        const bool inside = x < inVolume.w && y < inVolume.h && z < inVolume.d;
+        const vec4 it = inside ? Texel<F_RGBA16F>::load(inVolume.ptr, idx3(inVolume, x, y, z)) : vec4(0.f);
+        const float depthStart = froxelUVToDepth((float)z / (float)resZ, s.maxDistance);
+        const float depthEnd = froxelUVToDepth((float)(z + 1) / (float)resZ, s.maxDistance);
+        const float segmentLength = depthEnd - depthStart;
+        const vec3 inscattering = integrateInscattering(it.xyz(), vec3(it.w), segmentLength);
+        inscatteringTotal = inscatteringTotal + inscattering;
+        transmittance *= det_expf(-it.w * segmentLength);
+        if (z < resZ) Texel<F_RGBA16F>::store(integrationVolume.ptr, idx3(integrationVolume, x, y, z), vec4(inscatteringTotal, transmittance));
+    }
+}
+
+static void cover3(const PassCtx& c, const ImgView& vol, int wg, int* cx, int* cy, int* cz) {
+    *cx = std::min((int)(c.dispatch[0] * (unsigned)wg), vol.w); *cy = std::min((int)(c.dispatch[1] * (unsigned)wg), vol.h); *cz = std::min((int)(c.dispatch[2] * (unsigned)wg), vol.d);
+}
+static unsigned blocksFor(int cx, int cy, int cz) { return (unsigned)(((long long)cx * cy * cz + 255) / 256); }
+
+static int launchMaterial(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "froxelVolumeMaterial materialVolume")) return rc;
+    if (int rc = c.needSampled(1, F_R8, "froxelVolumeMaterial noiseTexture")) return rc;
+    if (int rc = c.needUbuf(2, sizeof(VolSettings), "froxelVolumeMaterial SettingsBuffer")) return rc;
+    int cx, cy, cz;
+    cover3(c, c.storage[0], 4, &cx, &cy, &cz);
+    if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    froxelVolumeMaterialKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], (const VolSettings*)c.ubuf[2].ptr, c.global, cx, cy, cz);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+static int launchScattering(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "froxelLightScattering scatteringTransmittanceVolume")) return rc;
+    if (int rc = c.needSampled(1, F_D16, "froxelLightScattering sunShadowMap")) return rc;
+    if (int rc = c.needSampled(2, F_RGBA16F, "froxelLightScattering materialVolume")) return rc;
+    if (int rc = c.needSbuf(3, sizeof(ShadowCascadeInfo), "froxelLightScattering sunShadowInfo")) return rc;
+    if (int rc = c.needSbuf(4, sizeof(LightBuffer), "froxelLightScattering lightStorageBuffer")) return rc;
+    if (int rc = c.needUbuf(5, sizeof(VolSettings), "froxelLightScattering SettingsBuffer")) return rc;
+    int cx, cy, cz;
+    cover3(c, c.storage[0], 4, &cx, &cy, &cz);
+    if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    froxelLightScatteringKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], c.sampled[2], (const ShadowCascadeInfo*)c.sbuf[3].ptr,
+                                                                            (const LightBuffer*)c.sbuf[4].ptr, (const VolSettings*)c.ubuf[5].ptr, c.global, cx, cy, cz);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+static int launchReprojection(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needStorage(0, F_RGBA16F, "volumeLightingReprojection targetImage")) return rc;
+    if (int rc = c.needSampled(1, F_RGBA16F, "volumeLightingReprojection inputVolume")) return rc;
+    if (int rc = c.needSampled(2, F_RGBA16F, "volumeLightingReprojection historyVolume")) return rc;
+    if (int rc = c.needUbuf(3, sizeof(VolSettings), "volumeLightingReprojection SettingsBuffer")) return rc;
+    int cx, cy, cz;
+    cover3(c, c.storage[0], 4, &cx, &cy, &cz);
+    if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    volumeLightingReprojectionKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], c.sampled[2], (const VolSettings*)c.ubuf[3].ptr, c.global, cx, cy, cz);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+static int launchIntegration(const PassCtx& c) {
+    if (int rc = c.needStorage(0, F_RGBA16F, "volumetricLightingIntegration integrationVolume")) return rc;
+    if (int rc = c.needSampled(1, F_RGBA16F, "volumetricLightingIntegration scatteringTransmittanceVolume")) return rc;
+    if (int rc = c.needUbuf(2, sizeof(VolSettings), "volumetricLightingIntegration SettingsBuffer")) return rc;
+    const ImgView& out = c.storage[0];
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = std::min((int)(c.dispatch[1] * 8u), out.h);
+    if (w <= 0 || h <= 0 || c.dispatch[2] == 0) return 0;
+    volumetricLightingIntegrationKernel<<<dim3(divUp((unsigned)w, 8u), divUp((unsigned)h, 8u)), 64, 0, c.stream>>>(out, c.sampled[1], (const VolSettings*)c.ubuf[2].ptr, w, h);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+} // namespace froxel
+
+static int froxel_material_launch(const PassCtx& c) { return froxel::launchMaterial(c); }
+static int froxel_scattering_launch(const PassCtx& c) { return froxel::launchScattering(c); }
+static int froxel_reprojection_launch(const PassCtx& c) { return froxel::launchReprojection(c); }
+static int froxel_integration_launch(const PassCtx& c) { return froxel::launchIntegration(c); }
+PLR_REGISTER_SHADER("froxelVolumeMaterial.comp", froxel_material_launch);
+PLR_REGISTER_SHADER("froxelLightScattering.comp", froxel_scattering_launch);
+PLR_REGISTER_SHADER("volumeLightingReprojection.comp", froxel_reprojection_launch);
+PLR_REGISTER_SHADER("volumetricLightingIntegration.comp", froxel_integration_launch);
+
 } // namespace plr

@@ -178,3 +178,85 @@ def test_gpu_frame_with_compute_sky_luts(backend):
     assert np.array_equal(got[:96], s[:96])  # rows 96..99 are never dispatched: they keep what was uploaded
     assert np.array_equal(got[96:], inputs.sky.reshape(100, 200)[96:])
     fp.destroy()
+
+
+# ------------------------------------------------------------------ volumetric froxel lighting
+def _volumetric_inputs(seed=970):
+    from util import light_buffer_bytes
+    rng = np.random.default_rng(0x504C4149 + seed)
+    cam = Camera.look((15.0, -7.0, -6.0), (0.0, 0.16, 1.0), aspect=W / H)
+    cam_prev = Camera.look((14.9, -7.0, -6.1), (0.01, 0.16, 1.0), aspect=W / H)
+    sun = np.array([0.35, -0.8, 0.45]); sun /= np.linalg.norm(sun)
+    g = GlobalShaderInfo(frameIndex=5, sunDirection=(*sun, 0.0), time=0.5, deltaTime=1 / 60.0)
+    g.viewProjectionPrevious = cam_prev.view_projection()
+    g.cameraPosPrevious = (*cam_prev.position, 0.0)
+    g.cameraForwardPrevious = (*cam_prev.forward, 0.0)
+    cam.fill_global(g, W, H)
+    scene = synth.SynthScene(grid=2, cell=8.0, seed_id=seed)
+    info, maps = scene.shadow_cascades(cam, sun, 2.0, 60.0, 64)
+    fw, fh, fd = (W + 7) // 8, (H + 7) // 8, 16
+    noise = rng.integers(0, 256, size=(8, 8, 8), dtype=np.uint8)
+    from plainrenderer_amd import pixfmt
+    hist = pixfmt.pack_half(np.stack([rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0.001, 0.01, (fd, fh, fw))], -1)
+                            .astype(np.float32))
+    return (fw, fh, fd, noise, hist, maps[2], 64, info, light_buffer_bytes(sun_strength_exposed=12.8), passes.VOLUMETRIC_SETTINGS_DEFAULT, g.pack())
+
+
+def test_oracle_volumetrics_known_answers():
+    from plainrenderer_amd import pixfmt
+    args = _volumetric_inputs()
+    fw, fh, fd = args[:3]
+    material, scattering, target, integration = [pixfmt.unpack_half(a).reshape(fd, fh, fw, 4) for a in passes.orc_volumetrics(*args)]
+    assert np.isfinite(integration).all()
+    # material: coefficients * max(baseDensity + range * (noise - 0.5), 0): scattering rgb equal (coefficients 1,1,1), absorption = same density
+    assert np.allclose(material[..., 0], material[..., 1]) and np.allclose(material[..., 0], material[..., 3])
+    assert material.min() >= 0 and material.max() <= 0.003 + 0.008 * 0.5 + 1e-5
+    # integration: transmittance starts near 1, decreases monotonically with depth and stays positive; inscattering accumulates
+    T = integration[..., 3]
+    assert (T[0] > 0.99).all() and (np.diff(T, axis=0) <= 1e-3).all() and (T > 0).all()
+    assert (np.diff(integration[..., 0], axis=0) >= -1e-4).all()
+
+
+@pytest.mark.gpu
+def test_gpu_volumetrics_bit_exact(backend):
+    args = _volumetric_inputs()
+    a = passes.gpu_volumetrics(backend, *args)
+    b = passes.orc_volumetrics(*args)
+    for x, y, what in zip(a, b, ("material", "scattering", "reprojection", "integration")):
+        assert np.array_equal(x, y), what
+
+
+@pytest.mark.gpu
+def test_gpu_frame_with_compute_volumetrics(backend):
+    """the frame graph with the four froxel passes recorded before the shade (RenderFrontend.cpp:366-371): the integration volume the
+    shade reads is this frame's compute result, the history ping-pongs with the frame index"""
+    from plainrenderer_amd import pixfmt
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    from plainrenderer_amd.scene import taa_jitter_pixels  # noqa: F401
+    w, h = 256, 144
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(3)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=971)
+    fd = 16
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=fd, max_sdf_instances=64, run_volumetrics=1)
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=128, froxel_depth=fd, sun_direction=(0.35, -0.8, 0.45))
+    inputs.upload(fp)
+    noise = np.random.default_rng(0x504C4149 + 972).integers(0, 256, size=(32, 32, 32), dtype=np.uint8)
+    backend.uploadImage(fp.image("perlinNoise3D"), noise)
+    fw, fh = (w + 7) // 8, (h + 7) // 8
+    hist = np.zeros(fw * fh * fd * 4, np.uint16)
+    def radical_inverse_base2(i):
+        return int("{:032b}".format(i)[::-1], 2) * 2.3283064365386963e-10
+    for f in range(2):
+        fp.frame(cams[f + 1], 1 / 60.0, 0.5 + f / 60.0)
+        cpu_frame = fp.cpu_frame_index()
+        settings = struct.pack("<13f", 0.0, 0.0, 0.0, np.float32(radical_inverse_base2(cpu_frame % 8)) - np.float32(0.5), 1.0, 1.0, 1.0, 30.0, 1.0, 0.003, 0.008, 0.5, 0.2)
+        light = backend.downloadStorageBuffer(fp.storage_buffer("light"), 20).tobytes()
+        exp = passes.orc_volumetrics(fw, fh, fd, noise, hist.reshape(fd, fh, fw, 4), inputs.shadow_maps[2], 128, bytes(inputs.shadow_info), light, settings,
+                                     bytes(fp.submitted_globals()))
+        got_target = backend.downloadImage(fp.image("volumetricHistory%d" % (cpu_frame % 2)), 0, np.uint16)
+        assert np.array_equal(got_target, exp[2]), "reprojection target, frame %d" % f
+        assert np.array_equal(backend.downloadImage(fp.image("volumetricIntegrationVolume"), 0, np.uint16), exp[3]), "integration volume, frame %d" % f
+        hist = exp[2]
+    it = pixfmt.unpack_half(exp[3]).reshape(fd, fh, fw, 4)
+    assert np.isfinite(it).all() and (it[..., 3] > 0).all()
+    fp.destroy()
