@@ -188,24 +188,55 @@ def main():
 
     from plainrenderer_amd import RenderBackend, tiling
     from plainrenderer_amd.frame import FramePipeline
-    w, h = args.width, args.height
-    band = exchange = None
-    if world > 1:
-        # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
-        # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
-        w, h = 2 * args.width, (args.height // 2) * world
-        band = tiling.band_rows(h, world, rank)
-    elif args.force_bands:
-        band = (0, h)
-    be = RenderBackend(w, h, device=local_rank)
-    if band is not None:
-        fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res, band_row_begin=band[0], band_row_end=band[1])
-        exchange = tiling.Exchange(fp, tiling.DistTransport(rank, world, device=device), h, world, rank)
+
+    def make(mode):
+        """mode 'single': the 4K frame on this GPU; 'bands': one band of the N x larger frame; -> (be, fp, scene-tuple, w, h, band)"""
+        w_, h_ = args.width, args.height
+        band_ = None
+        if mode == "bands":
+            if world > 1:
+                # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
+                # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
+                w_, h_ = 2 * args.width, (args.height // 2) * world
+                band_ = tiling.band_rows(h_, world, rank)
+            else:
+                band_ = (0, h_)
+        be_ = RenderBackend(w_, h_, device=local_rank)
+        if band_ is not None:
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=band_[0], band_row_end=band_[1])
+            tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank)
+        else:
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res)
+        sc = build_scene(args, device, w_, h_, band_)
+        sc[2].upload(fp_)
+        be_.waitForGPUIdle()
+        return be_, fp_, sc, w_, h_, band_
+
+    parallelism_note = None
+    if world > 1 or args.force_bands:
+        # the band path needs RCCL point-to-point between neighbouring ranks; if it cannot run here (one frame is tried on every rank),
+        # every rank falls back to an independent 4K replica and the JSON line says so
+        ok = 1
+        try:
+            be, fp, (scene, cams, inputs), w, h, band = make("bands")
+            fp.frame(cams[1], 1.0 / 60.0, 0.5)
+            be.waitForGPUIdle()
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            parallelism_note = "%s: %s" % (type(e).__name__, str(e)[:200])
+            sys.stderr.write("rank %d: band rendering unavailable (%s)\n" % (rank, parallelism_note))
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            try:
+                fp.destroy(); be.shutdown()
+            except Exception:  # noqa: BLE001
+                pass
+            parallelism_note = parallelism_note or "band rendering failed on another rank"
+            be, fp, (scene, cams, inputs), w, h, band = make("single")
     else:
-        fp = FramePipeline(be, w, h, shadow_map_res=args.shadow_res)
-    scene, cams, inputs = build_scene(args, device, w, h, band)
-    inputs.upload(fp)
-    be.waitForGPUIdle()
+        be, fp, (scene, cams, inputs), w, h, band = make("single")
+    replicas = world > 1 and band is None
 
     frame_no = [0]
 
@@ -274,7 +305,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec full GI+shade+post @4K; %HBM roofline; 1/2/4/8-GPU scaling",
-            "value": round(1000.0 / ms_per_step * (w * h) / float(args.width * args.height), 3),
+            "value": round(1000.0 / ms_per_step * (w * h) / float(args.width * args.height) * (world if replicas else 1), 3),
             "unit": "frames/s (3840x2160-equivalent: frames/s x frame pixels / 8294400)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "host_ms_per_step": round(host_elapsed * 1000.0 / args.steps, 4),
@@ -283,7 +314,8 @@ def main():
                                    "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
                        "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res,
                        "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point "
-                                       "%d times per frame + one 512 B histogram all-reduce" % (w, h, world, h // world, 4)) if world > 1 else "single GPU"},
+                                       "%d times per frame + one 512 B histogram all-reduce" % (w, h, world, h // world, 4)) if (world > 1 and not replicas) else
+                                      ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
             "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roofline,
