@@ -36,6 +36,7 @@ typedef struct plrf_settings {
     uint32_t run_light_matrix; float volumetrics_max_distance;
     uint32_t taa_use_separate_supersampling, taa_supersample_use_tonemapping; /* TAASettings::useSeparateSupersampling (off), supersampleUseTonemapping */
     uint32_t sdf_debug_mode, sdf_debug_tile_usage_with_hiz, sdf_debug_use_influence_radius; /* SDFDebugSettings (SDFGI.h:9-15): mode != 0 replaces the frame by the debug view */
+    uint32_t band_taa_history_halo; /* rows of the TAA history exchanged between bands (default 32) */
     uint32_t run_volumetrics; /* the four froxel passes produce volumetricIntegrationVolume (reference default VolumetricsSettings; noise volume "perlinNoise3D" is an input) */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
 } plrf_settings;

@@ -1125,7 +1125,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     if (band) {
         // the bloom chain reads postHalo rows around the band; next frame's temporal filter reprojects into the history image
         if (settings.runBloom && settings.bloom.enabled) addExchangeItem(ExchangePost, currentSrc, 1, settings.band.postHalo);
-        if (settings.runTAA && settings.taa.enabled) addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.postHalo);
+        if (settings.runTAA && settings.taa.enabled) addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
         if (!m_exchangeItems[ExchangePost].empty()) exchangePoint(ExchangePost, "Exchange: resolved colour halo rows");
     }
     if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0));

@@ -64,7 +64,8 @@ struct BandSettings {
     uint32_t giHalo = 64;               // trace-resolution rows of the GI images exchanged before each spatial filter pass
     uint32_t giHistoryHalo = 16;        // trace-resolution rows of the filtered GI exchanged for the upscale / next frame's reprojection
     uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
-    uint32_t postHalo = 320;            // full-resolution rows of the temporal filter's result exchanged (bloom chain, TAA history)
+    uint32_t postHalo = 320;            // full-resolution rows of the temporal filter's result exchanged for the bloom chain
+    uint32_t taaHistoryHalo = 32;       // full-resolution rows of the TAA history exchanged (reach of next frame's reprojection + bicubic footprint)
     bool enabled() const { return rowEnd > rowBegin; }
 };
 enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeCount = 5 };

@@ -24,7 +24,8 @@ class PlrfSettings(C.Structure):
                                           "band_row_begin", "band_row_end", "band_gi_halo", "band_gi_history_halo", "band_color_halo", "band_post_halo",
                                           "run_light_matrix")] + [("volumetrics_max_distance", C.c_float), ("taa_use_separate_supersampling", C.c_uint32), ("taa_supersample_use_tonemapping", C.c_uint32),
                                                                               ("sdf_debug_mode", C.c_uint32), ("sdf_debug_tile_usage_with_hiz", C.c_uint32),
-                                                                              ("sdf_debug_use_influence_radius", C.c_uint32), ("run_volumetrics", C.c_uint32), ("run_sky_luts", C.c_uint32)]
+                                                                              ("sdf_debug_use_influence_radius", C.c_uint32), ("band_taa_history_halo", C.c_uint32), ("run_volumetrics", C.c_uint32),
+                                                                              ("run_sky_luts", C.c_uint32)]
 
 
 class PlrfExchangeItem(C.Structure):

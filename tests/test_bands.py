@@ -219,7 +219,7 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
     # partitioned frame must equal the unpartitioned one in every bit, over 3 frames of temporal feedback
     inputs = _make_inputs()
     full = _run_full(inputs, True, half_res)
-    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H)
     bands = _run_bands(inputs, 2, True, halos, half_res)
     mism = _compare(full, bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
@@ -244,7 +244,7 @@ def test_gpu_two_bands_fast_math_matches_full_frame():
     # the default (PLR_MATH_FAST) kernel set through the same partition: fast kernels are deterministic too
     inputs = _make_inputs()
     full = _run_full(inputs, False)
-    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H)
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H)
     bands = _run_bands(inputs, 2, False, halos)
     mism = _compare(full, bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
