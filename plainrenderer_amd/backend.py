@@ -432,6 +432,11 @@ class RenderBackend:
         b = np.ascontiguousarray(data)
         self._check(self.lib.plr_upload_image(self._h(image), C.c_uint32(mip), b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes)))
 
+    def recreateSwapchain(self, width, height):
+        """RenderBackend::recreateSwapchain (RenderBackend.h:38)"""
+        self._check(self.lib.plr_recreate_swapchain(C.c_uint32(width), C.c_uint32(height)))
+        self.width, self.height = width, height
+
     def getLastFrameCPUTime(self):
         """RenderBackend::getLastFrameCPUTime: host milliseconds spent inside the last renderFrame (flush + launches)"""
         ms = C.c_float()
