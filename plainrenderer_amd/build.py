@@ -19,6 +19,7 @@ EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, 
 # kernels_fast/*.hip: restructured kernels for PLR_MATH_FAST. FMA contraction on, divide/sqrt may use the v_rcp/v_rsq based
 # sequences; still no -ffast-math (NaN guards and comparisons keep IEEE semantics).
 FAST_FLAGS_REPLACE = {"-ffp-contract=off": "-ffp-contract=fast", "-fhip-fp32-correctly-rounded-divide-sqrt": "-fno-hip-fp32-correctly-rounded-divide-sqrt"}
+FAST_FLAGS_EXTRA = os.environ.get("PLR_FAST_FLAGS", "").split()  # experiment hook for the fast set only
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -48,7 +49,7 @@ def _headers_digest():
                 if f.endswith((".h", ".hpp")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(fh.read())
-    h.update(" ".join(FLAGS + sorted(FAST_FLAGS_REPLACE.values()) + EXTRA_FLAGS).encode())
+    h.update(" ".join(FLAGS + sorted(FAST_FLAGS_REPLACE.values()) + EXTRA_FLAGS + FAST_FLAGS_EXTRA).encode())
     return h.hexdigest()
 
 
@@ -61,7 +62,7 @@ def _compile(src, digest, verbose):
         return obj, False
     flags = FLAGS
     if os.sep + "kernels_fast" + os.sep in src:
-        flags = [FAST_FLAGS_REPLACE.get(f, f) for f in FLAGS]
+        flags = [FAST_FLAGS_REPLACE.get(f, f) for f in FLAGS] + FAST_FLAGS_EXTRA
     cmd = [HIPCC, "-x", "hip"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)

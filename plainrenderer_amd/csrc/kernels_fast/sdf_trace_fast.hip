@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
             const bool hitInRange = (tr.closestHitDistance < *influenceRangeP) || !STRICT_CUTOFF;
             if (!hitInRange || tr.closestHitDistance < 0.0001f) hitColor = vec3(0.f);
         } else {
-            hitColor = sampleSkyLut(L, skyLut);
+            hitColor = fastm::sampleSkyLut(L, skyLut);
         }
         mine.cr = hitColor.x; mine.cg = hitColor.y; mine.cb = hitColor.z;
     }

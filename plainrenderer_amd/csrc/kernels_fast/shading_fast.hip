@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
     const vec3 ray = camFwd + (-g->cameraTanFovHalf * ndy) * ld3(g->cameraUp) + (g->cameraTanFovHalf * g->cameraAspectRatio * ndx) * ld3(g->cameraRight);
     if (depth == 0.f) {
-        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(sampleSkyLut(nrm(ray), P.skyLut));
+        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(nrm(ray), P.skyLut));
         return;
     }
     const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
