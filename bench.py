@@ -47,6 +47,7 @@ def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_d
         "SDF camera tile culling": n_instances * 36 + tiles * 404 / 4,
         "Indirect diffuse SDF trace": 20 * M + sdf + (tiles / 4) * 404,
         "Indirect diffuse spatial filter": 30 * M,
+        "Indirect diffuse spatial filter (texel packing)": 30 * M,  # pre-pass of the fast kernel set: reads the 14 B/px inputs, writes 16 B/px packed texels
         "Indirect diffuse temporal filter": 56 * M,
         "Indirect lighting upscale": 14 * M + 16 * N,
         "Forward shading (deferred)": 32 * N + lut,
@@ -66,7 +67,7 @@ INPUT_HALO = 256  # full-res rows of G-buffer a band needs beyond its own: 2 * (
 
 
 PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries under profiles/ (a pass may launch more than one kernel)
-    "Indirect diffuse spatial filter": ["plr::spatialFilter", "plr::spatialPack"], "Forward shading (deferred)": ["plr::fastshade::deferredShading"],
+    "Indirect diffuse spatial filter": ["plr::spatialFilter"], "Indirect diffuse spatial filter (texel packing)": ["plr::spatialPack"], "Forward shading (deferred)": ["plr::fastshade::deferredShading"],
     "Temporal filtering": ["plr::fasttaa::temporalFilter"], "Indirect diffuse SDF trace": ["plr::fasttrace::sdfDiffuseTrace"],
     "Indirect lighting upscale": ["plr::faststream::indirectLightUpscale"], "Indirect diffuse temporal filter": ["plr::faststream::temporalGiFilter"],
     "Depth min/max pyramid": ["plr::hizBase", "plr::hizTail"], "Tonemap": ["plr::faststream::tonemapping"], "Apply bloom": ["plr::faststream::applyBloom"],
@@ -289,7 +290,7 @@ def main():
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         default_workload = (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None
         traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        roofline = {"bound": "hbm", "kernel": name, "hip_kernel": (PASS_KERNEL.get(name) or [None])[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
     if args.pass_table and rank == 0:
         tot = sum(r[1] * r[2] for r in table)

@@ -188,7 +188,12 @@ struct Backend {
     uint64_t allocated = 0;
     bool passTiming = false;
     int mathMode = PLR_MATH_FAST;
-    std::vector<hipEvent_t> passEvents; // 2 per execution
+    std::vector<hipEvent_t> passEvents; // pool; a timed segment uses two consecutive events
+    struct Segment { size_t firstEvent; const char* name; };
+    std::vector<Segment> segments;      // of the frame being launched / last launched with timing on
+    size_t eventsUsed = 0;
+    const char* currentPassName = nullptr;
+    bool timingNow = false;
     std::vector<plr_renderpass_time> lastTimings;
     std::set<std::string> callbackNames; // stable storage for the labels of host callback executions
     size_t timedExecutions = 0;
@@ -543,23 +548,49 @@ static int flushBindless() {
     return PLR_OK;
 }
 
+static int timingEvent(hipEvent_t* out) {
+    if (g->eventsUsed == g->passEvents.size()) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        g->passEvents.push_back(ev);
+    }
+    *out = g->passEvents[g->eventsUsed++];
+    return PLR_OK;
+}
+static int beginSegment(const char* name) {
+    hipEvent_t ev;
+    if (int rc = timingEvent(&ev)) return rc;
+    g->segments.push_back({g->eventsUsed - 1, name});
+    HIP_TRY(hipEventRecord(ev, g->stream));
+    return PLR_OK;
+}
+static int endSegment() {
+    hipEvent_t ev;
+    if (int rc = timingEvent(&ev)) return rc;
+    HIP_TRY(hipEventRecord(ev, g->stream));
+    return PLR_OK;
+}
+void PassCtx::splitTiming(const char* label) const {
+    if (!g || !g->timingNow || g->segments.empty()) return;
+    // close the running segment under "<pass> (<label>)" and open a new one under the pass name
+    const char* pass = g->currentPassName ? g->currentPassName : "";
+    g->segments.back().name = g->callbackNames.insert(std::string(pass) + " (" + label + ")").first->c_str();
+    if (endSegment() != PLR_OK) return;
+    (void)beginSegment(pass);
+}
+
 static int launchAll(bool timed) {
     const size_t n = g->executions.size();
-    if (timed) {
-        while (g->passEvents.size() < 2 * n) {
-            hipEvent_t ev;
-            HIP_TRY(hipEventCreate(&ev));
-            g->passEvents.push_back(ev);
-        }
-    }
+    g->timingNow = timed;
+    if (timed) { g->segments.clear(); g->eventsUsed = 0; }
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
     for (size_t i = 0; i < n; i++) {
         Execution& x = g->executions[i];
         if (x.callback) {
-            if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
+            if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
             const int crc = x.callback(x.callbackUser, (void*)g->stream);
             if (crc) return setErr(crc, "host callback '" + std::string(x.callbackName) + "' failed with code " + std::to_string(crc));
-            if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
+            if (timed) if (int rc = endSegment()) return rc;
             continue;
         }
         PassRes& p = *g->passes[x.pass];
@@ -571,12 +602,14 @@ static int launchAll(bool timed) {
         x.ctx.err = &g_err;
         x.ctx.scratchSlot = &p.scratch;
         x.ctx.scratchSize = &p.scratchSize;
-        if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i], g->stream));
+        g->currentPassName = p.name.c_str();
+        if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
         int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
         if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
         if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
-        if (timed) HIP_TRY(hipEventRecord(g->passEvents[2 * i + 1], g->stream));
+        if (timed) if (int trc = endSegment()) return trc;
     }
+    g->timingNow = false;
     return PLR_OK;
 }
 
@@ -592,10 +625,10 @@ int plr_render_frame(int /*present_to_screen*/) {
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->frameEnd, g->stream));
     g->frameRecorded = true;
-    g->timedExecutions = g->passTiming ? g->executions.size() : 0;
+    g->timedExecutions = g->passTiming ? g->segments.size() : 0;
     if (g->passTiming) {
         g->lastTimings.clear();
-        for (auto& x : g->executions) g->lastTimings.push_back({0.f, x.callback ? x.callbackName : g->passes[x.pass]->name.c_str()});
+        for (auto& sg : g->segments) g->lastTimings.push_back({0.f, sg.name});
     }
     g->lastCpuMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PLR_OK;
@@ -735,7 +768,7 @@ int plr_get_renderpass_timings(plr_renderpass_time* out_times, uint32_t* inout_c
     const uint32_t m = std::min(n, *inout_count);
     for (uint32_t i = 0; i < m; i++) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, g->passEvents[2 * i], g->passEvents[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, g->passEvents[g->segments[i].firstEvent], g->passEvents[g->segments[i].firstEvent + 1]));
         out_times[i].time_ms = ms;
         out_times[i].name = g->lastTimings[i].name;
     }

@@ -73,6 +73,9 @@ struct PassCtx {
     int needUbuf(int binding, size_t minSize, const char* what) const;
     int needGlobal() const;
     void* scratch(size_t bytes) const;
+    // pass timing (plr_set_pass_timing): a pass that launches an auxiliary kernel before its main one calls this between the two, so the
+    // auxiliary part is reported as its own entry "<pass name> (<label>)" and the pass entry times the main kernel alone
+    void splitTiming(const char* label) const;
 };
 
 typedef int (*LaunchFn)(const PassCtx&);

@@ -257,6 +257,7 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         else if (c.sampled[4].fmt == F_D32) spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, p0, p1);
         else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
         PLR_CHECK_LAUNCH(c);
+        c.splitTiming("texel packing");
     }
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK) spatialFilterFastKernel<FMT, TXv, SG, PK><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], \
                                                                                               c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk)
