@@ -184,6 +184,15 @@ int plr_get_image_description(plr_image_handle image, plr_image_desc* out_desc);
 int plr_set_math_mode(int mode);
 int plr_get_math_mode(int* out_mode);
 int plr_set_pass_timing(int enabled);
+/* Stream overlap (default off - a cross-stream dependency costs 15-20 us on MI355X, more than the hot path's short independent chains
+ * win back; PLR_STREAM_OVERLAP=1 in the environment turns it on at plr_setup). When on, plr_render_frame launches the
+ * recorded executions in order, but an execution that has no read-after-write / write-after-read / write-after-write hazard with the
+ * tail of the main stream - judged from the allocations it binds - is placed on one of three side HIP streams and runs beside it
+ * (the Vulkan backend derives its barriers from the same read/write tracking, RenderBackend.cpp:632-767, and leaves independent passes unordered).
+ * All side streams join the main stream before a host callback and at the end of the frame. Results do not depend on the setting.
+ * out_overlapped_executions: how many executions of the last plr_render_frame ran on a side stream. */
+int plr_set_stream_overlap(int enabled);
+int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
 int plr_get_last_frame_gpu_time(float* out_ms);
 /* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */

@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_host_callback_execution", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -400,6 +400,15 @@ class RenderBackend:
                                 d.manual_mip_count, bool(d.auto_create_mips))
 
     # -- additions (tests / benchmarks)
+    def setStreamOverlap(self, enabled):
+        self._check(self.lib.plr_set_stream_overlap(C.c_int(1 if enabled else 0)))
+
+    def getStreamOverlap(self):
+        """(enabled, executions of the last frame that ran on a side stream)"""
+        en, n = C.c_int(0), C.c_uint32(0)
+        self._check(self.lib.plr_get_stream_overlap(C.byref(en), C.byref(n)))
+        return bool(en.value), int(n.value)
+
     def setMathMode(self, fast):
         self._check(self.lib.plr_set_math_mode(C.c_int(1 if fast else 0)))
 

@@ -7,7 +7,9 @@
 // write->read barrier rule, RenderBackend.cpp:632-767, for free).
 #include "backend.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <set>
 #include <cmath>
 #include <cstring>
@@ -20,6 +22,10 @@ namespace plr {
 
 // ---------------------------------------------------------------- registry
 struct ShaderEntry { std::string name; LaunchFn fn = nullptr; LaunchFn fast = nullptr; };
+// shaders whose kernels index the global texture array (set 2): they may read any non-transient image
+static bool shaderReadsBindless(const std::string& shader) {
+    return shader == "deferredShading.comp" || shader == "sdfDiffuseTrace.comp" || shader == "sdfDebugVisualisation.comp";
+}
 static std::vector<ShaderEntry>& registry() {
     static std::vector<ShaderEntry> r;
     return r;
@@ -147,13 +153,21 @@ struct PassRes {
     std::string shader, name;
     std::vector<SpecConstant> spec;
     LaunchFn fn = nullptr, fast = nullptr;
+    bool readsBindless = false;
     void* scratch = nullptr;
     size_t scratchSize = 0;
 };
 
+// one resource an execution touches, for the hazard analysis of the stream scheduler: key = base address of the allocation
+// (an image with all its mips, a buffer), or one of the pseudo keys below
+struct Access { const void* key; bool write; };
+static const char kBindlessKeyStorage = 0;
+static const void* const kBindlessKey = &kBindlessKeyStorage; // "some image of the global texture array (set 2)"
+
 struct Execution {
     uint32_t pass;
     PassCtx ctx;
+    std::vector<Access> access;
     plr_host_callback callback = nullptr; // host callback execution (pass is unused)
     void* callbackUser = nullptr;
     const char* callbackName = ""; // interned in Backend::callbackNames
@@ -200,6 +214,15 @@ struct Backend {
     hipEvent_t frameStart = nullptr, frameEnd = nullptr;
     bool frameRecorded = false;
     float lastCpuMs = 0.f;
+    // stream scheduler (launchAll): independent passes of a frame run on side streams
+    static constexpr int kSideStreams = 3;
+    hipStream_t sideStreams[kSideStreams] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> orderEvents; // pool of timing-less events for cross-stream dependencies
+    size_t orderEventsUsed = 0;
+    bool overlap = false;                // off by default: see the measurement in the scheduler comment
+    int activeSideStreams = 1;           // side streams the scheduler uses (PLR_SIDE_STREAMS, 1..kSideStreams)
+    hipStream_t curStream = nullptr;     // stream of the execution being launched (timing events go there)
+    uint32_t lastOverlapped = 0;         // executions of the last frame that were placed on a side stream
 };
 
 // one backend per host thread: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
@@ -302,6 +325,9 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipEventCreate(&g->frameStart));
     HIP_TRY(hipEventCreate(&g->frameEnd));
     HIP_TRY(hipEventCreateWithFlags(&g->pinnedFree, hipEventDisableTiming));
+    for (auto& st : g->sideStreams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (const char* ov = std::getenv("PLR_STREAM_OVERLAP")) g->overlap = std::atoi(ov) != 0;
+    if (const char* ns = std::getenv("PLR_SIDE_STREAMS")) g->activeSideStreams = std::min(std::max(std::atoi(ns), 1), (int)Backend::kSideStreams);
     return plr_recreate_swapchain(width, height);
 }
 
@@ -316,6 +342,8 @@ int plr_shutdown(void) {
     for (auto& b : g->sbufs) if (b.dev) hipFree(b.dev);
     for (auto& p : g->passes) if (p->scratch) hipFree(p->scratch);
     for (auto ev : g->passEvents) hipEventDestroy(ev);
+    for (auto ev : g->orderEvents) hipEventDestroy(ev);
+    for (auto st : g->sideStreams) if (st) hipStreamDestroy(st);
     if (g->bindlessDev) hipFree(g->bindlessDev);
     if (g->pinned) hipHostFree(g->pinned);
     hipEventDestroy(g->frameStart); hipEventDestroy(g->frameEnd); hipEventDestroy(g->pinnedFree);
@@ -413,6 +441,21 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
     if (rc) { g->executions.pop_back(); return rc; }
     if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
     for (int i = 0; i < 3; i++) { x.ctx.dispatch[i] = e->dispatch_count[i]; x.ctx.base[i] = e->dispatch_base[i]; }
+    {
+        // what the execution may touch (stream scheduler): whole allocations, so a kernel that walks the mip chain of a bound image or
+        // addresses rows outside its dispatch is covered; uniform buffers are only written between frames
+        const plr_pass_resources& r = e->resources;
+        bool writesDefaultImage = false;
+        for (uint32_t i = 0; i < r.sampled_image_count; i++) x.access.push_back({resolveImage(r.sampled_images[i].image)->dev, false});
+        for (uint32_t i = 0; i < r.storage_image_count; i++) {
+            x.access.push_back({resolveImage(r.storage_images[i].image)->dev, true});
+            writesDefaultImage = writesDefaultImage || r.storage_images[i].image.type == PLR_IMAGE_DEFAULT;
+        }
+        for (uint32_t i = 0; i < r.storage_buffer_count; i++) x.access.push_back({g->sbufs[r.storage_buffers[i].buffer].dev, r.storage_buffers[i].read_only == 0});
+        x.access.push_back({g->passes[e->handle].get(), true}); // the pass's scratch memory: executions of one pass never overlap
+        if (g->passes[e->handle]->readsBindless) x.access.push_back({kBindlessKey, false});
+        if (writesDefaultImage) x.access.push_back({kBindlessKey, true});
+    }
     if (e->dispatch_base[2] != 0) { g->executions.pop_back(); return setErr(PLR_ERR_INVALID_ARGUMENT, "dispatch_base[2] must be 0"); }
     return PLR_OK;
 }
@@ -477,6 +520,7 @@ static int fillPass(PassRes& p, const plr_compute_pass_desc* desc) {
     if (desc->name) p.name = desc->name;
     p.fn = entry->fn;
     p.fast = entry->fast;
+    p.readsBindless = shaderReadsBindless(entry->name);
     p.spec.clear();
     for (uint32_t i = 0; i < desc->specialisation_constant_count; i++) {
         const auto& s = desc->specialisation_constants[i];
@@ -561,13 +605,13 @@ static int beginSegment(const char* name) {
     hipEvent_t ev;
     if (int rc = timingEvent(&ev)) return rc;
     g->segments.push_back({g->eventsUsed - 1, name});
-    HIP_TRY(hipEventRecord(ev, g->stream));
+    HIP_TRY(hipEventRecord(ev, g->curStream ? g->curStream : g->stream));
     return PLR_OK;
 }
 static int endSegment() {
     hipEvent_t ev;
     if (int rc = timingEvent(&ev)) return rc;
-    HIP_TRY(hipEventRecord(ev, g->stream));
+    HIP_TRY(hipEventRecord(ev, g->curStream ? g->curStream : g->stream));
     return PLR_OK;
 }
 void PassCtx::splitTiming(const char* label) const {
@@ -579,36 +623,190 @@ void PassCtx::splitTiming(const char* label) const {
     (void)beginSegment(pass);
 }
 
+// ---------------------------------------------------------------- stream scheduler
+// The recorded executions are launched in order, but not all on one stream: an execution only has to wait for the earlier ones it
+// has a hazard with (read-after-write, write-after-read, write-after-write on an allocation it binds). Executions without such a
+// dependency on the tail of the main stream go to one of kSideStreams side streams and overlap with it - in the frame of this
+// hot path the luminance histogram -> exposure chain (small, latency-bound kernels) runs beside the depth pyramid / culling chain.
+// Cross-stream dependencies are events; every side stream joins the main stream before a host callback and at the end of the
+// list, so a frame as a whole is still ordered on the main stream (what plr_wait_for_gpu_idle, readbacks and the band exchange
+// callbacks rely on).
+// Off by default (plr_set_stream_overlap(1) / PLR_STREAM_OVERLAP=1 turns it on): on MI355X / ROCm 7.2 a cross-stream dependency
+// (event record + barrier packet on another hardware queue) costs 15-20 us, more than the 4K frame's independent chain (four small
+// exposure kernels, 53 us) can win back. Measured ms per 4K frame: one in-order stream 1.187; exposure chain on one side stream with
+// two waits per frame 1.206; two side streams 1.277; per-execution placement on three side streams 1.332. Results are byte-identical
+// either way (tests/test_full_frame.py); the scheduler pays off only for longer independent chains (sky LUT / froxel producers).
+constexpr int kMaxStreams = 1 + Backend::kSideStreams;
+struct PlanNode {
+    int stream = 0;            // 0 = main, 1.. = side stream
+    std::vector<int> waits;    // executions on other streams to wait for
+    bool signal = false;       // somebody on another stream waits for this execution
+    int after[kMaxStreams];    // once this execution has started, everything up to index after[s] on stream s has completed or precedes it
+};
+
+static int orderEvent(hipEvent_t* out) {
+    if (g->orderEventsUsed == g->orderEvents.size()) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->orderEvents.push_back(ev);
+    }
+    *out = g->orderEvents[g->orderEventsUsed++];
+    return PLR_OK;
+}
+
+// executions [first, last) contain no host callback; returns in mainAfter what the main stream is ordered after at the end of the run
+static void planStreams(size_t first, size_t last, std::vector<PlanNode>& plan, int nStreams, int* mainAfter) {
+    struct ResState { const void* key; int lastWriter; std::vector<int> readers; };
+    std::vector<ResState> states;
+    int tail[kMaxStreams], load[kMaxStreams];
+    for (int st = 0; st < kMaxStreams; st++) { tail[st] = -1; load[st] = 0; }
+    std::vector<int> deps;
+    auto stateOf = [&](const void* key) -> ResState& {
+        for (auto& s : states) if (s.key == key) return s;
+        states.push_back({key, -1, {}});
+        return states.back();
+    };
+    for (size_t i = first; i < last; i++) {
+        const Execution& x = g->executions[i];
+        deps.clear();
+        auto addDep = [&](int d) { if (d >= 0 && std::find(deps.begin(), deps.end(), d) == deps.end()) deps.push_back(d); };
+        for (const Access& a : x.access) {
+            const ResState& st = stateOf(a.key);
+            addDep(st.lastWriter);
+            if (a.write) for (int r : st.readers) addDep(r);
+        }
+        for (const Access& a : x.access) {
+            ResState& st = stateOf(a.key);
+            if (a.write) { st.lastWriter = (int)i; st.readers.clear(); }
+            else if (st.lastWriter != (int)i && (st.readers.empty() || st.readers.back() != (int)i)) st.readers.push_back((int)i);
+        }
+        PlanNode& node = plan[i];
+        // The stream of the latest dependency: stream order then covers every dependency on that stream and the chain stays together.
+        // An execution that depends on nothing launched in this run starts a new chain on the stream with the fewest executions so far
+        // (the main stream on a tie). A cross-stream wait costs several microseconds on this hardware, so chains are what is spread
+        // over streams, not single executions.
+        int chosen = 0;
+        if (!deps.empty()) chosen = plan[*std::max_element(deps.begin(), deps.end())].stream;
+        else
+            for (int st = 1; st < nStreams; st++) if (load[st] < load[chosen]) chosen = st;
+        node.stream = chosen;
+        for (int st = 0; st < kMaxStreams; st++) node.after[st] = tail[chosen] >= 0 ? plan[tail[chosen]].after[st] : -1;
+        node.after[chosen] = (int)i;
+        // wait for the latest dependency on every other stream unless an earlier wait of this stream already covers it
+        int latest[kMaxStreams];
+        for (int& l : latest) l = -1;
+        for (int d : deps) if (plan[d].stream != chosen) latest[plan[d].stream] = std::max(latest[plan[d].stream], d);
+        for (int st = 0; st < kMaxStreams; st++) {
+            const int d = latest[st];
+            if (d < 0 || d <= node.after[st]) continue;
+            node.waits.push_back(d);
+            plan[d].signal = true;
+            for (int t = 0; t < kMaxStreams; t++) node.after[t] = std::max(node.after[t], plan[d].after[t]);
+        }
+        tail[chosen] = (int)i;
+        load[chosen]++;
+    }
+    for (int st = 0; st < kMaxStreams; st++) mainAfter[st] = tail[0] >= 0 ? plan[tail[0]].after[st] : -1;
+}
+
+static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {
+    PassRes& p = *g->passes[x.pass];
+    x.ctx.stream = stream;
+    x.ctx.global = globalPtr;
+    x.ctx.bindless = g->bindlessDev;
+    x.ctx.bindlessCount = (uint32_t)g->images.size();
+    x.ctx.spec = &p.spec;
+    x.ctx.err = &g_err;
+    x.ctx.scratchSlot = &p.scratch;
+    x.ctx.scratchSize = &p.scratchSize;
+    g->currentPassName = p.name.c_str();
+    g->curStream = stream;
+    if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
+    int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
+    if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
+    if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
+    if (timed) if (int trc = endSegment()) return trc;
+    return PLR_OK;
+}
+
 static int launchAll(bool timed) {
     const size_t n = g->executions.size();
     g->timingNow = timed;
     if (timed) { g->segments.clear(); g->eventsUsed = 0; }
+    g->orderEventsUsed = 0;
+    g->lastOverlapped = 0;
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
-    for (size_t i = 0; i < n; i++) {
+    std::vector<PlanNode> plan(n);
+    std::vector<hipEvent_t> done(n, nullptr);
+    size_t i = 0;
+    while (i < n) {
         Execution& x = g->executions[i];
         if (x.callback) {
+            // everything before a callback has joined the main stream (end of the previous run)
+            g->curStream = g->stream;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
             const int crc = x.callback(x.callbackUser, (void*)g->stream);
             if (crc) return setErr(crc, "host callback '" + std::string(x.callbackName) + "' failed with code " + std::to_string(crc));
             if (timed) if (int rc = endSegment()) return rc;
+            i++;
             continue;
         }
-        PassRes& p = *g->passes[x.pass];
-        x.ctx.stream = g->stream;
-        x.ctx.global = globalPtr;
-        x.ctx.bindless = g->bindlessDev;
-        x.ctx.bindlessCount = (uint32_t)g->images.size();
-        x.ctx.spec = &p.spec;
-        x.ctx.err = &g_err;
-        x.ctx.scratchSlot = &p.scratch;
-        x.ctx.scratchSize = &p.scratchSize;
-        g->currentPassName = p.name.c_str();
-        if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
-        int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
-        if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
-        if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
-        if (timed) if (int trc = endSegment()) return trc;
+        size_t last = i;
+        while (last < n && !g->executions[last].callback) last++;
+        if (!g->overlap) {
+            for (; i < last; i++) if (int rc = launchExecution(g->executions[i], g->stream, globalPtr, timed)) return rc;
+            continue;
+        }
+        int mainAfter[kMaxStreams];
+        planStreams(i, last, plan, 1 + g->activeSideStreams, mainAfter);
+        static const bool debugPlan = std::getenv("PLR_STREAM_DEBUG") != nullptr;
+        if (debugPlan) {
+            for (size_t k = i; k < last; k++) {
+                std::string w;
+                for (int d : plan[k].waits) w += " " + std::to_string(d);
+                fprintf(stderr, "[plr streams] %2zu %-45s stream %d%s%s%s\n", k, g->passes[g->executions[k].pass]->name.c_str(), plan[k].stream,
+                        plan[k].signal ? " signals" : "", w.empty() ? "" : " waits for", w.c_str());
+            }
+        }
+        // side streams start after everything launched on the main stream so far (earlier frames, uploads, callbacks); the event is
+        // recorded before the first launch of the run, so a side stream does not wait for this run's main-stream executions
+        hipEvent_t runStart = nullptr;
+        for (size_t k = i; k < last && !runStart; k++)
+            if (plan[k].stream != 0) {
+                if (int rc = orderEvent(&runStart)) return rc;
+                HIP_TRY(hipEventRecord(runStart, g->stream));
+            }
+        bool joined[1 + Backend::kSideStreams] = {true, false, false, false};
+        int tail[1 + Backend::kSideStreams] = {-1, -1, -1, -1};
+        for (size_t k = i; k < last; k++) {
+            const PlanNode& node = plan[k];
+            hipStream_t stream = node.stream == 0 ? g->stream : g->sideStreams[node.stream - 1];
+            if (!joined[node.stream]) {
+                HIP_TRY(hipStreamWaitEvent(stream, runStart, 0));
+                joined[node.stream] = true;
+            }
+            for (int d : node.waits) HIP_TRY(hipStreamWaitEvent(stream, done[d], 0));
+            if (int rc = launchExecution(g->executions[k], stream, globalPtr, timed)) return rc;
+            if (node.signal) {
+                if (int rc = orderEvent(&done[k])) return rc;
+                HIP_TRY(hipEventRecord(done[k], stream));
+            }
+            tail[node.stream] = (int)k;
+            if (node.stream != 0) g->lastOverlapped++;
+        }
+        // join: the main stream continues after the tails of the side streams
+        for (int st = 1; st <= Backend::kSideStreams; st++) {
+            if (tail[st] < 0 || tail[st] <= mainAfter[st]) continue; // unused, or a main-stream execution already waited for its tail
+            hipEvent_t ev = done[tail[st]];
+            if (!ev) {
+                if (int rc = orderEvent(&ev)) return rc;
+                HIP_TRY(hipEventRecord(ev, g->sideStreams[st - 1]));
+            }
+            HIP_TRY(hipStreamWaitEvent(g->stream, ev, 0));
+        }
+        i = last;
     }
+    g->curStream = g->stream;
     g->timingNow = false;
     return PLR_OK;
 }
@@ -631,6 +829,18 @@ int plr_render_frame(int /*present_to_screen*/) {
         for (auto& sg : g->segments) g->lastTimings.push_back({0.f, sg.name});
     }
     g->lastCpuMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PLR_OK;
+}
+
+int plr_set_stream_overlap(int enabled) {
+    NEED_INIT();
+    g->overlap = enabled != 0;
+    return PLR_OK;
+}
+int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions) {
+    NEED_INIT();
+    if (out_enabled) *out_enabled = g->overlap ? 1 : 0;
+    if (out_overlapped_executions) *out_overlapped_executions = g->lastOverlapped;
     return PLR_OK;
 }
 

@@ -131,9 +131,12 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
     const uint2* yshTexels = (const uint2*)inYSH.ptr;
     const uint32_t* cocgTexels = (const uint32_t*)inCoCg.ptr;
-    // The kernel is bound by memory latency, not by issue: samples are processed four at a time, branch-free, so that the twelve
-    // gathers of a group are in flight together (a per-sample branch makes the compiler wait for each sample's loads in turn).
-    // Only lengthModifier chains the samples, and it depends on coordinates alone.
+    // Samples are processed four at a time, branch-free, so that the gathers of a group are in flight together (a per-sample branch
+    // makes the compiler wait for each sample's loads in turn); only lengthModifier chains the samples, and it depends on coordinates
+    // alone. With the loads overlapped the kernel is bound by VALU issue: SQ_INSTS_VALU = 1960 per wave (two of them per sample the
+    // quarter-rate v_rcp_f32) x 4 cycles x 31.6 waves per SIMD = 96% of the measured duration; replacing every gather by the pixel's
+    // own texel does not change the time. A wave-uniform "whole group on screen" shortcut was tried and gave nothing on the bench
+    // scene (waves near discs that leave the screen pay for both paths, and the extra registers cost two waves of occupancy).
     for (int i0 = 0; i0 < 32; i0 += 4) {
         float su[4], sv[4];
         uint32_t ti[4], di[4];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
             // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
             const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(u * yW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(v * yH, 0.f, yHm1);
-            ti[k] = ty * ywi + tx;
+            ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
             di[k] = SAME_GRID ? ti[k]
                               : (uint32_t)(int)__builtin_amdgcn_fmed3f(v * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(u * dW, 0.f, dWm1);
         }
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 const float den = u2f(t4[k].w); // <= 0: texel had a NaN component (skip)
                 const float q = k0 + sv[k] * k1 + su[k] * k2;
                 const float num = fabsf(c0 * den + nf * q);
-                float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
+                // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
+                float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(__builtin_fmaxf(num, 0.0001f * den)), 0.f, 1.f);
                 weight *= weight;
                 weight = (!off[k] && den > 0.f) ? weight : 0.f;
                 const vec4 sY(halfBitsToFloat(t4[k].x & 0xffffu), halfBitsToFloat(t4[k].x >> 16), halfBitsToFloat(t4[k].y & 0xffffu), halfBitsToFloat(t4[k].y >> 16));

@@ -86,3 +86,41 @@ def test_gpu_full_frame_with_separate_supersampling(backend):
         assert np.array_equal(be.downloadImage(fp.image("post0"), 0, np.uint32), ora.post0.reshape(-1)), "supersampled colour, frame %d" % f
         assert np.array_equal(be.downloadImage(fp.image("post1"), 0, np.uint32), ora.post1.reshape(-1)), "TAA+bloom output, frame %d" % f
     fp.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast", [False, True])
+def test_gpu_stream_overlap_does_not_change_the_frame(backend, fast):
+    """plr_set_stream_overlap: independent passes on side streams (hazards derived from the bound allocations) vs one in-order stream.
+    Large enough that the overlapped kernels really run side by side; every frame's outputs must be byte-identical."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h, n_frames = 1280, 720, 5
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=502)
+    inputs = None
+    results = {}
+    try:
+        backend.setMathMode(fast)
+        for overlap in (True, False):
+            backend.setStreamOverlap(overlap)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                enabled, overlapped = backend.getStreamOverlap()
+                assert enabled == overlap
+                assert (overlapped > 0) == overlap, "executions on side streams: %d" % overlapped
+                out.append((backend.downloadImage(fp.image("swapchain"), 0, np.uint8).copy(), backend.downloadImage(fp.image("post1"), 0, np.uint32).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.float32).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy()))
+            results[overlap] = out
+            fp.destroy()
+    finally:
+        backend.setStreamOverlap(False)
+        backend.setMathMode(False)
+    for f in range(n_frames):
+        for a, b, what in zip(results[True][f], results[False][f], ("swapchain", "post1", "light buffer", "histogram")):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "%s differs with stream overlap, frame %d" % (what, f)
