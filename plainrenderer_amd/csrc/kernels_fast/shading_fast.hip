@@ -22,7 +22,7 @@ namespace fastshade {
 
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
-PLR_DI float sqrth(float x) { return __builtin_amdgcn_sqrth(x); } // v_sqrt_f32 (1 ulp) without the denormal-range rescue sequence of sqrth()
+PLR_DI float sqrtv(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt_f32 (1 ulp) without the denormal-range rescue sequence of sqrtf()
 // v_min / v_max / v_med3: a NaN operand loses, as in the software forms of detmath.h, in one instruction
 PLR_DI float fmin1(float a, float b) { return __builtin_fminf(a, b); }
 PLR_DI float fmax1(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -41,8 +41,8 @@ PLR_DI float D_GGX(float NoH, float r) {
 }
 PLR_DI float Visibility(float NoV, float NoL, float r) {
     const float r_2 = r * r;
-    const float v1 = NoL * sqrth(NoV * NoV * (1.f - r_2) + r_2);
-    const float v2 = NoV * sqrth(NoL * NoL * (1.f - r_2) + r_2);
+    const float v1 = NoL * sqrtv(NoV * NoV * (1.f - r_2) + r_2);
+    const float v2 = NoV * sqrtv(NoL * NoL * (1.f - r_2) + r_2);
     return 0.5f * rcpf(v1 + v2);
 }
 PLR_DI vec3 F_Schlick(vec3 f0, vec3 f90, float VoH) { return f0 + (f90 - f0) * pow5(1.f - VoH); }
@@ -59,7 +59,7 @@ PLR_DI vec3 CoDWWIIDiffuse(vec3 diffuseColor, float NoL, float VoH, float NoV, f
     const float g = log2h(2.f * rcpf(r * r) - 1.f) * (1.f / 18.f);
     const float t = fclamp(2.2f * g - 0.5f, 0.f, 1.f);
     const float fd = f0Diffuse + (f1 - f0Diffuse) * t;
-    const float fb = (34.5f * g * g - 59.f * g + 24.5f) * VoH * exp2h(-fmax1(73.2f * g - 21.2f, 8.9f) * sqrth(NoH));
+    const float fb = (34.5f * g * g - 59.f * g + 24.5f) * VoH * exp2h(-fmax1(73.2f * g - 21.2f, 8.9f) * sqrtv(NoH));
     return diffuseColor * ((1.f / PLR_GLSL_PI) * (fd + fb));
 }
 PLR_DI float Titanfall2DiffuseSingleComponent(float NoL, float LoV, float NoV, float NoH, float r) {
@@ -72,7 +72,7 @@ PLR_DI vec3 GGXSingleScattering(float r, vec3 f0, float NoH, float NoV, float Vo
     return (D_GGX(NoH, r) * Visibility(NoV, NoL, r)) * F_Schlick(f0, vec3(1.f), VoH);
 }
 PLR_DI float ReflectedEnergyAverage(float roughness) {
-    const float smoothness = 1.f - sqrth(roughness);
+    const float smoothness = 1.f - sqrtv(roughness);
     float r = -0.0761947f - 0.383026f * smoothness;
     r = 1.04997f + smoothness * r;
     r = 0.409255f + smoothness * r;
@@ -127,34 +127,47 @@ PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
     return anyNan(N) ? raw : N;
 }
 
-// cos / sin of 2*pi*i/12
-__constant__ const float kTapCos[12] = {1.f, 0.8660254f, 0.5f, 0.f, -0.5f, -0.8660254f, -1.f, -0.8660254f, -0.5f, 0.f, 0.5f, 0.8660254f};
-__constant__ const float kTapSin[12] = {0.f, 0.5f, 0.8660254f, 1.f, 0.8660254f, 0.5f, 0.f, -0.5f, -0.8660254f, -1.f, -0.8660254f, -0.5f};
-
+// 12-tap rotated-disc PCF (lightingFunctions / shadow sampling of the shader). Per tap the shader evaluates
+//   d = sqrt((i + noise/2) / 12), angle = 2 pi (i / 12 + noise), uv = base + (cos, sin)(angle) * 0.03 * lightSpaceScale * d,
+//   nearest fetch with a black border, shadow += actualDepth >= texel.
+// Restructured for issue count (the kernel is bound by VALU issue): the twelve directions are the noise rotation turned by
+// multiples of 30 degrees, so they come from four products (c0, s0 times cos 30 / sin 30) and four sums; the texel-space scale is
+// folded into the per-tap radius; the border test is two unsigned compares on the floored texel coordinate; and the depth compare
+// runs on the raw 16-bit texel against floor(actualDepth * 65535) (for an integer texel t: t / 65535 <= a <=> t <= floor(65535 a)).
 PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMatrix, vec2 lightSpaceScale, float noise) {
     vec4 p = mulMat4(lightMatrix, vec4(pos, 1.f));
     const float iw = rcpf(p.w);
-    const float bx = p.x * iw * 0.5f + 0.5f, by = p.y * iw * 0.5f + 0.5f;
-    const float actualDepth = fclamp(p.z * iw, 0.f, 1.f);
-    const float sx = 0.03f * lightSpaceScale.x, sy = 0.03f * lightSpaceScale.y;
-    const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
     const float fw = (float)shadowMap.w, fh = (float)shadowMap.h;
+    const float bxw = (p.x * iw * 0.5f + 0.5f) * fw, byh = (p.y * iw * 0.5f + 0.5f) * fh; // tap centre in texels
+    const float actualDepth = fclamp(p.z * iw, 0.f, 1.f);
+    const uint32_t depthThreshold = (uint32_t)(actualDepth * 65535.f); // truncation = floor, the value is non-negative
+    const float sxw = 0.03f * lightSpaceScale.x * fw, syh = 0.03f * lightSpaceScale.y * fh;
+    const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
+    // directions i * 30 degrees + noise rotation
+    const float k = 0.8660254f;
+    const float ck = c0 * k, sh = s0 * 0.5f, ch = c0 * 0.5f, sk = s0 * k;
     const uint16_t* sm = (const uint16_t*)shadowMap.ptr;
-    float shadow = 0.f;
+    const uint32_t w = (uint32_t)shadowMap.w, h = (uint32_t)shadowMap.h;
+    const int wm1 = shadowMap.w - 1, hm1 = shadowMap.h - 1;
+    uint32_t lit = 0u;
+    auto tap = [&](int i, float cx, float cy) {
+        const float d = sqrtv(((float)i + 0.5f * noise) * (1.f / 12.f));
+        const float tu = bxw + cx * (sxw * d), tv = byh + cy * (syh * d);
+        const int xi = (int)floorf(tu), yi = (int)floorf(tv);
+        const bool inside = (uint32_t)xi < w && (uint32_t)yi < h; // black border outside: depth 0, always "lit"
+        const uint32_t x = (uint32_t)min(max(xi, 0), wm1), y = (uint32_t)min(max(yi, 0), hm1);
+        const uint32_t texel = sm[fastm::texelIndex(x, y, w)];
+        lit += ((inside ? texel : 0u) <= depthThreshold) ? 1u : 0u;
+    };
+    // taps i and i + 6 point in opposite directions
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const float d = sqrth(((float)i + 0.5f * noise) * (1.f / 12.f));
-        const float ca = c0 * kTapCos[i] - s0 * kTapSin[i], sa = s0 * kTapCos[i] + c0 * kTapSin[i];
-        const float u = bx + ca * (sx * d), v = by + sa * (sy * d);
-        // nearest tap with a black border: fetch the clamped texel unconditionally, select 0 outside (no branch per tap)
-        const float tu = u * fw, tv = v * fh;
-        const bool inside = tu >= 0.f && tv >= 0.f && tu < fw && tv < fh;
-        const uint32_t x = (uint32_t)(int)__builtin_amdgcn_fmed3f(tu, 0.f, fw - 1.f), y = (uint32_t)(int)__builtin_amdgcn_fmed3f(tv, 0.f, fh - 1.f);
-        const float texel = (float)sm[fastm::texelIndex(x, y, (uint32_t)shadowMap.w)] * (1.f / 65535.f);
-        const float depthTexel = inside ? texel : 0.f;
-        shadow += (actualDepth >= depthTexel) ? 1.f : 0.f;
+    for (int i = 0; i < 6; i++) {
+        const float cx = i == 0 ? c0 : i == 1 ? ck - sh : i == 2 ? ch - sk : i == 3 ? -s0 : i == 4 ? -ch - sk : -ck - sh;
+        const float cy = i == 0 ? s0 : i == 1 ? sk + ch : i == 2 ? sh + ck : i == 3 ? c0 : i == 4 ? ck - sh : ch - sk;
+        tap(i, cx, cy);
+        tap(i + 6, -cx, -cy);
     }
-    return shadow * (1.f / 12.f);
+    return (float)lit * (1.f / 12.f);
 }
 
 template <int MULTISCATTER>
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const vec3 N_U = Nn - N, N_V = Nm - N; // sign is irrelevant: only squared lengths are used
         const float variance = 0.25f * (dot(N_V, N_V) + dot(N_U, N_U));
         const float kernelRoughness2 = fmin1(2.f * variance, 0.18f);
-        r = fclamp(sqrth(r * r + kernelRoughness2), 0.f, 1.f);
+        r = fclamp(sqrtv(r * r + kernelRoughness2), 0.f, 1.f);
     }
     const float NoH = fmax1(dot(N, H), 0.f);
     const float NdotL = dot(N, L);
@@ -276,8 +289,8 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const vec3 irradiance = YCoCgToLinear(vec3(irradiance_Y, cc.x, cc.y));
         const vec3 diffuseIndirect = irradiance * diffuseColor * diffuseBRDFIntegral;
         const vec3 dominantDirection = dominantDirectionFromSH_L1(irradiance_Y_SH);
-        const float dominantDirectionLength = fclamp(sqrth(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
-        const float r_indirect = fmix(1.f, r, sqrth(dominantDirectionLength));
+        const float dominantDirectionLength = fclamp(sqrtv(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
+        const float r_indirect = fmix(1.f, r, sqrtv(dominantDirectionLength));
         const vec3 L_indirect = dominantDirection * rcpf(dominantDirectionLength);
         const vec3 H_indirect = nrm(L_indirect + V);
         const float NoH_indirect = fmax1(dot(N, H_indirect), 0.f);
