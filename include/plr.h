@@ -208,6 +208,11 @@ int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, voi
 int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size);
 /* the hipStream_t all passes are launched on */
 int plr_get_stream(void** out_hip_stream);
+/* raw copies ordered on the launch stream of the calling thread's backend: device-to-device (asynchronous), device-to-host and
+ * host-to-device (both return when the copy is done). For exchange callbacks that move rows between two backends of one process. */
+int plr_copy_device_memory(void* dst, const void* src, size_t size);
+int plr_read_device_memory(void* dst_host, const void* src, size_t size);
+int plr_write_device_memory(void* dst, const void* src_host, size_t size);
 /* lists the shader names the backend has kernels for; returns the count */
 int plr_get_supported_shaders(const char** out_names, uint32_t capacity);
 /* detmath / codec probes on the device (same function ids as oracle/probes.cpp); pointers are host memory */

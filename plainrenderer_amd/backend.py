@@ -223,7 +223,7 @@ EXPORTED_SYMBOLS = [
     "plr_create_temporary_image", "plr_get_swapchain_input_image", "plr_get_memory_stats", "plr_get_renderpass_timings",
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
-    "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_get_supported_shaders",
+    "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
     "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 

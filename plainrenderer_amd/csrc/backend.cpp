@@ -370,6 +370,32 @@ int plr_wait_for_gpu_idle(void) {
     return PLR_OK;
 }
 
+// raw copies on the calling thread's backend (band exchange inside one process, histogram reduction on the host): the host side
+// never has to load a HIP runtime of its own
+int plr_copy_device_memory(void* dst, const void* src, size_t size) {
+    NEED_INIT();
+    if (size == 0) return PLR_OK;
+    if (!dst || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory: null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, g->stream));
+    return PLR_OK;
+}
+int plr_read_device_memory(void* dst_host, const void* src, size_t size) {
+    NEED_INIT();
+    if (size == 0) return PLR_OK;
+    if (!dst_host || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_read_device_memory: null pointer");
+    HIP_TRY(hipMemcpyAsync(dst_host, src, size, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+int plr_write_device_memory(void* dst, const void* src_host, size_t size) {
+    NEED_INIT();
+    if (size == 0) return PLR_OK;
+    if (!dst || !src_host) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_write_device_memory: null pointer");
+    HIP_TRY(hipMemcpyAsync(dst, src_host, size, hipMemcpyHostToDevice, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return PLR_OK;
+}
+
 int plr_update_shader_code(void) { NEED_INIT(); return PLR_OK; }
 
 int plr_resize_images(const plr_image_handle* images, uint32_t count, uint32_t width, uint32_t height) {

@@ -26,6 +26,7 @@ struct HizParams {
     int count;     // pyramid levels
     int tileY0;    // first 32x32 mip-0 tile row of the launch (dispatch base)
     int baseCount; // levels produced by hizBaseKernel
+    int ldsA;      // texels of hizBaseKernel's first LDS buffer
 };
 
 struct MinMax { float mn, mx; };
@@ -54,8 +55,12 @@ PLR_DI MinMax footprint(int ulx, int uly, int srcW, int srcH, bool extraRow, boo
 }
 
 __global__ __launch_bounds__(256) void hizBaseKernel(HizParams p) {
-    __shared__ float2 bufA[64 * 64];
-    __shared__ float2 bufB[32 * 32];
+    // bufA holds the even levels' regions, bufB the odd ones; sized by the launcher for this pyramid's worst block (ldsA texels for bufA):
+    // with all-even level sizes that is 32x32 + 16x16 texels (10 KB, every block of a 4K frame resident at once), with odd sizes upstream
+    // up to 63x63 + 31x31
+    extern __shared__ float2 hizLds[];
+    float2* bufA = hizLds;
+    float2* bufB = hizLds + p.ldsA;
     const int K = p.baseCount;
     // per level: owned range [lo, hi] and computed range [lo, need] (need >= hi: halo for the odd-size footprints above)
     int lox[kHizBaseLevels], loy[kHizBaseLevels], hix[kHizBaseLevels], hiy[kHizBaseLevels], needx[kHizBaseLevels], needy[kHizBaseLevels];
@@ -178,7 +183,20 @@ static int launchDepthHiZPyramid(const PassCtx& c) {
     p.tileY0 = rs.y0;
     const bool wholePyramid = rs.y0 == 0 && rs.y1 == tileRows;
     const dim3 grid(divUp((unsigned)p.w[0], 32u), (unsigned)(rs.y1 - rs.y0));
-    hizBaseKernel<<<grid, 256, 0, c.stream>>>(p);
+    // LDS regions of the worst block: per axis count[l-1] = max(tile, 2 * count[l] + (source size odd)), see the need[] recursion in the kernel
+    int cx[kHizBaseLevels], cy[kHizBaseLevels];
+    const int K = p.baseCount;
+    cx[K - 1] = 32 >> (K - 1); cy[K - 1] = 32 >> (K - 1);
+    for (int l = K - 1; l >= 1; l--) {
+        cx[l - 1] = std::max(32 >> (l - 1), 2 * cx[l] + (p.w[l - 1] & 1));
+        cy[l - 1] = std::max(32 >> (l - 1), 2 * cy[l] + (p.h[l - 1] & 1));
+    }
+    int texA = 1, texB = 1;
+    for (int l = 0; l < K; l++) (l & 1 ? texB : texA) = std::max(l & 1 ? texB : texA, cx[l] * cy[l]);
+    p.ldsA = texA;
+    const size_t ldsBytes = (size_t)(texA + texB) * sizeof(float2);
+    if (ldsBytes > 64 * 1024) return c.fail(-6, "depthHiZPyramid: LDS region of a tile exceeds 64 KB");
+    hizBaseKernel<<<grid, 256, ldsBytes, c.stream>>>(p);
     PLR_CHECK_LAUNCH(c);
     if (p.count > p.baseCount && wholePyramid) {
         hizTailKernel<<<1, 1024, 0, c.stream>>>(p);

@@ -129,53 +129,53 @@ class LocalGroup:
         self.n, self.lib = n_bands, lib
         self.barrier = threading.Barrier(n_bands)
         self.slots = [None] * n_bands
-        self.hip = C.CDLL("libamdhip64.so")
+        lib.plr_copy_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.plr_read_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.plr_write_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 
 
 class LocalTransport:
+    """bands as threads of one process, each with its own (thread-local) backend on the same GPU: rows are copied device-to-device by the
+    receiving band's backend. All HIP calls go through libplr (the process must not end up with a second HIP runtime)."""
+
     def __init__(self, group, index):
         self.g, self.rank, self.world = group, index, group.n
 
-    def _sync(self, stream_ptr):
-        rc = self.g.hip.hipStreamSynchronize(C.c_void_p(stream_ptr))
+    def _call(self, rc, what):
         if rc != 0:
-            raise RuntimeError("hipStreamSynchronize failed: %d" % rc)
+            raise RuntimeError("%s failed: %d %s" % (what, rc, self.g.lib.plr_last_error().decode(errors="replace")))
 
-    def _publish(self, payload, stream_ptr):
-        self._sync(stream_ptr)            # my rows are complete in HBM
+    def _sync(self):
+        self._call(self.g.lib.plr_wait_for_gpu_idle(), "plr_wait_for_gpu_idle")
+
+    def _publish(self, payload):
+        self._sync()                      # my rows are complete in HBM
         self.g.slots[self.rank] = payload
         self.g.barrier.wait()             # everybody's rows are complete and published
 
-    def _retire(self, stream_ptr):
-        self._sync(stream_ptr)            # my copies are done
+    def _retire(self):
+        self._sync()                      # my copies are done
         self.g.barrier.wait()             # nobody still reads my rows
 
     def exchange(self, items, stream_ptr, band_meta):
-        self._publish(items, stream_ptr)
+        self._publish(items)
         for i, r in enumerate(items):
             bands = [self.g.slots[b][i] for b in range(self.world)]
             for peer, kind, a, b in neighbour_plan(bands, self.rank, self.world):
                 if kind != "recv":
                     continue
                 src = bands[peer].ptr + a * r.row_bytes
-                rc = self.g.hip.hipMemcpyAsync(C.c_void_p(r.ptr + a * r.row_bytes), C.c_void_p(src), C.c_size_t((b - a) * r.row_bytes), C.c_int(3), C.c_void_p(stream_ptr))
-                if rc != 0:
-                    raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
-        self._retire(stream_ptr)
+                self._call(self.g.lib.plr_copy_device_memory(C.c_void_p(r.ptr + a * r.row_bytes), C.c_void_p(src), C.c_size_t((b - a) * r.row_bytes)), "plr_copy_device_memory")
+        self._retire()
 
     def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
-        self._sync(stream_ptr)
         host = np.zeros(nbytes // 4, np.uint32)
-        rc = self.g.hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(2))
-        if rc != 0:
-            raise RuntimeError("hipMemcpy failed: %d" % rc)
+        self._call(self.g.lib.plr_read_device_memory(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes)), "plr_read_device_memory")
         self.g.slots[self.rank] = host
         self.g.barrier.wait()
         total = np.sum(np.stack(self.g.slots), axis=0, dtype=np.uint64).astype(np.uint32)
         self.g.barrier.wait()
-        rc = self.g.hip.hipMemcpy(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), C.c_int(1))
-        if rc != 0:
-            raise RuntimeError("hipMemcpy failed: %d" % rc)
+        self._call(self.g.lib.plr_write_device_memory(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes)), "plr_write_device_memory")
 
 
 class Exchange:
