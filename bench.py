@@ -306,7 +306,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "frames/sec full GI+shade+post @4K; %HBM roofline; 1/2/4/8-GPU scaling",
-            "value": round(1000.0 / ms_per_step * (w * h) / float(args.width * args.height) * (world if replicas else 1), 3),
+            "value": round(1000.0 / ms_per_step * (w * h) / 8294400.0 * (world if replicas else 1), 3),
             "unit": "frames/s (3840x2160-equivalent: frames/s x frame pixels / 8294400)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "host_ms_per_step": round(host_elapsed * 1000.0 / args.steps, 4),
