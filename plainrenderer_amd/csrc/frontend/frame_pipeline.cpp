@@ -490,6 +490,11 @@ static void singlePassMipChainDispatchCount(uint32_t width, uint32_t height, uin
 
 static const uint32_t bandAlignment = 64;      // HiZ tile (64 px), culling tile (32 trace px), histogram tile (32 px), 2^5 bloom texel
 static const uint32_t bandPyramidMipCount = 6; // per-tile levels of the HiZ kernel; the hot path reads mip 4 (SDFGI.cpp:567)
+static const uint32_t maxPyramidMipCount = 11; // depthHiZPyramid.comp binds at most 11 levels (pyramid base <= 2048)
+// A band builds only the levels one 64x64-pixel tile yields: the rest of the chain needs every band and has no consumer on this path.
+// A frame whose full chain would exceed the shader's 11 levels (8K un-tiled; the reference cannot render it) gets the same per-tile pyramid.
+static bool perTilePyramid(const FramePipelineSettings& s) { return s.band.enabled() || mipCountFromResolution(s.width / 2, s.height / 2, 1) > maxPyramidMipCount; }
+static uint32_t pyramidMipCount(const FramePipelineSettings& s) { return perTilePyramid(s) ? bandPyramidMipCount : mipCountFromResolution(s.width / 2, s.height / 2, 1); }
 
 FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     const uint32_t W = s.width, H = s.height;
@@ -538,8 +543,7 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     m_worldSpaceNormalImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
     m_albedoImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
     m_specularImage = m_be.createImage(desc2D(W, H, ImageFormat::RGBA8), nullptr, 0);
-    // a band builds only the levels one 64x64-pixel tile yields (the rest of the chain needs every band and has no consumer on this path)
-    m_minMaxDepthPyramid = s.band.enabled()
+    m_minMaxDepthPyramid = perTilePyramid(s)
         ? m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::Manual, bandPyramidMipCount), nullptr, 0)
         : m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::FullChain), nullptr, 0);
     m_depthHalfRes = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::R16_sFloat), nullptr, 0);
@@ -597,7 +601,7 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         d.name = "Depth min/max pyramid";
         d.shaderDescription.srcPathRelative = "depthHiZPyramid.comp";
         const uint32_t pw = W / 2, ph = H / 2;
-        const uint32_t depthMipCount = s.band.enabled() ? bandPyramidMipCount : mipCountFromResolution(pw, ph, 1);
+        const uint32_t depthMipCount = pyramidMipCount(s);
         uint32_t dc[2];
         singlePassMipChainDispatchCount(pw, ph, depthMipCount, 11, dc);
         m_depthPyramidThreadgroupCount = dc[0] * dc[1];
@@ -818,15 +822,18 @@ void FramePipeline::computeDepthPyramid(ImageHandle depthBuffer) { // RenderFron
     ComputePassExecution exe;
     exe.genericInfo.handle = m_depthPyramidPass;
     const uint32_t width = settings.width / 2, height = settings.height / 2, maxMipCount = 11;
-    const uint32_t mipCount = settings.band.enabled() ? bandPyramidMipCount : mipCountFromResolution(width, height, 1);
+    const uint32_t mipCount = pyramidMipCount(settings);
     uint32_t dc[2];
     singlePassMipChainDispatchCount(width, height, mipCount, maxMipCount, dc);
     exe.dispatchCount[0] = dc[0]; exe.dispatchCount[1] = dc[1]; exe.dispatchCount[2] = 1;
-    if (settings.band.enabled()) { // one workgroup per 32x32 texels of pyramid mip 0 = 64 full-resolution rows
-        const RowRange groups = scaleRows(bandRows(0), 64);
+    if (perTilePyramid(settings)) { // one workgroup per 32x32 texels of pyramid mip 0 = 64 full-resolution rows
         exe.dispatchCount[0] = (width + 31) / 32;
-        exe.dispatchBase[1] = groups.begin;
-        exe.dispatchCount[1] = groups.end - groups.begin;
+        exe.dispatchCount[1] = (height + 31) / 32;
+        if (settings.band.enabled()) {
+            const RowRange groups = scaleRows(bandRows(0), 64);
+            exe.dispatchBase[1] = groups.begin;
+            exe.dispatchCount[1] = groups.end - groups.begin;
+        }
     }
     exe.genericInfo.resources.sampledImages = {ImageResource(depthBuffer, 0, 13), ImageResource(m_minMaxDepthPyramid, 0, 15)};
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_depthPyramidSyncBuffer, false, 16)};
@@ -1064,7 +1071,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     if (settings.runSkyLuts) updateSkyLut();
     // [renderDepthPrepass: input]
     if (settings.runHiZ) computeDepthPyramid(currentRenderTarget.depthBuffer);
-    if (settings.runLightMatrix && settings.runHiZ && !band) computeSunLightMatrices();
+    if (settings.runLightMatrix && settings.runHiZ && !perTilePyramid(settings)) computeSunLightMatrices(); // needs the apex of the full chain
     // [renderSunShadowCascades: input]
     if (settings.runGI && settings.shading.indirectLightingTech == IndirectLightingTech::SDFTrace) {
         if (settings.sdfTrace.halfResTrace) downscaleDepth(currentRenderTarget);
