@@ -124,3 +124,28 @@ def test_gpu_stream_overlap_does_not_change_the_frame(backend, fast):
     for f in range(n_frames):
         for a, b, what in zip(results[True][f], results[False][f], ("swapchain", "post1", "light buffer", "histogram")):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "%s differs with stream overlap, frame %d" % (what, f)
+
+
+@pytest.mark.gpu
+def test_gpu_frame_wider_than_the_shader_pyramid_limit_builds_per_tile_levels(backend):
+    """A frame whose full HiZ chain would need more than the 11 levels depthHiZPyramid.comp binds (pyramid base >= 2048, i.e. width >= 4096;
+    the reference cannot render it un-tiled) gets the 6 per-tile levels of band rendering. They must equal the oracle's levels 0..5."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h = 4096, 128
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0), (0.0, 0.16, 1.0), aspect=w / h) for i in range(2)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=503)
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=LUT_RES, froxel_depth=8, max_sdf_instances=64)
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
+    inputs.upload(fp)
+    fp.frame(cams[1], 1.0 / 60.0, 0.5)
+    expected = passes.orc_hiz(inputs.gb["depth"], w, h)
+    assert len(expected) == 12  # what the full chain would be
+    pyramid = fp.image("pyramid")
+    for level in range(6):
+        got = backend.downloadImage(pyramid, level, np.float32).reshape(expected[level].shape)
+        assert np.array_equal(got.view(np.uint32), expected[level].view(np.uint32)), "pyramid level %d" % level
+    with pytest.raises(Exception):
+        backend.downloadImage(pyramid, 6, np.float32)  # the image has exactly six levels
+    sw = backend.downloadImage(fp.image("swapchain"), 0, np.uint8)
+    assert sw.reshape(h, w, 4)[..., :3].max() > 0
+    fp.destroy()
