@@ -28,6 +28,23 @@ def test_gpu_detmath_bit_identical(backend, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_r11g11b10_encoder_on_a_bit_pattern_lattice(backend, oracle):
+    """The device encoder is branch-free (both range results computed, special cases override); the oracle's is the early-return form.
+    Every sign/exponent value x every value of the top 10 mantissa bits x the low-bit patterns around the rounding ties of both
+    mantissa widths (6 and 5 bits): zeros, infinities, NaNs of both signs, subnormal inputs and outputs, overflow are all in it."""
+    hi = np.arange(512, dtype=np.uint64)[:, None, None] << np.uint64(23)
+    mid = np.arange(1024, dtype=np.uint64)[None, :, None] << np.uint64(13)
+    low = np.array([0, 1, 0xfff, 0x1000, 0x1001, 0x1fff], np.uint64)[None, None, :]
+    bits = (hi | mid | low).reshape(-1).astype(np.uint32)
+    v = np.repeat(bits.view(np.float32)[:, None], 3, axis=1).copy()  # channels x, y: 6-bit mantissa; z: 5-bit
+    n = v.shape[0]
+    got = backend.debugCodecEval(0, v, n, np.uint32, n)
+    want = oracle.codec_eval(0, v, n, np.uint32, n)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "%d mismatches, first input bits %08x: got %08x want %08x" % (bad.size, bits[bad[0]], got[bad[0]], want[bad[0]])
+
+
+@pytest.mark.gpu
 def test_gpu_codecs_bit_identical(backend, oracle):
     r = np.random.default_rng(22)
     n = 300000
