@@ -78,7 +78,11 @@ PLR_DI float ReflectedEnergyAverage(float roughness) {
     r = 0.409255f + smoothness * r;
     return fmin1(0.999f, r);
 }
-PLR_DI float sRGBToLinear1(float c) { return c <= 0.004045f ? c * (1.f / 12.92f) : fpow((c + 0.055f) * (1.f / 1.055f), 2.4f); }
+// both branches evaluated and selected: a divergent branch around the power costs more than the power (two quarter-rate instructions)
+PLR_DI float sRGBToLinear1(float c) {
+    const float lin = c * (1.f / 12.92f), pw = fpow((c + 0.055f) * (1.f / 1.055f), 2.4f);
+    return c <= 0.004045f ? lin : pw;
+}
 
 // bilinear RGBA16F fetch with clamp-to-edge; the two texels of a row come from one 16-byte load (a load instruction costs the
 // texture addresser the same whatever its width)
@@ -90,12 +94,9 @@ PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
     const int xb = max(min(x0, im.w - 2), 0);
     auto rowPair = [&](int y, vec4* t0, vec4* t1) {
         const uint2* row = (const uint2*)im.ptr + (size_t)y * (size_t)im.w;
-        uint2 lo, hi;
-        if (im.w >= 2) {
-            uint4 q;
-            __builtin_memcpy(&q, row + xb, 16);
-            lo = make_uint2(q.x, q.y); hi = make_uint2(q.z, q.w);
-        } else { lo = row[0]; hi = lo; }
+        uint4 q; // the launcher sends images narrower than two texels to the general kernel
+        __builtin_memcpy(&q, row + xb, 16);
+        const uint2 lo = make_uint2(q.x, q.y), hi = make_uint2(q.z, q.w);
         const uint2 e0 = x0 == xb ? lo : hi, e1 = x1 == xb ? lo : hi;
         *t0 = vec4(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
         *t1 = vec4(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
@@ -247,14 +248,17 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const vec2 noiseTexel = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
 
     int cascadeIndex = 0;
-    for (int cascade = 0; cascade < (int)P.cascadeCount - 1; cascade++) cascadeIndex += (pixelDepth >= P.shadowInfo->splits[cascade]) ? 1 : 0;
-    cascadeIndex = min(cascadeIndex, 3);
+#pragma unroll
+    for (int cascade = 0; cascade < 3; cascade++) cascadeIndex += (cascade < (int)P.cascadeCount - 1 && pixelDepth >= P.shadowInfo->splits[cascade]) ? 1 : 0;
     const vec2 lss(P.shadowInfo->lightSpaceScale[cascadeIndex][0], P.shadowInfo->lightSpaceScale[cascadeIndex][1]);
     // one instance of the PCF loop: the cascade only selects which image view and matrix it reads
-    ImgView shadowMap = P.shadowMaps[0];
-    if (cascadeIndex == 1) shadowMap = P.shadowMaps[1];
-    else if (cascadeIndex == 2) shadowMap = P.shadowMaps[2];
-    else if (cascadeIndex == 3) shadowMap = P.shadowMaps[3];
+    ImgView shadowMap = P.shadowMaps[0]; // field-wise selects (the cascade differs between the pixels of a wave)
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        shadowMap.ptr = cascadeIndex == i ? P.shadowMaps[i].ptr : shadowMap.ptr;
+        shadowMap.w = cascadeIndex == i ? P.shadowMaps[i].w : shadowMap.w;
+        shadowMap.h = cascadeIndex == i ? P.shadowMaps[i].h : shadowMap.h;
+    }
     const float sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[cascadeIndex], lss, noiseTexel.x);
     const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
     const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
@@ -323,9 +327,9 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const int xb = max(min(x0, vol.w - 2), 0);
         auto rowLerp = [&](size_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
             const uint2* row = (const uint2*)vol.ptr + rowBase;
-            uint2 tl, th;
-            if (vol.w >= 2) { uint4 q; __builtin_memcpy(&q, row + xb, 16); tl = make_uint2(q.x, q.y); th = make_uint2(q.z, q.w); }
-            else { tl = row[0]; th = tl; }
+            uint4 q;
+            __builtin_memcpy(&q, row + xb, 16);
+            const uint2 tl = make_uint2(q.x, q.y), th = make_uint2(q.z, q.w);
             const uint2 e0 = x0 == xb ? tl : th, e1 = x1 == xb ? tl : th;
             const vec4 t0(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
             const vec4 t1(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
@@ -373,6 +377,8 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     if (c.sampled[16].w != c.sampled[15].w || c.sampled[16].h != c.sampled[15].h) return c.fail(-4, "deferredShading: Y_SH and CoCg differ in size");
     // this kernel addresses depth / albedo / specular with the colour target's texel index: other layouts take the general kernel
     for (int b : {20, 22, 23}) if (c.sampled[b].w != c.storage[0].w || c.sampled[b].h != c.storage[0].h) return kUseGeneralKernel;
+    // the LUT / froxel fetches read the two texels of a row with one 16-byte load
+    if (c.sampled[3].w < 2 || c.sampled[18].w < 2) return kUseGeneralKernel;
     const int diffuseBRDF = c.specInt(0, 0), multi = c.specInt(1, 0), tech = c.specInt(3, 0);
     const bool aa = c.specBool(2, false);
     const uint32_t cascades = c.specUint(4, 4u);
