@@ -33,12 +33,19 @@ PLR_DI vec3 historyTap(const ImgView& im, float u, float v) {
     return top + (bot - top) * b;
 }
 
+// texelFetch of the motion buffer with the out-of-range test as a select instead of a branch per pixel row
+PLR_DI vec4 motionFetch(const ImgView& im, int x, int y) {
+    const bool inside = (uint32_t)x < (uint32_t)im.w && (uint32_t)y < (uint32_t)im.h;
+    const vec4 t = Texel<F_RG16SN>::load(im.ptr, (size_t)clampi(y, im.h) * (size_t)im.w + (size_t)clampi(x, im.w));
+    return vec4(inside ? t.x : 0.f, inside ? t.y : 0.f, inside ? t.z : 0.f, inside ? t.w : 0.f);
+}
+
 PLR_DI vec3 clipAABB(vec3 target, vec3 bbMin, vec3 bbMax) {
     const vec3 center = 0.5f * (bbMax + bbMin);
     const vec3 extend = 0.5f * (bbMax - bbMin) + vec3(0.0001f);
     const vec3 toTarget = target - center;
     const vec3 n(fabsf(toTarget.x) * rcpf(extend.x), fabsf(toTarget.y) * rcpf(extend.y), fabsf(toTarget.z) * rcpf(extend.z));
-    const float maxComponent = gmax(n.x, gmax(n.y, n.z));
+    const float maxComponent = __builtin_fmaxf(n.x, __builtin_fmaxf(n.y, n.z)); // v_max3_f32: a NaN operand loses, like gmax, without its branches
     if (maxComponent < 1.f) return target;
     return center + toTarget * rcpf(maxComponent);
 }
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void temporalFilterFastKernel(ImgView current,
                     if (d > closest) { closest = d; ox = x; oy = y; }
                 }
         }
-        const vec4 m = texelFetch2D<F_RG16SN>(motionBuffer, px + ox, py + oy);
+        const vec4 m = motionFetch(motionBuffer, px + ox, py + oy);
         motion = vec2(m.x, m.y);
     }
     const float rpx = u0 + motion.x, rpy = v0 + motion.y;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
                     if (d > closest) { closest = d; ox = x - 1; oy = y - 1; }
                 }
         }
-        const vec4 m = texelFetch2D<F_RG16SN>(motionBuffer, px + ox, py + oy);
+        const vec4 m = motionFetch(motionBuffer, px + ox, py + oy);
         const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
         const float rpx = u0 + m.x, rpy = v0 + m.y;
 
