@@ -19,7 +19,7 @@ EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, 
 # kernels_fast/*.hip: restructured kernels for PLR_MATH_FAST. FMA contraction on, divide/sqrt may use the v_rcp/v_rsq based
 # sequences; still no -ffast-math (NaN guards and comparisons keep IEEE semantics).
 FAST_FLAGS_REPLACE = {"-ffp-contract=off": "-ffp-contract=fast-honor-pragmas", "-fhip-fp32-correctly-rounded-divide-sqrt": "-fno-hip-fp32-correctly-rounded-divide-sqrt"}
-FAST_FLAGS_EXTRA = os.environ.get("PLR_FAST_FLAGS", "").split()  # experiment hook for the fast set only
+FAST_FLAGS_EXTRA = ["-DPLR_FAST_SET=1"] + os.environ.get("PLR_FAST_FLAGS", "").split()  # PLR_FAST_SET: detmath.h min/max as single instructions; + experiment hook
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

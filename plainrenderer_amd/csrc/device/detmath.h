@@ -18,8 +18,15 @@ PLR_DI float u2f(uint32_t u) { return __uint_as_float(u); }
 
 // GLSL 4.60 8.3 definitions; a NaN operand loses (IEEE minNum / maxNum, what v_min_f32 / v_max_f32 do), signed zeros
 // follow from the comparison. The reference relies on the NaN rule to recover from the 0/0 of its first frames.
+#ifdef PLR_FAST_SET
+// kernels_fast/: v_min_f32 / v_max_f32 (a NaN operand loses as well; only the sign of a zero result can differ from the comparison form,
+// which the compiler otherwise turns into divergent branches in several kernels)
+PLR_DI float gmin(float x, float y) { return __builtin_fminf(x, y); }
+PLR_DI float gmax(float x, float y) { return __builtin_fmaxf(x, y); }
+#else
 PLR_DI float gmin(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((y < x) ? y : x)); }
 PLR_DI float gmax(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((x < y) ? y : x)); }
+#endif
 PLR_DI float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 PLR_DI float gsign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 PLR_DI float gmix(float a, float b, float t) { return a * (1.f - t) + b * t; }

@@ -9,7 +9,7 @@ from plainrenderer_amd import build as b
 def main(src, pat, top=40):
     flags = b.FLAGS
     if os.sep + "kernels_fast" + os.sep in os.path.abspath(src):
-        flags = [b.FAST_FLAGS_REPLACE.get(f, f) for f in b.FLAGS]
+        flags = [b.FAST_FLAGS_REPLACE.get(f, f) for f in b.FLAGS] + b.FAST_FLAGS_EXTRA
     out = os.path.join(tempfile.gettempdir(), "valu_by_line.s")
     subprocess.run([b.HIPCC, "-x", "hip"] + flags + ["-gline-tables-only", "--cuda-device-only", "-S", "-o", out, src], check=True, capture_output=True)
     s = open(out).read()
