@@ -155,7 +155,7 @@ template <> struct Texel<F_R8> {
 // ---- samplers (resources/shaders/global.inc:35-42) ----
 enum Address { CLAMP = 0, REPEAT = 1, BORDER_WHITE = 2, BORDER_BLACK = 3 };
 
-PLR_DI int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+PLR_DI int clampi(int i, int n) { return min(max(i, 0), n - 1); } // v_med3_i32; n >= 1
 PLR_DI int repeati(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 PLR_DI float saneCoord(float u) { return gclamp(u, -1.0e6f, 1.0e6f); }
 PLR_DI void linearCoord(float u, int* i0, float* alpha) {

@@ -216,15 +216,16 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
 #pragma unroll
         for (int y = -1; y <= 1; y++) {
             if (x == 0 && y == 0) continue;
+            // selects instead of two divergent branches per neighbour (an excluded neighbour must not be added even with weight 0: it may be NaN)
             const int rx = lx + x, ry = ly + y;
-            if (!((rx > 0 && ry > 0) && (rx < 8 && ry < 8))) continue; // sic: > 0 (:88)
-            const RayInfo nb = sharedRays[wave][ry * 8 + rx];
+            const bool inGroup = (rx > 0 && ry > 0) && (rx < 8 && ry < 8); // sic: > 0 (:88)
+            const RayInfo nb = sharedRays[wave][inGroup ? ry * 8 + rx : lane];
             const float NoN = gclamp(dot(myN, vec3(nb.nx, nb.ny, nb.nz)), 0.f, 1.f);
-            if (NoN > 0.9f && fabsf(mine.depth - nb.depth) < 0.5f) {
-                const float weight = (x == 0 ? 1.f : 0.5f) * (y == 0 ? 1.f : 0.5f);
-                color = color + weight * vec3(nb.cr, nb.cg, nb.cb);
-                weightTotal += weight;
-            }
+            const bool take = inGroup && NoN > 0.9f && fabsf(mine.depth - nb.depth) < 0.5f;
+            const float weight = (x == 0 ? 1.f : 0.5f) * (y == 0 ? 1.f : 0.5f);
+            const vec3 sum = color + weight * vec3(nb.cr, nb.cg, nb.cb);
+            color = vec3(take ? sum.x : color.x, take ? sum.y : color.y, take ? sum.z : color.z);
+            weightTotal = take ? weightTotal + weight : weightTotal;
         }
     color = color * rcpf(weightTotal);
     const vec3 YCoCg = linearToYCoCg(color);
