@@ -24,6 +24,8 @@ PLR_DI vec2 unorm8x2(uint32_t u) {
 // repeat addressing of a non-negative or negative coordinate: a mask when n is a power of two (noise textures are 32x32)
 PLR_DI int repeatIndex(int i, int n) { return (n & (n - 1)) == 0 ? (i & (n - 1)) : repeati(i, n); }
 // texel index y * w + x for images below 2^24 texels per side: v_mad_u32_u24 (full rate) instead of a 32/64-bit multiply (quarter rate)
+// saneCoord of image.h (keeps the float -> int conversion of a sampler coordinate defined) as one v_med3_f32; a NaN coordinate becomes -1e6
+PLR_DI float clampCoord(float u) { return __builtin_amdgcn_fmed3f(u, -1.0e6f, 1.0e6f); }
 PLR_DI uint32_t texelIndex(uint32_t x, uint32_t y, uint32_t w) { return __umul24(y, w) + x; }
 
 // ---- sky LUT lookup (sky.inc:86-94, 112-116) for the fast kernels. The exact path spends ~350 VALU instructions per lookup on the software

@@ -25,6 +25,35 @@ struct Volume {
     float fw, fh, fd;
 };
 
+// Trilinear clamp-to-edge fetch for volumes of at least 2 texels per axis, without a branch: the sampler's 8.8 fixed-point coordinate
+// is clamped to [0, n-1] and split into a cell index <= n-2 and a weight in [0, 1], so both texels of every pair are always in range
+// (outside the first / last texel centre the weight saturates at 0 / 1, which is what clamping the two indices gives). The march starts
+// every instance on a face of its box, where the clamped-index form diverges into eight single-texel loads.
+PLR_DI void cellCoord(float t, int n, int* i0, float* a) {
+    int ti = (int)floorf((fastm::clampCoord(t) - 0.5f) * 256.0f + 0.5f);
+    ti = min(max(ti, 0), (n - 1) << 8);
+    *i0 = min(ti >> 8, n - 2);
+    *a = (float)(ti - (*i0 << 8)) * (1.0f / 256.0f);
+}
+PLR_DI float sampleSDFInterior(const Volume& v, float u, float vv, float ww) {
+    int i0, j0, k0; float a, b, c;
+    cellCoord(u * v.fw, v.w, &i0, &a);
+    cellCoord(vv * v.fh, v.h, &j0, &b);
+    cellCoord(ww * v.fd, v.d, &k0, &c);
+    const int sl = v.w * v.h;
+    const int o00 = k0 * sl + j0 * v.w + i0, o10 = o00 + v.w, o01 = o00 + sl, o11 = o01 + v.w;
+    auto pair = [&](int off, float& lo, float& hi) {
+        uint32_t u32;
+        __builtin_memcpy(&u32, v.p + off, 4);
+        lo = halfBitsToFloat(u32 & 0xffffu); hi = halfBitsToFloat(u32 >> 16);
+    };
+    float t000, t100, t010, t110, t001, t101, t011, t111;
+    pair(o00, t000, t100); pair(o10, t010, t110); pair(o01, t001, t101); pair(o11, t011, t111);
+    const float x00 = t000 + (t100 - t000) * a, x10 = t010 + (t110 - t010) * a, x01 = t001 + (t101 - t001) * a, x11 = t011 + (t111 - t011) * a;
+    const float y0v = x00 + (x10 - x00) * b, y1v = x01 + (x11 - x01) * b;
+    return y0v + (y1v - y0v) * c;
+}
+
 PLR_DI float sampleSDF(const Volume& v, float u, float vv, float ww) {
     int i0, j0, k0; float a, b, c;
     linearCoord(u * v.fw, &i0, &a);
@@ -106,10 +135,12 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
     const vec3 lim = sdfMaxLocal + 0.01f;
     vec3 pos = rayStartLocal;
     float dLast = 0.f, d = 0.f;
+    const bool thick = sdf.w >= 2 && sdf.h >= 2 && sdf.d >= 2; // uniform: the instance record is shared by the wave
     for (int i = 0; i < 128; i++) {
         if (fabsf(pos.x) > lim.x || fabsf(pos.y) > lim.y || fabsf(pos.z) > lim.z) break;
         dLast = d;
-        d = sampleSDF(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f);
+        d = thick ? sampleSDFInterior(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f)
+                  : sampleSDF(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f);
         if (d < distanceThreshold) {
             tr.hit = true;
             const float distanceGlobal = hitDistanceLocal * localToGlobalScale;
