@@ -91,19 +91,20 @@ struct TraceResult {
 };
 
 PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mx, float* tOut) {
-    bool hit = false;
-    float t = 100000.f;
+    // the three slab tests as selects (a face test is a handful of instructions; three divergent branches cost more)
     const float tx = ((o.x < 0.f ? -mx.x : mx.x) - o.x) * rcpf(dir.x);
-    vec3 p = o + tx * dir;
-    if (tx > 0.f && fabsf(p.y) <= mx.y && fabsf(p.z) <= mx.z) { t = gmin(t, tx); hit = true; }
     const float ty = ((o.y < 0.f ? -mx.y : mx.y) - o.y) * rcpf(dir.y);
-    p = o + ty * dir;
-    if (ty > 0.f && fabsf(p.x) <= mx.x && fabsf(p.z) <= mx.z) { t = gmin(t, ty); hit = true; }
     const float tz = ((o.z < 0.f ? -mx.z : mx.z) - o.z) * rcpf(dir.z);
-    p = o + tz * dir;
-    if (tz > 0.f && fabsf(p.x) <= mx.x && fabsf(p.y) <= mx.y) { t = gmin(t, tz); hit = true; }
+    const vec3 px = o + tx * dir, py = o + ty * dir, pz = o + tz * dir;
+    const bool hx = tx > 0.f && fabsf(px.y) <= mx.y && fabsf(px.z) <= mx.z;
+    const bool hy = ty > 0.f && fabsf(py.x) <= mx.x && fabsf(py.z) <= mx.z;
+    const bool hz = tz > 0.f && fabsf(pz.x) <= mx.x && fabsf(pz.y) <= mx.y;
+    float t = 100000.f;
+    t = hx ? gmin(t, tx) : t;
+    t = hy ? gmin(t, ty) : t;
+    t = hz ? gmin(t, tz) : t;
     *tOut = t;
-    return hit;
+    return hx || hy || hz;
 }
 
 PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Volume& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
