@@ -29,17 +29,18 @@ struct Volume {
 // is clamped to [0, n-1] and split into a cell index <= n-2 and a weight in [0, 1], so both texels of every pair are always in range
 // (outside the first / last texel centre the weight saturates at 0 / 1, which is what clamping the two indices gives). The march starts
 // every instance on a face of its box, where the clamped-index form diverges into eight single-texel loads.
-PLR_DI void cellCoord(float t, int n, int* i0, float* a) {
-    int ti = (int)floorf((fastm::clampCoord(t) - 0.5f) * 256.0f + 0.5f);
+// fx = (u * n - 0.5) * 256 + 0.5 arrives already folded into one multiply-add of the local position (see traceInstance)
+PLR_DI void cellCoord(float fx, int n, int* i0, float* a) {
+    int ti = (int)floorf(fastm::clampCoord(fx));
     ti = min(max(ti, 0), (n - 1) << 8);
     *i0 = min(ti >> 8, n - 2);
     *a = (float)(ti - (*i0 << 8)) * (1.0f / 256.0f);
 }
-PLR_DI float sampleSDFInterior(const Volume& v, float u, float vv, float ww) {
+PLR_DI float sampleSDFInterior(const Volume& v, vec3 fixedPoint) {
     int i0, j0, k0; float a, b, c;
-    cellCoord(u * v.fw, v.w, &i0, &a);
-    cellCoord(vv * v.fh, v.h, &j0, &b);
-    cellCoord(ww * v.fd, v.d, &k0, &c);
+    cellCoord(fixedPoint.x, v.w, &i0, &a);
+    cellCoord(fixedPoint.y, v.h, &j0, &b);
+    cellCoord(fixedPoint.z, v.d, &k0, &c);
     const int sl = v.w * v.h;
     const int o00 = k0 * sl + j0 * v.w + i0, o10 = o00 + v.w, o01 = o00 + sl, o11 = o01 + v.w;
     auto pair = [&](int off, float& lo, float& hi) {
@@ -137,10 +138,13 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
     vec3 pos = rayStartLocal;
     float dLast = 0.f, d = 0.f;
     const bool thick = sdf.w >= 2 && sdf.h >= 2 && sdf.d >= 2; // uniform: the instance record is shared by the wave
+    // uvw = pos / extends + 0.5 and the sampler's fixed-point texel coordinate (uvw * n - 0.5) * 256 + 0.5 as one multiply-add per axis
+    const vec3 fpScale(invExt.x * 256.f * sdf.fw, invExt.y * 256.f * sdf.fh, invExt.z * 256.f * sdf.fd);
+    const vec3 fpBias(128.f * sdf.fw - 127.5f, 128.f * sdf.fh - 127.5f, 128.f * sdf.fd - 127.5f);
     for (int i = 0; i < 128; i++) {
         if (fabsf(pos.x) > lim.x || fabsf(pos.y) > lim.y || fabsf(pos.z) > lim.z) break;
         dLast = d;
-        d = thick ? sampleSDFInterior(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f)
+        d = thick ? sampleSDFInterior(sdf, vec3(pos.x * fpScale.x + fpBias.x, pos.y * fpScale.y + fpBias.y, pos.z * fpScale.z + fpBias.z))
                   : sampleSDF(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f);
         if (d < distanceThreshold) {
             tr.hit = true;
