@@ -24,6 +24,8 @@ extern "C" void orc_math_eval(int fn, const float* a, const float* b, float* out
             case 9: r = std::sqrt(x); break;
             case 10: r = x / y; break;
             case 11: { const vec3 v = normalize(vec3(x, y, 1.f)); r = v.x; break; }
+            case 12: r = gmin(x, y); break;
+            case 13: r = gmax(x, y); break;
             default: break;
         }
         out[i] = r;

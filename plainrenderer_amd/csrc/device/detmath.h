@@ -24,8 +24,11 @@ PLR_DI float u2f(uint32_t u) { return __uint_as_float(u); }
 PLR_DI float gmin(float x, float y) { return __builtin_fminf(x, y); }
 PLR_DI float gmax(float x, float y) { return __builtin_fmaxf(x, y); }
 #else
-PLR_DI float gmin(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((y < x) ? y : x)); }
-PLR_DI float gmax(float x, float y) { return (x != x) ? y : ((y != y) ? x : ((x < y) ? y : x)); }
+// = (x != x) ? y : ((y != y) ? x : ((y < x) ? y : x)) for every operand pair (and likewise for the maximum): minNum / maxNum already return
+// the non-NaN operand and the smaller / larger one; the comparison form additionally returns x when the operands compare equal (zeros of
+// opposite sign), which the select restores. Written this way it is three instructions; the nested conditionals became divergent branches.
+PLR_DI float gmin(float x, float y) { return x == y ? x : __builtin_fminf(x, y); }
+PLR_DI float gmax(float x, float y) { return x == y ? x : __builtin_fmaxf(x, y); }
 #endif
 PLR_DI float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 PLR_DI float gsign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }

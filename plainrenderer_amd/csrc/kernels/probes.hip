@@ -25,6 +25,8 @@ __global__ void mathEvalKernel(int fn, const float* __restrict__ a, const float*
         case 9: r = sqrtf(x); break;
         case 10: r = x / y; break;
         case 11: { const vec3 v = normalize(vec3(x, y, 1.f)); r = v.x; break; }
+        case 12: r = gmin(x, y); break;
+        case 13: r = gmax(x, y); break;
         default: break;
     }
     out[i] = r;

@@ -28,6 +28,23 @@ def test_gpu_detmath_bit_identical(backend, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_min_max_match_the_comparison_form_on_special_operands(backend, oracle):
+    """detmath.h gmin / gmax on the device are `x == y ? x : minNum(x, y)`; the oracle's are the GLSL comparison form with the NaN rule.
+    All pairs of special values (zeros of both signs, infinities, NaN, denormals, ordinary numbers) plus random pairs."""
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 3.5, 3.5000002, -7.25, 65504.0], np.float32)
+    a, b = np.meshgrid(special, special, indexing="ij")
+    r = np.random.default_rng(9)
+    a = np.concatenate([a.reshape(-1), r.normal(0, 10, 50000).astype(np.float32)])
+    b = np.concatenate([b.reshape(-1), r.normal(0, 10, 50000).astype(np.float32)])
+    b[-1000:] = a[-1000:]  # equal operands
+    for fn in (12, 13):
+        g = backend.debugMathEval(fn, a, b)
+        o = oracle.math_eval(fn, a, b)
+        same = (g.view(np.uint32) == o.view(np.uint32)) | (np.isnan(g) & np.isnan(o))
+        assert same.all(), "fn %d: %s" % (fn, list(zip(a[~same][:5], b[~same][:5], g[~same][:5], o[~same][:5])))
+
+
+@pytest.mark.gpu
 def test_gpu_r11g11b10_encoder_on_a_bit_pattern_lattice(backend, oracle):
     """The device encoder is branch-free (both range results computed, special cases override); the oracle's is the early-return form.
     Every sign/exponent value x every value of the top 10 mantissa bits x the low-bit patterns around the rounding ties of both
