@@ -65,25 +65,26 @@ PLR_DI float det_log_reduced(float x, int* eOut) {
     return f - s * (f - z * p);
 }
 
+// special operands override the general result in reverse priority (NaN -> NaN, negative -> NaN, +-0 -> -inf, +inf -> +inf): same values as
+// early returns, without four divergent branches per call (the reduction is defined, if meaningless, for every bit pattern)
+PLR_DI float det_log_special(float x, float general) {
+    float r = f2u(x) == 0x7f800000u ? x : general;
+    r = x == 0.f ? u2f(0xff800000u) : r;
+    r = x < 0.f ? u2f(0x7fc00000u) : r;
+    return x != x ? x : r;
+}
+
 PLR_DI float det_logf(float x) {
-    if (x != x) return x;
-    if (x < 0.f) return u2f(0x7fc00000u);
-    if (x == 0.f) return u2f(0xff800000u);
-    if (f2u(x) == 0x7f800000u) return x;
     int e;
     const float r = det_log_reduced(x, &e);
     const float fe = (float)e;
-    return fe * PLR_LN2_HI + (fe * PLR_LN2_LO + r);
+    return det_log_special(x, fe * PLR_LN2_HI + (fe * PLR_LN2_LO + r));
 }
 
 PLR_DI float det_log2f(float x) {
-    if (x != x) return x;
-    if (x < 0.f) return u2f(0x7fc00000u);
-    if (x == 0.f) return u2f(0xff800000u);
-    if (f2u(x) == 0x7f800000u) return x;
     int e;
     const float r = det_log_reduced(x, &e);
-    return (float)e + r * PLR_INV_LN2;
+    return det_log_special(x, (float)e + r * PLR_INV_LN2);
 }
 
 PLR_DI float det_exp_poly_scale(float r, int k) {
