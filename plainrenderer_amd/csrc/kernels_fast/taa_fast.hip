@@ -11,6 +11,7 @@
 // kernel; here all nine use the centre tap's weights. Stated tolerance: tests/test_fast_kernels.py.
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../device/fastmath.h"
 
 namespace plr {
 namespace fasttaa {
@@ -36,7 +37,7 @@ PLR_DI vec3 historyTap(const ImgView& im, float u, float v) {
 // texelFetch of the motion buffer with the out-of-range test as a select instead of a branch per pixel row
 PLR_DI vec4 motionFetch(const ImgView& im, int x, int y) {
     const bool inside = (uint32_t)x < (uint32_t)im.w && (uint32_t)y < (uint32_t)im.h;
-    const vec4 t = Texel<F_RG16SN>::load(im.ptr, (size_t)clampi(y, im.h) * (size_t)im.w + (size_t)clampi(x, im.w));
+    const vec4 t = Texel<F_RG16SN>::load(im.ptr, fastm::texelIndex((uint32_t)clampi(x, im.w), (uint32_t)clampi(y, im.h), (uint32_t)im.w));
     return vec4(inside ? t.x : 0.f, inside ? t.y : 0.f, inside ? t.z : 0.f, inside ? t.w : 0.f);
 }
 
@@ -244,14 +245,14 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
     const float* dep = (const float*)depthBuffer.ptr;
 
     auto loadRow = [&](int y) -> Column {
-        const vec3 c = unpackR11G11B10(cur[(size_t)clampi(y, current.h) * (size_t)current.w + xc]);
+        const vec3 c = unpackR11G11B10(cur[fastm::texelIndex((uint32_t)xc, (uint32_t)clampi(y, current.h), (uint32_t)current.w)]);
         const float l = lum(c);
         Column o;
         if (TONEMAP) { const float s = rcpf(1.f + l); o.r = c.x * s; o.g = c.y * s; o.b = c.z * s; o.l = l * s; }
         else { o.r = c.x; o.g = c.y; o.b = c.z; o.l = l; }
         o.d = 0.f;
         if (DILATE) {
-            const float dv = dep[(size_t)clampi(y, depthBuffer.h) * (size_t)depthBuffer.w + clampi(px, depthBuffer.w)];
+            const float dv = dep[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
             o.d = (xInDepth && y >= 0 && y < depthBuffer.h) ? dv : 0.f;
         }
         return o;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 uint4 v;
-                __builtin_memcpy(&v, hist + (size_t)clampi(j0 - 1 + r, hh) * (size_t)hw + (size_t)(i0 - 1), 16);
+                __builtin_memcpy(&v, hist + fastm::texelIndex((uint32_t)(i0 - 1), (uint32_t)clampi(j0 - 1 + r, hh), (uint32_t)hw), 16);
                 t[r][0] = v.x; t[r][1] = v.y; t[r][2] = v.z; t[r][3] = v.w;
             }
         } else {
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
         if (TONEMAP) color = tonemapReverseF(color);
         const uint32_t packed = packR11G11B10(color);
         if (isOutputLane) {
-            if (px < historyDst.w && py < historyDst.h) ((uint32_t*)historyDst.ptr)[(size_t)py * (size_t)historyDst.w + px] = packed;
-            ((uint32_t*)output.ptr)[(size_t)py * (size_t)output.w + px] = packed;
+            if (px < historyDst.w && py < historyDst.h) ((uint32_t*)historyDst.ptr)[fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)historyDst.w)] = packed;
+            ((uint32_t*)output.ptr)[fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)output.w)] = packed;
         }
         // slide the window down one row
         C[0] = C[1]; L[0] = L[1]; R[0] = R[1];
