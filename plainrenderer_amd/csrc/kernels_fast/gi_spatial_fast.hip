@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     float lengthModifier = 1.f;
     const uint32_t ywi = (uint32_t)inYSH.w;
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
+    const float halfW = 0.5f * yW, halfH = 0.5f * yH, cu0 = u0 - 0.5f, cv0 = v0 - 0.5f;
+    const float k0c = k0 + 0.5f * (k1 + k2); // q = k0 + v k1 + u k2 in centred coordinates
     const uint2* yshTexels = (const uint2*)inYSH.ptr;
     const uint32_t* cocgTexels = (const uint32_t*)inCoCg.ptr;
     // Samples are processed four at a time, branch-free, so that the gathers of a group are in flight together (a per-sample branch
@@ -147,18 +149,19 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
             const vec3 clip = P0 + ox * PT + oy * PB;
             const float invW = rcpf(clip.z) * 0.5f;
-            float u = clip.x * invW + 0.5f, v = clip.y * invW + 0.5f;
+            // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
+            float cu = clip.x * invW, cv = clip.y * invW;
             // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
-            u = fabsf(u - 0.5f) > 0.5f ? u0 - ox : u;
-            v = fabsf(v - 0.5f) > 0.5f ? v0 - oy : v;
-            su[k] = u; sv[k] = v;
-            off[k] = fabsf(u - 0.5f) > 0.5f || fabsf(v - 0.5f) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
+            cu = fabsf(cu) > 0.5f ? cu0 - ox : cu;
+            cv = fabsf(cv) > 0.5f ? cv0 - oy : cv;
+            su[k] = cu; sv[k] = cv;
+            off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
             lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
             // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
-            const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(u * yW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(v * yH, 0.f, yHm1);
+            const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
             ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
             di[k] = SAME_GRID ? ti[k]
-                              : (uint32_t)(int)__builtin_amdgcn_fmed3f(v * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(u * dW, 0.f, dWm1);
+                              : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
         }
         if (PACKED) {
             uint4 t4[4];
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float den = u2f(t4[k].w); // <= 0: texel had a NaN component (skip)
-                const float q = k0 + sv[k] * k1 + su[k] * k2;
+                const float q = k0c + sv[k] * k1 + su[k] * k2;
                 const float num = fabsf(c0 * den + nf * q);
                 // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
                 float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(__builtin_fmaxf(num, 0.0001f * den)), 0.f, 1.f);
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             // depthLinear = nf / den with den = far + (1 - depth) * (near - far) > 0; the distance to the tangent plane is
             // |c0 + depthLinear * q| = |c0 * den + nf * q| / den, so weight = clamp(0.25 * den / max(|c0 * den + nf * q|, 1e-4 * den))^2: one reciprocal
             const float den = farP + (1.f - dep[k]) * nmf;
-            const float q = k0 + sv[k] * k1 + su[k] * k2;
+            const float q = k0c + sv[k] * k1 + su[k] * k2;
             const float num = fabsf(c0 * den + nf * q);
             float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
             weight *= weight;
