@@ -93,7 +93,7 @@ PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
     const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w), y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
     const int xb = max(min(x0, im.w - 2), 0);
     auto rowPair = [&](int y, vec4* t0, vec4* t1) {
-        const uint2* row = (const uint2*)im.ptr + (size_t)y * (size_t)im.w;
+        const uint2* row = (const uint2*)im.ptr + __umul24((uint32_t)y, (uint32_t)im.w);
         uint4 q; // the launcher sends images narrower than two texels to the general kernel
         __builtin_memcpy(&q, row + xb, 16);
         const uint2 lo = make_uint2(q.x, q.y), hi = make_uint2(q.z, q.w);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const GlobalUbo* g = P.g;
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const float su = fx * rcpf((float)g->screenResolution[0]), sv = fy * rcpf((float)g->screenResolution[1]);
-    const size_t idx = (size_t)py * (size_t)P.color.w + px;
+    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
     const float depth = ((const float*)P.depth.ptr)[idx];
     const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
     const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     vec3 lightingIndirect;
     if (INDIRECT_TECH == 0) {
         const int ix = min(max((int)floorf(su * (float)P.ysh.w), 0), P.ysh.w - 1), iy = min(max((int)floorf(sv * (float)P.ysh.h), 0), P.ysh.h - 1);
-        const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, (size_t)iy * (size_t)P.ysh.w + ix);
-        const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, (size_t)iy * (size_t)P.cocg.w + ix);
+        const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.ysh.w));
+        const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.cocg.w));
         // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
         const vec4 shN(0.5f, -0.8660254f * N.y, 0.8660254f * N.z, -0.8660254f * N.x);
         const float irradiance_Y = dot(irradiance_Y_SH, shN);
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         linearCoord(nv * (float)vol.h, &j0, &b);
         linearCoord(z * (float)vol.d, &k0, &c);
         const int x0 = clampi(i0, vol.w), x1 = clampi(i0 + 1, vol.w);
-        const size_t y0 = (size_t)clampi(j0, vol.h) * vol.w, y1 = (size_t)clampi(j0 + 1, vol.h) * vol.w;
-        const size_t sl = (size_t)vol.w * vol.h;
-        const size_t z0 = (size_t)clampi(k0, vol.d) * sl, z1 = (size_t)clampi(k0 + 1, vol.d) * sl;
+        const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
+        const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
+        const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
         const int xb = max(min(x0, vol.w - 2), 0);
-        auto rowLerp = [&](size_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
+        auto rowLerp = [&](uint32_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
             const uint2* row = (const uint2*)vol.ptr + rowBase;
             uint4 q;
             __builtin_memcpy(&q, row + xb, 16);
