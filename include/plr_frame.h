@@ -39,6 +39,8 @@ typedef struct plrf_settings {
     uint32_t band_taa_history_halo; /* rows of the TAA history exchanged between bands (default 32) */
     uint32_t run_volumetrics; /* the four froxel passes produce volumetricIntegrationVolume (reference default VolumetricsSettings; noise volume "perlinNoise3D" is an input) */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
+    uint32_t band_overlap_exchange; /* default 1: producers of exchanged images run their edge rows first and the exchange callback is called twice,
+                                       with PLRF_EXCHANGE_BEGIN (start, do not wait) and PLRF_EXCHANGE_END (wait); 0: one call per exchange */
 } plrf_settings;
 
 /* ---- band rendering: halo exchange hooks ----
@@ -48,6 +50,11 @@ typedef struct plrf_settings {
  * histogram over all bands in place (plrf_get_histogram_exchange). */
 enum plrf_exchange_id { PLRF_EXCHANGE_HISTOGRAM = 0, PLRF_EXCHANGE_GI_TRACE = 1, PLRF_EXCHANGE_GI_TEMPORAL = 2, PLRF_EXCHANGE_GI_HISTORY = 3,
                         PLRF_EXCHANGE_POST = 4, PLRF_EXCHANGE_COUNT = 5 };
+/* phase bits or-ed into exchange_id when band_overlap_exchange is on (ids 1..4; the histogram is always one call): after the producer's
+ * edge rows are launched the callback gets id | PLRF_EXCHANGE_BEGIN and must only START the transfers (stream-ordered after what is already
+ * on hip_stream); the producer's interior rows are launched next and run beside the transfers; before the first consumer of the halo rows
+ * the callback gets id | PLRF_EXCHANGE_END and must make hip_stream wait for their completion. No bits: start and wait in one call. */
+enum plrf_exchange_phase { PLRF_EXCHANGE_BEGIN = 0x100, PLRF_EXCHANGE_END = 0x200, PLRF_EXCHANGE_ID_MASK = 0xff };
 typedef int (*plrf_exchange_callback)(void* user, int exchange_id, void* hip_stream);
 /* an image of image_rows rows of row_bytes bytes at device_ptr; this band owns rows [row_begin, row_end): it sends its first
  * halo_rows owned rows to the band above and its last halo_rows to the band below, and receives rows

@@ -95,6 +95,32 @@ static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h, RowRang
     exe.dispatchCount[1] = hi > lo ? (hi + 7) / 8 - lo / 8 : 0;
     exe.dispatchCount[2] = 1;
 }
+
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo, const std::function<void()>& edgesDone) {
+    const uint32_t r0 = std::min(rows.begin, h), r1 = std::min(rows.end, h);
+    if (!edgesDone || halo == 0 || r1 <= r0) {
+        dispatch8(exe, w, h, rows);
+        be.setComputePassExecution(exe);
+        if (edgesDone) edgesDone();
+        return;
+    }
+    // rows the band above / below needs first; a pass's result does not depend on how its rows are split over dispatches
+    // (edges rounded up to 16 rows: the coarsest launch granularity of a pass, two 8-row workgroups of the trace)
+    halo = (halo + 15u) & ~15u;
+    // split points on 16-row boundaries of the image; no edge on a side without a neighbouring band (first / last rows of the image)
+    const uint32_t topEnd = r0 == 0 ? r0 : std::min((r0 + halo + 15u) & ~15u, r1);
+    const uint32_t bottomBegin = r1 >= h ? r1 : std::max((r1 > halo ? r1 - halo : 0u) & ~15u, topEnd);
+    auto part = [&](uint32_t a, uint32_t b) {
+        if (b <= a) return;
+        ComputePassExecution e = exe;
+        dispatch8(e, w, h, RowRange{a, b});
+        be.setComputePassExecution(e);
+    };
+    part(r0, topEnd);
+    part(bottomBegin, r1);
+    edgesDone();
+    part(topEnd, bottomBegin);
+}
 static RowRange scaleRows(RowRange r, uint32_t divisor) { // the rows of a 1/divisor resolution image that cover r
     if (r.end == 0xffffffffu && r.begin == 0) return r;
     return {r.begin / divisor, (r.end + divisor - 1) / divisor};
@@ -130,7 +156,7 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     m_taaResolveWeightBuffer = be.createUniformBuffer(ub);
 }
 void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                                RowRange rows) const {
+                                RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone) const {
     // TAA.cpp:139-166
     const size_t frameIndexMod2 = fi.mod2();
     const ImageHandle historySrc = m_historyBuffers[frameIndexMod2];
@@ -142,8 +168,7 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     exe.genericInfo.resources.sampledImages = {ImageResource(colorSrc, 0, 0), ImageResource(historySrc, 0, 3), ImageResource(currentFrame.motionBuffer, 0, 4),
                                                ImageResource(currentFrame.depthBuffer, 0, 5)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_taaResolveWeightBuffer, 6)};
-    dispatch8(exe, td.width, td.height, rows);
-    be.setComputePassExecution(exe);
+    recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone);
 }
 void TAA::computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
                                        ImageHandle target, RowRange rows) const { // TAA.cpp:85-137
@@ -419,8 +444,8 @@ void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps,
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
                                                 StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
-    dispatch8(exe, td.width, td.height, band ? band->traceRows : RowRange{});
-    be.setComputePassExecution(exe);
+    if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); });
+    else recordRows(be, exe, td.width, td.height, band ? band->traceRows : RowRange{});
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTrace); // spatial pass 0 reads neighbouring bands' rays
 }
 
@@ -446,8 +471,8 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
                                                    ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
                                                    ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
-        dispatch8(exe, td.width, td.height, rows);
-        be.setComputePassExecution(exe);
+        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); });
+        else recordRows(be, exe, td.width, td.height, rows);
     }
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
     {
@@ -456,10 +481,11 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
-        dispatch8(exe, td.width, td.height, rows);
-        be.setComputePassExecution(exe);
+        recordRows(be, exe, td.width, td.height, rows);
     }
-    if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiHistory); // upscale + next frame's reprojection read History[0]
+    // (this exchange is small - 16 rows - and its producer launches a packing pre-pass per dispatch: it is not split / overlapped)
+    if (band && band->exchangeWhole) band->exchangeWhole(band->user, ExchangeGiHistory);
+    else if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiHistory); // upscale + next frame's reprojection read History[0]
     if (s.halfResTrace) {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectLightingUpscale;
@@ -503,7 +529,11 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         if (b.rowEnd > H || b.rowBegin % bandAlignment != 0 || (b.rowEnd % bandAlignment != 0 && b.rowEnd != H))
             throw std::runtime_error("band rows must lie inside the frame and start/end on multiples of 64 (or at the last row)");
     }
-    for (int i = 0; i < ExchangeCount; i++) m_exchangeCtx[i] = {this, i};
+    for (int i = 0; i < ExchangeCount; i++) {
+        m_exchangeCtx[i] = {this, i};
+        m_exchangeCtx[ExchangeCount + i] = {this, i | ExchangeBegin};
+        m_exchangeCtx[2 * ExchangeCount + i] = {this, i | ExchangeEnd};
+    }
     // the backend is set up by the caller (plr_setup), like gRenderBackend.setup in the reference's main(); match the swapchain
     const ImageDescription sw = m_be.getImageDescription(m_be.getSwapchainInputImage());
     if (sw.width != W || sw.height != H) m_be.recreateSwapchain(W, H);
@@ -1022,7 +1052,9 @@ int FramePipeline::exchangeTrampoline(void* user, void* stream) {
 }
 
 void FramePipeline::exchangePoint(int id, const char* label) {
-    if (m_exchangeFn) m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[id], label);
+    // id may carry a phase (ExchangeBegin / ExchangeEnd)
+    const int phase = (id & ExchangeBegin) ? 1 : ((id & ExchangeEnd) ? 2 : 0);
+    if (m_exchangeFn) m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[phase * ExchangeCount + (id & ExchangeIdMask)], label);
 }
 
 void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
@@ -1091,25 +1123,32 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             gb.traceRows = bandRows(0, div);
             gb.upscaleRows = bandRows(settings.band.colorHalo);
             gb.user = this;
-            gb.exchangePoint = [](void* user, int id) {
-                FramePipeline* self = (FramePipeline*)user;
+            gb.giHalo = settings.band.giHalo; gb.giHistoryHalo = settings.band.giHistoryHalo;
+            // registers the images of a GI exchange and records its callback: phase 0 = whole exchange, ExchangeBegin after the producer's
+            // edge rows, ExchangeEnd (items already registered) before the consumer
+            static const auto giExchange = [](FramePipeline* self, int id, int phase) {
                 const SDFGI& gi = self->m_sdfGi;
                 const uint32_t d = self->settings.sdfTrace.halfResTrace ? 2 : 1;
                 const BandSettings& b = self->settings.band;
+                const bool reg = phase != ExchangeEnd;
+                const char* what = phase == ExchangeBegin ? " (start)" : (phase == ExchangeEnd ? " (wait)" : "");
                 if (id == ExchangeGiTrace) {
-                    self->addExchangeItem(id, gi.m_indirectDiffuse_Y_SH[0], d, b.giHalo);
-                    self->addExchangeItem(id, gi.m_indirectDiffuse_CoCg[0], d, b.giHalo);
-                    self->exchangePoint(id, "Exchange: traced GI halo rows");
+                    if (reg) { self->addExchangeItem(id, gi.m_indirectDiffuse_Y_SH[0], d, b.giHalo); self->addExchangeItem(id, gi.m_indirectDiffuse_CoCg[0], d, b.giHalo); }
+                    self->exchangePoint(id | phase, (std::string("Exchange: traced GI halo rows") + what).c_str());
                 } else if (id == ExchangeGiTemporal) {
-                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[1], d, b.giHalo);
-                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[1], d, b.giHalo);
-                    self->exchangePoint(id, "Exchange: temporally filtered GI halo rows");
+                    if (reg) { self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[1], d, b.giHalo); self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[1], d, b.giHalo); }
+                    self->exchangePoint(id | phase, (std::string("Exchange: temporally filtered GI halo rows") + what).c_str());
                 } else {
-                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[0], d, b.giHistoryHalo);
-                    self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[0], d, b.giHistoryHalo);
-                    self->exchangePoint(id, "Exchange: GI history halo rows");
+                    if (reg) { self->addExchangeItem(id, gi.m_indirectDiffuseHistory_Y_SH[0], d, b.giHistoryHalo); self->addExchangeItem(id, gi.m_indirectDiffuseHistory_CoCg[0], d, b.giHistoryHalo); }
+                    self->exchangePoint(id | phase, (std::string("Exchange: GI history halo rows") + what).c_str());
                 }
             };
+            const bool overlap = settings.band.overlapExchange && m_exchangeFn;
+            if (overlap) {
+                gb.exchangeBegin = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeBegin); };
+                gb.exchangePoint = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeEnd); };
+                gb.exchangeWhole = [](void* user, int id) { giExchange((FramePipeline*)user, id, 0); };
+            } else gb.exchangePoint = [](void* user, int id) { giExchange((FramePipeline*)user, id, 0); };
             m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace, &gb);
         } else m_sdfGi.computeIndirectLighting(m_be, m_frameIndex, deps, settings.sdfTrace);
     }
@@ -1120,20 +1159,33 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     if (settings.runShading) computeDeferredShading(currentRenderTarget.colorBuffer, currentRenderTarget);
     // [sky: folded into the deferred pass' sky stand-in]
     ImageHandle currentSrc = currentRenderTarget.colorBuffer;
+    bool postExchangeStarted = false;
     if (settings.runTAA && settings.taa.enabled) {
         if (settings.taa.useSeparateSupersampling) { // RenderFrontend.cpp:391-395 (whole-frame only: the stage has no halo plan for band rendering)
             if (band) throw std::runtime_error("useSeparateSupersampling is not supported in band rendering");
             m_taa.computeTemporalSuperSampling(m_be, m_frameIndex, currentRenderTarget, previousRenderTarget, m_postProcessBuffers[0]);
             currentSrc = m_postProcessBuffers[0];
         }
-        m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
+        // the bloom chain reads postHalo rows around the band; next frame's temporal filter reprojects into the history image
+        const bool bloomOn = settings.runBloom && settings.bloom.enabled;
+        if (band && settings.band.overlapExchange && m_exchangeFn) {
+            const uint32_t edge = bloomOn ? std::max(settings.band.postHalo, settings.band.taaHistoryHalo) : settings.band.taaHistoryHalo;
+            m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0), edge, [&] {
+                if (bloomOn) addExchangeItem(ExchangePost, m_postProcessBuffers[1], 1, settings.band.postHalo);
+                addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
+                exchangePoint(ExchangePost | ExchangeBegin, "Exchange: resolved colour halo rows (start)");
+            });
+            postExchangeStarted = true;
+        } else m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
         currentSrc = m_postProcessBuffers[1];
     }
     if (band) {
-        // the bloom chain reads postHalo rows around the band; next frame's temporal filter reprojects into the history image
-        if (settings.runBloom && settings.bloom.enabled) addExchangeItem(ExchangePost, currentSrc, 1, settings.band.postHalo);
-        if (settings.runTAA && settings.taa.enabled) addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
-        if (!m_exchangeItems[ExchangePost].empty()) exchangePoint(ExchangePost, "Exchange: resolved colour halo rows");
+        if (postExchangeStarted) exchangePoint(ExchangePost | ExchangeEnd, "Exchange: resolved colour halo rows (wait)");
+        else {
+            if (settings.runBloom && settings.bloom.enabled) addExchangeItem(ExchangePost, currentSrc, 1, settings.band.postHalo);
+            if (settings.runTAA && settings.taa.enabled) addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
+            if (!m_exchangeItems[ExchangePost].empty()) exchangePoint(ExchangePost, "Exchange: resolved colour halo rows");
+        }
     }
     if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0));
     if (settings.runTonemap) computeTonemapping(currentSrc);

@@ -7,6 +7,7 @@
 #pragma once
 #include <array>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../../include/plr_render_backend.hpp"
@@ -66,8 +67,15 @@ struct BandSettings {
     uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
     uint32_t postHalo = 320;            // full-resolution rows of the temporal filter's result exchanged for the bloom chain
     uint32_t taaHistoryHalo = 32;       // full-resolution rows of the TAA history exchanged (reach of next frame's reprojection + bicubic footprint)
+    // Overlap the halo transfers with compute: the pass that produces an exchanged image is recorded as "edge rows first" (the rows the
+    // neighbours need), then the exchange is STARTED (callback with ExchangeBegin: enqueue the sends / receives, do not wait), then the
+    // interior rows are recorded, and the callback with ExchangeEnd (wait) sits where the first consumer of the halo rows is recorded.
+    // Off: one callback per exchange point (start and wait), the producer in one dispatch.
+    bool overlapExchange = true;
     bool enabled() const { return rowEnd > rowBegin; }
 };
+// phase bits or-ed into the exchange id a callback receives (0: start the exchange and wait for it)
+enum ExchangePhase : int { ExchangeBegin = 0x100, ExchangeEnd = 0x200, ExchangeIdMask = 0xff };
 enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeCount = 5 };
 // one image whose rows next to the band must be refreshed from the neighbours: this band sends its first / last haloRows owned
 // rows up / down and receives [rowBegin - haloRows, rowBegin) and [rowEnd, rowEnd + haloRows) (clipped to the image)
@@ -122,7 +130,7 @@ class TAA {
 public:
     void init(RenderBackend& be, int imageWidth, int imageHeight, const TAASettings& settings);
     void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                               RowRange rows = {}) const;
+                               RowRange rows = {}, uint32_t edgeRows = 0, const std::function<void()>& edgesDone = nullptr) const;
     ImageHandle historyDst(const FrameIndexCounter& fi) const { return m_historyBuffers[(fi.mod2() + 1) % 2]; }
     // TAASettings::useSeparateSupersampling (TAA.cpp:85-137): luminance of the current frame, then a 2-frame blend with contrast / depth rejection
     void computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
@@ -151,8 +159,13 @@ struct GiBand {
     RowRange traceRows;    // trace-resolution rows traced and filtered
     RowRange upscaleRows;  // full-resolution rows of the upscale
     void* user = nullptr;
-    void (*exchangePoint)(void* user, int exchangeId) = nullptr; // records the exchange as a host callback execution
+    void (*exchangePoint)(void* user, int exchangeId) = nullptr; // records the exchange (or, with overlap, the wait for it) as a host callback execution
+    void (*exchangeBegin)(void* user, int exchangeId) = nullptr; // overlap: records the start of the exchange; null = no overlap
+    void (*exchangeWhole)(void* user, int exchangeId) = nullptr; // overlap: an exchange that is not split (start and wait in one callback)
+    uint32_t giHalo = 0, giHistoryHalo = 0;                      // trace-resolution halo rows of exchanges 1/2 and 3
 };
+// records exe over `rows` of a w x h image; with edgesDone the first / last `halo` rows are recorded first, then edgesDone(), then the rest
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo = 0, const std::function<void()>& edgesDone = nullptr);
 
 struct SDFTraceDependencies {
     FrameRenderTargets currentFrame, previousFrame;
@@ -320,7 +333,7 @@ private:
 
     ExchangeCallback m_exchangeFn = nullptr;
     void* m_exchangeUser = nullptr;
-    struct ExchangeCtx { FramePipeline* self; int id; } m_exchangeCtx[ExchangeCount];
+    struct ExchangeCtx { FramePipeline* self; int id; } m_exchangeCtx[3 * ExchangeCount]; // [phase * ExchangeCount + id], phase 0 / begin / end
     std::vector<ExchangeItem> m_exchangeItems[ExchangeCount];
 };
 

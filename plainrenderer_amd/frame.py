@@ -25,7 +25,7 @@ class PlrfSettings(C.Structure):
                                           "run_light_matrix")] + [("volumetrics_max_distance", C.c_float), ("taa_use_separate_supersampling", C.c_uint32), ("taa_supersample_use_tonemapping", C.c_uint32),
                                                                               ("sdf_debug_mode", C.c_uint32), ("sdf_debug_tile_usage_with_hiz", C.c_uint32),
                                                                               ("sdf_debug_use_influence_radius", C.c_uint32), ("band_taa_history_halo", C.c_uint32), ("run_volumetrics", C.c_uint32),
-                                                                              ("run_sky_luts", C.c_uint32)]
+                                                                              ("run_sky_luts", C.c_uint32), ("band_overlap_exchange", C.c_uint32)]
 
 
 class PlrfExchangeItem(C.Structure):
@@ -35,6 +35,7 @@ class PlrfExchangeItem(C.Structure):
 
 EXCHANGE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 EXCHANGE_HISTOGRAM, EXCHANGE_GI_TRACE, EXCHANGE_GI_TEMPORAL, EXCHANGE_GI_HISTORY, EXCHANGE_POST = range(5)
+EXCHANGE_BEGIN, EXCHANGE_END, EXCHANGE_ID_MASK = 0x100, 0x200, 0xff  # phase bits (band_overlap_exchange)
 
 
 class PlrfCamera(C.Structure):

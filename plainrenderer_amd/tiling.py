@@ -104,6 +104,10 @@ class DistTransport:
 
     def exchange(self, items, stream_ptr, band_meta):
         """items: [Rows] of this band; band_meta(i) -> (row_begin, row_end) scaled like items[i] for any band index."""
+        self.end_exchange(self.begin_exchange(items, stream_ptr, band_meta), stream_ptr)
+
+    def begin_exchange(self, items, stream_ptr, band_meta):
+        """start the sends / receives (ordered after what is on the stream now) and return the handle end_exchange waits for"""
         dist, ops = self.dist, []
         with self._on_stream(stream_ptr):
             for i, r in enumerate(items):
@@ -112,9 +116,12 @@ class DistTransport:
                 for peer, kind, a, b in neighbour_plan(bands, self.rank, self.world):
                     t = self._tensor(r.ptr + a * r.row_bytes, (b - a) * r.row_bytes)
                     ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+            return dist.batch_isend_irecv(ops) if ops else []
+
+    def end_exchange(self, handle, stream_ptr):
+        with self._on_stream(stream_ptr):
+            for req in handle:
+                req.wait()
 
     def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
         with self._on_stream(stream_ptr):
@@ -168,6 +175,13 @@ class LocalTransport:
                 self._call(self.g.lib.plr_copy_device_memory(C.c_void_p(r.ptr + a * r.row_bytes), C.c_void_p(src), C.c_size_t((b - a) * r.row_bytes)), "plr_copy_device_memory")
         self._retire()
 
+    def begin_exchange(self, items, stream_ptr, band_meta):
+        self.exchange(items, stream_ptr, band_meta)  # threads of one process: the copy is done when this returns
+        return None
+
+    def end_exchange(self, handle, stream_ptr):
+        pass
+
     def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
         host = np.zeros(nbytes // 4, np.uint32)
         self._call(self.g.lib.plr_read_device_memory(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes)), "plr_read_device_memory")
@@ -186,10 +200,16 @@ class Exchange:
         self.fp, self.t, self.height, self.n, self.index = fp, transport, height, n_bands, index
         self._hist_id = EXCHANGE_HISTOGRAM
         self.calls = []
+        self._pending = {}
         fp.set_exchange_callback(self.run)
 
     def run(self, exchange_id, stream_ptr):
+        from .frame import EXCHANGE_BEGIN, EXCHANGE_END, EXCHANGE_ID_MASK
         self.calls.append(exchange_id)
+        phase, exchange_id = exchange_id & (EXCHANGE_BEGIN | EXCHANGE_END), exchange_id & EXCHANGE_ID_MASK
+        if phase == EXCHANGE_END:
+            self.t.end_exchange(self._pending.pop(exchange_id), stream_ptr)
+            return
         if exchange_id == self._hist_id:
             ptr, nbytes = self.fp.histogram_exchange()
             self.t.all_reduce_histogram(ptr, nbytes, stream_ptr)
@@ -202,4 +222,7 @@ class Exchange:
             b0, b1 = band_rows(self.height, self.n, b)
             return b0 // div, min((b1 + div - 1) // div, items[i].image_rows)
 
-        self.t.exchange(items, stream_ptr, band_meta)
+        if phase == EXCHANGE_BEGIN:
+            self._pending[exchange_id] = self.t.begin_exchange(items, stream_ptr, band_meta)
+        else:
+            self.t.exchange(items, stream_ptr, band_meta)

@@ -219,12 +219,16 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
     # partitioned frame must equal the unpartitioned one in every bit, over 3 frames of temporal feedback
     inputs = _make_inputs()
     full = _run_full(inputs, True, half_res)
-    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H)
+    # half_res 1: the default overlapped exchange (producers' edge rows first, begin / end callbacks); half_res 0: one callback per exchange
+    overlap = half_res == 1
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H, band_overlap_exchange=int(overlap))
     bands = _run_bands(inputs, 2, True, halos, half_res)
     mism = _compare(full, bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
     assert not bad, bad
-    assert bands[0]["calls"][:5] == [0, 1, 2, 3, 4]
+    B, E = 0x100, 0x200
+    expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if overlap else [0, 1, 2, 3, 4]
+    assert bands[0]["calls"][:len(expected)] == expected
 
 
 @pytest.mark.gpu
@@ -237,6 +241,29 @@ def test_gpu_three_bands_default_halos():
     mism = _compare(full, bands, 3)
     assert max(v for (f, i, k), v in mism.items() if k == "color") < 0.05, mism
     assert max(mism.values()) < 0.6, mism
+    # splitting the producers into edge and interior dispatches (overlapped exchange, the default above) changes nothing
+    plain = _run_bands(inputs, 3, True, dict(band_overlap_exchange=0))
+    for i in range(3):
+        for f in range(N_FRAMES):
+            for k in ("post", "color", "swap"):
+                assert np.array_equal(bands[i]["frames"][f][k], plain[i]["frames"][f][k]), "overlapped vs plain exchange: band %d frame %d %s" % (i, f, k)
+
+
+@pytest.mark.gpu
+def test_gpu_overlapped_exchange_with_interior_rows_equals_plain_exchange():
+    # halos much smaller than the bands: every producer of an exchanged image is recorded as top edge, bottom edge, exchange start,
+    # interior; the frames must equal those of the one-callback-per-exchange recording in every bit (fast kernels, 3 frames)
+    inputs = _make_inputs()
+    small = dict(band_gi_halo=8, band_gi_history_halo=8, band_post_halo=16, band_taa_history_halo=8)
+    over = _run_bands(inputs, 2, False, dict(small, band_overlap_exchange=1))
+    plain = _run_bands(inputs, 2, False, dict(small, band_overlap_exchange=0))
+    B, E = 0x100, 0x200
+    assert over[0]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] and plain[0]["calls"][:5] == [0, 1, 2, 3, 4]
+    for i in range(2):
+        b0, b1 = tiling.band_rows(H, 2, i)
+        for f in range(N_FRAMES):
+            for k in ("post", "color", "swap"):
+                assert np.array_equal(over[i]["frames"][f][k][b0:b1], plain[i]["frames"][f][k][b0:b1]), "band %d frame %d %s" % (i, f, k)
 
 
 @pytest.mark.gpu

@@ -16,6 +16,8 @@ w, h = 7680, 1080 * n
 band = tiling.band_rows(h, n, index)
 be = RenderBackend(w, h, device=0)
 fp = FramePipeline(be, w, h, shadow_map_res=2048, band_row_begin=band[0], band_row_end=band[1])
+if "--split" in sys.argv:  # record the producers edge-rows-first as the overlapped exchange does (callbacks that move nothing)
+    fp.set_exchange_callback(lambda exchange_id, stream: None)
 scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, band)
 inputs.upload(fp)
 be.waitForGPUIdle()
