@@ -16,6 +16,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace plr {
 
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
     const float probe = ((halfBitsToFloat(yt.x & 0xffffu) + halfBitsToFloat(yt.x >> 16)) + (halfBitsToFloat(yt.y & 0xffffu) + halfBitsToFloat(yt.y >> 16))) +
                         (halfBitsToFloat(ct & 0xffffu) + halfBitsToFloat(ct >> 16));
     if (probe != probe || !(den > 0.f)) { yt = make_uint2(0u, 0u); ct = 0u; den = -1.f; }
-    packed[idx] = make_uint4(yt.x, yt.y, ct, f2u(den));
+    packed[idx] = make_uint4(yt.x, yt.y, ct, f2u(0.25f * den)); // a quarter of the denominator: the weight's numerator (negative: skip the texel)
 }
 
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED>
@@ -123,6 +124,17 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
 
     // dist = |c0 + lin * (k0 + sv * k1 + su * k2)|
     const float k0 = nF - nU - nR, k1 = 2.f * nU, k2 = 2.f * nR;
+    const float c0x4 = 4.f * c0;
+    // Can a sample of this pixel leave the screen? Its world offset is ox * T + oy * B with |ox| + |oy| <= sqrt(2) and |T| = |B| = radiusWorld,
+    // so |offset| <= dm; the clip coordinates move by at most (row norm) * dm, and |x'| <= w', |y'| <= w' is what "on screen" means.
+    bool safe;
+    {
+        const float dm = radiusWorld * 1.4143f * 1.01f;
+        const float sx = sqrtf(vp[0] * vp[0] + vp[4] * vp[4] + vp[8] * vp[8]), sy = sqrtf(vp[1] * vp[1] + vp[5] * vp[5] + vp[9] * vp[9]);
+        const float sw = sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
+        const float wMin = (P0.z - sw * dm) * 0.999f;
+        safe = wMin > 0.f && fabsf(P0.x) + sx * dm <= wMin && fabsf(P0.y) + sy * dm <= wMin;
+    }
     vec4 result_Y_SH(0.f);
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
@@ -139,82 +151,95 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // quarter-rate v_rcp_f32) x 4 cycles x 31.6 waves per SIMD = 96% of the measured duration; replacing every gather by the pixel's
     // own texel does not change the time. A wave-uniform "whole group on screen" shortcut was tried and gave nothing on the bench
     // scene (waves near discs that leave the screen pay for both paths, and the extra registers cost two waves of occupancy).
-    for (int i0 = 0; i0 < 32; i0 += 4) {
-        float su[4], sv[4];
-        uint32_t ti[4], di[4];
-        bool off[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float d = samples[i0 + k] * lengthModifier;
-            const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
-            const vec3 clip = P0 + ox * PT + oy * PB;
-            const float invW = rcpf(clip.z) * 0.5f;
-            // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
-            float cu = clip.x * invW, cv = clip.y * invW;
-            // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
-            cu = fabsf(cu) > 0.5f ? cu0 - ox : cu;
-            cv = fabsf(cv) > 0.5f ? cv0 - oy : cv;
-            su[k] = cu; sv[k] = cv;
-            off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
-            lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
-            // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
-            const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
-            ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
-            di[k] = SAME_GRID ? ti[k]
-                              : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
-        }
-        if (PACKED) {
-            uint4 t4[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) t4[k] = packed[ti[k]];
-#pragma unroll
+    // (Measured: SQ_INSTS_VALU 1897 -> 1700 per wave on the bench frame, duration unchanged at ~106 us: with the instruction diet the kernel
+    // sits on the gather path instead - 32 wave-wide 16-byte gathers per pixel at ~60 cycles each per CU.)
+    // Two copies of the sample loop. A wave whose pixels' discs provably stay on screen (see `safe` above) runs the copy without the
+    // mirroring, the off-screen test and the shrinking lengthModifier - a fifth of the per-sample instructions; those conditions could
+    // not have fired, so a pixel's result is the same whichever copy its wave ran.
+    auto sampleLoop = [&](auto safeTag) {
+        constexpr bool SAFE = decltype(safeTag)::value;
+        for (int i0 = 0; i0 < 32; i0 += 4) {
+            float su[4], sv[4];
+            uint32_t ti[4], di[4];
+            bool off[4];
+    #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float den = u2f(t4[k].w); // <= 0: texel had a NaN component (skip)
+                const float d = SAFE ? samples[i0 + k] : samples[i0 + k] * lengthModifier;
+                const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
+                const vec3 clip = P0 + ox * PT + oy * PB;
+                const float invW = rcpf(clip.z) * 0.5f;
+                // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
+                float cu = clip.x * invW, cv = clip.y * invW;
+                off[k] = false;
+                if (!SAFE) {
+                    // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
+                    cu = fabsf(cu) > 0.5f ? cu0 - ox : cu;
+                    cv = fabsf(cv) > 0.5f ? cv0 - oy : cv;
+                    off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
+                    lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
+                }
+                su[k] = cu; sv[k] = cv;
+                // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
+                const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
+                ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
+                di[k] = SAME_GRID ? ti[k]
+                                  : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
+            }
+            if (PACKED) {
+                uint4 t4[4];
+    #pragma unroll
+                for (int k = 0; k < 4; k++) t4[k] = packed[ti[k]];
+    #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float qden = u2f(t4[k].w); // den / 4; <= 0: texel had a NaN component (skip)
+                    const float q = k0c + sv[k] * k1 + su[k] * k2;
+                    const float num = fabsf(c0x4 * qden + nf * q); // |c0 * den + nf * q|
+                    // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
+                    float weight = __builtin_amdgcn_fmed3f(qden * rcpf(__builtin_fmaxf(num, 0.0004f * qden)), 0.f, 1.f);
+                    weight *= weight;
+                    weight = ((SAFE || !off[k]) && qden > 0.f) ? weight : 0.f;
+                    const vec4 sY(halfBitsToFloat(t4[k].x & 0xffffu), halfBitsToFloat(t4[k].x >> 16), halfBitsToFloat(t4[k].y & 0xffffu), halfBitsToFloat(t4[k].y >> 16));
+                    result_Y_SH = result_Y_SH + weight * sY;
+                    resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
+                    resCg += weight * halfBitsToFloat(t4[k].z >> 16);
+                    weightTotal += weight;
+                }
+            } else {
+            float dep[4];
+            uint2 yt[4];
+            uint32_t ct[4];
+    #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                dep[k] = Texel<DEPTH_FMT>::load(depthTexture.ptr, di[k]).x;
+                yt[k] = yshTexels[ti[k]];
+                ct[k] = cocgTexels[ti[k]];
+            }
+    #pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // depthLinear = nf / den with den = far + (1 - depth) * (near - far) > 0; the distance to the tangent plane is
+                // |c0 + depthLinear * q| = |c0 * den + nf * q| / den, so weight = clamp(0.25 * den / max(|c0 * den + nf * q|, 1e-4 * den))^2: one reciprocal
+                const float den = farP + (1.f - dep[k]) * nmf;
                 const float q = k0c + sv[k] * k1 + su[k] * k2;
                 const float num = fabsf(c0 * den + nf * q);
-                // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
-                float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(__builtin_fmaxf(num, 0.0001f * den)), 0.f, 1.f);
+                float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
                 weight *= weight;
-                weight = (!off[k] && den > 0.f) ? weight : 0.f;
-                const vec4 sY(halfBitsToFloat(t4[k].x & 0xffffu), halfBitsToFloat(t4[k].x >> 16), halfBitsToFloat(t4[k].y & 0xffffu), halfBitsToFloat(t4[k].y >> 16));
+                vec4 sY(halfBitsToFloat(yt[k].x & 0xffffu), halfBitsToFloat(yt[k].x >> 16), halfBitsToFloat(yt[k].y & 0xffffu), halfBitsToFloat(yt[k].y >> 16));
+                float co = halfBitsToFloat(ct[k] & 0xffffu), cg = halfBitsToFloat(ct[k] >> 16);
+                // NaN guard (:118): finite half inputs cannot overflow this sum, so it is NaN exactly when a component is NaN
+                const float nanProbe = ((sY.x + sY.y) + (sY.z + sY.w)) + (co + cg);
+                const bool use = !off[k] && weight > 0.f && nanProbe == nanProbe;
+                weight = use ? weight : 0.f;
+                if (nanProbe != nanProbe) { sY = vec4(0.f); co = 0.f; cg = 0.f; } // 0 * NaN would poison the sums
                 result_Y_SH = result_Y_SH + weight * sY;
-                resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
-                resCg += weight * halfBitsToFloat(t4[k].z >> 16);
+                resCo += weight * co;
+                resCg += weight * cg;
                 weightTotal += weight;
             }
-        } else {
-        float dep[4];
-        uint2 yt[4];
-        uint32_t ct[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            dep[k] = Texel<DEPTH_FMT>::load(depthTexture.ptr, di[k]).x;
-            yt[k] = yshTexels[ti[k]];
-            ct[k] = cocgTexels[ti[k]];
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // depthLinear = nf / den with den = far + (1 - depth) * (near - far) > 0; the distance to the tangent plane is
-            // |c0 + depthLinear * q| = |c0 * den + nf * q| / den, so weight = clamp(0.25 * den / max(|c0 * den + nf * q|, 1e-4 * den))^2: one reciprocal
-            const float den = farP + (1.f - dep[k]) * nmf;
-            const float q = k0c + sv[k] * k1 + su[k] * k2;
-            const float num = fabsf(c0 * den + nf * q);
-            float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
-            weight *= weight;
-            vec4 sY(halfBitsToFloat(yt[k].x & 0xffffu), halfBitsToFloat(yt[k].x >> 16), halfBitsToFloat(yt[k].y & 0xffffu), halfBitsToFloat(yt[k].y >> 16));
-            float co = halfBitsToFloat(ct[k] & 0xffffu), cg = halfBitsToFloat(ct[k] >> 16);
-            // NaN guard (:118): finite half inputs cannot overflow this sum, so it is NaN exactly when a component is NaN
-            const float nanProbe = ((sY.x + sY.y) + (sY.z + sY.w)) + (co + cg);
-            const bool use = !off[k] && weight > 0.f && nanProbe == nanProbe;
-            weight = use ? weight : 0.f;
-            if (nanProbe != nanProbe) { sY = vec4(0.f); co = 0.f; cg = 0.f; } // 0 * NaN would poison the sums
-            result_Y_SH = result_Y_SH + weight * sY;
-            resCo += weight * co;
-            resCg += weight * cg;
-            weightTotal += weight;
-        }
-        }
-    }
+    };
+    if (__builtin_amdgcn_ballot_w64(!safe) == 0ull) sampleLoop(std::true_type{});
+    else sampleLoop(std::false_type{});
     const float inv = rcpf(gmax(weightTotal, 0.00001f));
     const size_t idx = (size_t)py * (size_t)outYSH.w + px;
     Texel<F_RGBA16F>::store(outYSH.ptr, idx, result_Y_SH * inv);
