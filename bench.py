@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20, help="extra frames with per-pass hipEvent timing for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
+    ap.add_argument("--exact", action="store_true", help="diagnostic: run the bit-exact kernel set (PLR_MATH_EXACT) instead of the default fast set")
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     args = ap.parse_args()
 
@@ -238,6 +239,8 @@ def main():
     else:
         be, fp, (scene, cams, inputs), w, h, band = make("single")
     replicas = world > 1 and band is None
+    if args.exact:
+        be.setMathMode(False)
 
     frame_no = [0]
 
@@ -313,7 +316,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d, %d SDF instances x %d^3, "
                                    "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
-                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res,
+                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "kernel_set": "exact" if args.exact else "fast",
                        "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point "
                                        "%d times per frame + one 512 B histogram all-reduce" % (w, h, world, h // world, 4)) if (world > 1 and not replicas) else
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},

@@ -19,13 +19,14 @@ EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, 
 # kernels_fast/*.hip: restructured kernels for PLR_MATH_FAST. FMA contraction on, divide/sqrt may use the v_rcp/v_rsq based
 # sequences; still no -ffast-math (NaN guards and comparisons keep IEEE semantics).
 FAST_FLAGS_REPLACE = {"-ffp-contract=off": "-ffp-contract=fast-honor-pragmas", "-fhip-fp32-correctly-rounded-divide-sqrt": "-fno-hip-fp32-correctly-rounded-divide-sqrt"}
-# -fno-slp-vectorize: pairing scalar fp32 operations into v_pk_fma/mul/add_f32 costs register-pair shuffles (v_mov) and measured slower in
-# every VALU-bound kernel (4K frame 1.096 -> 1.051 ms: shade 218 -> 200 us, TAA 180 -> 163, spatial filter 113 -> 107)
-FAST_FLAGS_EXTRA = ["-DPLR_FAST_SET=1", "-fno-slp-vectorize"] + os.environ.get("PLR_FAST_FLAGS", "").split()  # PLR_FAST_SET: detmath.h min/max as single instructions; + experiment hook
+FAST_FLAGS_EXTRA = ["-DPLR_FAST_SET=1"] + os.environ.get("PLR_FAST_FLAGS", "").split()  # PLR_FAST_SET: detmath.h min/max as single instructions; + experiment hook
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+    # no SLP vectorisation: pairing scalar fp32 operations into v_pk_fma/mul/add_f32 costs register-pair shuffles (v_mov) and measured
+    # slower in every VALU-bound kernel (4K frame 1.096 -> 1.051 ms: shade 218 -> 200 us, TAA 180 -> 163, spatial filter 113 -> 107)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
 ]
 

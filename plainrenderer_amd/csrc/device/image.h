@@ -33,6 +33,12 @@ PLR_DI float halfBitsToFloat(uint32_t h) {
     return (float)c.f; // v_cvt_f32_f16, exact
 }
 PLR_DI uint32_t floatToHalfBits(float v) {
+#ifndef PLR_FAST_SET
+    // The value must exist as a rounded fp32 number before it is converted: without this barrier the compiler may select v_fma_mixlo_f16
+    // for "product, then conversion" - one rounding straight to half instead of two - even with -ffp-contract=off, and a texel in ten
+    // thousand then differs from the scalar evaluation by a half-float ulp (found in froxelLightScattering, tools/dbg_volumetrics.py).
+    asm volatile("" : "+v"(v));
+#endif
     union { uint16_t u; _Float16 f; } c;
     c.f = (_Float16)v; // v_cvt_f16_f32, round-to-nearest-even in the default mode
     return c.u;
