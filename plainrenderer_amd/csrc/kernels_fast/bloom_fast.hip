@@ -113,20 +113,28 @@ __global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, I
 // set-up, ~400 VALU instructions per output; this one ~175).
 struct ParityWeights { float tent[2][5]; float box[2][3]; };
 
+// QY quad rows per thread (2x2 outputs each): consecutive quad rows share four of their five source rows (two of three previous-mip rows),
+// so the decode and the horizontal filter of a source row are done once for both. Every output accumulates its rows in the same order
+// whatever QY is: the result does not depend on it.
+template <int QY>
 __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
                                                                int yBase) {
-    // thread -> 2x2 output quad; a wave covers 128 x 2 outputs, a block 128 x 8
+    // thread -> QY vertically adjacent 2x2 output quads; a wave covers 128 x 2 QY outputs
     const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6)) * QY;
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
     const int sw = source.w, sh = source.h;
     const uint32_t* src = (const uint32_t*)source.ptr;
     const bool interiorX = k >= 2 && k + 2 < sw;
-    // horizontally filtered rows: hT[row][parity] for source rows m-2 .. m+2
-    vec3 acc[2][2] = {{vec3(0.f), vec3(0.f)}, {vec3(0.f), vec3(0.f)}}; // [y parity][x parity]
+    vec3 acc[QY][2][2]; // [quad row][y parity][x parity]
 #pragma unroll
-    for (int r = 0; r < 5; r++) {
+    for (int q = 0; q < QY; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[q][i >> 1][i & 1] = vec3(0.f);
+    // horizontally filtered source rows m-2 .. m+2+(QY-1); row r is row r-q of quad row q
+#pragma unroll
+    for (int r = 0; r < 4 + QY; r++) {
         const uint32_t* row = src + (size_t)clampi(m - 2 + r, sh) * (size_t)sw;
         uint32_t t[5];
         if (interiorX) { uint4 v; __builtin_memcpy(&v, row + (k - 2), 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; t[4] = row[k + 2]; }
@@ -138,15 +146,20 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
             h0 = h0 + col * pw.tent[0][c];
             h1 = h1 + col * pw.tent[1][c];
         }
-        acc[0][0] = acc[0][0] + h0 * pw.tent[0][r]; acc[0][1] = acc[0][1] + h1 * pw.tent[0][r];
-        acc[1][0] = acc[1][0] + h0 * pw.tent[1][r]; acc[1][1] = acc[1][1] + h1 * pw.tent[1][r];
+#pragma unroll
+        for (int q = 0; q < QY; q++) {
+            const int j = r - q;
+            if (j < 0 || j > 4) continue;
+            acc[q][0][0] = acc[q][0][0] + h0 * pw.tent[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * pw.tent[0][j];
+            acc[q][1][0] = acc[q][1][0] + h0 * pw.tent[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * pw.tent[1][j];
+        }
     }
     if (!lowest) {
         const int pwid = previous.w, phei = previous.h;
         const uint32_t* prv = (const uint32_t*)previous.ptr;
         const bool interiorP = k >= 1 && k + 2 < pwid;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < 2 + QY; r++) {
             const uint32_t* row = prv + (size_t)clampi(m - 1 + r, phei) * (size_t)pwid;
             uint32_t t[3];
             if (interiorP) { uint4 v; __builtin_memcpy(&v, row + (k - 1), 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; }
@@ -158,19 +171,27 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
                 h0 = h0 + col * pw.box[0][c];
                 h1 = h1 + col * pw.box[1][c];
             }
-            acc[0][0] = acc[0][0] + h0 * pw.box[0][r]; acc[0][1] = acc[0][1] + h1 * pw.box[0][r];
-            acc[1][0] = acc[1][0] + h0 * pw.box[1][r]; acc[1][1] = acc[1][1] + h1 * pw.box[1][r];
+#pragma unroll
+            for (int q = 0; q < QY; q++) {
+                const int j = r - q;
+                if (j < 0 || j > 2) continue;
+                acc[q][0][0] = acc[q][0][0] + h0 * pw.box[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * pw.box[0][j];
+                acc[q][1][0] = acc[q][1][0] + h0 * pw.box[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * pw.box[1][j];
+            }
         }
     }
     uint32_t* out = (uint32_t*)target.ptr;
 #pragma unroll
-    for (int py = 0; py < 2; py++) {
-        if (Y + py >= coverH || Y + py < yBase) continue;
-        uint32_t* orow = out + (size_t)(Y + py) * (size_t)target.w + X;
-        const uint32_t p0 = packR11G11B10(acc[py][0]), p1 = packR11G11B10(acc[py][1]);
-        if (X + 1 < coverW) *(uint2*)orow = make_uint2(p0, p1); // X is even and the row pitch is even: 8-byte aligned
-        else orow[0] = p0;
-    }
+    for (int q = 0; q < QY; q++)
+#pragma unroll
+        for (int py = 0; py < 2; py++) {
+            const int y = Y + 2 * q + py;
+            if (y >= coverH || y < yBase) continue;
+            uint32_t* orow = out + (size_t)y * (size_t)target.w + X;
+            const uint32_t p0 = packR11G11B10(acc[q][py][0]), p1 = packR11G11B10(acc[q][py][1]);
+            if (X + 1 < coverW) *(uint2*)orow = make_uint2(p0, p1); // X is even and the row pitch is even: 8-byte aligned
+            else orow[0] = p0;
+        }
 }
 
 // the 1D footprint of one tap (sampler rule of image.h:linearCoord) accumulated into weights over texels base .. base + n - 1
@@ -222,8 +243,9 @@ static int launch(const PassCtx& c) {
         const bool regular = target.w == 2 * source.w && target.h == 2 * source.h && (lowest || (c.sampled[1].w == source.w && c.sampled[1].h == source.h)) &&
                              source.w >= 5 && (yBase & 1) == 0 && (target.w & 1) == 0 && makeParityWeights(blurRadius, &pw);
         if (regular) {
-            const dim3 qgrid(divUp((unsigned)divUp((unsigned)w, 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u));
-            bloomUpsampleQuadKernel<<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase);
+            constexpr int QY = 2; // 4: mip 0 35.0 vs 36.6 us, but the small mips lose more (fewer, longer waves)
+            const dim3 qgrid(divUp((unsigned)divUp((unsigned)w, 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * QY));
+            bloomUpsampleQuadKernel<QY><<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase);
             PLR_CHECK_LAUNCH(c);
             return 0;
         }
