@@ -262,27 +262,57 @@ static int launch(const PassCtx& c) {
 // When the source is exactly twice the target in both dimensions, every one of the 13 bilinear taps lands on a texel centre or
 // half way between two / four texels, so the filter is a fixed 4x4 stencil over source texels (2x-1 .. 2x+2) x (2y-1 .. 2y+2):
 //   the four centre texels weigh 0.125 (the +-0.5 taps) + 0.03125 (a quarter of the centre tap) = 0.15625, the other twelve 0.03125.
-// Four 16-byte row loads replace up to 36 texel fetches. (The exact kernel's sub-texel weights are quantised to 1/256 from a
+// Wide row loads replace up to 36 texel fetches. (The exact kernel's sub-texel weights are quantised to 1/256 from a
 // float coordinate; where that rounding lands one step off the ideal 0.5 the two kernels differ by 1/256 of a texel difference.)
+// One thread makes a 2x2 block of outputs from a 6x6 block of source texels (rows 4m-1 .. 4m+4, columns 4k-1 .. 4k+4): 9 texel decodes per
+// output instead of 16 - the pass is bound by VALU issue. Per source row and output column A = the two inner texels, B = the two outer
+// ones; a row is an inner row (centre += A, border += B) for one output row and an outer row (border += A + B) for the other.
 __global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (x >= coverW || y >= coverH) return;
+    const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int X = 2 * k, Y = 2 * m;
+    if (X >= coverW || Y >= coverH) return;
     const uint32_t* src = (const uint32_t*)source.ptr;
-    const int sx = 2 * x - 1;
-    const bool interior = sx >= 0 && sx + 3 < source.w;
-    vec3 centre(0.f), border(0.f);
+    const int sx = 4 * k - 1;
+    const bool interior = sx >= 0 && sx + 5 < source.w;
+    vec3 centre[2][2], border[2][2]; // [output row][output column]
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t* row = src + (size_t)clampi(2 * y - 1 + r, source.h) * (size_t)source.w;
-        uint32_t t[4];
-        if (interior) { uint4 v; __builtin_memcpy(&v, row + sx, 16); t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; }
-        else { for (int c = 0; c < 4; c++) t[c] = row[clampi(sx + c, source.w)]; }
-        const vec3 c0 = unpackR11G11B10(t[0]), c1 = unpackR11G11B10(t[1]), c2 = unpackR11G11B10(t[2]), c3 = unpackR11G11B10(t[3]);
-        if (r == 1 || r == 2) { centre = centre + (c1 + c2); border = border + (c0 + c3); }
-        else border = border + ((c0 + c1) + (c2 + c3));
+    for (int i = 0; i < 4; i++) { centre[i >> 1][i & 1] = vec3(0.f); border[i >> 1][i & 1] = vec3(0.f); }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const uint32_t* row = src + (size_t)clampi(4 * m - 1 + r, source.h) * (size_t)source.w;
+        uint32_t t[6];
+        if (interior) {
+            uint4 v; uint2 u;
+            __builtin_memcpy(&v, row + sx, 16);
+            __builtin_memcpy(&u, row + sx + 4, 8);
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; t[4] = u.x; t[5] = u.y;
+        } else { for (int c = 0; c < 6; c++) t[c] = row[clampi(sx + c, source.w)]; }
+        vec3 col[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) col[c] = unpackR11G11B10(t[c]);
+#pragma unroll
+        for (int px = 0; px < 2; px++) {
+            const vec3 A = col[2 * px + 1] + col[2 * px + 2], B = col[2 * px] + col[2 * px + 3];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int j = r - 2 * q; // row j of output row q's 4x4 stencil
+                if (j < 0 || j > 3) continue;
+                if (j == 1 || j == 2) { centre[q][px] = centre[q][px] + A; border[q][px] = border[q][px] + B; }
+                else border[q][px] = border[q][px] + (A + B);
+            }
+        }
     }
-    ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(centre * 0.15625f + border * 0.03125f);
+    uint32_t* out = (uint32_t*)target.ptr;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int y = Y + q;
+        if (y >= coverH || y < yBase) continue;
+        const uint32_t p0 = packR11G11B10(centre[q][0] * 0.15625f + border[q][0] * 0.03125f), p1 = packR11G11B10(centre[q][1] * 0.15625f + border[q][1] * 0.03125f);
+        uint32_t* orow = out + (size_t)y * (size_t)target.w + X;
+        if (X + 1 < coverW && (target.w & 1) == 0) *(uint2*)orow = make_uint2(p0, p1);
+        else { orow[0] = p0; if (X + 1 < coverW) orow[1] = p1; }
+    }
 }
 
 static int launchDown(const PassCtx& c) {
@@ -290,11 +320,12 @@ static int launchDown(const PassCtx& c) {
     if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
     const ImgView& target = c.storage[0];
     const ImgView& source = c.sampled[1];
-    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 4) return kUseGeneralKernel; // odd sizes: taps are not on texel centres
+    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) return kUseGeneralKernel; // odd sizes: taps are not on texel centres
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
     const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
     if (w <= 0 || h <= y0) return 0;
-    bloomDownsampleFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
+    if (y0 & 1) return kUseGeneralKernel; // 2x2 output blocks start on even rows
+    bloomDownsampleFastKernel<<<dim3(divUp(divUp((unsigned)w, 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
