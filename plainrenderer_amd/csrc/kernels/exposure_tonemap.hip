@@ -143,7 +143,16 @@ __global__ void histogramCombineKernel(const uint32_t* __restrict__ perTile, uin
     const uint32_t t0 = tile0 + blockIdx.x * kCombineTilesPerBlock;
     const uint32_t t1 = min(t0 + kCombineTilesPerBlock, tile0 + nTiles);
     uint32_t sum = 0u;
-    for (uint32_t t = t0; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
+    // eight loads in flight per step: one load per iteration made the kernel a chain of 32 memory round trips (13 us for 4 MB)
+    uint32_t t = t0;
+    for (; t + 8u <= t1; t += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) v[i] = perTile[(size_t)(t + i) * nBins + bin];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) sum += v[i];
+    }
+    for (; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
     if (sum) atomicAdd(&histogram[bin], sum);
 }
 static int launchHistogramCombine(const PassCtx& c) {
@@ -204,8 +213,13 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
     if (lane != 0) return;
     float mean = 0.f;
     uint32_t countedPixels = 0u;
+    // the float additions stay in bin order; a bin outside the percentile window has term 0 (mean + 0 = mean: the terms are non-negative, so
+    // mean is never -0) - without the per-bin branch the LDS reads of eight bins are in flight together instead of one after the other
+#pragma unroll 8
     for (int i = 0; i < nBins; i++) {
-        if (counted[i] != 0xffffffffu) { mean += term[i]; countedPixels += counted[i]; }
+        const uint32_t cnt = counted[i];
+        mean += term[i];
+        countedPixels += cnt != 0xffffffffu ? cnt : 0u;
     }
     mean /= (float)countedPixels;
     const float sceneEV100 = det_log2f(mean * 100.f / 12.5f);
