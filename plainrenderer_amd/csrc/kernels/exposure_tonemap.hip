@@ -186,6 +186,10 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
     __shared__ uint32_t counted[kMaxExposureBins];
     const int lane = threadIdx.x;
     const uint32_t pixelCount = (uint32_t)(g->screenResolution[0] * g->screenResolution[1]);
+    // inputs of the serial tail, fetched while the histogram scan runs (they do not depend on it)
+    const vec4 sunTransmission = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, vec2(0.f, -g->sunDirection[1] * 0.5f + 0.5f));
+    const float previousExposure = light->previousFrameExposure, exposureOffsetUser = g->exposureOffset, sunStrength = g->sunStrength;
+    const float evMaxChange = g->exposureAdaptionSpeedEvPerSec * g->deltaTime;
     uint32_t carry = 0u;
     for (int base = 0; base < nBins; base += 64) {
         const int i = base + lane;
@@ -224,20 +228,17 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
     mean /= (float)countedPixels;
     const float sceneEV100 = det_log2f(mean * 100.f / 12.5f);
     float exposureOffset = offsetFromSceneEV(sceneEV100);
-    exposureOffset += g->exposureOffset;
+    exposureOffset += exposureOffsetUser;
     float targetEV100 = sceneEV100 - exposureOffset;
     targetEV100 = gmax(targetEV100, 10.f);
-    const float previousEV100 = det_log2f(1.f / (gmax(light->previousFrameExposure, 0.000001f) * 1.2f));
+    const float previousEV100 = det_log2f(1.f / (gmax(previousExposure, 0.000001f) * 1.2f));
     const float evDelta = targetEV100 - previousEV100;
-    const float evMaxChange = g->exposureAdaptionSpeedEvPerSec * g->deltaTime;
     const float evChange = gsign(evDelta) * gmin(fabsf(evDelta), fabsf(evMaxChange));
     const float currentEV100 = previousEV100 + evChange;
     const float exposure = 1.f / (det_powf(2.f, currentEV100) * 1.2f);
-    light->sunStrengthExposed = g->sunStrength * exposure;
+    light->sunStrengthExposed = sunStrength * exposure;
     light->previousFrameExposure = exposure;
-    const vec2 lutUV(0.f, -g->sunDirection[1] * 0.5f + 0.5f);
-    const vec4 sc = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, lutUV);
-    light->sunColor[0] = sc.x; light->sunColor[1] = sc.y; light->sunColor[2] = sc.z;
+    light->sunColor[0] = sunTransmission.x; light->sunColor[1] = sunTransmission.y; light->sunColor[2] = sunTransmission.z;
 }
 
 static int launchPreExposeLights(const PassCtx& c) {
