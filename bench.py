@@ -5,11 +5,13 @@ One step = one frame of the hot path recorded by the C++ FramePipeline (referenc
 depth downscale, SDF frustum+tile culling, diffuse trace, spatial/temporal/spatial denoise, upscale, deferred shade, TAA,
 bloom x11, tonemap) on synthetic inputs that are resident in HBM before the timed region starts.
 
-  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-N > 1 (this round): replicas only, weak scaling - every rank renders its own 3840x2160 view of the scene (own camera), no
-data-path collective; ranks meet only at the timing barriers. Screen-tiling one 8K frame with RCCL halo exchange
-needs tile offsets in the per-pixel ray set-up and is the documented next step (DESIGN.md "multi-GPU").
+N > 1: ONE frame of N x the 4K pixel count (7680 x 1080*N; N = 4 is the 7680x4320 frame of BASELINE config 5), partitioned into N
+row bands, one rank per GPU, halo rows exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
+histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels). When WORLD_SIZE is not set, `--gpus N` spawns the N
+ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1); under torchrun WORLD_SIZE must equal --gpus. A band frame that
+cannot run fails the benchmark (non-zero exit) unless --allow-replicas is given.
 """
 import argparse
 import ctypes as C
@@ -171,14 +173,32 @@ def main():
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
     ap.add_argument("--exact", action="store_true", help="diagnostic: run the bit-exact kernel set (PLR_MATH_EXACT) instead of the default fast set")
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
+    ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched as `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and relay rank 0's JSON line
+        import subprocess
+        port = args.master_port or (20000 + os.getpid() % 20000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d; a scaling run must measure what it was asked for" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if torch.cuda.device_count() < (world if "LOCAL_RANK" in os.environ else 1):
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible on this node" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_bands:
@@ -216,8 +236,8 @@ def main():
 
     parallelism_note = None
     if world > 1 or args.force_bands:
-        # the band path needs RCCL point-to-point between neighbouring ranks; if it cannot run here (one frame is tried on every rank),
-        # every rank falls back to an independent 4K replica and the JSON line says so
+        # the band path needs RCCL point-to-point between neighbouring ranks; one frame is tried on every rank first. If it cannot run the
+        # benchmark fails; with --allow-replicas every rank falls back to an independent 4K replica and the JSON line says so
         ok = 1
         try:
             be, fp, (scene, cams, inputs), w, h, band = make("bands")
@@ -230,6 +250,10 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
+            if not args.allow_replicas:
+                # a scaling run that silently measured N independent frames would be measuring the wrong thing
+                raise SystemExit("bench.py rank %d: the band frame could not run (%s); pass --allow-replicas to measure independent replicas instead" % (
+                    rank, parallelism_note or "failed on another rank"))
             try:
                 fp.destroy(); be.shutdown()
             except Exception:  # noqa: BLE001

@@ -218,6 +218,19 @@ int plr_get_supported_shaders(const char** out_names, uint32_t capacity);
 /* detmath / codec probes on the device (same function ids as oracle/probes.cpp); pointers are host memory */
 int plr_debug_math_eval(int fn, const float* a, const float* b, float* out, int64_t n);
 int plr_debug_codec_eval(int fn, const void* in, void* out, int64_t n);
+/* decision signatures (parity tests of the PLR_MATH_FAST kernel set). While a buffer of `words` 32-bit words is set (0 frees it), the fast kernels
+ * of sdfDiffuseTrace, filterIndirectDiffuseSpatial, indirectLightUpscale and the deferred shade also write one word per output pixel
+ * (index y * outputWidth + x) recording the pixel's discrete decisions: ray hit / closest instance / shadow bit, parity of every disc
+ * sample's nearest texel, edge + closest-depth texel, shadow cascade + number of lit PCF taps. Bit layout: oracle/oracle.h,
+ * orc_set_decision_signature (the oracle emits the same words). A test compares the words to tell apart "same decisions, results must
+ * agree to the storage quantum" from "a float rounding flipped a decision". Costs nothing when no buffer is set. */
+int plr_debug_set_decision_signature(size_t words);
+int plr_debug_read_decision_signature(uint32_t* out_words, size_t words);
+/* sampler probe: evaluates one of the global samplers of resources/shaders/global.inc:35-42 on an image, with the device sampler code the pass
+ * kernels are built from. filter: 0 nearest, 1 linear, 2 textureGather (component 0); address: 0 clamp-to-edge, 1 repeat, 2 border white,
+ * 3 border black. coords: n x 2 (2D) or n x 3 (3D image) normalised coordinates, out: n x 4 floats; both host memory.
+ * Same arguments as the oracle's orc_sampler_eval. */
+int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filter, int address, const float* coords, float* out, int64_t n);
 
 #ifdef __cplusplus
 }

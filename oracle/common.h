@@ -21,6 +21,10 @@ static inline mat4 toMat4(const float* m) {
 static inline vec3 v3(const float* p) { return vec3(p[0], p[1], p[2]); }
 
 extern int g_threads;
+// decision signatures (orc_set_decision_signature, oracle.h): one word per output pixel of the next pass, or null
+extern uint32_t* g_sig;
+extern int64_t g_sigWords;
+static inline void writeSig(int64_t i, uint32_t word) { if (g_sig && i >= 0 && i < g_sigWords) g_sig[i] = word; }
 // rows [0,n) split into contiguous chunks, one std::thread per chunk
 void parallelFor(int n, const std::function<void(int, int)>& body);
 

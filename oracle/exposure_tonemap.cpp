@@ -6,6 +6,8 @@
 namespace orc {
 
 int g_threads = 1;
+uint32_t* g_sig = nullptr;
+int64_t g_sigWords = 0;
 
 void parallelFor(int n, const std::function<void(int, int)>& body) {
     const int t = std::max(1, std::min(g_threads, n));
@@ -59,6 +61,7 @@ static inline vec3 ditherRGB8(vec3 c, ivec2 uv, float g_time) {
 using namespace orc;
 
 extern "C" void orc_set_threads(int32_t n) { g_threads = n < 1 ? 1 : n; }
+extern "C" void orc_set_decision_signature(uint32_t* words, int64_t count) { orc::g_sig = words; orc::g_sigWords = words ? count : 0; }
 
 // histogramPerTile.comp:32-65, one iteration of the outer loops per 32x32 workgroup
 extern "C" void orc_histogram_per_tile(const orc_image* srcP, const orc_light_buffer* light, uint32_t* perTile,

@@ -408,3 +408,53 @@ extern "C" void orc_temporal_supersampling(const orc_image* currentP, const orc_
             }
     });
 }
+
+// ------------------------------------------------------------------------------------------------ known-answer probes (tests/test_kat.py)
+// fn 0: bicubic weights at iUV (in: 2 floats, pixel units) -> 16 floats: the 16-tap weights of the four taps along x, then along y
+//       (bicubicSampling.inc:28-45), then cubicSetup's (w0, wB = w1 + w2, w3, t = w2 / wB) along x, then along y (bicubicSampling.inc:72-90)
+// fn 1: clipAABB(target, bbMin, bbMax) (in: 9 floats) -> 3 floats (temporalReprojection.inc:8-30)
+// fn 2: tonemap then tonemapReverse (in: 3 floats) -> 6 floats (temporalReprojection.inc:34-40)
+extern "C" void orc_kat_taa(int fn, const float* in, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        if (fn == 0) {
+            const vec2 iUV(in[2 * i], in[2 * i + 1]);
+            const vec2 uvTrunc = floor(iUV - 0.5f) + 0.5f;
+            const vec2 d = iUV - uvTrunc;
+            const vec2 w[4] = {catmullRomWeight2D(abs(d) + 1.f), catmullRomWeight2D(abs(d)), catmullRomWeight2D(1.f - abs(d)), catmullRomWeight2D(2.f - abs(d))};
+            float* o = out + 16 * i;
+            for (int k = 0; k < 4; k++) { o[k] = w[k].x; o[4 + k] = w[k].y; }
+            const Cubic c = cubicSetup(iUV);
+            o[8] = c.w0.x; o[9] = c.wB.x; o[10] = c.w3.x; o[11] = c.t.x;
+            o[12] = c.w0.y; o[13] = c.wB.y; o[14] = c.w3.y; o[15] = c.t.y;
+        } else if (fn == 1) {
+            const float* p = in + 9 * i;
+            const vec3 r = clipAABB(vec3(p[0], p[1], p[2]), vec3(p[3], p[4], p[5]), vec3(p[6], p[7], p[8]));
+            out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+        } else if (fn == 2) {
+            const vec3 c(in[3 * i], in[3 * i + 1], in[3 * i + 2]);
+            const vec3 t = tonemap(c), r = tonemapReverse(t);
+            float* o = out + 6 * i;
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = r.x; o[4] = r.y; o[5] = r.z;
+        }
+    }
+}
+
+// history samplers of temporalFilter.comp:118-131 on one image: tech 0 bilinear, 1 bicubic 16 tap, 2 9 tap, 3 5 tap, 4 1 tap (its
+// neighbourhood = nbr9x3, the current frame's 3x3 colours, [x][y] order). iUV in pixel units (n x 2 floats) -> n x 3 floats
+extern "C" void orc_kat_history_sample(const orc_image* srcP, int32_t tech, const float* iUVs, const float* nbr9x3, float* out, int64_t n) {
+    const Image& src = img(srcP);
+    const vec2 texelSize = 1.f / vec2((float)src.w, (float)src.h);
+    N3 nb;
+    for (int x = 0; x < 3; x++)
+        for (int y = 0; y < 3; y++) nb.v[x][y] = nbr9x3 ? vec3(nbr9x3[(x * 3 + y) * 3], nbr9x3[(x * 3 + y) * 3 + 1], nbr9x3[(x * 3 + y) * 3 + 2]) : vec3(0.f);
+    for (int64_t i = 0; i < n; i++) {
+        const vec2 iUV(iUVs[2 * i], iUVs[2 * i + 1]);
+        vec3 r;
+        if (tech == 0) r = tex(src, iUV * texelSize);
+        else if (tech == 1) r = bicubicSample16Tap(src, iUV, texelSize);
+        else if (tech == 2) r = bicubicSample9Tap(src, iUV, texelSize);
+        else if (tech == 3) r = bicubicSample5Tap(src, iUV, texelSize);
+        else r = bicubicSample1Tap(src, iUV, texelSize, nb);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}

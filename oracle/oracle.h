@@ -199,6 +199,20 @@ uint16_t orc_pack_half_glm(float v);                                            
 /* row range variants used by the multi-threaded cpu_baseline (rows [y0,y1) of the dispatch domain) */
 void orc_set_threads(int32_t n);
 
+/* ---- decision signatures (parity tests of the PLR_MATH_FAST kernels) ----
+ * While a buffer is set, the passes below also write one 32-bit word per OUTPUT pixel (index y * outputWidth + x) that records the
+ * pixel's DISCRETE decisions - the places where a last-bit difference in float arithmetic selects a different branch, texel or
+ * ray result. The HIP kernels emit the same words (plr_debug_set_decision_signature, include/plr.h). A parity test then demands the
+ * per-channel tolerance from every pixel whose words agree and counts the pixels whose words differ against a hard cap.
+ *   sdfDiffuseTrace:  bit 0 ray hit, bit 1 simpleShadow(hit point) == 1, bit 2 hit colour zeroed (outside the influence radius or
+ *                     self intersection), bits 3-10 which of the 8 neighbours the 3x3 resolve accepted (loop order x outer, y inner,
+ *                     centre skipped), bits 11-31 (index of the instance that owns the closest hit) + 1, 0 without a hit
+ *   filterIndirectDiffuseSpatial: bit i (sample i of 32) = (texelX + texelY + offScreen) & 1 of the nearest texel the sample reads
+ *                     (a flip to a neighbouring texel or across the off-screen test toggles the bit)
+ *   indirectLightUpscale: bit 0 isEdge, bit 1 / bit 2 = x / y offset of the closest-depth texel
+ *   deferred shade:   bits 0-1 shadow cascade, bits 2-5 number of lit PCF taps (0..12), bit 6 geometry pixel, bit 7 sky pixel */
+void orc_set_decision_signature(uint32_t* words, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,3 +48,34 @@ extern "C" void orc_codec_eval(int fn, const void* in, void* out, int64_t n) {
         }
     }
 }
+
+// ---- sampler probe: the 8 global samplers of resources/shaders/global.inc:35-42 (nearest / linear x clamp / repeat / border white / border black)
+// on any image. coords = n x 2 (2D image) or n x 3 (3D image) normalised coordinates, out = n x 4. filter: 0 nearest, 1 linear, 2 textureGather
+// component 0 (2D only; order (i0,j1), (i1,j1), (i1,j0), (i0,j0), the offsets table of indirectLightUpscale.comp:42-47).
+// The HIP side is plr_debug_sampler_eval with the same arguments.
+extern "C" void orc_sampler_eval(const orc_image* image, int32_t filter, int32_t address, const float* coords, float* out, int64_t n) {
+    const Image& im = img(image);
+    const bool is3d = im.d > 1;
+    for (int64_t i = 0; i < n; i++) {
+        vec4 r;
+        if (is3d) r = texture3D(im, filter == 1 ? LINEAR : NEAREST, address, vec3(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]));
+        else if (filter == 2) r = textureGatherR(im, address, vec2(coords[2 * i], coords[2 * i + 1]));
+        else r = texture2D(im, filter == 1 ? LINEAR : NEAREST, address, vec2(coords[2 * i], coords[2 * i + 1]));
+        out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+    }
+}
+
+// fn 0: importanceSampleCosine(xi, N) (sampling.inc:25-45), in: 5 floats -> 3 floats
+// fn 1: directionToSH_L1(v) (SphericalHarmonics.inc), in: 3 floats -> 4 floats
+extern "C" void orc_kat_sampling(int fn, const float* in, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        if (fn == 0) {
+            const float* p = in + 5 * i;
+            const vec3 L = importanceSampleCosine(vec2(p[0], p[1]), vec3(p[2], p[3], p[4]));
+            out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
+        } else if (fn == 1) {
+            const vec4 s = directionToSH_L1(vec3(in[3 * i], in[3 * i + 1], in[3 * i + 2]));
+            out[4 * i] = s.x; out[4 * i + 1] = s.y; out[4 * i + 2] = s.z; out[4 * i + 3] = s.w;
+        }
+    }
+}

@@ -140,3 +140,56 @@ def sdf_bake(positions, indices, bb_min, bb_max, res):
     if rc != 0:
         raise ValueError("orc_sdf_bake failed: %d" % rc)
     return out.reshape(res[2], res[1], res[0])
+
+
+class decision_signature:
+    """with decision_signature(words) as s: <one oracle pass>; s.words -> uint32 array (oracle.h: orc_set_decision_signature)"""
+
+    def __init__(self, words):
+        self.words = np.full(int(words), 0xFFFFFFFF, np.uint32)
+
+    def __enter__(self):
+        lib().orc_set_decision_signature(_p(self.words), C.c_int64(self.words.size))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_decision_signature(None, C.c_int64(0))
+        return False
+
+
+# ---- known-answer probes (tests/test_kat.py)
+def kat_taa(fn, data, in_per, out_per):
+    a = np.ascontiguousarray(data, np.float32).reshape(-1, in_per)
+    out = np.zeros((a.shape[0], out_per), np.float32)
+    lib().orc_kat_taa(C.c_int(fn), _p(a), _p(out), C.c_int64(a.shape[0]))
+    return out
+
+
+def kat_history_sample(image, tech, iuvs, nbr=None):
+    a = np.ascontiguousarray(iuvs, np.float32).reshape(-1, 2)
+    out = np.zeros((a.shape[0], 3), np.float32)
+    nb = None if nbr is None else np.ascontiguousarray(nbr, np.float32).reshape(27)
+    lib().orc_kat_history_sample(image.ref(), C.c_int32(tech), _p(a), None if nb is None else _p(nb), _p(out), C.c_int64(a.shape[0]))
+    return out
+
+
+def kat_trace_ray(instance_bytes96, volume, rays):
+    a = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    out = np.zeros((a.shape[0], 9), np.float32)
+    inst = C.create_string_buffer(bytes(instance_bytes96), 96)
+    lib().orc_kat_trace_ray(inst, volume.ref(), _p(a), _p(out), C.c_int64(a.shape[0]))
+    return out
+
+
+def sampler_eval(image, filter, address, coords):
+    a = np.ascontiguousarray(coords, np.float32)
+    out = np.zeros((a.shape[0], 4), np.float32)
+    lib().orc_sampler_eval(image.ref(), C.c_int32(filter), C.c_int32(address), _p(a), _p(out), C.c_int64(a.shape[0]))
+    return out
+
+
+def kat_sampling(fn, data, in_per, out_per):
+    a = np.ascontiguousarray(data, np.float32).reshape(-1, in_per)
+    out = np.zeros((a.shape[0], out_per), np.float32)
+    lib().orc_kat_sampling(C.c_int(fn), _p(a), _p(out), C.c_int64(a.shape[0]))
+    return out

@@ -238,6 +238,7 @@ extern "C" void orc_sdf_diffuse_trace(const orc_image* outYSHP, const orc_image*
             for (int gx = 0; gx < groupsX; gx++) {
                 RayInfo sharedRays[8][8];
                 vec3 Ls[8][8];
+                uint32_t raySig[8][8];
                 // tileUV = gl_WorkGroupID.xy / (cullingTileSize / 8)
                 const ivec2 tileUV(gx / (int)(cullingTileSize / 8), gy / (int)(cullingTileSize / 8));
                 const uint32_t tileIndex = tileIndexFromTileUV(tileUV, g);
@@ -267,13 +268,18 @@ extern "C" void orc_sdf_diffuse_trace(const orc_image* outYSHP, const orc_image*
                         tr.closestHitDistance = 10000.f;
                         tr.hitCount = 0;
                         const uint32_t objectCount = cullingTile[0];
+                        uint32_t closestInstance = 0; // decision signature: owner of the closest hit, + 1
                         for (int i = 0; i < (int)objectCount; i++) {
                             const orc_sdf_instance& instance = instances[cullingTile[1 + i]];
+                            const float before = tr.closestHitDistance;
                             traceRayTroughSDFInstance(instance, rayOrigin, img(&bindless[instance.sdfTextureIndex]), L, tr);
+                            if (tr.closestHitDistance != before) closestInstance = cullingTile[1 + i] + 1u;
                         }
                         vec3 hitColor;
+                        raySig[lx][ly] = (tr.hit ? 1u : 0u) | (closestInstance << 11);
                         if (tr.hit) {
                             const float shadow = simpleShadow(tr.hitPos, lightMatrix, shadowMap, BORDER_WHITE);
+                            raySig[lx][ly] |= (shadow != 0.f ? 2u : 0u) | ((!(tr.closestHitDistance < influenceRange || !strictCutoff) || tr.closestHitDistance < 0.0001f) ? 4u : 0u);
                             const vec3 sunLight = shadow * light->sunStrengthExposed * v3(light->sunColor);
                             hitColor = tr.albedo * sunLight;
                             bool hitInRange = tr.closestHitDistance < influenceRange;
@@ -291,9 +297,12 @@ extern "C" void orc_sdf_diffuse_trace(const orc_image* outYSHP, const orc_image*
                         const vec3 initialColor = sharedRays[lx][ly].color;
                         float weightTotal = 1.f;
                         vec3 color = initialColor;
+                        uint32_t takeMask = 0u;
+                        int neighbour = -1;
                         for (int x = -1; x <= 1; x++)
                             for (int y = -1; y <= 1; y++) {
                                 if (x == 0 && y == 0) continue;
+                                neighbour++;
                                 const int rx = lx + x, ry = ly + y;
                                 const bool isValidIndex = (rx > 0 && ry > 0) && (rx < 8 && ry < 8); // sic: > 0, not >= 0 (:88)
                                 if (!isValidIndex) continue;
@@ -302,6 +311,7 @@ extern "C" void orc_sdf_diffuse_trace(const orc_image* outYSHP, const orc_image*
                                 const bool normalsMatch = NoN > 0.9f;
                                 const bool depthMatch = std::fabs(sharedRays[lx][ly].depth - neighbourRay.depth) < 0.5f;
                                 if (normalsMatch && depthMatch) {
+                                    takeMask |= 1u << neighbour;
                                     const float weightX = x == 0 ? 1.f : 0.5f, weightY = y == 0 ? 1.f : 0.5f;
                                     const float weight = weightX * weightY;
                                     color += weight * neighbourRay.color;
@@ -317,6 +327,7 @@ extern "C" void orc_sdf_diffuse_trace(const orc_image* outYSHP, const orc_image*
                         const ivec2 iUV(gx * 8 + lx, gy * 8 + ly);
                         imageStore(imageOut_Y_SH, iUV, result_Y_SH);
                         imageStore(imageOut_CoCg, iUV, vec4(result_CoCg.x, result_CoCg.y, 0.f, 0.f));
+                        if (iUV.x < imageOut_Y_SH.w && iUV.y < imageOut_Y_SH.h) writeSig((int64_t)iUV.y * imageOut_Y_SH.w + iUV.x, raySig[lx][ly] | (takeMask << 3));
                     }
             }
     });
@@ -360,6 +371,7 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                 float radiusWorld = 1.5f;
                 if (filterIndex == 1) radiusWorld = 1.f;
                 float lengthModifier = 1.f;
+                uint32_t sampleParity = 0u; // decision signature
                 for (int i = 0; i < sampleCount; i++) {
                     const float d = std::sqrt(rand01(rngState)) * lengthModifier;
                     const float angle = 2.f * pi * rand01(rngState);
@@ -379,9 +391,17 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                     const float maxDistance = 0.25f;
                     float weight = gclamp(maxDistance / gmax(distanceToTangentPlane, 0.0001f), 0.f, 1.f);
                     weight *= weight;
-                    if (sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f) {
+                    const bool offScreen = sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f;
+                    if (offScreen) {
                         weight = 0.f;
                         lengthModifier *= 0.98f;
+                    }
+                    {
+                        // nearest texel of the sample in the Y_SH input (clamp to edge), as texture2D(NEAREST, CLAMP) addresses it
+                        int tx = (int)std::floor(saneCoord(sampleUV.x * (float)texture_Y_SH.w)), ty = (int)std::floor(saneCoord(sampleUV.y * (float)texture_Y_SH.h));
+                        tx = tx < 0 ? 0 : (tx >= texture_Y_SH.w ? texture_Y_SH.w - 1 : tx);
+                        ty = ty < 0 ? 0 : (ty >= texture_Y_SH.h ? texture_Y_SH.h - 1 : ty);
+                        sampleParity |= (uint32_t)((tx + ty + (offScreen ? 1 : 0)) & 1) << i;
                     }
                     if (weight > 0.f) {
                         const vec4 sample_Y_SH = texture2D(texture_Y_SH, NEAREST, CLAMP, sampleUV);
@@ -400,6 +420,7 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                 result_CoCg /= weightTotal;
                 imageStore(imageOut_Y_SH, iUV, result_Y_SH);
                 imageStore(imageOut_CoCg, iUV, vec4(result_CoCg.x, result_CoCg.y, 0, 0));
+                writeSig((int64_t)py * imageOut_Y_SH.w + px, sampleParity);
             }
     });
 }
@@ -495,6 +516,7 @@ extern "C" void orc_indirect_light_upscale(const orc_image* dstYSHP, const orc_i
                 }
                 imageStore(fullResDst_Y_SH, iUV, result_Y_SH);
                 imageStore(fullResDst_CoCg, iUV, vec4(cc.x, cc.y, 0.f, 0.f));
+                writeSig((int64_t)py * fullResDst_Y_SH.w + px, (isEdge ? 1u : 0u) | (closestDepthTexel.x != 0.f ? 2u : 0u) | (closestDepthTexel.y != 0.f ? 4u : 0u));
             }
     });
 }
@@ -548,4 +570,19 @@ extern "C" void orc_sdf_debug_visualisation(const orc_image* outP, const orc_lig
                 imageStore(imageOut, uv, vec4(color, 1.f));
             }
     });
+}
+
+// ------------------------------------------------------------------------------------------------ known-answer probes (tests/test_kat.py)
+// One ray through one SDF instance (SDF.inc:101-184): rays = n x {origin3, direction3} in world space.
+// out = n x {hit, closestHitDistance, hitPos3, N3, hitCount} (9 floats).
+extern "C" void orc_kat_trace_ray(const orc_sdf_instance* instance, const orc_image* volume, const float* rays, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        const float* r = rays + 6 * i;
+        TraceResult tr;
+        tr.hit = false; tr.closestHitDistance = 10000.f; tr.hitPos = vec3(0.f); tr.N = vec3(0.f); tr.hitCount = 0; tr.albedo = vec3(0.f);
+        traceRayTroughSDFInstance(*instance, vec3(r[0], r[1], r[2]), img(volume), vec3(r[3], r[4], r[5]), tr);
+        float* o = out + 9 * i;
+        o[0] = tr.hit ? 1.f : 0.f; o[1] = tr.closestHitDistance; o[2] = tr.hitPos.x; o[3] = tr.hitPos.y; o[4] = tr.hitPos.z;
+        o[5] = tr.N.x; o[6] = tr.N.y; o[7] = tr.N.z; o[8] = (float)tr.hitCount;
+    }
 }

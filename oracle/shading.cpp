@@ -255,6 +255,7 @@ extern "C" void orc_deferred_shading(const orc_image* colorP, const orc_image* d
                 const vec3 Vcam = -calculateViewDirectionFromPixel(pixelNDC, camFwd, v3(g->cameraUp), v3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
                 if (depth == 0.f) { // sky stand-in
                     imageStore(color, iUV, vec4(sampleSkyLut(Vcam, skyLut), 1.f));
+                    writeSig((int64_t)py * color.w + px, 128u);
                     continue;
                 }
                 const float depthLinear = linearizeDepth(depth, g->nearPlane, g->farPlane);
@@ -291,6 +292,8 @@ extern "C" void orc_deferred_shading(const orc_image* colorP, const orc_image* d
                 int cascadeIndex = 0;
                 for (int cascade = 0; cascade < (int)sunShadowCascadeCount - 1; cascade++) cascadeIndex += (pixelDepth >= shadowInfo->splits[cascade]) ? 1 : 0;
                 const float sunShadow = calcShadow(c, passPos, c.shadowMaps[cascadeIndex], toMat4(shadowInfo->lightMatrices[cascadeIndex]), cascadeIndex, fragCoord);
+                // decision signature: cascade, number of lit PCF taps (sunShadow = count / 12 exactly representable counts), geometry pixel
+                writeSig((int64_t)py * color.w + px, (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u);
                 const vec3 directLighting = gmax(dot(N, L), 0.f) * sunShadow * v3(light->sunColor);
                 const vec3 brdfLut = texture2D(*c.brdfLut, LINEAR, CLAMP, vec2(r, NoV)).xyz();
 

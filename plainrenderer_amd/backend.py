@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_host_callback_execution", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -497,6 +497,24 @@ class RenderBackend:
             b = np.ascontiguousarray(b, np.float32)
             bp = b.ctypes.data_as(C.c_void_p)
         self._check(self.lib.plr_debug_math_eval(C.c_int(fn), a.ctypes.data_as(C.c_void_p), bp, out.ctypes.data_as(C.c_void_p), C.c_int64(a.size)))
+        return out
+
+    def setDecisionSignature(self, words):
+        """decision-signature buffer for the next single-pass frame (include/plr.h); 0 frees it"""
+        self._check(self.lib.plr_debug_set_decision_signature(C.c_size_t(int(words))))
+
+    def readDecisionSignature(self, words):
+        out = np.empty(int(words), np.uint32)
+        self._check(self.lib.plr_debug_read_decision_signature(out.ctypes.data_as(C.c_void_p), C.c_size_t(int(words))))
+        return out
+
+    def debugSamplerEval(self, image, filter, address, coords, mip=0):
+        """-> (n, 4) float32: the device sampler (0 nearest / 1 linear / 2 gather; 0 clamp / 1 repeat / 2 border white / 3 border black) at coords (n, 2|3)"""
+        coords = np.ascontiguousarray(coords, np.float32)
+        n = coords.shape[0]
+        out = np.empty((n, 4), np.float32)
+        self._check(self.lib.plr_debug_sampler_eval(_ImageHandle(image.type, image.index), C.c_uint32(mip), C.c_int(filter), C.c_int(address),
+                                                    coords.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int64(n)))
         return out
 
     def debugCodecEval(self, fn, data, n, out_dtype, out_count):

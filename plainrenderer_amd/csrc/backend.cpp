@@ -223,6 +223,8 @@ struct Backend {
     int activeSideStreams = 1;           // side streams the scheduler uses (PLR_SIDE_STREAMS, 1..kSideStreams)
     hipStream_t curStream = nullptr;     // stream of the execution being launched (timing events go there)
     uint32_t lastOverlapped = 0;         // executions of the last frame that were placed on a side stream
+    uint32_t* debugSig = nullptr;        // decision-signature buffer (plr_debug_set_decision_signature)
+    size_t debugSigWords = 0;
 };
 
 // one backend per host thread: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
@@ -303,6 +305,8 @@ static ImgView makeView(const ImageRes& im, uint32_t mip) {
 
 static bool sameDesc(const plr_image_desc& a, const plr_image_desc& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
+int launchSamplerProbe(const ImgView& view, int filter, int address, const float* coords, float* out, int64_t n); // kernels/probes.hip
+
 } // namespace plr
 
 using namespace plr;
@@ -341,6 +345,7 @@ int plr_shutdown(void) {
     for (auto& b : g->ubufs) if (b.dev) hipFree(b.dev);
     for (auto& b : g->sbufs) if (b.dev) hipFree(b.dev);
     for (auto& p : g->passes) if (p->scratch) hipFree(p->scratch);
+    if (g->debugSig) hipFree(g->debugSig);
     for (auto ev : g->passEvents) hipEventDestroy(ev);
     for (auto ev : g->orderEvents) hipEventDestroy(ev);
     for (auto st : g->sideStreams) if (st) hipStreamDestroy(st);
@@ -745,6 +750,8 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     x.ctx.err = &g_err;
     x.ctx.scratchSlot = &p.scratch;
     x.ctx.scratchSize = &p.scratchSize;
+    x.ctx.debugSig = g->debugSig;
+    x.ctx.debugSigWords = g->debugSigWords;
     g->currentPassName = p.name.c_str();
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
@@ -983,6 +990,33 @@ int plr_get_memory_stats(uint64_t* out_allocated_size, uint64_t* out_used_size) 
     if (out_allocated_size) *out_allocated_size = g->allocated;
     if (out_used_size) *out_used_size = g->allocated;
     return PLR_OK;
+}
+
+int plr_debug_set_decision_signature(size_t words) {
+    NEED_INIT();
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    if (g->debugSig) { hipFree(g->debugSig); g->debugSig = nullptr; g->debugSigWords = 0; }
+    if (words == 0) return PLR_OK;
+    HIP_TRY(hipMalloc((void**)&g->debugSig, words * 4));
+    HIP_TRY(hipMemset(g->debugSig, 0xff, words * 4));
+    g->debugSigWords = words;
+    return PLR_OK;
+}
+int plr_debug_read_decision_signature(uint32_t* out_words, size_t words) {
+    NEED_INIT();
+    if (!g->debugSig || !out_words || words > g->debugSigWords) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_read_decision_signature: no buffer of that size is set");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    HIP_TRY(hipMemcpy(out_words, g->debugSig, words * 4, hipMemcpyDeviceToHost));
+    return PLR_OK;
+}
+
+int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filter, int address, const float* coords, float* out, int64_t n) {
+    NEED_INIT();
+    ImageRes* im = resolveImage(image);
+    if (!im || mip_level >= im->mips.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sampler_eval: invalid image handle or mip level");
+    if (!coords || !out || n <= 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sampler_eval: null argument");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return launchSamplerProbe(makeView(*im, mip_level), filter, address, coords, out, n);
 }
 
 int plr_set_math_mode(int mode) {

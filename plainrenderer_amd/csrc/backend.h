@@ -42,6 +42,10 @@ struct PassCtx {
     std::string* err = nullptr;
     void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)
     size_t* scratchSize = nullptr;
+    // decision signatures (plr_debug_set_decision_signature, plr.h): when set, the kernels that support it write one word per output pixel
+    uint32_t* debugSig = nullptr;
+    size_t debugSigWords = 0;
+    uint32_t* sigFor(size_t pixels) const { return debugSig && debugSigWords >= pixels ? debugSig : nullptr; }
 
     bool hasSampled(int b) const { return (sampledMask >> b) & 1u; }
     bool hasStorage(int b) const { return (storageMask >> b) & 1u; }

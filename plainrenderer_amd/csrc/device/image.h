@@ -194,6 +194,49 @@ template <int FMT, int ADDR> PLR_DI vec4 sampleLinear2D(const ImgView& im, vec2 
     return t00 * w00 + t10 * w10 + t01 * w01 + t11 * w11;
 }
 
+
+template <int FMT, int ADDR> PLR_DI vec4 addressedTexel3D(const ImgView& im, int x, int y, int z) {
+    if (ADDR == CLAMP) { x = clampi(x, im.w); y = clampi(y, im.h); z = clampi(z, im.d); }
+    else if (ADDR == REPEAT) { x = repeati(x, im.w); y = repeati(y, im.h); z = repeati(z, im.d); }
+    else if (x < 0 || y < 0 || z < 0 || x >= im.w || y >= im.h || z >= im.d) return ADDR == BORDER_WHITE ? vec4(1.f, 1.f, 1.f, 1.f) : vec4(0.f, 0.f, 0.f, 1.f);
+    return Texel<FMT>::load(im.ptr, ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x);
+}
+
+template <int FMT, int ADDR> PLR_DI vec4 sampleNearest3D(const ImgView& im, vec3 uvw) {
+    return addressedTexel3D<FMT, ADDR>(im, (int)floorf(saneCoord(uvw.x * (float)im.w)), (int)floorf(saneCoord(uvw.y * (float)im.h)), (int)floorf(saneCoord(uvw.z * (float)im.d)));
+}
+
+// trilinear sample (8-bit sub-texel weights); ADDR = CLAMP or REPEAT; same term order as oracle/image.h texture3D
+template <int FMT, int ADDR> PLR_DI vec4 sampleLinear3D(const ImgView& im, vec3 uvw) {
+    int i0, j0, k0; float a, b, c;
+    linearCoord(uvw.x * (float)im.w, &i0, &a);
+    linearCoord(uvw.y * (float)im.h, &j0, &b);
+    linearCoord(uvw.z * (float)im.d, &k0, &c);
+    auto wrap = [](int i, int n) { return ADDR == REPEAT ? repeati(i, n) : clampi(i, n); };
+    const int x0 = wrap(i0, im.w), x1 = wrap(i0 + 1, im.w), y0 = wrap(j0, im.h), y1 = wrap(j0 + 1, im.h), z0 = wrap(k0, im.d), z1 = wrap(k0 + 1, im.d);
+    auto T = [&](int x, int y, int z) { return Texel<FMT>::load(im.ptr, ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x); };
+    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
+    vec4 r(0.f); // the sum starts from +0 like the oracle's loop (keeps the sign of an all-zero result)
+    r = r + T(x0, y0, z0) * ((a0 * b0) * c0);
+    r = r + T(x1, y0, z0) * ((a * b0) * c0);
+    r = r + T(x0, y1, z0) * ((a0 * b) * c0);
+    r = r + T(x1, y1, z0) * ((a * b) * c0);
+    r = r + T(x0, y0, z1) * ((a0 * b0) * c);
+    r = r + T(x1, y0, z1) * ((a * b0) * c);
+    r = r + T(x0, y1, z1) * ((a0 * b) * c);
+    r = r + T(x1, y1, z1) * ((a * b) * c);
+    return r;
+}
+
+// textureGather, component 0: (i0,j1), (i1,j1), (i1,j0), (i0,j0) of the bilinear footprint (the offsets table of indirectLightUpscale.comp:42-47)
+template <int FMT, int ADDR> PLR_DI vec4 gatherR2D(const ImgView& im, vec2 uv) {
+    int i0, j0; float a, b;
+    linearCoord(uv.x * (float)im.w, &i0, &a);
+    linearCoord(uv.y * (float)im.h, &j0, &b);
+    return vec4(addressedTexel2D<FMT, ADDR>(im, i0, j0 + 1).x, addressedTexel2D<FMT, ADDR>(im, i0 + 1, j0 + 1).x, addressedTexel2D<FMT, ADDR>(im, i0 + 1, j0).x,
+                addressedTexel2D<FMT, ADDR>(im, i0, j0).x);
+}
+
 template <int FMT> PLR_DI vec4 texelFetch2D(const ImgView& im, int x, int y) {
     if (x < 0 || y < 0 || x >= im.w || y >= im.h) return vec4(0.f);
     return Texel<FMT>::load(im.ptr, (size_t)y * (size_t)im.w + (size_t)x);

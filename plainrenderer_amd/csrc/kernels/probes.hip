@@ -46,6 +46,71 @@ __global__ void codecEvalKernel(int fn, const void* __restrict__ in, void* __res
     }
 }
 
+// ---- sampler probe (plr_debug_sampler_eval): the sampler definitions of device/image.h that the pass kernels are built from, on any image
+template <int FMT, int ADDR>
+__device__ vec4 sampleProbe(const ImgView& im, int filter, const float* c) {
+    if (im.d > 1) {
+        const vec3 uvw(c[0], c[1], c[2]);
+        if (filter == 1) {
+            if (ADDR == CLAMP || ADDR == REPEAT) return sampleLinear3D<FMT, ADDR>(im, uvw);
+            return vec4(0.f); // no 3D image of the hot path is sampled with a border
+        }
+        return sampleNearest3D<FMT, ADDR>(im, uvw);
+    }
+    const vec2 uv(c[0], c[1]);
+    if (filter == 2) return gatherR2D<FMT, ADDR>(im, uv);
+    if (filter == 1) return sampleLinear2D<FMT, ADDR>(im, uv);
+    return sampleNearest2D<FMT, ADDR>(im, uv);
+}
+template <int FMT>
+__device__ vec4 sampleProbeAddr(const ImgView& im, int filter, int addr, const float* c) {
+    switch (addr) {
+        case CLAMP: return sampleProbe<FMT, CLAMP>(im, filter, c);
+        case REPEAT: return sampleProbe<FMT, REPEAT>(im, filter, c);
+        case BORDER_WHITE: return sampleProbe<FMT, BORDER_WHITE>(im, filter, c);
+        default: return sampleProbe<FMT, BORDER_BLACK>(im, filter, c);
+    }
+}
+__global__ void samplerEvalKernel(ImgView im, int filter, int addr, const float* __restrict__ coords, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* c = coords + (im.d > 1 ? 3 : 2) * i;
+    vec4 r(0.f);
+    switch (im.fmt) {
+        case F_RGBA16F: r = sampleProbeAddr<F_RGBA16F>(im, filter, addr, c); break;
+        case F_RG16F: r = sampleProbeAddr<F_RG16F>(im, filter, addr, c); break;
+        case F_R16F: r = sampleProbeAddr<F_R16F>(im, filter, addr, c); break;
+        case F_R11G11B10: r = sampleProbeAddr<F_R11G11B10>(im, filter, addr, c); break;
+        case F_D32: r = sampleProbeAddr<F_D32>(im, filter, addr, c); break;
+        case F_D16: r = sampleProbeAddr<F_D16>(im, filter, addr, c); break;
+        case F_RG16SN: r = sampleProbeAddr<F_RG16SN>(im, filter, addr, c); break;
+        case F_RGBA8: r = sampleProbeAddr<F_RGBA8>(im, filter, addr, c); break;
+        case F_RG8: r = sampleProbeAddr<F_RG8>(im, filter, addr, c); break;
+        case F_RG32F: r = sampleProbeAddr<F_RG32F>(im, filter, addr, c); break;
+        default: break;
+    }
+    out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w;
+}
+
+// called by plr_debug_sampler_eval (backend.cpp resolves the image handle); coords / out are host memory
+int launchSamplerProbe(const ImgView& view, int filter, int address, const float* coords, float* out, int64_t n) {
+    switch (view.fmt) {
+        case F_RGBA16F: case F_RG16F: case F_R16F: case F_R11G11B10: case F_D32: case F_D16: case F_RG16SN: case F_RGBA8: case F_RG8: case F_RG32F: break;
+        default: return setLastError(PLR_ERR_UNSUPPORTED, "plr_debug_sampler_eval: image format has no sampler probe");
+    }
+    if (filter < 0 || filter > 2 || address < 0 || address > 3) return setLastError(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sampler_eval: filter must be 0..2, address 0..3");
+    const int dims = view.d > 1 ? 3 : 2;
+    if (dims == 3 && (filter == 2 || (filter == 1 && address >= 2))) return setLastError(PLR_ERR_UNSUPPORTED, "plr_debug_sampler_eval: 3D images: nearest, or linear with clamp / repeat");
+    float *dc = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&dc, n * dims * 4) != hipSuccess || hipMalloc((void**)&dout, n * 16) != hipSuccess) return setLastError(PLR_ERR_HIP, "plr_debug_sampler_eval: hipMalloc failed");
+    hipMemcpy(dc, coords, n * dims * 4, hipMemcpyHostToDevice);
+    samplerEvalKernel<<<(unsigned)((n + 255) / 256), 256>>>(view, filter, address, dc, dout, n);
+    const hipError_t e = hipGetLastError();
+    hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost);
+    hipFree(dc); hipFree(dout);
+    return e == hipSuccess ? PLR_OK : setLastError(PLR_ERR_HIP, std::string("plr_debug_sampler_eval: ") + hipGetErrorString(e));
+}
+
 } // namespace plr
 
 using namespace plr;

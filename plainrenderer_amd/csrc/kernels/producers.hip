@@ -374,28 +374,6 @@ PLR_DI vec3 froxelWorldPosition(int x, int y, int z, const ImgView& vol, float j
     return posWorld;
 }
 
-// trilinear sample with the sampler contract of image.h (8-bit sub-texel weights); ADDR = CLAMP or REPEAT; same term order as oracle/image.h texture3D
-template <int FMT, int ADDR> PLR_DI vec4 sampleLinear3D(const ImgView& im, vec3 uvw) {
-    int i0, j0, k0; float a, b, c;
-    linearCoord(uvw.x * (float)im.w, &i0, &a);
-    linearCoord(uvw.y * (float)im.h, &j0, &b);
-    linearCoord(uvw.z * (float)im.d, &k0, &c);
-    auto wrap = [](int i, int n) { return ADDR == REPEAT ? repeati(i, n) : clampi(i, n); };
-    const int x0 = wrap(i0, im.w), x1 = wrap(i0 + 1, im.w), y0 = wrap(j0, im.h), y1 = wrap(j0 + 1, im.h), z0 = wrap(k0, im.d), z1 = wrap(k0 + 1, im.d);
-    auto T = [&](int x, int y, int z) { return Texel<FMT>::load(im.ptr, ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x); };
-    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
-    vec4 r(0.f); // the sum starts from +0 like the oracle's loop (keeps the sign of an all-zero result)
-    r = r + T(x0, y0, z0) * ((a0 * b0) * c0);
-    r = r + T(x1, y0, z0) * ((a * b0) * c0);
-    r = r + T(x0, y1, z0) * ((a0 * b) * c0);
-    r = r + T(x1, y1, z0) * ((a * b) * c0);
-    r = r + T(x0, y0, z1) * ((a0 * b0) * c);
-    r = r + T(x1, y0, z1) * ((a * b0) * c);
-    r = r + T(x0, y1, z1) * ((a0 * b) * c);
-    r = r + T(x1, y1, z1) * ((a * b) * c);
-    return r;
-}
-
 PLR_DI size_t idx3(const ImgView& im, int x, int y, int z) { return ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x; }
 
 // thread -> froxel for the 4x4x4-workgroup passes: blocks of 64 lanes walk x fastest

@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
     packed[idx] = make_uint4(yt.x, yt.y, ct, f2u(0.25f * den)); // a quarter of the denominator: the weight's numerator (negative: skip the texel)
 }
 
-template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED>
+// SIG: also write the decision signature (bit i = parity of sample i's nearest texel, toggled when the sample is off screen; oracle/oracle.h)
+template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
-                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk) {
+                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk, uint32_t* __restrict__ sig) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
     float lengthModifier = 1.f;
+    uint32_t sampleParity = 0u;
     const uint32_t ywi = (uint32_t)inYSH.w;
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
     const float halfW = 0.5f * yW, halfH = 0.5f * yH, cu0 = u0 - 0.5f, cv0 = v0 - 0.5f;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
                 const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
+                if (SIG) sampleParity |= ((tx + ty + (off[k] ? 1u : 0u)) & 1u) << (i0 + k);
                 di[k] = SAME_GRID ? ti[k]
                                   : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
             }
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const size_t idx = (size_t)py * (size_t)outYSH.w + px;
     Texel<F_RGBA16F>::store(outYSH.ptr, idx, result_Y_SH * inv);
     Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(resCo * inv, resCg * inv, 0.f, 0.f));
+    if (SIG) sig[idx] = sampleParity;
 }
 
 static int launchSpatialFilterFast(const PassCtx& c) {
@@ -291,14 +295,20 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         PLR_CHECK_LAUNCH(c);
         c.splitTiming("texel packing");
     }
-#define PLR_SPATIAL_LAUNCH(FMT, SG, PK) spatialFilterFastKernel<FMT, TXv, SG, PK><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], \
-                                                                                              c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk)
+    uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
+#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk, sig
+#define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
+    do {                                                                                                            \
+        if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \
+        else spatialFilterFastKernel<FMT, TXv, SG, PK, false><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);        \
+    } while (0)
     if (c.sampled[4].fmt == F_R16F) {
         if (sameGrid) PLR_SPATIAL_LAUNCH(F_R16F, true, true); else PLR_SPATIAL_LAUNCH(F_R16F, false, false);
     } else if (c.sampled[4].fmt == F_D32) {
         if (sameGrid) PLR_SPATIAL_LAUNCH(F_D32, true, true); else PLR_SPATIAL_LAUNCH(F_D32, false, false);
     } else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
 #undef PLR_SPATIAL_LAUNCH
+#undef PLR_SPATIAL_ARGS
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -166,14 +166,16 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
 struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
 struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
 
-template <bool STRICT_CUTOFF>
+// SIG: also write the decision signature of every pixel (plr_debug_set_decision_signature; bit layout in oracle/oracle.h)
+template <bool STRICT_CUTOFF, bool SIG>
 __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
                                                                  uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
-                                                                 uint32_t tileCapacity, uint32_t instanceCapacity) {
+                                                                 uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig) {
     __shared__ RayInfo sharedRays[4][64];
+    uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
     const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
@@ -220,7 +222,9 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
             Volume vol;
             vol.p = (const uint16_t*)view.ptr; vol.w = view.w; vol.h = view.h; vol.d = view.d;
             vol.fw = (float)view.w; vol.fh = (float)view.h; vol.fd = (float)view.d;
+            const float before = tr.closestHitDistance;
             traceInstance(inst, rayOrigin, vol, L, tr);
+            if (SIG && tr.closestHitDistance != before) raySig = (instIndex + 1u) << 11;
         }
         vec3 hitColor;
         if (tr.hit) {
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
             hitColor = albedo * ((shadow * light->sunStrengthExposed) * ld3(light->sunColor));
             const bool hitInRange = (tr.closestHitDistance < *influenceRangeP) || !STRICT_CUTOFF;
             if (!hitInRange || tr.closestHitDistance < 0.0001f) hitColor = vec3(0.f);
+            if (SIG) raySig |= 1u | (shadow != 0.f ? 2u : 0u) | ((!hitInRange || tr.closestHitDistance < 0.0001f) ? 4u : 0u);
         } else {
             hitColor = fastm::sampleSkyLut(L, skyLut);
         }
@@ -247,11 +252,13 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
     float weightTotal = 1.f;
     vec3 color(mine.cr, mine.cg, mine.cb);
     const vec3 myN(mine.nx, mine.ny, mine.nz);
+    uint32_t takeMask = 0u;
 #pragma unroll
     for (int x = -1; x <= 1; x++)
 #pragma unroll
         for (int y = -1; y <= 1; y++) {
             if (x == 0 && y == 0) continue;
+            const int neighbour = (x + 1) * 3 + (y + 1) - ((x > 0 || (x == 0 && y > 0)) ? 1 : 0); // 0..7 in loop order
             // selects instead of two divergent branches per neighbour (an excluded neighbour must not be added even with weight 0: it may be NaN)
             const int rx = lx + x, ry = ly + y;
             const bool inGroup = (rx > 0 && ry > 0) && (rx < 8 && ry < 8); // sic: > 0 (:88)
@@ -262,6 +269,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
             const vec3 sum = color + weight * vec3(nb.cr, nb.cg, nb.cb);
             color = vec3(take ? sum.x : color.x, take ? sum.y : color.y, take ? sum.z : color.z);
             weightTotal = take ? weightTotal + weight : weightTotal;
+            if (SIG) takeMask |= take ? (1u << neighbour) : 0u;
         }
     color = color * rcpf(weightTotal);
     const vec3 YCoCg = linearToYCoCg(color);
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
         const size_t idx = (size_t)py * (size_t)outYSH.w + px;
         Texel<F_RGBA16F>::store(outYSH.ptr, idx, ysh);
         Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(YCoCg.y, YCoCg.z, 0.f, 0.f));
+        if (SIG) sig[idx] = raySig | (takeMask << 3);
     }
 }
 
@@ -303,9 +312,13 @@ static int launch(const PassCtx& c) {
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
-                       tileCapacity, instanceCapacity
-    if (strict) sdfDiffuseTraceFastKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-    else sdfDiffuseTraceFastKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+                       tileCapacity, instanceCapacity, sig
+    uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
+    if (sig) {
+        if (strict) sdfDiffuseTraceFastKernel<true, true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+        else sdfDiffuseTraceFastKernel<false, true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    } else if (strict) sdfDiffuseTraceFastKernel<true, false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    else sdfDiffuseTraceFastKernel<false, false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
 #undef PLR_TRACE_ARGS
     PLR_CHECK_LAUNCH(c);
     return 0;

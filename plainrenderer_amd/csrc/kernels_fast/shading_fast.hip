@@ -118,6 +118,7 @@ struct ShadeParams {
     uint32_t bindlessCount;
     uint32_t cascadeCount;
     int coverW, coverH, yBase;
+    uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
 };
 
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
     const vec3 ray = camFwd + (-g->cameraTanFovHalf * ndy) * ld3(g->cameraUp) + (g->cameraTanFovHalf * g->cameraAspectRatio * ndx) * ld3(g->cameraRight);
     if (depth == 0.f) {
         ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(nrm(ray), P.skyLut));
+        if (P.sig) P.sig[idx] = 128u;
         return;
     }
     const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         shadowMap.h = cascadeIndex == i ? P.shadowMaps[i].h : shadowMap.h;
     }
     const float sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[cascadeIndex], lss, noiseTexel.x);
+    if (P.sig) P.sig[idx] = (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u; // cascade, lit PCF taps, geometry (oracle/oracle.h)
     const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
     const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
 
@@ -401,6 +404,7 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
     if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
+    P.sig = c.sigFor((size_t)P.color.w * (size_t)P.color.h);
     k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
     PLR_CHECK_LAUNCH(c);
     return 0;

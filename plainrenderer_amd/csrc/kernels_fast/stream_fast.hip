@@ -186,7 +186,7 @@ PLR_DI vec2 bilinearRG16F(const ImgView& im, const Bilinear& q) {
 }
 
 PLR_DI void upscalePixel(const ImgView& dstYSH, const ImgView& dstCoCg, const ImgView& srcYSH, const ImgView& srcCoCg, const ImgView& fullResDepthT,
-                         const ImgView& halfResDepthT, const GlobalUbo* __restrict__ g, int px, int py) {
+                         const ImgView& halfResDepthT, const GlobalUbo* __restrict__ g, int px, int py, uint32_t* __restrict__ sig) {
     // no fused multiply-adds in this pass (-ffp-contract=fast-honor-pragmas): see linearDepthRounded; "linear depth - full-res depth" would
     // also be fused for some of the four candidates and not for others, which breaks exact ties (equal half-res depths) arbitrarily
 #pragma clang fp contract(off)
@@ -240,14 +240,15 @@ PLR_DI void upscalePixel(const ImgView& dstYSH, const ImgView& dstCoCg, const Im
     const size_t idx = (size_t)py * (size_t)dstYSH.w + px;
     Texel<F_RGBA16F>::store(dstYSH.ptr, idx, ysh);
     Texel<F_RG16F>::store(dstCoCg.ptr, idx, vec4(cc.x, cc.y, 0.f, 0.f));
+    if (sig) sig[idx] = (isEdge ? 1u : 0u) | (cx != 0.f ? 2u : 0u) | (cy != 0.f ? 4u : 0u); // decision signature (oracle/oracle.h)
 }
 
 __global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, uint32_t* __restrict__ sig) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
-    upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, px, py);
+    upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, px, py, sig);
 }
 
 // ---- 2x2 outputs per thread when the full-resolution image is exactly twice the half-resolution one.
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView ds
 // all lie in the 3x3 half-res neighbourhood (k-1 .. k+1) x (m-1 .. m+1). A thread loads that neighbourhood once (9 depths, 9 Y_SH,
 // 9 CoCg texels in 9 wide loads) and linearises each half-res depth once instead of four times.
 __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, uint32_t* __restrict__ sig) {
 #pragma clang fp contract(off)  // see upscalePixel
     const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView ds
         // uv is defined by the UBO's screen resolution (:19): when that is not the target size the quad reasoning does not hold
         for (int py = 0; py < 2; py++)
             for (int px = 0; px < 2; px++)
-                if (X + px < coverW && Y + py < coverH) upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, X + px, Y + py);
+                if (X + px < coverW && Y + py < coverH) upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, X + px, Y + py, sig);
         return;
     }
     const int hw = srcYSH.w, hh = srcYSH.h;
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView ds
             }
             outY[px] = make_uint2(floatToHalfBits(ysh.x) | (floatToHalfBits(ysh.y) << 16), floatToHalfBits(ysh.z) | (floatToHalfBits(ysh.w) << 16));
             outC[px] = floatToHalfBits(co.x) | (floatToHalfBits(co.y) << 16);
+            if (sig && X + px < coverW) sig[(size_t)(Y + py) * (size_t)dstYSH.w + (size_t)(X + px)] = (isEdge ? 1u : 0u) | (cx ? 2u : 0u) | (cy ? 4u : 0u); // decision signature
         }
         const size_t o = (size_t)(Y + py) * (size_t)dstYSH.w + X;
         if (X + 1 < coverW) {
@@ -384,12 +386,13 @@ static int launchUpscale(const PassCtx& c) {
     const bool regular = out.w == 2 * c.sampled[2].w && out.h == 2 * c.sampled[2].h && c.sampled[3].w == c.sampled[2].w && c.sampled[3].h == c.sampled[2].h &&
                          c.sampled[5].w == c.sampled[2].w && c.sampled[5].h == c.sampled[2].h && c.sampled[4].w == out.w && c.sampled[4].h == out.h &&
                          c.storage[1].w == out.w && c.storage[1].h == out.h && (y0 & 1) == 0 && c.sampled[2].w >= 4;
+    uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     if (regular)
         indirectLightUpscaleQuadKernel<<<dim3(divUp(divUp((unsigned)w, 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(
-            c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, w, h, y0);
+            c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, w, h, y0, sig);
     else
         indirectLightUpscaleFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
-                                                                                                                  c.sampled[4], c.sampled[5], c.global, w, h, y0);
+                                                                                                                  c.sampled[4], c.sampled[5], c.global, w, h, y0, sig);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (first: torch brings its own HIP runtime; if libplr.so loads the system one before it, torch then finds "no HIP GPUs")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -35,6 +35,10 @@ class OracleFrame:
         # oracle-side global texture array with the backend's indices
         vol_idx = inputs.volume_indices
         self._noise_idx = None
+        # capture=True: frame() keeps the inputs and outputs of every pass of the LAST frame in self.cap (per-pass parity tests feed the
+        # HIP passes exactly what the oracle pass consumed)
+        self.capture = False
+        self.cap = {}
 
     def _bindless(self, g):
         noise_idx = [int(x) for x in g.noiseTextureIndices]
@@ -71,17 +75,29 @@ class OracleFrame:
             self.ind_y[0], self.ind_c[0] = passes.orc_sdf_trace(depth, inp.gb["normal"], w, h, self.tw, self.th, inp.sky, 200, 100, self.light,
                                                                 inp.instance_bytes_patched, self.tiles, influence, inp.shadow_info, inp.shadow_maps[cascade],
                                                                 inp.shadow_res, global_bytes, arr, n, strict=bool(s.sdf_strict_influence_radius_cutoff), cascade=cascade)
+            if self.capture:
+                self.cap["trace"] = dict(light=self.light, tiles=self.tiles.copy(), cascade=cascade, out=(self.ind_y[0].copy(), self.ind_c[0].copy()))
             if self.half:
                 dsrc, dfmt, dw, dh = self.half_depth, F.R16_sFloat, self.tw, self.th
             else:
                 dsrc, dfmt, dw, dh = depth, F.Depth32, w, h
             self.ind_y[1], self.ind_c[1] = passes.orc_gi_spatial(self.ind_y[0], self.ind_c[0], self.tw, self.th, dsrc, dfmt, dw, dh, inp.gb["normal"], w, h, global_bytes, 0)
+            if self.capture:
+                self.cap["spatial0"] = dict(inp=(self.ind_y[0].copy(), self.ind_c[0].copy()), depth=(dsrc, dfmt, dw, dh), out=(self.ind_y[1].copy(), self.ind_c[1].copy()))
+                self.cap["temporal"] = dict(inp=(self.ind_y[1].copy(), self.ind_c[1].copy(), self.hist_y[0].copy(), self.hist_c[0].copy()))
             t = passes.orc_gi_temporal(self.ind_y[1], self.ind_c[1], self.hist_y[0], self.hist_c[0], self.tw, self.th, inp.gb["motion"], inp.gb["motion"], w, h, global_bytes)
             self.ind_y[0], self.ind_c[0], self.hist_y[1], self.hist_c[1] = t
+            if self.capture:
+                self.cap["temporal"]["out"] = tuple(a.copy() for a in t)
+                self.cap["spatial1"] = dict(inp=(self.hist_y[1].copy(), self.hist_c[1].copy()), depth=(dsrc, dfmt, dw, dh))
             self.hist_y[0], self.hist_c[0] = passes.orc_gi_spatial(self.hist_y[1], self.hist_c[1], self.tw, self.th, dsrc, dfmt, dw, dh, inp.gb["normal"], w, h,
                                                                    global_bytes, 1)
+            if self.capture:
+                self.cap["spatial1"]["out"] = (self.hist_y[0].copy(), self.hist_c[0].copy())
             if self.half:
                 self.full_y, self.full_c = passes.orc_gi_upscale(self.hist_y[0], self.hist_c[0], self.tw, self.th, depth, self.half_depth, w, h, global_bytes)
+                if self.capture:
+                    self.cap["upscale"] = dict(inp=(self.hist_y[0].copy(), self.hist_c[0].copy()), half_depth=self.half_depth, out=(self.full_y.copy(), self.full_c.copy()))
         if s.run_shading:
             arr, n = self._bindless(g)
             ysh, cocg = (self.full_y, self.full_c) if self.half else (self.hist_y[0], self.hist_c[0])
@@ -89,6 +105,8 @@ class OracleFrame:
                                                           inp.froxel, inp.froxel_dims, inp.vol_settings, inp.sky, global_bytes, arr, n, int(s.diffuse_brdf),
                                                           int(s.direct_multiscatter), bool(s.use_geometry_aa), int(s.indirect_lighting_tech),
                                                           int(s.sun_shadow_cascade_count))
+            if self.capture:
+                self.cap["shade"] = dict(light=self.light, gi=(ysh.copy(), cocg.copy()), out=self.color[cur].copy())
         src = self.color[cur]
         if s.run_taa and s.taa_enabled and getattr(s, "taa_use_separate_supersampling", 0):
             # TAA::computeTemporalSuperSampling (TAA.cpp:85-137): luminance of this frame, 2-frame blend into postProcessBuffers[0]
@@ -103,11 +121,17 @@ class OracleFrame:
             m2 = self.cpu_frame % 2
             out, hist = passes.orc_taa(src, self.taa_hist[m2], inp.gb["motion"], depth, w, h, weights9, global_bytes, bool(s.taa_use_clipping),
                                        bool(s.taa_use_motion_vector_dilation), int(s.taa_history_sampling_tech), bool(s.taa_filter_use_tonemapping))
+            if self.capture:
+                self.cap["taa"] = dict(inp=src.copy(), history=self.taa_hist[m2].copy(), weights=np.array(weights9, np.float32), out=out.copy())
             self.taa_hist[(m2 + 1) % 2] = hist
             self.post1 = out
             src = self.post1
         if s.run_bloom and s.bloom_enabled:
+            if self.capture:
+                self.cap["bloom"] = dict(inp=src.copy())
             out, _, _ = passes.orc_bloom(src, w, h, float(s.bloom_strength), float(s.bloom_radius))
+            if self.capture:
+                self.cap["bloom"]["out"] = out.copy()
             if src is self.post1:
                 self.post1 = out
             else:
@@ -115,4 +139,8 @@ class OracleFrame:
             src = out
         if s.run_tonemap:
             self.swapchain = passes.orc_tonemap(src, w, h, global_bytes)
+            if self.capture:
+                self.cap["tonemap"] = dict(inp=src.copy(), out=self.swapchain.copy())
+        if self.capture:
+            self.cap["global"] = bytes(global_bytes)
         return src

@@ -849,3 +849,24 @@ def orc_volumetrics(fw, fh, fd, noise_u8, history_u16, shadow_map_u16, shadow_re
     L.orc_volume_lighting_reprojection(target.ref(), scattering.ref(), history.ref(), st, C.byref(g))
     L.orc_volumetric_lighting_integration(integration.ref(), target.ref(), st)
     return [i.arr.view(np.uint16).copy() for i in (material, scattering, target, integration)]
+
+
+# ------------------------------------------------------------------ decision signatures (include/plr.h, oracle/oracle.h)
+class gpu_signature:
+    """with gpu_signature(be, words) as s: <one gpu_* pass>; s.words -> uint32 array written by the fast kernel of that pass"""
+
+    def __init__(self, be, words):
+        self.be, self.n = be, int(words)
+
+    def __enter__(self):
+        self.be.setDecisionSignature(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.words = self.be.readDecisionSignature(self.n)
+        self.be.setDecisionSignature(0)
+        return False
+
+
+orc_signature = orc.decision_signature

@@ -1,0 +1,236 @@
+"""The BENCHMARKED kernel set (PLR_MATH_FAST) against the oracle at the BENCHMARKED size: BASELINE configs 3, 4 and the full frame at
+3840x2160 with 256 SDF instances x 64^3 (bench.py's workload, frame 2 so that every history is populated).
+
+Every HIP pass is fed exactly what the oracle pass consumed and is held to the tolerance statement of tests/parity.py: one storage
+quantum per channel for every pixel whose discrete decisions agree with the oracle's (decision signatures, oracle/oracle.h), a hard cap
+on the number of pixels where a float rounding flipped a decision, and a bound on what a flipped pixel may differ by.
+PLR_PARITY_SIZE=WxH (multiples of 64) runs the same tests at another size. Measured numbers: profiles/r02_parity_4k.txt.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+import passes
+from plainrenderer_amd import pixfmt
+from util import F
+
+W, H = (int(v) for v in os.environ.get("PLR_PARITY_SIZE", "3840x2160").split("x"))
+TW, TH = W // 2, H // 2
+U = pixfmt.unpack_half
+
+
+class State:
+    pass
+
+
+@pytest.fixture(scope="module")
+def fs(backend):
+    """bench.py's scene; two frames of the C++ FramePipeline in PLR_MATH_FAST with the oracle frame run beside it on what the pipeline submitted"""
+    import bench
+    from oracle_frame import OracleFrame
+    from plainrenderer_amd.frame import FramePipeline
+
+    class A:
+        grid, sdf_res, shadow_res, steps, warmup, profile_frames = 16, 64, 2048, 4, 0, 0
+    s = State()
+    backend.setMathMode(True)
+    fp = FramePipeline(backend, W, H, shadow_map_res=2048)
+    scene, cams, inputs = bench.build_scene(A, "cuda:0", W, H)
+    inputs.upload(fp)
+    ora = OracleFrame(inputs, W, H, 512, fp.settings)
+    for f in range(2):
+        fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+        frustum = backend.downloadUniformBuffer(fp.uniform_buffer("sdfCameraFrustum"), 192).tobytes()
+        ora.capture = f == 1
+        ora.frame(fp.submitted_globals(), fp.resolve_weights(), frustum, 5.0)
+    s.fp, s.ora, s.inputs, s.cap, s.gp, s.gb, s.settings = fp, ora, inputs, ora.cap, ora.cap["global"], inputs.gb, fp.settings
+    s.post_gpu = backend.downloadImage(fp.image("post1"), 0, np.uint32).copy()
+    s.swap_gpu = backend.downloadImage(fp.image("swapchain"), 0, np.uint8).copy()
+    s.hist_gpu = backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy()
+    yield s
+    fp.destroy()
+    backend.setMathMode(False)
+
+
+def report(name, **kv):
+    print("PARITY %-14s %s" % (name, " ".join("%s=%s" % (k, ("%.6g" % v) if isinstance(v, float) else v) for k, v in kv.items())), flush=True)
+
+
+# ------------------------------------------------------------------ config 4: trace + denoise
+@pytest.mark.gpu
+def test_gpu_fullsize_trace(backend, fs):
+    c = fs.cap["trace"]
+    args = (fs.gb["depth"], fs.gb["normal"], W, H, TW, TH, fs.inputs.sky, 200, 100, c["light"], fs.inputs.instance_bytes_patched, c["tiles"], 5.0, fs.inputs.shadow_info,
+            fs.inputs.shadow_maps[c["cascade"]], fs.inputs.shadow_res, fs.gp)
+    with passes.gpu_signature(backend, TW * TH) as sg:
+        yg, cg = passes.gpu_sdf_trace(backend, *args, strict=True, cascade=c["cascade"])
+    arr, n = fs.ora._bindless(passes.orc.global_from_bytes(fs.gp))
+    with passes.orc_signature(TW * TH) as so:
+        yo, co = passes.orc_sdf_trace(*args, arr, n, strict=True, cascade=c["cascade"])
+    assert np.array_equal(yo, c["out"][0]) and np.array_equal(co, c["out"][1])  # the oracle reproduces its own frame (and the signature run changes nothing)
+    counts = c["tiles"].reshape(-1, passes.TILE_UINTS)[:, 0]
+    ray_flip = ((sg.words ^ so.words) & ~np.uint32(0x7F8)).reshape(TH, TW) != 0     # hit / shadow / zeroed / closest instance of the pixel's own ray
+    take_flip = ((sg.words ^ so.words) & np.uint32(0x7F8)).reshape(TH, TW) != 0      # the resolve accepted different neighbours
+    touched = (parity.dilate3x3(ray_flip) | take_flip).reshape(-1)                    # a flipped ray reaches its 8 neighbours through the 3x3 resolve
+    got = np.concatenate([U(yg).reshape(-1, 4), U(cg).reshape(-1, 2)], axis=1)
+    ref = np.concatenate([U(yo).reshape(-1, 4), U(co).reshape(-1, 2)], axis=1)
+    bad = parity.half_violations(got, ref, floor_frac=2.0 ** -10)
+    report("trace", rays_flipped=float(ray_flip.mean()), take_flipped=float(take_flip.mean()), pixels_touched=float(touched.mean()),
+           clean_violations=int((bad & ~touched).sum()), touched_violations=float((bad & touched).mean()), max_tile_count=int(counts.max()))
+    assert not (bad & ~touched).any(), "pixels with identical ray decisions must agree to max(2^-7 |x|, 2^-10 max|x|)"
+    assert ray_flip.mean() <= 0.004, "hard cap: at most 0.4 % of the rays may resolve differently (hit / miss, owner, shadow bit)"
+    assert take_flip.mean() <= 0.0005
+    assert np.isfinite(got).all() and np.abs(got - ref)[touched].max(initial=0.0) <= 2.0 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,filter_index", [("spatial0", 0), ("spatial1", 1)])
+def test_gpu_fullsize_spatial_filter(backend, fs, which, filter_index):
+    c = fs.cap[which]
+    dsrc, dfmt, dw, dh = c["depth"]
+    args = (c["inp"][0], c["inp"][1], TW, TH, dsrc, dfmt, dw, dh, fs.gb["normal"], W, H, fs.gp, filter_index)
+    with passes.gpu_signature(backend, TW * TH) as sg:
+        yg, cg = passes.gpu_gi_spatial(backend, *args)
+    with passes.orc_signature(TW * TH) as so:
+        yo, co = passes.orc_gi_spatial(*args)
+    assert np.array_equal(yo, c["out"][0])
+    x = sg.words ^ so.words
+    flipped_samples = np.zeros(x.size, np.int32)
+    for b in range(32):
+        flipped_samples += ((x >> np.uint32(b)) & np.uint32(1)).astype(np.int32)
+    clean = flipped_samples == 0
+    got = np.concatenate([U(yg).reshape(-1, 4), U(cg).reshape(-1, 2)], axis=1)
+    ref = np.concatenate([U(yo).reshape(-1, 4), U(co).reshape(-1, 2)], axis=1)
+    bad = parity.half_violations(got, ref, floor_frac=2.0 ** -10)
+    # a pixel with k of its 32 samples on another texel: each sample carries at most weight 1 of a total >= (32 - k) * (smallest weight) - bounded
+    # here by the spread of the input around the pixel: |delta| <= k / 32 * (max - min of the input image) is far too loose to be useful, so the
+    # statement for flipped pixels is statistical: their error stays below 1/4 of the image's range and shrinks with k
+    err = np.abs(got - ref).max(axis=1)
+    report(which, sample_flip_rate=float(flipped_samples.sum() / (32.0 * x.size)), pixels_with_flip=float((~clean).mean()), clean_violations=int((bad & clean).sum()),
+           flipped_pixel_violations=float((bad & ~clean).mean()), max_err_clean=float(err[clean].max()), max_err_flipped=float(err[~clean].max(initial=0.0)), scale=float(np.abs(ref).max()))
+    assert not (bad & clean).any(), "pixels whose 32 samples read the same texels as the oracle's must agree to max(2^-7 |x|, 2^-10 max|x|)"
+    assert flipped_samples.sum() <= 0.02 * 32 * x.size, "hard cap: at most 2 % of all disc samples may land on a neighbouring texel"
+    assert err[~clean].max(initial=0.0) <= 0.5 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_gpu_fullsize_temporal_filter(backend, fs):
+    c = fs.cap["temporal"]
+    args = (*c["inp"], TW, TH, fs.gb["motion"], fs.gb["motion"], W, H, fs.gp)
+    tg = passes.gpu_gi_temporal(backend, *args)
+    got = np.concatenate([U(tg[0]).reshape(-1, 4), U(tg[1]).reshape(-1, 2)], axis=1)
+    ref = np.concatenate([U(c["out"][0]).reshape(-1, 4), U(c["out"][1]).reshape(-1, 2)], axis=1)
+    bad = parity.half_violations(got, ref, floor_frac=2.0 ** -10)
+    report("temporal", violations=int(bad.sum()), max_err=float(np.abs(got - ref).max()), scale=float(np.abs(ref).max()))
+    assert not bad.any()
+    assert np.array_equal(tg[0], tg[2]) and np.array_equal(tg[1], tg[3])
+
+
+@pytest.mark.gpu
+def test_gpu_fullsize_upscale(backend, fs):
+    c = fs.cap["upscale"]
+    args = (c["inp"][0], c["inp"][1], TW, TH, fs.gb["depth"], c["half_depth"], W, H, fs.gp)
+    with passes.gpu_signature(backend, W * H) as sg:
+        yg, cg = passes.gpu_gi_upscale(backend, *args)
+    with passes.orc_signature(W * H) as so:
+        yo, co = passes.orc_gi_upscale(*args)
+    assert np.array_equal(yo, c["out"][0])
+    flip = sg.words != so.words
+    got = np.concatenate([U(yg).reshape(-1, 4), U(cg).reshape(-1, 2)], axis=1)
+    ref = np.concatenate([U(yo).reshape(-1, 4), U(co).reshape(-1, 2)], axis=1)
+    bad = parity.half_violations(got, ref, floor_frac=2.0 ** -10)
+    report("upscale", flipped=float(flip.mean()), clean_violations=int((bad & ~flip).sum()), edge_pixels=float((so.words & 1).mean()))
+    assert not (bad & ~flip).any()
+    assert flip.mean() <= 1e-4, "hard cap: edge / closest-depth decisions (the kernel evaluates them with the shader's rounding)"
+
+
+# ------------------------------------------------------------------ shade
+@pytest.mark.gpu
+def test_gpu_fullsize_deferred_shading(backend, fs):
+    c, s = fs.cap["shade"], fs.settings
+    args = (fs.gb, W, H, fs.ora.brdf_lut, 512, c["light"], fs.inputs.shadow_info, fs.inputs.shadow_maps, fs.inputs.shadow_res, c["gi"][0], c["gi"][1], fs.inputs.froxel,
+            fs.inputs.froxel_dims, fs.inputs.vol_settings, fs.inputs.sky, fs.gp)
+    var = (int(s.diffuse_brdf), int(s.direct_multiscatter), bool(s.use_geometry_aa), int(s.indirect_lighting_tech), int(s.sun_shadow_cascade_count))
+    with passes.gpu_signature(backend, W * H) as sg:
+        got = passes.gpu_deferred_shading(backend, *args, *var)
+    arr, n = fs.ora._bindless(passes.orc.global_from_bytes(fs.gp))
+    with passes.orc_signature(W * H) as so:
+        ref = passes.orc_deferred_shading(*args, arr, n, *var)
+    assert np.array_equal(ref, c["out"])
+    flip = sg.words != so.words
+    cascade_flip = ((sg.words ^ so.words) & 3) != 0
+    d = parity.r11g11b10_code_diff(got, ref)
+    worst_clean = d[~flip].max()
+    lit = (so.words >> 2) & 15
+    report("shade", pcf_flipped=float(flip.mean()), cascade_flipped=float(cascade_flip.mean()), clean_max_code_diff=int(worst_clean), clean_differing=float((d[~flip] != 0).any(axis=1).mean()),
+           flipped_max_code_diff=int(d[flip].max(initial=0)), partially_lit=float(((lit > 0) & (lit < 12)).mean()))
+    assert worst_clean <= 1, "same cascade and the same number of lit PCF taps: every channel within one R11G11B10 code"
+    assert flip.mean() <= 0.03, "hard cap: pixels where one of the 12 shadow-map comparisons (D16 equality on lit surfaces) resolves differently"
+    assert cascade_flip.mean() <= 1e-5
+    tap = np.abs(((sg.words >> 2) & 15).astype(int) - lit.astype(int))
+    assert tap.max() <= 3, "a flipped pixel differs in at most a few of its 12 taps"
+
+
+# ------------------------------------------------------------------ config 3: TAA + bloom (+ HiZ: bit exact in tests/test_hiz_bloom_taa.py at 3840x2160)
+@pytest.mark.gpu
+def test_gpu_fullsize_taa(backend, fs):
+    c = fs.cap["taa"]
+    og, hg = passes.gpu_taa(backend, c["inp"], c["history"], fs.gb["motion"], fs.gb["depth"], W, H, c["weights"], fs.gp, True, True, 4, True)
+    d = parity.r11g11b10_code_diff(og, c["out"])
+    report("taa", max_code_diff=int(d.max()), differing=float((d != 0).any(axis=1).mean()))
+    assert d.max() <= 1, "TAA resolve (clip, dilate, Bicubic1Tap, tonemapped): every channel of every pixel within one R11G11B10 code"
+    assert np.array_equal(og, hg)
+
+
+@pytest.mark.gpu
+def test_gpu_fullsize_bloom(backend, fs):
+    c, s = fs.cap["bloom"], fs.settings
+    out_g, downs_g, ups_g = passes.gpu_bloom(backend, c["inp"], W, H, float(s.bloom_strength), float(s.bloom_radius))
+    out_o, downs_o, ups_o = passes.orc_bloom(c["inp"], W, H, float(s.bloom_strength), float(s.bloom_radius))
+    assert np.array_equal(out_o, c["out"])
+    worst = 0
+    for i, (a, b) in enumerate(zip(downs_g + ups_g, downs_o + ups_o)):
+        d = parity.r11g11b10_code_diff(a, b)
+        worst = max(worst, int(d.max()))
+    d = parity.r11g11b10_code_diff(out_g, out_o)
+    report("bloom", chain_max_code_diff=worst, applied_max_code_diff=int(d.max()), applied_differing=float((d != 0).any(axis=1).mean()))
+    # every level re-quantises to R11G11B10 and feeds the next: a one-code difference at a coarse level can move a finer level's value across
+    # a rounding boundary, never further
+    assert worst <= 2 and d.max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_fullsize_tonemap_and_exposure(backend, fs):
+    c = fs.cap["tonemap"]
+    a = passes.gpu_tonemap(backend, c["inp"], W, H, fs.gp, F.BGRA8_uNorm).astype(int).reshape(-1)
+    d = np.abs(a - c["out"].astype(int).reshape(-1))
+    report("tonemap", max_lsb=int(d.max()), differing=float((d != 0).mean()))
+    assert d.max() <= 1
+    # luminance histogram of the oracle's previous frame image: integer bins, bit exact at 4K
+    _, hist_g = passes.gpu_histogram(backend, fs.ora.color[fs.ora.rt_index], W, H, fs.ora.light)
+    _, hist_o = passes.orc_histogram(fs.ora.color[fs.ora.rt_index], W, H, fs.ora.light)
+    assert np.array_equal(hist_g, hist_o) and int(hist_o.sum()) == W * H
+
+
+# ------------------------------------------------------------------ the whole frame, end to end (decision flips propagate through the chain here)
+@pytest.mark.gpu
+def test_gpu_fullsize_frame_end_to_end(backend, fs):
+    """Two full frames of the C++ FramePipeline in PLR_MATH_FAST against the oracle frame. A flipped ray / sample / PCF tap of an early pass
+    is carried through denoise, shade, TAA and bloom, so the end-to-end statement is statistical; the per-pass tests above carry the bound."""
+    d = parity.r11g11b10_code_diff(fs.post_gpu, fs.ora.post1)
+    within1 = (d <= 1).all(axis=1)
+    sw = np.abs(fs.swap_gpu.astype(int).reshape(-1) - fs.ora.swapchain.astype(int).reshape(-1))
+    lit = pixfmt.unpack_r11g11b10(fs.post_gpu)
+    ref = pixfmt.unpack_r11g11b10(fs.ora.post1)
+    mean_rel = float(np.abs(lit - ref).mean() / ref.mean())
+    hist_equal = float((fs.hist_gpu == fs.ora.hist).mean())
+    report("frame", within_one_code=float(within1.mean()), within_4_codes=float((d <= 4).all(axis=1).mean()), max_code_diff=int(d.max()), swapchain_within_1lsb=float((sw <= 1).mean()),
+           swapchain_max_lsb=int(sw.max()), mean_rel_err=mean_rel, histogram_bins_equal=hist_equal, histogram_total=int(fs.hist_gpu.sum()))
+    assert np.isfinite(lit).all()
+    assert within1.mean() >= 0.985, "at least 98.5 % of the pixels of the final HDR image within one R11G11B10 code of the oracle frame"
+    assert (d <= 4).all(axis=1).mean() >= 0.997
+    assert (sw <= 1).mean() >= 0.9999, "tonemapped swapchain: 99.99 % of the channels within 1 LSB"
+    assert mean_rel <= 2e-3
+    assert int(fs.hist_gpu.sum()) == W * H
