@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
     ap.add_argument("--exact", action="store_true", help="diagnostic: run the bit-exact kernel set (PLR_MATH_EXACT) instead of the default fast set")
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
+    ap.add_argument("--python-exchange", action="store_true", help="diagnostic: drive the halo exchange from Python (torch.distributed) instead of the C++ host's RCCL exchange")
     ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
@@ -226,7 +227,17 @@ def main():
         be_ = RenderBackend(w_, h_, device=local_rank)
         if band_ is not None:
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=band_[0], band_row_end=band_[1])
-            tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank)
+            if args.python_exchange:
+                tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank)  # diagnostic: torch.distributed transport driven from Python
+            else:
+                # the C++ host's RCCL exchange: rank 0 creates the ncclUniqueId, every rank receives it once (this broadcast is the only use of
+                # torch.distributed on the data path's behalf), then ncclCommInitRank inside libplr
+                uid = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(fp_.rccl_unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(uid, src=0)
+                fp_.attach_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, h_)
         else:
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res)
         sc = build_scene(args, device, w_, h_, band_)
@@ -326,6 +337,10 @@ def main():
             sys.stderr.write("%-36s %9.4f %7.1f %9.1f %8.1f\n" % (name, avg, launches, nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0, 100 * avg * launches / tot))
         sys.stderr.write("sum of pass times %.3f ms; frame (wall) %.3f ms\n" % (tot, ms_per_step))
 
+    exchange_stats = None
+    if band is not None and not args.python_exchange:
+        sent, received, groups = fp.rccl_stats()
+        exchange_stats = {"rank0_bytes_sent_per_frame": sent, "rank0_bytes_received_per_frame": received, "point_to_point_groups_per_frame": groups}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, os.cpu_count() or 1, device)
@@ -341,13 +356,15 @@ def main():
             "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d, %d SDF instances x %d^3, "
                                    "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
                        "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "kernel_set": "exact" if args.exact else "fast",
-                       "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point "
-                                       "%d times per frame + one 512 B histogram all-reduce" % (w, h, world, h // world, 4)) if (world > 1 and not replicas) else
+                       "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point (%s) "
+                                       "+ one 512 B histogram all-reduce per frame" % (w, h, world, h // world, "torch.distributed from Python" if args.python_exchange else
+                                                                                        "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
             "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "exchange": exchange_stats,
             "passes_ms": {name: round(avg * launches, 4) for name, avg, launches, _ in table},
         }
         print(json.dumps(out))

@@ -192,6 +192,13 @@ int plr_set_pass_timing(int enabled);
  * All side streams join the main stream before a host callback and at the end of the frame. Results do not depend on the setting.
  * out_overlapped_executions: how many executions of the last plr_render_frame ran on a side stream. */
 int plr_set_stream_overlap(int enabled);
+/* Pass fusion (default on, PLR_MATH_FAST only): where the recorded frame contains certain shaders back to back - histogramReset +
+ * histogramCombineTiles + preExposeLights; depthHiZPyramid + depthDownscale; sdfCameraFrustumCulling + sdfCameraTileCulling; applyBloom +
+ * tonemapping; a GI pass followed by the spatial filter that reads its output - the backend covers them with fewer kernel launches. The
+ * boundary is unchanged (one plr_set_compute_pass_execution per reference dispatch) and so are the results (byte-identical with fusion
+ * off, tests/test_fusion.py). out_fused_executions: how many executions of the last plr_render_frame ran inside a fused launch. */
+int plr_set_pass_fusion(int enabled);
+int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions);
 int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
 int plr_get_last_frame_gpu_time(float* out_ms);

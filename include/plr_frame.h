@@ -69,6 +69,29 @@ int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, 
 int plrf_get_exchange_items(void* pipeline, int exchange_id, plrf_exchange_item* out_items, uint32_t* inout_count);
 int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes);
 
+/* ---- the same exchange, natively over RCCL (csrc/frontend/band_exchange.cpp): one process per GPU, one band per process ----
+ * plrf_rccl_attach creates this rank's communicator (ncclCommInitRank with the id rank 0 obtained from plrf_rccl_get_unique_id and handed to
+ * every rank by the launcher, once) and installs a C++ exchange callback on the pipeline: per exchange one group of ncclSend / ncclRecv with
+ * the band above and the band below on a communication stream ordered against the launch stream by events (BEGIN / END phases), and one
+ * 512-byte ncclAllReduce for the luminance histogram. frame_height = rows of the whole frame (bands = plrf_band_rows of it). */
+#define PLRF_RCCL_UNIQUE_ID_BYTES 128
+int plrf_rccl_get_unique_id(void* out_128_bytes);
+int plrf_rccl_attach(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_height, void** out_exchange);
+int plrf_rccl_detach(void* pipeline, void* exchange);
+/* bytes this rank sent / received and the number of point-to-point exchange groups of the last frame */
+int plrf_rccl_get_stats(void* exchange, uint64_t* out_bytes_sent, uint64_t* out_bytes_received, uint64_t* out_exchanges);
+/* single-GPU check of the transport: rows [src_row, src_row + rows) of an image are sent to and received from this rank itself onto
+ * rows [dst_row, ...) through the same group / stream / event sequence as an overlapped exchange */
+int plrf_rccl_self_test(void* exchange, void* device_ptr, uint32_t row_bytes, uint32_t src_row, uint32_t dst_row, uint32_t rows, void* launch_stream);
+const char* plrf_rccl_last_error(void);
+/* the partition and the per-item transfer plan the exchange uses (pure functions, no GPU): band `band` of `n_bands` owns full-resolution rows
+ * [begin, end), multiples of 64; for one exchange item (an image of image_rows rows showing the frame at frame_height / image_rows scale, of
+ * which this band owns [row_begin, row_end)) the plan lists up to 4 transfers: send / receive with the band above and below */
+typedef struct plrf_exchange_op { uint32_t peer, send, row_begin, row_end; } plrf_exchange_op;
+int plrf_band_rows(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t* out_row_begin, uint32_t* out_row_end);
+int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,
+                       plrf_exchange_op* out_ops_4, uint32_t* out_count);
+
 typedef struct plrf_camera { float position[3], forward[3], up[3], right[3]; } plrf_camera;
 
 int plrf_default_settings(plrf_settings* out, uint32_t width, uint32_t height);

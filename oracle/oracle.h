@@ -207,8 +207,9 @@ void orc_set_threads(int32_t n);
  *   sdfDiffuseTrace:  bit 0 ray hit, bit 1 simpleShadow(hit point) == 1, bit 2 hit colour zeroed (outside the influence radius or
  *                     self intersection), bits 3-10 which of the 8 neighbours the 3x3 resolve accepted (loop order x outer, y inner,
  *                     centre skipped), bits 11-31 (index of the instance that owns the closest hit) + 1, 0 without a hit
- *   filterIndirectDiffuseSpatial: bit i (sample i of 32) = (texelX + texelY + offScreen) & 1 of the nearest texel the sample reads
- *                     (a flip to a neighbouring texel or across the off-screen test toggles the bit)
+ *   filterIndirectDiffuseSpatial: TWO words per pixel (index 2 * pixel, 2 * pixel + 1): bit i (sample i of 32) of the first = (texelX + offScreen) & 1,
+ *                     of the second = (texelY + offScreen) & 1 of the nearest texel the sample reads (a step to a neighbouring texel in x / y or
+ *                     across the off-screen test toggles a bit)
  *   indirectLightUpscale: bit 0 isEdge, bit 1 / bit 2 = x / y offset of the closest-depth texel
  *   deferred shade:   bits 0-1 shadow cascade, bits 2-5 number of lit PCF taps (0..12), bit 6 geometry pixel, bit 7 sky pixel */
 void orc_set_decision_signature(uint32_t* words, int64_t count);

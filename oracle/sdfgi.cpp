@@ -371,7 +371,7 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                 float radiusWorld = 1.5f;
                 if (filterIndex == 1) radiusWorld = 1.f;
                 float lengthModifier = 1.f;
-                uint32_t sampleParity = 0u; // decision signature
+                uint32_t sampleParityX = 0u, sampleParityY = 0u; // decision signature
                 for (int i = 0; i < sampleCount; i++) {
                     const float d = std::sqrt(rand01(rngState)) * lengthModifier;
                     const float angle = 2.f * pi * rand01(rngState);
@@ -401,7 +401,8 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                         int tx = (int)std::floor(saneCoord(sampleUV.x * (float)texture_Y_SH.w)), ty = (int)std::floor(saneCoord(sampleUV.y * (float)texture_Y_SH.h));
                         tx = tx < 0 ? 0 : (tx >= texture_Y_SH.w ? texture_Y_SH.w - 1 : tx);
                         ty = ty < 0 ? 0 : (ty >= texture_Y_SH.h ? texture_Y_SH.h - 1 : ty);
-                        sampleParity |= (uint32_t)((tx + ty + (offScreen ? 1 : 0)) & 1) << i;
+                        sampleParityX |= (uint32_t)((tx + (offScreen ? 1 : 0)) & 1) << i;
+                        sampleParityY |= (uint32_t)((ty + (offScreen ? 1 : 0)) & 1) << i;
                     }
                     if (weight > 0.f) {
                         const vec4 sample_Y_SH = texture2D(texture_Y_SH, NEAREST, CLAMP, sampleUV);
@@ -420,7 +421,8 @@ extern "C" void orc_filter_indirect_diffuse_spatial(const orc_image* outYSHP, co
                 result_CoCg /= weightTotal;
                 imageStore(imageOut_Y_SH, iUV, result_Y_SH);
                 imageStore(imageOut_CoCg, iUV, vec4(result_CoCg.x, result_CoCg.y, 0, 0));
-                writeSig((int64_t)py * imageOut_Y_SH.w + px, sampleParity);
+                writeSig(2 * ((int64_t)py * imageOut_Y_SH.w + px), sampleParityX);
+                writeSig(2 * ((int64_t)py * imageOut_Y_SH.w + px) + 1, sampleParityY);
             }
     });
 }

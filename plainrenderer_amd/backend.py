@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_host_callback_execution", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -498,6 +498,15 @@ class RenderBackend:
             bp = b.ctypes.data_as(C.c_void_p)
         self._check(self.lib.plr_debug_math_eval(C.c_int(fn), a.ctypes.data_as(C.c_void_p), bp, out.ctypes.data_as(C.c_void_p), C.c_int64(a.size)))
         return out
+
+    def setPassFusion(self, enabled):
+        self._check(self.lib.plr_set_pass_fusion(C.c_int(int(bool(enabled)))))
+
+    def getPassFusion(self):
+        """-> (enabled, executions of the last frame that ran inside a fused launch)"""
+        e, n = C.c_int(), C.c_uint32()
+        self._check(self.lib.plr_get_pass_fusion(C.byref(e), C.byref(n)))
+        return bool(e.value), n.value
 
     def setDecisionSignature(self, words):
         """decision-signature buffer for the next single-pass frame (include/plr.h); 0 frees it"""

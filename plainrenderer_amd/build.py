@@ -66,6 +66,11 @@ def _compile(src, digest, verbose):
     flags = FLAGS
     if os.sep + "kernels_fast" + os.sep in src:
         flags = [FAST_FLAGS_REPLACE.get(f, f) for f in FLAGS] + FAST_FLAGS_EXTRA
+    # a source may ask for extra flags of its own with a line "// PLR_BUILD_FLAGS: <flags>" (they go last, so they win over the set's defaults)
+    with open(src) as fh:
+        for line in fh:
+            if line.startswith("// PLR_BUILD_FLAGS:"):
+                flags = flags + line.split(":", 1)[1].split()
     cmd = [HIPCC, "-x", "hip"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -90,7 +95,8 @@ def build(verbose=False, jobs=None):
     objs = [o for o, _ in results]
     changed = any(c for _, c in results)
     if changed or not os.path.exists(LIB_PATH):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        # librccl: the band exchange of the C++ host (csrc/frontend/band_exchange.cpp) calls ncclSend / ncclRecv / ncclAllReduce directly
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-L/opt/rocm/lib", "-lrccl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

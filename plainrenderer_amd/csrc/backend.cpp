@@ -39,6 +39,27 @@ ShaderRegistrar::ShaderRegistrar(const char* name, LaunchFn fn, bool fast) {
     registry().push_back(e);
 }
 
+struct FusionEntry {
+    std::string label;
+    std::vector<std::string> shaders;
+    FusedLaunchFn fn;
+};
+static std::vector<FusionEntry>& fusions() {
+    static std::vector<FusionEntry> r;
+    return r;
+}
+FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn) {
+    FusionEntry e;
+    e.label = label;
+    for (const char* sname : shaders) e.shaders.push_back(sname);
+    e.fn = fn;
+    // longer sequences first: a chain of three is tried before a pair that is its prefix
+    auto& list = fusions();
+    auto pos = list.begin();
+    while (pos != list.end() && pos->shaders.size() >= e.shaders.size()) ++pos;
+    list.insert(pos, std::move(e));
+}
+
 static const ShaderEntry* findShader(const std::string& path) {
     std::string base = path;
     const size_t slash = base.find_last_of("/\\");
@@ -225,6 +246,9 @@ struct Backend {
     uint32_t lastOverlapped = 0;         // executions of the last frame that were placed on a side stream
     uint32_t* debugSig = nullptr;        // decision-signature buffer (plr_debug_set_decision_signature)
     size_t debugSigWords = 0;
+    bool fusion = true;                  // plr_set_pass_fusion
+    uint32_t lastFused = 0;              // executions of the last frame that ran inside a fused launch
+    std::set<std::string> fusedNames;    // stable storage for the timing labels of fused launches
 };
 
 // one backend per host thread: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
@@ -740,7 +764,7 @@ static void planStreams(size_t first, size_t last, std::vector<PlanNode>& plan, 
     for (int st = 0; st < kMaxStreams; st++) mainAfter[st] = tail[0] >= 0 ? plan[tail[0]].after[st] : -1;
 }
 
-static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {
+static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr) {
     PassRes& p = *g->passes[x.pass];
     x.ctx.stream = stream;
     x.ctx.global = globalPtr;
@@ -752,6 +776,11 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     x.ctx.scratchSize = &p.scratchSize;
     x.ctx.debugSig = g->debugSig;
     x.ctx.debugSigWords = g->debugSigWords;
+}
+
+static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {
+    PassRes& p = *g->passes[x.pass];
+    prepareCtx(x, stream, globalPtr);
     g->currentPassName = p.name.c_str();
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
@@ -762,12 +791,50 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     return PLR_OK;
 }
 
+// executions [i, last) are compute passes (no host callback). If a fused launcher matches the shaders starting at i and accepts the
+// bindings, it is launched and the number of executions it covered is returned; 0: nothing fused (launch execution i on its own)
+static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const GlobalUbo* globalPtr, bool timed, size_t* covered) {
+    *covered = 0;
+    if (!g->fusion || g->mathMode != PLR_MATH_FAST || g->debugSig) return PLR_OK;
+    for (const FusionEntry& f : fusions()) {
+        const size_t n = f.shaders.size();
+        if (i + n > last) continue;
+        bool match = true;
+        for (size_t k = 0; k < n && match; k++) match = g->passes[g->executions[i + k].pass]->shader == f.shaders[k];
+        if (!match) continue;
+        const PassCtx* ctxs[8];
+        if (n > 8) continue;
+        for (size_t k = 0; k < n; k++) { prepareCtx(g->executions[i + k], stream, globalPtr); ctxs[k] = &g->executions[i + k].ctx; }
+        const char* label = nullptr;
+        g->curStream = stream;
+        if (timed) {
+            std::string name;
+            for (size_t k = 0; k < n; k++) name += (k ? " + " : "") + g->passes[g->executions[i + k].pass]->name;
+            label = g->fusedNames.insert(name).first->c_str();
+            if (int trc = beginSegment(label)) return trc;
+        }
+        g->currentPassName = label ? label : f.label.c_str();
+        const int rc = f.fn(ctxs, n);
+        if (rc == kUseGeneralKernel) {
+            if (timed) { g->segments.pop_back(); g->eventsUsed -= 1; } // the opening event stays recorded on the stream; its slot is reused
+            continue;
+        }
+        if (rc) { g_err = "fused launch '" + f.label + "': " + g_err; return rc; }
+        if (timed) if (int trc = endSegment()) return trc;
+        *covered = n;
+        g->lastFused += (uint32_t)n;
+        return PLR_OK;
+    }
+    return PLR_OK;
+}
+
 static int launchAll(bool timed) {
     const size_t n = g->executions.size();
     g->timingNow = timed;
     if (timed) { g->segments.clear(); g->eventsUsed = 0; }
     g->orderEventsUsed = 0;
     g->lastOverlapped = 0;
+    g->lastFused = 0;
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
     std::vector<PlanNode> plan(n);
     std::vector<hipEvent_t> done(n, nullptr);
@@ -787,7 +854,13 @@ static int launchAll(bool timed) {
         size_t last = i;
         while (last < n && !g->executions[last].callback) last++;
         if (!g->overlap) {
-            for (; i < last; i++) if (int rc = launchExecution(g->executions[i], g->stream, globalPtr, timed)) return rc;
+            while (i < last) {
+                size_t covered = 0;
+                if (int rc = tryFusedLaunch(i, last, g->stream, globalPtr, timed, &covered)) return rc;
+                if (covered) { i += covered; continue; }
+                if (int rc = launchExecution(g->executions[i], g->stream, globalPtr, timed)) return rc;
+                i++;
+            }
             continue;
         }
         int mainAfter[kMaxStreams];
@@ -862,6 +935,18 @@ int plr_render_frame(int /*present_to_screen*/) {
         for (auto& sg : g->segments) g->lastTimings.push_back({0.f, sg.name});
     }
     g->lastCpuMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PLR_OK;
+}
+
+int plr_set_pass_fusion(int enabled) {
+    NEED_INIT();
+    g->fusion = enabled != 0;
+    return PLR_OK;
+}
+int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions) {
+    NEED_INIT();
+    if (out_enabled) *out_enabled = g->fusion ? 1 : 0;
+    if (out_fused_executions) *out_fused_executions = g->lastFused;
     return PLR_OK;
 }
 

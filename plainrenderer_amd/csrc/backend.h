@@ -94,6 +94,17 @@ struct ShaderRegistrar {
 // restructured / fast-math variant of a shader, used when the math mode is PLR_MATH_FAST (kernels_fast/*.hip)
 #define PLR_REGISTER_SHADER_FAST(name, fn) static ::plr::ShaderRegistrar plr_registrar_fast_##fn(name, fn, true)
 
+// Fusion of ADJACENT recorded executions (PLR_MATH_FAST only; plr_set_pass_fusion). The boundary stays one setComputePassExecution per
+// reference dispatch; when the recorded sequence contains the shaders of a fused launcher back to back (no host callback in between), the
+// backend hands all their contexts to it and it covers them with fewer kernels. A launcher returns kUseGeneralKernel when the bindings are
+// not what it was built for (the executions then run one by one), 0 when it launched everything, < 0 on error. Results must not depend on
+// whether a sequence was fused (tests/test_fusion.py compares bytes).
+typedef int (*FusedLaunchFn)(const PassCtx* const* ctxs, size_t count);
+struct FusionRegistrar {
+    FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn);
+};
+#define PLR_REGISTER_FUSION(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn)
+
 inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // records the message plr_last_error() returns on this thread; returns code

@@ -29,12 +29,14 @@ PLR_DI float clampCoord(float u) { return __builtin_amdgcn_fmed3f(u, -1.0e6f, 1.
 PLR_DI uint32_t texelIndex(uint32_t x, uint32_t y, uint32_t w) { return __umul24(y, w) + x; }
 
 // ---- sky LUT lookup (sky.inc:86-94, 112-116) for the fast kernels. The exact path spends ~350 VALU instructions per lookup on the software
-// acos / atan2 of detmath.h and on integer modulo for the repeat addressing. Here: polynomial acos (Abramowitz & Stegun 4.4.45,
-// |error| <= 7e-5 rad) and atan (|error| <= 1e-5 rad) - a hundredth of a LUT texel - and a conditional wrap (the u coordinate lies in
-// [0, 1], so the bilinear footprint can only step one texel across the seam).
+// acos / atan2 of detmath.h and on integer modulo for the repeat addressing. Here: polynomial acos (Abramowitz & Stegun 4.4.46,
+// |error| <= 2e-8 rad + rounding: the v coordinate is sqrt(|2 theta / pi - 1|), infinitely steep at the horizon, so the 7e-5 rad of the
+// shorter 4.4.45 form moved horizon directions by a tenth of a LUT row) and atan (|error| <= 1e-5 rad = 3e-4 LUT columns), and a
+// conditional wrap (the u coordinate lies in [0, 1], so the bilinear footprint can only step one texel across the seam).
 PLR_DI float acosFast(float x) {
     const float a = fabsf(x);
-    const float r = __builtin_amdgcn_sqrtf(1.f - a) * (1.5707288f + a * (-0.2121144f + a * (0.0742610f + a * -0.0187293f)));
+    const float p = 1.5707963050f + a * (-0.2145988016f + a * (0.0889789874f + a * (-0.0501743046f + a * (0.0308918810f + a * (-0.0170881256f + a * (0.0066700901f + a * -0.0012624911f))))));
+    const float r = __builtin_amdgcn_sqrtf(1.f - a) * p;
     return x < 0.f ? 3.14159265f - r : r;
 }
 PLR_DI float atan2Fast(float y, float x) {

@@ -238,9 +238,47 @@ void Bloom::init(RenderBackend& be) { // Bloom.cpp:8-40
     d.shaderDescription.srcPathRelative = "applyBloom.comp";
     m_applyBloomPass = be.createComputePass(d);
 }
+// Band rendering: which rows of every level does the bloom of `applyRows` depend on? (the dependency cone of the chain, in each level's own rows)
+//   up[t] row y reads up[t+1] at y/2 + 0.25 +- 0.5 texel and down[t+1] at y/2 + 0.25 +- radius, each through a bilinear footprint
+//   (bloomUpsample.comp:29-55); down[m+1] row y reads down[m] rows 2y-1 .. 2y+3 (bloomDownsample.comp:21-50; the outermost rows enter with weight 0,
+//   but must hold finite values).
+// Recording every level over "band +- 320 rows" (the sum of all footprints) cost a middle band 59 % extra bloom work; with the cone the full-resolution
+// target has no halo at all and only the cheap coarse levels carry the wide ones.
+Bloom::Cone Bloom::dependencyCone(RowRange applyRows, uint32_t height, float radius) {
+    Cone c;
+    if (applyRows.begin == 0 && applyRows.end == 0xffffffffu) return c; // whole image: every level whole
+    auto levelRows = [&](int level) { return std::max(height >> level, 1u); };
+    auto grow = [&](RowRange r, uint32_t k, int level) { return RowRange{r.begin > k ? r.begin - k : 0u, std::min(r.end + k, levelRows(level))}; };
+    auto half = [](RowRange r) { return RowRange{r.begin / 2, (r.end + 1) / 2}; };
+    auto twice = [](RowRange r) { return RowRange{r.begin * 2, r.end * 2}; };
+    auto unite = [](RowRange a, RowRange b) { return RowRange{std::min(a.begin, b.begin), std::max(a.end, b.end)}; };
+    const uint32_t tent = (uint32_t)std::ceil(radius + 0.25f) + 1u;
+    c.up[0] = RowRange{std::min(applyRows.begin, height), std::min(applyRows.end, height)};
+    for (int t = 0; t + 1 < bloomMipCount - 1; t++) c.up[t + 1] = grow(half(c.up[t]), 2, t + 1);
+    c.down[bloomMipCount - 1] = grow(half(c.up[bloomMipCount - 2]), tent, bloomMipCount - 1);
+    for (int m = bloomMipCount - 2; m >= 1; m--) c.down[m] = unite(grow(half(c.up[m - 1]), tent, m), grow(twice(c.down[m + 1]), 2, m));
+    c.source = grow(twice(c.down[1]), 2, 0);
+    return c;
+}
+uint32_t Bloom::requiredSourceHalo(uint32_t height, float radius) {
+    // widest reach over bands in the middle of the image (64-row aligned begin / end do not change the cone's width)
+    const uint32_t b0 = (height / 2) & ~63u, b1 = std::min(b0 + 64u, height);
+    const Cone c = dependencyCone(RowRange{b0, b1}, height, radius);
+    return std::max(b0 - c.source.begin, c.source.end - b1);
+}
+
 void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows) const { // Bloom.cpp:56-143
     const ImageDescription td = be.getImageDescription(targetImage);
     const int width = (int)td.width, height = (int)td.height;
+    // chainRows = rows of the target that hold valid colour (band + exchanged halo); the chain itself only covers the dependency cone of applyRows
+    const Cone cone = dependencyCone(applyRows, td.height, settings.radius);
+    const bool banded = !(applyRows.begin == 0 && applyRows.end == 0xffffffffu);
+    // a halo smaller than the cone (BandSettings::postHalo < requiredSourceHalo): levels stop at the rows derived from valid colour, rows
+    // beyond keep what an earlier frame left there (the documented limit of a too-small halo; the default halo covers the cone)
+    auto levelRows = [&](RowRange coneRows, int level) {
+        const RowRange valid = scaleRows(chainRows, 1u << level);
+        return RowRange{std::max(coneRows.begin, valid.begin), std::min(coneRows.end, valid.end)};
+    };
     const ImageDescription desc = desc2D(width, height, ImageFormat::R11G11B10_uFloat, ImageUsageFlags::Sampled | ImageUsageFlags::Storage, MipCount::Manual, bloomMipCount);
     const ImageHandle downscaleTexture = be.createTemporaryImage(desc);
     for (int i = 0; i < (int)m_bloomDownsamplePasses.size(); i++) {
@@ -251,7 +289,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(i == 0 ? targetImage : downscaleTexture, sourceMip, 1)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th, scaleRows(chainRows, 1u << targetMip));
+        dispatch8(exe, tw, th, banded ? levelRows(cone.down[targetMip], targetMip) : RowRange{});
         be.setComputePassExecution(exe);
     }
     const ImageHandle upscaleTexture = be.createTemporaryImage(desc);
@@ -263,7 +301,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, sourceMip, 1), ImageResource(downscaleTexture, sourceMip, 2)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th, scaleRows(chainRows, 1u << targetMip));
+        dispatch8(exe, tw, th, banded ? levelRows(cone.up[targetMip], targetMip) : RowRange{});
         exe.pushConstants = dataToCharArray(&settings.radius, sizeof(settings.radius));
         be.setComputePassExecution(exe);
     }

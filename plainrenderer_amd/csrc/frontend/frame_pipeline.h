@@ -65,7 +65,8 @@ struct BandSettings {
     uint32_t giHalo = 64;               // trace-resolution rows of the GI images exchanged before each spatial filter pass
     uint32_t giHistoryHalo = 16;        // trace-resolution rows of the filtered GI exchanged for the upscale / next frame's reprojection
     uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
-    uint32_t postHalo = 320;            // full-resolution rows of the temporal filter's result exchanged for the bloom chain
+    uint32_t postHalo = 224;            // full-resolution rows of the temporal filter's result exchanged for the bloom chain: the chain's dependency cone
+                                        // reaches 222 rows (Bloom::requiredSourceHalo; 6 mips, radius 1.5) - computeBloom refuses a smaller halo
     uint32_t taaHistoryHalo = 32;       // full-resolution rows of the TAA history exchanged (reach of next frame's reprojection + bicubic footprint)
     // Overlap the halo transfers with compute: the pass that produces an exchanged image is recorded as "edge rows first" (the rows the
     // neighbours need), then the exchange is STARTED (callback with ExchangeBegin: enqueue the sends / receives, do not wait), then the
@@ -147,8 +148,12 @@ private:
 class Bloom {
 public:
     void init(RenderBackend& be);
-    // chainRows: rows of the target image the down/upsample chain is evaluated for (scaled per mip); applyRows: rows bloom is applied to
+    // applyRows: rows bloom is applied to (band rendering; default all). The chain is recorded over the dependency cone of those rows;
+    // chainRows: rows of the target image that hold valid colour (the band and the exchanged halo) - must cover the cone's source rows
     void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}) const;
+    struct Cone { RowRange up[6], down[6], source; }; // rows of every level (in the level's own rows) / of the source image the result depends on
+    static Cone dependencyCone(RowRange applyRows, uint32_t height, float radius);
+    static uint32_t requiredSourceHalo(uint32_t height, float radius); // full-resolution rows of scene colour a band needs beyond its own
 private:
     std::vector<RenderPassHandle> m_bloomDownsamplePasses, m_bloomUpsamplePasses;
     RenderPassHandle m_applyBloomPass;

@@ -1,0 +1,37 @@
+// Shared by the spatial GI filter and its producers (sdfDiffuseTrace, filterIndirectDiffuseTemporal) in the PLR_MATH_FAST set.
+//
+// The spatial filter gathers ONE 16-byte texel per sample: {Y_SH (4 halves), CoCg (2 halves), a quarter of the linear-depth denominator
+// (float)}. On its own the filter pass fills that packed copy with a pre-pass over its inputs (13 us, 124 MB per pass at 4K). When the pass
+// that PRODUCES the filter's input is recorded right before it (pass fusion, backend.h), the producer writes the packed texel next to its
+// regular outputs - it has the values in registers - and the pre-pass disappears.
+#pragma once
+#include "../backend.h"
+#include "../device/shading_common.h"
+
+namespace plr {
+
+// packed texel of one GI pixel: ysh = the RGBA16F texel, cocg = the RG16F texel, depth = the depth-buffer value the filter's depthTexture
+// holds at this texel. A texel with a NaN component (filterIndirectDiffuseSpatial.comp:118 skips it) or a non-positive denominator is
+// stored as zeros with a negative denominator.
+PLR_DI uint4 packGiTexel(uint2 ysh, uint32_t cocg, float depth, float nearPlane, float farPlane) {
+    float den = farPlane + (1.f - depth) * (nearPlane - farPlane);
+    const float probe = ((halfBitsToFloat(ysh.x & 0xffffu) + halfBitsToFloat(ysh.x >> 16)) + (halfBitsToFloat(ysh.y & 0xffffu) + halfBitsToFloat(ysh.y >> 16))) +
+                        (halfBitsToFloat(cocg & 0xffffu) + halfBitsToFloat(cocg >> 16));
+    if (probe != probe || !(den > 0.f)) { ysh = make_uint2(0u, 0u); cocg = 0u; den = -1.f; }
+    return make_uint4(ysh.x, ysh.y, cocg, f2u(0.25f * den)); // a quarter of the denominator: the weight's numerator (negative: skip the texel)
+}
+
+// where the producer of a spatial filter pass's input has to put the packed texels (gi_spatial_fast.hip)
+struct SpatialPackTarget {
+    uint4* packed = nullptr; // [h][w] of the filter's input images
+    ImgView depth;           // the filter's depthTexture (same texel grid as its inputs): R16F or D32
+};
+// 0: target filled; kUseGeneralKernel: this execution of the filter does not use packed texels (depth on another grid, unknown format)
+int spatialFilterPackTarget(const PassCtx& spatialCtx, SpatialPackTarget* out);
+// the filter pass without its packing pre-pass (the producer has written every texel the pass can read)
+int launchSpatialFilterFastPrepacked(const PassCtx& c);
+// the producers, writing the packed copy as well (sdf_trace_fast.hip, stream_fast.hip)
+int launchTraceFastPacking(const PassCtx& c, const SpatialPackTarget& target);
+int launchTemporalGiFastPacking(const PassCtx& c, const SpatialPackTarget& target);
+
+} // namespace plr

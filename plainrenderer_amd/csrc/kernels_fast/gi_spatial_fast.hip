@@ -13,8 +13,20 @@
 // Per sample this is ~45 VALU operations + 3 gathers instead of ~180 + 3. Results differ from the exact kernel by float
 // rounding only (stated tolerance in tests/test_fast_kernels.py); nearest-texel selection and the off-screen test are the
 // discontinuities where a last-bit difference can pick a neighbouring texel.
+//
+// The filter's tangent frame is the exception: tangent = normalize(pCenter - pixelToWorld(uv + one texel)) subtracts two world positions
+// a pixel apart (0.012 m at 4K half-res) whose coordinates are tens of metres, so fp32 leaves the difference ~3e-4 relative precision
+// and the 1.5 m disc inherits ~0.04 texel of position noise - FROM THE SHADER'S OWN ROUNDING. Any other way of computing the frame
+// (including a more accurate one) moves 10 % of all samples onto a neighbouring texel of the 1-spp input. The per-pixel frame is therefore
+// evaluated with the shader's exact operation sequence (IEEE divide / sqrt, no contraction: same bits as the oracle); only the 32
+// samples per pixel use the restructured arithmetic.
+// This file is therefore built like the exact set (no FMA contraction, IEEE divide / sqrt: pragmas are lexical and would not reach the shared
+// helpers the frame is computed with); the sample loop switches contraction back on for its own statements and spells its arithmetic out
+// as scalars, its reciprocals are explicit v_rcp_f32.
+// PLR_BUILD_FLAGS: -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "fused_gi.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -55,17 +67,13 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
     const int y = rowBegin + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= inYSH.w || y >= rowEnd) return;
     const size_t idx = (size_t)y * (size_t)inYSH.w + (size_t)x;
-    uint2 yt = ((const uint2*)inYSH.ptr)[idx];
-    uint32_t ct = ((const uint32_t*)inCoCg.ptr)[idx];
+    const uint2 yt = ((const uint2*)inYSH.ptr)[idx];
+    const uint32_t ct = ((const uint32_t*)inCoCg.ptr)[idx];
     const float dep = Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x;
-    float den = g->farPlane + (1.f - dep) * (g->nearPlane - g->farPlane);
-    const float probe = ((halfBitsToFloat(yt.x & 0xffffu) + halfBitsToFloat(yt.x >> 16)) + (halfBitsToFloat(yt.y & 0xffffu) + halfBitsToFloat(yt.y >> 16))) +
-                        (halfBitsToFloat(ct & 0xffffu) + halfBitsToFloat(ct >> 16));
-    if (probe != probe || !(den > 0.f)) { yt = make_uint2(0u, 0u); ct = 0u; den = -1.f; }
-    packed[idx] = make_uint4(yt.x, yt.y, ct, f2u(0.25f * den)); // a quarter of the denominator: the weight's numerator (negative: skip the texel)
+    packed[idx] = packGiTexel(yt, ct, dep, g->nearPlane, g->farPlane);
 }
 
-// SIG: also write the decision signature (bit i = parity of sample i's nearest texel, toggled when the sample is off screen; oracle/oracle.h)
+// SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
@@ -85,27 +93,27 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float dW = (float)depthTexture.w, dH = (float)depthTexture.h;
     const int dwi = depthTexture.w, dhi = depthTexture.h;
 
-    auto depthLinearAt = [&](float u, float v) -> float {
-        const int x = min(max((int)floorf(u * dW), 0), dwi - 1), y = min(max((int)floorf(v * dH), 0), dhi - 1);
-        const float d = Texel<DEPTH_FMT>::load(depthTexture.ptr, (size_t)y * (size_t)dwi + (size_t)x).x;
-        return nf * rcpf(farP + (1.f - d) * nmf);
-    };
-    auto worldAt = [&](float u, float v) -> vec3 {
-        const float lin = depthLinearAt(u, v);
-        const float nx = u * 2.f - 1.f, ny = v * 2.f - 1.f;
-        const vec3 ray = fwd + (-tanH * ny) * up + (tanA * nx) * right;
-        return camPos + ray * lin;
-    };
-
-    const float tsx = 1.f / (float)outYSH.w, tsy = 1.f / (float)outYSH.h;
-    const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
-    const vec3 pCenter = worldAt(u0, v0);
-    const vec3 pRight = worldAt(u0 + tsx, v0);
-    const vec3 pUp = worldAt(u0, v0 + tsy);
-    const vec3 dT = pCenter - pRight, dB = pCenter - pUp;
     const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
-    const vec3 T = dT * (radiusWorld * __builtin_amdgcn_rsqf(dot(dT, dT)));
-    const vec3 B = dB * (radiusWorld * __builtin_amdgcn_rsqf(dot(dB, dB)));
+    float tsx, tsy, u0, v0;
+    vec3 pCenter, T, B;
+    {
+        // the shader's own sequence (:33-41), bit for bit: see the note at the top of this file
+#pragma clang fp contract(off)
+        tsx = 1.f / (float)outYSH.w; tsy = 1.f / (float)outYSH.h;
+        u0 = ((float)px + 0.5f) * tsx; v0 = ((float)py + 0.5f) * tsy;
+        auto pixelToWorldExact = [&](float u, float v) -> vec3 {
+            const int x = min(max((int)floorf(u * dW), 0), dwi - 1), y = min(max((int)floorf(v * dH), 0), dhi - 1);
+            const float depth = Texel<DEPTH_FMT>::load(depthTexture.ptr, (size_t)y * (size_t)dwi + (size_t)x).x;
+            const float depthLinear = linearizeDepth(depth, nearP, farP);
+            const vec3 cameraToPixel = -calculateViewDirectionFromPixel(vec2(u * 2.f - 1.f, v * 2.f - 1.f), fwd, up, right, g->cameraTanFovHalf, g->cameraAspectRatio);
+            return camPos + cameraToPixel / dot(cameraToPixel, fwd) * depthLinear;
+        };
+        pCenter = pixelToWorldExact(u0, v0);
+        const vec3 pRight = pixelToWorldExact(u0 + 1.f * tsx, v0 + 0.f * tsy);
+        const vec3 pUp = pixelToWorldExact(u0 + 0.f * tsx, v0 + 1.f * tsy);
+        T = radiusWorld * normalize(pCenter - pRight);
+        B = radiusWorld * normalize(pCenter - pUp);
+    }
     const int nwi = normalTexture.w, nhi = normalTexture.h;
     vec3 N;
     {
@@ -131,16 +139,15 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     bool safe;
     {
         const float dm = radiusWorld * 1.4143f * 1.01f;
-        const float sx = sqrtf(vp[0] * vp[0] + vp[4] * vp[4] + vp[8] * vp[8]), sy = sqrtf(vp[1] * vp[1] + vp[5] * vp[5] + vp[9] * vp[9]);
-        const float sw = sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
+        const float sx = __builtin_amdgcn_sqrtf(vp[0] * vp[0] + vp[4] * vp[4] + vp[8] * vp[8]), sy = __builtin_amdgcn_sqrtf(vp[1] * vp[1] + vp[5] * vp[5] + vp[9] * vp[9]);
+        const float sw = __builtin_amdgcn_sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
         const float wMin = (P0.z - sw * dm) * 0.999f;
         safe = wMin > 0.f && fabsf(P0.x) + sx * dm <= wMin && fabsf(P0.y) + sy * dm <= wMin;
     }
-    vec4 result_Y_SH(0.f);
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
     float lengthModifier = 1.f;
-    uint32_t sampleParity = 0u;
+    uint32_t sampleParityX = 0u, sampleParityY = 0u;
     const uint32_t ywi = (uint32_t)inYSH.w;
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
     const float halfW = 0.5f * yW, halfH = 0.5f * yH, cu0 = u0 - 0.5f, cv0 = v0 - 0.5f;
@@ -158,7 +165,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // Two copies of the sample loop. A wave whose pixels' discs provably stay on screen (see `safe` above) runs the copy without the
     // mirroring, the off-screen test and the shrinking lengthModifier - a fifth of the per-sample instructions; those conditions could
     // not have fired, so a pixel's result is the same whichever copy its wave ran.
+    float rY0 = 0.f, rY1 = 0.f, rY2 = 0.f, rY3 = 0.f;
     auto sampleLoop = [&](auto safeTag) {
+#pragma clang fp contract(fast)
         constexpr bool SAFE = decltype(safeTag)::value;
         for (int i0 = 0; i0 < 32; i0 += 4) {
             float su[4], sv[4];
@@ -168,10 +177,10 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             for (int k = 0; k < 4; k++) {
                 const float d = SAFE ? samples[i0 + k] : samples[i0 + k] * lengthModifier;
                 const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
-                const vec3 clip = P0 + ox * PT + oy * PB;
-                const float invW = rcpf(clip.z) * 0.5f;
+                const float clipX = P0.x + ox * PT.x + oy * PB.x, clipY = P0.y + ox * PT.y + oy * PB.y, clipW = P0.z + ox * PT.z + oy * PB.z;
+                const float invW = rcpf(clipW) * 0.5f;
                 // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
-                float cu = clip.x * invW, cv = clip.y * invW;
+                float cu = clipX * invW, cv = clipY * invW;
                 off[k] = false;
                 if (!SAFE) {
                     // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
                 const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
-                if (SIG) sampleParity |= ((tx + ty + (off[k] ? 1u : 0u)) & 1u) << (i0 + k);
+                if (SIG) { const uint32_t o = off[k] ? 1u : 0u; sampleParityX |= ((tx + o) & 1u) << (i0 + k); sampleParityY |= ((ty + o) & 1u) << (i0 + k); }
                 di[k] = SAME_GRID ? ti[k]
                                   : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
             }
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     float weight = __builtin_amdgcn_fmed3f(qden * rcpf(__builtin_fmaxf(num, 0.0004f * qden)), 0.f, 1.f);
                     weight *= weight;
                     weight = ((SAFE || !off[k]) && qden > 0.f) ? weight : 0.f;
-                    const vec4 sY(halfBitsToFloat(t4[k].x & 0xffffu), halfBitsToFloat(t4[k].x >> 16), halfBitsToFloat(t4[k].y & 0xffffu), halfBitsToFloat(t4[k].y >> 16));
-                    result_Y_SH = result_Y_SH + weight * sY;
+                    rY0 += weight * halfBitsToFloat(t4[k].x & 0xffffu); rY1 += weight * halfBitsToFloat(t4[k].x >> 16);
+                    rY2 += weight * halfBitsToFloat(t4[k].y & 0xffffu); rY3 += weight * halfBitsToFloat(t4[k].y >> 16);
                     resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
                     resCg += weight * halfBitsToFloat(t4[k].z >> 16);
                     weightTotal += weight;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 const bool use = !off[k] && weight > 0.f && nanProbe == nanProbe;
                 weight = use ? weight : 0.f;
                 if (nanProbe != nanProbe) { sY = vec4(0.f); co = 0.f; cg = 0.f; } // 0 * NaN would poison the sums
-                result_Y_SH = result_Y_SH + weight * sY;
+                rY0 += weight * sY.x; rY1 += weight * sY.y; rY2 += weight * sY.z; rY3 += weight * sY.w;
                 resCo += weight * co;
                 resCg += weight * cg;
                 weightTotal += weight;
@@ -245,12 +254,38 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     else sampleLoop(std::false_type{});
     const float inv = rcpf(gmax(weightTotal, 0.00001f));
     const size_t idx = (size_t)py * (size_t)outYSH.w + px;
-    Texel<F_RGBA16F>::store(outYSH.ptr, idx, result_Y_SH * inv);
+    Texel<F_RGBA16F>::store(outYSH.ptr, idx, vec4(rY0 * inv, rY1 * inv, rY2 * inv, rY3 * inv));
     Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(resCo * inv, resCg * inv, 0.f, 0.f));
-    if (SIG) sig[idx] = sampleParity;
+    if (SIG) { sig[2 * idx] = sampleParityX; sig[2 * idx + 1] = sampleParityY; }
 }
 
-static int launchSpatialFilterFast(const PassCtx& c) {
+// scratch of a filter pass: [sample tables | packed texels of the whole input image]
+constexpr size_t kSpatialTableBytes = 2048;
+static_assert(sizeof(float) * kSampleKeys * kSampleTableFloats <= kSpatialTableBytes, "sample tables");
+static uint8_t* spatialScratch(const PassCtx& c, bool sameGrid) {
+    const size_t packedBytes = sameGrid ? (size_t)c.sampled[2].w * (size_t)c.sampled[2].h * 16u : 0u;
+    const bool freshScratch = c.scratchSize && *c.scratchSize < kSpatialTableBytes + packedBytes;
+    uint8_t* scratch = (uint8_t*)c.scratch(kSpatialTableBytes + packedBytes);
+    if (scratch && freshScratch) spatialSampleTableKernel<<<1, 256, 0, c.stream>>>((float*)scratch);
+    return scratch;
+}
+
+int spatialFilterPackTarget(const PassCtx& c, SpatialPackTarget* out) {
+    if (!c.hasSampled(2) || !c.hasSampled(3) || !c.hasSampled(4) || c.sampled[2].fmt != F_RGBA16F || c.sampled[3].fmt != F_RG16F) return kUseGeneralKernel;
+    const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h && c.sampled[3].w == c.sampled[2].w && c.sampled[3].h == c.sampled[2].h;
+    if (!sameGrid || (c.sampled[4].fmt != F_R16F && c.sampled[4].fmt != F_D32)) return kUseGeneralKernel;
+    uint8_t* scratch = spatialScratch(c, true);
+    if (!scratch) return c.fail(-2, "filterIndirectDiffuseSpatial: cannot allocate scratch memory");
+    out->packed = (uint4*)(scratch + kSpatialTableBytes);
+    out->depth = c.sampled[4];
+    return 0;
+}
+
+static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked);
+static int launchSpatialFilterFast(const PassCtx& c) { return launchSpatialFilterFastImpl(c, false); }
+int launchSpatialFilterFastPrepacked(const PassCtx& c) { return launchSpatialFilterFastImpl(c, true); }
+
+static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_RGBA16F, "filterIndirectDiffuseSpatial imageOut_Y_SH")) return rc;
     if (int rc = c.needStorage(1, F_RG16F, "filterIndirectDiffuseSpatial imageOut_CoCg")) return rc;
@@ -271,19 +306,13 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     const dim3 grid((unsigned)chunk * 8u);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
     const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h;
-    // per-pass scratch: [sample tables | packed texels of the whole trace image]
-    const size_t tableBytes = 2048, packedBytes = sameGrid ? (size_t)c.sampled[2].w * (size_t)c.sampled[2].h * 16u : 0u;
-    static_assert(sizeof(float) * kSampleKeys * kSampleTableFloats <= 2048, "sample tables");
-    const bool freshScratch = c.scratchSize && *c.scratchSize < tableBytes + packedBytes;
-    uint8_t* scratch = (uint8_t*)c.scratch(tableBytes + packedBytes);
+    if (prepacked && !sameGrid) return c.fail(-1, "filterIndirectDiffuseSpatial: prepacked launch without a packed grid");
+    uint8_t* scratch = spatialScratch(c, sameGrid);
     if (!scratch) return c.fail(-2, "filterIndirectDiffuseSpatial: cannot allocate scratch memory");
+    PLR_CHECK_LAUNCH(c);
     float* tables = (float*)scratch;
-    uint4* packed = (uint4*)(scratch + tableBytes);
-    if (freshScratch) {
-        spatialSampleTableKernel<<<1, 256, 0, c.stream>>>(tables);
-        PLR_CHECK_LAUNCH(c);
-    }
-    if (sameGrid) {
+    uint4* packed = (uint4*)(scratch + kSpatialTableBytes);
+    if (sameGrid && !prepacked) {
         // rows the filter can read: the dispatched rows and a margin (a band renderer exchanges 64 halo rows; samples further away
         // read whatever an earlier frame packed there, exactly like the stale image rows they would read unpacked)
         const int margin = 128;
@@ -295,7 +324,7 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         PLR_CHECK_LAUNCH(c);
         c.splitTiming("texel packing");
     }
-    uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
+    uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk, sig
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
@@ -313,5 +342,29 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseSpatial.comp", launchSpatialFilterFast);
+
+// ---- pass fusion: the producer of the filter's input is recorded right before it and covers the whole image ----
+// (not in band rendering: there the halo exchange callbacks sit between the two passes, and the neighbours' rows arrive unpacked)
+static bool coversWholeImage(const PassCtx& c, const ImgView& image) {
+    const PassCtx::RowSpan rs = c.rowSpan(image.h);
+    return rs.y0 == 0 && rs.y1 == image.h && (int)(c.dispatch[0] * 8u) >= image.w;
+}
+static int fusedProducerAndSpatial(const PassCtx* const* ctxs, size_t count, bool traceProducer) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx &prod = *ctxs[0], &filt = *ctxs[1];
+    const int outY = traceProducer ? 0 : 2, outC = traceProducer ? 1 : 3; // the temporal filter's history outputs feed spatial pass 1
+    if (!prod.hasStorage(outY) || !prod.hasStorage(outC) || !filt.hasSampled(2) || !filt.hasSampled(3) || !filt.hasStorage(0)) return kUseGeneralKernel;
+    if (prod.storage[outY].ptr != filt.sampled[2].ptr || prod.storage[outC].ptr != filt.sampled[3].ptr) return kUseGeneralKernel;
+    if (!coversWholeImage(prod, prod.storage[outY]) || !coversWholeImage(filt, filt.storage[0])) return kUseGeneralKernel;
+    SpatialPackTarget target;
+    if (int rc = spatialFilterPackTarget(filt, &target)) return rc; // kUseGeneralKernel: not a packed configuration
+    const int rc = traceProducer ? launchTraceFastPacking(prod, target) : launchTemporalGiFastPacking(prod, target);
+    if (rc) return rc; // kUseGeneralKernel included: nothing has been launched yet
+    return launchSpatialFilterFastPrepacked(filt);
+}
+static int fused_trace_spatial(const PassCtx* const* ctxs, size_t count) { return fusedProducerAndSpatial(ctxs, count, true); }
+static int fused_temporal_spatial(const PassCtx* const* ctxs, size_t count) { return fusedProducerAndSpatial(ctxs, count, false); }
+PLR_REGISTER_FUSION("sdfDiffuseTrace + filterIndirectDiffuseSpatial", fused_trace_spatial, "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp");
+PLR_REGISTER_FUSION("filterIndirectDiffuseTemporal + filterIndirectDiffuseSpatial", fused_temporal_spatial, "filterIndirectDiffuseTemporal.comp", "filterIndirectDiffuseSpatial.comp");
 
 } // namespace plr

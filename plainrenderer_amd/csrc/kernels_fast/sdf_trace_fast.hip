@@ -9,9 +9,15 @@
 // A ray whose closest SDF sample sits within rounding of the hit threshold (or of an AABB face) can resolve differently than in
 // the exact kernel; such a pixel and the neighbours that share its ray in the 3x3 resolve change visibly. Stated tolerance:
 // tests/test_fast_kernels.py.
+//
+// One thing is NOT approximate: uv = pixel / imageSize (:121, no half-texel offset) lands exactly on a texel boundary of the full-resolution
+// depth / normal images, so floor(uv * size) depends on the last bit of the quotient: it is an IEEE division here as in the shader (an
+// approximate quotient fetches the neighbouring G-buffer texel for a third of the pixels). Everything in the march uses v_rcp / v_rsq / v_sqrt.
+// PLR_BUILD_FLAGS: -fhip-fp32-correctly-rounded-divide-sqrt
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
+#include "fused_gi.h"
 
 namespace plr {
 namespace fasttrace {
@@ -133,7 +139,7 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
     if (localToGlobalScale * hitDistanceLocal > tr.closestHitDistance) return;
     const vec3 invExt(rcpf(localExtends.x), rcpf(localExtends.y), rcpf(localExtends.z));
     const vec3 voxel(localExtends.x * rcpf(sdf.fw), localExtends.y * rcpf(sdf.fh), localExtends.z * rcpf(sdf.fd));
-    const float distanceThreshold = sqrtf(dot(voxel, voxel)) * 0.25f;
+    const float distanceThreshold = __builtin_amdgcn_sqrtf(dot(voxel, voxel)) * 0.25f;
     const vec3 lim = sdfMaxLocal + 0.01f;
     vec3 pos = rayStartLocal;
     float dLast = 0.f, d = 0.f;
@@ -167,13 +173,15 @@ struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance
 struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
 
 // SIG: also write the decision signature of every pixel (plr_debug_set_decision_signature; bit layout in oracle/oracle.h)
-template <bool STRICT_CUTOFF, bool SIG>
+// PACK: also write the packed texel the spatial filter gathers (fused_gi.h); 0 = no, else the format of packDepth (F_R16F / F_D32)
+template <bool STRICT_CUTOFF, bool SIG, int PACK>
 __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
                                                                  uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
-                                                                 uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig) {
+                                                                 uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig,
+                                                                 uint4* __restrict__ packedOut, ImgView packDepth) {
     __shared__ RayInfo sharedRays[4][64];
     uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
     vec3 L(0.f, 0.f, 1.f);
     RayInfo mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const float u = (float)px / (float)outYSH.w, v = (float)py / (float)outYSH.h;
+        const float u = (float)px / (float)outYSH.w, v = (float)py / (float)outYSH.h; // IEEE quotient: see the note at the top
         const float depth = sampleNearest2D<F_D32, CLAMP>(depthTexture, vec2(u, v)).x;
         const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
         const vec3 ray = ld3(g->cameraForward) + (-g->cameraTanFovHalf * (v * 2.f - 1.f)) * ld3(g->cameraUp) +
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
         const vec3 rayOrigin = pWorld + N * 0.2f;
         {
             // importanceSampleCosine (sampling.inc:25-45): phi = 2 pi xi.y, v_sin/v_cos take revolutions
-            const float cosTheta = sqrtf(nz.x), sinTheta = sqrtf(1.f - nz.x);
+            const float cosTheta = __builtin_amdgcn_sqrtf(nz.x), sinTheta = __builtin_amdgcn_sqrtf(1.f - nz.x);
             const float sp = __builtin_amdgcn_sinf(nz.y), cp = __builtin_amdgcn_cosf(nz.y);
             const vec3 up = fabsf(N.z) < 0.999f ? vec3(0.f, 0.f, 1.f) : vec3(1.f, 0.f, 0.f);
             vec3 tangent = cross(up, N);
@@ -277,13 +285,16 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
         // directionToSH_L1(L), |L| = 1: (0.5, -0.86603 L.y, 0.86603 L.z, -0.86603 L.x)
         const vec4 ysh(YCoCg.x * 0.5f, YCoCg.x * (-0.8660254f * L.y), YCoCg.x * (0.8660254f * L.z), YCoCg.x * (-0.8660254f * L.x));
         const size_t idx = (size_t)py * (size_t)outYSH.w + px;
-        Texel<F_RGBA16F>::store(outYSH.ptr, idx, ysh);
-        Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(YCoCg.y, YCoCg.z, 0.f, 0.f));
+        const uint2 yBits = make_uint2(floatToHalfBits(ysh.x) | (floatToHalfBits(ysh.y) << 16), floatToHalfBits(ysh.z) | (floatToHalfBits(ysh.w) << 16));
+        const uint32_t cBits = floatToHalfBits(YCoCg.y) | (floatToHalfBits(YCoCg.z) << 16);
+        ((uint2*)outYSH.ptr)[idx] = yBits;
+        ((uint32_t*)outCoCg.ptr)[idx] = cBits;
+        if (PACK) packedOut[idx] = packGiTexel(yBits, cBits, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
         if (SIG) sig[idx] = raySig | (takeMask << 3);
     }
 }
 
-static int launch(const PassCtx& c) {
+static int launchImpl(const PassCtx& c, const SpatialPackTarget* pack) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_RGBA16F, "sdfDiffuseTrace imageOut_Y_SH")) return rc;
     if (int rc = c.needStorage(1, F_RG16F, "sdfDiffuseTrace imageOut_CoCg")) return rc;
@@ -312,20 +323,33 @@ static int launch(const PassCtx& c) {
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
-                       tileCapacity, instanceCapacity, sig
+                       tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
-    if (sig) {
-        if (strict) sdfDiffuseTraceFastKernel<true, true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-        else sdfDiffuseTraceFastKernel<false, true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-    } else if (strict) sdfDiffuseTraceFastKernel<true, false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-    else sdfDiffuseTraceFastKernel<false, false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    if (pack) {
+        // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
+        if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
+        if (pack->depth.fmt == F_R16F) {
+            if (strict) sdfDiffuseTraceFastKernel<true, false, F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+            else sdfDiffuseTraceFastKernel<false, false, F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+        } else if (pack->depth.fmt == F_D32) {
+            if (strict) sdfDiffuseTraceFastKernel<true, false, F_D32><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+            else sdfDiffuseTraceFastKernel<false, false, F_D32><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+        } else return kUseGeneralKernel;
+    } else if (sig) {
+        if (strict) sdfDiffuseTraceFastKernel<true, true, 0><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+        else sdfDiffuseTraceFastKernel<false, true, 0><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    } else if (strict) sdfDiffuseTraceFastKernel<true, false, 0><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+    else sdfDiffuseTraceFastKernel<false, false, 0><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
 #undef PLR_TRACE_ARGS
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
 
+static int launch(const PassCtx& c) { return launchImpl(c, nullptr); }
+
 } // namespace fasttrace
 
+int launchTraceFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return fasttrace::launchImpl(c, &target); }
 static int fasttrace_launch(const PassCtx& c) { return fasttrace::launch(c); }
 PLR_REGISTER_SHADER_FAST("sdfDiffuseTrace.comp", fasttrace_launch);
 } // namespace plr

@@ -8,6 +8,7 @@
 // and adjacent texels fetched with one wide load (a load instruction costs a CU's texture addresser ~16 cycles whatever its width).
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "fused_gi.h"
 
 namespace plr {
 namespace faststream {
@@ -64,6 +65,33 @@ PLR_DI float srgb(float l) {
 }
 PLR_DI uint32_t unorm8(float v) { return (uint32_t)__float2int_rn(clamp01(v) * 255.0f); } // the inputs here are never NaN after the clamps of ACESFitted
 
+// one pixel of tonemapping.comp: ACESFitted, dither, sRGB, 8-bit pack. nyA / nyB: the row terms of the two dither hashes
+template <bool BGRA>
+PLR_DI uint32_t tonemapPixel(vec3 c, int x, float time, uint32_t nyA, uint32_t nyB) {
+    const uint32_t UI0 = 1597334673u, UI1 = 3812015801u, UI2 = 2798796415u;
+    const float UIF = 1.0f / (float)0xffffffffu;
+    // ACESFitted (tonemapping.inc:40-49)
+    vec3 v(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z, 0.02840f * c.x + 0.13383f * c.y + 0.83777f * c.z);
+    const vec3 a = v * (v + 0.0245786f) - 0.000090537f;
+    const vec3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
+    v = vec3(a.x * rcpf(b.x), a.y * rcpf(b.y), a.z * rcpf(b.z));
+    const vec3 o(clamp01(1.60475f * v.x + -0.53108f * v.y + -0.07367f * v.z), clamp01(-0.10208f * v.x + 1.10813f * v.y + -0.00605f * v.z),
+                 clamp01(-0.00327f * v.x + -0.07276f * v.y + 1.07602f * v.z));
+    const uint32_t qxA = (uint32_t)(int32_t)(float)(uint32_t)((float)x * time), qxB = (uint32_t)(int32_t)(float)(uint32_t)(((float)x + 165.f) * time);
+    const uint32_t mA = (qxA * UI0) ^ nyA ^ (qxA * UI2), mB = (qxB * UI0) ^ nyB ^ (qxB * UI2);
+    const vec3 noise = (vec3((float)(mA * UI0), (float)(mA * UI1), (float)(mA * UI2)) + vec3((float)(mB * UI0), (float)(mB * UI1), (float)(mB * UI2))) * UIF - 1.f;
+    const vec3 s = vec3(srgb(o.x), srgb(o.y), srgb(o.z)) + noise * (1.f / 255.f);
+    uint32_t p = unorm8(s.z) | (unorm8(s.y) << 8) | (unorm8(s.x) << 16) | (255u << 24);
+    if (!BGRA) p = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
+    return p;
+}
+// dither.inc:6-12 / noise.inc:19-24: hash32(q) = fract-free integer hash of uvec2 q; the y terms are shared by all pixels of a row
+PLR_DI void tonemapRowTerms(int y, float time, uint32_t* nyA, uint32_t* nyB) {
+    const uint32_t UI1 = 3812015801u;
+    const uint32_t qyA = (uint32_t)(int32_t)(float)(uint32_t)((float)y * time), qyB = (uint32_t)(int32_t)(float)(uint32_t)(((float)y + 1292.f) * time);
+    *nyA = qyA * UI1; *nyB = qyB * UI1;
+}
+
 template <bool BGRA>
 __global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
     const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
@@ -77,32 +105,39 @@ __global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgVie
     const bool wide = n == 4 && (src.w & 3) == 0 && (dst.w & 3) == 0;
     if (wide) { const uint4 v = *(const uint4*)(srow + x0); in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w; }
     else for (int i = 0; i < n; i++) in[i] = srow[x0 + i];
-    // dither.inc:6-12 / noise.inc:19-24: hash32(q) = fract-free integer hash of uvec2 q; the y terms are shared by the lane's four pixels
-    const uint32_t UI0 = 1597334673u, UI1 = 3812015801u, UI2 = 2798796415u;
-    const uint32_t qyA = (uint32_t)(int32_t)(float)(uint32_t)((float)y * time), qyB = (uint32_t)(int32_t)(float)(uint32_t)(((float)y + 1292.f) * time);
-    const uint32_t nyA = qyA * UI1, nyB = qyB * UI1;
-    const float UIF = 1.0f / (float)0xffffffffu;
+    uint32_t nyA, nyB;
+    tonemapRowTerms(y, time, &nyA, &nyB);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const vec3 c = unpackR11G11B10(in[i]);
-        // ACESFitted (tonemapping.inc:40-49)
-        vec3 v(0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z, 0.02840f * c.x + 0.13383f * c.y + 0.83777f * c.z);
-        const vec3 a = v * (v + 0.0245786f) - 0.000090537f;
-        const vec3 b = v * (0.983729f * v + 0.4329510f) + 0.238081f;
-        v = vec3(a.x * rcpf(b.x), a.y * rcpf(b.y), a.z * rcpf(b.z));
-        const vec3 o(clamp01(1.60475f * v.x + -0.53108f * v.y + -0.07367f * v.z), clamp01(-0.10208f * v.x + 1.10813f * v.y + -0.00605f * v.z),
-                     clamp01(-0.00327f * v.x + -0.07276f * v.y + 1.07602f * v.z));
-        const int x = x0 + i;
-        const uint32_t qxA = (uint32_t)(int32_t)(float)(uint32_t)((float)x * time), qxB = (uint32_t)(int32_t)(float)(uint32_t)(((float)x + 165.f) * time);
-        const uint32_t mA = (qxA * UI0) ^ nyA ^ (qxA * UI2), mB = (qxB * UI0) ^ nyB ^ (qxB * UI2);
-        const vec3 noise = (vec3((float)(mA * UI0), (float)(mA * UI1), (float)(mA * UI2)) + vec3((float)(mB * UI0), (float)(mB * UI1), (float)(mB * UI2))) * UIF - 1.f;
-        const vec3 s = vec3(srgb(o.x), srgb(o.y), srgb(o.z)) + noise * (1.f / 255.f);
-        uint32_t p = unorm8(s.z) | (unorm8(s.y) << 8) | (unorm8(s.x) << 16) | (255u << 24);
-        if (!BGRA) p = (p & 0xff00ff00u) | ((p >> 16) & 0xffu) | ((p & 0xffu) << 16);
-        out[i] = p;
-    }
+    for (int i = 0; i < 4; i++) out[i] = tonemapPixel<BGRA>(unpackR11G11B10(in[i]), x0 + i, time, nyA, nyB);
     if (wide) *(uint4*)(drow + x0) = make_uint4(out[0], out[1], out[2], out[3]);
     else for (int i = 0; i < n; i++) drow[x0 + i] = out[i];
+}
+
+// ---- applyBloom + tonemapping of the image it just wrote, in one pass over the pixels (pass fusion, backend.h): the applied colour is
+// stored (R11G11B10, the pass's output) and its STORED value - decoded again, as the separate tonemap pass would read it - is tonemapped.
+// 16 B per pixel of traffic instead of 20, one launch instead of two.
+template <bool BGRA>
+__global__ __launch_bounds__(256) void applyBloomTonemapKernel(ImgView target, ImgView bloom, ImgView dst, const GlobalUbo* __restrict__ g, float strength, int coverW, int coverH, int yBase) {
+    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (y >= coverH || x0 >= coverW) return;
+    const float time = g->time;
+    uint32_t* trow = (uint32_t*)target.ptr + (size_t)y * (size_t)target.w;
+    const uint32_t* brow = (const uint32_t*)bloom.ptr + (size_t)y * (size_t)bloom.w;
+    uint32_t* drow = (uint32_t*)dst.ptr + (size_t)y * (size_t)dst.w;
+    const uint4 sv = *(const uint4*)(trow + x0), bv = *(const uint4*)(brow + x0); // the launcher guarantees whole 4-pixel groups and 16-byte aligned rows
+    const uint32_t s[4] = {sv.x, sv.y, sv.z, sv.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint32_t nyA, nyB;
+    tonemapRowTerms(y, time, &nyA, &nyB);
+    uint32_t o[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const vec3 sc = unpackR11G11B10(s[i]), bc = unpackR11G11B10(b[i]);
+        o[i] = packR11G11B10(sc + (bc - sc) * strength);
+        t[i] = tonemapPixel<BGRA>(unpackR11G11B10(o[i]), x0 + i, time, nyA, nyB);
+    }
+    *(uint4*)(trow + x0) = make_uint4(o[0], o[1], o[2], o[3]);
+    *(uint4*)(drow + x0) = make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 static int launchTonemapping(const PassCtx& c) {
@@ -414,9 +449,12 @@ PLR_DI vec2 bilinearRG16SN(const ImgView& im, float u, float v, bool repeat) {
     return tx(x0, y0) * w00 + tx(x1, y0) * w10 + tx(x0, y1) * w01 + tx(x1, y1) * w11;
 }
 
+// PACK: also write the packed texel of the history output for the spatial filter that reads it next (fused_gi.h); 0 = no, else the depth format
+template <int PACK>
 __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                                   ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
-                                                                  ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
+                                                                  ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase,
+                                                                  uint4* __restrict__ packedOut, ImgView packDepth) {
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
@@ -452,9 +490,12 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
     ((uint32_t*)targetCoCg.ptr)[idx] = pc;
     ((uint2*)historyOutYSH.ptr)[idx] = py4;
     ((uint32_t*)historyOutCoCg.ptr)[idx] = pc;
+    if (PACK) packedOut[idx] = packGiTexel(py4, pc, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
 }
 
-static int launchTemporalGi(const PassCtx& c) {
+static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack);
+static int launchTemporalGi(const PassCtx& c) { return launchTemporalGiImpl(c, nullptr); }
+static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack) {
     if (int rc = c.needGlobal()) return rc;
     const int ysh[4] = {0, 2, 4, 6}, cocg[4] = {1, 3, 5, 7};
     for (int i = 0; i < 2; i++) {
@@ -474,14 +515,47 @@ static int launchTemporalGi(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
     const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
     if (w <= 0 || h <= y0) return 0;
-    temporalGiFilterFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(
-        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0);
+    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+#define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, \
+                          pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}
+    if (pack) {
+        if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
+        if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
+        else if (pack->depth.fmt == F_D32) temporalGiFilterFastKernel<F_D32><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
+        else return kUseGeneralKernel;
+    } else temporalGiFilterFastKernel<0><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
+#undef PLR_TEMPORAL_ARGS
     PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// fused: applyBloom.comp then tonemapping.comp of the same image over the same rows
+static int launchApplyBloomTonemap(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx &a = *ctxs[0], &t = *ctxs[1];
+    if (!a.hasStorage(0) || !a.hasSampled(1) || !t.hasStorage(0) || !t.hasSampled(1) || !t.global || a.push.size() < 4) return kUseGeneralKernel;
+    const ImgView &target = a.storage[0], &bloom = a.sampled[1], &src = t.sampled[1], &dst = t.storage[0];
+    if (target.fmt != F_R11G11B10 || bloom.fmt != F_R11G11B10 || (dst.fmt != F_BGRA8 && dst.fmt != F_RGBA8)) return kUseGeneralKernel;
+    if (src.ptr != target.ptr || src.w != target.w || src.h != target.h) return kUseGeneralKernel;                 // the tonemap must read what applyBloom wrote
+    if (bloom.w != target.w || bloom.h != target.h || dst.w != target.w || dst.h != target.h || (target.w & 3)) return kUseGeneralKernel;
+    const PassCtx::RowSpan ra = a.rowSpan(target.h), rt = t.rowSpan(target.h);
+    const int wa = std::min((int)(a.dispatch[0] * 8u), target.w), wt = std::min((int)(t.dispatch[0] * 8u), target.w);
+    if (ra.y0 != rt.y0 || ra.y1 != rt.y1 || wa != target.w || wt != target.w) return kUseGeneralKernel;             // same rows, whole rows
+    if (ra.y1 <= ra.y0) return 0;
+    float strength;
+    std::memcpy(&strength, a.push.data(), 4);
+    const dim3 grid(divUp((unsigned)target.w, 256u), divUp((unsigned)(ra.y1 - ra.y0), 4u));
+    if (dst.fmt == F_BGRA8) applyBloomTonemapKernel<true><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, target.w, ra.y1, ra.y0);
+    else applyBloomTonemapKernel<false><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, target.w, ra.y1, ra.y0);
+    PLR_CHECK_LAUNCH(a);
     return 0;
 }
 
 } // namespace faststream
 
+int launchTemporalGiFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return faststream::launchTemporalGiImpl(c, &target); }
+static int fused_apply_bloom_tonemap(const PassCtx* const* ctxs, size_t count) { return faststream::launchApplyBloomTonemap(ctxs, count); }
+PLR_REGISTER_FUSION("applyBloom + tonemapping", fused_apply_bloom_tonemap, "applyBloom.comp", "tonemapping.comp");
 static int faststream_apply_bloom(const PassCtx& c) { return faststream::launchApplyBloom(c); }
 static int faststream_tonemapping(const PassCtx& c) { return faststream::launchTonemapping(c); }
 static int faststream_upscale(const PassCtx& c) { return faststream::launchUpscale(c); }

@@ -64,8 +64,44 @@ class FramePipeline:
 
     def destroy(self):
         if self.handle:
+            self.detach_rccl()
             self.lib.plrf_destroy(self.handle)
             self.handle = None
+
+    # ---- native RCCL halo exchange (include/plr_frame.h, csrc/frontend/band_exchange.cpp): no Python in the frame loop
+    def rccl_unique_id(self):
+        """bytes of a fresh ncclUniqueId (rank 0 calls this and hands the bytes to every rank)"""
+        buf = C.create_string_buffer(128)
+        if self.lib.plrf_rccl_get_unique_id(buf) != 0:
+            self.lib.plrf_rccl_last_error.restype = C.c_char_p
+            raise PlrError("plrf_rccl_get_unique_id: " + self.lib.plrf_rccl_last_error().decode())
+        return buf.raw
+
+    def attach_rccl(self, unique_id, rank, world, frame_height):
+        self.lib.plrf_rccl_last_error.restype = C.c_char_p
+        x = C.c_void_p()
+        rc = self.lib.plrf_rccl_attach(self.handle, C.create_string_buffer(bytes(unique_id), 128), C.c_int(rank), C.c_int(world), C.c_uint32(frame_height), C.byref(x))
+        if rc != 0:
+            raise PlrError("plrf_rccl_attach failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
+        self._rccl = x
+
+    def detach_rccl(self):
+        if getattr(self, "_rccl", None):
+            self.lib.plrf_rccl_detach(self.handle, self._rccl)
+            self._rccl = None
+
+    def rccl_stats(self):
+        """(bytes sent, bytes received, point-to-point exchange groups) of the last frame on this rank"""
+        a, b, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.plrf_rccl_get_stats(self._rccl, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def rccl_self_test(self, device_ptr, row_bytes, src_row, dst_row, rows):
+        stream = C.c_void_p()
+        self.be._check(self.lib.plr_get_stream(C.byref(stream)))
+        rc = self.lib.plrf_rccl_self_test(self._rccl, C.c_void_p(device_ptr), C.c_uint32(row_bytes), C.c_uint32(src_row), C.c_uint32(dst_row), C.c_uint32(rows), stream)
+        if rc != 0:
+            raise PlrError("plrf_rccl_self_test failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
 
     def image(self, name):
         h = _ImageHandle()

@@ -286,17 +286,94 @@ def test_gpu_two_bands_fast_math_matches_full_frame():
 
 
 @pytest.mark.gpu
-def test_gpu_bench_band_path_over_rccl_group_of_one():
-    """bench.py's multi-GPU code path (band pipeline + torch.distributed "nccl" = RCCL transport on the backend's stream) with a
-    process group of size 1: device pointers wrapped as tensors, the histogram all-reduce and the exchange callbacks all run."""
+@pytest.mark.parametrize("transport", ["rccl-c++", "torch-python"])
+def test_gpu_bench_band_path_over_rccl_group_of_one(transport):
+    """bench.py's multi-GPU code path with a group of size 1: the band pipeline, the C++ host's RCCL exchange (ncclCommInitRank, the histogram
+    ncclAllReduce, the send / receive groups - empty for a single band) or, with --python-exchange, the torch.distributed transport"""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-bands", "--steps", "3", "--warmup", "1", "--profile-frames", "2", "--no-cpu-baseline",
-           "--width", "512", "--height", "256", "--grid", "4", "--sdf-res", "16", "--shadow-res", "256"]
+           "--width", "512", "--height", "256", "--grid", "4", "--sdf-res", "16", "--shadow-res", "256"] + (["--python-exchange"] if transport == "torch-python" else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["value"] > 0 and any(k.startswith("Exchange:") for k in out["passes_ms"]), out["passes_ms"]
+    if transport == "rccl-c++":
+        assert out["exchange"]["point_to_point_groups_per_frame"] >= 3 and out["exchange"]["rank0_bytes_sent_per_frame"] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_bench_refuses_a_world_size_it_was_not_asked_for():
+    """`--gpus 2` under WORLD_SIZE=1 (or on a one-GPU box) must fail loudly, not measure a single GPU and label it 2"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_transport_moves_rows_through_the_overlapped_exchange_sequence(backend):
+    """One GPU cannot host two RCCL ranks, so the C++ transport's mechanics (group of ncclSend / ncclRecv on the communication stream, ordered
+    against the launch stream by events) are exercised with this rank as its own peer: rows [4, 12) of an image arrive on rows [40, 48)."""
+    from plainrenderer_amd.frame import FramePipeline
+    w, h = 256, 128
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=8, max_sdf_instances=16, band_row_begin=0, band_row_end=h)
+    try:
+        fp.attach_rccl(fp.rccl_unique_id(), 0, 1, h)
+        img = fp.image("post1")
+        data = np.random.default_rng(3).integers(0, 2 ** 32, (h, w), dtype=np.uint32)
+        backend.uploadImage(img, data)
+        ptr, size = backend.imageDevicePointer(img, 0)
+        assert size == w * h * 4
+        fp.rccl_self_test(ptr, w * 4, 4, 40, 8)
+        got = backend.downloadImage(img, 0, np.uint32).reshape(h, w)
+        expect = data.copy()
+        expect[40:48] = data[4:12]
+        assert np.array_equal(got, expect)
+    finally:
+        fp.destroy()
+
+
+def test_cpp_exchange_plan_equals_the_python_plan():
+    """the C++ RCCL exchange (csrc/frontend/band_exchange.cpp) plans its ncclSend / ncclRecv with plrf_band_rows / plrf_exchange_plan; the gloo
+    test above exercises the Python plan - both must describe the same transfers for every band count, image scale and halo"""
+    import ctypes as C
+    from plainrenderer_amd import backend, tiling
+
+    class Op(C.Structure):
+        _fields_ = [("peer", C.c_uint32), ("send", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
+    lib = C.CDLL(backend.LIB_PATH)
+    for height in (4320, 2160, 1088, 8640, 200):
+        for n in (1, 2, 3, 4, 8):
+            if n > (height + 63) // 64:
+                continue
+            for b in range(n):
+                r0, r1 = C.c_uint32(), C.c_uint32()
+                assert lib.plrf_band_rows(C.c_uint32(height), C.c_uint32(n), C.c_uint32(b), C.byref(r0), C.byref(r1)) == 0
+                assert (r0.value, r1.value) == tiling.band_rows(height, n, b)
+            for div in (1, 2):
+                image_rows = height // div
+                for halo in (0, 8, 16, 32, 64, 320, 5000):
+                    def rows_of(band):
+                        b0, b1 = tiling.band_rows(height, n, band)
+                        return tiling.Rows(0, b0 // div, min((b1 + div - 1) // div, image_rows), halo, 16, image_rows)
+                    bands = [rows_of(k) for k in range(n)]
+                    for b in range(n):
+                        ops = (Op * 4)()
+                        cnt = C.c_uint32()
+                        me = bands[b]
+                        assert lib.plrf_exchange_plan(C.c_uint32(height), C.c_uint32(n), C.c_uint32(b), C.c_uint32(image_rows), C.c_uint32(halo), C.c_uint32(me.row_begin),
+                                                      C.c_uint32(me.row_end), ops, C.byref(cnt)) == 0
+                        got = [(int(o.peer), "send" if o.send else "recv", int(o.row_begin), int(o.row_end)) for o in ops[:cnt.value]]
+                        assert got == tiling.neighbour_plan(bands, b, n), (height, n, b, div, halo)
+    # what one rank sends, its neighbour receives: the plans of two adjacent bands mirror each other
+    height, n, halo = 4320, 4, 218
+    bands = [tiling.Rows(0, *tiling.band_rows(height, n, k), halo, 16, height) for k in range(n)]
+    for b in range(n - 1):
+        down = [o for o in tiling.neighbour_plan(bands, b, n) if o[0] == b + 1]
+        up = [o for o in tiling.neighbour_plan(bands, b + 1, n) if o[0] == b]
+        assert {(k, a, e) for _, k, a, e in down} == {("recv" if k == "send" else "send", a, e) for _, k, a, e in up}

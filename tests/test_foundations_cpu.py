@@ -100,6 +100,12 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(backend.EXPORTED_SYMBOLS) == declared
+    # ... and every function the other public headers declare (frame pipeline, RCCL band exchange, SDF bake, image IO)
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        names = sorted(set(re.findall(r"\b(plr[a-z]*_[a-z0-9_]+)\s*\(", open(path).read())))
+        missing = [s for s in names if not hasattr(lib, s)]
+        assert not missing, (os.path.basename(path), missing)
 
 
 def test_backend_fails_loudly_without_gpu():
