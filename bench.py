@@ -101,7 +101,7 @@ def build_scene(args, device, w, h, band=None):
     scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
     span = args.grid * 8.0
     x0 = span * 0.35
-    cams = [Camera.look((x0 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(args.steps + args.warmup + args.profile_frames + 4)]
+    cams = [Camera.look((x0 + 0.002 * i, -9.0, -10.0 + 0.004 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(args.steps + args.warmup + args.profile_frames + 28)]
     rows = depth_range = None
     if band is not None:
         # every band must fit the same shadow cascades: depth range of the whole frame from a 1/8-resolution G-buffer (same on all ranks)
@@ -130,7 +130,7 @@ def cpu_baseline(args, cores, device):
     scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
     span = args.grid * 8.0
     cams = [Camera.look((span * 0.35 + 0.004 * i, -9.0, -10.0 + 0.01 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(4)]
-    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+    inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=args.shadow_res, froxel_depth=64, sun_direction=(0.35, -0.8, 0.45))
     inputs.volume_indices = list(range(len(inputs.volumes)))
     inputs.instance_bytes_patched = inputs.instance_bytes
     s = PlrfSettings()
@@ -140,7 +140,7 @@ def cpu_baseline(args, cores, device):
     s.sdf_half_res_trace, s.sdf_strict_influence_radius_cutoff, s.sdf_trace_influence_radius = 1, 1, 5.0
     s.diffuse_brdf, s.direct_multiscatter, s.indirect_lighting_tech, s.use_geometry_aa, s.sun_shadow_cascade_count = 2, 0, 0, 1, 3
     s.run_exposure = s.run_hiz = s.run_gi = s.run_shading = s.run_taa = s.run_bloom = s.run_tonemap = 1
-    ora = OracleFrame(inputs, w, h, 32, s)
+    ora = OracleFrame(inputs, w, h, 512, s)
     n_vol = len(inputs.volumes)
     times = []
     for f in range(3):
@@ -154,15 +154,15 @@ def cpu_baseline(args, cores, device):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))  # frame 0 bakes the BRDF LUT
     return {"value": 1.0 / (t * scale * scale), "unit": "frames/s (3840x2160-equivalent)", "cores": cores, "kind": "port",
-            "sample": "full frame at %dx%d (1/%d of the pixels, %d instances x %d^3 SDF), median of 2 frames = %.2f s each, scaled by the pixel ratio" % (
-                w, h, scale * scale, args.grid ** 2, args.sdf_res, t)}
+            "sample": "full frame at %dx%d (1/%d of the pixels; %d instances x %d^3 SDF, %d^2 shadow cascades, 64 froxel slices, 512^2 BRDF LUT as on the GPU), "
+                      "median of 2 frames = %.2f s each, scaled by the pixel ratio" % (w, h, scale * scale, args.grid ** 2, args.sdf_res, args.shadow_res, t)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=600, help="timed frames (default: ~0.6 s of GPU time at 4K)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--grid", type=int, default=16, help="SDF instances = grid^2 (16 -> 256)")
@@ -304,6 +304,16 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1000.0 / args.steps
 
+    # ---- host cost of one frame with the GPU idle (record + launch of the C++ pipeline through the C-ABI, nothing to wait for)
+    host_idle = []
+    for _ in range(20):
+        be.waitForGPUIdle()
+        th = time.perf_counter()
+        step()
+        host_idle.append((time.perf_counter() - th) * 1e3)
+    be.waitForGPUIdle()
+    host_idle_ms = float(np.median(host_idle))
+
     # ---- per-pass hipEvent timings (events recorded on the backend's launch stream) for the roofline object
     pass_ms = {}
     if args.profile_frames > 0:
@@ -316,11 +326,15 @@ def main():
     # per-GPU pixels: the band's rows (a band renders w x rows of the frame)
     bh = h if band is None else band[1] - band[0]
     bytes_per_pass, frame_bytes = algorithmic_bytes(w, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
+    def pass_bytes(name):
+        # a fused launch (pass fusion, include/plr.h) is reported as "A + B": its compulsory traffic is the sum of its passes', minus nothing -
+        # an image one pass writes and the next reads back still has to be written (it is an output of the boundary), only the re-read is saved
+        return sum(bytes_per_pass.get(part, 0.0) for part in name.split(" + "))
     table = []
     for name, v in pass_ms.items():
         launches = len(v) / args.profile_frames
         avg = float(np.mean(v))
-        table.append((name, avg, launches, bytes_per_pass.get(name, 0.0)))
+        table.append((name, avg, launches, pass_bytes(name)))
     table.sort(key=lambda r: -r[1] * r[2])
     roofline = None
     if table:
@@ -328,7 +342,7 @@ def main():
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         default_workload = (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None
         traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
-        roofline = {"bound": "hbm", "kernel": name, "hip_kernel": (PASS_KERNEL.get(name) or [None])[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        roofline = {"bound": "hbm", "kernel": name, "hip_kernel": (PASS_KERNEL.get(name) or PASS_KERNEL.get(name.split(" + ")[-1]) or [None])[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
     if args.pass_table and rank == 0:
         tot = sum(r[1] * r[2] for r in table)
@@ -352,6 +366,7 @@ def main():
             "unit": "frames/s (3840x2160-equivalent: frames/s x frame pixels / 8294400)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "host_ms_per_step": round(host_elapsed * 1000.0 / args.steps, 4),
+            "host_ms_per_frame_idle_gpu": round(host_idle_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d, %d SDF instances x %d^3, "
                                    "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),

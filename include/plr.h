@@ -96,6 +96,11 @@ typedef struct plr_compute_pass_execution {
      * reference's recorder code. A band renderer (one GPU per range of screen rows) sets [1] so a pass covers only its rows;
      * [0] is honoured by histogramCombineTiles (first tile), [2] must be 0. */
     uint32_t dispatch_base[3];
+    /* extension (band rendering): rows [valid_rows[0], valid_rows[1]) of the pass's INPUT images hold valid data - the band's own rows plus the
+     * halo rows received from the neighbouring GPUs; {0, 0} = every row (the reference's recorder code). Honoured by filterIndirectDiffuseSpatial,
+     * whose world-space disc can reach arbitrarily far on near geometry: a sample that lands outside gets the shader's own off-screen treatment
+     * (weight 0, disc shrinks: filterIndirectDiffuseSpatial.comp:100-105) instead of reading rows no neighbour sent. */
+    uint32_t valid_rows[2];
 } plr_compute_pass_execution;
 
 /* extension: host function executed in recording order while plr_render_frame launches the recorded passes; it may enqueue
@@ -233,6 +238,12 @@ int plr_debug_codec_eval(int fn, const void* in, void* out, int64_t n);
  * agree to the storage quantum" from "a float rounding flipped a decision". Costs nothing when no buffer is set. */
 int plr_debug_set_decision_signature(size_t words);
 int plr_debug_read_decision_signature(uint32_t* out_words, size_t words);
+/* the PLR_MATH_FAST luminance histogram bins by comparison against a threshold table instead of evaluating the logarithm (kernels_fast/
+ * histogram_fast.hip): this checks the table-driven bin against the shader's formula for ALL 2^32 float bit patterns. *out_mismatches must be 0. */
+int plr_debug_verify_histogram_thresholds(float min_luminance, float max_luminance, uint64_t* out_mismatches);
+/* the PLR_MATH_FAST sky LUT lookup (polynomial acos / atan, device/fastmath.h) for n directions (3 floats each) -> n x 3 floats; the oracle's
+ * orc_kat_sky_lut takes the same arguments */
+int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, float* out_rgb, int64_t n);
 /* sampler probe: evaluates one of the global samplers of resources/shaders/global.inc:35-42 on an image, with the device sampler code the pass
  * kernels are built from. filter: 0 nearest, 1 linear, 2 textureGather (component 0); address: 0 clamp-to-edge, 1 repeat, 2 border white,
  * 3 border black. coords: n x 2 (2D) or n x 3 (3D image) normalised coordinates, out: n x 4 floats; both host memory.

@@ -79,3 +79,11 @@ extern "C" void orc_kat_sampling(int fn, const float* in, float* out, int64_t n)
         }
     }
 }
+
+// sampleSkyLut (sky.inc:85-116) for n directions (3 floats each) -> n x 3 floats
+extern "C" void orc_kat_sky_lut(const orc_image* lut, const float* dirs, float* out, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        const vec3 c = sampleSkyLut(vec3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), img(lut));
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}

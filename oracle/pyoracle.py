@@ -193,3 +193,10 @@ def kat_sampling(fn, data, in_per, out_per):
     out = np.zeros((a.shape[0], out_per), np.float32)
     lib().orc_kat_sampling(C.c_int(fn), _p(a), _p(out), C.c_int64(a.shape[0]))
     return out
+
+
+def kat_sky_lut(image, dirs):
+    a = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    out = np.zeros((a.shape[0], 3), np.float32)
+    lib().orc_kat_sky_lut(image.ref(), _p(a), _p(out), C.c_int64(a.shape[0]))
+    return out

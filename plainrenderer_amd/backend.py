@@ -110,7 +110,7 @@ class _PassResources(C.Structure):
 
 class _ComputePassExecution(C.Structure):
     _fields_ = [("handle", C.c_uint32), ("resources", _PassResources), ("push_constants", C.c_void_p),
-                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3)]
+                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3), ("valid_rows", C.c_uint32 * 2)]
 
 
 class _SpecConstant(C.Structure):
@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_host_callback_execution", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -298,6 +298,7 @@ class RenderBackend:
         e.push_constant_size = len(pc)
         e.dispatch_count = (C.c_uint32 * 3)(*[int(x) for x in exe.dispatchCount])
         e.dispatch_base = (C.c_uint32 * 3)(*[int(x) for x in getattr(exe, "dispatchBase", (0, 0, 0))])
+        e.valid_rows = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "validRows", (0, 0))])
         self._check(self.lib.plr_set_compute_pass_execution(C.byref(e)))
 
     def prepareForDrawcallRecording(self):
@@ -498,6 +499,18 @@ class RenderBackend:
             bp = b.ctypes.data_as(C.c_void_p)
         self._check(self.lib.plr_debug_math_eval(C.c_int(fn), a.ctypes.data_as(C.c_void_p), bp, out.ctypes.data_as(C.c_void_p), C.c_int64(a.size)))
         return out
+
+    def debugSkyLutEval(self, sky_lut, directions):
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        out = np.empty_like(d)
+        self._check(self.lib.plr_debug_sky_lut_eval(_ImageHandle(sky_lut.type, sky_lut.index), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int64(d.shape[0])))
+        return out
+
+    def debugVerifyHistogramThresholds(self, min_luminance, max_luminance):
+        """-> number of float bit patterns (of all 2^32) whose table-driven histogram bin differs from the shader's formula"""
+        n = C.c_uint64()
+        self._check(self.lib.plr_debug_verify_histogram_thresholds(C.c_float(min_luminance), C.c_float(max_luminance), C.byref(n)))
+        return n.value
 
     def setPassFusion(self, enabled):
         self._check(self.lib.plr_set_pass_fusion(C.c_int(int(bool(enabled)))))

@@ -329,6 +329,7 @@ static ImgView makeView(const ImageRes& im, uint32_t mip) {
 
 static bool sameDesc(const plr_image_desc& a, const plr_image_desc& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
+int launchSkyLutProbe(const ImgView& lut, const float* dirs, float* out, int64_t n); // kernels_fast/stream_fast.hip
 int launchSamplerProbe(const ImgView& view, int filter, int address, const float* coords, float* out, int64_t n); // kernels/probes.hip
 
 } // namespace plr
@@ -355,6 +356,7 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipEventCreateWithFlags(&g->pinnedFree, hipEventDisableTiming));
     for (auto& st : g->sideStreams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (const char* ov = std::getenv("PLR_STREAM_OVERLAP")) g->overlap = std::atoi(ov) != 0;
+    if (const char* pf = std::getenv("PLR_PASS_FUSION")) g->fusion = std::atoi(pf) != 0;
     if (const char* ns = std::getenv("PLR_SIDE_STREAMS")) g->activeSideStreams = std::min(std::max(std::atoi(ns), 1), (int)Backend::kSideStreams);
     return plr_recreate_swapchain(width, height);
 }
@@ -496,6 +498,7 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
     if (rc) { g->executions.pop_back(); return rc; }
     if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
     for (int i = 0; i < 3; i++) { x.ctx.dispatch[i] = e->dispatch_count[i]; x.ctx.base[i] = e->dispatch_base[i]; }
+    x.ctx.validRows[0] = e->valid_rows[0]; x.ctx.validRows[1] = e->valid_rows[1];
     {
         // what the execution may touch (stream scheduler): whole allocations, so a kernel that walks the mip chain of a bound image or
         // addresses rows outside its dispatch is covered; uniform buffers are only written between frames
@@ -1093,6 +1096,14 @@ int plr_debug_read_decision_signature(uint32_t* out_words, size_t words) {
     HIP_TRY(hipStreamSynchronize(g->stream));
     HIP_TRY(hipMemcpy(out_words, g->debugSig, words * 4, hipMemcpyDeviceToHost));
     return PLR_OK;
+}
+
+int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, float* out_rgb, int64_t n) {
+    NEED_INIT();
+    ImageRes* im = resolveImage(sky_lut);
+    if (!im || !directions || !out_rgb || n <= 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sky_lut_eval: invalid argument");
+    HIP_TRY(hipStreamSynchronize(g->stream));
+    return launchSkyLutProbe(makeView(*im, 0), directions, out_rgb, n);
 }
 
 int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filter, int address, const float* coords, float* out, int64_t n) {

@@ -38,6 +38,13 @@ struct PassCtx {
     std::vector<uint8_t> push;
     uint32_t dispatch[3] = {1, 1, 1};
     uint32_t base[3] = {0, 0, 0};         // first workgroup of the dispatch (vkCmdDispatchBase semantics; band rendering, plr.h)
+    uint32_t validRows[2] = {0, 0};       // rows of the input images that hold valid data (band rendering, plr.h); {0, 0} = all
+    // [lo, hi) for an input image of imageH rows
+    void validRowRange(int imageH, int* lo, int* hi) const {
+        const bool all = validRows[0] == 0 && validRows[1] == 0;
+        *lo = all ? 0 : (int)(validRows[0] < (uint32_t)imageH ? validRows[0] : (uint32_t)imageH);
+        *hi = all ? imageH : (int)(validRows[1] < (uint32_t)imageH ? validRows[1] : (uint32_t)imageH);
+    }
     const std::vector<SpecConstant>* spec = nullptr;
     std::string* err = nullptr;
     void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)

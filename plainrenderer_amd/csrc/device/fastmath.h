@@ -34,7 +34,7 @@ PLR_DI uint32_t texelIndex(uint32_t x, uint32_t y, uint32_t w) { return __umul24
 // shorter 4.4.45 form moved horizon directions by a tenth of a LUT row) and atan (|error| <= 1e-5 rad = 3e-4 LUT columns), and a
 // conditional wrap (the u coordinate lies in [0, 1], so the bilinear footprint can only step one texel across the seam).
 PLR_DI float acosFast(float x) {
-    const float a = fabsf(x);
+    const float a = __builtin_fminf(fabsf(x), 1.f); // a direction normalised in fp32 can have a component of 1 + 1 ulp: sqrt(1 - a) must not see it
     const float p = 1.5707963050f + a * (-0.2145988016f + a * (0.0889789874f + a * (-0.0501743046f + a * (0.0308918810f + a * (-0.0170881256f + a * (0.0066700901f + a * -0.0012624911f))))));
     const float r = __builtin_amdgcn_sqrtf(1.f - a) * p;
     return x < 0.f ? 3.14159265f - r : r;

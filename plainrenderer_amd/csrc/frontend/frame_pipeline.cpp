@@ -491,6 +491,14 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
     const ImageHandle depthSrc = s.halfResTrace ? deps.depthHalfRes : deps.currentFrame.depthBuffer;
     const ImageDescription td = be.getImageDescription(m_indirectDiffuse_Y_SH[1]);
     const RowRange rows = band ? band->traceRows : RowRange{};
+    // band rendering: the spatial filter's inputs are valid on the band's rows and the giHalo rows received from each neighbour; a disc sample
+    // beyond them is treated like an off-screen sample (ComputePassExecution::validRows, plr.h) instead of reading rows nobody sent
+    auto setValidRows = [&](ComputePassExecution& exe) {
+        if (!band) return;
+        const uint32_t r0 = std::min(rows.begin, td.height), r1 = std::min(rows.end, td.height);
+        exe.validRows[0] = r0 > band->giHalo ? r0 - band->giHalo : 0u;
+        exe.validRows[1] = std::min(r1 + band->giHalo, td.height);
+    };
     {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[0];
@@ -498,6 +506,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuse_CoCg[0], 0, 3), ImageResource(depthSrc, 0, 4),
                                                    ImageResource(deps.worldSpaceNormals, 0, 5)};
         dispatch8(exe, td.width, td.height, rows);
+        setValidRows(exe);
         be.setComputePassExecution(exe);
     }
     {
@@ -519,6 +528,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
+        setValidRows(exe);
         recordRows(be, exe, td.width, td.height, rows);
     }
     // (this exchange is small - 16 rows - and its producer launches a packing pre-pass per dispatch: it is not split / overlapped)

@@ -30,6 +30,44 @@ static float hostDetLog(float x) {
     return fe * PLR_LN2_HI + (fe * PLR_LN2_LO + r);
 }
 
+// bin of one luminance value (histogramPerTile.comp:53-57); the deterministic log makes it the same bits on host, device and in the oracle
+PLR_DI uint32_t histogramBin(float luminance, uint32_t maxIndex, float minLuminanceLog, float range) {
+    const float luminanceLog = det_logf(luminance);
+    return (uint32_t)((float)maxIndex * gclamp((luminanceLog - minLuminanceLog) / range, 0.f, 1.f));
+}
+
+// ---- threshold table of the PLR_MATH_FAST per-tile kernel (kernels_fast/histogram_fast.hip) ----
+// histogramBin is monotone in the luminance, so bin(l) = number of b in 1..maxIndex with l >= threshold[b], threshold[b] = the smallest
+// non-negative float whose bin is >= b. One thread per threshold bisects over the float bit patterns with the exact function above;
+// plr_debug_verify_histogram_thresholds checks the table-driven bin against the exact one for EVERY float (2^32 patterns).
+__global__ void histogramThresholdKernel(uint32_t* __restrict__ thresholds, uint32_t nBins, float minLuminanceLog, float maxLuminanceLog) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBins) return;
+    const uint32_t maxIndex = nBins - 1u;
+    const float range = maxLuminanceLog - minLuminanceLog;
+    uint32_t lo = 0u, hi = 0x7f800000u; // bit patterns of +0 .. +inf: ordered like the values
+    if (b == 0u) { thresholds[0] = 0u; return; }
+    if (histogramBin(u2f(hi), maxIndex, minLuminanceLog, range) < b) { thresholds[b] = 0x7fc00000u; return; } // never reached: NaN compares false
+    while (lo < hi) { // smallest pattern whose bin is >= b
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (histogramBin(u2f(mid), maxIndex, minLuminanceLog, range) >= b) hi = mid; else lo = mid + 1u;
+    }
+    thresholds[b] = lo;
+}
+int launchHistogramThresholds(uint32_t* thresholds, uint32_t nBins, float minLuminance, float maxLuminance, hipStream_t stream) {
+    histogramThresholdKernel<<<divUp(nBins, 64u), 64, 0, stream>>>(thresholds, nBins, hostDetLog(minLuminance), hostDetLog(maxLuminance));
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+// exact bins of `count` consecutive float bit patterns starting at `first` (the verification's reference side)
+__global__ void histogramExactBinsKernel(uint8_t* __restrict__ out, uint32_t first, uint32_t count, uint32_t nBins, float minLuminanceLog, float maxLuminanceLog) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (uint8_t)histogramBin(u2f(first + i), nBins - 1u, minLuminanceLog, maxLuminanceLog - minLuminanceLog);
+}
+int launchHistogramExactBins(uint8_t* out, uint32_t first, uint32_t count, uint32_t nBins, float minLuminance, float maxLuminance, hipStream_t stream) {
+    histogramExactBinsKernel<<<divUp(count, 256u), 256, 0, stream>>>(out, first, count, nBins, hostDetLog(minLuminance), hostDetLog(maxLuminance));
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // ------------------------------------------------------------------------------------------------
 // histogramPerTile.comp:32-65. One 256-thread block per 32x32 tile; thread t owns 4 consecutive pixels of
 // row t/8. The bin index must be bit exact, so the log is the deterministic one.
@@ -68,8 +106,7 @@ __global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const
         if (valid) {
             const vec3 c = unpackR11G11B10(texels[i]);
             const float luminance = dot(c, vec3(0.2126f, 0.7152f, 0.0722f)) / prevExposure; // :28-30, :53
-            const float luminanceLog = det_logf(luminance);
-            bin = (uint32_t)((float)maxIndex * gclamp((luminanceLog - minLuminanceLog) / range, 0.f, 1.f));
+            bin = histogramBin(luminance, maxIndex, minLuminanceLog, range);
         }
         // wave vote aggregation: neighbouring pixels mostly share a bin, so peel the leading bins with one LDS
         // atomic each, then let the stragglers add individually
@@ -180,11 +217,10 @@ PLR_DI float offsetFromSceneEV(float sceneEV100) {
 }
 
 constexpr int kMaxExposureBins = 1024;
-__global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restrict__ light, const uint32_t* __restrict__ histogram, ImgView transmissionLut,
-                                                            const GlobalUbo* __restrict__ g, int nBins, float minLuminanceLog, float maxLuminanceLog) {
-    __shared__ float term[kMaxExposureBins];
-    __shared__ uint32_t counted[kMaxExposureBins];
-    const int lane = threadIdx.x;
+// one wave; term / counted: LDS arrays of kMaxExposureBins entries. HIST(i) returns bin i's count.
+template <class Hist>
+PLR_DI void preExposeLightsWave(LightBuffer* __restrict__ light, Hist hist, const ImgView& transmissionLut, const GlobalUbo* __restrict__ g, int nBins,
+                                float minLuminanceLog, float maxLuminanceLog, float* term, uint32_t* counted, int lane) {
     const uint32_t pixelCount = (uint32_t)(g->screenResolution[0] * g->screenResolution[1]);
     // inputs of the serial tail, fetched while the histogram scan runs (they do not depend on it)
     const vec4 sunTransmission = sampleLinear2D<F_R11G11B10, CLAMP>(transmissionLut, vec2(0.f, -g->sunDirection[1] * 0.5f + 0.5f));
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
     uint32_t carry = 0u;
     for (int base = 0; base < nBins; base += 64) {
         const int i = base + lane;
-        const uint32_t h = i < nBins ? histogram[i] : 0u;
+        const uint32_t h = i < nBins ? hist(i) : 0u;
         uint32_t incl = h;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
@@ -213,7 +249,8 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
             counted[i] = take ? h : 0xffffffffu;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the wave's own LDS writes before lane 0 reads them back
     if (lane != 0) return;
     float mean = 0.f;
     uint32_t countedPixels = 0u;
@@ -241,6 +278,55 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
     light->sunColor[0] = sunTransmission.x; light->sunColor[1] = sunTransmission.y; light->sunColor[2] = sunTransmission.z;
 }
 
+__global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restrict__ light, const uint32_t* __restrict__ histogram, ImgView transmissionLut,
+                                                            const GlobalUbo* __restrict__ g, int nBins, float minLuminanceLog, float maxLuminanceLog) {
+    __shared__ float term[kMaxExposureBins];
+    __shared__ uint32_t counted[kMaxExposureBins];
+    preExposeLightsWave(light, [&](int i) { return histogram[i]; }, transmissionLut, g, nBins, minLuminanceLog, maxLuminanceLog, term, counted, (int)threadIdx.x);
+}
+
+// ---- pass fusion (backend.h): histogramReset + histogramCombineTiles + preExposeLights recorded back to back, as one launch.
+// Every block sums its slab of tiles like histogramCombineKernel and adds it to a zeroed accumulator with device-scope atomics; the block that
+// takes the last ticket stores the totals into the histogram buffer (= reset + combine), zeroes the accumulator for the next frame and runs
+// the exposure wave on the totals. All cross-block traffic goes through device-scope atomics (performed at the memory side, coherent across
+// the eight XCDs' L2s); a thread's atomics have completed when its vmcnt reaches 0, the block's when all its threads passed the barrier.
+constexpr int kFusedExposureMaxBins = 256;
+struct ExposureScratch { uint32_t ticket; uint32_t pad[3]; uint32_t acc[kFusedExposureMaxBins]; };
+__global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
+                                                                    ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
+                                                                    const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog) {
+    __shared__ float term[kMaxExposureBins];
+    __shared__ uint32_t counted[kMaxExposureBins];
+    __shared__ uint32_t totals[kFusedExposureMaxBins];
+    __shared__ uint32_t isLast;
+    const uint32_t t0 = blockIdx.x * kCombineTilesPerBlock, t1 = min(t0 + kCombineTilesPerBlock, nTiles);
+    for (uint32_t bin = threadIdx.x; bin < nBins; bin += blockDim.x) {
+        uint32_t sum = 0u, t = t0;
+        for (; t + 8u <= t1; t += 8u) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) v[i] = perTile[(size_t)(t + i) * nBins + bin];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) sum += v[i];
+        }
+        for (; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
+        if (sum) __hip_atomic_fetch_add(&scratch->acc[bin], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!isLast) return;
+    for (uint32_t bin = threadIdx.x; bin < nBins; bin += blockDim.x) {
+        const uint32_t v = __hip_atomic_exchange(&scratch->acc[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // read the total, leave zero for the next frame
+        totals[bin] = v;
+        histogram[bin] = v;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x < 64) preExposeLightsWave(light, [&](int i) { return totals[i]; }, transmissionLut, g, (int)nBins, minLuminanceLog, maxLuminanceLog, term, counted, (int)threadIdx.x);
+}
+
 static int launchPreExposeLights(const PassCtx& c) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needSbuf(0, sizeof(LightBuffer), "preExposeLights lightBuffer")) return rc;
@@ -256,6 +342,28 @@ static int launchPreExposeLights(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("preExposeLights.comp", launchPreExposeLights);
+
+static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
+    if (count != 3) return kUseGeneralKernel;
+    const PassCtx &reset = *ctxs[0], &comb = *ctxs[1], &expo = *ctxs[2];
+    const uint32_t nBins = comb.specUint(0, 64u);
+    if (nBins == 0 || nBins > (uint32_t)kFusedExposureMaxBins || reset.specUint(0, 64u) != nBins || (uint32_t)expo.specInt(0, 64) != nBins) return kUseGeneralKernel;
+    if (!reset.hasSbuf(1) || !comb.hasSbuf(0) || !comb.hasSbuf(1) || !expo.hasSbuf(0) || !expo.hasSbuf(1) || !expo.hasSampled(2) || !expo.global) return kUseGeneralKernel;
+    // one histogram buffer through the chain, whole-histogram dispatches, all tiles from tile 0 (not a band's partial combine)
+    if (reset.sbuf[1].ptr != comb.sbuf[1].ptr || expo.sbuf[1].ptr != comb.sbuf[1].ptr || comb.sbuf[1].size < (size_t)nBins * 4u) return kUseGeneralKernel;
+    if (reset.dispatch[0] * 64u < nBins || comb.dispatch[1] * 64u < nBins || comb.base[0] != 0 || comb.dispatch[0] == 0) return kUseGeneralKernel;
+    const uint32_t nTiles = comb.dispatch[0];
+    if (comb.sbuf[0].size < (size_t)nTiles * nBins * 4u || expo.sbuf[0].size < sizeof(LightBuffer) || expo.sampled[2].fmt != F_R11G11B10) return kUseGeneralKernel;
+    const float minL = expo.specFloat(1, 1.f), maxL = expo.specFloat(2, 100.f);
+    if (!(minL > 0.f) || !(maxL > 0.f)) return kUseGeneralKernel;
+    ExposureScratch* scratch = (ExposureScratch*)comb.scratch(sizeof(ExposureScratch)); // zero-initialised by the backend, kept zero by the kernel
+    if (!scratch) return comb.fail(-2, "histogramCombineTiles: cannot allocate scratch memory");
+    histogramCombineExposeKernel<<<divUp(nTiles, kCombineTilesPerBlock), 128, 0, comb.stream>>>((const uint32_t*)comb.sbuf[0].ptr, (uint32_t*)comb.sbuf[1].ptr, nBins, nTiles, scratch,
+                                                                                                 (LightBuffer*)expo.sbuf[0].ptr, expo.sampled[2], expo.global, hostDetLog(minL), hostDetLog(maxL));
+    PLR_CHECK_LAUNCH(comb);
+    return 0;
+}
+PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles + preExposeLights", launchFusedExposureChain, "histogramReset.comp", "histogramCombineTiles.comp", "preExposeLights.comp");
 
 // ------------------------------------------------------------------------------------------------
 // tonemapping.comp:17-27 + tonemapping.inc:17-49 + colorConversion.inc:5-13 + dither.inc:6-12 + noise.inc:14-24.

@@ -22,7 +22,7 @@ PLR_DI vec3 pixelToWorld(vec2 uv, const ImgView& depthTexture, const GlobalUbo* 
 // filterIndirectDiffuseSpatial.comp:30-135
 template <int DEPTH_FMT>
 __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
-                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase) {
+                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase, int validY0, int validY1) {
     __shared__ float sqrtRand[32], cosA[32], sinA[32];
     if (threadIdx.x < 64) {
         // lane i replays the xorshift sequence up to its own pair of draws (2*i + 2 steps at most 64: negligible)
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgVi
         const float distanceToTangentPlane = fabsf(dot(N, pixelWorld - pCenter));
         float weight = gclamp(0.25f / gmax(distanceToTangentPlane, 0.0001f), 0.f, 1.f);
         weight *= weight;
-        if (sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f) {
+        // band rendering (PassCtx::validRows): a sample on a row no neighbouring band has sent is treated like an off-screen one
+        const int sampleRow = clampi((int)floorf(saneCoord(sampleUV.y * (float)inYSH.h)), inYSH.h);
+        if (sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f || sampleRow < validY0 || sampleRow >= validY1) {
             weight = 0.f;
             lengthModifier *= 0.98f;
         }
@@ -109,10 +111,12 @@ static int launchSpatialFilter(const PassCtx& c) {
     if (w <= 0 || h <= y0) return 0;
     const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
     // depth is the half-res R16F copy for a half-res trace, the D32 depth buffer otherwise (Techniques/SDFGI.cpp:423)
+    int validY0, validY1;
+    c.validRowRange(c.sampled[2].h, &validY0, &validY1);
     if (c.sampled[4].fmt == F_R16F)
-        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0);
+        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1);
     else if (c.sampled[4].fmt == F_D32)
-        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0);
+        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1);
     else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
     PLR_CHECK_LAUNCH(c);
     return 0;

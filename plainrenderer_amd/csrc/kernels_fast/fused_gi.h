@@ -14,6 +14,7 @@ namespace plr {
 // holds at this texel. A texel with a NaN component (filterIndirectDiffuseSpatial.comp:118 skips it) or a non-positive denominator is
 // stored as zeros with a negative denominator.
 PLR_DI uint4 packGiTexel(uint2 ysh, uint32_t cocg, float depth, float nearPlane, float farPlane) {
+#pragma clang fp contract(off) // the same bits whichever file (contraction on or off) the caller is compiled in: fused and unfused frames stay identical
     float den = farPlane + (1.f - depth) * (nearPlane - farPlane);
     const float probe = ((halfBitsToFloat(ysh.x & 0xffffu) + halfBitsToFloat(ysh.x >> 16)) + (halfBitsToFloat(ysh.y & 0xffffu) + halfBitsToFloat(ysh.y >> 16))) +
                         (halfBitsToFloat(cocg & 0xffffu) + halfBitsToFloat(cocg >> 16));

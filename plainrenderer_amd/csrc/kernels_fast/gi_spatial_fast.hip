@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
-                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk, uint32_t* __restrict__ sig) {
+                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk, uint32_t* __restrict__ sig,
+                                                               uint32_t validY0, uint32_t validRowCount) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         const float sw = __builtin_amdgcn_sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
         const float wMin = (P0.z - sw * dm) * 0.999f;
         safe = wMin > 0.f && fabsf(P0.x) + sx * dm <= wMin && fabsf(P0.y) + sy * dm <= wMin;
+        // band rendering: only part of the input rows is valid (PassCtx::validRows) - every sample has to be tested against it
+        safe = safe && validRowCount >= (uint32_t)inYSH.h;
     }
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
@@ -187,11 +190,14 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     cu = fabsf(cu) > 0.5f ? cu0 - ox : cu;
                     cv = fabsf(cv) > 0.5f ? cv0 - oy : cv;
                     off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
-                    lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
                 }
                 su[k] = cu; sv[k] = cv;
                 // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
                 const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
+                if (!SAFE) {
+                    off[k] = off[k] || (ty - validY0) >= validRowCount; // a row no neighbouring band has sent counts as off-screen (band rendering)
+                    lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
+                }
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
                 if (SIG) { const uint32_t o = off[k] ? 1u : 0u; sampleParityX |= ((tx + o) & 1u) << (i0 + k); sampleParityY |= ((ty + o) & 1u) << (i0 + k); }
                 di[k] = SAME_GRID ? ti[k]
@@ -325,7 +331,10 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
         c.splitTiming("texel packing");
     }
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
-#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk, sig
+    int validLo, validHi;
+    c.validRowRange(c.sampled[2].h, &validLo, &validHi);
+#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk, sig, \
+                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0)
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
         if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \

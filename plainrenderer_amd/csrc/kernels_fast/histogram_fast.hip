@@ -1,0 +1,160 @@
+// histogramPerTile.comp for the PLR_MATH_FAST set: the same integer bin counts as kernels/exposure_tonemap.hip (bit exact), without
+// a software logarithm per pixel.
+//
+// bin(l) = uint(127 * clamp((log(l) - log(min)) / range, 0, 1)) is monotone in l, so it equals the number of thresholds t[1..127] with
+// l >= t[b], where t[b] is the smallest float whose bin is >= b. The table is bisected once per pass with the exact function
+// (launchHistogramThresholds, kernels/exposure_tonemap.hip) and lives in LDS; per pixel the hardware log2 gives a guess that is at most
+// one bin off and two table compares settle it. tests/test_exposure_tonemap.py checks the table-driven bin against the exact one for every
+// one of the 2^32 float bit patterns (plr_debug_verify_histogram_thresholds).
+// The luminance itself (dot product, division by the previous exposure) keeps the shader's IEEE operation sequence, hence:
+// PLR_BUILD_FLAGS: -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include "../backend.h"
+#include "../device/shading_common.h"
+#include "../../../include/plr.h"
+
+namespace plr {
+
+int launchHistogramThresholds(uint32_t* thresholds, uint32_t nBins, float minLuminance, float maxLuminance, hipStream_t stream);                            // kernels/exposure_tonemap.hip
+int launchHistogramExactBins(uint8_t* out, uint32_t first, uint32_t count, uint32_t nBins, float minLuminance, float maxLuminance, hipStream_t stream);
+
+namespace fasthist {
+
+constexpr uint32_t kBins = 128; // the table-driven kernel is built for the reference's 128 bins (RenderFrontend.cpp:46); other counts take the general kernel
+
+// thr: kBins floats, thr[0] = 0 (every non-negative value), thr[b] ascending; NaN entries (unreachable bins) compare false
+PLR_DI uint32_t tableBin(float luminance, const float* thr, float guessScale, float guessBias) {
+    // guess from the hardware log2: bin ~ (log2(l) * ln2 - logMin) / range * 127, at most one off before the compares
+    const float g = __builtin_amdgcn_logf(luminance) * guessScale + guessBias; // -inf for l = 0, NaN for NaN / negative input
+    int gi = (int)__builtin_amdgcn_fmed3f(g, 0.f, (float)(kBins - 2u));        // 0 .. 126; NaN -> 0
+    // exact: count of thresholds <= l among {gi, gi + 1}, everything below gi is <=, everything above gi + 1 is >
+    const float lo = thr[gi], hi = thr[gi + 1];
+    gi += (luminance >= hi) ? 1 : 0;
+    gi -= (luminance >= lo) ? 0 : 1;
+    return (uint32_t)max(gi, 0);
+}
+
+__global__ __launch_bounds__(256) void histogramPerTileFastKernel(ImgView src, const LightBuffer* __restrict__ light, uint32_t* __restrict__ perTile,
+                                                                  const uint32_t* __restrict__ thresholds, float guessScale, float guessBias, uint32_t tilesX, uint32_t tileY0) {
+    __shared__ uint32_t localHistogram[kBins];
+    __shared__ float thr[kBins];
+    const uint32_t t = threadIdx.x;
+    const uint32_t tileY = blockIdx.y + tileY0;
+    if (t < kBins) { localHistogram[t] = 0u; thr[t] = u2f(thresholds[t]); }
+    __syncthreads();
+    const int x0 = (int)blockIdx.x * 32 + (int)(t & 7u) * 4;
+    const int y = (int)tileY * 32 + (int)(t >> 3);
+    const float prevExposure = light->previousFrameExposure;
+    uint32_t texels[4] = {0u, 0u, 0u, 0u};
+    int nValid = 0;
+    if (y < src.h && x0 < src.w) {
+        const uint32_t* row = (const uint32_t*)src.ptr + (size_t)y * (size_t)src.w;
+        nValid = min(4, src.w - x0);
+        if (nValid == 4 && ((src.w & 3) == 0)) {
+            const uint4 v = *(const uint4*)(row + x0);
+            texels[0] = v.x; texels[1] = v.y; texels[2] = v.z; texels[3] = v.w;
+        } else {
+            for (int i = 0; i < nValid; i++) texels[i] = row[x0 + i];
+        }
+    }
+    const uint32_t lane = t & 63u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool valid = i < nValid;
+        uint32_t bin = 0u;
+        if (valid) {
+            const vec3 c = unpackR11G11B10(texels[i]);
+            const float luminance = dot(c, vec3(0.2126f, 0.7152f, 0.0722f)) / prevExposure; // :28-30, :53 (IEEE, as in the shader)
+            bin = tableBin(luminance, thr, guessScale, guessBias);
+        }
+        // wave vote aggregation: neighbouring pixels mostly share a bin. The leading bins are peeled with one LDS atomic each (the leader's bin
+        // travels through v_readlane, not the LDS crossbar), stragglers add individually.
+        bool pending = valid;
+        for (int round = 0; round < 3; round++) {
+            const unsigned long long todo = __ballot(pending);
+            if (todo == 0ull) break;
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t leaderBin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+            const unsigned long long same = __ballot(pending && bin == leaderBin);
+            if ((int)lane == leader) atomicAdd(&localHistogram[leaderBin], (uint32_t)__popcll(same));
+            if (bin == leaderBin) pending = false;
+        }
+        if (pending) atomicAdd(&localHistogram[bin], 1u);
+    }
+    __syncthreads();
+    const uint32_t tileIndex = blockIdx.x + tileY * tilesX;
+    if (t < kBins) {
+        // bin b of a tile is written back only if the reference invocation with localIndexFlat == b lies inside the image (see kernels/exposure_tonemap.hip)
+        const int rx = (int)blockIdx.x * 32 + (int)(t & 31u), ry = (int)tileY * 32 + (int)(t >> 5);
+        if (rx < src.w && ry < src.h) perTile[(size_t)tileIndex * kBins + t] = localHistogram[t];
+    }
+}
+
+struct TableKey { float minL, maxL; uint32_t valid; };
+
+static int launch(const PassCtx& c) {
+    if (!c.hasSampled(2) || c.sampled[2].fmt != F_R11G11B10 || !c.hasSbuf(3) || !c.hasSbuf(0)) return kUseGeneralKernel;
+    const uint32_t nBins = c.specUint(0, 64u);
+    const float minL = c.specFloat(1, 1.f), maxL = c.specFloat(2, 100.f);
+    if (nBins != kBins || !(minL > 0.f) || !(maxL > minL)) return kUseGeneralKernel;
+    const ImgView& src = c.sampled[2];
+    const uint32_t tilesX = divUp((unsigned)src.w, 32u), tilesY = divUp((unsigned)src.h, 32u);
+    if (c.sbuf[0].size < (size_t)tilesX * tilesY * nBins * 4u || c.sbuf[3].size < sizeof(LightBuffer)) return kUseGeneralKernel;
+    const PassCtx::RowSpan rs = c.rowSpan((int)tilesY, 1);
+    if (rs.y1 <= rs.y0) return 0;
+    // per-pass scratch: the threshold table (built on the first launch: the specialisation constants of a pass never change)
+    const bool fresh = c.scratchSize && *c.scratchSize < kBins * 4u;
+    uint32_t* thresholds = (uint32_t*)c.scratch(kBins * 4u);
+    if (!thresholds) return c.fail(-2, "histogramPerTile: cannot allocate scratch memory");
+    if (fresh) if (launchHistogramThresholds(thresholds, kBins, minL, maxL, c.stream)) return c.fail(-2, "histogramPerTile: threshold table launch failed");
+    // guess = (log2(l) * ln2 - log(min)) / (log(max) - log(min)) * 127
+    const double logMin = std::log((double)minL), range = std::log((double)maxL) - logMin;
+    const float guessScale = (float)(0.6931471805599453 / range * (kBins - 1u)), guessBias = (float)(-logMin / range * (kBins - 1u));
+    const dim3 grid(std::min(c.dispatch[0], tilesX), (unsigned)(rs.y1 - rs.y0));
+    histogramPerTileFastKernel<<<grid, 256, 0, c.stream>>>(src, (const LightBuffer*)c.sbuf[3].ptr, (uint32_t*)c.sbuf[0].ptr, thresholds, guessScale, guessBias, tilesX, (uint32_t)rs.y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ---- exhaustive verification (plr_debug_verify_histogram_thresholds)
+__global__ void verifyKernel(const uint32_t* __restrict__ thresholds, const uint8_t* __restrict__ exact, uint32_t first, uint32_t count, float guessScale, float guessBias,
+                             unsigned long long* __restrict__ mismatches) {
+    __shared__ float thr[kBins];
+    if (threadIdx.x < kBins) thr[threadIdx.x] = u2f(thresholds[threadIdx.x]);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (tableBin(u2f(first + i), thr, guessScale, guessBias) != (uint32_t)exact[i]) atomicAdd(mismatches, 1ull);
+}
+
+} // namespace fasthist
+
+static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
+PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
+} // namespace plr
+
+using namespace plr;
+
+// compares the table-driven bin with the shader's formula for all 2^32 float bit patterns; *out_mismatches must come back 0
+extern "C" int plr_debug_verify_histogram_thresholds(float min_luminance, float max_luminance, uint64_t* out_mismatches) {
+    if (!out_mismatches || !(min_luminance > 0.f) || !(max_luminance > min_luminance)) return setLastError(PLR_ERR_INVALID_ARGUMENT, "plr_debug_verify_histogram_thresholds: invalid argument");
+    uint32_t* thresholds = nullptr;
+    uint8_t* exact = nullptr;
+    unsigned long long* counter = nullptr;
+    const uint32_t chunk = 1u << 26;
+    if (hipMalloc((void**)&thresholds, fasthist::kBins * 4u) != hipSuccess || hipMalloc((void**)&exact, chunk) != hipSuccess || hipMalloc((void**)&counter, 8) != hipSuccess)
+        return setLastError(PLR_ERR_HIP, "plr_debug_verify_histogram_thresholds: hipMalloc failed");
+    hipMemset(counter, 0, 8);
+    int rc = launchHistogramThresholds(thresholds, fasthist::kBins, min_luminance, max_luminance, nullptr);
+    const double logMin = std::log((double)min_luminance), range = std::log((double)max_luminance) - logMin;
+    const float guessScale = (float)(0.6931471805599453 / range * (fasthist::kBins - 1u)), guessBias = (float)(-logMin / range * (fasthist::kBins - 1u));
+    for (uint64_t first = 0; first < (1ull << 32) && !rc; first += chunk) {
+        rc = launchHistogramExactBins(exact, (uint32_t)first, chunk, fasthist::kBins, min_luminance, max_luminance, nullptr);
+        fasthist::verifyKernel<<<chunk / 256u, 256>>>(thresholds, exact, (uint32_t)first, chunk, guessScale, guessBias, counter);
+    }
+    unsigned long long host = ~0ull;
+    const hipError_t e = hipMemcpy(&host, counter, 8, hipMemcpyDeviceToHost);
+    hipFree(thresholds); hipFree(exact); hipFree(counter);
+    if (rc || e != hipSuccess) return setLastError(PLR_ERR_HIP, "plr_debug_verify_histogram_thresholds: launch failed");
+    *out_mismatches = host;
+    return PLR_OK;
+}

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH,
         const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
         const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
         const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
-        const vec2 nz = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
+        // exact UNORM8 decode (c / 255, an IEEE quotient in this file): a noise value of 255 must be exactly 1 - then sinTheta is exactly 0 and L = N, and
+        // for a horizontal N the sky LUT's v coordinate sits on its sqrt-steep horizon, where 2e-4 rad of direction is half a LUT row
+        const uint32_t nzTexel = ((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)];
+        const vec2 nz(decodeUnorm8(nzTexel & 0xffu), decodeUnorm8(nzTexel >> 8));
         const vec3 N = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, vec2(u, v)).xyz() * 2.f - 1.f;
         mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
         const vec3 rayOrigin = pWorld + N * 0.2f;

@@ -9,6 +9,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "fused_gi.h"
+#include "../device/fastmath.h"
 
 namespace plr {
 namespace faststream {
@@ -554,6 +555,24 @@ static int launchApplyBloomTonemap(const PassCtx* const* ctxs, size_t count) {
 } // namespace faststream
 
 int launchTemporalGiFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return faststream::launchTemporalGiImpl(c, &target); }
+// ---- probe: the PLR_MATH_FAST sky LUT lookup (device/fastmath.h) for n directions, same arguments as the oracle's orc_kat_sky_lut
+__global__ void skyLutEvalKernel(ImgView lut, const float* __restrict__ dirs, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const vec3 c = fastm::sampleSkyLut(vec3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), lut);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+}
+int launchSkyLutProbe(const ImgView& lut, const float* dirs, float* out, int64_t n) {
+    if (lut.fmt != F_R11G11B10 || lut.d > 1) return setLastError(-1, "plr_debug_sky_lut_eval: the sky LUT must be a 2D R11G11B10 image");
+    float *dd = nullptr, *dout = nullptr;
+    if (hipMalloc((void**)&dd, n * 12) != hipSuccess || hipMalloc((void**)&dout, n * 12) != hipSuccess) return setLastError(-2, "plr_debug_sky_lut_eval: hipMalloc failed");
+    hipMemcpy(dd, dirs, n * 12, hipMemcpyHostToDevice);
+    skyLutEvalKernel<<<(unsigned)((n + 255) / 256), 256>>>(lut, dd, dout, n);
+    const hipError_t e = hipGetLastError();
+    hipMemcpy(out, dout, n * 12, hipMemcpyDeviceToHost);
+    hipFree(dd); hipFree(dout);
+    return e == hipSuccess ? 0 : setLastError(-2, "plr_debug_sky_lut_eval: launch failed");
+}
 static int fused_apply_bloom_tonemap(const PassCtx* const* ctxs, size_t count) { return faststream::launchApplyBloomTonemap(ctxs, count); }
 PLR_REGISTER_FUSION("applyBloom + tonemapping", fused_apply_bloom_tonemap, "applyBloom.comp", "tonemapping.comp");
 static int faststream_apply_bloom(const PassCtx& c) { return faststream::launchApplyBloom(c); }

@@ -278,7 +278,10 @@ def sky_lut(w=200, h=100):
     u = (np.arange(w, dtype=np.float32)[None, :] + 0.5) / w
     horizon = np.exp(-((v - 0.5) ** 2) * 40.0)
     rgb = np.stack([0.2 + 0.8 * horizon + 0.1 * np.sin(u * 6.28), 0.35 + 0.6 * horizon + 0 * u, 0.7 * (1 - v) + 0.4 * horizon + 0 * u], -1)
-    rgb = rgb * np.where(v[..., None] > 0.52, 0.15, 1.0)
+    # darker below the horizon: a smooth ramp over eight rows (a real sky LUT has no texel-to-texel jumps; a hard step here would turn every
+    # 1/256 flip of a bilinear filter weight - a legitimate fixed-point decision - into a several-percent difference between two implementations)
+    t = np.clip((v - 0.50) / 0.08, 0.0, 1.0)
+    rgb = rgb * (1.0 - 0.85 * (t * t * (3.0 - 2.0 * t)))[..., None]
     return pixfmt.pack_r11g11b10((rgb * 0.02).astype(np.float32))
 
 

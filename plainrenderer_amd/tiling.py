@@ -205,6 +205,9 @@ class Exchange:
 
     def run(self, exchange_id, stream_ptr):
         from .frame import EXCHANGE_BEGIN, EXCHANGE_END, EXCHANGE_ID_MASK
+        from .frame import EXCHANGE_HISTOGRAM
+        if (exchange_id & EXCHANGE_ID_MASK) == EXCHANGE_HISTOGRAM:
+            self.calls = []  # the histogram all-reduce is the first exchange of a frame: the log covers one frame
         self.calls.append(exchange_id)
         phase, exchange_id = exchange_id & (EXCHANGE_BEGIN | EXCHANGE_END), exchange_id & EXCHANGE_ID_MASK
         if phase == EXCHANGE_END:

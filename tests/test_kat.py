@@ -282,3 +282,31 @@ def test_gpu_sampler_probe_3d_bit_exact(backend):
             a = backend.debugSamplerEval(gimg, filt, addr, uvw)
             b = orc.sampler_eval(oimg, filt, addr, uvw)
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (filt, addr)
+
+
+# ------------------------------------------------------------------ fast sky LUT lookup against the oracle's
+@pytest.mark.gpu
+def test_gpu_fast_sky_lut_lookup_follows_the_oracle(backend):
+    """sampleSkyLut (sky.inc:85-116) of the PLR_MATH_FAST set uses polynomial acos / atan (device/fastmath.h). Directions sweep the sphere, densely
+    around the horizon (where the LUT's v coordinate is sqrt-steep) and the poles (where |V.y| can exceed 1 by an ulp): per channel within one
+    R11G11B10 code of the oracle's lookup wherever the LUT is smooth; the synthetic LUT's 6.7x step between two rows is reported separately."""
+    from plainrenderer_amd import synth
+    r = rng(90)
+    lut = synth.sky_lut()
+    n = 400000
+    v = r.normal(size=(n, 3))
+    v[: n // 2, 1] *= 0.02                      # near the horizon
+    v[n // 2: n // 2 + 2000, [0, 2]] *= 1e-4    # near the poles
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = v.astype(np.float32)
+    v[0], v[1], v[2], v[3] = (0, 1, 0), (0, -1, 0), (0, np.float32(1.0000001), 0), (1, 0, 0)
+    gimg = backend.createImage(image_desc_2d(200, 100, F.R11G11B10_uFloat), lut)
+    got = backend.debugSkyLutEval(gimg, v)
+    ref = orc.kat_sky_lut(orc.Img(lut, 200, 100, F.R11G11B10_uFloat), v)
+    assert np.isfinite(got).all()
+    d = np.abs(pixfmt.pack_r11g11b10(got).astype(np.int64)[:, None] >> np.array([0, 11, 22]) & np.array([0x7ff, 0x7ff, 0x3ff]))
+    d = np.abs(d - (pixfmt.pack_r11g11b10(ref).astype(np.int64)[:, None] >> np.array([0, 11, 22]) & np.array([0x7ff, 0x7ff, 0x3ff])))
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9)
+    worst = np.argsort(-rel.max(1))[:5]
+    print("sky lookup: max code diff %d, >1 code: %d of %d, max rel %.3g at V=%s (got %s ref %s)" % (d.max(), (d > 1).any(1).sum(), n, rel.max(), v[worst[0]], got[worst[0]], ref[worst[0]]))
+    assert d.max() <= 1, "fast sky lookup differs from the oracle's by more than one R11G11B10 code"
