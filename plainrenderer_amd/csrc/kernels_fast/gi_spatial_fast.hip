@@ -100,20 +100,37 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     {
         // the shader's own sequence (:33-41), bit for bit: see the note at the top of this file
 #pragma clang fp contract(off)
-        tsx = 1.f / (float)outYSH.w; tsy = 1.f / (float)outYSH.h;
+        // IEEE quotient / square root by one Newton step on v_rcp_f32 / v_rsq_f32: the residual is exact (FMA), so the result is the correctly rounded
+        // one except when the true value sits within ~2^-24 ulp of a rounding boundary - a third of the instructions of the full division
+        // sequence, and the 19 divisions + 5 square roots of the frame are most of its cost. (A miss shows up as sample flips in the parity test.)
+        auto quot = [](float a, float b, float rb) { const float q = a * rb; return __builtin_fmaf(__builtin_fmaf(-b, q, a), rb, q); };
+        auto root = [](float x) { const float r = __builtin_amdgcn_rsqf(x), s0 = x * r; return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * r, s0); };
+        auto unit = [&](vec3 a) { // vecmath.h normalize: a * (1 / sqrt(dot(a, a)))
+            const float len = root(dot(a, a));
+            return a * quot(1.f, len, rcpf(len));
+        };
+        const float fw = (float)outYSH.w, fh = (float)outYSH.h;
+        tsx = quot(1.f, fw, rcpf(fw)); tsy = quot(1.f, fh, rcpf(fh));
         u0 = ((float)px + 0.5f) * tsx; v0 = ((float)py + 0.5f) * tsy;
+        const float tanH = g->cameraTanFovHalf, aspect = g->cameraAspectRatio;
         auto pixelToWorldExact = [&](float u, float v) -> vec3 {
             const int x = min(max((int)floorf(u * dW), 0), dwi - 1), y = min(max((int)floorf(v * dH), 0), dhi - 1);
             const float depth = Texel<DEPTH_FMT>::load(depthTexture.ptr, (size_t)y * (size_t)dwi + (size_t)x).x;
-            const float depthLinear = linearizeDepth(depth, nearP, farP);
-            const vec3 cameraToPixel = -calculateViewDirectionFromPixel(vec2(u * 2.f - 1.f, v * 2.f - 1.f), fwd, up, right, g->cameraTanFovHalf, g->cameraAspectRatio);
-            return camPos + cameraToPixel / dot(cameraToPixel, fwd) * depthLinear;
+            const float den = farP + (-depth + 1.f) * (nearP - farP);                 // linearizeDepth (linearDepth.inc:5-8)
+            const float depthLinear = quot(nearP * farP, den, rcpf(den));
+            const float ndx = u * 2.f - 1.f, ndy = v * 2.f - 1.f;
+            vec3 V = -fwd;                                                            // calculateViewDirectionFromPixel (screenToWorld.inc:4-9)
+            V += tanH * ndy * up;
+            V -= tanH * aspect * ndx * right;
+            const vec3 cameraToPixel = -unit(V);
+            const float d = dot(cameraToPixel, fwd), rd = rcpf(d);
+            return camPos + vec3(quot(cameraToPixel.x, d, rd), quot(cameraToPixel.y, d, rd), quot(cameraToPixel.z, d, rd)) * depthLinear;
         };
         pCenter = pixelToWorldExact(u0, v0);
         const vec3 pRight = pixelToWorldExact(u0 + 1.f * tsx, v0 + 0.f * tsy);
         const vec3 pUp = pixelToWorldExact(u0 + 0.f * tsx, v0 + 1.f * tsy);
-        T = radiusWorld * normalize(pCenter - pRight);
-        B = radiusWorld * normalize(pCenter - pUp);
+        T = radiusWorld * unit(pCenter - pRight);
+        B = radiusWorld * unit(pCenter - pUp);
     }
     const int nwi = normalTexture.w, nhi = normalTexture.h;
     vec3 N;

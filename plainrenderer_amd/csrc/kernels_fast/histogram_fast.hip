@@ -56,29 +56,25 @@ __global__ __launch_bounds__(256) void histogramPerTileFastKernel(ImgView src, c
             for (int i = 0; i < nValid; i++) texels[i] = row[x0 + i];
         }
     }
-    const uint32_t lane = t & 63u;
+    // A lane's four neighbouring pixels usually fall into one or two bins: they are merged in registers, then every distinct bin is one LDS
+    // atomic. (The exact kernel peels the wave's leading bins with ballots; on images with per-pixel variation the wave holds a dozen bins and
+    // the votes cost more than the atomics they save. A constant image serialises 64 lanes on one counter: 64 cycles per wave instruction,
+    // ~13 us for a 4K frame in the worst case.)
+    uint32_t bins[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const bool valid = i < nValid;
-        uint32_t bin = 0u;
-        if (valid) {
-            const vec3 c = unpackR11G11B10(texels[i]);
-            const float luminance = dot(c, vec3(0.2126f, 0.7152f, 0.0722f)) / prevExposure; // :28-30, :53 (IEEE, as in the shader)
-            bin = tableBin(luminance, thr, guessScale, guessBias);
-        }
-        // wave vote aggregation: neighbouring pixels mostly share a bin. The leading bins are peeled with one LDS atomic each (the leader's bin
-        // travels through v_readlane, not the LDS crossbar), stragglers add individually.
-        bool pending = valid;
-        for (int round = 0; round < 3; round++) {
-            const unsigned long long todo = __ballot(pending);
-            if (todo == 0ull) break;
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t leaderBin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
-            const unsigned long long same = __ballot(pending && bin == leaderBin);
-            if ((int)lane == leader) atomicAdd(&localHistogram[leaderBin], (uint32_t)__popcll(same));
-            if (bin == leaderBin) pending = false;
-        }
-        if (pending) atomicAdd(&localHistogram[bin], 1u);
+        const vec3 c = unpackR11G11B10(texels[i]);
+        const float luminance = dot(c, vec3(0.2126f, 0.7152f, 0.0722f)) / prevExposure; // :28-30, :53 (IEEE, as in the shader)
+        bins[i] = i < nValid ? tableBin(luminance, thr, guessScale, guessBias) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (bins[i] == 0xffffffffu) continue;
+        uint32_t count = 1u;
+#pragma unroll
+        for (int j = i + 1; j < 4; j++)
+            if (bins[j] == bins[i]) { count++; bins[j] = 0xffffffffu; }
+        atomicAdd(&localHistogram[bins[i]], count);
     }
     __syncthreads();
     const uint32_t tileIndex = blockIdx.x + tileY * tilesX;

@@ -1,5 +1,6 @@
-"""Compute cost of ONE band of a row-partitioned frame on one GPU, without the exchange: how much of a 4K frame's time a
-7680 x ~1080 band of the 7680 x (1080 N) frame costs (halo rows are computed redundantly). Usage: python tools/band_cost.py [N] [band index]"""
+"""Redundant compute of band rendering, measured on ONE GPU without the exchange: the N bands of the 7680 x (1080 N) frame are rendered one after
+the other (each with the halo rows it recomputes, producers split into edge / interior dispatches as the overlapped exchange records them) and
+their times are summed and compared with the time of the unpartitioned frame.   python tools/band_cost.py [N]   (default 4: the 8K frame)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,38 +10,58 @@ from plainrenderer_amd import RenderBackend, tiling
 from plainrenderer_amd.frame import FramePipeline
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-index = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 class A: pass
-args = A(); args.grid = 16; args.sdf_res = 64; args.shadow_res = 2048; args.steps = 40; args.warmup = 5; args.profile_frames = 10
+args = A(); args.grid = 16; args.sdf_res = 64; args.shadow_res = 2048; args.steps = 40; args.warmup = 5; args.profile_frames = 0
 w, h = 7680, 1080 * n
-band = tiling.band_rows(h, n, index)
-be = RenderBackend(w, h, device=0)
-fp = FramePipeline(be, w, h, shadow_map_res=2048, band_row_begin=band[0], band_row_end=band[1])
-if "--split" in sys.argv:  # record the producers edge-rows-first as the overlapped exchange does (callbacks that move nothing)
-    fp.set_exchange_callback(lambda exchange_id, stream: None)
-scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, band)
-inputs.upload(fp)
-be.waitForGPUIdle()
-for i in range(args.warmup):
-    fp.frame(cams[i + 1], 1 / 60, 0.5)
-be.waitForGPUIdle()
-t0 = time.perf_counter()
-for i in range(args.steps):
-    fp.frame(cams[i + 6], 1 / 60, 0.5)
-be.waitForGPUIdle()
-ms = (time.perf_counter() - t0) * 1e3 / args.steps
-be.setPassTiming(True)
-acc = {}
-for i in range(args.profile_frames):
-    fp.frame(cams[i + 46], 1 / 60, 0.5)
-    for name, t in be.getRenderpassTimings():
-        acc.setdefault(name, []).append(t)
-rows = band[1] - band[0]
-print("band %d of %d: rows %d..%d (%d rows of %d), %dx%d pixels = %.3f of a 3840x2160 frame" % (index, n, band[0], band[1], rows, h, w, rows, w * rows / 8294400.0))
-print("frame time %.3f ms (no exchange)" % ms)
-tot = 0
-for name, v in sorted(acc.items(), key=lambda kv: -np.mean(kv[1]) * len(kv[1])):
-    t = np.mean(v) * len(v) / args.profile_frames
-    tot += t
-    print("  %-40s %.4f ms" % (name, t))
-print("  sum %.3f ms" % tot)
+
+
+def measure(band):
+    be = RenderBackend(w, h, device=0)
+    kw = dict(band_row_begin=band[0], band_row_end=band[1]) if band else {}
+    fp = FramePipeline(be, w, h, shadow_map_res=2048, **kw)
+    if band:
+        fp.set_exchange_callback(lambda exchange_id, stream: None)  # callbacks that move nothing: the recording is the multi-GPU one
+    scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, band)
+    inputs.upload(fp)
+    be.waitForGPUIdle()
+    for i in range(args.warmup):
+        fp.frame(cams[i + 1], 1 / 60, 0.5)
+    be.waitForGPUIdle()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        fp.frame(cams[i + 6], 1 / 60, 0.5)
+    be.waitForGPUIdle()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    be.setPassTiming(True)
+    acc = {}
+    for i in range(8):
+        fp.frame(cams[i + 20], 1 / 60, 0.5)
+        for name, t in be.getRenderpassTimings():
+            acc[name] = acc.get(name, 0.0) + t / 8
+    fp.destroy()
+    be.shutdown()
+    return ms, acc
+
+
+full, full_passes = measure(None)
+print("unpartitioned %dx%d frame: %.3f ms" % (w, h, full))
+total, band_passes = 0.0, {}
+for i in range(n):
+    band = tiling.band_rows(h, n, i)
+    ms, acc = measure(band)
+    total += ms
+    for k, v in acc.items():
+        band_passes[k] = band_passes.get(k, 0.0) + v
+    print("band %d of %d (rows %d..%d): %.3f ms" % (i, n, band[0], band[1], ms))
+def group(d):  # fused launches of the unpartitioned frame count towards their passes' group
+    g = {}
+    for k, v in d.items():
+        key = "GI trace + filters" if ("Indirect" in k) else ("bloom" if "loom" in k or "Tonemap" in k else ("exposure" if "istogram" in k or "expose" in k else k.split(" + ")[0]))
+        g[key] = g.get(key, 0.0) + v
+    return g
+gf, gb = group(full_passes), group(band_passes)
+for k in sorted(gb, key=lambda k: -gb[k]):
+    print("  %-34s bands %.3f ms, unpartitioned %.3f ms (%+.1f %%)" % (k, gb[k], gf.get(k, 0.0), 100.0 * (gb[k] / gf[k] - 1.0) if gf.get(k) else 0.0))
+print("sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute; slowest band %.3f ms -> compute-only speed-up %.2fx on %d GPUs" % (
+    total, total / full, 100.0 * (total / full - 1.0), 0.0, 0.0, n) if False else
+      "sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute" % (total, total / full, 100.0 * (total / full - 1.0)))

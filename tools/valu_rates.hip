@@ -17,7 +17,7 @@ constexpr int ITER = 4096;
     for (int i = 0; i < ITER; i++) {                                                                                  \
         asm volatile(ASM(0) "\n" ASM(1) "\n" ASM(2) "\n" ASM(3) "\n" ASM(4) "\n" ASM(5) "\n" ASM(6) "\n" ASM(7)     \
                      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) \
-                     : "v"(b), "v"(c));                                                                               \
+                     : "v"(b), "v"(c) : "vcc", "s4", "s5", "s6");                                                     \
     }
 
 #define KERNEL(NAME, ASM)                                                                                             \
@@ -112,6 +112,9 @@ constexpr int ITER = 4096;
 #define A_LSHRREV(k) "v_lshrrev_b32 %" #k ", 16, %" #k
 #define A_CND64(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[4:5]"
 #define A_FMAK(k) "v_fmaak_f32 %" #k ", %" #k ", %8, 0x3f000000"
+#define A_CMPCND(k) "v_cmp_lt_f32 vcc, %" #k ", %8\nv_cndmask_b32 %" #k ", %" #k ", %9, vcc"
+#define A_CMPCND64(k) "v_cmp_lt_f32_e64 s[4:5], %" #k ", %8\nv_cndmask_b32_e64 %" #k ", %" #k ", %9, s[4:5]"
+#define A_CND_VCCSET(k) "v_cndmask_b32 %" #k ", %8, %9, vcc"
 #define A_MULSGPR(k) "v_mul_f32 %" #k ", s6, %" #k
 #define A_FMA2S(k) "v_fma_f32 %" #k ", %" #k ", s6, %8"
 
@@ -126,7 +129,7 @@ KERNEL(k_cvtpkrtz, A_CVTPKRTZ) KERNEL(k_min3, A_MIN3) KERNEL(k_ldexp, A_LDEXP) K
 KERNEL(k_and_or, A_AND_OR)
 KERNEL(k_or, A_OR) KERNEL(k_xor, A_XOR) KERNEL(k_subf, A_SUBF) KERNEL(k_min, A_MIN) KERNEL(k_maxi, A_MAXI) KERNEL(k_med3i, A_MED3I) KERNEL(k_dot2, A_DOT2)
 KERNEL(k_cvti, A_CVTI) KERNEL(k_cvtub, A_CVTUB) KERNEL(k_add3, A_ADD3) KERNEL(k_lshrrev, A_LSHRREV) KERNEL(k_cnd64, A_CND64) KERNEL(k_fmak, A_FMAK)
-KERNEL(k_mulsgpr, A_MULSGPR) KERNEL(k_fma2s, A_FMA2S)
+KERNEL(k_mulsgpr, A_MULSGPR) KERNEL(k_fma2s, A_FMA2S) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_cmpcnd64, A_CMPCND64) KERNEL(k_cndvccset, A_CND_VCCSET)
 PK_KERNEL(k_pkfma, A_PKFMA) PK_KERNEL(k_pkmul, A_PKMUL) PK_KERNEL(k_pkadd, A_PKADD) PK_KERNEL(k_pkmov, A_PKMOV)
 
 typedef void (*kern_t)(float*, unsigned long long*, float, float);
@@ -152,6 +155,7 @@ int main() {
         {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1}, {"v_sub_f32", k_subf, 1}, {"v_min_f32", k_min, 1}, {"v_max_i32", k_maxi, 1}, {"v_med3_i32", k_med3i, 1},
         {"v_dot2_f32_f16", k_dot2, 1}, {"v_cvt_i32_f32", k_cvti, 1}, {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_add3_u32", k_add3, 1}, {"v_lshrrev_b32", k_lshrrev, 1},
         {"v_cndmask_b32_e64 (sgpr mask)", k_cnd64, 1}, {"v_fmaak_f32 (literal)", k_fmak, 1}, {"v_mul_f32 (sgpr src)", k_mulsgpr, 1}, {"v_fma_f32 (sgpr src)", k_fma2s, 1},
+        {"v_cmp + v_cndmask (vcc) pair", k_cmpcnd, 2}, {"v_cmp_e64 + v_cndmask_e64 (s[4:5]) pair", k_cmpcnd64, 2}, {"v_cndmask_b32 vcc, no dst dependency", k_cndvccset, 1},
         {"v_mov_b32_dpp row_shr:1", k_dpp_shr, 1}, {"v_add_f32_dpp quad_perm", k_dpp_add, 1}, {"v_mov_b32_dpp row_bcast:15", k_dpp_bcast, 1},
         {"v_permlane32_swap", k_permlane, 1}, {"ds_bpermute_b32 (+wait)", k_bperm, 1}, {"ds_swizzle_b32 (+wait)", k_swiz, 1},
     };
@@ -169,7 +173,7 @@ int main() {
         CHECK(hipEventSynchronize(e1));
         float ms;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
-        const double instrPerSimd = (double)ITER * 8 * wavesPerSimd;
+        const double instrPerSimd = (double)ITER * 8 * wavesPerSimd * t.instrPerSlot;
         const double secPerInstr = ms * 1e-3 / instrPerSimd;
         printf("%-30s %10.3f %12.2f %14.1f\n", t.name, ms, secPerInstr * 2.4e9, instrPerSimd * cus * 4 / (ms * 1e-3) / 1e9);
     }
