@@ -7,6 +7,7 @@
 // one wave with the float accumulation kept in bin order so results stay bit-identical to a scalar evaluation.
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../kernels_fast/fused_front.h"
 
 namespace plr {
 
@@ -292,14 +293,11 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
 // the eight XCDs' L2s); a thread's atomics have completed when its vmcnt reaches 0, the block's when all its threads passed the barrier.
 constexpr int kFusedExposureMaxBins = 256;
 struct ExposureScratch { uint32_t ticket; uint32_t pad[3]; uint32_t acc[kFusedExposureMaxBins]; };
-__global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
-                                                                    ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
-                                                                    const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog) {
-    __shared__ float term[kMaxExposureBins];
-    __shared__ uint32_t counted[kMaxExposureBins];
-    __shared__ uint32_t totals[kFusedExposureMaxBins];
-    __shared__ uint32_t isLast;
-    const uint32_t t0 = blockIdx.x * kCombineTilesPerBlock, t1 = min(t0 + kCombineTilesPerBlock, nTiles);
+// block `block` of `blocks`; term / counted / totals / isLast: the block's LDS
+PLR_DI void histogramCombineExposeBlock(uint32_t block, uint32_t blocks, const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
+                                        ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, const ImgView& transmissionLut, const GlobalUbo* __restrict__ g,
+                                        float minLuminanceLog, float maxLuminanceLog, float* term, uint32_t* counted, uint32_t* totals, uint32_t* isLast) {
+    const uint32_t t0 = block * kCombineTilesPerBlock, t1 = min(t0 + kCombineTilesPerBlock, nTiles);
     for (uint32_t bin = threadIdx.x; bin < nBins; bin += blockDim.x) {
         uint32_t sum = 0u, t = t0;
         for (; t + 8u <= t1; t += 8u) {
@@ -314,9 +312,9 @@ __global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's atomics have been performed
     __syncthreads();
-    if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    if (threadIdx.x == 0) *isLast = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == blocks - 1u ? 1u : 0u;
     __syncthreads();
-    if (!isLast) return;
+    if (!*isLast) return;
     for (uint32_t bin = threadIdx.x; bin < nBins; bin += blockDim.x) {
         const uint32_t v = __hip_atomic_exchange(&scratch->acc[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // read the total, leave zero for the next frame
         totals[bin] = v;
@@ -325,6 +323,31 @@ __global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32
     if (threadIdx.x == 0) __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x < 64) preExposeLightsWave(light, [&](int i) { return totals[i]; }, transmissionLut, g, (int)nBins, minLuminanceLog, maxLuminanceLog, term, counted, (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
+                                                                    ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
+                                                                    const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog) {
+    __shared__ float term[kMaxExposureBins];
+    __shared__ uint32_t counted[kMaxExposureBins];
+    __shared__ uint32_t totals[kFusedExposureMaxBins];
+    __shared__ uint32_t isLast;
+    histogramCombineExposeBlock(blockIdx.x, gridDim.x, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog, maxLuminanceLog, term, counted, totals, &isLast);
+}
+
+// launch 2 of the fused frame front (kernels_fast/fused_front.h): block 0 finishes the depth pyramid, the others are the exposure chain's
+__global__ __launch_bounds__(1024) void exposureChainAndPyramidTailKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
+                                                                          ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
+                                                                          const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog, HizParams tail,
+                                                                          int tailFirst, int tailTexelsA) {
+    extern __shared__ float2 pyramidTailLds[];
+    __shared__ float term[kMaxExposureBins];
+    __shared__ uint32_t counted[kMaxExposureBins];
+    __shared__ uint32_t totals[kFusedExposureMaxBins];
+    __shared__ uint32_t isLast;
+    if (blockIdx.x == 0) { fasthiz::hizTailBlock<1024>(tail, tailFirst, tailTexelsA, pyramidTailLds); return; }
+    histogramCombineExposeBlock(blockIdx.x - 1u, gridDim.x - 1u, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog, maxLuminanceLog, term, counted,
+                                totals, &isLast);
 }
 
 static int launchPreExposeLights(const PassCtx& c) {
@@ -343,8 +366,7 @@ static int launchPreExposeLights(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("preExposeLights.comp", launchPreExposeLights);
 
-static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
-    if (count != 3) return kUseGeneralKernel;
+int prepareExposureChain(const PassCtx* const* ctxs, ExposureChainPlan* out) {
     const PassCtx &reset = *ctxs[0], &comb = *ctxs[1], &expo = *ctxs[2];
     const uint32_t nBins = comb.specUint(0, 64u);
     if (nBins == 0 || nBins > (uint32_t)kFusedExposureMaxBins || reset.specUint(0, 64u) != nBins || (uint32_t)expo.specInt(0, 64) != nBins) return kUseGeneralKernel;
@@ -358,10 +380,31 @@ static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
     if (!(minL > 0.f) || !(maxL > 0.f)) return kUseGeneralKernel;
     ExposureScratch* scratch = (ExposureScratch*)comb.scratch(sizeof(ExposureScratch)); // zero-initialised by the backend, kept zero by the kernel
     if (!scratch) return comb.fail(-2, "histogramCombineTiles: cannot allocate scratch memory");
-    histogramCombineExposeKernel<<<divUp(nTiles, kCombineTilesPerBlock), 128, 0, comb.stream>>>((const uint32_t*)comb.sbuf[0].ptr, (uint32_t*)comb.sbuf[1].ptr, nBins, nTiles, scratch,
-                                                                                                 (LightBuffer*)expo.sbuf[0].ptr, expo.sampled[2], expo.global, hostDetLog(minL), hostDetLog(maxL));
-    PLR_CHECK_LAUNCH(comb);
+    out->perTile = (const uint32_t*)comb.sbuf[0].ptr; out->histogram = (uint32_t*)comb.sbuf[1].ptr; out->nBins = nBins; out->nTiles = nTiles;
+    out->blocks = divUp(nTiles, kCombineTilesPerBlock); out->scratch = scratch; out->light = expo.sbuf[0].ptr; out->transmissionLut = expo.sampled[2]; out->global = expo.global;
+    out->minLuminanceLog = hostDetLog(minL); out->maxLuminanceLog = hostDetLog(maxL);
     return 0;
+}
+static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
+    if (count != 3) return kUseGeneralKernel;
+    ExposureChainPlan e;
+    if (int rc = prepareExposureChain(ctxs, &e)) return rc;
+    histogramCombineExposeKernel<<<e.blocks, 128, 0, ctxs[1]->stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light, e.transmissionLut,
+                                                                        e.global, e.minLuminanceLog, e.maxLuminanceLog);
+    PLR_CHECK_LAUNCH(*ctxs[1]);
+    return 0;
+}
+int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream) {
+    static bool ldsRaised = false;
+    if (!ldsRaised) {
+        if (hipFuncSetAttribute((const void*)exposureChainAndPyramidTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+            return setLastError(-2, "exposure chain + pyramid tail: cannot raise the dynamic LDS limit");
+        ldsRaised = true;
+    }
+    exposureChainAndPyramidTailKernel<<<e.blocks + 1u, 1024, h.tailLdsBytes, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
+                                                                                        e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst, h.tailTexelsA);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : setLastError(-2, std::string("exposure chain + pyramid tail launch failed: ") + hipGetErrorString(err));
 }
 PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles + preExposeLights", launchFusedExposureChain, "histogramReset.comp", "histogramCombineTiles.comp", "preExposeLights.comp");
 

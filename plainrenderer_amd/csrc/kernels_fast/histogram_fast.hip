@@ -11,6 +11,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../../../include/plr.h"
+#include "fused_front.h"
 
 namespace plr {
 
@@ -33,15 +34,28 @@ PLR_DI uint32_t tableBin(float luminance, const float* thr, float guessScale, fl
     return (uint32_t)max(gi, 0);
 }
 
-__global__ __launch_bounds__(256) void histogramPerTileFastKernel(ImgView src, const LightBuffer* __restrict__ light, uint32_t* __restrict__ perTile,
-                                                                  const uint32_t* __restrict__ thresholds, float guessScale, float guessBias, uint32_t tilesX, uint32_t tileY0) {
-    __shared__ uint32_t localHistogram[kBins];
-    __shared__ float thr[kBins];
+struct HistParams {
+    ImgView src;
+    const LightBuffer* light;
+    uint32_t* perTile;
+    const uint32_t* thresholds;
+    float guessScale, guessBias;
+    uint32_t tilesX, tileY0, gridX, gridY;
+};
+
+// one 32x32 tile; localHistogram / thr: kBins entries of LDS each
+PLR_DI void histogramTileBlock(const HistParams& p, uint32_t tileXIndex, uint32_t tileYIndex, uint32_t* localHistogram, float* thr) {
+    const ImgView& src = p.src;
+    const LightBuffer* __restrict__ light = p.light;
+    uint32_t* __restrict__ perTile = p.perTile;
+    const uint32_t* __restrict__ thresholds = p.thresholds;
+    const float guessScale = p.guessScale, guessBias = p.guessBias;
+    const uint32_t tilesX = p.tilesX;
     const uint32_t t = threadIdx.x;
-    const uint32_t tileY = blockIdx.y + tileY0;
+    const uint32_t tileY = tileYIndex + p.tileY0;
     if (t < kBins) { localHistogram[t] = 0u; thr[t] = u2f(thresholds[t]); }
     __syncthreads();
-    const int x0 = (int)blockIdx.x * 32 + (int)(t & 7u) * 4;
+    const int x0 = (int)tileXIndex * 32 + (int)(t & 7u) * 4;
     const int y = (int)tileY * 32 + (int)(t >> 3);
     const float prevExposure = light->previousFrameExposure;
     uint32_t texels[4] = {0u, 0u, 0u, 0u};
@@ -77,17 +91,40 @@ __global__ __launch_bounds__(256) void histogramPerTileFastKernel(ImgView src, c
         atomicAdd(&localHistogram[bins[i]], count);
     }
     __syncthreads();
-    const uint32_t tileIndex = blockIdx.x + tileY * tilesX;
+    const uint32_t tileIndex = tileXIndex + tileY * tilesX;
     if (t < kBins) {
         // bin b of a tile is written back only if the reference invocation with localIndexFlat == b lies inside the image (see kernels/exposure_tonemap.hip)
-        const int rx = (int)blockIdx.x * 32 + (int)(t & 31u), ry = (int)tileY * 32 + (int)(t >> 5);
+        const int rx = (int)tileXIndex * 32 + (int)(t & 31u), ry = (int)tileY * 32 + (int)(t >> 5);
         if (rx < src.w && ry < src.h) perTile[(size_t)tileIndex * kBins + t] = localHistogram[t];
     }
 }
 
+__global__ __launch_bounds__(256) void histogramPerTileFastKernel(HistParams p) {
+    __shared__ uint32_t localHistogram[kBins];
+    __shared__ float thr[kBins];
+    histogramTileBlock(p, blockIdx.x, blockIdx.y, localHistogram, thr);
+}
+
+// launch 1 of the fused frame front (fused_front.h): the per-tile histogram's blocks and the depth pyramid's quad blocks in one grid, four to one
+// while both last (the first kind is bound by VALU / LDS, the second by HBM: interleaved, every CU hosts both)
+template <bool DOWNSCALE>
+__global__ __launch_bounds__(256) void histogramAndPyramidKernel(HistParams p, fasthiz::QuadParams q, uint32_t histBlocks, uint32_t hizBlocks, uint32_t hizGridX) {
+    __shared__ uint32_t localHistogram[kBins];
+    __shared__ float thr[kBins];
+    const uint32_t b = blockIdx.x;
+    const uint32_t paired = min(hizBlocks, histBlocks / 4u), remHist = histBlocks - 4u * paired;
+    bool isHiz;
+    uint32_t index;
+    if (b < 5u * paired) { const uint32_t g = b / 5u, r = b % 5u; isHiz = r == 4u; index = isHiz ? g : 4u * g + r; }
+    else { const uint32_t rem = b - 5u * paired; isHiz = rem >= remHist; index = isHiz ? paired + (rem - remHist) : 4u * paired + rem; }
+    if (isHiz) fasthiz::hizQuadBlock<4, DOWNSCALE>(q, (int)(index % hizGridX), (int)(index / hizGridX));
+    else histogramTileBlock(p, index % p.gridX, index / p.gridX, localHistogram, thr);
+}
+
 struct TableKey { float minL, maxL; uint32_t valid; };
 
-static int launch(const PassCtx& c) {
+// 0: *out filled (gridY == 0: nothing to do); kUseGeneralKernel; < 0
+static int prepare(const PassCtx& c, HistParams* out) {
     if (!c.hasSampled(2) || c.sampled[2].fmt != F_R11G11B10 || !c.hasSbuf(3) || !c.hasSbuf(0)) return kUseGeneralKernel;
     const uint32_t nBins = c.specUint(0, 64u);
     const float minL = c.specFloat(1, 1.f), maxL = c.specFloat(2, 100.f);
@@ -96,7 +133,6 @@ static int launch(const PassCtx& c) {
     const uint32_t tilesX = divUp((unsigned)src.w, 32u), tilesY = divUp((unsigned)src.h, 32u);
     if (c.sbuf[0].size < (size_t)tilesX * tilesY * nBins * 4u || c.sbuf[3].size < sizeof(LightBuffer)) return kUseGeneralKernel;
     const PassCtx::RowSpan rs = c.rowSpan((int)tilesY, 1);
-    if (rs.y1 <= rs.y0) return 0;
     // per-pass scratch: the threshold table (built on the first launch: the specialisation constants of a pass never change)
     const bool fresh = c.scratchSize && *c.scratchSize < kBins * 4u;
     uint32_t* thresholds = (uint32_t*)c.scratch(kBins * 4u);
@@ -104,11 +140,36 @@ static int launch(const PassCtx& c) {
     if (fresh) if (launchHistogramThresholds(thresholds, kBins, minL, maxL, c.stream)) return c.fail(-2, "histogramPerTile: threshold table launch failed");
     // guess = (log2(l) * ln2 - log(min)) / (log(max) - log(min)) * 127
     const double logMin = std::log((double)minL), range = std::log((double)maxL) - logMin;
-    const float guessScale = (float)(0.6931471805599453 / range * (kBins - 1u)), guessBias = (float)(-logMin / range * (kBins - 1u));
-    const dim3 grid(std::min(c.dispatch[0], tilesX), (unsigned)(rs.y1 - rs.y0));
-    histogramPerTileFastKernel<<<grid, 256, 0, c.stream>>>(src, (const LightBuffer*)c.sbuf[3].ptr, (uint32_t*)c.sbuf[0].ptr, thresholds, guessScale, guessBias, tilesX, (uint32_t)rs.y0);
+    out->src = src; out->light = (const LightBuffer*)c.sbuf[3].ptr; out->perTile = (uint32_t*)c.sbuf[0].ptr; out->thresholds = thresholds;
+    out->guessScale = (float)(0.6931471805599453 / range * (kBins - 1u)); out->guessBias = (float)(-logMin / range * (kBins - 1u));
+    out->tilesX = tilesX; out->tileY0 = (uint32_t)rs.y0; out->gridX = std::min(c.dispatch[0], tilesX); out->gridY = rs.y1 > rs.y0 ? (uint32_t)(rs.y1 - rs.y0) : 0u;
+    return 0;
+}
+static int launch(const PassCtx& c) {
+    HistParams p;
+    if (int rc = prepare(c, &p)) return rc;
+    if (p.gridY == 0 || p.gridX == 0) return 0;
+    histogramPerTileFastKernel<<<dim3(p.gridX, p.gridY), 256, 0, c.stream>>>(p);
     PLR_CHECK_LAUNCH(c);
     return 0;
+}
+
+// the six passes of the frame front as two launches (fused_front.h)
+static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
+    if (count != 6) return kUseGeneralKernel;
+    HistParams hp;
+    if (int rc = prepare(*ctxs[0], &hp)) return rc;
+    if (hp.gridX == 0 || hp.gridY == 0) return kUseGeneralKernel;
+    ExposureChainPlan ep;
+    if (int rc = prepareExposureChain(ctxs + 1, &ep)) return rc;
+    if (ep.perTile != hp.perTile) return kUseGeneralKernel; // the combine must read what the per-tile pass writes
+    fasthiz::Plan zp;
+    if (int rc = fasthiz::prepare(*ctxs[4], ctxs[5], &zp)) return rc;
+    // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
+    const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
+    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX);
+    PLR_CHECK_LAUNCH(*ctxs[0]);
+    return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream);
 }
 
 // ---- exhaustive verification (plr_debug_verify_histogram_thresholds)
@@ -126,6 +187,9 @@ __global__ void verifyKernel(const uint32_t* __restrict__ thresholds, const uint
 
 static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
 PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
+static int fused_frame_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
+PLR_REGISTER_FUSION("frame front: histogram + exposure chain || depth pyramid", fused_frame_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+                    "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp");
 } // namespace plr
 
 using namespace plr;

@@ -115,3 +115,16 @@ def test_backend_fails_loudly_without_gpu():
     from plainrenderer_amd import PlrError, RenderBackend
     with pytest.raises(PlrError):
         RenderBackend(64, 64)
+
+
+def test_every_hot_path_shader_has_a_registered_kernel():
+    """the shader -> kernel registry is static: a launcher that loses its registration (an edit gone wrong) is caught here, without a GPU"""
+    from plainrenderer_amd import supported_shaders
+    have = set(supported_shaders())
+    need = {"histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp", "preExposeLights.comp", "tonemapping.comp", "depthHiZPyramid.comp",
+            "temporalFilter.comp", "temporalSupersampling.comp", "colorToLuminance.comp", "bloomDownsample.comp", "bloomUpsample.comp", "applyBloom.comp",
+            "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp", "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp",
+            "filterIndirectDiffuseTemporal.comp", "indirectLightUpscale.comp", "brdfLut.comp", "deferredShading.comp", "sdfDebugVisualisation.comp", "lightMatrix.comp",
+            "skyTransmissionLut.comp", "skyMultiscatterLut.comp", "skyLut.comp", "froxelVolumeMaterial.comp", "froxelLightScattering.comp",
+            "volumeLightingReprojection.comp", "volumetricLightingIntegration.comp"}
+    assert need <= have, sorted(need - have)
