@@ -73,7 +73,9 @@ PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries
     "Temporal filtering": ["plr::fasttaa::temporalFilter"], "Indirect diffuse SDF trace": ["plr::fasttrace::sdfDiffuseTrace"],
     "Indirect lighting upscale": ["plr::faststream::indirectLightUpscale"], "Indirect diffuse temporal filter": ["plr::faststream::temporalGiFilter"],
     "Depth min/max pyramid": ["plr::hizBase", "plr::hizTail"], "Tonemap": ["plr::faststream::tonemapping"], "Apply bloom": ["plr::faststream::applyBloom"],
-    "Histogram per tile": ["plr::histogramPerTile"],
+    "Histogram per tile": ["plr::fasthist::histogramPerTile"], "Apply bloom + Tonemap": ["plr::faststream::applyBloomTonemap"],
+    "Histogram per tile + Histogram reset + Histogram combine tiles + Pre-expose lights + Depth min/max pyramid + Depth downscale": ["plr::fasthist::histogramAndPyramid", "plr::exposureChainAndPyramidTail"],
+    "SDF camera frustum culling + SDF camera tile culling": ["plr::frustumAndTileCulling"], "Bloom Upsample mip 0": ["plr::fastbloom::bloomUpsampleQuad"],
 }
 
 
@@ -88,6 +90,7 @@ def pmc_traffic(pass_name):
     total, found = 0, False
     for line in open(files[-1]):
         if any(line.startswith(p) for p in prefixes):
+            # mean bytes per dispatch of that kernel; a kernel launched k times per frame by several passes (bloom levels) is not attributed here
             total += int(line.strip().split(",")[-1])
             found = True
     return (total, os.path.basename(files[-1])) if found else (None, None)

@@ -681,6 +681,13 @@ void PassCtx::splitTiming(const char* label) const {
     (void)beginSegment(pass);
 }
 
+void PassCtx::splitTimingBetween(const PassCtx& first, const PassCtx& second) {
+    if (!g || !g->timingNow || g->segments.empty() || !first.passName || !second.passName) return;
+    g->segments.back().name = first.passName;
+    if (endSegment() != PLR_OK) return;
+    (void)beginSegment(second.passName);
+}
+
 // ---------------------------------------------------------------- stream scheduler
 // The recorded executions are launched in order, but not all on one stream: an execution only has to wait for the earlier ones it
 // has a hazard with (read-after-write, write-after-read, write-after-write on an allocation it binds). Executions without such a
@@ -779,6 +786,7 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     x.ctx.scratchSize = &p.scratchSize;
     x.ctx.debugSig = g->debugSig;
     x.ctx.debugSigWords = g->debugSigWords;
+    x.ctx.passName = p.name.c_str();
 }
 
 static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {

@@ -87,6 +87,10 @@ struct PassCtx {
     // pass timing (plr_set_pass_timing): a pass that launches an auxiliary kernel before its main one calls this between the two, so the
     // auxiliary part is reported as its own entry "<pass name> (<label>)" and the pass entry times the main kernel alone
     void splitTiming(const char* label) const;
+    // a fused launcher (pass fusion) that covers its passes with one kernel EACH calls this between two of them: the running timing segment is
+    // closed under the first pass's own name and a new one opened under the second's, so per-pass timings stay per pass
+    static void splitTimingBetween(const PassCtx& first, const PassCtx& second);
+    const char* passName = nullptr; // debug label of the pass (plr_get_renderpass_timings)
 };
 
 typedef int (*LaunchFn)(const PassCtx&);

@@ -26,6 +26,7 @@
 // PLR_BUILD_FLAGS: -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../device/xcd.h"
 #include "fused_gi.h"
 #include <cstdlib>
 #include <type_traits>
@@ -36,8 +37,10 @@ PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Work-groups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with a private 4 MB L2. The filter gathers
 // from a ~100-pixel disc around every pixel, so neighbouring tiles share most of their footprint: with the natural mapping the
-// eight L2s each fetch their own copy (measured 364 MB of L2 fills for 62 MB of inputs). The remap below hands every XCD one
-// contiguous horizontal band of tiles, so a band's sliding window stays resident in that XCD's L2.
+// eight L2s each fetch their own copy (measured 364 MB of L2 fills for 62 MB of inputs). The remap hands every XCD one contiguous
+// horizontal chunk of tile rows at a time and walks it column by column (device/xcd.h), so the tiles in flight on an XCD form a
+// compact block whose footprint stays in that XCD's L2 at any frame width. Walking a band row by row instead (round 1) holds
+// (rows in flight + 100) x the whole image width: 4 MB at 4K (half-res 1920 x 16-byte texels), 7 MB at 8K.
 // The 32 disc samples are the same for every pixel: the shader seeds its RNG with wang_hash(frameIndexMod4 + filterIndex)
 // (:53), so there are only five distinct tables. They are derived once (first launch of a pass) into the pass's scratch memory:
 // table[key][0..31] = sqrt(r0), [32..63] = cos(2 pi r1), [64..95] = sin(2 pi r1). The filter kernel reads them with uniform
@@ -77,14 +80,14 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
-                                                               int coverW, int coverH, int yBase, int tilesX, int numTiles, int chunk, uint32_t* __restrict__ sig,
+                                                               int coverW, int coverH, int yBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
                                                                uint32_t validY0, uint32_t validRowCount) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
-    const int tile = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-    if (tile >= numTiles) return;
-    const int px = (tile % tilesX) * TX + (int)(threadIdx.x % TX);
-    const int py = yBase + (tile / tilesX) * TY + (int)(threadIdx.x / TX);
+    int tileX, tileY;
+    if (!xcdWalk(tilesX, tilesY, chunkRows, tileX, tileY)) return; // device/xcd.h: the note on the XCDs' L2s above
+    const int px = tileX * TX + (int)(threadIdx.x % TX);
+    const int py = yBase + tileY * TY + (int)(threadIdx.x / TX);
     if (px >= coverW || py >= coverH) return;
 
     const float nearP = g->nearPlane, farP = g->farPlane;
@@ -325,8 +328,10 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
     // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
     constexpr int TXv = 64, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
-    const int numTiles = tilesX * tilesY, chunk = (numTiles + 7) / 8;
-    const dim3 grid((unsigned)chunk * 8u);
+    // chunks of ~17 tile rows (68 pixel rows) measured best at 4K (2 per XCD: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
+    const int chunksPerXcd = std::max(1, (tilesY + 68) / 136);
+    const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
+    const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
     const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h;
     if (prepacked && !sameGrid) return c.fail(-1, "filterIndirectDiffuseSpatial: prepacked launch without a packed grid");
@@ -350,7 +355,7 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
     int validLo, validHi;
     c.validRowRange(c.sampled[2].h, &validLo, &validHi);
-#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, numTiles, chunk, sig, \
+#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, tilesY, chunkRows, sig, \
                          (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0)
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
@@ -386,6 +391,7 @@ static int fusedProducerAndSpatial(const PassCtx* const* ctxs, size_t count, boo
     if (int rc = spatialFilterPackTarget(filt, &target)) return rc; // kUseGeneralKernel: not a packed configuration
     const int rc = traceProducer ? launchTraceFastPacking(prod, target) : launchTemporalGiFastPacking(prod, target);
     if (rc) return rc; // kUseGeneralKernel included: nothing has been launched yet
+    PassCtx::splitTimingBetween(prod, filt); // two kernels: each pass keeps its own timing entry
     return launchSpatialFilterFastPrepacked(filt);
 }
 static int fused_trace_spatial(const PassCtx* const* ctxs, size_t count) { return fusedProducerAndSpatial(ctxs, count, true); }

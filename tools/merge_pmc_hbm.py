@@ -19,6 +19,7 @@ with open(out, "w") as fh:
     fh.write("# calibrated on tonemapping (reads 4 B/px) and applyBloom (reads 8 B/px): 2*FETCH_SIZE matches the algorithmic reads within 0.5 %\n")
     fh.write("kernel,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,traffic_bytes\n")
     for r in rows: fh.write("%s,%d,%.1f,%.1f,%d\n" % r)
-for a, b in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"), ("kernel_stats.csv", "_kernel_stats.csv"), ("pass_table.txt", "_pass_table.txt")):
-    shutil.copy(os.path.join(src, a), os.path.join(ROOT, "profiles", tag + b))
+for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pass_table.txt", "bench_1080p.json", "bench_8k.json", "parity_4k.txt", "valu_rates.txt", "band_cost.txt"):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(ROOT, "profiles", tag + "_" + a))
 print(open(out).read()[:1500])
