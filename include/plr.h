@@ -241,6 +241,10 @@ int plr_debug_read_decision_signature(uint32_t* out_words, size_t words);
 /* the PLR_MATH_FAST luminance histogram bins by comparison against a threshold table instead of evaluating the logarithm (kernels_fast/
  * histogram_fast.hip): this checks the table-driven bin against the shader's formula for ALL 2^32 float bit patterns. *out_mismatches must be 0. */
 int plr_debug_verify_histogram_thresholds(float min_luminance, float max_luminance, uint64_t* out_mismatches);
+/* the PLR_MATH_FAST R11G11B10 encoder (device/image.h packR11G11B10Fast) against the exact one for ALL 2^32 float bit patterns, per channel width:
+ * out[0] / out[1] = patterns whose 11-bit / 10-bit code differs, out[2] = largest code difference, out[3] = largest input bit pattern that differs
+ * (expected: differences of one code, only below 2^-14 = 0x38800000; see the encoder's comment) */
+int plr_debug_verify_r11g11b10_fast(uint64_t* out4);
 /* the PLR_MATH_FAST sky LUT lookup (polynomial acos / atan, device/fastmath.h) for n directions (3 floats each) -> n x 3 floats; the oracle's
  * orc_kat_sky_lut takes the same arguments */
 int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, float* out_rgb, int64_t n);

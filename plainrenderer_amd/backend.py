@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_host_callback_execution", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_verify_r11g11b10_fast", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_host_callback_execution", "plr_upload_image_rows",
 ]
 
 
@@ -511,6 +511,13 @@ class RenderBackend:
         n = C.c_uint64()
         self._check(self.lib.plr_debug_verify_histogram_thresholds(C.c_float(min_luminance), C.c_float(max_luminance), C.byref(n)))
         return n.value
+
+    def debugVerifyR11G11B10Fast(self):
+        """-> (patterns whose 11-bit code differs, whose 10-bit code differs, largest code difference, largest differing input bit pattern) of the
+        PLR_MATH_FAST R11G11B10 encoder against the exact one over all 2^32 float bit patterns"""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.plr_debug_verify_r11g11b10_fast(out))
+        return tuple(int(v) for v in out)
 
     def setPassFusion(self, enabled):
         self._check(self.lib.plr_set_pass_fusion(C.c_int(int(bool(enabled)))))

@@ -71,8 +71,39 @@ template <int M> PLR_DI uint32_t encodeUFloat(float v) {
     return r;
 }
 
-PLR_DI uint32_t packR11G11B10(vec3 c) {
+PLR_DI uint32_t packR11G11B10Exact(vec3 c) {
     return encodeUFloat<6>(c.x) | (encodeUFloat<6>(c.y) << 11) | (encodeUFloat<5>(c.z) << 22);
+}
+
+// PLR_MATH_FAST encoder. encodeUFloat above spends most of its ~19 instructions per channel (11 of them half-rate compares / selects) on inputs
+// that almost never occur; every pass that writes a colour image pays that three times per pixel (the bloom chain: half its instructions).
+// Here a value v in [0, 64768) is scaled by 2^-112, which moves the 5-bit exponent range onto fp32's biased exponents 1 .. 30 and the
+// subnormals of the small format onto fp32's subnormals, so ONE integer round-to-nearest-even of the fp32 bit pattern yields exponent and
+// mantissa for normal and subnormal results alike (4 instructions, carries into the exponent included). Anything else - negative, -0,
+// infinity, NaN, or large enough to round past the largest finite value of the 10-bit channel - sends the whole wave through the exact
+// encoder (one max3 + compare per pixel to find out). Same bits as the exact encoder except for the double rounding in the subnormal range
+// (the scaling itself rounds once to fp32's subnormal grid): one code for < 2^-17 of the inputs below 2^-14, none above; counted for all
+// 2^32 bit patterns by plr_debug_verify_r11g11b10_fast.
+template <int M> PLR_DI uint32_t encodeUFloatInRange(float v) {
+    constexpr int shift = 23 - M;
+    const uint32_t s = f2u(v * 1.92592994438723585e-34f); // 2^-112, exact for results that stay normal
+    return (s + ((1u << (shift - 1)) - 1u) + ((s >> shift) & 1u)) >> shift;
+}
+constexpr uint32_t kUFloatInRangeLimit = 0x477d0000u; // 64768.0f: 10-bit channel's largest finite value 64512 + half a step (ties round up to infinity)
+// out of line: the exact encoder is ~60 instructions and a kernel may encode at dozens of sites
+__device__ __attribute__((noinline)) inline uint32_t packR11G11B10OutOfRange(float x, float y, float z) { return packR11G11B10Exact(vec3(x, y, z)); }
+PLR_DI uint32_t packR11G11B10Fast(vec3 c) {
+    const uint32_t top = max(max(f2u(c.x), f2u(c.y)), f2u(c.z)); // as unsigned integers negative values and NaNs are the largest
+    if (__builtin_amdgcn_ballot_w64(top >= kUFloatInRangeLimit) != 0ull) return packR11G11B10OutOfRange(c.x, c.y, c.z); // wave-uniform
+    return encodeUFloatInRange<6>(c.x) | (encodeUFloatInRange<6>(c.y) << 11) | (encodeUFloatInRange<5>(c.z) << 22);
+}
+
+PLR_DI uint32_t packR11G11B10(vec3 c) {
+#ifdef PLR_FAST_SET
+    return packR11G11B10Fast(c);
+#else
+    return packR11G11B10Exact(c);
+#endif
 }
 
 PLR_DI float decodeUnorm8(uint32_t c) { return (float)c / 255.0f; }

@@ -9,6 +9,7 @@
 // per tap exactly as in the sampler contract; only the association order of the weighted sum differs from the exact kernel.
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include <cstdlib>
 
 namespace plr {
 namespace fastbloom {
@@ -124,6 +125,14 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6)) * QY;
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
+    float wt[2][5], wb[2][3]; // in vector registers: see the strip kernel below
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) { wt[p][j] = pw.tent[p][j]; asm volatile("" : "+v"(wt[p][j])); }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { wb[p][j] = pw.box[p][j]; asm volatile("" : "+v"(wb[p][j])); }
+    }
     const int sw = source.w, sh = source.h;
     const uint32_t* src = (const uint32_t*)source.ptr;
     const bool interiorX = k >= 2 && k + 2 < sw;
@@ -143,15 +152,15 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             const vec3 col = unpackR11G11B10(t[c]);
-            h0 = h0 + col * pw.tent[0][c];
-            h1 = h1 + col * pw.tent[1][c];
+            h0 = h0 + col * wt[0][c];
+            h1 = h1 + col * wt[1][c];
         }
 #pragma unroll
         for (int q = 0; q < QY; q++) {
             const int j = r - q;
             if (j < 0 || j > 4) continue;
-            acc[q][0][0] = acc[q][0][0] + h0 * pw.tent[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * pw.tent[0][j];
-            acc[q][1][0] = acc[q][1][0] + h0 * pw.tent[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * pw.tent[1][j];
+            acc[q][0][0] = acc[q][0][0] + h0 * wt[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * wt[0][j];
+            acc[q][1][0] = acc[q][1][0] + h0 * wt[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * wt[1][j];
         }
     }
     if (!lowest) {
@@ -168,15 +177,15 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const vec3 col = unpackR11G11B10(t[c]);
-                h0 = h0 + col * pw.box[0][c];
-                h1 = h1 + col * pw.box[1][c];
+                h0 = h0 + col * wb[0][c];
+                h1 = h1 + col * wb[1][c];
             }
 #pragma unroll
             for (int q = 0; q < QY; q++) {
                 const int j = r - q;
                 if (j < 0 || j > 2) continue;
-                acc[q][0][0] = acc[q][0][0] + h0 * pw.box[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * pw.box[0][j];
-                acc[q][1][0] = acc[q][1][0] + h0 * pw.box[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * pw.box[1][j];
+                acc[q][0][0] = acc[q][0][0] + h0 * wb[0][j]; acc[q][0][1] = acc[q][0][1] + h1 * wb[0][j];
+                acc[q][1][0] = acc[q][1][0] + h0 * wb[1][j]; acc[q][1][1] = acc[q][1][1] + h1 * wb[1][j];
             }
         }
     }
@@ -192,6 +201,100 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
             if (X + 1 < coverW) *(uint2*)orow = make_uint2(p0, p1); // X is even and the row pitch is even: 8-byte aligned
             else orow[0] = p0;
         }
+}
+
+// ---- the same filter with the lanes of a wave holding neighbouring source columns (the quad kernel's 175 instructions per output are
+// mostly texel decodes: each lane decodes the 5 x 6 + 3 x 4 texels of its own footprint although its neighbours decode four fifths of the
+// same texels). Lane l of a wave holds source column k0 - 2 + l: it loads and decodes ONE texel per source row, the horizontal filter takes
+// the neighbouring columns from the neighbouring lanes (DPP wave_shr / wave_shl, no LDS), lanes 2 .. 61 own two output columns each.
+// A wave walks kStripRows quad rows down its strip, all its loads issued up front. Every sum is accumulated in the quad kernel's order:
+// the results are the same bits.
+constexpr int kStripCols = 60, kStripRows = 8;
+PLR_DI float laneLeft(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true)); }  // wave_shr:1
+PLR_DI float laneRight(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true)); } // wave_shl:1
+PLR_DI vec3 laneLeft(const vec3& v) { return vec3(laneLeft(v.x), laneLeft(v.y), laneLeft(v.z)); }
+PLR_DI vec3 laneRight(const vec3& v) { return vec3(laneRight(v.x), laneRight(v.y), laneRight(v.z)); }
+
+template <bool LOWEST>
+__global__ __launch_bounds__(256) void bloomUpsampleStripKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, int coverW, int coverH, int yBase) {
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int kc = (int)blockIdx.x * kStripCols - 2 + lane;                          // the source column this lane holds
+    const int m0 = (yBase >> 1) + ((int)blockIdx.y * 4 + wave) * kStripRows;         // first quad row (= source row) of the wave
+    if (2 * m0 >= coverH) return; // wave-uniform
+    // the filter weights live in vector registers: a multiply-add that reads a scalar register issues at half rate (tools/valu_rates.hip),
+    // and nearly every instruction of this kernel is a multiply-add by one of these sixteen values
+    float wt[2][5], wb[2][3];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) { wt[p][j] = pw.tent[p][j]; asm volatile("" : "+v"(wt[p][j])); }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { wb[p][j] = pw.box[p][j]; asm volatile("" : "+v"(wb[p][j])); }
+    }
+    const int sw = source.w, sh = source.h;
+    const uint32_t* src = (const uint32_t*)source.ptr + clampi(kc, sw);
+    uint32_t ta[kStripRows + 4], tb[kStripRows + 2];
+#pragma unroll
+    for (int r = 0; r < kStripRows + 4; r++) ta[r] = src[(size_t)clampi(m0 - 2 + r, sh) * (size_t)sw];
+    if (!LOWEST) {
+        const int pwid = previous.w, phei = previous.h;
+        const uint32_t* prv = (const uint32_t*)previous.ptr + clampi(kc, pwid);
+#pragma unroll
+        for (int r = 0; r < kStripRows + 2; r++) tb[r] = prv[(size_t)clampi(m0 - 1 + r, phei) * (size_t)pwid];
+    }
+    // horizontally filtered rows for the two x parities: tent rows m0-2 .. , box rows m0-1 ..
+    vec3 h0[kStripRows + 4], h1[kStripRows + 4], g0[kStripRows + 2], g1[kStripRows + 2];
+    auto tentRow = [&](int r) {
+        const vec3 c2 = unpackR11G11B10(ta[r]);
+        const vec3 c1 = laneLeft(c2), c0 = laneLeft(c1), c3 = laneRight(c2), c4 = laneRight(c3);
+        vec3 a(0.f), b(0.f);
+        a = a + c0 * wt[0][0]; b = b + c0 * wt[1][0];
+        a = a + c1 * wt[0][1]; b = b + c1 * wt[1][1];
+        a = a + c2 * wt[0][2]; b = b + c2 * wt[1][2];
+        a = a + c3 * wt[0][3]; b = b + c3 * wt[1][3];
+        a = a + c4 * wt[0][4]; b = b + c4 * wt[1][4];
+        h0[r] = a; h1[r] = b;
+    };
+    auto boxRow = [&](int r) {
+        const vec3 c1 = unpackR11G11B10(tb[r]);
+        const vec3 c0 = laneLeft(c1), c2 = laneRight(c1);
+        vec3 a(0.f), b(0.f);
+        a = a + c0 * wb[0][0]; b = b + c0 * wb[1][0];
+        a = a + c1 * wb[0][1]; b = b + c1 * wb[1][1];
+        a = a + c2 * wb[0][2]; b = b + c2 * wb[1][2];
+        g0[r] = a; g1[r] = b;
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++) tentRow(r);
+    if (!LOWEST) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) boxRow(r);
+    }
+    const bool outputLane = lane >= 2 && lane < 2 + kStripCols && 2 * kc < coverW;
+    const bool both = 2 * kc + 1 < coverW;
+    uint32_t* out = (uint32_t*)target.ptr + 2 * kc;
+#pragma unroll
+    for (int q = 0; q < kStripRows; q++) {
+        tentRow(q + 4);
+        if (!LOWEST) boxRow(q + 2);
+#pragma unroll
+        for (int py = 0; py < 2; py++) {
+            vec3 a(0.f), b(0.f);
+#pragma unroll
+            for (int j = 0; j < 5; j++) { a = a + h0[q + j] * wt[py][j]; b = b + h1[q + j] * wt[py][j]; }
+            if (!LOWEST) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) { a = a + g0[q + j] * wb[py][j]; b = b + g1[q + j] * wb[py][j]; }
+            }
+            const int y = 2 * (m0 + q) + py;
+            if (y < coverH && outputLane) { // y >= yBase: m0 starts at yBase / 2 and yBase is even
+                uint32_t* orow = out + (size_t)y * (size_t)target.w;
+                const uint32_t p0 = packR11G11B10(a), p1 = packR11G11B10(b);
+                if (both) *(uint2*)orow = make_uint2(p0, p1); // 2 kc is even and the row pitch is even: 8-byte aligned
+                else orow[0] = p0;
+            }
+        }
+    }
 }
 
 // the 1D footprint of one tap (sampler rule of image.h:linearCoord) accumulated into weights over texels base .. base + n - 1
@@ -243,6 +346,16 @@ static int launch(const PassCtx& c) {
         const bool regular = target.w == 2 * source.w && target.h == 2 * source.h && (lowest || (c.sampled[1].w == source.w && c.sampled[1].h == source.h)) &&
                              source.w >= 5 && (yBase & 1) == 0 && (target.w & 1) == 0 && makeParityWeights(blurRadius, &pw);
         if (regular) {
+            // the strip kernel needs enough waves to fill the SIMDs (a wave is 60 x 8 quads): mip 0 of a 4K frame has 4320, mip 1 1088
+            static const int stripMinWaves = std::getenv("PLR_BLOOM_STRIP_MIN_WAVES") ? atoi(std::getenv("PLR_BLOOM_STRIP_MIN_WAVES")) : 2048;
+            const unsigned stripWaves = divUp((unsigned)divUp((unsigned)w, 2u), (unsigned)kStripCols) * divUp((unsigned)divUp((unsigned)(h - yBase), 2u), (unsigned)kStripRows);
+            if ((int)stripWaves >= stripMinWaves) {
+                const dim3 sgrid(divUp((unsigned)divUp((unsigned)w, 2u), (unsigned)kStripCols), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kStripRows));
+                if (lowest) bloomUpsampleStripKernel<true><<<sgrid, 256, 0, c.stream>>>(source, source, target, pw, w, h, yBase);
+                else bloomUpsampleStripKernel<false><<<sgrid, 256, 0, c.stream>>>(source, c.sampled[1], target, pw, w, h, yBase);
+                PLR_CHECK_LAUNCH(c);
+                return 0;
+            }
             constexpr int QY = 2; // 4: mip 0 35.0 vs 36.6 us, but the small mips lose more (fewer, longer waves)
             const dim3 qgrid(divUp((unsigned)divUp((unsigned)w, 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * QY));
             bloomUpsampleQuadKernel<QY><<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase);

@@ -584,3 +584,32 @@ PLR_REGISTER_SHADER_FAST("tonemapping.comp", faststream_tonemapping);
 PLR_REGISTER_SHADER_FAST("indirectLightUpscale.comp", faststream_upscale);
 PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseTemporal.comp", faststream_temporal_gi);
 } // namespace plr
+
+// ---- exhaustive check of the fast R11G11B10 encoder (include/plr.h plr_debug_verify_r11g11b10_fast)
+namespace plr {
+__global__ void verifyUFloatKernel(uint32_t first, unsigned long long* __restrict__ out) {
+    const uint32_t u = first + blockIdx.x * blockDim.x + threadIdx.x;
+    const float v = u2f(u);
+    // one channel at a time, the other two zero: a pattern the fast path does not take falls back to the exact encoder inside packR11G11B10Fast
+    const uint32_t fr = packR11G11B10Fast(vec3(v, 0.f, 0.f)) & 0x7ffu, er = encodeUFloat<6>(v);
+    const uint32_t fb = packR11G11B10Fast(vec3(0.f, 0.f, v)) >> 22, eb = encodeUFloat<5>(v);
+    if (fr != er) { atomicAdd(out + 0, 1ull); atomicMax(out + 2, (unsigned long long)(fr > er ? fr - er : er - fr)); atomicMax(out + 3, (unsigned long long)u); }
+    if (fb != eb) { atomicAdd(out + 1, 1ull); atomicMax(out + 2, (unsigned long long)(fb > eb ? fb - eb : eb - fb)); atomicMax(out + 3, (unsigned long long)u); }
+}
+} // namespace plr
+
+extern "C" int plr_debug_verify_r11g11b10_fast(uint64_t* out4) {
+    using namespace plr;
+    if (!out4) return setLastError(-1, "plr_debug_verify_r11g11b10_fast: null argument");
+    unsigned long long* dev = nullptr;
+    if (hipMalloc((void**)&dev, 32) != hipSuccess) return setLastError(-2, "plr_debug_verify_r11g11b10_fast: hipMalloc failed");
+    hipMemset(dev, 0, 32);
+    const uint32_t chunk = 1u << 28;
+    for (uint64_t first = 0; first < (1ull << 32); first += chunk) verifyUFloatKernel<<<chunk / 256u, 256>>>((uint32_t)first, dev);
+    unsigned long long host[4];
+    const hipError_t e = hipMemcpy(host, dev, 32, hipMemcpyDeviceToHost);
+    hipFree(dev);
+    if (e != hipSuccess) return setLastError(-2, "plr_debug_verify_r11g11b10_fast: kernel failed");
+    for (int i = 0; i < 4; i++) out4[i] = host[i];
+    return 0;
+}

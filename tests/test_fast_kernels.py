@@ -186,3 +186,16 @@ def test_gpu_fast_tonemap_within_one_lsb(fast, w, h):
     assert d.max() <= 1  # stated tolerance: +-1/255
     assert (d != 0).mean() < 0.03
     assert np.all(a[..., 3] == 255)
+
+
+@pytest.mark.gpu
+def test_fast_r11g11b10_encoder_against_the_exact_one_for_every_float(backend):
+    """device/image.h packR11G11B10Fast (every colour write of the PLR_MATH_FAST kernels) against the exact encoder, per channel width, over all
+    2^32 float bit patterns: negative values, infinities, NaNs and overflow take the exact encoder; in range the single integer rounding gives the
+    same code except where the 2^-112 scaling itself rounds (results below 2^-14) and lands on a tie: one code, a handful of patterns per binade"""
+    diff11, diff10, max_diff, last = backend.debugVerifyR11G11B10Fast()
+    print("PARITY r11g11b10_fast differing_11bit=%d differing_10bit=%d max_code_diff=%d largest_differing_pattern=0x%08x" % (diff11, diff10, max_diff, last))
+    assert max_diff <= 1
+    assert last < 0x38800000  # nothing at or above 2^-14 differs
+    # of the 0x38800000 positive patterns below 2^-14 fewer than 2^-17 may differ
+    assert diff11 < 0x38800000 >> 17 and diff10 < 0x38800000 >> 17

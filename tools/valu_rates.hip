@@ -79,6 +79,9 @@ constexpr int ITER = 4096;
 #define A_LOG(k) "v_log_f32 %" #k ", %" #k
 #define A_SIN(k) "v_sin_f32 %" #k ", %" #k
 #define A_DPP_SHR(k) "v_mov_b32_dpp %" #k ", %" #k " row_shr:1 row_mask:0xf bank_mask:0xf"
+#define A_DPP_WSHR(k) "v_mov_b32_dpp %" #k ", %" #k " wave_shr:1 row_mask:0xf bank_mask:0xf"
+#define A_DPP_WSHL(k) "v_mov_b32_dpp %" #k ", %" #k " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define A_DPP_FMAC(k) "v_fmac_f32_dpp %" #k ", %8, %9 row_shr:1 row_mask:0xf bank_mask:0xf"
 #define A_DPP_ADD(k) "v_add_f32_dpp %" #k ", %" #k ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
 #define A_DPP_BCAST(k) "v_mov_b32_dpp %" #k ", %" #k " row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define A_BPERM(k) "ds_bpermute_b32 %" #k ", %8, %" #k "\ns_waitcnt lgkmcnt(0)"
@@ -123,7 +126,7 @@ KERNEL(k_addu, A_ADDU) KERNEL(k_and, A_AND) KERNEL(k_lshl, A_LSHL) KERNEL(k_lshl
 KERNEL(k_bfe, A_BFE) KERNEL(k_perm, A_PERM) KERNEL(k_mov, A_MOV) KERNEL(k_cndmask, A_CNDMASK) KERNEL(k_cmp, A_CMP)
 KERNEL(k_cvtfu, A_CVTFU) KERNEL(k_cvtuf, A_CVTUF) KERNEL(k_cvtf16, A_CVTF16) KERNEL(k_cvtf32h, A_CVTF32H) KERNEL(k_floor, A_FLOOR) KERNEL(k_fract, A_FRACT)
 KERNEL(k_rcp, A_RCP) KERNEL(k_rsq, A_RSQ) KERNEL(k_sqrt, A_SQRT) KERNEL(k_exp, A_EXP) KERNEL(k_log, A_LOG) KERNEL(k_sin, A_SIN)
-KERNEL(k_dpp_shr, A_DPP_SHR) KERNEL(k_dpp_add, A_DPP_ADD) KERNEL(k_dpp_bcast, A_DPP_BCAST) KERNEL(k_bperm, A_BPERM) KERNEL(k_swiz, A_SWIZ)
+KERNEL(k_dpp_wshr, A_DPP_WSHR) KERNEL(k_dpp_wshl, A_DPP_WSHL) KERNEL(k_dpp_fmac, A_DPP_FMAC) KERNEL(k_dpp_shr, A_DPP_SHR) KERNEL(k_dpp_add, A_DPP_ADD) KERNEL(k_dpp_bcast, A_DPP_BCAST) KERNEL(k_bperm, A_BPERM) KERNEL(k_swiz, A_SWIZ)
 KERNEL(k_permlane, A_PERMLANE) KERNEL(k_fmamix, A_FMAMIX) KERNEL(k_pkfma16, A_PKFMA16) KERNEL(k_pkadd16, A_PKADD16) KERNEL(k_pkmax16, A_PKMAX16)
 KERNEL(k_cvtpkrtz, A_CVTPKRTZ) KERNEL(k_min3, A_MIN3) KERNEL(k_ldexp, A_LDEXP) KERNEL(k_alignbit, A_ALIGNBIT) KERNEL(k_bfi, A_BFI) KERNEL(k_xad, A_XOR3)
 KERNEL(k_and_or, A_AND_OR)
@@ -156,6 +159,7 @@ int main() {
         {"v_dot2_f32_f16", k_dot2, 1}, {"v_cvt_i32_f32", k_cvti, 1}, {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_add3_u32", k_add3, 1}, {"v_lshrrev_b32", k_lshrrev, 1},
         {"v_cndmask_b32_e64 (sgpr mask)", k_cnd64, 1}, {"v_fmaak_f32 (literal)", k_fmak, 1}, {"v_mul_f32 (sgpr src)", k_mulsgpr, 1}, {"v_fma_f32 (sgpr src)", k_fma2s, 1},
         {"v_cmp + v_cndmask (vcc) pair", k_cmpcnd, 2}, {"v_cmp_e64 + v_cndmask_e64 (s[4:5]) pair", k_cmpcnd64, 2}, {"v_cndmask_b32 vcc, no dst dependency", k_cndvccset, 1},
+        {"v_mov_b32_dpp wave_shr:1", k_dpp_wshr, 1}, {"v_mov_b32_dpp wave_shl:1 bound_ctrl", k_dpp_wshl, 1}, {"v_fmac_f32_dpp row_shr:1", k_dpp_fmac, 1},
         {"v_mov_b32_dpp row_shr:1", k_dpp_shr, 1}, {"v_add_f32_dpp quad_perm", k_dpp_add, 1}, {"v_mov_b32_dpp row_bcast:15", k_dpp_bcast, 1},
         {"v_permlane32_swap", k_permlane, 1}, {"ds_bpermute_b32 (+wait)", k_bperm, 1}, {"ds_swizzle_b32 (+wait)", k_swiz, 1},
     };
