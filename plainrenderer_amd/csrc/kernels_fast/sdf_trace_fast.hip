@@ -25,6 +25,9 @@ namespace fasttrace {
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
 
+#ifndef PLR_TRACE_OCC
+#define PLR_TRACE_OCC
+#endif
 struct Volume {
     const uint16_t* p;
     int w, h, d;
@@ -175,7 +178,7 @@ struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
 // SIG: also write the decision signature of every pixel (plr_debug_set_decision_signature; bit layout in oracle/oracle.h)
 // PACK: also write the packed texel the spatial filter gathers (fused_gi.h); 0 = no, else the format of packDepth (F_R16F / F_D32)
 template <bool STRICT_CUTOFF, bool SIG, int PACK>
-__global__ __launch_bounds__(256) void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
+__global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,

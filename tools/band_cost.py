@@ -9,7 +9,7 @@ import bench
 from plainrenderer_amd import RenderBackend, tiling
 from plainrenderer_amd.frame import FramePipeline
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4
 class A: pass
 args = A(); args.grid = 16; args.sdf_res = 64; args.shadow_res = 2048; args.steps = 40; args.warmup = 5; args.profile_frames = 0
 w, h = 7680, 1080 * n
@@ -59,6 +59,9 @@ def group(d):  # fused launches of the unpartitioned frame count towards their p
         key = "GI trace + filters" if ("Indirect" in k) else ("bloom" if "loom" in k or "Tonemap" in k else ("exposure" if "istogram" in k or "expose" in k else k.split(" + ")[0]))
         g[key] = g.get(key, 0.0) + v
     return g
+if "--passes" in sys.argv:
+    for k in sorted(set(full_passes) | set(band_passes), key=lambda k: -band_passes.get(k, 0.0)):
+        print("    %-60s bands %.4f ms (%.4f per band), unpartitioned %.4f ms" % (k[:60], band_passes.get(k, 0.0), band_passes.get(k, 0.0) / n, full_passes.get(k, 0.0)))
 gf, gb = group(full_passes), group(band_passes)
 for k in sorted(gb, key=lambda k: -gb[k]):
     print("  %-34s bands %.3f ms, unpartitioned %.3f ms (%+.1f %%)" % (k, gb[k], gf.get(k, 0.0), 100.0 * (gb[k] / gf[k] - 1.0) if gf.get(k) else 0.0))

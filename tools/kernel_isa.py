@@ -18,7 +18,7 @@ meta = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co]).decode()
 want = sys.argv[2] if len(sys.argv) > 2 else ""
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
-FULL = re.compile(r"v_(fma|fmac|mul|add|sub|subrev|mac|mad|fmaak|fmamk)_f32|v_(add|sub|subrev)_u32|v_add3_u32|v_(and|or|xor)_b32|v_mov_b32|v_lshrrev_b32|v_lshl_add_u32|v_and_or_b32|v_or3_b32|v_add_co|v_addc_co|v_lshl_add_u64|v_ashrrev_i32")
+FULL = re.compile(r"v_(fma|fmac|mul|add|sub|subrev|mac|mad|fmaak|fmamk)_f32|v_(add|sub|subrev)_u32|v_(and|or|xor)_b32|v_mov_b32|v_lshrrev_b32|v_add_co|v_addc_co|v_ashrrev_i32")
 TRANS = re.compile(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_")
 SGPR = re.compile(r"[ ,]s\d+\b|[ ,]s\[|[ ,]vcc")
 
