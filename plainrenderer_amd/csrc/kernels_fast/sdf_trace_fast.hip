@@ -173,6 +173,9 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
 }
 
 struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
+// one culled instance of the block's tile as staged in LDS: the 96-byte record, its volume's view and the record's index (decision signature)
+struct StagedInstance { SDFInstance inst; ImgView view; uint32_t instIndex, pad; };
+static_assert(sizeof(StagedInstance) == 128 && sizeof(ImgView) == 24, "StagedInstance is 32 dwords");
 struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
 
 // SIG: also write the decision signature of every pixel (plr_debug_set_decision_signature; bit layout in oracle/oracle.h)
@@ -193,6 +196,30 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
     vec3 L(0.f, 0.f, 1.f);
+    // ---- the tile's instance table, staged once per block. The four waves of a block lie in one culling tile; walking the tile's list straight
+    // from memory is a chain of three dependent loads per instance and wave (list entry -> instance record -> volume view) in front of the
+    // first SDF fetch, ~1 k cycles in which a wave has nothing else to do (59 % of this kernel's wave cycles were parked). Here the block
+    // fetches all records, then all views, side by side, and the instance loop reads them from LDS.
+    __shared__ StagedInstance staged[kMaxObjectsPerTile];
+    const uint32_t tileIndex = min((uint32_t)(gx / 4) + (uint32_t)(gy / 4) * (uint32_t)ceilf((float)g->screenResolution[0] / 32.f), tileCapacity - 1u);
+    const CulledInstancesPerTile* tile = tiles + tileIndex;
+    const int objectCount = (int)min(tile->objectCount, kMaxObjectsPerTile);
+    {
+        uint32_t* lds = (uint32_t*)staged;
+        for (int e = (int)threadIdx.x; e < objectCount * 24; e += 256) {
+            const int i = e / 24, j = e - i * 24;
+            const uint32_t instIndex = min(tile->indices[i], instanceCapacity - 1u);
+            lds[i * 32 + j] = ((const uint32_t*)&instanceBuffer->instances[instIndex])[j];
+            if (j == 0) lds[i * 32 + 30] = instIndex;
+        }
+        __syncthreads();
+        for (int e = (int)threadIdx.x; e < objectCount * 6; e += 256) {
+            const int i = e / 6, j = e - i * 6;
+            const uint32_t texIndex = min(staged[i].inst.sdfTextureIndex, bindlessCount - 1u);
+            lds[i * 32 + 24 + j] = ((const uint32_t*)&bindless[texIndex])[j];
+        }
+        __syncthreads();
+    }
     RayInfo mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
         const float u = (float)px / (float)outYSH.w, v = (float)py / (float)outYSH.h; // IEEE quotient: see the note at the top
@@ -225,14 +252,10 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         tr.closestHitDistance = 10000.f;
         tr.hitPos = vec3(0.f);
         tr.albedoSrgb = vec3(0.f);
-        const uint32_t tileIndex = min((uint32_t)(gx / 4) + (uint32_t)(gy / 4) * (uint32_t)ceilf((float)g->screenResolution[0] / 32.f), tileCapacity - 1u);
-        const CulledInstancesPerTile* tile = tiles + tileIndex;
-        const int objectCount = (int)min(tile->objectCount, kMaxObjectsPerTile);
         for (int i = 0; i < objectCount; i++) {
-            const uint32_t instIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tile->indices[i]), instanceCapacity - 1u);
-            const SDFInstance& inst = instanceBuffer->instances[instIndex];
-            const uint32_t texIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)inst.sdfTextureIndex), bindlessCount - 1u);
-            const ImgView view = bindless[texIndex];
+            const SDFInstance& inst = staged[i].inst;
+            const ImgView view = staged[i].view;
+            const uint32_t instIndex = staged[i].instIndex;
             Volume vol;
             vol.p = (const uint16_t*)view.ptr; vol.w = view.w; vol.h = view.h; vol.d = view.d;
             vol.fw = (float)view.w; vol.fh = (float)view.h; vol.fd = (float)view.d;
@@ -260,7 +283,9 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         mine.cr = hitColor.x; mine.cg = hitColor.y; mine.cb = hitColor.z;
     }
     sharedRays[wave][lane] = mine;
-    __syncthreads();
+    // a wave only reads the slice it wrote: no block barrier (the four waves of a tile finish their rays at different times)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (!active) return;
 
     float weightTotal = 1.f;
