@@ -410,8 +410,110 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ brdfLut.comp:20-101, PLR_MATH_FAST
+// One lane per texel, the shader's 1024 Hammersley samples accumulated in the shader's order (the exact kernel: 4.7 ms, almost all of it
+// software sin / cos / pow). Everything that depends on the sample index only is the same for every texel and is tabulated once per block in
+// LDS: the GGX azimuth's sine / cosine, the second Hammersley coordinate, and the whole cosine-weighted direction of the diffuse sample (N is
+// +z: the tangent frame of sampling.inc:4-45 is tangent = -y, bitangent = +x, so a sample h becomes (h.y, -h.x, h.z)). The loop body is then
+// hardware sqrt / rcp / exp2 / log2 on per-texel terms; per-texel invariants (r, NoV) are hoisted by the compiler.
+constexpr int kLutSamples = 1024;
+template <int DIFFUSE_BRDF>
+__global__ __launch_bounds__(256) void brdfLutFastKernel(ImgView lut, int coverW, int coverH) {
+    __shared__ float4 ggx[kLutSamples];     // sin(phi), cos(phi), xi.y, -
+    __shared__ float4 cosine[kLutSamples];  // L of the cosine-weighted sample
+    for (int i = (int)threadIdx.x; i < kLutSamples; i += 256) {
+        const float x0 = (float)i * (1.f / (float)kLutSamples);
+        uint32_t bits = (uint32_t)i;
+        bits = __builtin_bitreverse32(bits); // radicalInverse_VdC (sampling.inc: the five swaps are a 32-bit bit reversal)
+        const float x1 = (float)bits * 2.3283064365386963e-10f;
+        // the table is 1024 entries per block: the shader's own operations (software sin / cos, IEEE sqrt), so that every texel integrates over the
+        // oracle's sample directions - the grazing, low-roughness texels sum a handful of spikes and follow every bit of the directions
+        float sg, cg, sp, cp;
+        det_sincosf(2.f * PLR_GLSL_PI * x0, &sg, &cg);
+        det_sincosf(2.f * PLR_GLSL_PI * x1, &sp, &cp);
+        ggx[i] = make_float4(sg, cg, x1, 0.f);
+        const float cosT = sqrtf(x0), sinT = sqrtf(1.f - x0);
+        cosine[i] = make_float4(sp * sinT, -(cp * sinT), cosT, 0.f);
+    }
+    __syncthreads();
+    const int ux = (int)(blockIdx.x * 16u + (threadIdx.x & 15u)), uy = (int)(blockIdx.y * 16u + (threadIdx.x >> 4));
+    if (ux >= coverW || uy >= coverH) return;
+    const float r = fmax1((float)ux / (float)lut.w, 0.0001f);
+    const float NoV = fmax1((float)uy, 0.1f) / (float)lut.h;
+    const vec3 V(sqrtv(1.0f - NoV * NoV), 0.f, NoV);
+    float r4m1;
+    {
+#pragma clang fp contract(off)
+        const float r2 = r * r;
+        r4m1 = r2 * r2 - 1.f;
+    }
+    const float fresnelOutV = 1.f - F_Schlick(vec3(0.04f), vec3(1.f), NoV).x;
+    vec3 result(0.f);
+    for (int i = 0; i < kLutSamples; i++) {
+        const float4 gq = ggx[i], cq = cosine[i];
+        {
+            // the polar angle cancels catastrophically for low roughness (1 - cos^2 with cos within an ulp of 1): its operations are the
+            // shader's, separately rounded, with a correctly rounded quotient and roots (Newton step on v_rcp / v_rsq), or the grazing rows
+            // of the LUT end up tens of per cent away from the oracle's
+            float cosT, sinT;
+            {
+#pragma clang fp contract(off)
+                const float den = 1.f + r4m1 * gq.z, num = 1.f - gq.z;
+                const float rd = rcpf(den), q0 = num * rd;
+                const float q = __builtin_fmaf(__builtin_fmaf(-den, q0, num), rd, q0);
+                auto root = [](float x) { const float r = rsqf(x), s0 = x * r; return x > 0.f ? __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * r, s0) : 0.f; };
+                cosT = root(q);
+                const float c2 = cosT * cosT;
+                sinT = root(1.f - c2);
+            }
+            const vec3 H(gq.x * sinT, -(gq.y * sinT), cosT);
+            const float VdotH = dot(V, H);
+            const float Lz = 2.f * VdotH * H.z - V.z;
+            const float VoH = fmax1(VdotH, 0.f), NoH = fmax1(H.z, 0.f), NoL = fmax1(Lz, 0.f);
+            const float F_c = pow5(1.f - VoH);
+            const float k = Visibility(NoV, NoL, r) * VoH * NoL * rcpf(NoH);
+            const bool lit = NoL > 0.f;
+            result.x += lit ? F_c * k : 0.f;
+            result.y += lit ? k : 0.f;
+        }
+        {
+            const vec3 L(cq.x, cq.y, cq.z);
+            const vec3 H = nrm(V + L);
+            const float VoH = fclamp(dot(V, H), 0.f, 1.f), NoL = fmax1(L.z, 0.f), NoH = fmax1(H.z, 0.f);
+            const float fresnelInOut = fresnelOutV * (1.f - F_Schlick(vec3(0.04f), vec3(1.f), NoL).x);
+            if (DIFFUSE_BRDF == 0) result.z += (1.f / PLR_GLSL_PI) * fresnelInOut;
+            else if (DIFFUSE_BRDF == 1) result.z += DisneyDiffuse(vec3(1.f), NoL, VoH, NoV, r).x * fresnelInOut;
+            else if (DIFFUSE_BRDF == 2) result.z += CoDWWIIDiffuse(vec3(1.f), NoL, VoH, NoV, NoH, r).x * fresnelInOut;
+            else result.z += Titanfall2DiffuseSingleComponent(NoL, fclamp(dot(L, V), 0.f, 1.f), NoV, NoH, r) * fresnelInOut;
+        }
+    }
+    result = result * (1.f / (float)kLutSamples);
+    result.x *= 4.f;
+    result.y *= 4.f;
+    Texel<F_RGBA16F>::store(lut.ptr, (size_t)uy * (size_t)lut.w + ux, vec4(result, 0.f));
+}
+
+static int launchBrdfLutFast(const PassCtx& c) {
+    if (!c.hasStorage(0) || c.storage[0].fmt != F_RGBA16F) return kUseGeneralKernel;
+    const ImgView& lut = c.storage[0];
+    const int w = std::min((int)(c.dispatch[0] * 8u), lut.w), h = std::min((int)(c.dispatch[1] * 8u), lut.h);
+    if (w <= 0 || h <= 0) return 0;
+    const dim3 grid(divUp((unsigned)w, 16u), divUp((unsigned)h, 16u));
+    switch (c.specInt(0, 0)) {
+        case 0: brdfLutFastKernel<0><<<grid, 256, 0, c.stream>>>(lut, w, h); break;
+        case 1: brdfLutFastKernel<1><<<grid, 256, 0, c.stream>>>(lut, w, h); break;
+        case 2: brdfLutFastKernel<2><<<grid, 256, 0, c.stream>>>(lut, w, h); break;
+        case 3: brdfLutFastKernel<3><<<grid, 256, 0, c.stream>>>(lut, w, h); break;
+        default: return kUseGeneralKernel;
+    }
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
 } // namespace fastshade
 
 static int fastshade_launch(const PassCtx& c) { return fastshade::launchDeferredShadingFast(c); }
 PLR_REGISTER_SHADER_FAST("deferredShading.comp", fastshade_launch);
+static int fastshade_brdf_lut(const PassCtx& c) { return fastshade::launchBrdfLutFast(c); }
+PLR_REGISTER_SHADER_FAST("brdfLut.comp", fastshade_brdf_lut);
 } // namespace plr

@@ -199,3 +199,24 @@ def test_fast_r11g11b10_encoder_against_the_exact_one_for_every_float(backend):
     assert last < 0x38800000  # nothing at or above 2^-14 differs
     # of the 0x38800000 positive patterns below 2^-14 fewer than 2^-17 may differ
     assert diff11 < 0x38800000 >> 17 and diff10 < 0x38800000 >> 17
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("brdf", [0, 1, 2, 3])
+def test_fast_brdf_lut_within_a_half_float_step(backend, brdf):
+    """kernels_fast/shading_fast.hip brdfLutFastKernel (hardware sin / cos / sqrt / rcp, tabulated sample directions, the shader's summation order)
+    against the oracle's LUT (diffuse model 2 at the reference's 512 x 512): every texel within one half-float step, almost all equal"""
+    res = 512 if brdf == 2 else 64
+    ref = pixfmt.unpack_half(passes.orc_brdf_lut(res, brdf)).reshape(res, res, 4).astype(np.float64)
+    backend.setMathMode(True)
+    try:
+        raw, _ = passes.gpu_brdf_lut(backend, res, brdf)
+    finally:
+        backend.setMathMode(False)
+    got = pixfmt.unpack_half(raw).reshape(res, res, 4).astype(np.float64)
+    assert np.isfinite(got).all()
+    step = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10)  # half-float spacing at the reference value
+    steps = np.abs(got - ref) / step
+    print("PARITY brdf_lut_fast brdf=%d res=%d equal=%.5f within_1_step=%.5f max_steps=%.2f" % (brdf, res, (steps == 0).mean(), (steps <= 1).mean(), steps.max()))
+    assert steps[..., :3].max() <= 1.0 and (steps == 0).mean() >= 0.99  # measured: no texel further than one step, > 99.8 % equal
+    assert (got[..., 3] == 0).all()
