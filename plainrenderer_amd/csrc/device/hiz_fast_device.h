@@ -24,6 +24,7 @@ struct QuadParams {
     float2* level[4];
     uint16_t* halfDepth; // depthDownscale.comp's target (fused) or null
     int halfW;
+    int levels;          // 4: both sides are multiples of 16; 3: multiples of 8 (1920 x 1080), level 3 is then the tail's first level (its 3-wide odd-size footprints need LDS)
 };
 
 // min / max contribution of a (min, max) texel to the level above (depthHiZPyramid.comp:95-110): a texel whose max is 0 is all sky and must not
@@ -37,7 +38,7 @@ PLR_DI void hizQuadBlock(const QuadParams& p, int bx, int by) {
     // lane bits: [1:0] position in a 2x2 quad of lanes, [3:2] position of the quad in a 16-lane row (2x2 quads), [5:4] position of the row in the wave
     const int x8 = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4), y8 = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     const int px = bx * 64 + (wave & 1) * 32 + x8 * 4, py = by * 64 + (wave >> 1) * 32 + y8 * 4;
-    const bool active = px < p.depthW && py < p.depthH; // sides are multiples of 16: a 4x4 patch (and every coarser texel) is inside or outside as a whole
+    const bool active = px < p.depthW && py < p.depthH; // sides are multiples of 8 << (levels - 3): a 4x4 patch (and every coarser texel made here) is inside or outside as a whole
     float mn1 = 1.f, mx1 = 0.f;
     if (active) {
         float4 r[4];
@@ -78,7 +79,7 @@ PLR_DI void hizQuadBlock(const QuadParams& p, int bx, int by) {
     a = __builtin_fminf(a, dppf(a, 0x4E)); b = __builtin_fmaxf(b, dppf(b, 0x4E));
     const float mn2 = __builtin_fminf(1.f, a), mx2 = b;
     if (active && (lane & 3) == 0) p.level[2][(size_t)(py / 8) * (size_t)(p.depthW / 8) + (size_t)(px / 8)] = make_float2(mn2, mx2);
-    if (LEVELS >= 4) {
+    if (LEVELS >= 4 && p.levels >= 4) {
         // level 3: the four quads of a 16-lane row
         float c = active ? minTerm(mn2, mx2) : 1.f, d = active ? mx2 : 0.f;
         c = __builtin_fminf(c, dppf(c, 0x124)); d = __builtin_fmaxf(d, dppf(d, 0x124));

@@ -1,4 +1,4 @@
-// Min/max depth pyramid for depth buffers whose sides are multiples of 16 (the 4K benchmark frame), PLR_MATH_FAST set.
+// Min/max depth pyramid for depth buffers whose sides are multiples of 8 (1920x1080, 3840x2160, ...), PLR_MATH_FAST set.
 // Results are the same bits as kernels/hiz.hip (min / max of exact values: nothing is rounded).
 //
 // kernels/hiz.hip handles any size with per-level loops over LDS regions (scalar 4-byte depth loads, runtime div / mod indexing): 36 us at
@@ -30,7 +30,8 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     const int mipCount = c.specInt(0, 0);
     if (mipCount < 5 || mipCount > kHizMaxLevels || !c.hasSampled(13) || c.sampled[13].fmt != F_D32) return kUseGeneralKernel;
     const ImgView& depth = c.sampled[13];
-    if (c.specInt(1, 0) != depth.w || c.specInt(2, 0) != depth.h || (depth.w & 15) || (depth.h & 15)) return kUseGeneralKernel;
+    if (c.specInt(1, 0) != depth.w || c.specInt(2, 0) != depth.h || (depth.w & 7) || (depth.h & 7)) return kUseGeneralKernel;
+    const int levels = ((depth.w | depth.h) & 15) ? 3 : 4; // levels made without LDS (every texel of them has an even-sized source)
     HizParams p{};
     p.count = mipCount;
     const int unused = kHizMaxLevels - mipCount;
@@ -46,12 +47,13 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     // the whole pyramid only: a dispatch that covers part of the tile rows (band rendering) takes the general kernel
     const int tileRows = (int)divUp((unsigned)p.h[0], 32u);
     if (c.base[1] != 0 || (int)c.dispatch[1] < tileRows) return kUseGeneralKernel;
-    const int texA = p.w[4] * p.h[4], texB = mipCount > 5 ? p.w[5] * p.h[5] : 1;
+    const int texA = p.w[levels] * p.h[levels], texB = mipCount > levels + 1 ? p.w[levels + 1] * p.h[levels + 1] : 1;
     const size_t tailLds = (size_t)(texA + texB) * sizeof(float2);
     if (tailLds > 140 * 1024) return kUseGeneralKernel;
     QuadParams q{};
     q.depth = (const float*)depth.ptr; q.depthW = depth.w; q.depthH = depth.h;
     for (int l = 0; l < 4; l++) q.level[l] = p.level[l];
+    q.levels = levels;
     if (down) {
         if (!down->hasStorage(0) || !down->hasSampled(1) || down->storage[0].fmt != F_R16F || down->sampled[1].ptr != depth.ptr) return kUseGeneralKernel;
         const ImgView& dst = down->storage[0];
@@ -61,7 +63,7 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     }
     out->quad = q; out->tail = p;
     out->gridX = (int)divUp((unsigned)depth.w, 64u); out->gridY = (int)divUp((unsigned)depth.h, 64u);
-    out->tailFirst = 4; out->tailTexelsA = texA; out->tailLdsBytes = tailLds; out->downscale = down != nullptr;
+    out->tailFirst = levels; out->tailTexelsA = texA; out->tailLdsBytes = tailLds; out->downscale = down != nullptr;
     return 0;
 }
 

@@ -127,10 +127,17 @@ def test_kat_taa_camera_cut_ignores_history():
 
 # ------------------------------------------------------------------ GPU parity
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h", [(3840, 2160), (1920, 1080), (540, 272), (130, 94), (64, 48), (34, 2), (4, 4)])
-def test_gpu_hiz_bit_exact(backend, w, h):
+@pytest.mark.parametrize("fast_set", [False, True])
+@pytest.mark.parametrize("w,h", [(3840, 2160), (1920, 1080), (2560, 1432), (540, 272), (130, 94), (64, 48), (34, 2), (4, 4)])
+def test_gpu_hiz_bit_exact(backend, w, h, fast_set):
+    """both kernel sets: min / max of exact values, nothing is rounded. The fast set's DPP pyramid takes sides that are multiples of 16 (four
+    levels without LDS) or of 8 (three: 1920 x 1080, 2560 x 1432), everything else runs the general kernel"""
     d = synth_depth(w, h, buffer_id=30)
-    got, _, _ = passes.gpu_hiz(backend, d, w, h)
+    backend.setMathMode(fast_set)
+    try:
+        got, _, _ = passes.gpu_hiz(backend, d, w, h)
+    finally:
+        backend.setMathMode(False)
     ref = passes.orc_hiz(d, w, h)
     assert len(got) == len(ref)
     for m, (a, b) in enumerate(zip(got, ref)):
