@@ -43,9 +43,9 @@ PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 // (rows in flight + 100) x the whole image width: 4 MB at 4K (half-res 1920 x 16-byte texels), 7 MB at 8K.
 // The 32 disc samples are the same for every pixel: the shader seeds its RNG with wang_hash(frameIndexMod4 + filterIndex)
 // (:53), so there are only five distinct tables. They are derived once (first launch of a pass) into the pass's scratch memory:
-// table[key][0..31] = sqrt(r0), [32..63] = cos(2 pi r1), [64..95] = sin(2 pi r1). The filter kernel reads them with uniform
+// table[key][0..31] = sqrt(r0), [32..63] = cos(2 pi r1), [64..95] = sin(2 pi r1), [96..127] / [128..159] = their products. The filter kernel reads them with uniform
 // (scalar) loads instead of every block re-deriving them.
-constexpr int kSampleKeys = 5, kSampleTableFloats = 96;
+constexpr int kSampleKeys = 5, kSampleTableFloats = 160;
 __global__ void spatialSampleTableKernel(float* __restrict__ table) {
     const int key = (int)threadIdx.x / 32, i = (int)threadIdx.x % 32;
     if (key >= kSampleKeys) return;
@@ -56,6 +56,7 @@ __global__ void spatialSampleTableKernel(float* __restrict__ table) {
     det_sincosf(2.f * PLR_GLSL_PI * r1, &sn, &cs);
     float* t = table + key * kSampleTableFloats;
     t[i] = sqrtf(r0); t[32 + i] = cs; t[64 + i] = sn;
+    t[96 + i] = cs * t[i]; t[128 + i] = sn * t[i]; // the disc offsets themselves, for waves whose discs cannot shrink (the same single products the loop forms)
 }
 
 // Vector memory instructions, not bytes, are what this filter runs out of: a CU's texture addresser retires one wave-wide load
@@ -198,8 +199,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             bool off[4];
     #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float d = SAFE ? samples[i0 + k] : samples[i0 + k] * lengthModifier;
-                const float ox = samples[32 + i0 + k] * d, oy = samples[64 + i0 + k] * d;
+                float ox, oy;
+                if (SAFE) { ox = samples[96 + i0 + k]; oy = samples[128 + i0 + k]; }
+                else { const float d = samples[i0 + k] * lengthModifier; ox = samples[32 + i0 + k] * d; oy = samples[64 + i0 + k] * d; }
                 const float clipX = P0.x + ox * PT.x + oy * PB.x, clipY = P0.y + ox * PT.y + oy * PB.y, clipW = P0.z + ox * PT.z + oy * PB.z;
                 const float invW = rcpf(clipW) * 0.5f;
                 // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
                     float weight = __builtin_amdgcn_fmed3f(qden * rcpf(__builtin_fmaxf(num, 0.0004f * qden)), 0.f, 1.f);
                     weight *= weight;
-                    weight = ((SAFE || !off[k]) && qden > 0.f) ? weight : 0.f;
+                    // a texel to skip has qden < 0: max(num, negative) = num >= 0, the quotient is <= 0 and the clamp has already made the weight 0
+                    if (!SAFE) weight = off[k] ? 0.f : weight;
                     rY0 += weight * halfBitsToFloat(t4[k].x & 0xffffu); rY1 += weight * halfBitsToFloat(t4[k].x >> 16);
                     rY2 += weight * halfBitsToFloat(t4[k].y & 0xffffu); rY3 += weight * halfBitsToFloat(t4[k].y >> 16);
                     resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
 }
 
 // scratch of a filter pass: [sample tables | packed texels of the whole input image]
-constexpr size_t kSpatialTableBytes = 2048;
+constexpr size_t kSpatialTableBytes = 4096;
 static_assert(sizeof(float) * kSampleKeys * kSampleTableFloats <= kSpatialTableBytes, "sample tables");
 static uint8_t* spatialScratch(const PassCtx& c, bool sameGrid) {
     const size_t packedBytes = sameGrid ? (size_t)c.sampled[2].w * (size_t)c.sampled[2].h * 16u : 0u;
