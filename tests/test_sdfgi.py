@@ -264,3 +264,63 @@ def test_gpu_frame_sdf_debug_view(backend):
     lit = pixfmt.unpack_r11g11b10(exp.reshape(-1))
     assert np.isfinite(lit).all() and lit.max() > 0
     fp.destroy()
+
+
+# ------------------------------------------------------------------ tiles at the 100-instance cap (sdfCulling.inc:7-15)
+@pytest.fixture(scope="module")
+def dense_scene():
+    """256 instances packed 1 m apart: the camera looks along the field, 10 of the 24 culling tiles hold the maximum of 100 instances"""
+    s = Scene()
+    sc = synth.SynthScene(grid=16, cell=1.0, seed_id=301)
+    cam = Camera.look((8.0, -5.0, -6.0), (0.0, 0.35, 1.0), aspect=W / H)
+    s.sc, s.cam, s.gb = sc, cam, sc.gbuffer(cam, W, H, cam)
+    s.inst_bytes, s.bb_bytes, s.vols = sc.sdf_instances(SDF_RES)
+    s.noise = synth.blue_noise_standins()
+    s.sky = synth.sky_lut()
+    sun = np.array([0.35, -0.8, 0.45])
+    sun /= np.linalg.norm(sun)
+    s.shadow_info, s.shadow_maps = sc.shadow_cascades(cam, sun, 2.0, 60.0, 256)
+    g = GlobalShaderInfo(frameIndex=6, sunDirection=(*sun.tolist(), 0.0), time=3.0)
+    g.viewProjectionPrevious = cam.view_projection()
+    cam.fill_global(g, W, H)
+    s.g = g
+    s.light = light_buffer_bytes(sun_color=(1.0, 0.92, 0.8), prev_exposure=8e-5, sun_strength_exposed=128000 * 8e-5)
+    s.fpts, s.fnrm = cam.frustum_points_normals()
+    return s
+
+
+def test_kat_dense_scene_reaches_the_tile_cap(dense_scene):
+    c = oracle_chain(dense_scene)
+    counts = c["tiles"].reshape(-1, passes.TILE_UINTS)[:, 0]
+    assert c["culled"][0] == 256 and counts.max() == 100 and (counts == 100).sum() >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast_set", [False, True])
+def test_gpu_culling_and_trace_with_tiles_at_the_cap(backend, dense_scene, fast_set):
+    """tiles holding exactly the 100 instances the list can store: the culling writes the same lists as the oracle, the exact trace the same bits, and
+    the fast trace (which stages a tile's whole instance table in LDS) agrees within the fast set's tolerance"""
+    s = dense_scene
+    c, inst_bytes, arr, n, keep = _trace_inputs(backend, s)
+    gp = s.g.pack()
+    backend.setMathMode(fast_set)
+    try:
+        _, pyramid, _ = passes.gpu_hiz(backend, s.gb["depth"], W, H)
+        culled_g, tiles_g, _ = passes.gpu_sdf_culling(backend, s.inst_bytes, s.bb_bytes, s.fpts, s.fnrm, INFLUENCE, pyramid, TW, TH, gp)
+        args = (s.gb["depth"], s.gb["normal"], W, H, TW, TH, s.sky, 200, 100, s.light, inst_bytes, c["tiles"], INFLUENCE, s.shadow_info, s.shadow_maps[2], 256, gp)
+        y_g, c_g = passes.gpu_sdf_trace(backend, *args, strict=True, cascade=2)
+    finally:
+        backend.setMathMode(False)
+    got, ref = tiles_g.reshape(-1, passes.TILE_UINTS), c["tiles"].reshape(-1, passes.TILE_UINTS)
+    assert np.array_equal(got[:, 0], ref[:, 0])
+    for t in range(ref.shape[0]):
+        assert np.array_equal(got[t, 1:1 + ref[t, 0]], ref[t, 1:1 + ref[t, 0]]), "instance list of tile %d" % t
+    y_o, c_o = passes.orc_sdf_trace(*args, arr, n, strict=True, cascade=2)
+    if not fast_set:
+        assert mismatch_fraction(y_g, y_o) == 0.0 and mismatch_fraction(c_g, c_o) == 0.0
+    else:
+        fy, fo = pixfmt.unpack_half(y_g).astype(np.float64), pixfmt.unpack_half(y_o).astype(np.float64)
+        assert np.isfinite(fy).all()
+        bad = np.abs(fy - fo) > np.maximum(2.0 ** -7 * np.abs(fo), 2.0 ** -10 * np.abs(fo).max())
+        print("PARITY trace_at_cap pixels_outside_tolerance=%g" % bad.reshape(TH * TW, -1).any(axis=1).mean())
+        assert bad.reshape(TH * TW, -1).any(axis=1).mean() <= 0.01  # rays that resolve differently and their 3x3 neighbours
