@@ -240,7 +240,7 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
 
 @pytest.mark.gpu
 def test_gpu_three_bands_default_halos():
-    # default halos (64 trace rows GI, 16 history, 320 post): bands of 64 rows here, so halos are clipped to the neighbouring
+    # default halos (64 trace rows GI, 16 history, 224 post): bands of 64 rows here - smaller than the halos, which are clipped to the neighbouring
     # band; pixels whose 1.5 m denoiser disc or bloom footprint reaches past the neighbouring band may differ - they must be few
     inputs = _make_inputs()
     full = _run_full(inputs, True)
@@ -405,7 +405,7 @@ def test_gpu_two_bands_of_realistic_height_with_default_halos(monkeypatch):
             mean_rel = float(np.abs(a - b).mean() / b.mean())
             print("BANDS frame %d band %d: pixels within one code of the unpartitioned frame %.5f, max code diff %d, mean rel err %.2e" % (f, i, within1, int(d.max()), mean_rel))
             worst_within1, worst_mean = min(worst_within1, within1), max(worst_mean, mean_rel)
-    assert worst_within1 >= 0.97 and worst_mean <= 2e-3
+    assert worst_within1 >= 0.995 and worst_mean <= 1e-3  # measured on MI355X: 1.00000 of the pixels within one code in every band and frame
 
 
 def pixfmt_unpack(a):
