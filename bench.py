@@ -9,7 +9,8 @@ bloom x11, tonemap) on synthetic inputs that are resident in HBM before the time
 
 N > 1: ONE frame of N x the 4K pixel count (7680 x 1080*N; N = 4 is the 7680x4320 frame of BASELINE config 5), partitioned into N
 row bands, one rank per GPU, halo rows exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
-histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels). When WORLD_SIZE is not set, `--gpus N` spawns the N
+histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels). The bands' heights are balanced before the timed region
+from measured per-band render times (two calibration rounds, `band_partition` in the JSON line; --no-balance keeps equal heights). When WORLD_SIZE is not set, `--gpus N` spawns the N
 ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1); under torchrun WORLD_SIZE must equal --gpus. A band frame that
 cannot run fails the benchmark (non-zero exit) unless --allow-replicas is given.
 """
@@ -178,6 +179,7 @@ def main():
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     ap.add_argument("--python-exchange", action="store_true", help="diagnostic: drive the halo exchange from Python (torch.distributed) instead of the C++ host's RCCL exchange")
     ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal row partition instead of balancing the bands' heights from measured band times")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
 
@@ -192,6 +194,12 @@ def main():
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(cmd, env=env))
+
+    # stdout carries exactly ONE line, the JSON result of rank 0: everything else a library may print there (RCCL's version banner is written to
+    # the C stdout and flushed at exit, i.e. after the JSON line) is sent to stderr by pointing file descriptor 1 at it for the life of the process
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -215,23 +223,65 @@ def main():
     from plainrenderer_amd import RenderBackend, tiling
     from plainrenderer_amd.frame import FramePipeline
 
+    band_partition = {"bounds": None, "calibration": []}
+
+    def band_frame_size():
+        # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
+        # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
+        return (2 * args.width, (args.height // 2) * world) if world > 1 else (args.width, args.height)
+
+    def calibrate_partition():
+        """Static load balancing: the bands are rendered with an exchange that moves nothing (compute only; with the real exchange every rank would
+        show the slowest rank's time), the per-band times are gathered and the row boundaries re-cut so that every band costs the same
+        (tiling.balanced_bounds). Two rounds; the same partition on every rank."""
+        w_, h_ = band_frame_size()
+        bounds = tiling.equal_bounds(h_, world)
+        for _ in range(2):
+            b0, b1 = bounds[rank], bounds[rank + 1]
+            be_ = RenderBackend(w_, h_, device=local_rank)
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=b0, band_row_end=b1)
+            fp_.set_exchange_callback(lambda exchange_id, stream: None)
+            _, cams_, inputs_ = build_scene(args, device, w_, h_, (b0, b1))
+            inputs_.upload(fp_)
+            for i in range(4):
+                fp_.frame(cams_[i + 1], 1.0 / 60.0, 0.5)
+            be_.waitForGPUIdle()
+            tc = time.perf_counter()
+            for i in range(12):
+                fp_.frame(cams_[i + 5], 1.0 / 60.0, 0.5)
+            be_.waitForGPUIdle()
+            mine = (time.perf_counter() - tc) / 12.0
+            fp_.destroy()
+            be_.shutdown()
+            del inputs_
+            torch.cuda.empty_cache()
+            times = torch.zeros(world, dtype=torch.float64, device=device)
+            times[rank] = mine
+            if world > 1:
+                dist.all_reduce(times, op=dist.ReduceOp.SUM)
+            times = [float(v) for v in times.cpu().tolist()]
+            band_partition["calibration"].append({"bounds": list(bounds), "band_ms": [round(t * 1e3, 4) for t in times]})
+            new = tiling.balanced_bounds(h_, bounds, times)
+            if new == bounds:
+                break
+            bounds = new
+        return bounds
+
     def make(mode):
         """mode 'single': the 4K frame on this GPU; 'bands': one band of the N x larger frame; -> (be, fp, scene-tuple, w, h, band)"""
         w_, h_ = args.width, args.height
         band_ = None
+        bounds_ = None
         if mode == "bands":
-            if world > 1:
-                # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
-                # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
-                w_, h_ = 2 * args.width, (args.height // 2) * world
-                band_ = tiling.band_rows(h_, world, rank)
-            else:
-                band_ = (0, h_)
+            w_, h_ = band_frame_size()
+            bounds_ = tiling.equal_bounds(h_, world) if args.no_balance else calibrate_partition()
+            band_ = (bounds_[rank], bounds_[rank + 1])
+            band_partition["bounds"] = bounds_
         be_ = RenderBackend(w_, h_, device=local_rank)
         if band_ is not None:
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=band_[0], band_row_end=band_[1])
             if args.python_exchange:
-                tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank)  # diagnostic: torch.distributed transport driven from Python
+                tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank, bounds_)  # diagnostic: torch.distributed transport driven from Python
             else:
                 # the C++ host's RCCL exchange: rank 0 creates the ncclUniqueId, every rank receives it once (this broadcast is the only use of
                 # torch.distributed on the data path's behalf), then ncclCommInitRank inside libplr
@@ -240,7 +290,7 @@ def main():
                     uid.copy_(torch.frombuffer(bytearray(fp_.rccl_unique_id()), dtype=torch.uint8))
                 if world > 1:
                     dist.broadcast(uid, src=0)
-                fp_.attach_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, h_)
+                fp_.attach_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, h_, bounds_)
         else:
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res)
         sc = build_scene(args, device, w_, h_, band_)
@@ -380,12 +430,13 @@ def main():
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
             "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "band_partition": band_partition if band is not None else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "exchange": exchange_stats,
             "passes_ms": {name: round(avg * launches, 4) for name, avg, launches, _ in table},
         }
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     fp.destroy()
     be.shutdown()
     if dist is not None:

@@ -77,6 +77,9 @@ int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* o
 #define PLRF_RCCL_UNIQUE_ID_BYTES 128
 int plrf_rccl_get_unique_id(void* out_128_bytes);
 int plrf_rccl_attach(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_height, void** out_exchange);
+/* the same for a partition chosen by the caller (load balancing: bands of unequal height): row_bounds = world + 1 row boundaries, 0 ... frame_height,
+ * interior ones multiples of 64; band r owns rows [row_bounds[r], row_bounds[r + 1]) and must have been created with exactly those rows. NULL = plrf_band_rows */
+int plrf_rccl_attach_rows(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_height, const uint32_t* row_bounds, void** out_exchange);
 int plrf_rccl_detach(void* pipeline, void* exchange);
 /* bytes this rank sent / received and the number of point-to-point exchange groups of the last frame */
 int plrf_rccl_get_stats(void* exchange, uint64_t* out_bytes_sent, uint64_t* out_bytes_received, uint64_t* out_exchanges);
@@ -89,6 +92,8 @@ const char* plrf_rccl_last_error(void);
  * which this band owns [row_begin, row_end)) the plan lists up to 4 transfers: send / receive with the band above and below */
 typedef struct plrf_exchange_op { uint32_t peer, send, row_begin, row_end; } plrf_exchange_op;
 int plrf_band_rows(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t* out_row_begin, uint32_t* out_row_end);
+int plrf_exchange_plan_rows(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin,
+                            uint32_t row_end, plrf_exchange_op* out_ops, uint32_t* out_count);
 int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,
                        plrf_exchange_op* out_ops_4, uint32_t* out_count);
 

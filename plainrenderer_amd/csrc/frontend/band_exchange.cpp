@@ -41,11 +41,13 @@ void bandRowsOf(uint32_t height, uint32_t nBands, uint32_t index, uint32_t* begi
     *end = std::min(e * kBandAlignment, height);
 }
 
-// rows of band b in an image of imageRows rows that shows the frame at 1 / divisor resolution
-void bandRowsInImage(uint32_t frameHeight, uint32_t nBands, uint32_t b, uint32_t imageRows, uint32_t* begin, uint32_t* end) {
+// rows of band b in an image of imageRows rows that shows the frame at 1 / divisor resolution. bounds: nBands + 1 row boundaries of a
+// partition chosen by the caller (load balancing: bands of unequal height), or null for the equal partition of bandRowsOf
+void bandRowsInImage(uint32_t frameHeight, uint32_t nBands, const uint32_t* bounds, uint32_t b, uint32_t imageRows, uint32_t* begin, uint32_t* end) {
     const uint32_t divisor = std::max(1u, (frameHeight + imageRows / 2) / std::max(imageRows, 1u));
     uint32_t b0, b1;
-    bandRowsOf(frameHeight, nBands, b, &b0, &b1);
+    if (bounds) { b0 = bounds[b]; b1 = bounds[b + 1]; }
+    else bandRowsOf(frameHeight, nBands, b, &b0, &b1);
     *begin = b0 / divisor;
     *end = std::min((b1 + divisor - 1) / divisor, imageRows);
 }
@@ -53,20 +55,21 @@ void bandRowsInImage(uint32_t frameHeight, uint32_t nBands, uint32_t b, uint32_t
 // The transfers of one exchange item for band `band`: it sends its first / last haloRows owned rows up / down and receives the rows
 // just above / below its own from the neighbours. A halo taller than the neighbouring band is clipped to that band (rows further
 // away belong to the band after it and are not exchanged: stated limit halo <= height of the neighbouring band).
-uint32_t planItem(uint32_t frameHeight, uint32_t nBands, uint32_t band, uint32_t imageRows, uint32_t haloRows, uint32_t rowBegin, uint32_t rowEnd, plrf_exchange_op* ops) {
+uint32_t planItem(uint32_t frameHeight, uint32_t nBands, const uint32_t* bounds, uint32_t band, uint32_t imageRows, uint32_t haloRows, uint32_t rowBegin, uint32_t rowEnd,
+                  plrf_exchange_op* ops) {
     uint32_t n = 0;
     auto add = [&](uint32_t peer, uint32_t send, uint32_t a, uint32_t b) {
         if (b > a) { ops[n].peer = peer; ops[n].send = send; ops[n].row_begin = a; ops[n].row_end = b; n++; }
     };
     if (band > 0) {
         uint32_t ub, ue;
-        bandRowsInImage(frameHeight, nBands, band - 1, imageRows, &ub, &ue);
+        bandRowsInImage(frameHeight, nBands, bounds, band - 1, imageRows, &ub, &ue);
         add(band - 1, 1, rowBegin, std::min(rowBegin + haloRows, rowEnd));
         add(band - 1, 0, std::max(rowBegin > haloRows ? rowBegin - haloRows : 0u, ub), rowBegin);
     }
     if (band + 1 < nBands) {
         uint32_t db, de;
-        bandRowsInImage(frameHeight, nBands, band + 1, imageRows, &db, &de);
+        bandRowsInImage(frameHeight, nBands, bounds, band + 1, imageRows, &db, &de);
         add(band + 1, 1, std::max(rowEnd > haloRows ? rowEnd - haloRows : 0u, rowBegin), rowEnd);
         add(band + 1, 0, rowEnd, std::min(std::min(rowEnd + haloRows, imageRows), de));
     }
@@ -78,6 +81,7 @@ struct RcclExchange {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     uint32_t frameHeight = 0;
+    std::vector<uint32_t> bounds; // world + 1 row boundaries, or empty: the equal partition
     hipStream_t commStream = nullptr;
     hipEvent_t ready[PLRF_EXCHANGE_COUNT] = {}, done[PLRF_EXCHANGE_COUNT] = {};
     uint64_t bytesSent = 0, bytesReceived = 0, exchanges = 0; // of the last frame (reset by the histogram exchange, the first of a frame)
@@ -103,7 +107,7 @@ struct RcclExchange {
         for (uint32_t i = 0; i < count && !rc; i++) {
             const plrf_exchange_item& it = items[i];
             plrf_exchange_op ops[4];
-            const uint32_t n = planItem(frameHeight, (uint32_t)world, (uint32_t)rank, it.image_rows, it.halo_rows, it.row_begin, it.row_end, ops);
+            const uint32_t n = planItem(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, it.image_rows, it.halo_rows, it.row_begin, it.row_end, ops);
             for (uint32_t k = 0; k < n && !rc; k++) {
                 uint8_t* p = (uint8_t*)it.device_ptr + (size_t)ops[k].row_begin * it.row_bytes;
                 const size_t bytes = (size_t)(ops[k].row_end - ops[k].row_begin) * it.row_bytes;
@@ -153,11 +157,26 @@ int plrf_band_rows(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint3
     return PLR_OK;
 }
 
+static int checkBounds(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, const char* who) {
+    if (!row_bounds) return PLR_OK;
+    if (row_bounds[0] != 0 || row_bounds[n_bands] != frame_height) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": row_bounds must start at 0 and end at frame_height");
+    for (uint32_t b = 0; b < n_bands; b++) {
+        if (row_bounds[b + 1] <= row_bounds[b]) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": row_bounds must be strictly increasing");
+        if (b + 1 < n_bands && row_bounds[b + 1] % kBandAlignment) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": interior row_bounds must be multiples of 64");
+    }
+    return PLR_OK;
+}
+
+int plrf_exchange_plan_rows(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin,
+                            uint32_t row_end, plrf_exchange_op* out_ops, uint32_t* out_count) {
+    if (!out_ops || !out_count || n_bands == 0 || band >= n_bands || image_rows == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_exchange_plan: invalid argument");
+    if (int rc = checkBounds(frame_height, n_bands, row_bounds, "plrf_exchange_plan_rows")) return rc;
+    *out_count = planItem(frame_height, n_bands, row_bounds, band, image_rows, halo_rows, row_begin, row_end, out_ops);
+    return PLR_OK;
+}
 int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,
                        plrf_exchange_op* out_ops, uint32_t* out_count) {
-    if (!out_ops || !out_count || n_bands == 0 || band >= n_bands || image_rows == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_exchange_plan: invalid argument");
-    *out_count = planItem(frame_height, n_bands, band, image_rows, halo_rows, row_begin, row_end, out_ops);
-    return PLR_OK;
+    return plrf_exchange_plan_rows(frame_height, n_bands, nullptr, band, image_rows, halo_rows, row_begin, row_end, out_ops, out_count);
 }
 
 int plrf_rccl_get_unique_id(void* out_128_bytes) {
@@ -170,10 +189,16 @@ int plrf_rccl_get_unique_id(void* out_128_bytes) {
 }
 
 int plrf_rccl_attach(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_height, void** out_exchange) {
+    return plrf_rccl_attach_rows(pipeline, unique_id_128_bytes, rank, world, frame_height, nullptr, out_exchange);
+}
+
+int plrf_rccl_attach_rows(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_height, const uint32_t* row_bounds, void** out_exchange) {
     if (!pipeline || !unique_id_128_bytes || !out_exchange || world < 1 || rank < 0 || rank >= world) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach: invalid argument");
+    if (int rc = checkBounds(frame_height, (uint32_t)world, row_bounds, "plrf_rccl_attach_rows")) return rc;
     RcclExchange* x = new RcclExchange();
     x->fp = (FramePipeline*)pipeline;
     x->rank = rank; x->world = world; x->frameHeight = frame_height;
+    if (row_bounds) x->bounds.assign(row_bounds, row_bounds + world + 1);
     ncclUniqueId id;
     std::memcpy(&id, unique_id_128_bytes, sizeof(id));
     int rc = x->nccl(ncclCommInitRank(&x->comm, world, id, rank), "ncclCommInitRank");

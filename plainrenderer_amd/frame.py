@@ -77,10 +77,12 @@ class FramePipeline:
             raise PlrError("plrf_rccl_get_unique_id: " + self.lib.plrf_rccl_last_error().decode())
         return buf.raw
 
-    def attach_rccl(self, unique_id, rank, world, frame_height):
+    def attach_rccl(self, unique_id, rank, world, frame_height, bounds=None):
+        """bounds: world + 1 row boundaries of a partition chosen by the caller (tiling.balanced_bounds), or None for the equal partition"""
         self.lib.plrf_rccl_last_error.restype = C.c_char_p
         x = C.c_void_p()
-        rc = self.lib.plrf_rccl_attach(self.handle, C.create_string_buffer(bytes(unique_id), 128), C.c_int(rank), C.c_int(world), C.c_uint32(frame_height), C.byref(x))
+        rows = (C.c_uint32 * (world + 1))(*[int(v) for v in bounds]) if bounds is not None else None
+        rc = self.lib.plrf_rccl_attach_rows(self.handle, C.create_string_buffer(bytes(unique_id), 128), C.c_int(rank), C.c_int(world), C.c_uint32(frame_height), rows, C.byref(x))
         if rc != 0:
             raise PlrError("plrf_rccl_attach failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
         self._rccl = x

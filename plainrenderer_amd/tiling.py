@@ -17,8 +17,11 @@ import numpy as np
 BAND_ALIGNMENT = 64
 
 
-def band_rows(height, n_bands, index):
-    """Rows [begin, end) of band `index`: multiples of 64 rows (the last band ends at `height`), sizes differing by at most 64."""
+def band_rows(height, n_bands, index, bounds=None):
+    """Rows [begin, end) of band `index`: multiples of 64 rows (the last band ends at `height`), sizes differing by at most 64;
+    or, with `bounds` (n_bands + 1 row boundaries, balanced_bounds), the rows of that partition."""
+    if bounds is not None:
+        return int(bounds[index]), int(bounds[index + 1])
     tiles = (height + BAND_ALIGNMENT - 1) // BAND_ALIGNMENT
     if n_bands > tiles:
         raise ValueError("more bands (%d) than 64-row tiles (%d)" % (n_bands, tiles))
@@ -26,6 +29,42 @@ def band_rows(height, n_bands, index):
     begin = index * base + min(index, extra)
     end = begin + base + (1 if index < extra else 0)
     return begin * BAND_ALIGNMENT, min(end * BAND_ALIGNMENT, height)
+
+
+def equal_bounds(height, n_bands):
+    return [band_rows(height, n_bands, 0)[0]] + [band_rows(height, n_bands, i)[1] for i in range(n_bands)]
+
+
+def balanced_bounds(height, bounds, band_times, min_rows=2 * BAND_ALIGNMENT):
+    """Static load balancing of the bands from measured per-band render times: the time of a band is spread evenly over its rows (a
+    piecewise-constant cost density over the frame's rows) and the new boundaries cut that density into n equal parts, rounded to 64 rows,
+    every band keeping at least `min_rows`. Deterministic: every rank computes the same partition from the same gathered times.
+    -> n + 1 row boundaries."""
+    n = len(band_times)
+    assert len(bounds) == n + 1 and bounds[0] == 0 and bounds[-1] == height
+    times = [max(float(t), 1e-9) for t in band_times]
+    total = sum(times)
+    cum = [0.0]
+    for t in times:
+        cum.append(cum[-1] + t)
+
+    def row_at(cost):  # row where the cumulative cost reaches `cost`
+        for b in range(n):
+            if cost <= cum[b + 1] or b == n - 1:
+                frac = (cost - cum[b]) / times[b]
+                return bounds[b] + min(max(frac, 0.0), 1.0) * (bounds[b + 1] - bounds[b])
+        return float(height)
+
+    out = [0]
+    for k in range(1, n):
+        r = int(round(row_at(total * k / n) / BAND_ALIGNMENT)) * BAND_ALIGNMENT
+        lo = out[-1] + min_rows
+        hi = height - (n - k) * min_rows
+        out.append(min(max(r, lo), hi))
+    out.append(height)
+    if any(out[i + 1] - out[i] < min(min_rows, height // n) for i in range(n)) or any(v % BAND_ALIGNMENT for v in out[1:-1]):
+        return list(bounds)  # a frame too small to move boundaries in: keep the partition
+    return out
 
 
 class Rows:
@@ -195,9 +234,9 @@ class LocalTransport:
 class Exchange:
     """the exchange callback of one band: glue between the C++ host's exchange points and a transport"""
 
-    def __init__(self, fp, transport, height, n_bands, index):
+    def __init__(self, fp, transport, height, n_bands, index, bounds=None):
         from .frame import EXCHANGE_HISTOGRAM
-        self.fp, self.t, self.height, self.n, self.index = fp, transport, height, n_bands, index
+        self.fp, self.t, self.height, self.n, self.index, self.bounds = fp, transport, height, n_bands, index, bounds
         self._hist_id = EXCHANGE_HISTOGRAM
         self.calls = []
         self._pending = {}
@@ -222,7 +261,7 @@ class Exchange:
         def band_meta(i, b):
             # rows of band b in item i's image: the full-resolution band scaled by the item's resolution divisor
             div = max(1, round(self.height / items[i].image_rows))
-            b0, b1 = band_rows(self.height, self.n, b)
+            b0, b1 = band_rows(self.height, self.n, b, self.bounds)
             return b0 // div, min((b1 + div - 1) // div, items[i].image_rows)
 
         if phase == EXCHANGE_BEGIN:

@@ -379,6 +379,40 @@ def test_cpp_exchange_plan_equals_the_python_plan():
         assert {(k, a, e) for _, k, a, e in down} == {("recv" if k == "send" else "send", a, e) for _, k, a, e in up}
 
 
+def test_balanced_partition_and_its_exchange_plan():
+    """tiling.balanced_bounds (bench.py's static load balancing): boundaries stay multiples of 64 and strictly increasing, a band that took longer
+    gets fewer rows, equal times are a fixed point; the C++ plan (plrf_exchange_plan_rows) of such a partition equals the Python plan"""
+    import ctypes as C
+    from plainrenderer_amd import backend, tiling
+
+    class Op(C.Structure):
+        _fields_ = [("peer", C.c_uint32), ("send", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32)]
+    lib = C.CDLL(backend.LIB_PATH)
+    height, n = 4320, 4
+    eq = tiling.equal_bounds(height, n)
+    assert eq == [0, 1088, 2176, 3264, 4320]
+    bal = tiling.balanced_bounds(height, eq, [0.788, 1.073, 1.172, 1.113])  # the measured band times of the 8K frame (profiles/r02n_band_cost.txt)
+    assert bal[0] == 0 and bal[-1] == height and all(b % 64 == 0 for b in bal[1:-1]) and all(bal[i + 1] > bal[i] for i in range(n))
+    assert bal[1] - bal[0] > eq[1] - eq[0] and bal[3] - bal[2] < eq[3] - eq[2]  # the cheap sky band grows, the slowest band shrinks
+    assert tiling.balanced_bounds(height, bal, [1.0] * n) == bal
+    assert tiling.balanced_bounds(128, [0, 64, 128], [1.0, 5.0]) == [0, 64, 128]  # nothing to move in a two-tile frame
+    assert tiling.band_rows(height, n, 2, bal) == (bal[2], bal[3])
+    for div in (1, 2):
+        image_rows = height // div
+        for halo in (16, 64, 224, 2000):
+            bands = [tiling.Rows(0, bal[k] // div, min((bal[k + 1] + div - 1) // div, image_rows), halo, 16, image_rows) for k in range(n)]
+            for b in range(n):
+                ops, cnt = (Op * 4)(), C.c_uint32()
+                rows = (C.c_uint32 * (n + 1))(*bal)
+                assert lib.plrf_exchange_plan_rows(C.c_uint32(height), C.c_uint32(n), rows, C.c_uint32(b), C.c_uint32(image_rows), C.c_uint32(halo),
+                                                   C.c_uint32(bands[b].row_begin), C.c_uint32(bands[b].row_end), ops, C.byref(cnt)) == 0
+                got = [(int(o.peer), "send" if o.send else "recv", int(o.row_begin), int(o.row_end)) for o in ops[:cnt.value]]
+                assert got == tiling.neighbour_plan(bands, b, n), (b, div, halo)
+    bad = (C.c_uint32 * (n + 1))(0, 1000, 2176, 3264, 4320)  # an interior boundary that is not a multiple of 64 is refused
+    assert lib.plrf_exchange_plan_rows(C.c_uint32(height), C.c_uint32(n), bad, C.c_uint32(0), C.c_uint32(height), C.c_uint32(16), C.c_uint32(0), C.c_uint32(1000), (Op * 4)(),
+                                       C.byref(C.c_uint32())) != 0
+
+
 @pytest.mark.gpu
 def test_gpu_two_bands_of_realistic_height_with_default_halos(monkeypatch):
     """Two bands of 576 rows of a 1024 x 1152 frame with the DEFAULT halos (64 trace rows of GI, 16 of GI history, 224 rows of resolved colour,

@@ -1,6 +1,7 @@
 """Redundant compute of band rendering, measured on ONE GPU without the exchange: the N bands of the 7680 x (1080 N) frame are rendered one after
 the other (each with the halo rows it recomputes, producers split into edge / interior dispatches as the overlapped exchange records them) and
-their times are summed and compared with the time of the unpartitioned frame.   python tools/band_cost.py [N]   (default 4: the 8K frame)"""
+their times are summed and compared with the time of the unpartitioned frame.
+    python tools/band_cost.py [N] [--passes] [--balance]   (default N = 4: the 8K frame; --balance: band heights from measured band times, as bench.py does)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -45,11 +46,22 @@ def measure(band):
 
 full, full_passes = measure(None)
 print("unpartitioned %dx%d frame: %.3f ms" % (w, h, full))
-total, band_passes = 0.0, {}
+bounds = tiling.equal_bounds(h, n)
+if "--balance" in sys.argv:
+    # what bench.py --gpus N does before its timed region (static load balancing from measured band times), here with the bands one after the other
+    for it in range(2):
+        times = [measure((bounds[i], bounds[i + 1]))[0] for i in range(n)]
+        print("partition %s: band times %s ms, slowest / mean = %.3f" % (bounds, ["%.3f" % t for t in times], max(times) / (sum(times) / n)))
+        new = tiling.balanced_bounds(h, bounds, times)
+        if new == bounds:
+            break
+        bounds = new
+total, band_passes, slowest = 0.0, {}, 0.0
 for i in range(n):
-    band = tiling.band_rows(h, n, i)
+    band = (bounds[i], bounds[i + 1])
     ms, acc = measure(band)
     total += ms
+    slowest = max(slowest, ms)
     for k, v in acc.items():
         band_passes[k] = band_passes.get(k, 0.0) + v
     print("band %d of %d (rows %d..%d): %.3f ms" % (i, n, band[0], band[1], ms))
@@ -65,6 +77,5 @@ if "--passes" in sys.argv:
 gf, gb = group(full_passes), group(band_passes)
 for k in sorted(gb, key=lambda k: -gb[k]):
     print("  %-34s bands %.3f ms, unpartitioned %.3f ms (%+.1f %%)" % (k, gb[k], gf.get(k, 0.0), 100.0 * (gb[k] / gf[k] - 1.0) if gf.get(k) else 0.0))
-print("sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute; slowest band %.3f ms -> compute-only speed-up %.2fx on %d GPUs" % (
-    total, total / full, 100.0 * (total / full - 1.0), 0.0, 0.0, n) if False else
-      "sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute" % (total, total / full, 100.0 * (total / full - 1.0)))
+print("sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute; slowest band %.3f ms -> at most %.2fx on %d GPUs before any exchange wait" % (
+    total, total / full, 100.0 * (total / full - 1.0), slowest, full / slowest, n))
