@@ -192,7 +192,14 @@ template <> struct Texel<F_R8> {
 // ---- samplers (resources/shaders/global.inc:35-42) ----
 enum Address { CLAMP = 0, REPEAT = 1, BORDER_WHITE = 2, BORDER_BLACK = 3 };
 
-PLR_DI int clampi(int i, int n) { return min(max(i, 0), n - 1); } // v_med3_i32; n >= 1
+// clamp to [0, hi], hi >= 0: ONE v_med3_i32. The compiler only forms it from min(max()) when both bounds are constants, and leaves two half-rate
+// instructions otherwise (the deferred shade had 108 of them); the asm is not volatile, so it is scheduled and hoisted like any other instruction
+PLR_DI int clampTo(int i, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(hi));
+    return r;
+}
+PLR_DI int clampi(int i, int n) { return clampTo(i, n - 1); } // n >= 1
 PLR_DI int repeati(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 PLR_DI float saneCoord(float u) { return gclamp(u, -1.0e6f, 1.0e6f); }
 PLR_DI void linearCoord(float u, int* i0, float* alpha) {

@@ -91,7 +91,7 @@ PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
     linearCoord(u * (float)im.w, &i0, &a);
     linearCoord(v * (float)im.h, &j0, &b);
     const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w), y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
-    const int xb = max(min(x0, im.w - 2), 0);
+    const int xb = clampTo(x0, im.w - 2);
     auto rowPair = [&](int y, vec4* t0, vec4* t1) {
         const uint2* row = (const uint2*)im.ptr + __umul24((uint32_t)y, (uint32_t)im.w);
         uint4 q; // the launcher sends images narrower than two texels to the general kernel
@@ -157,7 +157,7 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
         const float tu = bxw + cx * (sxw * d), tv = byh + cy * (syh * d);
         const int xi = (int)floorf(tu), yi = (int)floorf(tv);
         const bool inside = (uint32_t)xi < w && (uint32_t)yi < h; // black border outside: depth 0, always "lit"
-        const uint32_t x = (uint32_t)min(max(xi, 0), wm1), y = (uint32_t)min(max(yi, 0), hm1);
+        const uint32_t x = (uint32_t)clampTo(xi, wm1), y = (uint32_t)clampTo(yi, hm1);
         const uint32_t texel = sm[fastm::texelIndex(x, y, w)];
         lit += ((inside ? texel : 0u) <= depthThreshold) ? 1u : 0u;
     };
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
 
     vec3 lightingIndirect;
     if (INDIRECT_TECH == 0) {
-        const int ix = min(max((int)floorf(su * (float)P.ysh.w), 0), P.ysh.w - 1), iy = min(max((int)floorf(sv * (float)P.ysh.h), 0), P.ysh.h - 1);
+        const int ix = clampTo((int)floorf(su * (float)P.ysh.w), P.ysh.w - 1), iy = clampTo((int)floorf(sv * (float)P.ysh.h), P.ysh.h - 1);
         const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.ysh.w));
         const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.cocg.w));
         // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
         const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
         const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
-        const int xb = max(min(x0, vol.w - 2), 0);
+        const int xb = clampTo(x0, vol.w - 2);
         auto rowLerp = [&](uint32_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
             const uint2* row = (const uint2*)vol.ptr + rowBase;
             uint4 q;
