@@ -80,6 +80,21 @@ PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries
 }
 
 
+def kernel_source_digest():
+    """sha1 over the kernel sources (plainrenderer_amd/csrc): stamps a PMC summary with the build it was measured on"""
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "plainrenderer_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        if os.path.basename(d) == "_obj":
+            continue
+        for f in sorted(files):
+            if f.endswith((".hip", ".h", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def pmc_traffic(pass_name):
     """HBM-side bytes per launch of the pass (all its kernels) from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
     FETCH_SIZE / WRITE_SIZE passes of this same command at the default workload, gfx950 x2 fetch correction applied)."""
@@ -88,13 +103,17 @@ def pmc_traffic(pass_name):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
     if not prefixes or not files:
         return None, None
-    total, found = 0, False
+    total, found, digest = 0, False, None
     for line in open(files[-1]):
+        if line.startswith("# kernel source digest:"):
+            digest = line.split(":", 1)[1].strip()
         if any(line.startswith(p) for p in prefixes):
             # mean bytes per dispatch of that kernel; a kernel launched k times per frame by several passes (bloom levels) is not attributed here
             total += int(line.strip().split(",")[-1])
             found = True
-    return (total, os.path.basename(files[-1])) if found else (None, None)
+    # the summary is only as good as the build it was taken on: say whether the kernels have changed since
+    src = os.path.basename(files[-1]) + (" (kernel sources unchanged since)" if digest == kernel_source_digest() else " (kernel sources CHANGED since: stale)" if digest else "")
+    return (total, src) if found else (None, None)
 
 
 def build_scene(args, device, w, h, band=None):
@@ -261,7 +280,7 @@ def main():
                 dist.all_reduce(times, op=dist.ReduceOp.SUM)
             times = [float(v) for v in times.cpu().tolist()]
             band_partition["calibration"].append({"bounds": list(bounds), "band_ms": [round(t * 1e3, 4) for t in times]})
-            new = tiling.balanced_bounds(h_, bounds, times)
+            new = tiling.balanced_bounds(h_, bounds, times, min_rows=512)  # every band keeps more rows than the widest halo (224)
             if new == bounds:
                 break
             bounds = new

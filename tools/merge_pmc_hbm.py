@@ -17,6 +17,9 @@ with open(out, "w") as fh:
     fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-include-regex plr::), mean per dispatch, python bench.py --steps 4 --warmup 2\n")
     fh.write("# units: KiB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B -> traffic = 2*FETCH_SIZE + WRITE_SIZE;\n")
     fh.write("# calibrated on tonemapping (reads 4 B/px) and applyBloom (reads 8 B/px): 2*FETCH_SIZE matches the algorithmic reads within 0.5 %\n")
+    dig = os.path.join(src, "source_digest.txt")
+    if os.path.exists(dig):
+        fh.write("# kernel source digest: %s\n" % open(dig).read().strip())
     fh.write("kernel,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,traffic_bytes\n")
     for r in rows: fh.write("%s,%d,%.1f,%.1f,%d\n" % r)
 for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pass_table.txt", "bench_1080p.json", "bench_8k.json", "parity_4k.txt", "valu_rates.txt", "band_cost.txt"):

@@ -8,6 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())" > $OUT/source_digest.txt
 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 python $REPO/tools/summarize_profile.py $(ls $OUT/kt/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
