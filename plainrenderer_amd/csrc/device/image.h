@@ -202,8 +202,23 @@ PLR_DI int clampTo(int i, int hi) {
 PLR_DI int clampi(int i, int n) { return clampTo(i, n - 1); } // n >= 1
 PLR_DI int repeati(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 PLR_DI float saneCoord(float u) { return gclamp(u, -1.0e6f, 1.0e6f); }
+#ifdef PLR_FAST_SET
+// floor and conversion in ONE instruction (v_cvt_flr_i32_f32, gfx9). The conversion saturates and maps NaN to 0, so the range clamp that keeps
+// (int)floorf() defined is not needed in front of it: a coordinate beyond +-2^31 ends on the first / last texel after the index clamp either way
+PLR_DI int floorToInt(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#else
+PLR_DI int floorToInt(float x) { return (int)floorf(saneCoord(x)); }
+#endif
 PLR_DI void linearCoord(float u, int* i0, float* alpha) {
+#ifdef PLR_FAST_SET
+    const int ti = floorToInt((u - 0.5f) * 256.0f + 0.5f);
+#else
     const int ti = (int)floorf((saneCoord(u) - 0.5f) * 256.0f + 0.5f);
+#endif
     *i0 = ti >> 8;
     *alpha = (float)(ti & 255) * (1.0f / 256.0f);
 }

@@ -40,8 +40,7 @@ struct Volume {
 // every instance on a face of its box, where the clamped-index form diverges into eight single-texel loads.
 // fx = (u * n - 0.5) * 256 + 0.5 arrives already folded into one multiply-add of the local position (see traceInstance)
 PLR_DI void cellCoord(float fx, int n, int* i0, float* a) {
-    int ti = (int)floorf(fastm::clampCoord(fx));
-    ti = min(max(ti, 0), (n - 1) << 8);
+    const int ti = clampTo(floorToInt(fx), (n - 1) << 8); // the same integer as (int)floorf(clamp(fx)) clamped: the conversion saturates, NaN -> 0
     *i0 = min(ti >> 8, n - 2);
     *a = (float)(ti - (*i0 << 8)) * (1.0f / 256.0f);
 }

@@ -155,7 +155,7 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
     auto tap = [&](int i, float cx, float cy) {
         const float d = sqrtv(((float)i + 0.5f * noise) * (1.f / 12.f));
         const float tu = bxw + cx * (sxw * d), tv = byh + cy * (syh * d);
-        const int xi = (int)floorf(tu), yi = (int)floorf(tv);
+        const int xi = floorToInt(tu), yi = floorToInt(tv);
         const bool inside = (uint32_t)xi < w && (uint32_t)yi < h; // black border outside: depth 0, always "lit"
         const uint32_t x = (uint32_t)clampTo(xi, wm1), y = (uint32_t)clampTo(yi, hm1);
         const uint32_t texel = sm[fastm::texelIndex(x, y, w)];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
 
     vec3 lightingIndirect;
     if (INDIRECT_TECH == 0) {
-        const int ix = clampTo((int)floorf(su * (float)P.ysh.w), P.ysh.w - 1), iy = clampTo((int)floorf(sv * (float)P.ysh.h), P.ysh.h - 1);
+        const int ix = clampTo(floorToInt(su * (float)P.ysh.w), P.ysh.w - 1), iy = clampTo(floorToInt(sv * (float)P.ysh.h), P.ysh.h - 1);
         const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.ysh.w));
         const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.cocg.w));
         // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
