@@ -6,7 +6,8 @@
 // geometry rows are spread over the XCDs) and walks a chunk column by column: the tiles in flight on an XCD form a compact block whose
 // footprint does not grow with the image width. Launch with xcdWalkGrid(...) blocks (one-dimensional).
 // Measured on kernels with SMALL footprints (deferred shading, TAA, SDF trace) the same mapping is neutral to harmful (one chunk per XCD:
-// shading +33 %, trace +20 % from the load imbalance between bands): they keep the natural mapping.
+// shading +33 %, trace +20 % from the load imbalance between bands), and on the streaming passes whose tiles share only a halo row or two (GI
+// upscale 51 -> 55 us, temporal GI filter 43.4 -> 44.5 us with 2 chunks per XCD): they keep the natural mapping.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "types.h"
