@@ -459,7 +459,12 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
-    const float u = ((float)px + 0.5f) * rcpf((float)targetYSH.w), v = ((float)py + 0.5f) * rcpf((float)targetYSH.h);
+    // texel size as the shader has it: the correctly rounded 1 / size (Newton step on v_rcp_f32). With the raw approximation a reprojected coordinate
+    // lands on the other side of a 1/256 sub-texel weight step for a few pixels in 10^5, which is visible against the half-float quantum
+    const float fw = (float)targetYSH.w, fh = (float)targetYSH.h;
+    const float rw0 = rcpf(fw), rh0 = rcpf(fh);
+    const float tsx = __builtin_fmaf(__builtin_fmaf(-fw, rw0, 1.f), rw0, rw0), tsy = __builtin_fmaf(__builtin_fmaf(-fh, rh0, 1.f), rh0, rh0);
+    const float u = ((float)px + 0.5f) * tsx, v = ((float)py + 0.5f) * tsy;
     // the input images have the target's size: the tap at the pixel centre is the texel itself (weights 1,0,0,0)
     const size_t idx = (size_t)py * (size_t)targetYSH.w + px;
     const vec4 current_Y_SH = halves4(((const uint2*)inYSH.ptr)[idx]);

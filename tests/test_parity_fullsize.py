@@ -4,7 +4,7 @@
 Every HIP pass is fed exactly what the oracle pass consumed and is held to the tolerance statement of tests/parity.py: one storage
 quantum per channel for every pixel whose discrete decisions agree with the oracle's (decision signatures, oracle/oracle.h), a hard cap
 on the number of pixels where a float rounding flipped a decision, and a bound on what a flipped pixel may differ by.
-PLR_PARITY_SIZE=WxH (multiples of 64) runs the same tests at another size. Measured numbers: profiles/r02_parity_4k.txt.
+PLR_PARITY_SIZE=WxH (multiples of 64) runs the same tests at another size. Measured numbers: profiles/r02p_parity_4k.txt.
 """
 import os
 
