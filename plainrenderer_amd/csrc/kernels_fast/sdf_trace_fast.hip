@@ -223,7 +223,14 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
     if (active) {
         const float u = (float)px / (float)outYSH.w, v = (float)py / (float)outYSH.h; // IEEE quotient: see the note at the top
         const float depth = sampleNearest2D<F_D32, CLAMP>(depthTexture, vec2(u, v)).x;
-        const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
+        // linear depth as the shader rounds it (product, sum and quotient separately; an IEEE quotient in this file): it is one side of the 0.5 m
+        // depth test that decides which neighbours' rays a pixel takes in the 3x3 resolve
+        float depthLinear;
+        {
+#pragma clang fp contract(off)
+            const float span = g->nearPlane - g->farPlane, t = (-depth + 1.f) * span, den = g->farPlane + t, nf = g->nearPlane * g->farPlane;
+            depthLinear = nf / den;
+        }
         const vec3 ray = ld3(g->cameraForward) + (-g->cameraTanFovHalf * (v * 2.f - 1.f)) * ld3(g->cameraUp) +
                          (g->cameraTanFovHalf * g->cameraAspectRatio * (u * 2.f - 1.f)) * ld3(g->cameraRight);
         const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
