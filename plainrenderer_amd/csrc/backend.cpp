@@ -332,6 +332,46 @@ static bool sameDesc(const plr_image_desc& a, const plr_image_desc& b) { return 
 int launchSkyLutProbe(const ImgView& lut, const float* dirs, float* out, int64_t n); // kernels_fast/stream_fast.hip
 int launchSamplerProbe(const ImgView& view, int filter, int address, const float* coords, float* out, int64_t n); // kernels/probes.hip
 
+
+static bool sameView(const ImgView& a, const ImgView& b) { return a.ptr == b.ptr && a.w == b.w && a.h == b.h && a.d == b.d && a.fmt == b.fmt; }
+int launchOverTwoRowRanges(const PassCtx* const* ctxs, size_t count, LaunchFn single) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx& a = *ctxs[0];
+    const PassCtx& b = *ctxs[1];
+    if (a.sampledMask != b.sampledMask || a.storageMask != b.storageMask || a.sbufMask != b.sbufMask || a.ubufMask != b.ubufMask || a.push != b.push || a.spec != b.spec ||
+        a.dispatch[0] != b.dispatch[0] || a.base[0] != b.base[0] || a.dispatch[2] != b.dispatch[2] || a.validRows[0] != b.validRows[0] || a.validRows[1] != b.validRows[1] ||
+        a.extraCountY || b.extraCountY || a.scratchSlot != b.scratchSlot)
+        return kUseGeneralKernel;
+    for (int i = 0; i < kMaxBindings; i++) {
+        if (a.hasSampled(i) && !sameView(a.sampled[i], b.sampled[i])) return kUseGeneralKernel;
+        if (a.hasStorage(i) && !sameView(a.storage[i], b.storage[i])) return kUseGeneralKernel;
+        if (a.hasSbuf(i) && (a.sbuf[i].ptr != b.sbuf[i].ptr || a.sbuf[i].size != b.sbuf[i].size)) return kUseGeneralKernel;
+        if (a.hasUbuf(i) && (a.ubuf[i].ptr != b.ubuf[i].ptr || a.ubuf[i].size != b.ubuf[i].size)) return kUseGeneralKernel;
+    }
+    if (b.base[1] < a.base[1] + a.dispatch[1] || a.dispatch[1] == 0 || b.dispatch[1] == 0) return kUseGeneralKernel; // the second range lies below the first
+    PassCtx both = a;
+    both.extraBaseY = b.base[1];
+    both.extraCountY = b.dispatch[1];
+    return single(both);
+}
+
+int twoRangeBlocks(const PassCtx& c, int imageH, int blockRows, int wgRows, TwoRanges* out, int* blocks, int* y0, int* end) {
+    const PassCtx::RowSpan a = c.rowSpan(imageH, wgRows);
+    *out = TwoRanges{};
+    *y0 = a.y0; *end = a.y1;
+    *blocks = a.y1 > a.y0 ? (a.y1 - a.y0 + blockRows - 1) / blockRows : 0;
+    if (!c.extraCountY) return 0;
+    const long long b0 = (long long)c.extraBaseY * wgRows, b1 = b0 + (long long)c.extraCountY * wgRows;
+    const int e0 = (int)(b0 < imageH ? b0 : imageH), e1 = (int)(b1 < imageH ? b1 : imageH);
+    // the first range must end on a block boundary (its last block would otherwise run into rows of neither range) and the second start on one
+    if ((a.y1 - a.y0) % blockRows || (e0 - a.y0) % blockRows || e0 < a.y1 || e1 <= e0) return 1;
+    out->split = *blocks;
+    out->gap = (e0 - a.y0) / blockRows - *blocks;
+    *blocks += (e1 - e0 + blockRows - 1) / blockRows;
+    *end = e1;
+    return 0;
+}
+
 } // namespace plr
 
 using namespace plr;
@@ -687,6 +727,7 @@ void PassCtx::splitTimingBetween(const PassCtx& first, const PassCtx& second) {
     if (endSegment() != PLR_OK) return;
     (void)beginSegment(second.passName);
 }
+
 
 // ---------------------------------------------------------------- stream scheduler
 // The recorded executions are launched in order, but not all on one stream: an execution only has to wait for the earlier ones it

@@ -38,6 +38,9 @@ struct PassCtx {
     std::vector<uint8_t> push;
     uint32_t dispatch[3] = {1, 1, 1};
     uint32_t base[3] = {0, 0, 0};         // first workgroup of the dispatch (vkCmdDispatchBase semantics; band rendering, plr.h)
+    // a second range of workgroup rows covered by the same launch (pass fusion of two executions of one pass that differ in their rows only:
+    // the edge rows a band renderer produces first, above and below its interior); 0 rows = none. Set by launchOverTwoRowRanges
+    uint32_t extraBaseY = 0, extraCountY = 0;
     uint32_t validRows[2] = {0, 0};       // rows of the input images that hold valid data (band rendering, plr.h); {0, 0} = all
     // [lo, hi) for an input image of imageH rows
     void validRowRange(int imageH, int* lo, int* hi) const {
@@ -94,6 +97,13 @@ struct PassCtx {
 };
 
 typedef int (*LaunchFn)(const PassCtx&);
+// fused launcher body for "the same pass twice, over two row ranges": if the two executions bind the same resources and the second one's rows lie
+// below the first one's, `single` is called once with the second range in extraBaseY / extraCountY; kUseGeneralKernel otherwise (two launches)
+int launchOverTwoRowRanges(const PassCtx* const* ctxs, size_t count, LaunchFn single);
+// the remap a kernel applies to its block row when a launch covers two row ranges: rows of the second range start `gap` block rows further down
+struct TwoRanges { int split = 0x7fffffff, gap = 0; };
+// block rows of the two ranges for blocks of blockRows pixel rows: 0 = fine (*blocks = total block rows, *end = end row of the launch), else not expressible
+int twoRangeBlocks(const PassCtx& c, int imageH, int blockRows, int wgRows, TwoRanges* out, int* blocks, int* y0, int* end);
 // a PLR_MATH_FAST launcher returns this when the recorded execution is outside the configuration its kernel was built for;
 // the backend then runs the general (exact-order) kernel of the same shader
 constexpr int kUseGeneralKernel = 1;

@@ -186,11 +186,12 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
                                                                  uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
                                                                  uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig,
-                                                                 uint4* __restrict__ packedOut, ImgView packDepth) {
+                                                                 uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges) {
     __shared__ RayInfo sharedRays[4][64];
     uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1);
+    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
+    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + blockRow * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
@@ -351,16 +352,28 @@ static int launchImpl(const PassCtx& c, const SpatialPackTarget* pack) {
     const ImgView& out = c.storage[0];
     if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
     // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
-    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
+    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1];
+    int groupsY = groupY0 + (int)c.dispatch[1];
     if (groupsX <= 0 || groupsY <= groupY0) return 0;
     if (groupY0 & 1) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
+    // rows in units of workgroups (8 pixel rows), blocks of 2 workgroups; a second row range covered by the same launch (pass fusion of the two
+    // edge dispatches of band rendering) is expressed as a jump in the block row
+    TwoRanges ranges;
+    int blockRowsTotal = (int)divUp((unsigned)(groupsY - groupY0), 2u);
+    if (c.extraCountY) {
+        if ((c.dispatch[1] & 1u) || ((c.extraBaseY - (uint32_t)groupY0) & 1u) || c.extraBaseY < (uint32_t)groupsY) return kUseGeneralKernel;
+        ranges.split = blockRowsTotal;
+        ranges.gap = (int)(c.extraBaseY - (uint32_t)groupY0) / 2 - blockRowsTotal;
+        blockRowsTotal += (int)divUp(c.extraCountY, 2u);
+        groupsY = (int)(c.extraBaseY + c.extraCountY);
+    }
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)(groupsY - groupY0), 2u));
+    const dim3 grid(divUp((unsigned)groupsX, 2u), (unsigned)blockRowsTotal);
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
-                       tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}
+                       tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     if (pack) {
         // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
@@ -389,4 +402,7 @@ static int launch(const PassCtx& c) { return launchImpl(c, nullptr); }
 int launchTraceFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return fasttrace::launchImpl(c, &target); }
 static int fasttrace_launch(const PassCtx& c) { return fasttrace::launch(c); }
 PLR_REGISTER_SHADER_FAST("sdfDiffuseTrace.comp", fasttrace_launch);
+// band rendering records the rows its neighbours need as two dispatches (above and below the interior): one launch
+static int fasttrace_two_ranges(const PassCtx* const* ctxs, size_t count) { return launchOverTwoRowRanges(ctxs, count, fasttrace_launch); }
+PLR_REGISTER_FUSION("sdfDiffuseTrace over two row ranges", fasttrace_two_ranges, "sdfDiffuseTrace.comp", "sdfDiffuseTrace.comp");
 } // namespace plr

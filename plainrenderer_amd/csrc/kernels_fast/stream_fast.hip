@@ -455,9 +455,10 @@ template <int PACK>
 __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                                   ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
                                                                   ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase,
-                                                                  uint4* __restrict__ packedOut, ImgView packDepth) {
+                                                                  uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges) {
+    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    const int py = yBase + blockRow * 4 + (int)(threadIdx.x >> 6);
     if (px >= coverW || py >= coverH) return;
     // texel size as the shader has it: the correctly rounded 1 / size (Newton step on v_rcp_f32). With the raw approximation a reprojected coordinate
     // lands on the other side of a 1/256 sub-texel weight step for a few pixels in 10^5, which is visible against the half-float quantum
@@ -518,12 +519,15 @@ static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack)
     // the centre-tap shortcut and the shared store index need all trace-resolution images to have one size
     for (int b : {1, 2, 3}) if (c.storage[b].w != out.w || c.storage[b].h != out.h) return kUseGeneralKernel;
     for (int b : {4, 5, 6, 7}) if (c.sampled[b].w != out.w || c.sampled[b].h != out.h) return kUseGeneralKernel;
-    const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
+    // rows [y0, h) in blocks of 4; a second row range in the same launch (pass fusion of band rendering's two edge dispatches)
+    TwoRanges ranges;
+    int blockRows, y0, h;
+    if (twoRangeBlocks(c, out.h, 4, 8, &ranges, &blockRows, &y0, &h)) return kUseGeneralKernel;
+    const int w = std::min((int)(c.dispatch[0] * 8u), out.w);
     if (w <= 0 || h <= y0) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+    const dim3 grid(divUp((unsigned)w, 64u), (unsigned)blockRows);
 #define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, \
-                          pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}
+                          pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
     if (pack) {
         if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
         if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
@@ -588,6 +592,8 @@ PLR_REGISTER_SHADER_FAST("applyBloom.comp", faststream_apply_bloom);
 PLR_REGISTER_SHADER_FAST("tonemapping.comp", faststream_tonemapping);
 PLR_REGISTER_SHADER_FAST("indirectLightUpscale.comp", faststream_upscale);
 PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseTemporal.comp", faststream_temporal_gi);
+static int faststream_temporal_gi_two_ranges(const PassCtx* const* ctxs, size_t count) { return launchOverTwoRowRanges(ctxs, count, faststream_temporal_gi); }
+PLR_REGISTER_FUSION("filterIndirectDiffuseTemporal over two row ranges", faststream_temporal_gi_two_ranges, "filterIndirectDiffuseTemporal.comp", "filterIndirectDiffuseTemporal.comp");
 } // namespace plr
 
 // ---- exhaustive check of the fast R11G11B10 encoder (include/plr.h plr_debug_verify_r11g11b10_fast)

@@ -233,11 +233,12 @@ constexpr int kStripW = 62, kStripRows = 4;
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
 __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
-                                                                 int coverW, int coverH, int yBase) {
+                                                                 int coverW, int coverH, int yBase, TwoRanges ranges) {
     static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
-    const int rowFirst = yBase + ((int)blockIdx.y * 4 + wave) * kStripRows;
+    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
+    const int rowFirst = yBase + (blockRow * 4 + wave) * kStripRows;
     if (rowFirst >= coverH) return; // wave-uniform
     const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
     const int xc = clampi(px, current.w);
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
 }
 
 typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
+typedef void (*TaaStripKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int, TwoRanges);
 template <bool CLIP, bool DILATE, bool TONEMAP> static TaaKernel pickTech(int tech) {
     switch (tech) {
         case 0: return temporalFilterFastKernel<CLIP, DILATE, 0, TONEMAP>;
@@ -460,7 +462,7 @@ static int launch(const PassCtx& c) {
         else k = tonemap ? pickTech<false, false, true>(tech) : pickTech<false, false, false>(tech);
     }
     if (!k) return c.fail(-6, "temporalFilter: historySampleTech must be 0..4");
-    TaaKernel strip = nullptr;
+    TaaStripKernel strip = nullptr;
     if (tech == 0 || tech == 4) {
 #define PLR_STRIP(T) (clip ? (dilate ? (tonemap ? temporalFilterStripKernel<true, true, T, true> : temporalFilterStripKernel<true, true, T, false>)   \
                                      : (tonemap ? temporalFilterStripKernel<true, false, T, true> : temporalFilterStripKernel<true, false, T, false>)) \
@@ -471,15 +473,18 @@ static int launch(const PassCtx& c) {
     }
     const ImgView& out = c.storage[1];
     const int w = std::min({(int)(c.dispatch[0] * 8u), out.w, c.sampled[0].w});
-    const PassCtx::RowSpan rs = c.rowSpan(std::min(out.h, c.sampled[0].h));
-    const int h = rs.y1, y0 = rs.y0; // rows [y0, h)
+    // rows [y0, h), in blocks of 16 (4 waves x kStripRows); a second row range in the same launch (pass fusion of band rendering's two edge dispatches)
+    TwoRanges ranges;
+    int stripBlocks, y0, h;
+    const bool expressible = twoRangeBlocks(c, std::min(out.h, c.sampled[0].h), 4 * kStripRows, 8, &ranges, &stripBlocks, &y0, &h) == 0;
     if (w <= 0 || h <= y0) return 0;
     // the strip kernel indexes all per-pixel images with one coordinate: it needs them to be the same size
     const bool sameSize = c.sampled[0].w == out.w && c.sampled[0].h == out.h && c.sampled[3].w == out.w && c.sampled[3].h == out.h && c.sampled[5].w == out.w &&
                           c.sampled[5].h == out.h && out.w >= 4;
+    if (c.extraCountY && !(strip && sameSize && expressible)) return kUseGeneralKernel; // two ranges: strip kernel only (else two launches)
     if (strip && sameSize)
-        strip<<<dim3(divUp((unsigned)w, (unsigned)kStripW), divUp((unsigned)(h - y0), 4u * kStripRows)), 256, 0, c.stream>>>(
-            c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
+        strip<<<dim3(divUp((unsigned)w, (unsigned)kStripW), (unsigned)stripBlocks), 256, 0, c.stream>>>(
+            c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, ranges);
     else
         k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
                                                                                        (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
@@ -491,4 +496,6 @@ static int launch(const PassCtx& c) {
 
 static int fasttaa_launch(const PassCtx& c) { return fasttaa::launch(c); }
 PLR_REGISTER_SHADER_FAST("temporalFilter.comp", fasttaa_launch);
+static int fasttaa_two_ranges(const PassCtx* const* ctxs, size_t count) { return launchOverTwoRowRanges(ctxs, count, fasttaa_launch); }
+PLR_REGISTER_FUSION("temporalFilter over two row ranges", fasttaa_two_ranges, "temporalFilter.comp", "temporalFilter.comp");
 } // namespace plr

@@ -166,7 +166,7 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1)
                                swap=be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(H, W, 4).copy(),
                                hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
                                light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes()))
-        res = dict(frames=frames, calls=list(ex.calls) if ex else [])
+        res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1])
         fp.destroy()
         be.shutdown()
         out[band[0] if band is not None else "full"] = res
@@ -268,6 +268,24 @@ def test_gpu_overlapped_exchange_with_interior_rows_equals_plain_exchange():
     assert over[0]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] and plain[0]["calls"][:5] == [0, 1, 2, 3, 4]
     for i in range(2):
         b0, b1 = tiling.band_rows(H, 2, i)
+        for f in range(N_FRAMES):
+            for k in ("post", "color", "swap"):
+                assert np.array_equal(over[i]["frames"][f][k][b0:b1], plain[i]["frames"][f][k][b0:b1]), "band %d frame %d %s" % (i, f, k)
+
+
+@pytest.mark.gpu
+def test_gpu_middle_band_launches_both_edges_at_once():
+    """three bands, halos smaller than the bands: the middle band records every producer of an exchanged image as top edge, bottom edge, exchange start,
+    interior; the backend issues the two edge dispatches of the trace, the temporal GI filter and the TAA resolve as ONE launch each over two row ranges
+    (pass fusion, backend.h launchOverTwoRowRanges). Frames are the same bits as with the plain exchange (one dispatch per producer)."""
+    inputs = _make_inputs()
+    small = dict(band_gi_halo=8, band_gi_history_halo=8, band_post_halo=16, band_taa_history_halo=8)
+    over = _run_bands(inputs, 3, False, dict(small, band_overlap_exchange=1))
+    plain = _run_bands(inputs, 3, False, dict(small, band_overlap_exchange=0))
+    # the outer bands have one edge each; the middle band fuses 3 x 2 edge executions on top of whatever both recordings fuse
+    assert over[1]["fused"] >= plain[1]["fused"] + 6, (over[1]["fused"], plain[1]["fused"])
+    for i in range(3):
+        b0, b1 = tiling.band_rows(H, 3, i)
         for f in range(N_FRAMES):
             for k in ("post", "color", "swap"):
                 assert np.array_equal(over[i]["frames"][f][k][b0:b1], plain[i]["frames"][f][k][b0:b1]), "band %d frame %d %s" % (i, f, k)
