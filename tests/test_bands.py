@@ -55,7 +55,7 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, height, out):
+def _gloo_worker(rank, world, port, height, out, bounds=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,16 +66,16 @@ def _gloo_worker(rank, world, port, height, out):
         items, arrays = [], []
         for div, row_bytes, halo in ((1, 24, 16), (2, 12, 8)):
             rows = height // div
-            b0, b1 = tiling.band_rows(height, world, rank)
+            b0, b1 = tiling.band_rows(height, world, rank, bounds)
             b0, b1 = b0 // div, min((b1 + div - 1) // div, rows)
             img = np.full((rows, row_bytes), 0xEE, np.uint8)
-            img[b0:b1] = (np.arange(b0, b1, dtype=np.uint8)[:, None] * 3 + np.arange(row_bytes, dtype=np.uint8)[None, :]) ^ 0x5A
+            img[b0:b1] = ((np.arange(b0, b1)[:, None] * 3 + np.arange(row_bytes)[None, :]) % 256).astype(np.uint8) ^ 0x5A
             arrays.append(img)
             items.append(tiling.Rows(img.ctypes.data, b0, b1, halo, row_bytes, rows))
 
         def band_meta(i, b):
             div = (1, 2)[i]
-            a0, a1 = tiling.band_rows(height, world, b)
+            a0, a1 = tiling.band_rows(height, world, b, bounds)
             return a0 // div, min((a1 + div - 1) // div, height // div)
 
         # first image in one call, second as the overlapped form: start, "interior work" on rows the exchange does not touch, wait
@@ -93,13 +93,15 @@ def _gloo_worker(rank, world, port, height, out):
         dist.destroy_process_group()
 
 
-def test_dist_transport_gloo_world2():
+@pytest.mark.parametrize("height,world,bounds", [(192, 2, None), (384, 3, [0, 192, 256, 384])])
+def test_dist_transport_gloo_world2(height, world, bounds):
+    """world 2 with the equal partition; world 3 with bands of unequal height (a balanced partition, tiling.balanced_bounds): the middle band of 64 rows
+    exchanges with both neighbours"""
     import torch.multiprocessing as mp
-    height, world = 192, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, height, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, height, q, bounds)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -111,12 +113,12 @@ def test_dist_transport_gloo_world2():
         assert p.exitcode == 0
     for rank in range(world):
         arrays, hist = got[rank]
-        assert np.array_equal(hist, np.arange(128, dtype=np.uint32) * 3)  # (0+1) + (1+1)
+        assert np.array_equal(hist, np.arange(128, dtype=np.uint32) * (world * (world + 1) // 2))  # sum of (rank + 1)
         for (div, row_bytes, halo), img in zip(((1, 24, 16), (2, 12, 8)), arrays):
             rows = height // div
-            b0, b1 = tiling.band_rows(height, world, rank)
+            b0, b1 = tiling.band_rows(height, world, rank, bounds)
             b0, b1 = b0 // div, min((b1 + div - 1) // div, rows)
-            expect = (np.arange(rows, dtype=np.uint8)[:, None] * 3 + np.arange(row_bytes, dtype=np.uint8)[None, :]) ^ 0x5A
+            expect = ((np.arange(rows)[:, None] * 3 + np.arange(row_bytes)[None, :]) % 256).astype(np.uint8) ^ 0x5A
             lo, hi = max(b0 - halo, 0), min(b1 + halo, rows)
             assert np.array_equal(img[lo:hi], expect[lo:hi]), "band + halo rows hold the owners' data"
             assert (img[:lo] == 0xEE).all() and (img[hi:] == 0xEE).all(), "rows beyond the halo are untouched"
