@@ -428,12 +428,68 @@ __global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source,
     }
 }
 
+// ---- any source / target size (the one odd level of a 4K chain, 135 -> 68 rows: 8 k outputs, a fraction of a wave per CU, so the launch is one
+// wave's latency). The exact kernel fetches a tap's texels only where the weight is not zero - thirteen taps of up to four dependent, branch-guarded
+// loads one after the other (10.6 us for 8 k outputs). Here all 52 loads of a thread are issued first and the zero-weight rule is applied as a select
+// on the decoded value (a texel with weight 0 must not contribute even if it is not finite).
+struct TapFetch { uint32_t t00, t10, t01, t11; float w00, w10, w01, w11; };
+PLR_DI TapFetch bloomTapFetch(const ImgView& im, float u, float v) {
+    int i0, j0; float a, b;
+    linearCoord(u * (float)im.w, &i0, &a);
+    linearCoord(v * (float)im.h, &j0, &b);
+    const uint32_t* base = (const uint32_t*)im.ptr;
+    const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w);
+    const uint32_t r0 = __umul24((uint32_t)clampi(j0, im.h), (uint32_t)im.w), r1 = __umul24((uint32_t)clampi(j0 + 1, im.h), (uint32_t)im.w);
+    TapFetch f;
+    f.t00 = base[r0 + x0]; f.t10 = base[r0 + x1]; f.t01 = base[r1 + x0]; f.t11 = base[r1 + x1];
+    f.w00 = (1.f - a) * (1.f - b); f.w10 = a * (1.f - b); f.w01 = (1.f - a) * b; f.w11 = a * b;
+    return f;
+}
+PLR_DI vec3 bloomTapValue(const TapFetch& f) {
+    // the exact kernel's accumulation order: t00*w00 + t10*w10 + t01*w01 + t11*w11, zero-weight terms absent
+    vec3 r = unpackR11G11B10(f.t00) * f.w00;
+    const vec3 c10 = unpackR11G11B10(f.t10) * f.w10, c01 = unpackR11G11B10(f.t01) * f.w01, c11 = unpackR11G11B10(f.t11) * f.w11;
+    r = f.w10 != 0.f ? r + c10 : r;
+    r = f.w01 != 0.f ? r + c01 : r;
+    r = f.w11 != 0.f ? r + c11 : r;
+    return r;
+}
+__global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= coverW || y >= coverH) return;
+    // correctly rounded quotients / reciprocals (Newton step on v_rcp_f32), as the shader's divisions: the taps sit on 1/256 sub-texel weight steps
+    auto quot = [](float a, float b) { const float r = __builtin_amdgcn_rcpf(b), q = a * r; return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q); };
+    const float uvx = quot((float)x + 0.5f, (float)target.w), uvy = quot((float)y + 0.5f, (float)target.h);
+    const float tsx = quot(1.f, (float)source.w), tsy = quot(1.f, (float)source.h);
+    // bloomDownsample.comp:12-49: tap offsets in source texels and their weights, in the shader's order
+    const float ox[13] = {0.f, 0.5f, 0.5f, -0.5f, -0.5f, 1.5f, -1.5f, 0.f, 0.f, 1.5f, 1.5f, -1.5f, -1.5f};
+    const float oy[13] = {0.f, 0.5f, -0.5f, 0.5f, -0.5f, 0.f, 0.f, 1.5f, -1.5f, 1.5f, -1.5f, 1.5f, -1.5f};
+    const float wt[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.125f, 0.0625f, 0.0625f, 0.0625f, 0.0625f, 0.03125f, 0.03125f, 0.03125f, 0.03125f};
+    TapFetch f[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) f[i] = bloomTapFetch(source, uvx + tsx * ox[i], uvy + tsy * oy[i]);
+    vec3 color(0.f);
+#pragma unroll
+    for (int i = 0; i < 13; i++) color = color + bloomTapValue(f[i]) * wt[i];
+    ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
+}
+static int launchDownAnySize(const PassCtx& c, const ImgView& source, const ImgView& target) {
+    const PassCtx::RowSpan rs = c.rowSpan(target.h);
+    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
+    if (w <= 0 || h <= y0) return 0;
+    if (source.w < 1 || source.h < 1 || source.w >= (1 << 12) || source.h >= (1 << 12)) return kUseGeneralKernel; // 24-bit texel index arithmetic
+    bloomDownsampleAnySizeKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
 static int launchDown(const PassCtx& c) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomDownsample target")) return rc;
     if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
     const ImgView& target = c.storage[0];
     const ImgView& source = c.sampled[1];
-    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) return kUseGeneralKernel; // odd sizes: taps are not on texel centres
+    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) return launchDownAnySize(c, source, target); // odd sizes: taps are not on texel centres
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
     const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
     if (w <= 0 || h <= y0) return 0;
