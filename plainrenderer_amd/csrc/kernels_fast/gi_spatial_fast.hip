@@ -329,10 +329,13 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
     const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
     if (w <= 0 || h <= y0) return 0;
     // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
-    constexpr int TXv = 64, TYv = 256 / TXv;
+#ifndef PLR_SPATIAL_TX
+#define PLR_SPATIAL_TX 64
+#endif
+    constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     // chunks of ~17 tile rows (68 pixel rows) measured best at 4K (2 per XCD: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
-    const int chunksPerXcd = std::max(1, (tilesY + 68) / 136);
+    const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544); // chunks of ~68 pixel rows
     const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
     const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
