@@ -98,9 +98,17 @@ typedef struct plr_compute_pass_execution {
     uint32_t dispatch_base[3];
     /* extension (band rendering): rows [valid_rows[0], valid_rows[1]) of the pass's INPUT images hold valid data - the band's own rows plus the
      * halo rows received from the neighbouring GPUs; {0, 0} = every row (the reference's recorder code). Honoured by filterIndirectDiffuseSpatial,
-     * whose world-space disc can reach arbitrarily far on near geometry: a sample that lands outside gets the shader's own off-screen treatment
-     * (weight 0, disc shrinks: filterIndirectDiffuseSpatial.comp:100-105) instead of reading rows no neighbour sent. */
+     * whose world-space disc can reach arbitrarily far on near geometry: a sample that lands on a row outside gets the shader's own off-screen
+     * treatment (weight 0, disc shrinks: filterIndirectDiffuseSpatial.comp:100-105) instead of reading rows no neighbour sent. */
     uint32_t valid_rows[2];
+    /* extension (no reference counterpart): non-zero = this execution belongs to the frame's ASYNCHRONOUS TAIL. The backend launches it on a second
+     * HIP stream, ordered behind everything recorded before it; executions recorded after it - the next frame's included - run beside it unless
+     * they touch an image / buffer it touches (the same read / write tracking the Vulkan backend derives its barriers from, RenderBackend.cpp:632-767),
+     * in which case the launch stream waits for the tail first. Host reads / writes of device memory (plr_download_*, plr_upload_*,
+     * plr_wait_for_gpu_idle, host callbacks) always wait for it. Results are identical with plr_set_async_tail(0), which runs everything in order.
+     * The C++ host mirror flags the bloom chain + tonemap: ten short, dependent launches that leave the chip mostly idle, and that nothing reads
+     * before the next frame's TAA resolve. */
+    uint32_t async_tail;
 } plr_compute_pass_execution;
 
 /* extension: host function executed in recording order while plr_render_frame launches the recorded passes; it may enqueue
@@ -197,11 +205,20 @@ int plr_set_pass_timing(int enabled);
  * All side streams join the main stream before a host callback and at the end of the frame. Results do not depend on the setting.
  * out_overlapped_executions: how many executions of the last plr_render_frame ran on a side stream. */
 int plr_set_stream_overlap(int enabled);
-/* Pass fusion (default on, PLR_MATH_FAST only): where the recorded frame contains certain shaders back to back - histogramReset +
+/* asynchronous frame tail (plr_compute_pass_execution::async_tail; default on, PLR_ASYNC_TAIL=0 turns it off): out_async_executions = executions of
+ * the last plr_render_frame launched on the tail stream. plr_get_last_frame_gpu_time covers the launch stream only. */
+int plr_set_async_tail(int enabled);
+int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions);
+/* Pass fusion (default level 2, PLR_MATH_FAST only): where the recorded frame contains certain shaders back to back - histogramReset +
  * histogramCombineTiles + preExposeLights; depthHiZPyramid + depthDownscale; sdfCameraFrustumCulling + sdfCameraTileCulling; applyBloom +
  * tonemapping; a GI pass followed by the spatial filter that reads its output - the backend covers them with fewer kernel launches. The
  * boundary is unchanged (one plr_set_compute_pass_execution per reference dispatch) and so are the results (byte-identical with fusion
- * off, tests/test_fusion.py). out_fused_executions: how many executions of the last plr_render_frame ran inside a fused launch. */
+ * off, tests/test_fusion.py). out_fused_executions: how many executions of the last plr_render_frame ran inside a fused launch.
+ * enabled = 2 (PLR_PASS_FUSION=2) additionally lets a fused launcher ELIDE an intermediate image: indirectLightUpscale + the deferred shade run as
+ * one kernel that hands the upscaled GI texels over in registers / LDS, and when no other execution recorded for the frame binds the two upscaled
+ * images they are not written at all; plr_download_image of such an image fails (it does not return last frame's bytes). Every other image
+ * and buffer is byte-identical to level 1 (tests/test_fusion.py compares levels 2, 1 and 0). Fusion and plr_set_stream_overlap(1) exclude each
+ * other: the side-stream scheduler launches pass by pass. */
 int plr_set_pass_fusion(int enabled);
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions);
 int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions);

@@ -43,14 +43,16 @@ struct FusionEntry {
     std::string label;
     std::vector<std::string> shaders;
     FusedLaunchFn fn;
+    bool writesSignatures = false;
 };
 static std::vector<FusionEntry>& fusions() {
     static std::vector<FusionEntry> r;
     return r;
 }
-FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn) {
+FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures) {
     FusionEntry e;
     e.label = label;
+    e.writesSignatures = writesSignatures;
     for (const char* sname : shaders) e.shaders.push_back(sname);
     e.fn = fn;
     // longer sequences first: a chain of three is tried before a pair that is its prefix
@@ -59,6 +61,13 @@ FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const 
     while (pos != list.end() && pos->shaders.size() >= e.shaders.size()) ++pos;
     list.insert(pos, std::move(e));
 }
+
+struct ConsumerLink { std::string producer, consumer; };
+static std::vector<ConsumerLink>& consumerLinks() {
+    static std::vector<ConsumerLink> r;
+    return r;
+}
+ConsumerLinkRegistrar::ConsumerLinkRegistrar(const char* producerShader, const char* consumerShader) { consumerLinks().push_back({producerShader, consumerShader}); }
 
 static const ShaderEntry* findShader(const std::string& path) {
     std::string base = path;
@@ -163,6 +172,7 @@ struct ImageRes {
     void* dev = nullptr;
     size_t bytes = 0;
     bool inUse = false; // transient pool bookkeeping
+    bool elided = false; // the last frame's fused launch consumed this image inside its kernel and did not write it (pass fusion level 2)
 };
 
 struct BufferRes {
@@ -192,6 +202,7 @@ struct Execution {
     plr_host_callback callback = nullptr; // host callback execution (pass is unused)
     void* callbackUser = nullptr;
     const char* callbackName = ""; // interned in Backend::callbackNames
+    bool asyncTail = false;        // plr_compute_pass_execution::async_tail
 };
 
 struct FillOrder {
@@ -246,8 +257,20 @@ struct Backend {
     uint32_t lastOverlapped = 0;         // executions of the last frame that were placed on a side stream
     uint32_t* debugSig = nullptr;        // decision-signature buffer (plr_debug_set_decision_signature)
     size_t debugSigWords = 0;
-    bool fusion = true;                  // plr_set_pass_fusion
+    int fusion = 2;                      // plr_set_pass_fusion: 0 off, 1 on, 2 on + a fused launcher may leave an intermediate image unwritten
+    GlobalUbo globalShadow{};            // host copy of the global uniform buffer as of the last flushed fill (PassCtx::globalHost)
+    bool globalShadowValid = false;
     uint32_t lastFused = 0;              // executions of the last frame that ran inside a fused launch
+    uint64_t frameSerial = 0;            // launchAll calls so far (PassCtx::frameSerial)
+    // asynchronous frame tail (plr_compute_pass_execution::async_tail, plr.h): executions launched on tailStream that the main stream has not
+    // waited for yet, as the union of what they touch; tailDone is recorded behind the last of them
+    hipStream_t tailStream = nullptr;
+    hipEvent_t tailDone = nullptr, tailStart = nullptr;
+    std::vector<Access> tailPending;
+    bool asyncTail = true;               // plr_set_async_tail
+    uint32_t lastAsync = 0;              // executions of the last frame that ran on the tail stream
+    void* globalCopies[2] = {nullptr, nullptr}; // rotating device copies of the global uniform buffer: a tail that still reads frame N's must not see frame N + 1's fill
+    uint32_t globalCopyIndex = 0;
     std::set<std::string> fusedNames;    // stable storage for the timing labels of fused launches
 };
 
@@ -265,6 +288,30 @@ int setLastError(int code, const std::string& msg) { return setErr(code, msg); }
     } while (0)
 #define NEED_INIT() \
     if (!g) return setErr(PLR_ERR_NOT_INITIALISED, "plr_setup has not been called")
+// entry points that read or write device memory, or wait for the GPU, from the host: the asynchronous frame tail has to be behind them
+static int joinAsyncTail();
+#define NEED_INIT_JOINED() \
+    NEED_INIT();           \
+    if (int jrc_ = joinAsyncTail()) return jrc_
+
+// the main stream waits for everything launched on the tail stream so far (a no-op when nothing is pending)
+static int joinAsyncTail() {
+    if (!g || g->tailPending.empty()) return PLR_OK;
+    HIP_TRY(hipStreamWaitEvent(g->stream, g->tailDone, 0));
+    g->tailPending.clear();
+    return PLR_OK;
+}
+static bool hazardWithTail(const std::vector<Access>& access) {
+    // (the pseudo key "some image of the global texture array" does not take part: the array is read for images no pass writes - SDF volumes, noise
+    //  textures - and an image a pass does write is ordered through its explicit binding, which is all the reference's barrier tracking sees as well,
+    //  RenderBackend.cpp:632-767. With it every pass that writes any default image would collide with the tail's write of the TAA target.)
+    for (const Access& a : access) {
+        if (a.key == kBindlessKey) continue;
+        for (const Access& t : g->tailPending)
+            if (a.key == t.key && (a.write || t.write)) return true;
+    }
+    return false;
+}
 
 static uint32_t mipCountFromResolution(uint32_t w, uint32_t h, uint32_t d) {
     // Common/Utilities/MathUtils.cpp:17-19
@@ -372,6 +419,8 @@ int twoRangeBlocks(const PassCtx& c, int imageH, int blockRows, int wgRows, TwoR
     return 0;
 }
 
+void countFusedExecutions(uint32_t n) { if (g) g->lastFused += n; }
+
 } // namespace plr
 
 using namespace plr;
@@ -395,8 +444,12 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipEventCreate(&g->frameEnd));
     HIP_TRY(hipEventCreateWithFlags(&g->pinnedFree, hipEventDisableTiming));
     for (auto& st : g->sideStreams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g->tailStream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->tailDone, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g->tailStart, hipEventDisableTiming));
+    if (const char* at = std::getenv("PLR_ASYNC_TAIL")) g->asyncTail = std::atoi(at) != 0;
     if (const char* ov = std::getenv("PLR_STREAM_OVERLAP")) g->overlap = std::atoi(ov) != 0;
-    if (const char* pf = std::getenv("PLR_PASS_FUSION")) g->fusion = std::atoi(pf) != 0;
+    if (const char* pf = std::getenv("PLR_PASS_FUSION")) g->fusion = std::min(std::max(std::atoi(pf), 0), 2);
     if (const char* ns = std::getenv("PLR_SIDE_STREAMS")) g->activeSideStreams = std::min(std::max(std::atoi(ns), 1), (int)Backend::kSideStreams);
     return plr_recreate_swapchain(width, height);
 }
@@ -405,6 +458,11 @@ int plr_shutdown(void) {
     if (!g) return PLR_OK;
     hipSetDevice(g->device);
     hipDeviceSynchronize();
+    g->tailPending.clear();
+    if (g->tailStream) hipStreamDestroy(g->tailStream);
+    if (g->tailDone) hipEventDestroy(g->tailDone);
+    if (g->tailStart) hipEventDestroy(g->tailStart);
+    for (void* c : g->globalCopies) if (c) hipFree(c);
     for (auto& im : g->images) freeImage(im);
     for (auto& im : g->transient) freeImage(im);
     freeImage(g->swapchain);
@@ -425,7 +483,7 @@ int plr_shutdown(void) {
 }
 
 int plr_recreate_swapchain(uint32_t width, uint32_t height) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (width == 0 || height == 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "swapchain size must be non-zero");
     HIP_TRY(hipStreamSynchronize(g->stream));
     freeImage(g->swapchain);
@@ -436,7 +494,7 @@ int plr_recreate_swapchain(uint32_t width, uint32_t height) {
 }
 
 int plr_wait_for_gpu_idle(void) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     HIP_TRY(hipStreamSynchronize(g->stream));
     return PLR_OK;
 }
@@ -444,14 +502,14 @@ int plr_wait_for_gpu_idle(void) {
 // raw copies on the calling thread's backend (band exchange inside one process, histogram reduction on the host): the host side
 // never has to load a HIP runtime of its own
 int plr_copy_device_memory(void* dst, const void* src, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (size == 0) return PLR_OK;
     if (!dst || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, g->stream));
     return PLR_OK;
 }
 int plr_read_device_memory(void* dst_host, const void* src, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (size == 0) return PLR_OK;
     if (!dst_host || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_read_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst_host, src, size, hipMemcpyDeviceToHost, g->stream));
@@ -459,7 +517,7 @@ int plr_read_device_memory(void* dst_host, const void* src, size_t size) {
     return PLR_OK;
 }
 int plr_write_device_memory(void* dst, const void* src_host, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (size == 0) return PLR_OK;
     if (!dst || !src_host) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_write_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src_host, size, hipMemcpyHostToDevice, g->stream));
@@ -470,7 +528,7 @@ int plr_write_device_memory(void* dst, const void* src_host, size_t size) {
 int plr_update_shader_code(void) { NEED_INIT(); return PLR_OK; }
 
 int plr_resize_images(const plr_image_handle* images, uint32_t count, uint32_t width, uint32_t height) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     HIP_TRY(hipStreamSynchronize(g->stream));
     for (uint32_t i = 0; i < count; i++) {
         if (images[i].type != PLR_IMAGE_DEFAULT) return setErr(PLR_ERR_INVALID_ARGUMENT, "only default images can be resized");
@@ -539,6 +597,7 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
     if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
     for (int i = 0; i < 3; i++) { x.ctx.dispatch[i] = e->dispatch_count[i]; x.ctx.base[i] = e->dispatch_base[i]; }
     x.ctx.validRows[0] = e->valid_rows[0]; x.ctx.validRows[1] = e->valid_rows[1];
+    x.asyncTail = e->async_tail != 0;
     {
         // what the execution may touch (stream scheduler): whole allocations, so a kernel that walks the mip chain of a bound image or
         // addresses rows outside its dispatch is covered; uniform buffers are only written between frames
@@ -602,6 +661,11 @@ int plr_set_global_descriptor_set_resources(const plr_pass_resources* r) {
         if (r->uniform_buffers[i].binding == 0) {
             if (r->uniform_buffers[i].buffer >= g->ubufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid global uniform buffer handle");
             if (g->ubufs[r->uniform_buffers[i].buffer].size < sizeof(GlobalUbo)) return setErr(PLR_ERR_INVALID_ARGUMENT, "global uniform buffer smaller than 340 bytes");
+            if (g->globalUbo != r->uniform_buffers[i].buffer) {
+                g->globalShadowValid = false;
+                if (int rc = joinAsyncTail()) return rc;
+                for (void*& c : g->globalCopies) { if (c) hipFree(c); c = nullptr; } // copies of another buffer: the kernels read the real one until its next fill
+            }
             g->globalUbo = r->uniform_buffers[i].buffer;
         }
     }
@@ -660,8 +724,28 @@ static int flushFills() {
         HIP_TRY(hipHostMalloc(&g->pinned, g->pinnedSize, hipHostMallocDefault));
     }
     std::memcpy(g->pinned, g->fillData.data(), g->fillData.size());
+    // a fill of a buffer the asynchronous tail of the previous frame still uses waits for it - except the global uniform buffer, which every pass
+    // reads: the kernels read rotating device copies of it (below), so the tail keeps the values of its own frame
+    const void* globalDev = g->globalUbo != PLR_INVALID_INDEX ? g->ubufs[g->globalUbo].dev : nullptr;
     for (const auto& f : g->fills)
+        if (f.dst != globalDev && hazardWithTail({Access{f.dst, true}})) { if (int rc = joinAsyncTail()) return rc; break; }
+    for (const auto& f : g->fills) {
         HIP_TRY(hipMemcpyAsync(f.dst, (uint8_t*)g->pinned + f.stagingOffset, f.size, hipMemcpyHostToDevice, g->stream));
+        if (g->globalUbo != PLR_INVALID_INDEX && f.dst == g->ubufs[g->globalUbo].dev) { // fills are applied in call order: the shadow ends up as the buffer does
+            std::memcpy(&g->globalShadow, (uint8_t*)g->pinned + f.stagingOffset, std::min(f.size, sizeof(GlobalUbo)));
+            if (f.size >= sizeof(GlobalUbo)) g->globalShadowValid = true;
+        }
+    }
+    bool globalFilled = false;
+    for (const auto& f : g->fills) globalFilled = globalFilled || (globalDev && f.dst == globalDev);
+    if (globalFilled && g->asyncTail) {
+        // next rotating copy of the global uniform buffer = the buffer as it is now; a pending tail may still read that copy (two frames back): join first
+        const uint32_t next = g->globalCopyIndex ^ 1u;
+        if (!g->globalCopies[next]) HIP_TRY(hipMalloc(&g->globalCopies[next], sizeof(GlobalUbo)));
+        if (hazardWithTail({Access{g->globalCopies[next], true}})) if (int rc = joinAsyncTail()) return rc;
+        HIP_TRY(hipMemcpyAsync(g->globalCopies[next], globalDev, sizeof(GlobalUbo), hipMemcpyDeviceToDevice, g->stream));
+        g->globalCopyIndex = next;
+    }
     HIP_TRY(hipEventRecord(g->pinnedFree, g->stream));
     g->pinnedBusy = true;
     g->fills.clear();
@@ -819,6 +903,10 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     PassRes& p = *g->passes[x.pass];
     x.ctx.stream = stream;
     x.ctx.global = globalPtr;
+    x.ctx.globalHost = globalPtr && g->globalShadowValid ? &g->globalShadow : nullptr;
+    x.ctx.elidableStorage = 0;
+    x.ctx.elidedStorage = 0;
+    x.ctx.frameSerial = g->frameSerial;
     x.ctx.bindless = g->bindlessDev;
     x.ctx.bindlessCount = (uint32_t)g->images.size();
     x.ctx.spec = &p.spec;
@@ -847,16 +935,35 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
 // bindings, it is launched and the number of executions it covered is returned; 0: nothing fused (launch execution i on its own)
 static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const GlobalUbo* globalPtr, bool timed, size_t* covered) {
     *covered = 0;
-    if (!g->fusion || g->mathMode != PLR_MATH_FAST || g->debugSig) return PLR_OK;
+    if (!g->fusion || g->mathMode != PLR_MATH_FAST) return PLR_OK;
     for (const FusionEntry& f : fusions()) {
         const size_t n = f.shaders.size();
         if (i + n > last) continue;
+        if (g->debugSig && !f.writesSignatures) continue;
         bool match = true;
         for (size_t k = 0; k < n && match; k++) match = g->passes[g->executions[i + k].pass]->shader == f.shaders[k];
         if (!match) continue;
         const PassCtx* ctxs[8];
         if (n > 8) continue;
         for (size_t k = 0; k < n; k++) { prepareCtx(g->executions[i + k], stream, globalPtr); ctxs[k] = &g->executions[i + k].ctx; }
+        if (g->fusion >= 2) {
+            // which storage images of the sequence does nothing else in this frame touch? (keys are allocation bases: an image with all its mips)
+            for (size_t k = 0; k < n; k++) {
+                Execution& x = g->executions[i + k];
+                for (int b = 0; b < kMaxBindings; b++) {
+                    if (!x.ctx.hasStorage(b)) continue;
+                    const void* key = nullptr;
+                    for (const Access& a : x.access) if (a.write && a.key == x.ctx.storage[b].ptr) key = a.key; // mip 0 of an image the pass writes
+                    if (!key) continue;
+                    bool outside = false;
+                    for (size_t j = 0; j < g->executions.size() && !outside; j++) {
+                        if (j >= i && j < i + n) continue;
+                        for (const Access& a : g->executions[j].access) if (a.key == key) { outside = true; break; }
+                    }
+                    if (!outside) x.ctx.elidableStorage |= 1u << b;
+                }
+            }
+        }
         const char* label = nullptr;
         g->curStream = stream;
         if (timed) {
@@ -873,6 +980,12 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         }
         if (rc) { g_err = "fused launch '" + f.label + "': " + g_err; return rc; }
         if (timed) if (int trc = endSegment()) return trc;
+        for (size_t k = 0; k < n; k++) { // images the launcher left unwritten: a host download must not return last frame's bytes silently
+            const PassCtx& cx = g->executions[i + k].ctx;
+            for (int b = 0; b < kMaxBindings && cx.elidedStorage; b++)
+                if ((cx.elidedStorage >> b) & 1u)
+                    for (ImageRes& im : g->images) if (im.dev && im.dev == cx.storage[b].ptr) im.elided = true;
+        }
         *covered = n;
         g->lastFused += (uint32_t)n;
         return PLR_OK;
@@ -880,14 +993,68 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
     return PLR_OK;
 }
 
+// how many executions starting at i a fused launch could cover (shader names only; the launcher may still decline)
+static size_t fusionWindow(size_t i, size_t last) {
+    size_t best = 1;
+    if (!g->fusion || g->mathMode != PLR_MATH_FAST) return best;
+    for (const FusionEntry& f : fusions()) {
+        const size_t n = f.shaders.size();
+        if (n <= best || i + n > last) continue;
+        bool match = true;
+        for (size_t k = 0; k < n && match; k++) match = g->passes[g->executions[i + k].pass]->shader == f.shaders[k];
+        if (match) best = n;
+    }
+    return best;
+}
+
+
+// PassCtx::consumer of every execution (backend.h PLR_REGISTER_CONSUMER_LINK)
+static void linkConsumers(const GlobalUbo* globalPtr) {
+    const size_t n = g->executions.size();
+    for (size_t i = 0; i < n; i++) g->executions[i].ctx.consumer = nullptr;
+    if (!g->fusion || g->mathMode != PLR_MATH_FAST || g->debugSig || g->overlap || consumerLinks().empty()) return;
+    for (size_t i = 0; i < n; i++) {
+        Execution& x = g->executions[i];
+        if (x.callback) continue;
+        const std::string& shader = g->passes[x.pass]->shader;
+        for (const ConsumerLink& link : consumerLinks()) {
+            if (link.producer != shader || x.ctx.consumer) continue;
+            // keys of the images this execution writes
+            std::vector<const void*> written;
+            for (const Access& a : x.access) if (a.write && a.key != kBindlessKey && a.key != (const void*)g->passes[x.pass].get()) written.push_back(a.key);
+            bool stop = false;
+            for (size_t j = i + 1; j < n && !stop && !x.ctx.consumer; j++) {
+                Execution& y = g->executions[j];
+                if (y.callback || y.pass == x.pass) continue; // exchange callbacks and the pass's other row ranges do not end the search
+                bool reads = false;
+                for (const Access& a : y.access)
+                    for (const void* key : written)
+                        if (a.key == key) { if (a.write) stop = true; else reads = true; }
+                if (reads && !stop && g->passes[y.pass]->shader == link.consumer) {
+                    prepareCtx(y, g->stream, globalPtr);
+                    x.ctx.consumer = &y.ctx;
+                } else if (reads) stop = true; // somebody else reads it first: the order of packing and reading is no longer ours to reason about
+            }
+        }
+    }
+}
+
 static int launchAll(bool timed) {
     const size_t n = g->executions.size();
+    g->frameSerial++;
     g->timingNow = timed;
     if (timed) { g->segments.clear(); g->eventsUsed = 0; }
     g->orderEventsUsed = 0;
     g->lastOverlapped = 0;
     g->lastFused = 0;
+    for (ImageRes& im : g->images) im.elided = false;
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
+    const bool tailAllowed = g->asyncTail && !g->overlap;
+    if (globalPtr && tailAllowed && g->globalCopies[g->globalCopyIndex]) globalPtr = (const GlobalUbo*)g->globalCopies[g->globalCopyIndex];
+    g->lastAsync = 0;
+    bool tailOpen = false, tailDirty = false; // tailOpen: the tail stream is ordered behind the main stream's work so far; tailDirty: tailDone is stale
+    auto closeTail = [&]() -> int { if (tailDirty) { HIP_TRY(hipEventRecord(g->tailDone, g->tailStream)); tailDirty = false; } return PLR_OK; };
+    linkConsumers(globalPtr);
     std::vector<PlanNode> plan(n);
     std::vector<hipEvent_t> done(n, nullptr);
     size_t i = 0;
@@ -895,6 +1062,10 @@ static int launchAll(bool timed) {
         Execution& x = g->executions[i];
         if (x.callback) {
             // everything before a callback has joined the main stream (end of the previous run)
+            // a host callback may touch anything (halo exchange on raw pointers): the asynchronous tail joins first
+            if (int rc = closeTail()) return rc;
+            if (int rc = joinAsyncTail()) return rc;
+            tailOpen = false;
             g->curStream = g->stream;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
             const int crc = x.callback(x.callbackUser, (void*)g->stream);
@@ -907,11 +1078,39 @@ static int launchAll(bool timed) {
         while (last < n && !g->executions[last].callback) last++;
         if (!g->overlap) {
             while (i < last) {
+                // executions flagged async_tail (plr.h) go to the tail stream: behind everything launched before them, beside everything launched
+                // after them that shares no resource with them - the next frame's passes included
+                const bool async = tailAllowed && g->executions[i].asyncTail;
+                size_t runEnd = i + 1; // [i, runEnd): executions of the same kind (a fused launch never mixes the two)
+                while (runEnd < last && (tailAllowed && g->executions[runEnd].asyncTail) == async) runEnd++;
+                hipStream_t stream = g->stream;
+                if (async) {
+                    if (!tailOpen) {
+                        HIP_TRY(hipEventRecord(g->tailStart, g->stream));
+                        HIP_TRY(hipStreamWaitEvent(g->tailStream, g->tailStart, 0));
+                        tailOpen = true;
+                    }
+                    stream = g->tailStream;
+                }
+                if (!async && !g->tailPending.empty()) {
+                    // anything this launch (or the fused launch it may become) shares with the pending tail: the main stream waits for the tail first
+                    const size_t window = fusionWindow(i, runEnd);
+                    bool hazard = false;
+                    for (size_t k = i; k < i + window && !hazard; k++) hazard = hazardWithTail(g->executions[k].access);
+                    if (hazard) { if (int rc = closeTail()) return rc; if (int rc = joinAsyncTail()) return rc; }
+                }
                 size_t covered = 0;
-                if (int rc = tryFusedLaunch(i, last, g->stream, globalPtr, timed, &covered)) return rc;
-                if (covered) { i += covered; continue; }
-                if (int rc = launchExecution(g->executions[i], g->stream, globalPtr, timed)) return rc;
-                i++;
+                if (int rc = tryFusedLaunch(i, runEnd, stream, globalPtr, timed, &covered)) return rc;
+                const size_t count = covered ? covered : 1;
+                if (async) {
+                    for (size_t k = i; k < i + count; k++)
+                        for (const Access& a : g->executions[k].access) g->tailPending.push_back(a);
+                    g->tailPending.push_back(Access{(const void*)globalPtr, false});
+                    tailDirty = true;
+                    g->lastAsync += (uint32_t)count;
+                } else tailOpen = false; // the main stream moves on: a later tail execution must be ordered behind this one
+                if (!covered) if (int rc = launchExecution(g->executions[i], stream, globalPtr, timed)) return rc;
+                i += count;
             }
             continue;
         }
@@ -964,6 +1163,7 @@ static int launchAll(bool timed) {
         }
         i = last;
     }
+    if (int rc = closeTail()) return rc;
     g->curStream = g->stream;
     g->timingNow = false;
     return PLR_OK;
@@ -992,18 +1192,30 @@ int plr_render_frame(int /*present_to_screen*/) {
 
 int plr_set_pass_fusion(int enabled) {
     NEED_INIT();
-    g->fusion = enabled != 0;
+    g->fusion = std::min(std::max(enabled, 0), 2);
     return PLR_OK;
 }
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions) {
     NEED_INIT();
-    if (out_enabled) *out_enabled = g->fusion ? 1 : 0;
+    if (out_enabled) *out_enabled = g->fusion;
     if (out_fused_executions) *out_fused_executions = g->lastFused;
     return PLR_OK;
 }
 
-int plr_set_stream_overlap(int enabled) {
+int plr_set_async_tail(int enabled) {
+    NEED_INIT_JOINED();
+    g->asyncTail = enabled != 0;
+    return PLR_OK;
+}
+int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions) {
     NEED_INIT();
+    if (out_enabled) *out_enabled = g->asyncTail ? 1 : 0;
+    if (out_async_executions) *out_async_executions = g->lastAsync;
+    return PLR_OK;
+}
+
+int plr_set_stream_overlap(int enabled) {
+    NEED_INIT_JOINED();
     g->overlap = enabled != 0;
     return PLR_OK;
 }
@@ -1015,7 +1227,7 @@ int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions
 }
 
 int plr_replay_frame(uint32_t count, float* out_total_gpu_ms) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     int rc = flushFills();
     if (rc) return rc;
     rc = flushBindless();
@@ -1130,7 +1342,7 @@ int plr_get_memory_stats(uint64_t* out_allocated_size, uint64_t* out_used_size) 
 }
 
 int plr_debug_set_decision_signature(size_t words) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     HIP_TRY(hipStreamSynchronize(g->stream));
     if (g->debugSig) { hipFree(g->debugSig); g->debugSig = nullptr; g->debugSigWords = 0; }
     if (words == 0) return PLR_OK;
@@ -1140,7 +1352,7 @@ int plr_debug_set_decision_signature(size_t words) {
     return PLR_OK;
 }
 int plr_debug_read_decision_signature(uint32_t* out_words, size_t words) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (!g->debugSig || !out_words || words > g->debugSigWords) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_read_decision_signature: no buffer of that size is set");
     HIP_TRY(hipStreamSynchronize(g->stream));
     HIP_TRY(hipMemcpy(out_words, g->debugSig, words * 4, hipMemcpyDeviceToHost));
@@ -1148,7 +1360,7 @@ int plr_debug_read_decision_signature(uint32_t* out_words, size_t words) {
 }
 
 int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, float* out_rgb, int64_t n) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     ImageRes* im = resolveImage(sky_lut);
     if (!im || !directions || !out_rgb || n <= 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sky_lut_eval: invalid argument");
     HIP_TRY(hipStreamSynchronize(g->stream));
@@ -1156,7 +1368,7 @@ int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, fl
 }
 
 int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filter, int address, const float* coords, float* out, int64_t n) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     ImageRes* im = resolveImage(image);
     if (!im || mip_level >= im->mips.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sampler_eval: invalid image handle or mip level");
     if (!coords || !out || n <= 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sampler_eval: null argument");
@@ -1165,7 +1377,7 @@ int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filte
 }
 
 int plr_set_math_mode(int mode) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (mode != PLR_MATH_EXACT && mode != PLR_MATH_FAST) return setErr(PLR_ERR_INVALID_ARGUMENT, "math mode must be PLR_MATH_EXACT or PLR_MATH_FAST");
     g->mathMode = mode;
     return PLR_OK;
@@ -1180,6 +1392,7 @@ int plr_get_renderpass_timings(plr_renderpass_time* out_times, uint32_t* inout_c
     const uint32_t n = (uint32_t)g->timedExecutions;
     if (!out_times) { *inout_count = n; return PLR_OK; }
     if (n) HIP_TRY(hipEventSynchronize(g->frameEnd));
+    if (n && g->tailStream) HIP_TRY(hipStreamSynchronize(g->tailStream)); // segments of the asynchronous tail end on its own stream
     const uint32_t m = std::min(n, *inout_count);
     for (uint32_t i = 0; i < m; i++) {
         float ms = 0.f;
@@ -1194,7 +1407,7 @@ int plr_get_renderpass_timings(plr_renderpass_time* out_times, uint32_t* inout_c
 int plr_get_last_frame_cpu_time(float* out_ms) { NEED_INIT(); *out_ms = g->lastCpuMs; return PLR_OK; }
 
 int plr_get_last_frame_gpu_time(float* out_ms) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (!g->frameRecorded) return setErr(PLR_ERR_INVALID_ARGUMENT, "no frame rendered yet");
     HIP_TRY(hipEventSynchronize(g->frameEnd));
     HIP_TRY(hipEventElapsedTime(out_ms, g->frameStart, g->frameEnd));
@@ -1218,7 +1431,7 @@ static int imageMip(plr_image_handle image, uint32_t mip, ImageRes** im, MipInfo
 }
 
 int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     ImageRes* im; MipInfo* mi;
     int rc = imageMip(image, mip_level, &im, &mi);
     if (rc) return rc;
@@ -1229,7 +1442,7 @@ int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* dat
 }
 
 int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t row_begin, uint32_t row_count, const void* data, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     ImageRes* im; MipInfo* mi;
     int rc = imageMip(image, mip_level, &im, &mi);
     if (rc) return rc;
@@ -1244,11 +1457,14 @@ int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t r
 }
 
 int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     ImageRes* im; MipInfo* mi;
     int rc = imageMip(image, mip_level, &im, &mi);
     if (rc) return rc;
     if (size != mi->bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "download size " + std::to_string(size) + " != mip size " + std::to_string(mi->bytes));
+    if (im->elided)
+        return setErr(PLR_ERR_UNSUPPORTED, "this image was not written in the last frame: the fused launch that consumes it kept it in registers (pass fusion level 2); "
+                                           "plr_set_pass_fusion(1) keeps intermediates");
     HIP_TRY(hipMemcpyAsync(out_data, (uint8_t*)im->dev + mi->offset, size, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return PLR_OK;
@@ -1262,11 +1478,11 @@ static int downloadBuffer(std::vector<BufferRes>& list, uint32_t h, void* out, s
     return PLR_OK;
 }
 int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     return downloadBuffer(g->sbufs, buffer, out_data, offset, size);
 }
 int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     return downloadBuffer(g->ubufs, buffer, out_data, offset, size);
 }
 

@@ -28,6 +28,9 @@ struct BufferBinding {
 struct PassCtx {
     hipStream_t stream = nullptr;
     const GlobalUbo* global = nullptr;    // set 0 binding 0 (device memory)
+    // host copy of what the device buffer holds when this frame's passes run (the last setUniformBufferData of the global buffer, applied before the
+    // first pass): launchers that must decide on the host from a UBO field (the screen resolution) read it here; null if the host never filled it
+    const GlobalUbo* globalHost = nullptr;
     const ImgView* bindless = nullptr;    // set 2 (device array of mip-0 views, indexed by global texture index)
     uint32_t bindlessCount = 0;
     ImgView sampled[kMaxBindings];
@@ -41,6 +44,10 @@ struct PassCtx {
     // a second range of workgroup rows covered by the same launch (pass fusion of two executions of one pass that differ in their rows only:
     // the edge rows a band renderer produces first, above and below its interior); 0 rows = none. Set by launchOverTwoRowRanges
     uint32_t extraBaseY = 0, extraCountY = 0;
+    // pass fusion with elision (plr_set_pass_fusion(2)): bit b set = the image at storage binding b is touched by no execution of this frame outside the
+    // fused sequence this context is part of, so a fused launcher that consumes it inside its own kernel may leave it unwritten
+    uint32_t elidableStorage = 0;
+    mutable uint32_t elidedStorage = 0;   // set by the fused launcher: the storage bindings it really left unwritten (the backend flags those images)
     uint32_t validRows[2] = {0, 0};       // rows of the input images that hold valid data (band rendering, plr.h); {0, 0} = all
     // [lo, hi) for an input image of imageH rows
     void validRowRange(int imageH, int* lo, int* hi) const {
@@ -48,6 +55,11 @@ struct PassCtx {
         *lo = all ? 0 : (int)(validRows[0] < (uint32_t)imageH ? validRows[0] : (uint32_t)imageH);
         *hi = all ? imageH : (int)(validRows[1] < (uint32_t)imageH ? validRows[1] : (uint32_t)imageH);
     }
+    // producer -> consumer link (PLR_REGISTER_CONSUMER_LINK below): the context of the LATER execution of this frame that is the first to read an
+    // image this execution writes, possibly with host callbacks (halo exchanges) and further executions of this same pass in between; null if
+    // there is none, if another pass writes the image first, in PLR_MATH_EXACT, with pass fusion off or a signature buffer set
+    const PassCtx* consumer = nullptr;
+    uint64_t frameSerial = 0;             // counts plr_render_frame calls: lets a pass's host-side bookkeeping tell this frame's entries from stale ones
     const std::vector<SpecConstant>* spec = nullptr;
     std::string* err = nullptr;
     void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)
@@ -122,9 +134,23 @@ struct ShaderRegistrar {
 // whether a sequence was fused (tests/test_fusion.py compares bytes).
 typedef int (*FusedLaunchFn)(const PassCtx* const* ctxs, size_t count);
 struct FusionRegistrar {
-    FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn);
+    // writesSignatures: the fused kernels write the decision signatures of all their passes (plr_debug_set_decision_signature) - such a sequence
+    // stays fused while a signature buffer is set; all others run pass by pass then
+    FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures = false);
 };
 #define PLR_REGISTER_FUSION(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn)
+#define PLR_REGISTER_FUSION_WITH_SIGNATURES(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn, true)
+
+// Fusion ACROSS the recorded order: when an execution of `producer` is launched, PassCtx::consumer points at the first later execution of
+// `consumer` that samples one of its storage images. The producer's fast launcher may then do part of the consumer's work on the rows it
+// produces (sdfDiffuseTrace / filterIndirectDiffuseTemporal write the spatial filter's packed texels, fused_gi.h) - this also works in band
+// rendering, where exchange callbacks separate the two and the producer runs as several executions (edge rows, interior rows).
+struct ConsumerLinkRegistrar {
+    ConsumerLinkRegistrar(const char* producerShader, const char* consumerShader);
+};
+#define PLR_REGISTER_CONSUMER_LINK(id, producer, consumer) static ::plr::ConsumerLinkRegistrar plr_consumer_link_##id(producer, consumer)
+// a launcher that did (part of) another pass's work / found its own pre-pass already done reports it: plr_get_pass_fusion's counter
+void countFusedExecutions(uint32_t n);
 
 inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 

@@ -25,6 +25,8 @@ struct QuadParams {
     uint16_t* halfDepth; // depthDownscale.comp's target (fused) or null
     int halfW;
     int levels;          // 4: both sides are multiples of 16; 3: multiples of 8 (1920 x 1080), level 3 is then the tail's first level (its 3-wide odd-size footprints need LDS)
+    int tileY0;          // first 64-row tile row of the launch (band rendering / per-tile pyramids: a launch covers the tile rows it is asked for)
+    int halfRow0, halfRow1; // rows of halfDepth this launch may write (the depthDownscale execution's rows)
 };
 
 // min / max contribution of a (min, max) texel to the level above (depthHiZPyramid.comp:95-110): a texel whose max is 0 is all sky and must not
@@ -68,8 +70,8 @@ PLR_DI void hizQuadBlock(const QuadParams& p, int bx, int by) {
         if (DOWNSCALE) {
             // depthDownscale.comp:12-20: half-res texel (x, y) = depth texel (2x, 2y), stored as a half float
             uint16_t* h0 = p.halfDepth + (size_t)(py / 2) * (size_t)p.halfW + (size_t)(px / 2);
-            *(uint32_t*)h0 = floatToHalfBits(r[0].x) | (floatToHalfBits(r[0].z) << 16);
-            *(uint32_t*)(h0 + p.halfW) = floatToHalfBits(r[2].x) | (floatToHalfBits(r[2].z) << 16);
+            if (py / 2 >= p.halfRow0 && py / 2 < p.halfRow1) *(uint32_t*)h0 = floatToHalfBits(r[0].x) | (floatToHalfBits(r[0].z) << 16);
+            if (py / 2 + 1 >= p.halfRow0 && py / 2 + 1 < p.halfRow1) *(uint32_t*)(h0 + p.halfW) = floatToHalfBits(r[2].x) | (floatToHalfBits(r[2].z) << 16);
         }
     }
     // level 2: the four lanes of a quad hold the four level-1 texels of one level-2 texel. An inactive lane contributes the neutral pair
@@ -139,6 +141,34 @@ PLR_DI void hizTailBlock(const HizParams& p, int first, int texelsA, float2* lds
 }
 
 
+// ---- per-tile pyramids (band rendering; frames whose full chain exceeds the shader's 11 levels): six levels, no chain tail. Levels 4 and 5 of the
+// tile rows [tileY0, tileY1) from level 3 in global memory (written by the quad blocks of an earlier launch), by as many blocks as it takes.
+// A level-4 texel is the footprint of level 3, a level-5 texel the footprint of level-4 footprints - recomputed, not re-read: the launch has no
+// grid-wide barrier, min / max are exact, so the bits are those of the level-by-level evaluation (kernels/hiz.hip). Footprints follow the
+// reference's rule (depthHiZPyramid.comp:52-124): 3 rows / columns wherever the SOURCE level has an odd size.
+struct TileTailParams {
+    const float2* level3;
+    float2* level4;
+    float2* level5;
+    int w3, h3, w4, h4, w5, h5;
+    int row4Begin, row4End, row5Begin, row5End; // rows of levels 4 / 5 owned by the launch's tile rows
+};
+PLR_DI void hizTileTailThread(const TileTailParams& p, int i) {
+    const int n4 = p.w4 * (p.row4End - p.row4Begin), n5 = p.w5 * (p.row5End - p.row5Begin);
+    auto level4At = [&](int x, int y) {
+        const MinMax m = footprint<false>(2 * x, 2 * y, p.w3, p.h3, p.h3 & 1, p.w3 & 1, [&](int sx, int sy) { return p.level3[(size_t)sy * p.w3 + sx]; });
+        return make_float2(m.mn, m.mx);
+    };
+    if (i < n4) {
+        const int x = i % p.w4, y = p.row4Begin + i / p.w4;
+        p.level4[(size_t)y * p.w4 + x] = level4At(x, y);
+    } else if (i < n4 + n5) {
+        const int j = i - n4, x = j % p.w5, y = p.row5Begin + j / p.w5;
+        const MinMax m = footprint<false>(2 * x, 2 * y, p.w4, p.h4, p.h4 & 1, p.w4 & 1, [&](int sx, int sy) { return level4At(sx, sy); });
+        p.level5[(size_t)y * p.w5 + x] = make_float2(m.mn, m.mx);
+    }
+}
+
 // everything a launch needs to host the pyramid's blocks (filled by fasthiz::prepare, kernels_fast/hiz_fast.hip)
 struct Plan {
     QuadParams quad;
@@ -147,6 +177,8 @@ struct Plan {
     int tailFirst = 4, tailTexelsA = 0;
     size_t tailLdsBytes = 0;
     bool downscale = false;
+    bool perTile = false;     // six-level per-tile pyramid: tileTail replaces the chain tail, the quad blocks start at quad.tileY0
+    TileTailParams tileTail;
 };
 // c: the depthHiZPyramid execution; down: the depthDownscale execution fused into it, or null. 0 / kUseGeneralKernel
 int prepare(const PassCtx& c, const PassCtx* down, Plan* out);

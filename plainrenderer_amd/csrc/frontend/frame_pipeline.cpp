@@ -267,7 +267,7 @@ uint32_t Bloom::requiredSourceHalo(uint32_t height, float radius) {
     return std::max(b0 - c.source.begin, c.source.end - b1);
 }
 
-void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows) const { // Bloom.cpp:56-143
+void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows, bool asyncTail) const { // Bloom.cpp:56-143
     const ImageDescription td = be.getImageDescription(targetImage);
     const int width = (int)td.width, height = (int)td.height;
     // chainRows = rows of the target that hold valid colour (band + exchanged halo); the chain itself only covers the dependency cone of applyRows
@@ -290,6 +290,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
         dispatch8(exe, tw, th, banded ? levelRows(cone.down[targetMip], targetMip) : RowRange{});
+        exe.asyncTail = asyncTail;
         be.setComputePassExecution(exe);
     }
     const ImageHandle upscaleTexture = be.createTemporaryImage(desc);
@@ -303,6 +304,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         resolutionFromMip(width, height, targetMip, &tw, &th);
         dispatch8(exe, tw, th, banded ? levelRows(cone.up[targetMip], targetMip) : RowRange{});
         exe.pushConstants = dataToCharArray(&settings.radius, sizeof(settings.radius));
+        exe.asyncTail = asyncTail;
         be.setComputePassExecution(exe);
     }
     ComputePassExecution exe;
@@ -311,6 +313,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
     exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, 0, 1)};
     dispatch8(exe, width, height, applyRows);
     exe.pushConstants = dataToCharArray(&settings.strength, sizeof(settings.strength));
+    exe.asyncTail = asyncTail;
     be.setComputePassExecution(exe);
 }
 
@@ -955,6 +958,7 @@ void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:
     exe.genericInfo.resources.storageImages = {ImageResource(m_be.getSwapchainInputImage(), 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(src, 0, 1)};
     dispatch8(exe, settings.width, settings.height, bandRows(0));
+    exe.asyncTail = asyncPostTail();
     m_be.setComputePassExecution(exe);
 }
 
@@ -1235,7 +1239,10 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             if (!m_exchangeItems[ExchangePost].empty()) exchangePoint(ExchangePost, "Exchange: resolved colour halo rows");
         }
     }
-    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0));
+    // the bloom chain and the tonemap are the frame's asynchronous tail (plr.h async_tail): nothing reads their outputs before the next frame's TAA
+    // resolve, and their ten short launches leave the chip mostly idle - they run beside the next frame's exposure / GI / shade passes. Not in band
+    // rendering: the exchange callbacks of the next frame join the tail before it could overlap anything.
+    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0), asyncPostTail());
     if (settings.runTonemap) computeTonemapping(currentSrc);
 }
 

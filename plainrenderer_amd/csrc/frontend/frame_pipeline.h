@@ -150,7 +150,7 @@ public:
     void init(RenderBackend& be);
     // applyRows: rows bloom is applied to (band rendering; default all). The chain is recorded over the dependency cone of those rows;
     // chainRows: rows of the target image that hold valid colour (the band and the exchanged halo) - must cover the cone's source rows
-    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}) const;
+    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}, bool asyncTail = false) const;
     struct Cone { RowRange up[6], down[6], source; }; // rows of every level (in the level's own rows) / of the source image the result depends on
     static Cone dependencyCone(RowRange applyRows, uint32_t height, float radius);
     static uint32_t requiredSourceHalo(uint32_t height, float radius); // full-resolution rows of scene colour a band needs beyond its own
@@ -290,6 +290,7 @@ private:
     void downscaleDepth(const FrameRenderTargets& currentTarget);
     void computeDeferredShading(ImageHandle colorTarget, const FrameRenderTargets& current);
     void computeTonemapping(ImageHandle src);
+    bool asyncPostTail() const { return !settings.band.enabled(); } // bloom chain + tonemap as the frame's asynchronous tail (plr.h async_tail)
     void computeBRDFLut();
     void computeSunLightMatrices();
     void updateTransmissionLut();

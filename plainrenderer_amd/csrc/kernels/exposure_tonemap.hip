@@ -290,10 +290,12 @@ __global__ __launch_bounds__(64) void preExposeLightsKernel(LightBuffer* __restr
 // Every block sums its slab of tiles like histogramCombineKernel and adds it to a zeroed accumulator with device-scope atomics; the block that
 // takes the last ticket stores the totals into the histogram buffer (= reset + combine), zeroes the accumulator for the next frame and runs
 // the exposure wave on the totals. All cross-block traffic goes through device-scope atomics (performed at the memory side, coherent across
-// the eight XCDs' L2s); a thread's atomics have completed when its vmcnt reaches 0, the block's when all its threads passed the barrier.
+// the eight XCDs' L2s), ordered by a release / acquire ticket (below), not by instruction timing.
 constexpr int kFusedExposureMaxBins = 256;
 struct ExposureScratch { uint32_t ticket; uint32_t pad[3]; uint32_t acc[kFusedExposureMaxBins]; };
-// block `block` of `blocks`; term / counted / totals / isLast: the block's LDS
+// block `block` of `blocks`; term / counted / totals / isLast: the block's LDS. EXPOSE = false: reset + combine only (band rendering: the exposure
+// follows the all-reduce over the bands, perTile then points at the band's first tile)
+template <bool EXPOSE = true>
 PLR_DI void histogramCombineExposeBlock(uint32_t block, uint32_t blocks, const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
                                         ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, const ImgView& transmissionLut, const GlobalUbo* __restrict__ g,
                                         float minLuminanceLog, float maxLuminanceLog, float* term, uint32_t* counted, uint32_t* totals, uint32_t* isLast) {
@@ -310,9 +312,11 @@ PLR_DI void histogramCombineExposeBlock(uint32_t block, uint32_t blocks, const u
         for (; t < t1; t++) sum += perTile[(size_t)t * nBins + bin];
         if (sum) __hip_atomic_fetch_add(&scratch->acc[bin], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's atomics have been performed
+    // publication protocol: the block's accumulator adds happen-before the barrier, thread 0 then takes its ticket with an agent-scope
+    // RELEASE (orders the whole block's adds before the ticket, by cumulativity over the workgroup barrier) + ACQUIRE (the block that draws
+    // the last ticket observes every other block's adds); the second barrier hands the acquire to the other threads of the last block
     __syncthreads();
-    if (threadIdx.x == 0) *isLast = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == blocks - 1u ? 1u : 0u;
+    if (threadIdx.x == 0) *isLast = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == blocks - 1u ? 1u : 0u;
     __syncthreads();
     if (!*isLast) return;
     for (uint32_t bin = threadIdx.x; bin < nBins; bin += blockDim.x) {
@@ -321,6 +325,7 @@ PLR_DI void histogramCombineExposeBlock(uint32_t block, uint32_t blocks, const u
         histogram[bin] = v;
     }
     if (threadIdx.x == 0) __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!EXPOSE) return;
     __syncthreads();
     if (threadIdx.x < 64) preExposeLightsWave(light, [&](int i) { return totals[i]; }, transmissionLut, g, (int)nBins, minLuminanceLog, maxLuminanceLog, term, counted, (int)threadIdx.x);
 }
@@ -333,6 +338,14 @@ __global__ __launch_bounds__(128) void histogramCombineExposeKernel(const uint32
     __shared__ uint32_t totals[kFusedExposureMaxBins];
     __shared__ uint32_t isLast;
     histogramCombineExposeBlock(blockIdx.x, gridDim.x, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog, maxLuminanceLog, term, counted, totals, &isLast);
+}
+
+// histogramReset + histogramCombineTiles of a band's tiles (the exposure pass follows the all-reduce callback)
+__global__ __launch_bounds__(128) void histogramResetCombineKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
+                                                                   ExposureScratch* __restrict__ scratch) {
+    __shared__ uint32_t totals[kFusedExposureMaxBins];
+    __shared__ uint32_t isLast;
+    histogramCombineExposeBlock<false>(blockIdx.x, gridDim.x, perTile, histogram, nBins, nTiles, scratch, nullptr, ImgView{}, nullptr, 0.f, 0.f, nullptr, nullptr, totals, &isLast);
 }
 
 // launch 2 of the fused frame front (kernels_fast/fused_front.h): block 0 finishes the depth pyramid, the others are the exposure chain's
@@ -407,6 +420,24 @@ int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz:
     return err == hipSuccess ? 0 : setLastError(-2, std::string("exposure chain + pyramid tail launch failed: ") + hipGetErrorString(err));
 }
 PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles + preExposeLights", launchFusedExposureChain, "histogramReset.comp", "histogramCombineTiles.comp", "preExposeLights.comp");
+// band rendering: reset + combine of the band's tiles (any first tile), one launch; the all-reduce callback and the exposure pass follow
+static int launchFusedResetCombine(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx &reset = *ctxs[0], &comb = *ctxs[1];
+    const uint32_t nBins = comb.specUint(0, 64u);
+    if (nBins == 0 || nBins > (uint32_t)kFusedExposureMaxBins || reset.specUint(0, 64u) != nBins) return kUseGeneralKernel;
+    if (!reset.hasSbuf(1) || !comb.hasSbuf(0) || !comb.hasSbuf(1) || reset.sbuf[1].ptr != comb.sbuf[1].ptr || comb.sbuf[1].size < (size_t)nBins * 4u) return kUseGeneralKernel;
+    if (reset.dispatch[0] * 64u < nBins || comb.dispatch[1] * 64u < nBins || comb.dispatch[0] == 0) return kUseGeneralKernel;
+    const uint32_t tile0 = comb.base[0], nTiles = comb.dispatch[0];
+    if (comb.sbuf[0].size < (size_t)(tile0 + nTiles) * nBins * 4u) return kUseGeneralKernel;
+    ExposureScratch* scratch = (ExposureScratch*)comb.scratch(sizeof(ExposureScratch)); // zero-initialised by the backend, kept zero by the kernel
+    if (!scratch) return comb.fail(-2, "histogramCombineTiles: cannot allocate scratch memory");
+    histogramResetCombineKernel<<<divUp(nTiles, kCombineTilesPerBlock), 128, 0, comb.stream>>>((const uint32_t*)comb.sbuf[0].ptr + (size_t)tile0 * nBins, (uint32_t*)comb.sbuf[1].ptr, nBins,
+                                                                                              nTiles, scratch);
+    PLR_CHECK_LAUNCH(comb);
+    return 0;
+}
+PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles", launchFusedResetCombine, "histogramReset.comp", "histogramCombineTiles.comp");
 
 // ------------------------------------------------------------------------------------------------
 // tonemapping.comp:17-27 + tonemapping.inc:17-49 + colorConversion.inc:5-13 + dither.inc:6-12 + noise.inc:14-24.

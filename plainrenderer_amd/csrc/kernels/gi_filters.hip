@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgVi
         const float distanceToTangentPlane = fabsf(dot(N, pixelWorld - pCenter));
         float weight = gclamp(0.25f / gmax(distanceToTangentPlane, 0.0001f), 0.f, 1.f);
         weight *= weight;
-        // band rendering (PassCtx::validRows): a sample on a row no neighbouring band has sent is treated like an off-screen one
+        // band rendering (PassCtx::validRows): a sample on a row no neighbouring band has sent is treated like an off-screen one. (Reflecting such a
+        // sample through the pixel's row instead was measured at 8K in four bands: 97.2 % of a band's pixels within one code of the unpartitioned
+        // frame after three frames against 98.6 % for the plain drop - the reflected texel is a worse stand-in than a renormalised smaller disc.)
         const int sampleRow = clampi((int)floorf(saneCoord(sampleUV.y * (float)inYSH.h)), inYSH.h);
         if (sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f || sampleRow < validY0 || sampleRow >= validY1) {
             weight = 0.f;

@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void frustumAndTileCullingKernel(const uint32_
     cullTile<USE_HIZ>([&](uint32_t i) { return i < base0 ? culled[1 + i] : list[i]; }, listCount, lane, blockIdx.x * 4u + wave, bbs, tiles, *influenceRangeP, depthMinMax, g,
                       tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity);
     __syncthreads();
-    if (t == 0 && __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+    // every block read culled[0] (base0) before this barrier; the ticket is release / acquire at agent scope so that the last block's store of
+    // the new count is ordered after all of those reads
+    if (t == 0 && __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
         culled[0] = finalCount;
         __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -3,7 +3,7 @@
 // The spatial filter gathers ONE 16-byte texel per sample: {Y_SH (4 halves), CoCg (2 halves), a quarter of the linear-depth denominator
 // (float)}. On its own the filter pass fills that packed copy with a pre-pass over its inputs (13 us, 124 MB per pass at 4K). When the pass
 // that PRODUCES the filter's input is recorded right before it (pass fusion, backend.h), the producer writes the packed texel next to its
-// regular outputs - it has the values in registers - and the pre-pass disappears.
+// regular outputs - it has the values in registers - and the pre-pass disappears (or shrinks to the rows other GPUs sent, in band rendering).
 #pragma once
 #include "../backend.h"
 #include "../device/shading_common.h"
@@ -27,12 +27,12 @@ struct SpatialPackTarget {
     uint4* packed = nullptr; // [h][w] of the filter's input images
     ImgView depth;           // the filter's depthTexture (same texel grid as its inputs): R16F or D32
 };
-// 0: target filled; kUseGeneralKernel: this execution of the filter does not use packed texels (depth on another grid, unknown format)
-int spatialFilterPackTarget(const PassCtx& spatialCtx, SpatialPackTarget* out);
-// the filter pass without its packing pre-pass (the producer has written every texel the pass can read)
-int launchSpatialFilterFastPrepacked(const PassCtx& c);
-// the producers, writing the packed copy as well (sdf_trace_fast.hip, stream_fast.hip)
-int launchTraceFastPacking(const PassCtx& c, const SpatialPackTarget& target);
-int launchTemporalGiFastPacking(const PassCtx& c, const SpatialPackTarget& target);
+// Called by a producer's launcher (PassCtx::consumer, backend.h): if the consumer is a spatial filter execution that samples the producer's
+// storage images outY / outC through packed texels, fills *out and returns 0; kUseGeneralKernel: no packing for this execution.
+int spatialPackTargetOfConsumer(const PassCtx& producer, int outY, int outC, SpatialPackTarget* out);
+// the producer has launched a kernel that writes the packed texels of rows [y0, y1) of the consumer's input: the filter's own packing
+// pre-pass then covers only the rows it can read that nobody packed this frame (none in a whole-frame dispatch; the halo rows a
+// neighbouring band sent, in band rendering)
+void spatialNotePackedRows(const PassCtx& producer, int y0, int y1);
 
 } // namespace plr

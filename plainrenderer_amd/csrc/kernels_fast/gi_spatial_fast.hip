@@ -29,6 +29,9 @@
 #include "../device/xcd.h"
 #include "fused_gi.h"
 #include <cstdlib>
+#include <map>
+#include <utility>
+#include <vector>
 #include <type_traits>
 
 namespace plr {
@@ -75,6 +78,18 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
     const uint32_t ct = ((const uint32_t*)inCoCg.ptr)[idx];
     const float dep = Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x;
     packed[idx] = packGiTexel(yt, ct, dep, g->nearPlane, g->farPlane);
+}
+// the same over two row ranges in one launch: rows [rowBegin, holeBegin) and [holeEnd, rowEnd) - the halo rows above and below a band whose own rows
+// the producer has packed
+template <int DEPTH_FMT>
+__global__ __launch_bounds__(256) void spatialPackAroundKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
+                                                               int rowBegin, int holeBegin, int holeEnd, int rowEnd) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    int y = rowBegin + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (y >= holeBegin) y += holeEnd - holeBegin;
+    if (x >= inYSH.w || y >= rowEnd) return;
+    const size_t idx = (size_t)y * (size_t)inYSH.w + (size_t)x;
+    packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
 }
 
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
@@ -165,8 +180,12 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         const float sw = __builtin_amdgcn_sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
         const float wMin = (P0.z - sw * dm) * 0.999f;
         safe = wMin > 0.f && fabsf(P0.x) + sx * dm <= wMin && fabsf(P0.y) + sy * dm <= wMin;
-        // band rendering: only part of the input rows is valid (PassCtx::validRows) - every sample has to be tested against it
-        safe = safe && validRowCount >= (uint32_t)inYSH.h;
+        // band rendering: only part of the input rows is valid (PassCtx::validRows). A sample's v moves by at most 0.5 (|dy| + |y / w| |dw|) / w <=
+        // 0.5 (sy + sw) dm / wMin from the centre's: a disc whose rows provably stay inside the valid rows needs no per-sample row test either
+        if (validRowCount < (uint32_t)inYSH.h) {
+            const float reach = 0.5f * (sy + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.h + 1.f; // rows
+            safe = safe && (float)py - reach >= (float)validY0 && (float)py + reach < (float)(validY0 + validRowCount);
+        }
     }
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
@@ -310,11 +329,56 @@ int spatialFilterPackTarget(const PassCtx& c, SpatialPackTarget* out) {
     return 0;
 }
 
-static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked);
-static int launchSpatialFilterFast(const PassCtx& c) { return launchSpatialFilterFastImpl(c, false); }
-int launchSpatialFilterFastPrepacked(const PassCtx& c) { return launchSpatialFilterFastImpl(c, true); }
+// ---- rows of a filter pass's packed copy that its producer filled this frame (host-side bookkeeping, one entry per filter pass = per scratch slot;
+// the backend is one instance per host thread)
+struct PackedRows {
+    uint64_t frameSerial = 0;
+    const void* source = nullptr;             // the Y_SH image the rows were packed from
+    const void* packed = nullptr;             // the packed copy they were written to (a re-allocated scratch invalidates the entry)
+    std::vector<std::pair<int, int>> rows;    // [y0, y1)
+};
+static thread_local std::map<const void*, PackedRows> g_packedRows;
 
-static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
+int spatialPackTargetOfConsumer(const PassCtx& producer, int outY, int outC, SpatialPackTarget* out) {
+    const PassCtx* f = producer.consumer;
+    if (!f || !producer.hasStorage(outY) || !producer.hasStorage(outC) || !f->hasSampled(2) || !f->hasSampled(3) || !f->hasStorage(0)) return kUseGeneralKernel;
+    if (producer.storage[outY].ptr != f->sampled[2].ptr || producer.storage[outC].ptr != f->sampled[3].ptr || producer.storage[outY].w != f->sampled[2].w ||
+        producer.storage[outY].h != f->sampled[2].h)
+        return kUseGeneralKernel;
+    return spatialFilterPackTarget(*f, out);
+}
+void spatialNotePackedRows(const PassCtx& producer, int y0, int y1) {
+    const PassCtx* f = producer.consumer;
+    if (!f || !f->scratchSlot || y1 <= y0) return;
+    PackedRows& e = g_packedRows[(const void*)f->scratchSlot];
+    const void* packed = *f->scratchSlot ? (const uint8_t*)*f->scratchSlot + kSpatialTableBytes : nullptr;
+    if (e.frameSerial != producer.frameSerial || e.source != f->sampled[2].ptr || e.packed != packed) {
+        e.frameSerial = producer.frameSerial; e.source = f->sampled[2].ptr; e.packed = packed; e.rows.clear();
+    }
+    e.rows.push_back({y0, y1});
+    countFusedExecutions(1);
+}
+// [lo, hi) minus the rows the producer packed this frame, as at most two intervals (more: the caller packs [lo, hi) whole)
+static int unpackedRows(const PassCtx& c, const void* packed, int lo, int hi, std::pair<int, int> out[2]) {
+    std::vector<std::pair<int, int>> rest{{lo, hi}};
+    auto it = c.scratchSlot ? g_packedRows.find((const void*)c.scratchSlot) : g_packedRows.end();
+    if (it != g_packedRows.end() && it->second.frameSerial == c.frameSerial && it->second.source == c.sampled[2].ptr && it->second.packed == packed) {
+        for (const auto& r : it->second.rows) {
+            std::vector<std::pair<int, int>> next;
+            for (const auto& q : rest) {
+                if (r.second <= q.first || r.first >= q.second) { next.push_back(q); continue; }
+                if (q.first < r.first) next.push_back({q.first, r.first});
+                if (r.second < q.second) next.push_back({r.second, q.second});
+            }
+            rest.swap(next);
+        }
+    }
+    if (rest.size() > 2) { out[0] = {lo, hi}; return 1; }
+    for (size_t i = 0; i < rest.size(); i++) out[i] = rest[i];
+    return (int)rest.size();
+}
+
+static int launchSpatialFilterFast(const PassCtx& c) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_RGBA16F, "filterIndirectDiffuseSpatial imageOut_Y_SH")) return rc;
     if (int rc = c.needStorage(1, F_RG16F, "filterIndirectDiffuseSpatial imageOut_CoCg")) return rc;
@@ -340,27 +404,39 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
     const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
     const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h;
-    if (prepacked && !sameGrid) return c.fail(-1, "filterIndirectDiffuseSpatial: prepacked launch without a packed grid");
     uint8_t* scratch = spatialScratch(c, sameGrid);
     if (!scratch) return c.fail(-2, "filterIndirectDiffuseSpatial: cannot allocate scratch memory");
     PLR_CHECK_LAUNCH(c);
     float* tables = (float*)scratch;
     uint4* packed = (uint4*)(scratch + kSpatialTableBytes);
-    if (sameGrid && !prepacked) {
-        // rows the filter can read: the dispatched rows and a margin (a band renderer exchanges 64 halo rows; samples further away
-        // read whatever an earlier frame packed there, exactly like the stale image rows they would read unpacked)
-        const int margin = 128;
-        const int p0 = std::max(y0 - margin, 0), p1 = std::min(h + margin, c.sampled[2].h);
-        const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)(p1 - p0), 4u));
-        if (c.sampled[4].fmt == F_R16F) spatialPackKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, p0, p1);
-        else if (c.sampled[4].fmt == F_D32) spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, p0, p1);
-        else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
-        PLR_CHECK_LAUNCH(c);
-        c.splitTiming("texel packing");
-    }
-    uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
     int validLo, validHi;
     c.validRowRange(c.sampled[2].h, &validLo, &validHi);
+    if (sameGrid) {
+        // rows the filter can read: the dispatched rows and a margin (samples further away read whatever an earlier frame packed there, exactly like
+        // the stale image rows they would read unpacked), inside the rows declared valid (band rendering: a sample on any other row has weight 0);
+        // minus the rows the producer of the input packed itself (fused_gi.h)
+        const int margin = 128;
+        const int p0 = std::max({y0 - margin, 0, validLo}), p1 = std::min({h + margin, (int)c.sampled[2].h, validHi});
+        std::pair<int, int> todo[2];
+        const int nTodo = p1 > p0 ? unpackedRows(c, packed, p0, p1, todo) : 0;
+        if (c.sampled[4].fmt != F_R16F && c.sampled[4].fmt != F_D32) return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
+        const bool r16 = c.sampled[4].fmt == F_R16F;
+        if (nTodo == 2 && (todo[0].second - todo[0].first) % 4 == 0) { // the halo rows above and below the producer's rows: one launch
+            const int rows = (todo[0].second - todo[0].first) + (todo[1].second - todo[1].first);
+            const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)rows, 4u));
+            if (r16) spatialPackAroundKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[0].first, todo[0].second, todo[1].first, todo[1].second);
+            else spatialPackAroundKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[0].first, todo[0].second, todo[1].first, todo[1].second);
+        } else
+            for (int i = 0; i < nTodo; i++) {
+                const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)(todo[i].second - todo[i].first), 4u));
+                if (r16) spatialPackKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[i].first, todo[i].second);
+                else spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[i].first, todo[i].second);
+            }
+        PLR_CHECK_LAUNCH(c);
+        if (nTodo) c.splitTiming("texel packing");
+        else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
+    }
+    uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, tilesY, chunkRows, sig, \
                          (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0)
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
@@ -380,29 +456,8 @@ static int launchSpatialFilterFastImpl(const PassCtx& c, bool prepacked) {
 }
 PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseSpatial.comp", launchSpatialFilterFast);
 
-// ---- pass fusion: the producer of the filter's input is recorded right before it and covers the whole image ----
-// (not in band rendering: there the halo exchange callbacks sit between the two passes, and the neighbours' rows arrive unpacked)
-static bool coversWholeImage(const PassCtx& c, const ImgView& image) {
-    const PassCtx::RowSpan rs = c.rowSpan(image.h);
-    return rs.y0 == 0 && rs.y1 == image.h && (int)(c.dispatch[0] * 8u) >= image.w;
-}
-static int fusedProducerAndSpatial(const PassCtx* const* ctxs, size_t count, bool traceProducer) {
-    if (count != 2) return kUseGeneralKernel;
-    const PassCtx &prod = *ctxs[0], &filt = *ctxs[1];
-    const int outY = traceProducer ? 0 : 2, outC = traceProducer ? 1 : 3; // the temporal filter's history outputs feed spatial pass 1
-    if (!prod.hasStorage(outY) || !prod.hasStorage(outC) || !filt.hasSampled(2) || !filt.hasSampled(3) || !filt.hasStorage(0)) return kUseGeneralKernel;
-    if (prod.storage[outY].ptr != filt.sampled[2].ptr || prod.storage[outC].ptr != filt.sampled[3].ptr) return kUseGeneralKernel;
-    if (!coversWholeImage(prod, prod.storage[outY]) || !coversWholeImage(filt, filt.storage[0])) return kUseGeneralKernel;
-    SpatialPackTarget target;
-    if (int rc = spatialFilterPackTarget(filt, &target)) return rc; // kUseGeneralKernel: not a packed configuration
-    const int rc = traceProducer ? launchTraceFastPacking(prod, target) : launchTemporalGiFastPacking(prod, target);
-    if (rc) return rc; // kUseGeneralKernel included: nothing has been launched yet
-    PassCtx::splitTimingBetween(prod, filt); // two kernels: each pass keeps its own timing entry
-    return launchSpatialFilterFastPrepacked(filt);
-}
-static int fused_trace_spatial(const PassCtx* const* ctxs, size_t count) { return fusedProducerAndSpatial(ctxs, count, true); }
-static int fused_temporal_spatial(const PassCtx* const* ctxs, size_t count) { return fusedProducerAndSpatial(ctxs, count, false); }
-PLR_REGISTER_FUSION("sdfDiffuseTrace + filterIndirectDiffuseSpatial", fused_trace_spatial, "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp");
-PLR_REGISTER_FUSION("filterIndirectDiffuseTemporal + filterIndirectDiffuseSpatial", fused_temporal_spatial, "filterIndirectDiffuseTemporal.comp", "filterIndirectDiffuseSpatial.comp");
+// ---- the producers of the filter's input write the packed texels of the rows they produce (PassCtx::consumer; fused_gi.h)
+PLR_REGISTER_CONSUMER_LINK(trace_spatial, "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp");
+PLR_REGISTER_CONSUMER_LINK(temporal_spatial, "filterIndirectDiffuseTemporal.comp", "filterIndirectDiffuseSpatial.comp");
 
 } // namespace plr

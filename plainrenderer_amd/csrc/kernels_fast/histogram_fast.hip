@@ -165,6 +165,7 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (ep.perTile != hp.perTile) return kUseGeneralKernel; // the combine must read what the per-tile pass writes
     fasthiz::Plan zp;
     if (int rc = fasthiz::prepare(*ctxs[4], ctxs[5], &zp)) return rc;
+    if (zp.perTile) return kUseGeneralKernel; // a per-tile pyramid has no chain tail for launch 2 to host: its passes fuse on their own (hiz_fast.hip)
     // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
     histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX);

@@ -9,6 +9,7 @@
 //                  and 8 B (level 1) per lane. With pass fusion the same lane also writes the half-resolution depth of depthDownscale.comp
 //                  (texel (2x, 2y) of its patch as a half float) and that pass's launch disappears.
 //   hizTailKernel: one 1024-thread block finishes levels 4.. out of LDS (level 4 of the 4K frame is 120 x 67 texels = 63 KB).
+//   hizTileTailKernel: six-level per-tile pyramids (band rendering, 8K): levels 4 and 5 of the launch's tile rows straight from level 3 (device/hiz_fast_device.h).
 // 55 MB of compulsory traffic in two launches.
 #include "../backend.h"
 #include "../device/shading_common.h"
@@ -19,7 +20,9 @@ namespace plr {
 namespace fasthiz {
 
 template <int LEVELS, bool DOWNSCALE>
-__global__ __launch_bounds__(256) void hizQuadKernel(QuadParams p) { hizQuadBlock<LEVELS, DOWNSCALE>(p, (int)blockIdx.x, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void hizQuadKernel(QuadParams p) { hizQuadBlock<LEVELS, DOWNSCALE>(p, (int)blockIdx.x, (int)blockIdx.y + p.tileY0); }
+
+__global__ __launch_bounds__(256) void hizTileTailKernel(TileTailParams p) { hizTileTailThread(p, (int)(blockIdx.x * 256u + threadIdx.x)); }
 
 __global__ __launch_bounds__(1024) void hizTailKernel(HizParams p, int first, int texelsA) {
     extern __shared__ float2 hizTailLds[];
@@ -44,26 +47,53 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
         p.level[l] = (float2*)c.storage[b].ptr; p.w[l] = w; p.h[l] = h;
         sw = w; sh = h;
     }
-    // the whole pyramid only: a dispatch that covers part of the tile rows (band rendering) takes the general kernel
+    // tile rows (64 depth rows each) of the recorded dispatch. The whole chain needs every tile; a SIX-level pyramid is per tile (band rendering, and
+    // frames beyond the shader's 11 levels: frame_pipeline.cpp perTilePyramid) and can be built for any range of tile rows
     const int tileRows = (int)divUp((unsigned)p.h[0], 32u);
-    if (c.base[1] != 0 || (int)c.dispatch[1] < tileRows) return kUseGeneralKernel;
+    const bool whole = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows;
+    const bool perTile = mipCount == 6 && levels == 4;
+    if (!whole && !perTile) return kUseGeneralKernel;
+    int tile0 = 0, tile1 = tileRows;
+    if (!whole) {
+        const PassCtx::RowSpan rs = c.rowSpan(tileRows, 1);
+        tile0 = rs.y0; tile1 = rs.y1;
+        if (tile1 <= tile0) return kUseGeneralKernel; // nothing to do: let the general launcher say so
+    }
     const int texA = p.w[levels] * p.h[levels], texB = mipCount > levels + 1 ? p.w[levels + 1] * p.h[levels + 1] : 1;
     const size_t tailLds = (size_t)(texA + texB) * sizeof(float2);
-    if (tailLds > 140 * 1024) return kUseGeneralKernel;
+    if (!perTile && tailLds > 140 * 1024) return kUseGeneralKernel;
     QuadParams q{};
     q.depth = (const float*)depth.ptr; q.depthW = depth.w; q.depthH = depth.h;
     for (int l = 0; l < 4; l++) q.level[l] = p.level[l];
     q.levels = levels;
+    // quad blocks: the tile rows of the dispatch; per tile, one more when a 3-row footprint of level 4 / 5 reaches into the next tile's level-3 rows
+    int quad0 = tile0, quad1 = tile1;
+    if (perTile && ((p.h[3] | p.h[4]) & 1)) quad1 = std::min(tile1 + 1, tileRows);
     if (down) {
         if (!down->hasStorage(0) || !down->hasSampled(1) || down->storage[0].fmt != F_R16F || down->sampled[1].ptr != depth.ptr) return kUseGeneralKernel;
         const ImgView& dst = down->storage[0];
         const PassCtx::RowSpan rs = down->rowSpan(dst.h);
-        if (dst.w * 2 != depth.w || dst.h * 2 != depth.h || rs.y0 != 0 || rs.y1 != dst.h || (int)(down->dispatch[0] * 8u) < dst.w) return kUseGeneralKernel;
+        if (dst.w * 2 != depth.w || dst.h * 2 != depth.h || (int)(down->dispatch[0] * 8u) < dst.w || rs.y1 <= rs.y0) return kUseGeneralKernel;
+        if (!perTile && (rs.y0 != 0 || rs.y1 != dst.h)) return kUseGeneralKernel;
         q.halfDepth = (uint16_t*)dst.ptr; q.halfW = dst.w;
+        q.halfRow0 = rs.y0; q.halfRow1 = rs.y1;
+        // the quad blocks also cover the tile rows of the half-resolution rows the downscale pass was asked for (32 half-res rows per tile)
+        quad0 = std::min(quad0, rs.y0 / 32); quad1 = std::max(quad1, std::min((rs.y1 + 31) / 32, tileRows));
     }
+    q.tileY0 = quad0;
     out->quad = q; out->tail = p;
-    out->gridX = (int)divUp((unsigned)depth.w, 64u); out->gridY = (int)divUp((unsigned)depth.h, 64u);
+    out->gridX = (int)divUp((unsigned)depth.w, 64u); out->gridY = quad1 - quad0;
     out->tailFirst = levels; out->tailTexelsA = texA; out->tailLdsBytes = tailLds; out->downscale = down != nullptr;
+    out->perTile = perTile;
+    if (perTile) {
+        TileTailParams t{};
+        t.level3 = p.level[3]; t.level4 = p.level[4]; t.level5 = p.level[5];
+        t.w3 = p.w[3]; t.h3 = p.h[3]; t.w4 = p.w[4]; t.h4 = p.h[4]; t.w5 = p.w[5]; t.h5 = p.h[5];
+        // a tile owns 2 rows of level 4 and 1 row of level 5 (kernels/hiz.hip: lo = tile * (32 >> level))
+        t.row4Begin = std::min(2 * tile0, t.h4); t.row4End = std::min(2 * tile1, t.h4);
+        t.row5Begin = std::min(tile0, t.h5); t.row5End = std::min(tile1, t.h5);
+        out->tileTail = t;
+    }
     return 0;
 }
 
@@ -79,7 +109,11 @@ static int launchImpl(const PassCtx& c, const PassCtx* down) {
     if (down) hizQuadKernel<4, true><<<grid, 256, 0, c.stream>>>(plan.quad);
     else hizQuadKernel<4, false><<<grid, 256, 0, c.stream>>>(plan.quad);
     PLR_CHECK_LAUNCH(c);
-    hizTailKernel<<<1, 1024, plan.tailLdsBytes, c.stream>>>(plan.tail, plan.tailFirst, plan.tailTexelsA);
+    if (plan.perTile) {
+        const TileTailParams& t = plan.tileTail;
+        const int n = t.w4 * (t.row4End - t.row4Begin) + t.w5 * (t.row5End - t.row5Begin);
+        if (n > 0) hizTileTailKernel<<<divUp((unsigned)n, 256u), 256, 0, c.stream>>>(t);
+    } else hizTailKernel<<<1, 1024, plan.tailLdsBytes, c.stream>>>(plan.tail, plan.tailFirst, plan.tailTexelsA);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

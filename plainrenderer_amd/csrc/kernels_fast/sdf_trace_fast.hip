@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
     }
 }
 
-static int launchImpl(const PassCtx& c, const SpatialPackTarget* pack) {
+static int launchImpl(const PassCtx& c) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_RGBA16F, "sdfDiffuseTrace imageOut_Y_SH")) return rc;
     if (int rc = c.needStorage(1, F_RG16F, "sdfDiffuseTrace imageOut_CoCg")) return rc;
@@ -375,6 +375,10 @@ static int launchImpl(const PassCtx& c, const SpatialPackTarget* pack) {
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
                        tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
+    // the spatial filter that reads this pass's output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
+    SpatialPackTarget packTarget;
+    const SpatialPackTarget* pack = !sig && spatialPackTargetOfConsumer(c, 0, 1, &packTarget) == 0 ? &packTarget : nullptr;
+    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32))) pack = nullptr;
     if (pack) {
         // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
         if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
@@ -392,14 +396,19 @@ static int launchImpl(const PassCtx& c, const SpatialPackTarget* pack) {
     else sdfDiffuseTraceFastKernel<false, false, 0><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
 #undef PLR_TRACE_ARGS
     PLR_CHECK_LAUNCH(c);
+    if (pack) {
+        if (c.extraCountY) {
+            spatialNotePackedRows(c, std::min(groupY0 * 8, (int)out.h), std::min((groupY0 + (int)c.dispatch[1]) * 8, (int)out.h));
+            spatialNotePackedRows(c, std::min((int)c.extraBaseY * 8, (int)out.h), std::min(groupsY * 8, (int)out.h));
+        } else spatialNotePackedRows(c, std::min(groupY0 * 8, (int)out.h), std::min(groupsY * 8, (int)out.h));
+    }
     return 0;
 }
 
-static int launch(const PassCtx& c) { return launchImpl(c, nullptr); }
+static int launch(const PassCtx& c) { return launchImpl(c); }
 
 } // namespace fasttrace
 
-int launchTraceFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return fasttrace::launchImpl(c, &target); }
 static int fasttrace_launch(const PassCtx& c) { return fasttrace::launch(c); }
 PLR_REGISTER_SHADER_FAST("sdfDiffuseTrace.comp", fasttrace_launch);
 // band rendering records the rows its neighbours need as two dispatches (above and below the interior): one launch

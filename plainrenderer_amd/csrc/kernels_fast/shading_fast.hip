@@ -6,11 +6,18 @@
 //    cancels against the division by dot(ray, forward)); normalisations use v_rsq_f32, divisions v_rcp_f32, FMA contraction is on
 //  * the 12 PCF tap directions are one hardware sin/cos of the per-pixel noise angle rotated by a constant 12-entry table
 //  * directionToSH_L1 of a unit vector has a constant norm, so its normalize() is two constants
-// Output is R11G11B10 (6/5-bit mantissas); stated tolerance in tests/test_fast_kernels.py. A PCF tap whose depth comparison sits
-// within rounding of equality can flip (1/12 of the sun term for that pixel).
+// Output is R11G11B10 (6/5-bit mantissas); stated tolerance in tests/test_fast_kernels.py.
+//
+// What is NOT relaxed: the geometry that feeds a discrete decision. The world position, the light-space position and the D16 comparison of
+// a PCF tap are evaluated in the shader's operation order with correctly rounded quotients / roots (exactViewRay / exactSurface /
+// calcShadow below): the synthetic - and any bias-free - shadow map holds the depth of the very surface being shaded, so a third of the
+// lit pixels have taps within one D16 step of equality and a last-bit difference in the light-space depth flips them (round 2: 1.55 % of
+// the 4K pixels resolved a tap differently from the oracle; now the tap count differs on < 1e-3 of them, profiles/r03_parity_4k.txt).
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
+#include "upscale_quad.h"
+#include <type_traits>
 
 namespace plr {
 
@@ -33,6 +40,51 @@ PLR_DI float exp2h(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 
 PLR_DI vec3 nrm(vec3 v) { return v * rsqf(dot(v, v)); }
 PLR_DI float pow5(float x) { x = fmax1(x, 0.f); const float x2 = x * x; return x2 * x2 * x; }
 PLR_DI float fpow(float x, float y) { return x <= 0.f ? 0.f : exp2h(y * log2h(x)); }
+
+// ---- correctly rounded quotient / reciprocal / root from v_rcp_f32 / v_rsq_f32 (1 ulp) and one Newton step with fused residuals: the IEEE result
+// for every operand this kernel sees (finite, normal, non-zero divisors) in 4-5 instructions instead of the 10-instruction v_div_scale sequence
+PLR_DI float rcpRN(float d) { const float r = rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r); }
+PLR_DI float divRNr(float n, float d, float r) { const float q = n * r; return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q); } // r = rcpRN(d)
+PLR_DI float divRN(float n, float d) { return divRNr(n, d, rcpRN(d)); }
+PLR_DI float sqrtRN(float x) { const float r = rsqf(x), s = x * r; return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * r, s); } // x > 0
+
+// view direction of a pixel (surface -> camera, unit length) and its screen uv, bit for bit as deferredShadingKernel (kernels/shading.hip)
+// computes them: screenToWorld.inc:4-9 with every operation rounded separately. Scalar expressions on purpose: `#pragma clang fp contract`
+// is lexical, the vec3 operators of vecmath.h would be contracted with the file's default
+struct ViewRay { vec3 Vn; float su, sv; };
+PLR_DI ViewRay exactViewRay(const GlobalUbo* __restrict__ g, int px, int py) {
+#pragma clang fp contract(off)
+    ViewRay o;
+    o.su = divRN((float)px + 0.5f, (float)g->screenResolution[0]);
+    o.sv = divRN((float)py + 0.5f, (float)g->screenResolution[1]);
+    const float ndx = o.su * 2.f - 1.f, ndy = o.sv * 2.f - 1.f;
+    const float ty = g->cameraTanFovHalf * ndy, tx = (g->cameraTanFovHalf * g->cameraAspectRatio) * ndx;
+    const float vx = (-g->cameraForward[0] + ty * g->cameraUp[0]) - tx * g->cameraRight[0];
+    const float vy = (-g->cameraForward[1] + ty * g->cameraUp[1]) - tx * g->cameraRight[1];
+    const float vz = (-g->cameraForward[2] + ty * g->cameraUp[2]) - tx * g->cameraRight[2];
+    const float inv = rcpRN(sqrtRN((vx * vx + vy * vy) + vz * vz));
+    o.Vn = vec3(vx * inv, vy * inv, vz * inv);
+    return o;
+}
+// world position of the surface and its view depth (deferredShadingKernel: linearizeDepth, passPos = camPos + Vcam / dot(Vcam, fwd) * depthLinear,
+// pixelDepth = dot(camPos - passPos, -fwd)), same operations, same order
+struct Surface { vec3 passPos; float pixelDepth; };
+PLR_DI Surface exactSurface(const GlobalUbo* __restrict__ g, vec3 Vn, float depth) {
+#pragma clang fp contract(off)
+    const float cx = -Vn.x, cy = -Vn.y, cz = -Vn.z; // Vcam
+    const float fx = g->cameraForward[0], fy = g->cameraForward[1], fz = g->cameraForward[2];
+    const float dvf = (cx * fx + cy * fy) + cz * fz;
+    const float den = g->farPlane + (-depth + 1.f) * (g->nearPlane - g->farPlane);
+    const float depthLinear = divRN(g->nearPlane * g->farPlane, den);
+    const float rd = rcpRN(dvf);
+    Surface s;
+    s.passPos.x = g->cameraPosition[0] + divRNr(cx, dvf, rd) * depthLinear;
+    s.passPos.y = g->cameraPosition[1] + divRNr(cy, dvf, rd) * depthLinear;
+    s.passPos.z = g->cameraPosition[2] + divRNr(cz, dvf, rd) * depthLinear;
+    const float wx = g->cameraPosition[0] - s.passPos.x, wy = g->cameraPosition[1] - s.passPos.y, wz = g->cameraPosition[2] - s.passPos.z;
+    s.pixelDepth = (wx * -fx + wy * -fy) + wz * -fz;
+    return s;
+}
 
 PLR_DI float D_GGX(float NoH, float r) {
     const float a = NoH * r;
@@ -132,17 +184,34 @@ PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
 // 12-tap rotated-disc PCF (lightingFunctions / shadow sampling of the shader). Per tap the shader evaluates
 //   d = sqrt((i + noise/2) / 12), angle = 2 pi (i / 12 + noise), uv = base + (cos, sin)(angle) * 0.03 * lightSpaceScale * d,
 //   nearest fetch with a black border, shadow += actualDepth >= texel.
-// Restructured for issue count (the kernel is bound by VALU issue): the twelve directions are the noise rotation turned by
-// multiples of 30 degrees, so they come from four products (c0, s0 times cos 30 / sin 30) and four sums; the texel-space scale is
-// folded into the per-tap radius; the border test is two unsigned compares on the floored texel coordinate; and the depth compare
-// runs on the raw 16-bit texel against floor(actualDepth * 65535) (for an integer texel t: t / 65535 <= a <=> t <= floor(65535 a)).
+// The light-space position (matrix product, perspective division) is the shader's, operation by operation (see the file header), and so
+// is the comparison: a D16 texel t decodes to fl(t / 65535) (IEEE quotient), so "actualDepth >= texel" is "t <= T" with
+// T = max{t : fl(t / 65535) <= actualDepth}, found once per pixel from the guess floor(actualDepth * 65535) (off by at most one) and two
+// correctly rounded quotients. The taps themselves are restructured for issue count (the kernel is bound by VALU issue): the twelve
+// directions are the noise rotation turned by multiples of 30 degrees, so they come from four products (c0, s0 times cos 30 / sin 30) and
+// four sums; the texel-space scale is folded into the per-tap radius; the border test is two unsigned compares on the floored texel
+// coordinate. (A tap position differs from the shader's by ~1e-5 texels - hardware sin / cos - which picks another texel for ~1e-5 of the taps.)
 PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMatrix, vec2 lightSpaceScale, float noise) {
-    vec4 p = mulMat4(lightMatrix, vec4(pos, 1.f));
-    const float iw = rcpf(p.w);
+    float cxy0, cxy1; // tap centre, uv
+    uint32_t depthThreshold;
+    {
+#pragma clang fp contract(off)
+        const float* m = lightMatrix;
+        const float x = ((m[0] * pos.x + m[4] * pos.y) + m[8] * pos.z) + m[12];
+        const float y = ((m[1] * pos.x + m[5] * pos.y) + m[9] * pos.z) + m[13];
+        const float z = ((m[2] * pos.x + m[6] * pos.y) + m[10] * pos.z) + m[14];
+        const float w = ((m[3] * pos.x + m[7] * pos.y) + m[11] * pos.z) + m[15];
+        const float rw = rcpRN(w);
+        cxy0 = divRNr(x, w, rw) * 0.5f + 0.5f;
+        cxy1 = divRNr(y, w, rw) * 0.5f + 0.5f;
+        const float actualDepth = fclamp(divRNr(z, w, rw), 0.f, 1.f);
+        const uint32_t t0 = (uint32_t)(actualDepth * 65535.f); // truncation = floor, the value is non-negative
+        const float r16 = 1.f / 65535.f; // the compiler's constant is the correctly rounded reciprocal
+        const float q1 = divRNr((float)(t0 + 1u), 65535.f, r16), q0 = divRNr((float)t0, 65535.f, r16);
+        depthThreshold = q1 <= actualDepth ? t0 + 1u : (q0 <= actualDepth ? t0 : t0 - 1u); // t0 = 0 always passes its own test: no wrap
+    }
     const float fw = (float)shadowMap.w, fh = (float)shadowMap.h;
-    const float bxw = (p.x * iw * 0.5f + 0.5f) * fw, byh = (p.y * iw * 0.5f + 0.5f) * fh; // tap centre in texels
-    const float actualDepth = fclamp(p.z * iw, 0.f, 1.f);
-    const uint32_t depthThreshold = (uint32_t)(actualDepth * 65535.f); // truncation = floor, the value is non-negative
+    const float bxw = cxy0 * fw, byh = cxy1 * fh; // tap centre in texels
     const float sxw = 0.03f * lightSpaceScale.x * fw, syh = 0.03f * lightSpaceScale.y * fh;
     const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
     // directions i * 30 degrees + noise rotation
@@ -152,6 +221,8 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
     const uint32_t w = (uint32_t)shadowMap.w, h = (uint32_t)shadowMap.h;
     const int wm1 = shadowMap.w - 1, hm1 = shadowMap.h - 1;
     uint32_t lit = 0u;
+    // (a second copy of the tap loop without the border test and the index clamps, for waves whose discs lie inside the map, was measured: 249 us
+    //  against 245 us for the fused launch at 4K - the six half-rate instructions per tap are not what the kernel waits for)
     auto tap = [&](int i, float cx, float cy) {
         const float d = sqrtv(((float)i + 0.5f * noise) * (1.f / 12.f));
         const float tu = bxw + cx * (sxw * d), tv = byh + cy * (syh * d);
@@ -193,46 +264,42 @@ PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, floa
     return vec3(0.f);
 }
 
-template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
-__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (px >= P.coverW || py >= P.coverH) return;
-    const GlobalUbo* g = P.g;
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const float su = fx * rcpf((float)g->screenResolution[0]), sv = fy * rcpf((float)g->screenResolution[1]);
-    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
-    const float depth = ((const float*)P.depth.ptr)[idx];
-    const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
-    const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
-    const vec3 ray = camFwd + (-g->cameraTanFovHalf * ndy) * ld3(g->cameraUp) + (g->cameraTanFovHalf * g->cameraAspectRatio * ndx) * ld3(g->cameraRight);
-    if (depth == 0.f) {
-        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(nrm(ray), P.skyLut));
-        if (P.sig) P.sig[idx] = 128u;
-        return;
-    }
-    const float depthLinear = g->nearPlane * g->farPlane * rcpf(g->farPlane + (1.f - depth) * (g->nearPlane - g->farPlane));
-    const vec3 toPixel = ray * depthLinear; // passPos - camPos
-    const vec3 passPos = camPos + toPixel;
+// raw texels one pixel's shade reads from the G-buffer and from the (upscaled) indirect light
+struct PixelInputs {
+    float depth;
+    uint32_t albedo, specular;
+    uint32_t normal, normalH, normalV; // the pixel's own world normal and those of its horizontal / vertical partner in the 2x2 quad (GeometricAA.inc)
+    uint2 ysh;                         // indirectDiffuse_Y_SH texel (RGBA16F)
+    uint32_t cocg;                     // indirectDiffuse_CoCg texel (RG16F)
+};
+PLR_DI vec3 decodeNormal(uint32_t texel) {
+    const vec3 raw = fastm::unorm8x4(texel).xyz() * 2.f - 1.f;
+    const vec3 N = nrm(raw);
+    return anyNan(N) ? raw : N;
+}
 
-    // the launcher guarantees that the G-buffer images have the colour target's size: one texel index serves all of them
-    const vec3 albedoTexel = fastm::unorm8x4(((const uint32_t*)P.albedo.ptr)[idx]).xyz();
-    const vec3 specularTexel = fastm::unorm8x4(((const uint32_t*)P.specular.ptr)[idx]).xyz();
+// one geometry pixel (depth != 0) of the deferred shade: returns the R11G11B10 colour; *sigWord = decision signature (oracle/oracle.h)
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
+PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const ViewRay& vr, const PixelInputs& in, uint32_t* sigWord) {
+    const GlobalUbo* g = P.g;
+    const float su = vr.su, sv = vr.sv;
+    const Surface surf = exactSurface(g, vr.Vn, in.depth);
+    const vec3 passPos = surf.passPos;
+    const float pixelDepth = surf.pixelDepth;
+
+    const vec3 albedoTexel = fastm::unorm8x4(in.albedo).xyz();
+    const vec3 specularTexel = fastm::unorm8x4(in.specular).xyz();
     const float metalic = specularTexel.z;
     float r = specularTexel.y;
     r = fmax1(r * r, 0.0045f);
     const vec3 albedo(sRGBToLinear1(albedoTexel.x), sRGBToLinear1(albedoTexel.y), sRGBToLinear1(albedoTexel.z));
     const vec3 diffuseColor = (1.f - metalic) * albedo;
-    const vec3 N = gbufferNormal(P.normal, px, py);
+    const vec3 N = decodeNormal(in.normal);
     const vec3 L = nrm(ld3(g->sunDirection));
-    const float pixelDepth = depthLinear; // dot(camPos - passPos, -forward) = depthLinear * dot(ray, forward) = depthLinear
-    const vec3 V = -nrm(ray);
+    const vec3 V = vr.Vn; // normalize(camPos - passPos) is the view ray itself
     const vec3 H = nrm(V + L);
     if (GEOMETRIC_AA) {
-        const int xl = px & ~1, yl = py & ~1;
-        const vec3 Nn = (px & 1) ? gbufferNormal(P.normal, xl, py) : gbufferNormal(P.normal, xl + 1, py);
-        const vec3 Nm = (py & 1) ? gbufferNormal(P.normal, px, yl) : gbufferNormal(P.normal, px, yl + 1);
-        const vec3 N_U = Nn - N, N_V = Nm - N; // sign is irrelevant: only squared lengths are used
+        const vec3 N_U = decodeNormal(in.normalH) - N, N_V = decodeNormal(in.normalV) - N; // sign is irrelevant: only squared lengths are used
         const float variance = 0.25f * (dot(N_V, N_V) + dot(N_U, N_U));
         const float kernelRoughness2 = fmin1(2.f * variance, 0.18f);
         r = fclamp(sqrtv(r * r + kernelRoughness2), 0.f, 1.f);
@@ -262,7 +329,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         shadowMap.h = cascadeIndex == i ? P.shadowMaps[i].h : shadowMap.h;
     }
     const float sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[cascadeIndex], lss, noiseTexel.x);
-    if (P.sig) P.sig[idx] = (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u; // cascade, lit PCF taps, geometry (oracle/oracle.h)
+    *sigWord = (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u; // cascade, lit PCF taps, geometry (oracle/oracle.h)
     const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
     const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
 
@@ -287,9 +354,8 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
 
     vec3 lightingIndirect;
     if (INDIRECT_TECH == 0) {
-        const int ix = clampTo(floorToInt(su * (float)P.ysh.w), P.ysh.w - 1), iy = clampTo(floorToInt(sv * (float)P.ysh.h), P.ysh.h - 1);
-        const vec4 irradiance_Y_SH = Texel<F_RGBA16F>::load(P.ysh.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.ysh.w));
-        const vec4 cc = Texel<F_RG16F>::load(P.cocg.ptr, fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.cocg.w));
+        const vec4 irradiance_Y_SH(halfBitsToFloat(in.ysh.x & 0xffffu), halfBitsToFloat(in.ysh.x >> 16), halfBitsToFloat(in.ysh.y & 0xffffu), halfBitsToFloat(in.ysh.y >> 16));
+        const vec2 cc(halfBitsToFloat(in.cocg & 0xffffu), halfBitsToFloat(in.cocg >> 16));
         // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
         const vec4 shN(0.5f, -0.8660254f * N.y, 0.8660254f * N.z, -0.8660254f * N.x);
         const float irradiance_Y = dot(irradiance_Y_SH, shN);
@@ -343,7 +409,153 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKerne
         const vec4 it = lo + (hi - lo) * c;
         outColor = outColor * it.w + it.xyz();
     }
-    ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(outColor);
+    return packR11G11B10(outColor);
+}
+
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P) {
+    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= P.coverW || py >= P.coverH) return;
+    const ViewRay vr = exactViewRay(P.g, px, py);
+    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
+    PixelInputs in;
+    in.depth = ((const float*)P.depth.ptr)[idx];
+    if (in.depth == 0.f) {
+        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(-vr.Vn, P.skyLut));
+        if (P.sig) P.sig[idx] = 128u;
+        return;
+    }
+    // the launcher guarantees that the G-buffer images have the colour target's size: one texel index serves all of them
+    in.albedo = ((const uint32_t*)P.albedo.ptr)[idx];
+    in.specular = ((const uint32_t*)P.specular.ptr)[idx];
+    const uint32_t* normals = (const uint32_t*)P.normal.ptr;
+    const uint32_t nw = (uint32_t)P.normal.w;
+    const int nx = clampi(px, P.normal.w), ny = clampi(py, P.normal.h);
+    in.normal = normals[fastm::texelIndex((uint32_t)nx, (uint32_t)ny, nw)];
+    in.normalH = in.normalV = in.normal;
+    if (GEOMETRIC_AA) {
+        in.normalH = normals[fastm::texelIndex((uint32_t)clampi(px ^ 1, P.normal.w), (uint32_t)ny, nw)];
+        in.normalV = normals[fastm::texelIndex((uint32_t)nx, (uint32_t)clampi(py ^ 1, P.normal.h), nw)];
+    }
+    in.ysh = make_uint2(0u, 0u);
+    in.cocg = 0u;
+    if (INDIRECT_TECH == 0) {
+        const int ix = clampTo(floorToInt(vr.su * (float)P.ysh.w), P.ysh.w - 1), iy = clampTo(floorToInt(vr.sv * (float)P.ysh.h), P.ysh.h - 1);
+        in.ysh = ((const uint2*)P.ysh.ptr)[fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.ysh.w)];
+        in.cocg = ((const uint32_t*)P.cocg.ptr)[fastm::texelIndex((uint32_t)ix, (uint32_t)iy, (uint32_t)P.cocg.w)];
+    }
+    uint32_t sigWord;
+    const uint32_t colour = shadeGeometryPixel<DIFFUSE_BRDF, MULTISCATTER, GEOMETRIC_AA, INDIRECT_TECH>(P, px, py, vr, in, &sigWord);
+    ((uint32_t*)P.color.ptr)[idx] = colour;
+    if (P.sig) P.sig[idx] = sigWord;
+}
+
+// ---- indirectLightUpscale.comp + the deferred shade as ONE launch (pass fusion, backend.h). Same thread layout as the shade
+// on its own (a lane is a pixel, a wave a 64-pixel row segment, a block 64 x 4 pixels), so the shade part runs exactly as it does there. The block
+// first stages the half-resolution GI texels its pixels can touch - (32 + 2) x (2 + 2) texels: decoded Y_SH / CoCg and the LINEARISED half-res
+// depth, 32 bytes each - in LDS: one load, one linearisation and one decode per texel instead of four to nine per pixel. A pixel then resolves its
+// upscale (indirectLightUpscale.comp:17-71: closest-depth choice, edge test, bilinear blend with the 2x grid's constant 0.25 / 0.75 weights) from
+// LDS and shades with the result in registers. The upscaled images are written only if somebody else could read them (U.storeUpscaled):
+// otherwise their 12 B/px of stores and 12 B/px of loads never happen. Operation for operation the upscale is upscaleQuad's (upscale_quad.h),
+// so the fused launch and the two separate passes produce the same bytes (tests/test_fusion.py).
+// (First built with a thread per 2x2 quad that upscaled the quad in registers and shaded its four pixels in a rolled loop: 281 us against 237 us
+//  for the two separate launches at 4K - the loop serialises four pixels' dependent gather chains in one wave. This form keeps one pixel per lane.)
+struct FusedUpscale {
+    ImgView srcYSH, srcCoCg, halfResDepth, dstYSH, dstCoCg;
+    int storeUpscaled;
+};
+constexpr int kGiTileW = 34, kGiTileH = 4; // half-res texels staged per block
+struct GiTexel { float depthLinear, y0, y1, y2, y3, co, cg, pad; };
+static_assert(sizeof(GiTexel) == 32, "two 16-byte LDS reads per texel");
+
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA>
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(ShadeParams P, FusedUpscale U) {
+    __shared__ GiTexel tile[kGiTileH][kGiTileW];
+    const int t = (int)threadIdx.x;
+    const int X0 = (int)(blockIdx.x * 64u), Y0 = P.yBase + (int)(blockIdx.y * 4u); // both even
+    const int k0 = (X0 >> 1) - 1, m0 = (Y0 >> 1) - 1;                               // half-res texel of tile[0][0]
+    const GlobalUbo* g = P.g;
+    const float nearP = g->nearPlane, farP = g->farPlane, nf = nearP * farP, nmf = nearP - farP;
+    if (t < kGiTileW * kGiTileH) {
+        const int r = t / kGiTileW, c = t - r * kGiTileW;
+        const int hw = U.srcYSH.w, hh = U.srcYSH.h;
+        const size_t i = (size_t)clampi(m0 + r, hh) * (size_t)hw + (size_t)clampi(k0 + c, hw); // clamp-to-edge, as the sampler
+        const uint2 ys = ((const uint2*)U.srcYSH.ptr)[i];
+        const uint32_t cc = ((const uint32_t*)U.srcCoCg.ptr)[i];
+        GiTexel e;
+        e.depthLinear = fastquad::linearDepthRounded(halfBitsToFloat(((const uint16_t*)U.halfResDepth.ptr)[i]), nf, nmf, farP);
+        e.y0 = halfBitsToFloat(ys.x & 0xffffu); e.y1 = halfBitsToFloat(ys.x >> 16); e.y2 = halfBitsToFloat(ys.y & 0xffffu); e.y3 = halfBitsToFloat(ys.y >> 16);
+        e.co = halfBitsToFloat(cc & 0xffffu); e.cg = halfBitsToFloat(cc >> 16); e.pad = 0.f;
+        tile[r][c] = e;
+    }
+    __syncthreads();
+    const int px = X0 + (t & 63), py = Y0 + (t >> 6);
+    if (px >= P.coverW || py >= P.coverH) return;
+    const ViewRay vr = exactViewRay(g, px, py);
+    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
+    PixelInputs in;
+    in.depth = ((const float*)P.depth.ptr)[idx];
+    // ---- the pixel's upscaled GI texel: upscaleQuad's statements for pixel (parity p, q) of quad (k, m) (upscale_quad.h)
+    uint32_t upSig;
+    {
+#pragma clang fp contract(off)
+        const int p = px & 1, q = py & 1;
+        const int kc = (px >> 1) - k0, mr = (py >> 1) - m0; // the quad's own texel inside the tile (>= 1: the neighbourhood's column / row 0 is kc - 1 / mr - 1)
+        const int c0 = kc - 1 + p, r0 = mr - 1 + q;         // texel i0 / j0 of the bilinear footprint
+        const GiTexel f00 = tile[r0][c0], f10 = tile[r0][c0 + 1], f01 = tile[r0 + 1][c0], f11 = tile[r0 + 1][c0 + 1];
+        const float full = fastquad::linearDepthRounded(in.depth, nf, nmf, farP);
+        // textureGather order: (i0, j1), (i1, j1), (i1, j0), (i0, j0)
+        const float ds[4] = {f01.depthLinear, f11.depthLinear, f10.depthLinear, f00.depthLinear};
+        const int offx[4] = {0, 1, 1, 0}, offy[4] = {1, 1, 0, 0};
+        float minDiff = 1000.f;
+        int cx = 0, cy = 0;
+        bool isEdge = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float diff = fabsf(ds[i] - full);
+            isEdge = isEdge || diff > 0.5f;
+            if (diff < minDiff) { minDiff = diff; cx = offx[i]; cy = offy[i]; }
+        }
+        float y0, y1, y2, y3, co, cg;
+        if (isEdge) {
+            // nearest texel at uv + offset * halfResTexelSize = half-res texel (k + cx, m + cy), clamped to the image
+            const int hw = U.srcYSH.w, hh = U.srcYSH.h;
+            const GiTexel n = tile[min((py >> 1) + cy, hh - 1) - m0][min((px >> 1) + cx, hw - 1) - k0];
+            y0 = n.y0; y1 = n.y1; y2 = n.y2; y3 = n.y3; co = n.co; cg = n.cg;
+        } else {
+            const float a = p ? 0.25f : 0.75f, b = q ? 0.25f : 0.75f;
+            const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+            auto bl = [&](float t00, float t10, float t01, float t11) { return __builtin_fmaf(t11, w11, __builtin_fmaf(t01, w01, __builtin_fmaf(t10, w10, t00 * w00))); };
+            y0 = bl(f00.y0, f10.y0, f01.y0, f11.y0); y1 = bl(f00.y1, f10.y1, f01.y1, f11.y1); y2 = bl(f00.y2, f10.y2, f01.y2, f11.y2); y3 = bl(f00.y3, f10.y3, f01.y3, f11.y3);
+            co = bl(f00.co, f10.co, f01.co, f11.co); cg = bl(f00.cg, f10.cg, f01.cg, f11.cg);
+        }
+        in.ysh = make_uint2(floatToHalfBits(y0) | (floatToHalfBits(y1) << 16), floatToHalfBits(y2) | (floatToHalfBits(y3) << 16));
+        in.cocg = floatToHalfBits(co) | (floatToHalfBits(cg) << 16);
+        upSig = (isEdge ? 1u : 0u) | (cx ? 2u : 0u) | (cy ? 4u : 0u);
+    }
+    if (U.storeUpscaled) {
+        ((uint2*)U.dstYSH.ptr)[idx] = in.ysh;
+        ((uint32_t*)U.dstCoCg.ptr)[idx] = in.cocg;
+    }
+    if (in.depth == 0.f) {
+        ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(-vr.Vn, P.skyLut));
+        if (P.sig) P.sig[idx] = 128u | (upSig << 8);
+        return;
+    }
+    in.albedo = ((const uint32_t*)P.albedo.ptr)[idx];
+    in.specular = ((const uint32_t*)P.specular.ptr)[idx];
+    const uint32_t* normals = (const uint32_t*)P.normal.ptr;
+    in.normal = normals[idx]; // the launcher guarantees the normal image has the colour target's size
+    in.normalH = in.normalV = in.normal;
+    if (GEOMETRIC_AA) {
+        in.normalH = normals[fastm::texelIndex((uint32_t)clampi(px ^ 1, P.normal.w), (uint32_t)py, (uint32_t)P.normal.w)];
+        in.normalV = normals[fastm::texelIndex((uint32_t)px, (uint32_t)clampi(py ^ 1, P.normal.h), (uint32_t)P.normal.w)];
+    }
+    uint32_t sigWord;
+    const uint32_t colour = shadeGeometryPixel<DIFFUSE_BRDF, MULTISCATTER, GEOMETRIC_AA, 0>(P, px, py, vr, in, &sigWord);
+    ((uint32_t*)P.color.ptr)[idx] = colour;
+    if (P.sig) P.sig[idx] = sigWord | (upSig << 8); // decision signature of the fused launch: the shade's word | the upscale's word << 8
 }
 
 typedef void (*ShadeKernel)(ShadeParams);
@@ -359,8 +571,19 @@ template <int D> static ShadeKernel pickMulti(int m, bool aa, int tech) {
         default: return pickAA<D, 3>(aa, tech);
     }
 }
+typedef void (*FusedKernel)(ShadeParams, FusedUpscale);
+template <int D, int M> static FusedKernel pickFusedAA(bool aa) { return aa ? (FusedKernel)upscaleAndShadeKernel<D, M, true> : (FusedKernel)upscaleAndShadeKernel<D, M, false>; }
+template <int D> static FusedKernel pickFusedMulti(int m, bool aa) {
+    switch (m) {
+        case 0: return pickFusedAA<D, 0>(aa);
+        case 1: return pickFusedAA<D, 1>(aa);
+        case 2: return pickFusedAA<D, 2>(aa);
+        default: return pickFusedAA<D, 3>(aa);
+    }
+}
 
-static int launchDeferredShadingFast(const PassCtx& c) {
+// validates the bindings of a deferred shade execution and fills the kernel parameters; 0, kUseGeneralKernel or an error
+static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, int* multi, bool* aa, int* tech) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_R11G11B10, "deferredShading colour target")) return rc;
     if (int rc = c.needSampled(3, F_RGBA16F, "deferredShading brdfLutTexture")) return rc;
@@ -382,17 +605,10 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     for (int b : {20, 22, 23}) if (c.sampled[b].w != c.storage[0].w || c.sampled[b].h != c.storage[0].h) return kUseGeneralKernel;
     // the LUT / froxel fetches read the two texels of a row with one 16-byte load
     if (c.sampled[3].w < 2 || c.sampled[18].w < 2) return kUseGeneralKernel;
-    const int diffuseBRDF = c.specInt(0, 0), multi = c.specInt(1, 0), tech = c.specInt(3, 0);
-    const bool aa = c.specBool(2, false);
+    *diffuseBRDF = c.specInt(0, 0); *multi = c.specInt(1, 0); *tech = c.specInt(3, 0);
+    *aa = c.specBool(2, false);
     const uint32_t cascades = c.specUint(4, 4u);
-    if (diffuseBRDF < 0 || diffuseBRDF > 3 || multi < 0 || multi > 3 || cascades < 1 || cascades > 4) return c.fail(-1, "deferredShading: specialisation constant out of range");
-    ShadeKernel k = nullptr;
-    switch (diffuseBRDF) {
-        case 0: k = pickMulti<0>(multi, aa, tech); break;
-        case 1: k = pickMulti<1>(multi, aa, tech); break;
-        case 2: k = pickMulti<2>(multi, aa, tech); break;
-        default: k = pickMulti<3>(multi, aa, tech); break;
-    }
+    if (*diffuseBRDF < 0 || *diffuseBRDF > 3 || *multi < 0 || *multi > 3 || cascades < 1 || cascades > 4) return c.fail(-1, "deferredShading: specialisation constant out of range");
     ShadeParams P{};
     P.color = c.storage[0]; P.depth = c.sampled[20]; P.normal = c.sampled[21]; P.albedo = c.sampled[22]; P.specular = c.sampled[23];
     P.brdfLut = c.sampled[3];
@@ -403,9 +619,70 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
-    if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
     P.sig = c.sigFor((size_t)P.color.w * (size_t)P.color.h);
+    *out = P;
+    return 0;
+}
+
+static int launchDeferredShadingFast(const PassCtx& c) {
+    ShadeParams P;
+    int diffuseBRDF, multi, tech;
+    bool aa;
+    if (int rc = shadeParamsFor(c, &P, &diffuseBRDF, &multi, &aa, &tech)) return rc;
+    ShadeKernel k = nullptr;
+    switch (diffuseBRDF) {
+        case 0: k = pickMulti<0>(multi, aa, tech); break;
+        case 1: k = pickMulti<1>(multi, aa, tech); break;
+        case 2: k = pickMulti<2>(multi, aa, tech); break;
+        default: k = pickMulti<3>(multi, aa, tech); break;
+    }
+    if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
     k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// fused: indirectLightUpscale.comp, then the deferred shade that samples the images it wrote, over the same rows
+static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx &u = *ctxs[0], &c = *ctxs[1];
+    // the upscale's bindings (launchUpscale, stream_fast.hip) in its "regular" 2x case
+    if (!u.global || !u.hasStorage(0) || !u.hasStorage(1) || !u.hasSampled(2) || !u.hasSampled(3) || !u.hasSampled(4) || !u.hasSampled(5)) return kUseGeneralKernel;
+    if (u.storage[0].fmt != F_RGBA16F || u.storage[1].fmt != F_RG16F || u.sampled[2].fmt != F_RGBA16F || u.sampled[3].fmt != F_RG16F || u.sampled[4].fmt != F_D32 ||
+        u.sampled[5].fmt != F_R16F)
+        return kUseGeneralKernel;
+    const ImgView& out = u.storage[0];
+    const PassCtx::RowSpan ur = u.rowSpan(out.h);
+    const bool regular = out.w == 2 * u.sampled[2].w && out.h == 2 * u.sampled[2].h && u.sampled[3].w == u.sampled[2].w && u.sampled[3].h == u.sampled[2].h &&
+                         u.sampled[5].w == u.sampled[2].w && u.sampled[5].h == u.sampled[2].h && u.sampled[4].w == out.w && u.sampled[4].h == out.h &&
+                         u.storage[1].w == out.w && u.storage[1].h == out.h && (ur.y0 & 1) == 0 && u.sampled[2].w >= 4;
+    if (!regular) return kUseGeneralKernel;
+    ShadeParams P;
+    int diffuseBRDF, multi, tech;
+    bool aa;
+    if (int rc = shadeParamsFor(c, &P, &diffuseBRDF, &multi, &aa, &tech)) return rc;
+    if (tech != 0) return kUseGeneralKernel; // the shade does not read the upscaled images
+    // the shade must read exactly what the upscale writes, on the same pixel grid, the same depth buffer, over the same rows and whole rows
+    if (c.sampled[15].ptr != out.ptr || c.sampled[16].ptr != u.storage[1].ptr || c.sampled[15].w != out.w || c.sampled[15].h != out.h || P.color.w != out.w ||
+        P.color.h != out.h || c.sampled[20].ptr != u.sampled[4].ptr || c.sampled[21].w != out.w || c.sampled[21].h != out.h)
+        return kUseGeneralKernel;
+    const int uw = std::min((int)(u.dispatch[0] * 8u), out.w);
+    if (uw != out.w || P.coverW != out.w || ur.y0 != P.yBase || ur.y1 != P.coverH) return kUseGeneralKernel;
+    // uv is defined by the UBO's screen resolution (indirectLightUpscale.comp:19): the quad reasoning needs it to be the target size
+    if (c.global != u.global || !u.globalHost || u.globalHost->screenResolution[0] != out.w || u.globalHost->screenResolution[1] != out.h) return kUseGeneralKernel;
+    if (P.coverH <= P.yBase) return 0;
+    FusedUpscale U;
+    U.srcYSH = u.sampled[2]; U.srcCoCg = u.sampled[3]; U.halfResDepth = u.sampled[5]; U.dstYSH = u.storage[0]; U.dstCoCg = u.storage[1];
+    U.storeUpscaled = (u.elidableStorage & 3u) == 3u ? 0 : 1;
+    if (!U.storeUpscaled) u.elidedStorage = 3u;
+    FusedKernel k = nullptr;
+    switch (diffuseBRDF) {
+        case 0: k = pickFusedMulti<0>(multi, aa); break;
+        case 1: k = pickFusedMulti<1>(multi, aa); break;
+        case 2: k = pickFusedMulti<2>(multi, aa); break;
+        default: k = pickFusedMulti<3>(multi, aa); break;
+    }
+    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -514,6 +791,8 @@ static int launchBrdfLutFast(const PassCtx& c) {
 
 static int fastshade_launch(const PassCtx& c) { return fastshade::launchDeferredShadingFast(c); }
 PLR_REGISTER_SHADER_FAST("deferredShading.comp", fastshade_launch);
+static int fastshade_upscale_and_shade(const PassCtx* const* ctxs, size_t count) { return fastshade::launchUpscaleAndShade(ctxs, count); }
+PLR_REGISTER_FUSION_WITH_SIGNATURES("indirectLightUpscale + deferredShading", fastshade_upscale_and_shade, "indirectLightUpscale.comp", "deferredShading.comp");
 static int fastshade_brdf_lut(const PassCtx& c) { return fastshade::launchBrdfLutFast(c); }
 PLR_REGISTER_SHADER_FAST("brdfLut.comp", fastshade_brdf_lut);
 } // namespace plr

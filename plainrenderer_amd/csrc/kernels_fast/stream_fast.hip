@@ -9,6 +9,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "fused_gi.h"
+#include "upscale_quad.h"
 #include "../device/fastmath.h"
 
 namespace plr {
@@ -160,16 +161,6 @@ static int launchTonemapping(const PassCtx& c) {
 }
 
 // ------------------------------------------------------------------------------------------------ indirectLightUpscale.comp:17-71
-// linearizeDepth (shading_common.h) with the product and the sum rounded separately, as the shader compiler evaluates them: at far depths
-// far + (1 - d) * (near - far) cancels to ~far * d and the rounding of the product (half an ulp of far) moves the result by tenths of a
-// metre - the same size as the 0.5 m edge threshold and the differences the closest-texel choice compares. A fused multiply-add is more
-// accurate and therefore picks different texels; only the reciprocal stays approximate (1 ulp, 1e-4 m at 1 km).
-PLR_DI float linearDepthRounded(float d, float nf, float nmf, float farP) {
-#pragma clang fp contract(off)
-    const float t = (1.f - d) * nmf;
-    const float den = farP + t;
-    return nf * rcpf(den);
-}
 // bilinear footprint of an RGBA16F / RG16F / R16F image at (i0..i0+1, j0..j0+1) with clamp-to-edge, the two texels of a row in one load
 struct Pair8 { uint2 a, b; };
 PLR_DI Pair8 loadPairRGBA16F(const ImgView& im, int x0, int x1, int y) {
@@ -195,8 +186,11 @@ PLR_DI void loadPairRG16F(const ImgView& im, int x0, int x1, int y, uint32_t* a,
         *b = x1 == xb ? v.x : v.y;
     } else { *a = row[x0]; *b = row[x1]; }
 }
-PLR_DI vec4 halves4(uint2 t) { return vec4(halfBitsToFloat(t.x & 0xffffu), halfBitsToFloat(t.x >> 16), halfBitsToFloat(t.y & 0xffffu), halfBitsToFloat(t.y >> 16)); }
-PLR_DI vec2 halves2(uint32_t t) { return vec2(halfBitsToFloat(t & 0xffffu), halfBitsToFloat(t >> 16)); }
+using fastquad::halves2;
+using fastquad::halves4;
+using fastquad::linearDepthRounded;
+using fastquad::UpscaledQuad;
+using fastquad::upscaleQuad;
 
 struct Bilinear { int x0, x1, y0, y1; float a, b; };
 PLR_DI Bilinear bilinearCoords(const ImgView& im, float u, float v) {
@@ -287,14 +281,10 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView ds
     upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, px, py, sig);
 }
 
-// ---- 2x2 outputs per thread when the full-resolution image is exactly twice the half-resolution one.
-// A full-res pixel X = 2k + p samples the half-res images at k + 0.25 + 0.5 p: the gather / bilinear footprints of the four pixels
-// of a quad, and the texels their "closest depth" choice can select (uv + offset * halfResTexelSize lands on texel k + offset),
-// all lie in the 3x3 half-res neighbourhood (k-1 .. k+1) x (m-1 .. m+1). A thread loads that neighbourhood once (9 depths, 9 Y_SH,
-// 9 CoCg texels in 9 wide loads) and linearises each half-res depth once instead of four times.
+// ---- 2x2 outputs per thread when the full-resolution image is exactly twice the half-resolution one: upscaleQuad (upscale_quad.h, shared with
+// the fused upscale + deferred shade of shading_fast.hip)
 __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
                                                                       ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, uint32_t* __restrict__ sig) {
-#pragma clang fp contract(off)  // see upscalePixel
     const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     const int X = 2 * k, Y = 2 * m;
@@ -306,102 +296,22 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView ds
                 if (X + px < coverW && Y + py < coverH) upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, X + px, Y + py, sig);
         return;
     }
-    const int hw = srcYSH.w, hh = srcYSH.h;
-    const float nearP = g->nearPlane, farP = g->farPlane, nf = nearP * farP, nmf = nearP - farP;
-    auto linearize = [&](float d) { return linearDepthRounded(d, nf, nmf, farP); };
-    // 3x3 half-res neighbourhood with clamp-to-edge: N[r][c] = texel (clamp(k-1+c), clamp(m-1+r))
-    float hd[3][3];
-    uint2 ys[3][3];
-    uint32_t cc[3][3];
-    const bool interiorX = k >= 1 && k + 2 < hw; // a 4-texel wide load starting at k-1 stays inside the row
-    const uint16_t* hdp = (const uint16_t*)halfResDepthT.ptr;
-    const uint2* ysp = (const uint2*)srcYSH.ptr;
-    const uint32_t* ccp = (const uint32_t*)srcCoCg.ptr;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const size_t row = (size_t)clampi(m - 1 + r, hh) * (size_t)hw;
-        if (interiorX) {
-            uint2 d4;  // four half depths (8 bytes) starting at k-1
-            __builtin_memcpy(&d4, hdp + row + (k - 1), 8);
-            hd[r][0] = linearize(halfBitsToFloat(d4.x & 0xffffu)); hd[r][1] = linearize(halfBitsToFloat(d4.x >> 16)); hd[r][2] = linearize(halfBitsToFloat(d4.y & 0xffffu));
-            uint4 ya, cb;
-            uint2 yb;
-            __builtin_memcpy(&ya, ysp + row + (k - 1), 16);
-            yb = ysp[row + (k + 1)];
-            ys[r][0] = make_uint2(ya.x, ya.y); ys[r][1] = make_uint2(ya.z, ya.w); ys[r][2] = yb;
-            __builtin_memcpy(&cb, ccp + row + (k - 1), 16);
-            cc[r][0] = cb.x; cc[r][1] = cb.y; cc[r][2] = cb.z;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const size_t i = row + (size_t)clampi(k - 1 + c, hw);
-                hd[r][c] = linearize(halfBitsToFloat(hdp[i]));
-                ys[r][c] = ysp[i];
-                cc[r][c] = ccp[i];
-            }
-        }
-    }
-    // full-res depths of the quad (one 8-byte load per row when X + 1 exists)
-    float fd[2][2];
-#pragma unroll
-    for (int py = 0; py < 2; py++) {
-        const float* row = (const float*)fullResDepthT.ptr + (size_t)min(Y + py, fullResDepthT.h - 1) * (size_t)fullResDepthT.w;
-        if (X + 1 < fullResDepthT.w) { float2 v; __builtin_memcpy(&v, row + X, 8); fd[py][0] = linearize(v.x); fd[py][1] = linearize(v.y); }
-        else { fd[py][0] = linearize(row[X]); fd[py][1] = fd[py][0]; }
-    }
+    UpscaledQuad q;
+    upscaleQuad(srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, k, m, &q);
 #pragma unroll
     for (int py = 0; py < 2; py++) {
         if (Y + py >= coverH || Y + py < yBase) continue;
-        uint2 outY[2];
-        uint32_t outC[2];
-#pragma unroll
-        for (int px = 0; px < 2; px++) {
-            // footprint columns / rows inside the 3x3: parity 0 -> texels (k-1, k) with weight 0.75 on k-1's neighbour... a = 0.75; parity 1 -> (k, k+1), a = 0.25
-            const int c0 = px, r0 = py;           // index of texel i0 / j0 inside the neighbourhood
-            const float a = px ? 0.25f : 0.75f, b = py ? 0.25f : 0.75f;
-            const float full = fd[py][px];
-            // textureGather order: (i0, j1), (i1, j1), (i1, j0), (i0, j0)
-            const float ds[4] = {hd[r0 + 1][c0], hd[r0 + 1][c0 + 1], hd[r0][c0 + 1], hd[r0][c0]};
-            const int offx[4] = {0, 1, 1, 0}, offy[4] = {1, 1, 0, 0};
-            float minDiff = 1000.f;
-            int cx = 0, cy = 0;
-            bool isEdge = false;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float diff = fabsf(ds[i] - full);
-                isEdge = isEdge || diff > 0.5f;
-                if (diff < minDiff) { minDiff = diff; cx = offx[i]; cy = offy[i]; }
-            }
-            vec4 ysh;
-            vec2 co;
-            if (isEdge) {
-                // nearest texel at uv + offset * halfResTexelSize = half-res texel (k + cx, m + cy), clamped: neighbourhood index (1 + cx, 1 + cy)
-                const int nc = min(k + cx, hw - 1) - (k - 1), nr = min(m + cy, hh - 1) - (m - 1);
-                uint2 ty = ys[1][1];
-                uint32_t tc = cc[1][1];
-#pragma unroll
-                for (int r = 1; r < 3; r++)
-#pragma unroll
-                    for (int c = 1; c < 3; c++)
-                        if (r == nr && c == nc) { ty = ys[r][c]; tc = cc[r][c]; }
-                ysh = halves4(ty);
-                co = halves2(tc);
-            } else {
-                const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
-                ysh = halves4(ys[r0][c0]) * w00 + halves4(ys[r0][c0 + 1]) * w10 + halves4(ys[r0 + 1][c0]) * w01 + halves4(ys[r0 + 1][c0 + 1]) * w11;
-                co = halves2(cc[r0][c0]) * w00 + halves2(cc[r0][c0 + 1]) * w10 + halves2(cc[r0 + 1][c0]) * w01 + halves2(cc[r0 + 1][c0 + 1]) * w11;
-            }
-            outY[px] = make_uint2(floatToHalfBits(ysh.x) | (floatToHalfBits(ysh.y) << 16), floatToHalfBits(ysh.z) | (floatToHalfBits(ysh.w) << 16));
-            outC[px] = floatToHalfBits(co.x) | (floatToHalfBits(co.y) << 16);
-            if (sig && X + px < coverW) sig[(size_t)(Y + py) * (size_t)dstYSH.w + (size_t)(X + px)] = (isEdge ? 1u : 0u) | (cx ? 2u : 0u) | (cy ? 4u : 0u); // decision signature
-        }
         const size_t o = (size_t)(Y + py) * (size_t)dstYSH.w + X;
+        if (sig) {
+            sig[o] = q.sig[py][0];
+            if (X + 1 < coverW) sig[o + 1] = q.sig[py][1];
+        }
         if (X + 1 < coverW) {
-            *(uint4*)((uint2*)dstYSH.ptr + o) = make_uint4(outY[0].x, outY[0].y, outY[1].x, outY[1].y); // X even, even pitch: 16-byte aligned
-            *(uint2*)((uint32_t*)dstCoCg.ptr + o) = make_uint2(outC[0], outC[1]);
+            *(uint4*)((uint2*)dstYSH.ptr + o) = make_uint4(q.ysh[py][0].x, q.ysh[py][0].y, q.ysh[py][1].x, q.ysh[py][1].y); // X even, even pitch: 16-byte aligned
+            *(uint2*)((uint32_t*)dstCoCg.ptr + o) = make_uint2(q.cocg[py][0], q.cocg[py][1]);
         } else {
-            ((uint2*)dstYSH.ptr)[o] = outY[0];
-            ((uint32_t*)dstCoCg.ptr)[o] = outC[0];
+            ((uint2*)dstYSH.ptr)[o] = q.ysh[py][0];
+            ((uint32_t*)dstCoCg.ptr)[o] = q.cocg[py][0];
         }
     }
 }
@@ -500,9 +410,7 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
     if (PACK) packedOut[idx] = packGiTexel(py4, pc, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
 }
 
-static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack);
-static int launchTemporalGi(const PassCtx& c) { return launchTemporalGiImpl(c, nullptr); }
-static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack) {
+static int launchTemporalGi(const PassCtx& c) {
     if (int rc = c.needGlobal()) return rc;
     const int ysh[4] = {0, 2, 4, 6}, cocg[4] = {1, 3, 5, 7};
     for (int i = 0; i < 2; i++) {
@@ -526,16 +434,26 @@ static int launchTemporalGiImpl(const PassCtx& c, const SpatialPackTarget* pack)
     const int w = std::min((int)(c.dispatch[0] * 8u), out.w);
     if (w <= 0 || h <= y0) return 0;
     const dim3 grid(divUp((unsigned)w, 64u), (unsigned)blockRows);
+    // the spatial filter that reads the history output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
+    SpatialPackTarget packTarget;
+    const SpatialPackTarget* pack = spatialPackTargetOfConsumer(c, 2, 3, &packTarget) == 0 ? &packTarget : nullptr;
+    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32) || w != out.w)) pack = nullptr;
 #define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, \
                           pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
     if (pack) {
-        if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
         if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
-        else if (pack->depth.fmt == F_D32) temporalGiFilterFastKernel<F_D32><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
-        else return kUseGeneralKernel;
+        else temporalGiFilterFastKernel<F_D32><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
     } else temporalGiFilterFastKernel<0><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
 #undef PLR_TEMPORAL_ARGS
     PLR_CHECK_LAUNCH(c);
+    if (pack) {
+        // pixel rows of this launch: [y0, first range end) and, for a launch over two row ranges, the second range (twoRangeBlocks)
+        if (c.extraCountY) {
+            const PassCtx::RowSpan a = c.rowSpan(out.h, 8);
+            spatialNotePackedRows(c, a.y0, a.y1);
+            spatialNotePackedRows(c, std::min((int)c.extraBaseY * 8, (int)out.h), h);
+        } else spatialNotePackedRows(c, y0, h);
+    }
     return 0;
 }
 
@@ -563,7 +481,6 @@ static int launchApplyBloomTonemap(const PassCtx* const* ctxs, size_t count) {
 
 } // namespace faststream
 
-int launchTemporalGiFastPacking(const PassCtx& c, const SpatialPackTarget& target) { return faststream::launchTemporalGiImpl(c, &target); }
 // ---- probe: the PLR_MATH_FAST sky LUT lookup (device/fastmath.h) for n directions, same arguments as the oracle's orc_kat_sky_lut
 __global__ void skyLutEvalKernel(ImgView lut, const float* __restrict__ dirs, float* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

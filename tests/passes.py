@@ -608,6 +608,51 @@ def gpu_deferred_shading(be, gb, w, h, brdf_lut_u16, lut_res, light_bytes, shado
     return be.downloadImage(color, 0, np.uint32).copy()
 
 
+def gpu_upscale_and_shade(be, half_ysh, half_cocg, tw, th, half_depth_u16, gb, w, h, brdf_lut_u16, lut_res, light_bytes, shadow_info, shadow_maps, shadow_res, froxel_u16,
+                          froxel_dims, vol_settings, sky_packed, global_packed, diffuse_brdf=2, multiscatter=0, geometric_aa=True, cascades=3, download_upscaled=False):
+    """indirectLightUpscale.comp and the deferred shade recorded back to back, the shade sampling the images the upscale writes
+    (Techniques/SDFGI.cpp:510-535 followed by RenderFrontend.cpp:894-929): in PLR_MATH_FAST with pass fusion this is ONE launch
+    (kernels_fast/shading_fast.hip upscaleAndShadeQuadKernel). Returns the colour image (and the upscaled Y_SH / CoCg images if asked)."""
+    from plainrenderer_amd.backend import ImageDescription, ImageType, ImageUsageFlags
+    global_binding(be).set(global_packed)
+    mk = lambda fmt, data, ww=w, hh=h: be.createImage(image_desc_2d(ww, hh, fmt), np.ascontiguousarray(data))
+    s_y, s_c = mk(F.RGBA16_sFloat, half_ysh, tw, th), mk(F.RG16_sFloat, half_cocg, tw, th)
+    hd = mk(F.R16_sFloat, half_depth_u16, tw, th)
+    d_y, d_c = be.createImage(image_desc_2d(w, h, F.RGBA16_sFloat)), be.createImage(image_desc_2d(w, h, F.RG16_sFloat))
+    color = be.createImage(image_desc_2d(w, h, F.R11G11B10_uFloat))
+    depth, normal = mk(F.Depth32, np.ascontiguousarray(gb["depth"], np.float32)), mk(F.RGBA8, gb["normal"])
+    albedo, spec = mk(F.RGBA8, gb["albedo"]), mk(F.RGBA8, gb["specular"])
+    lut = mk(F.RGBA16_sFloat, brdf_lut_u16, lut_res, lut_res)
+    smaps = [mk(F.Depth16, m, shadow_res, shadow_res) for m in shadow_maps]
+    fw, fh, fd = froxel_dims
+    vol = be.createImage(ImageDescription(width=fw, height=fh, depth=fd, type=ImageType.Type3D, format=F.RGBA16_sFloat, usageFlags=int(ImageUsageFlags.Sampled)),
+                         np.ascontiguousarray(froxel_u16))
+    sky = mk(F.R11G11B10_uFloat, sky_packed, 200, 100)
+    light = be.createStorageBuffer(20, light_bytes)
+    sinfo = be.createStorageBuffer(304, shadow_info)
+    vset = be.createUniformBuffer(64, vol_settings)
+    pu = be.createComputePass("indirectLightUpscale.comp", [], "Indirect lighting upscale")
+    ps = be.createComputePass("deferredShading.comp", [spec_int(0, diffuse_brdf), spec_int(1, multiscatter), spec_bool(2, geometric_aa), spec_int(3, 0), spec_uint(4, cascades)],
+                              "Forward shading (deferred)")
+    be.newFrame()
+    groups = (math.ceil(w / 8.0), math.ceil(h / 8.0), 1)
+    be.setComputePassExecution(ComputePassExecution(pu, RenderPassResources(
+        storageImages=[ImageResource(d_y, 0, 0), ImageResource(d_c, 0, 1)],
+        sampledImages=[ImageResource(s_y, 0, 2), ImageResource(s_c, 0, 3), ImageResource(depth, 0, 4), ImageResource(hd, 0, 5)]), b"", groups))
+    sampled = [ImageResource(lut, 0, 3), ImageResource(d_y, 0, 15), ImageResource(d_c, 0, 16), ImageResource(vol, 0, 18), ImageResource(depth, 0, 20),
+               ImageResource(normal, 0, 21), ImageResource(albedo, 0, 22), ImageResource(spec, 0, 23), ImageResource(sky, 0, 24)]
+    sampled += [ImageResource(smaps[i], 0, 9 + i) for i in range(4)]
+    be.setComputePassExecution(ComputePassExecution(ps, RenderPassResources(
+        storageImages=[ImageResource(color, 0, 0)], sampledImages=sampled,
+        storageBuffers=[StorageBufferResource(light, True, 7), StorageBufferResource(sinfo, True, 8)],
+        uniformBuffers=[UniformBufferResource(vset, 19)]), b"", groups))
+    be.renderFrame()
+    out = be.downloadImage(color, 0, np.uint32).copy()
+    if download_upscaled:
+        return out, be.downloadImage(d_y, 0, np.uint16).copy(), be.downloadImage(d_c, 0, np.uint16).copy()
+    return out
+
+
 def orc_deferred_shading(gb, w, h, brdf_lut_u16, lut_res, light_bytes, shadow_info, shadow_maps, shadow_res, ysh_u16, cocg_u16, froxel_u16, froxel_dims, vol_settings,
                          sky_packed, global_packed, bindless_arr, n_bindless, diffuse_brdf=2, multiscatter=0, geometric_aa=True, indirect_tech=0, cascades=3):
     L = orc.lib()

@@ -1,5 +1,7 @@
 """Pass fusion (include/plr.h plr_set_pass_fusion, csrc/backend.h): the backend covers certain ADJACENT recorded executions with fewer kernel
-launches. The boundary and the results are unchanged: every frame of a fused run equals the unfused run byte for byte."""
+launches. The boundary and the results are unchanged: every frame of a fused run equals the unfused run byte for byte. At level 2 (the default)
+the fused upscale + deferred shade keeps the upscaled GI texels in registers when no other pass reads them: those two images are then not
+written, a download of them fails loudly, and everything else still equals the unfused run."""
 import numpy as np
 import pytest
 
@@ -20,7 +22,7 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
     results, fused_counts = {}, {}
     try:
         backend.setMathMode(True)
-        for fusion in (True, False):
+        for fusion in (2, 1, 0):
             backend.setPassFusion(fusion)
             fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64, sdf_half_res_trace=half_res)
             if inputs is None:
@@ -34,19 +36,28 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
                 fused_counts[fusion] = fused
                 names = ["swapchain", "post1", "giYSH0", "giCoCg1", "giHistoryYSH0", "giHistoryYSH1", "giHistoryCoCg0", "giFullResYSH", "pyramid", "depthHalfRes", "taaHistory0",
                          "taaHistory1"]
+                if fusion == 2:
+                    if half_res:  # the half-res trace has an upscale pass: its output is consumed inside the fused upscale + shade launch
+                        with pytest.raises(RuntimeError, match="not written in the last frame"):
+                            backend.downloadImage(fp.image("giFullResYSH"), 0, np.uint8)
+                    names = [n for n in names if n != "giFullResYSH"]
                 imgs = [backend.downloadImage(fp.image(name), 0, np.uint8).copy() for name in names]
                 out.append(imgs + [backend.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).copy(),
                                    backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint8).copy()])
             results[fusion] = (out, names + ["light buffer", "histogram"])
             fp.destroy()
     finally:
-        backend.setPassFusion(True)
+        backend.setPassFusion(2)
         backend.setMathMode(False)
-    assert fused_counts[False] == 0
-    assert fused_counts[True] >= 6, "executions inside fused launches: %d" % fused_counts[True]
-    for f in range(n_frames):
-        for a, b, what in zip(results[True][0][f], results[False][0][f], results[True][1]):
-            assert np.array_equal(a, b), "%s differs with pass fusion, frame %d (%dx%d)" % (what, f, w, h)
+    assert fused_counts[0] == 0
+    assert fused_counts[1] >= 6, "executions inside fused launches: %d" % fused_counts[1]
+    assert fused_counts[2] == fused_counts[1]
+    if half_res: assert fused_counts[1] >= 8, "the upscale + deferred shade pair is fused when the trace runs at half resolution"
+    for level in (1, 2):
+        for f in range(n_frames):
+            unfused = dict(zip(results[0][1], results[0][0][f]))
+            for a, what in zip(results[level][0][f], results[level][1]):
+                assert np.array_equal(a, unfused[what]), "%s differs with pass fusion level %d, frame %d (%dx%d)" % (what, level, f, w, h)
 
 
 @pytest.mark.gpu
@@ -60,5 +71,47 @@ def test_gpu_fusion_is_off_in_exact_mode_and_when_a_callback_separates_the_passe
     fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=8, max_sdf_instances=64)
     SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45)).upload(fp)
     fp.frame(cams[1], 1.0 / 60.0, 0.5)
-    assert backend.getPassFusion() == (True, 0)
+    assert backend.getPassFusion() == (2, 0)
     fp.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1280, 720), (648, 360)])
+def test_gpu_async_frame_tail_changes_nothing_but_the_schedule(backend, w, h):
+    """plr_compute_pass_execution::async_tail (include/plr.h): the C++ FramePipeline flags the bloom chain + tonemap, the backend runs them on a second
+    stream beside the NEXT frame's exposure / GI / shade passes and orders the two by the images they touch. Six frames of temporal feedback with the
+    tail asynchronous equal the in-order run byte for byte - downloads in between (which join the tail) and at the end only."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    n_frames = 6
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=512)
+    names = ["swapchain", "post1", "giHistoryYSH0", "taaHistory0", "taaHistory1", "color0", "color1"]
+    inputs, results = None, {}
+    try:
+        backend.setMathMode(True)
+        for mode in ("async", "async, no host sync between frames", "in order"):
+            backend.setAsyncTail(mode != "in order")
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                enabled, n_async = backend.getAsyncTail()
+                assert enabled == (mode != "in order")
+                # 5 downsamples + 5 upsamples + apply + tonemap
+                assert n_async == (12 if enabled else 0), "executions on the tail stream: %d" % n_async
+                if mode != "async, no host sync between frames" or f == n_frames - 1:
+                    out.append([backend.downloadImage(fp.image(name), 0, np.uint8).copy() for name in names] +
+                               [backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint8).copy()])
+            results[mode] = out
+            fp.destroy()
+    finally:
+        backend.setAsyncTail(True)
+        backend.setMathMode(False)
+    for f in range(n_frames):
+        for a, b, what in zip(results["async"][f], results["in order"][f], names + ["histogram"]):
+            assert np.array_equal(a, b), "%s differs with the asynchronous tail, frame %d" % (what, f)
+    for a, b, what in zip(results["async, no host sync between frames"][0], results["in order"][-1], names + ["histogram"]):
+        assert np.array_equal(a, b), "%s differs after %d back-to-back frames with the asynchronous tail" % (what, n_frames)

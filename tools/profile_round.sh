@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the per-round evidence under gpurun_out/prof_$1: kernel-trace stats of the default bench, then FETCH_SIZE and WRITE_SIZE
-# (separate PMC passes, plr:: kernels only). Usage on the GPU box:  bash tools/profile_round.sh r01b
+# (separate PMC passes, plr:: kernels only), the other frame sizes, and the parity / config-5 / band-cost reports of the SAME build. Usage on the GPU box:  bash tools/profile_round.sh r01b
 set -u
 TAG=${1:-r01}
 REPO=$(pwd)
@@ -22,4 +22,16 @@ python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --pass-table 2> $O
 python $REPO/bench.py --width 1920 --height 1080 --no-cpu-baseline > $OUT/bench_1080p.json 2>> $OUT/bench.err
 python $REPO/bench.py --width 7680 --height 4320 --steps 150 --no-cpu-baseline > $OUT/bench_8k.json 2>> $OUT/bench.err
 rm -rf $OUT/kt
+# ---- parity evidence FROM THIS BUILD: the full-size suite at the benchmarked size, config 5 at 8K, the band cost table; every
+# report carries the kernel source digest the PMC summary was stamped with, and the run fails if the sources changed in between
+DIGEST=$(cat $OUT/source_digest.txt)
+cd $REPO
+{ echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_parity_fullsize.py -m gpu -s   (3840x2160, 256 x 64^3: bench.py's scene)";
+  python -m pytest tests/test_parity_fullsize.py -m gpu -q -s 2>&1 | grep -E "^\.?PARITY|passed|failed" | sed 's/^\.//'; } > $OUT/parity_4k.txt
+{ echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_config5_8k.py -m gpu -s   (7680x4320 in 4 bands on one GPU vs the unpartitioned frame and the oracle)";
+  python -m pytest tests/test_config5_8k.py -m gpu -q -s 2>&1 | grep -E "CONFIG5|passed|failed"; } > $OUT/config5_8k.txt
+{ echo "# kernel source digest: $DIGEST"; python tools/band_cost.py 4 --passes --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/band_cost.txt
+NOW=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())")
+if [ "$NOW" != "$DIGEST" ]; then echo "kernel sources changed during the profile run ($DIGEST -> $NOW): evidence is inconsistent" >&2; exit 1; fi
+grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt && { echo "parity suite failed" >&2; exit 1; }
 ls -la $OUT
