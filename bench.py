@@ -66,13 +66,17 @@ def algorithmic_bytes(w, h, n_instances, sdf_res, shadow_res, brdf_res, froxel_d
     return b, frame
 
 
-INPUT_HALO = 256  # full-res rows of G-buffer a band needs beyond its own: 2 * (giHalo + giHistoryHalo) + 16 = 176 for the half-res depth
+def input_halo(height):
+    """full-res rows of G-buffer a band needs beyond its own: 2 * (giHalo + giHistoryHalo) + 16 for the half-res depth (giHalo = 64 trace rows per 2160
+    rows of frame height, plrf_default_settings), one more 64-row tile for the per-tile depth pyramid; rounded up to 128"""
+    gi = 64 * ((height + 2159) // 2160)
+    return ((2 * (gi + 16) + 16 + 64 + 127) // 128) * 128
 
 
 PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries under profiles/ (a pass may launch more than one kernel)
     "Indirect diffuse spatial filter": ["plr::spatialFilter"], "Indirect diffuse spatial filter (texel packing)": ["plr::spatialPack"], "Forward shading (deferred)": ["plr::fastshade::deferredShading"],
     "Temporal filtering": ["plr::fasttaa::temporalFilter"], "Indirect diffuse SDF trace": ["plr::fasttrace::sdfDiffuseTrace"],
-    "Indirect lighting upscale": ["plr::faststream::indirectLightUpscale"], "Indirect diffuse temporal filter": ["plr::faststream::temporalGiFilter"],
+    "Indirect lighting upscale": ["plr::faststream::indirectLightUpscale"], "Indirect lighting upscale + Forward shading (deferred)": ["plr::fastshade::upscaleAndShade"], "Indirect diffuse temporal filter": ["plr::faststream::temporalGiFilter"],
     "Depth min/max pyramid": ["plr::hizBase", "plr::hizTail"], "Tonemap": ["plr::faststream::tonemapping"], "Apply bloom": ["plr::faststream::applyBloom"],
     "Histogram per tile": ["plr::fasthist::histogramPerTile"], "Apply bloom + Tonemap": ["plr::faststream::applyBloomTonemap"],
     "Histogram per tile + Histogram reset + Histogram combine tiles + Pre-expose lights + Depth min/max pyramid + Depth downscale": ["plr::fasthist::histogramAndPyramid", "plr::exposureChainAndPyramidTail"],
@@ -133,7 +137,7 @@ def build_scene(args, device, w, h, band=None):
         n, f = cams[1].near, cams[1].far
         lin = n * f / (f + (1.0 - vis) * (n - f)) if vis.size else np.array([1.0, 50.0])
         depth_range = (float(lin.min()), float(lin.max()))
-        rows = (max(band[0] - INPUT_HALO, 0), min(band[1] + INPUT_HALO, h))
+        rows = (max(band[0] - input_halo(h), 0), min(band[1] + input_halo(h), h))
     inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=args.sdf_res, shadow_res=args.shadow_res, froxel_depth=64, sun_direction=(0.35, -0.8, 0.45),
                              rows=rows, depth_range=depth_range)
     return scene, cams, inputs
@@ -399,9 +403,17 @@ def main():
     bh = h if band is None else band[1] - band[0]
     bytes_per_pass, frame_bytes = algorithmic_bytes(w, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
     def pass_bytes(name):
-        # a fused launch (pass fusion, include/plr.h) is reported as "A + B": its compulsory traffic is the sum of its passes', minus nothing -
-        # an image one pass writes and the next reads back still has to be written (it is an output of the boundary), only the re-read is saved
-        return sum(bytes_per_pass.get(part, 0.0) for part in name.split(" + "))
+        # a fused launch (pass fusion, include/plr.h) is reported as "A + B": its compulsory traffic is the sum of its passes' - an image one pass
+        # writes and the next reads back still has to be written (it is an output of the boundary). Two exceptions: "X + X" is ONE pass over two
+        # row ranges (band rendering), counted once; and the fused upscale + shade at fusion level 2 neither writes nor re-reads the upscaled GI
+        # images (12 B/px each way) and reads the depth buffer once instead of twice (4 B/px)
+        parts = name.split(" + ")
+        if len(parts) == 2 and parts[0] == parts[1]:
+            parts = parts[:1]
+        total = sum(bytes_per_pass.get(part, 0.0) for part in parts)
+        if parts == ["Indirect lighting upscale", "Forward shading (deferred)"] and be.getPassFusion()[0] >= 2:
+            total -= 28.0 * w * h
+        return total
     table = []
     for name, v in pass_ms.items():
         launches = len(v) / args.profile_frames

@@ -148,6 +148,10 @@ int plr_new_frame(void);
 int plr_set_compute_pass_execution(const plr_compute_pass_execution* execution);
 /* extension: see plr_host_callback; name is the label reported by plr_get_renderpass_timings */
 int plr_set_host_callback_execution(plr_host_callback callback, void* user, const char* name);
+/* the same, with the images and storage buffers the callback's work reads or writes (a halo exchange knows its images): the frame's asynchronous tail
+ * (async_tail above) then waits for the callback only if it shares one of them, instead of always. n_images = n_buffers = 0: touches nothing. */
+int plr_set_host_callback_execution_on(plr_host_callback callback, void* user, const char* name, const plr_image_handle* images, uint32_t n_images,
+                                       const plr_storage_buffer_handle* buffers, uint32_t n_buffers);
 /* RenderBackend::prepareForDrawcallRecording, RenderBackend.h:59: resolves transient images, validates bindings */
 int plr_prepare_for_drawcall_recording(void);
 /* RenderBackend::setUniformBufferData / setStorageBufferData, RenderBackend.h:64-70:

@@ -158,6 +158,14 @@ public:
         check(plr_set_compute_pass_execution(&e));
     }
     void setHostCallbackExecution(plr_host_callback callback, void* user, const char* name) { check(plr_set_host_callback_execution(callback, user, name)); }
+    // with the resources the callback's work touches (plr.h plr_set_host_callback_execution_on)
+    void setHostCallbackExecution(plr_host_callback callback, void* user, const char* name, const std::vector<ImageHandle>& images, const std::vector<StorageBufferHandle>& buffers) {
+        std::vector<plr_image_handle> im;
+        std::vector<plr_storage_buffer_handle> sb;
+        for (const auto& i : images) im.push_back(toC(i));
+        for (const auto& b : buffers) sb.push_back(b.index);
+        check(plr_set_host_callback_execution_on(callback, user, name, im.data(), (uint32_t)im.size(), sb.data(), (uint32_t)sb.size()));
+    }
     void getImageDevicePointer(const ImageHandle image, uint32_t mipLevel, void** outPtr, size_t* outSize) { check(plr_get_image_device_pointer(toC(image), mipLevel, outPtr, outSize)); }
     void prepareForDrawcallRecording() { check(plr_prepare_for_drawcall_recording()); }
     void setUniformBufferData(const UniformBufferHandle buffer, const void* data, const size_t size) { check(plr_set_uniform_buffer_data(buffer.index, data, size)); }

@@ -31,6 +31,14 @@ FLAGS = [
 ]
 
 
+def _rocm_lib_dir():
+    """where librccl lives: $ROCM_PATH/lib, else the lib directory next to the hipcc in use, else /opt/rocm/lib"""
+    for root in (os.environ.get("ROCM_PATH"), os.path.dirname(os.path.dirname(os.path.realpath(HIPCC)))):
+        if root and os.path.exists(os.path.join(root, "lib", "librccl.so")):
+            return os.path.join(root, "lib")
+    return "/opt/rocm/lib"
+
+
 def _sources():
     out = [os.path.join(CSRC, "backend.cpp")]
     for sub in ("kernels", "kernels_fast", "frontend"):
@@ -96,7 +104,7 @@ def build(verbose=False, jobs=None):
     changed = any(c for _, c in results)
     if changed or not os.path.exists(LIB_PATH):
         # librccl: the band exchange of the C++ host (csrc/frontend/band_exchange.cpp) calls ncclSend / ncclRecv / ncclAllReduce directly
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-L" + _rocm_lib_dir(), "-lrccl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <atomic>
 #include <set>
 #include <cmath>
 #include <cstring>
@@ -203,6 +204,7 @@ struct Execution {
     void* callbackUser = nullptr;
     const char* callbackName = ""; // interned in Backend::callbackNames
     bool asyncTail = false;        // plr_compute_pass_execution::async_tail
+    bool callbackAccessKnown = false; // host callback recorded with its resource list (plr_set_host_callback_execution_on): `access` is complete
 };
 
 struct FillOrder {
@@ -274,10 +276,24 @@ struct Backend {
     std::set<std::string> fusedNames;    // stable storage for the timing labels of fused launches
 };
 
-// one backend per host thread: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
-// uses one thread per backend
+// A thread that calls plr_setup owns its backend: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
+// uses one thread per backend. A thread that never called plr_setup ADOPTS the process's first backend - the reference's single process-global
+// gRenderBackend (RenderBackend.cpp:39): a host that sets up on one thread and records from a worker thread works as it does there (calls must
+// not overlap in time, as in the reference). The adoption ends when that backend is shut down (epoch check).
 static thread_local Backend* g = nullptr;
 static thread_local std::string g_err;
+static thread_local bool g_adopted = false;
+static thread_local uint64_t g_adoptedEpoch = 0;
+static std::atomic<Backend*> g_first{nullptr};
+static std::atomic<uint64_t> g_firstEpoch{0};
+static bool resolveBackend() {
+    if (g && g_adopted && g_adoptedEpoch != g_firstEpoch.load()) { g = nullptr; g_adopted = false; }
+    if (!g) {
+        Backend* first = g_first.load();
+        if (first) { g = first; g_adopted = true; g_adoptedEpoch = g_firstEpoch.load(); }
+    }
+    return g != nullptr;
+}
 
 static int setErr(int code, const std::string& msg) { g_err = msg; return code; }
 int setLastError(int code, const std::string& msg) { return setErr(code, msg); }
@@ -287,7 +303,7 @@ int setLastError(int code, const std::string& msg) { return setErr(code, msg); }
         if (e_ != hipSuccess) return setErr(PLR_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 #define NEED_INIT() \
-    if (!g) return setErr(PLR_ERR_NOT_INITIALISED, "plr_setup has not been called")
+    if (!resolveBackend()) return setErr(PLR_ERR_NOT_INITIALISED, "plr_setup has not been called")
 // entry points that read or write device memory, or wait for the GPU, from the host: the asynchronous frame tail has to be behind them
 static int joinAsyncTail();
 #define NEED_INIT_JOINED() \
@@ -430,6 +446,7 @@ extern "C" {
 const char* plr_last_error(void) { return g_err.c_str(); }
 
 int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
+    if (g && g_adopted) { g = nullptr; g_adopted = false; } // a thread that had adopted the process's first backend now gets its own
     if (g) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_setup called twice; call plr_shutdown first");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -438,6 +455,10 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     if (device_ordinal < 0 || device_ordinal >= count) return setErr(PLR_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
     g = new Backend();
+    {
+        Backend* none = nullptr;
+        g_first.compare_exchange_strong(none, g); // the process's first backend: what threads without a backend of their own use
+    }
     g->device = device_ordinal;
     HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g->frameStart));
@@ -455,7 +476,8 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
 }
 
 int plr_shutdown(void) {
-    if (!g) return PLR_OK;
+    if (!resolveBackend()) return PLR_OK;
+    if (g_adopted) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_shutdown: this thread uses the backend another thread set up; that thread shuts it down");
     hipSetDevice(g->device);
     hipDeviceSynchronize();
     g->tailPending.clear();
@@ -477,8 +499,13 @@ int plr_shutdown(void) {
     if (g->pinned) hipHostFree(g->pinned);
     hipEventDestroy(g->frameStart); hipEventDestroy(g->frameEnd); hipEventDestroy(g->pinnedFree);
     hipStreamDestroy(g->stream);
+    {
+        Backend* mine = g;
+        if (g_first.compare_exchange_strong(mine, nullptr)) g_firstEpoch++; // adopters let go at their next call
+    }
     delete g;
     g = nullptr;
+    g_adopted = false;
     return PLR_OK;
 }
 
@@ -614,6 +641,20 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
         if (writesDefaultImage) x.access.push_back({kBindlessKey, true});
     }
     if (e->dispatch_base[2] != 0) { g->executions.pop_back(); return setErr(PLR_ERR_INVALID_ARGUMENT, "dispatch_base[2] must be 0"); }
+    return PLR_OK;
+}
+
+int plr_set_host_callback_execution_on(plr_host_callback callback, void* user, const char* name, const plr_image_handle* images, uint32_t n_images,
+                                       const plr_storage_buffer_handle* buffers, uint32_t n_buffers) {
+    NEED_INIT();
+    if ((n_images && !images) || (n_buffers && !buffers)) return setErr(PLR_ERR_INVALID_ARGUMENT, "null resource list");
+    for (uint32_t i = 0; i < n_images; i++) if (!resolveImage(images[i])) return setErr(PLR_ERR_INVALID_ARGUMENT, "host callback: invalid image handle");
+    for (uint32_t i = 0; i < n_buffers; i++) if (buffers[i] >= g->sbufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "host callback: invalid storage buffer handle");
+    if (int rc = plr_set_host_callback_execution(callback, user, name)) return rc;
+    Execution& x = g->executions.back();
+    x.callbackAccessKnown = true;
+    for (uint32_t i = 0; i < n_images; i++) x.access.push_back({resolveImage(images[i])->dev, true});
+    for (uint32_t i = 0; i < n_buffers; i++) x.access.push_back({g->sbufs[buffers[i]].dev, true});
     return PLR_OK;
 }
 
@@ -1062,9 +1103,12 @@ static int launchAll(bool timed) {
         Execution& x = g->executions[i];
         if (x.callback) {
             // everything before a callback has joined the main stream (end of the previous run)
-            // a host callback may touch anything (halo exchange on raw pointers): the asynchronous tail joins first
-            if (int rc = closeTail()) return rc;
-            if (int rc = joinAsyncTail()) return rc;
+            // a host callback may touch anything (halo exchange on raw pointers): the asynchronous tail joins first - unless the callback was
+            // recorded with the resources it touches and shares none with the tail
+            if (!x.callbackAccessKnown || hazardWithTail(x.access)) {
+                if (int rc = closeTail()) return rc;
+                if (int rc = joinAsyncTail()) return rc;
+            }
             tailOpen = false;
             g->curStream = g->stream;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;

@@ -1106,7 +1106,13 @@ int FramePipeline::exchangeTrampoline(void* user, void* stream) {
 void FramePipeline::exchangePoint(int id, const char* label) {
     // id may carry a phase (ExchangeBegin / ExchangeEnd)
     const int phase = (id & ExchangeBegin) ? 1 : ((id & ExchangeEnd) ? 2 : 0);
-    if (m_exchangeFn) m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[phase * ExchangeCount + (id & ExchangeIdMask)], label);
+    if (!m_exchangeFn) return;
+    // what the exchange moves: the registered images' halo rows, or the histogram buffer (the backend orders the frame's asynchronous tail by it)
+    std::vector<ImageHandle> images;
+    std::vector<StorageBufferHandle> buffers;
+    if ((id & ExchangeIdMask) == ExchangeHistogram) buffers.push_back(m_histogramBuffer);
+    else for (const ExchangeItem& it : m_exchangeItems[id & ExchangeIdMask]) images.push_back(it.image);
+    m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[phase * ExchangeCount + (id & ExchangeIdMask)], label, images, buffers);
 }
 
 void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
@@ -1240,8 +1246,8 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
         }
     }
     // the bloom chain and the tonemap are the frame's asynchronous tail (plr.h async_tail): nothing reads their outputs before the next frame's TAA
-    // resolve, and their ten short launches leave the chip mostly idle - they run beside the next frame's exposure / GI / shade passes. Not in band
-    // rendering: the exchange callbacks of the next frame join the tail before it could overlap anything.
+    // resolve, and their ten short launches leave the chip mostly idle - they run beside the next frame's exposure / GI / shade passes. In band
+    // rendering too: the exchange callbacks are recorded with the images they move (exchangePoint), and only the resolved-colour exchange shares one.
     if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0), asyncPostTail());
     if (settings.runTonemap) computeTonemapping(currentSrc);
 }

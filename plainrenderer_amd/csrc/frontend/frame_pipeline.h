@@ -74,6 +74,8 @@ struct BandSettings {
     // Off: one callback per exchange point (start and wait), the producer in one dispatch.
     bool overlapExchange = true;
     bool enabled() const { return rowEnd > rowBegin; }
+    // default giHalo for a frame of `height` rows: 64 trace rows per 2160 rows of frame height (plrf_default_settings)
+    static uint32_t giHaloForHeight(uint32_t height) { return 64u * ((height + 2159u) / 2160u); }
 };
 // phase bits or-ed into the exchange id a callback receives (0: start the exchange and wait for it)
 enum ExchangePhase : int { ExchangeBegin = 0x100, ExchangeEnd = 0x200, ExchangeIdMask = 0xff };
@@ -290,7 +292,7 @@ private:
     void downscaleDepth(const FrameRenderTargets& currentTarget);
     void computeDeferredShading(ImageHandle colorTarget, const FrameRenderTargets& current);
     void computeTonemapping(ImageHandle src);
-    bool asyncPostTail() const { return !settings.band.enabled(); } // bloom chain + tonemap as the frame's asynchronous tail (plr.h async_tail)
+    bool asyncPostTail() const { return true; } // bloom chain + tonemap as the frame's asynchronous tail (plr.h async_tail)
     void computeBRDFLut();
     void computeSunLightMatrices();
     void updateTransmissionLut();

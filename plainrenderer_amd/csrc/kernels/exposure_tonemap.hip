@@ -408,12 +408,9 @@ static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
     return 0;
 }
 int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream) {
-    static bool ldsRaised = false;
-    if (!ldsRaised) {
-        if (hipFuncSetAttribute((const void*)exposureChainAndPyramidTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
-            return setLastError(-2, "exposure chain + pyramid tail: cannot raise the dynamic LDS limit");
-        ldsRaised = true;
-    }
+    // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
+    if (hipFuncSetAttribute((const void*)exposureChainAndPyramidTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+        return setLastError(-2, "exposure chain + pyramid tail: cannot raise the dynamic LDS limit");
     exposureChainAndPyramidTailKernel<<<e.blocks + 1u, 1024, h.tailLdsBytes, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
                                                                                         e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst, h.tailTexelsA);
     const hipError_t err = hipGetLastError();

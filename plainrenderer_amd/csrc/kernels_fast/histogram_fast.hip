@@ -9,6 +9,7 @@
 // The luminance itself (dot product, division by the previous exposure) keeps the shader's IEEE operation sequence, hence:
 // PLR_BUILD_FLAGS: -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 #include "../backend.h"
+#include <map>
 #include "../device/shading_common.h"
 #include "../../../include/plr.h"
 #include "fused_front.h"
@@ -133,11 +134,21 @@ static int prepare(const PassCtx& c, HistParams* out) {
     const uint32_t tilesX = divUp((unsigned)src.w, 32u), tilesY = divUp((unsigned)src.h, 32u);
     if (c.sbuf[0].size < (size_t)tilesX * tilesY * nBins * 4u || c.sbuf[3].size < sizeof(LightBuffer)) return kUseGeneralKernel;
     const PassCtx::RowSpan rs = c.rowSpan((int)tilesY, 1);
-    // per-pass scratch: the threshold table (built on the first launch: the specialisation constants of a pass never change)
-    const bool fresh = c.scratchSize && *c.scratchSize < kBins * 4u;
+    // per-pass scratch: the threshold table, keyed on (memory, minL, maxL) and marked valid only once its launch succeeded: a failed launch or a pass
+    // re-created with another luminance range rebuilds it instead of binning against a zero / stale table. The "guess is at most one bin off"
+    // property is verified for every float for the reference's range only (plr_debug_verify_histogram_thresholds): other ranges take the general kernel
+    if (minL != 0.001f || maxL != 200000.f) return kUseGeneralKernel;
+    const bool fresh = c.scratchSize && *c.scratchSize < kBins * 4u; // about to be allocated (zero-filled): whatever the map says about this address is history
     uint32_t* thresholds = (uint32_t*)c.scratch(kBins * 4u);
     if (!thresholds) return c.fail(-2, "histogramPerTile: cannot allocate scratch memory");
-    if (fresh) if (launchHistogramThresholds(thresholds, kBins, minL, maxL, c.stream)) return c.fail(-2, "histogramPerTile: threshold table launch failed");
+    static thread_local std::map<const void*, TableKey> built; // scratch memory -> what it holds (one backend per host thread)
+    TableKey& key = built[(const void*)thresholds];
+    if (fresh) key.valid = 0u;
+    if (!key.valid || key.minL != minL || key.maxL != maxL) {
+        key.valid = 0u;
+        if (launchHistogramThresholds(thresholds, kBins, minL, maxL, c.stream)) return c.fail(-2, "histogramPerTile: threshold table launch failed");
+        key.minL = minL; key.maxL = maxL; key.valid = 1u;
+    }
     // guess = (log2(l) * ln2 - log(min)) / (log(max) - log(min)) * 127
     const double logMin = std::log((double)minL), range = std::log((double)maxL) - logMin;
     out->src = src; out->light = (const LightBuffer*)c.sbuf[3].ptr; out->perTile = (uint32_t*)c.sbuf[0].ptr; out->thresholds = thresholds;

@@ -100,11 +100,8 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
 static int launchImpl(const PassCtx& c, const PassCtx* down) {
     Plan plan;
     if (int rc = prepare(c, down, &plan)) return rc;
-    static bool ldsRaised = false;
-    if (!ldsRaised) {
-        if (hipFuncSetAttribute((const void*)hizTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return kUseGeneralKernel;
-        ldsRaised = true;
-    }
+    // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
+    if (!plan.perTile && hipFuncSetAttribute((const void*)hizTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return kUseGeneralKernel;
     const dim3 grid((unsigned)plan.gridX, (unsigned)plan.gridY);
     if (down) hizQuadKernel<4, true><<<grid, 256, 0, c.stream>>>(plan.quad);
     else hizQuadKernel<4, false><<<grid, 256, 0, c.stream>>>(plan.quad);

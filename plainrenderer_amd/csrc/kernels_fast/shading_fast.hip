@@ -489,13 +489,25 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
         e.co = halfBitsToFloat(cc & 0xffffu); e.cg = halfBitsToFloat(cc >> 16); e.pad = 0.f;
         tile[r][c] = e;
     }
-    __syncthreads();
+    // the pixel's own G-buffer texels and its view ray do not depend on the tile: their loads are in flight while the tile is being staged
     const int px = X0 + (t & 63), py = Y0 + (t >> 6);
-    if (px >= P.coverW || py >= P.coverH) return;
-    const ViewRay vr = exactViewRay(g, px, py);
-    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
+    const bool covered = px < P.coverW && py < P.coverH;
+    const int cpx = covered ? px : 0, cpy = covered ? py : 0;
+    const uint32_t idx = fastm::texelIndex((uint32_t)cpx, (uint32_t)cpy, (uint32_t)P.color.w);
     PixelInputs in;
     in.depth = ((const float*)P.depth.ptr)[idx];
+    in.albedo = ((const uint32_t*)P.albedo.ptr)[idx];
+    in.specular = ((const uint32_t*)P.specular.ptr)[idx];
+    const uint32_t* normals = (const uint32_t*)P.normal.ptr;
+    in.normal = normals[idx]; // the launcher guarantees the normal image has the colour target's size
+    in.normalH = in.normalV = in.normal;
+    if (GEOMETRIC_AA) {
+        in.normalH = normals[fastm::texelIndex((uint32_t)clampi(cpx ^ 1, P.normal.w), (uint32_t)cpy, (uint32_t)P.normal.w)];
+        in.normalV = normals[fastm::texelIndex((uint32_t)cpx, (uint32_t)clampi(cpy ^ 1, P.normal.h), (uint32_t)P.normal.w)];
+    }
+    const ViewRay vr = exactViewRay(g, cpx, cpy);
+    __syncthreads();
+    if (!covered) return;
     // ---- the pixel's upscaled GI texel: upscaleQuad's statements for pixel (parity p, q) of quad (k, m) (upscale_quad.h)
     uint32_t upSig;
     {
@@ -542,15 +554,6 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
         ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(fastm::sampleSkyLut(-vr.Vn, P.skyLut));
         if (P.sig) P.sig[idx] = 128u | (upSig << 8);
         return;
-    }
-    in.albedo = ((const uint32_t*)P.albedo.ptr)[idx];
-    in.specular = ((const uint32_t*)P.specular.ptr)[idx];
-    const uint32_t* normals = (const uint32_t*)P.normal.ptr;
-    in.normal = normals[idx]; // the launcher guarantees the normal image has the colour target's size
-    in.normalH = in.normalV = in.normal;
-    if (GEOMETRIC_AA) {
-        in.normalH = normals[fastm::texelIndex((uint32_t)clampi(px ^ 1, P.normal.w), (uint32_t)py, (uint32_t)P.normal.w)];
-        in.normalV = normals[fastm::texelIndex((uint32_t)px, (uint32_t)clampi(py ^ 1, P.normal.h), (uint32_t)P.normal.w)];
     }
     uint32_t sigWord;
     const uint32_t colour = shadeGeometryPixel<DIFFUSE_BRDF, MULTISCATTER, GEOMETRIC_AA, 0>(P, px, py, vr, in, &sigWord);

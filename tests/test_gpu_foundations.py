@@ -82,3 +82,35 @@ def test_gpu_codecs_bit_identical(backend, oracle):
     assert np.array_equal(a[~np.isnan(b)], b[~np.isnan(b)])
     u = r.uniform(-0.2, 1.2, n).astype(np.float32)
     assert np.array_equal(backend.debugCodecEval(4, u, n, np.uint8, n), oracle.codec_eval(4, u, n, np.uint8, n))
+
+
+@pytest.mark.gpu
+def test_gpu_a_thread_without_its_own_backend_uses_the_process_global_one(backend):
+    """the reference's gRenderBackend is one process-global object (RenderBackend.cpp:39): a host that calls setup on its main thread and records from a
+    worker thread must find the same backend there. A thread that calls plr_setup itself gets its own (band rendering: one thread per band)."""
+    import threading
+    import numpy as np
+    import passes
+    from plainrenderer_amd.backend import PlrError
+    from util import F
+    got = {}
+
+    def worker():
+        try:
+            img = backend.createImage(passes.image_desc_2d(8, 4, F.RGBA8), np.arange(8 * 4 * 4, dtype=np.uint8))
+            got["bytes"] = backend.downloadImage(img, 0, np.uint8).copy()
+            got["fusion"] = backend.getPassFusion()[0]
+            try:
+                backend._check(backend.lib.plr_shutdown())
+            except PlrError as e:
+                got["shutdown"] = str(e)
+        except BaseException as e:
+            got["error"] = e
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join(timeout=120)
+    assert "error" not in got, got.get("error")
+    assert np.array_equal(got["bytes"], np.arange(8 * 4 * 4, dtype=np.uint8)) and got["fusion"] == backend.getPassFusion()[0]
+    assert "another thread set up" in got["shutdown"], "only the thread that called plr_setup shuts the backend down"
+    backend.getPassFusion()  # the owner's backend is alive
