@@ -44,8 +44,8 @@ PLR_DI float fpow(float x, float y) { return x <= 0.f ? 0.f : exp2h(y * log2h(x)
 // ---- correctly rounded quotient / reciprocal / root from v_rcp_f32 / v_rsq_f32 (1 ulp) and one Newton step with fused residuals: the IEEE result
 // for every operand this kernel sees (finite, normal, non-zero divisors) in 4-5 instructions instead of the 10-instruction v_div_scale sequence
 PLR_DI float rcpRN(float d) { const float r = rcpf(d); return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r); }
-PLR_DI float divRNr(float n, float d, float r) { const float q = n * r; return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q); } // r = rcpRN(d)
-PLR_DI float divRN(float n, float d) { return divRNr(n, d, rcpRN(d)); }
+PLR_DI float divRNr(float n, float d, float r) { const float q = n * r; return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q); } // r = rcpf(d) (1 ulp is enough: the residual is exact)
+PLR_DI float divRN(float n, float d) { return divRNr(n, d, rcpf(d)); } // the residual step corrects the raw reciprocal's ulp as well: no Newton step on r first
 PLR_DI float sqrtRN(float x) { const float r = rsqf(x), s = x * r; return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * r, s); } // x > 0
 
 // view direction of a pixel (surface -> camera, unit length) and its screen uv, bit for bit as deferredShadingKernel (kernels/shading.hip)
@@ -76,7 +76,7 @@ PLR_DI Surface exactSurface(const GlobalUbo* __restrict__ g, vec3 Vn, float dept
     const float dvf = (cx * fx + cy * fy) + cz * fz;
     const float den = g->farPlane + (-depth + 1.f) * (g->nearPlane - g->farPlane);
     const float depthLinear = divRN(g->nearPlane * g->farPlane, den);
-    const float rd = rcpRN(dvf);
+    const float rd = rcpf(dvf);
     Surface s;
     s.passPos.x = g->cameraPosition[0] + divRNr(cx, dvf, rd) * depthLinear;
     s.passPos.y = g->cameraPosition[1] + divRNr(cy, dvf, rd) * depthLinear;
@@ -201,7 +201,7 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
         const float y = ((m[1] * pos.x + m[5] * pos.y) + m[9] * pos.z) + m[13];
         const float z = ((m[2] * pos.x + m[6] * pos.y) + m[10] * pos.z) + m[14];
         const float w = ((m[3] * pos.x + m[7] * pos.y) + m[11] * pos.z) + m[15];
-        const float rw = rcpRN(w);
+        const float rw = rcpf(w);
         cxy0 = divRNr(x, w, rw) * 0.5f + 0.5f;
         cxy1 = divRNr(y, w, rw) * 0.5f + 0.5f;
         const float actualDepth = fclamp(divRNr(z, w, rw), 0.f, 1.f);

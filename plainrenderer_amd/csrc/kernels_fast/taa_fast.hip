@@ -229,12 +229,33 @@ PLR_DI Column shiftFromLeft(const Column& c) { return {fromLeft(c.r), fromLeft(c
 PLR_DI Column shiftFromRight(const Column& c) { return {fromRight(c.r), fromRight(c.g), fromRight(c.b), fromRight(c.l), 0.f}; }
 
 constexpr int kStripW = 62, kStripRows = 4;
+// History texels a wave stages in LDS (round 3; north star: framebuffer tiles through LDS): {luminance, packed texel} of the bounding box of its
+// 62 x 4 pixels' 4x4 reprojection footprints. With a static or slowly moving camera that box is ~66 x 7 texels: a lane decodes ~8 texels per strip
+// instead of 16 per pixel = 64 (the sixteen R11G11B10 decodes + luminances per pixel were 40 % of this kernel's instructions). A wave whose
+// footprints spread further (fast motion, a disocclusion edge through the strip) takes the direct path: its pixels read their footprints from
+// memory as before. The strip's reprojection (depth rows -> closest depth -> motion vectors) is resolved for all four rows first; the box's
+// texels are then fetched with all loads of a lane in flight at once, next to the first colour rows of the resolve - a first version that
+// staged in a rolled loop (one load, one decode, one store per trip) ran 171 us against 155 us for the unstaged kernel: eight exposed round
+// trips per strip outweighed a fifth fewer instructions.
+constexpr int kStageTexels = 1024, kStageMaxW = 128, kStagePerLane = kStageTexels / 64;
+
+// minimum over the wave's lanes (lanes that do not take part pass INT_MAX); result valid in every lane
+PLR_DI int waveMinI(int v) {
+    constexpr int kIdentity = 0x7fffffff;
+#define PLR_TAA_MIN_STEP(ctrl, rowMask) v = min(v, __builtin_amdgcn_update_dpp(kIdentity, v, ctrl, rowMask, 0xf, false))
+    PLR_TAA_MIN_STEP(0x111, 0xf); PLR_TAA_MIN_STEP(0x112, 0xf); PLR_TAA_MIN_STEP(0x114, 0xf); PLR_TAA_MIN_STEP(0x118, 0xf); // row_shr:1, 2, 4, 8: lane 15 of every row holds the row's minimum
+    PLR_TAA_MIN_STEP(0x142, 0xa); // row_bcast:15 into rows 1 and 3
+    PLR_TAA_MIN_STEP(0x143, 0xc); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's minimum
+#undef PLR_TAA_MIN_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
 __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
                                                                  int coverW, int coverH, int yBase, TwoRanges ranges) {
     static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");
+    __shared__ uint2 stage[4][kStageTexels]; // per wave: {luminance bits, packed texel}
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
     const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
@@ -246,18 +267,20 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
     const uint32_t* cur = (const uint32_t*)current.ptr;
     const float* dep = (const float*)depthBuffer.ptr;
 
-    auto loadRow = [&](int y) -> Column {
-        const vec3 c = unpackR11G11B10(cur[fastm::texelIndex((uint32_t)xc, (uint32_t)clampi(y, current.h), (uint32_t)current.w)]);
+    auto fetchRow = [&](int y) -> uint32_t { return cur[fastm::texelIndex((uint32_t)xc, (uint32_t)clampi(y, current.h), (uint32_t)current.w)]; };
+    auto decodeRow = [&](uint32_t texel) -> Column {
+        const vec3 c = unpackR11G11B10(texel);
         const float l = lum(c);
         Column o;
         if (TONEMAP) { const float s = rcpf(1.f + l); o.r = c.x * s; o.g = c.y * s; o.b = c.z * s; o.l = l * s; }
         else { o.r = c.x; o.g = c.y; o.b = c.z; o.l = l; }
         o.d = 0.f;
-        if (DILATE) {
-            const float dv = dep[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
-            o.d = (xInDepth && y >= 0 && y < depthBuffer.h) ? dv : 0.f;
-        }
         return o;
+    };
+    auto loadRow = [&](int y) -> Column { return decodeRow(fetchRow(y)); };
+    auto loadDepth = [&](int y) -> float { // raw depth, 0 outside the image (texelFetch)
+        const float dv = dep[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
+        return (xInDepth && y >= 0 && y < depthBuffer.h) ? dv : 0.f;
     };
 
     const ResolveWeights rw = *rwp;
@@ -267,9 +290,75 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
     const uint32_t* hist = (const uint32_t*)historySrc.ptr;
     const int hw = historySrc.w, hh = historySrc.h;
 
-    // three-row window: C[0] = row y-1, C[1] = row y, C[2] = row y+1; L / R = the neighbour lanes' columns
+    // ---- phase A: where do the strip's pixels reproject to? (motion vector at the closest depth of the 3x3, temporalFilter.comp:93-117)
+    const uint32_t raw0 = fetchRow(rowFirst - 1), raw1 = fetchRow(rowFirst); // the resolve's first two colour rows: in flight through phase A
+    float mvx[kStripRows], mvy[kStripRows], wa[kStripRows], wb[kStripRows]; // motion, sub-texel weights of the footprint
+    int fi[kStripRows], fj[kStripRows];                                     // i0, j0 of the footprint (texels i0 - 1 .. i0 + 2)
+    int iLo = 0x7fffffff, iHi = 0x7fffffff, jLo = 0x7fffffff, jHi = 0x7fffffff; // min of i0, min of -i0, ...: one kind of reduction
+    {
+        float dw[kStripRows + 2];
+        if (DILATE) {
+#pragma unroll
+            for (int j = 0; j < kStripRows + 2; j++) dw[j] = loadDepth(rowFirst - 1 + j); // all six depth rows at once
+        }
+#pragma unroll
+        for (int j = 0; j < kStripRows; j++) {
+            const int py = rowFirst + j;
+            mvx[j] = mvy[j] = wa[j] = wb[j] = 0.f; fi[j] = fj[j] = 0;
+            if (py >= coverH) continue; // wave-uniform
+            // closest (largest reverse-Z) depth of the 3x3, scanned x outer / y inner by the reference loop with a strict comparison from 0: the first
+            // column whose maximum is the overall maximum (> 0), and in it the first row that reaches it. Every lane finds (maximum, first row) of its own
+            // column; the neighbours' pairs come over DPP: 18 compares / selects / shifts instead of 36 on the nine depths
+            int ox = 0, oy = 0;
+            if (DILATE) {
+                float cd = dw[j]; int cy = -1;
+                if (dw[j + 1] > cd) { cd = dw[j + 1]; cy = 0; }
+                if (dw[j + 2] > cd) { cd = dw[j + 2]; cy = 1; }
+                const float ld = fromLeft(cd), rd = fromRight(cd);
+                const int ly = __builtin_bit_cast(int, fromLeft(__builtin_bit_cast(float, cy))), ry = __builtin_bit_cast(int, fromRight(__builtin_bit_cast(float, cy)));
+                float closest = 0.f;
+                if (ld > closest) { closest = ld; ox = -1; oy = ly; }
+                if (cd > closest) { closest = cd; ox = 0; oy = cy; }
+                if (rd > closest) { closest = rd; ox = 1; oy = ry; }
+            }
+            const vec4 m = motionFetch(motionBuffer, px + ox, py + oy);
+            mvx[j] = m.x; mvy[j] = m.y;
+            const float rpx = ((float)px + 0.5f) * tsx + m.x, rpy = ((float)py + 0.5f) * tsy + m.y;
+            linearCoord(rpx * (float)hw, &fi[j], &wa[j]);
+            linearCoord(rpy * (float)hh, &fj[j], &wb[j]);
+            if (isOutputLane) { iLo = min(iLo, fi[j]); iHi = min(iHi, -fi[j]); jLo = min(jLo, fj[j]); jHi = min(jHi, -fj[j]); }
+        }
+    }
+    // bounding box of the footprints (texels i0 - 1 .. i0 + 2 of every pixel), staged if it fits
+    const int orgI = waveMinI(iLo) - 1, endI = -waveMinI(iHi) + 3, orgJ = waveMinI(jLo) - 1, endJ = -waveMinI(jHi) + 3; // [org, end)
+    const int stageW = endI - orgI, stageH = endJ - orgJ, stageN = stageW * stageH;
+    const bool staged = stageW > 0 && stageH > 0 && stageW <= kStageMaxW && stageN <= kStageTexels; // wave-uniform (a wave without output pixels: not staged)
+    uint2* __restrict__ myStage = stage[wave];
+    if (staged) {
+        // entry e = lane + 64 k is box texel (e % stageW, e / stageW); all of a lane's loads are issued before the first is decoded
+        const float invW = 1.f / (float)stageW;
+        uint32_t tx[kStagePerLane];
+#pragma unroll
+        for (int k = 0; k < kStagePerLane; k++) {
+            const int e = k * 64 + lane;
+            tx[k] = 0u;
+            if (k * 64 < stageN) { // wave-uniform
+                const int r = (int)(((float)e + 0.5f) * invW), x = e - r * stageW; // exact for e < 1024, stageW <= 128
+                if (e < stageN) tx[k] = hist[__umul24((uint32_t)clampi(orgJ + r, hh), (uint32_t)hw) + (uint32_t)clampi(orgI + x, hw)]; // clamp-to-edge resolved here
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kStagePerLane; k++) {
+            const int e = k * 64 + lane;
+            if (k * 64 < stageN && e < stageN) myStage[e] = make_uint2(f2u(lum(unpackR11G11B10(tx[k]))), tx[k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the wave's own LDS writes before its lanes read each other's entries
+    }
+
+    // ---- phase B: the resolve. Three-row window: C[0] = row y-1, C[1] = row y, C[2] = row y+1; L / R = the neighbour lanes' columns
     Column C[3], L[3], R[3];
-    C[0] = loadRow(rowFirst - 1); C[1] = loadRow(rowFirst);
+    C[0] = decodeRow(raw0); C[1] = decodeRow(raw1);
     L[0] = shiftFromLeft(C[0]); R[0] = shiftFromRight(C[0]);
     L[1] = shiftFromLeft(C[1]); R[1] = shiftFromRight(C[1]);
 
@@ -295,32 +384,30 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
                           wsum(L[0].g, C[0].g, R[0].g, L[1].g, C[1].g, R[1].g, L[2].g, C[2].g, R[2].g),
                           wsum(L[0].b, C[0].b, R[0].b, L[1].b, C[1].b, R[1].b, L[2].b, C[2].b, R[2].b));
 
-        // closest (largest reverse-Z) depth of the 3x3, scanned x outer / y inner by the reference loop with a strict comparison from 0: the first
-        // column whose maximum is the overall maximum (> 0), and in it the first row that reaches it. Every lane finds (maximum, first row) of its own
-        // column; the neighbours' pairs come over DPP: 18 compares / selects / shifts instead of 36 on the nine depths
-        int ox = 0, oy = 0;
-        if (DILATE) {
-            float cd = C[0].d; int cy = -1;
-            if (C[1].d > cd) { cd = C[1].d; cy = 0; }
-            if (C[2].d > cd) { cd = C[2].d; cy = 1; }
-            const float ld = fromLeft(cd), rd = fromRight(cd);
-            const int ly = __builtin_bit_cast(int, fromLeft(__builtin_bit_cast(float, cy))), ry = __builtin_bit_cast(int, fromRight(__builtin_bit_cast(float, cy)));
-            float closest = 0.f;
-            if (ld > closest) { closest = ld; ox = -1; oy = ly; }
-            if (cd > closest) { closest = cd; ox = 0; oy = cy; }
-            if (rd > closest) { closest = rd; ox = 1; oy = ry; }
-        }
-        const vec4 m = motionFetch(motionBuffer, px + ox, py + oy);
-        const float u0 = ((float)px + 0.5f) * tsx, v0 = ((float)py + 0.5f) * tsy;
-        const float rpx = u0 + m.x, rpy = v0 + m.y;
+        const float rpx = ((float)px + 0.5f) * tsx + mvx[j], rpy = ((float)py + 0.5f) * tsy + mvy[j];
+        const int i0 = fi[j], j0 = fj[j];
+        const float a = wa[j], b = wb[j];
+        struct { float x, y; } m = {mvx[j], mvy[j]};
 
-        // ---- history: the 4x4 texel footprint of the nine bilinear neighbourhood taps around uv + motion.
-        // Tried and not kept: (i) a streaming pre-pass that turns the history image into a float luminance plane, so that only the centre
-        // 2x2 texels are unpacked here (filter 194 -> 181 us, pre-pass 15 us: no net gain); (ii) writing {texel, luminance} entries beside
-        // the history texels and validating them against the image when read (222 VGPRs, 2 waves per SIMD).
-        int i0, j0; float a, b;
-        linearCoord(rpx * (float)hw, &i0, &a);
-        linearCoord(rpy * (float)hh, &j0, &b);
+        // ---- history: the 4x4 texel footprint of the nine bilinear neighbourhood taps around uv + motion: luminances of all sixteen, colours of
+        // the centre 2x2 (= the footprint of the bilinear tap at uv + motion)
+        float tl[4][4];
+        vec3 tc[2][2]; // colours of the centre 2x2 = footprint of the bilinear tap at uv + motion
+        if (staged) {
+            // lanes that hold no output pixel (strip borders, beyond the image) may point anywhere: they read the box's first rows
+            const int base = isOutputLane ? (j0 - 1 - orgJ) * stageW + (i0 - 1 - orgI) : 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int e = base + r * stageW + c;
+                    if (r >= 1 && r <= 2 && c >= 1 && c <= 2) {
+                        const uint2 v = myStage[e];
+                        tl[r][c] = u2f(v.x);
+                        tc[r - 1][c - 1] = unpackR11G11B10(v.y);
+                    } else tl[r][c] = u2f(myStage[e].x);
+                }
+        } else {
         uint32_t t[4][4]; // [row][col] = texel (i0 - 1 + col, j0 - 1 + row), clamped to the edge
         const bool interior = i0 >= 1 && i0 + 2 < hw;
         if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
@@ -338,8 +425,6 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
                 for (int c = 0; c < 4; c++) t[r][c] = hist[row + clampi(i0 - 1 + c, hw)];
             }
         }
-        float tl[4][4];
-        vec3 tc[2][2]; // colours of the centre 2x2 = footprint of the bilinear tap at uv + motion
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -348,6 +433,7 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
                 tl[r][c] = lum(col);
                 if (r >= 1 && r <= 2 && c >= 1 && c <= 2) tc[r - 1][c - 1] = col;
             }
+        }
 
         vec3 historySample;
         {

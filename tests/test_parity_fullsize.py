@@ -310,8 +310,9 @@ def test_gpu_fullsize_frame_end_to_end(backend, fs):
     report("frame", within_one_code=float(within1.mean()), within_4_codes=float((d <= 4).all(axis=1).mean()), max_code_diff=int(d.max()), swapchain_within_1lsb=float((sw <= 1).mean()),
            swapchain_max_lsb=int(sw.max()), mean_rel_err=mean_rel, histogram_bins_equal=hist_equal, histogram_total=int(fs.hist_gpu.sum()))
     assert np.isfinite(lit).all()
-    assert within1.mean() >= 0.975, "at least 97.5 % of the pixels of the final HDR image within one R11G11B10 code of the oracle frame"
-    assert (d <= 4).all(axis=1).mean() >= 0.994
+    # measured on MI355X: 99.989 % (round 2, before the shade's light-space geometry followed the shader's operation order: 98.04 %)
+    assert within1.mean() >= 0.995, "at least 99.5 % of the pixels of the final HDR image within one R11G11B10 code of the oracle frame"
+    assert (d <= 4).all(axis=1).mean() >= 0.9995
     assert (sw <= 1).mean() >= 0.9999, "tonemapped swapchain: 99.99 % of the channels within 1 LSB"
     assert mean_rel <= 2e-3
     assert int(fs.hist_gpu.sum()) == W * H
