@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--profile-frames", type=int, default=20, help="extra frames with per-pass hipEvent timing for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
+    ap.add_argument("--producers", action="store_true", help="NOT the headline workload: also run the input producers as compute passes every frame (sun light matrices, "
+                    "the three sky LUTs, the four froxel passes: SURVEY 8 f3) instead of reading uploaded LUTs / matrices; single GPU only")
     ap.add_argument("--exact", action="store_true", help="diagnostic: run the bit-exact kernel set (PLR_MATH_EXACT) instead of the default fast set")
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     ap.add_argument("--python-exchange", action="store_true", help="diagnostic: drive the halo exchange from Python (torch.distributed) instead of the C++ host's RCCL exchange")
@@ -315,7 +317,8 @@ def main():
                     dist.broadcast(uid, src=0)
                 fp_.attach_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, h_, bounds_)
         else:
-            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res)
+            extra = dict(run_sky_luts=1, run_volumetrics=1, run_light_matrix=1) if args.producers else {}
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **extra)
         sc = build_scene(args, device, w_, h_, band_)
         sc[2].upload(fp_)
         be_.waitForGPUIdle()
@@ -359,6 +362,27 @@ def main():
         fp.frame(cams[frame_no[0] + 1], 1.0 / 60.0, 0.5 + frame_no[0] / 60.0)
         frame_no[0] += 1
 
+    # ---- the two auxiliary measurements come FIRST, untimed: the 40 frames they render also take the GPU out of its idle clocks before the W warm-up
+    # frames (measured on MI355X with --steps 20: 0.878 / 0.886 ms per frame after 5 warm-up frames from idle, 0.863 after 100, 0.861 after 400).
+    # ---- host cost of one frame with the GPU idle (record + launch of the C++ pipeline through the C-ABI, nothing to wait for)
+    host_idle = []
+    for _ in range(20):
+        be.waitForGPUIdle()
+        th = time.perf_counter()
+        step()
+        host_idle.append((time.perf_counter() - th) * 1e3)
+    be.waitForGPUIdle()
+    host_idle_ms = float(np.median(host_idle))
+
+    # ---- per-pass hipEvent timings (events recorded on the backend's launch stream) for the roofline object
+    pass_ms = {}
+    if args.profile_frames > 0:
+        be.setPassTiming(True)
+        for _ in range(args.profile_frames):
+            step()
+            for name, ms in be.getRenderpassTimings():
+                pass_ms.setdefault(name, []).append(ms)
+        be.setPassTiming(False)
     for _ in range(args.warmup):
         step()
     be.waitForGPUIdle()
@@ -380,25 +404,6 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1000.0 / args.steps
 
-    # ---- host cost of one frame with the GPU idle (record + launch of the C++ pipeline through the C-ABI, nothing to wait for)
-    host_idle = []
-    for _ in range(20):
-        be.waitForGPUIdle()
-        th = time.perf_counter()
-        step()
-        host_idle.append((time.perf_counter() - th) * 1e3)
-    be.waitForGPUIdle()
-    host_idle_ms = float(np.median(host_idle))
-
-    # ---- per-pass hipEvent timings (events recorded on the backend's launch stream) for the roofline object
-    pass_ms = {}
-    if args.profile_frames > 0:
-        be.setPassTiming(True)
-        for _ in range(args.profile_frames):
-            step()
-            for name, ms in be.getRenderpassTimings():
-                pass_ms.setdefault(name, []).append(ms)
-        be.setPassTiming(False)
     # per-GPU pixels: the band's rows (a band renders w x rows of the frame)
     bh = h if band is None else band[1] - band[0]
     bytes_per_pass, frame_bytes = algorithmic_bytes(w, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
@@ -457,7 +462,7 @@ def main():
                        "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "kernel_set": "exact" if args.exact else "fast",
                        # what the timed frames do besides the workload's size: camera translation per frame (static G-buffer, moving view for the reprojections),
                        # backend scheduling switches (include/plr.h): pass fusion level, asynchronous frame tail (bloom chain + tonemap beside the next frame)
-                       "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
+                       "input_producers_as_compute": bool(args.producers), "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
                        "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point (%s) "
                                        "+ one 512 B histogram all-reduce per frame" % (w, h, world, h // world, "torch.distributed from Python" if args.python_exchange else
                                                                                         "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else

@@ -263,7 +263,7 @@ struct Backend {
     GlobalUbo globalShadow{};            // host copy of the global uniform buffer as of the last flushed fill (PassCtx::globalHost)
     bool globalShadowValid = false;
     uint32_t lastFused = 0;              // executions of the last frame that ran inside a fused launch
-    uint64_t frameSerial = 0;            // launchAll calls so far (PassCtx::frameSerial)
+    uint64_t frameSerial = 0;            // serial of the running launchAll call, unique in the process (PassCtx::frameSerial)
     // asynchronous frame tail (plr_compute_pass_execution::async_tail, plr.h): executions launched on tailStream that the main stream has not
     // waited for yet, as the union of what they touch; tailDone is recorded behind the last of them
     hipStream_t tailStream = nullptr;
@@ -1082,7 +1082,10 @@ static void linkConsumers(const GlobalUbo* globalPtr) {
 
 static int launchAll(bool timed) {
     const size_t n = g->executions.size();
-    g->frameSerial++;
+    // unique across backends: host-side bookkeeping of the launchers (the spatial filter's packed rows) is keyed by device addresses, which a
+    // later backend on the same thread gets handed again - an entry of this serial was written by this backend in this frame
+    static std::atomic<uint64_t> serialCounter{0};
+    g->frameSerial = ++serialCounter;
     g->timingNow = timed;
     if (timed) { g->segments.clear(); g->eventsUsed = 0; }
     g->orderEventsUsed = 0;

@@ -59,7 +59,7 @@ struct PassCtx {
     // image this execution writes, possibly with host callbacks (halo exchanges) and further executions of this same pass in between; null if
     // there is none, if another pass writes the image first, in PLR_MATH_EXACT, with pass fusion off or a signature buffer set
     const PassCtx* consumer = nullptr;
-    uint64_t frameSerial = 0;             // counts plr_render_frame calls: lets a pass's host-side bookkeeping tell this frame's entries from stale ones
+    uint64_t frameSerial = 0;             // serial of this plr_render_frame call, unique in the process: lets a pass's host-side bookkeeping tell this frame's entries from stale ones
     const std::vector<SpecConstant>* spec = nullptr;
     std::string* err = nullptr;
     void** scratchSlot = nullptr;         // persistent per-pass scratch (device memory, grow-only)

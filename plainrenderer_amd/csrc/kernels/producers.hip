@@ -378,10 +378,15 @@ PLR_DI size_t idx3(const ImgView& im, int x, int y, int z) { return ((size_t)z *
 
 // thread -> froxel for the 4x4x4-workgroup passes: blocks of 64 lanes walk x fastest
 PLR_DI bool froxelOfThread(const ImgView& vol, int coverX, int coverY, int coverZ, int* x, int* y, int* z) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long n = (long long)coverX * coverY * coverZ;
+    // 32-bit index arithmetic (the launcher refuses volumes of 2^31 froxels or more): the 64-bit divisions this replaced were software sequences of
+    // several hundred instructions each, three per thread
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = (uint32_t)coverX * (uint32_t)coverY * (uint32_t)coverZ;
     if (i >= n) return false;
-    *x = (int)(i % coverX); *y = (int)((i / coverX) % coverY); *z = (int)(i / ((long long)coverX * coverY));
+    const uint32_t row = i / (uint32_t)coverX;
+    *x = (int)(i - row * (uint32_t)coverX);
+    *z = (int)(row / (uint32_t)coverY);
+    *y = (int)(row - (uint32_t)*z * (uint32_t)coverY);
     return true;
 }
 
@@ -457,6 +462,73 @@ __global__ __launch_bounds__(256) void volumeLightingReprojectionKernel(ImgView 
     Texel<F_RGBA16F>::store(target.ptr, idx3(target, x, y, z), result);
 }
 
+// ---- the three per-froxel passes as ONE launch (PLR_MATH_FAST + pass fusion; plr_set_pass_fusion). Each pass reads the previous one's volume at
+// its OWN froxel only, so a thread carries the texel through registers - rounded to half floats exactly where the stored volume would round it -
+// and the result equals the three separate launches bit for bit (tests/test_producers.py, tests/test_fusion.py). What it saves: two launches,
+// the material + scattering volumes' round trip through HBM (4 x 8 bytes per froxel; with fusion level 2 their stores go as well when nothing
+// else in the frame binds them), and one of the three world-position chains: froxelVolumeMaterial.comp:34 writes the NDC as 2 * (uv - 0.5),
+// froxelLightScattering.comp:36 as 2 * uv - 1 - the same float for every uv in [0, 1) (both subtractions round the exact 2 uv - 1 onto the same
+// grid: for uv >= 0.25 both are exact by Sterbenz, below it the product by two is exact), and both passes use the same jitter. The reprojection
+// pass evaluates the position without jitter: its chain stays its own.
+// The arithmetic is the exact set's: sub-texel weights of the noise / history samples and the shadow-map texel are discrete in the position.
+PLR_DI float roundToHalf(float v) { return halfBitsToFloat(floatToHalfBits(v)); } // what a texel of an RGBA16F volume gives back
+template <bool STORE_INTERMEDIATES>
+__global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, ImgView noiseTexture, ImgView scattering, ImgView shadowMap, const ShadowCascadeInfo* __restrict__ shadowInfo,
+                                                              const LightBuffer* __restrict__ light, ImgView target, ImgView historyVolume, const VolSettings* __restrict__ sp,
+                                                              const GlobalUbo* __restrict__ g, int cx, int cy, int cz) {
+    int x, y, z;
+    if (!froxelOfThread(target, cx, cy, cz, &x, &y, &z)) return;
+    const VolSettings s = *sp;
+    const float kPi = PLR_GLSL_PI;
+    const size_t texel = idx3(target, x, y, z); // the launcher checked: all three volumes have the target's size
+    // froxelVolumeMaterial.comp
+    vec3 V;
+    const vec3 posWorld = froxelWorldPosition(x, y, z, target, s.sampleOffset, g, s.maxDistance, &V, true);
+    vec4 sa;
+    {
+        const vec3 noiseSample = posWorld * 0.5f + ld3(s.windSampleOffset);
+        const float noise = sampleLinear3D<F_R8, REPEAT>(noiseTexture, noiseSample).x;
+        float densityMultiplier = s.baseDensity;
+        densityMultiplier += s.densityNoiseRange * (noise - 0.5f);
+        densityMultiplier = gmax(densityMultiplier, 0.f);
+        const vec4 m(ld3(s.scatteringCoefficients) * densityMultiplier, s.absorptionCoefficient * densityMultiplier);
+        if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(material.ptr, texel, m);
+        sa = vec4(roundToHalf(m.x), roundToHalf(m.y), roundToHalf(m.z), roundToHalf(m.w));
+    }
+    // froxelLightScattering.comp
+    vec4 current;
+    {
+        vec4 p = mulMat4(shadowInfo->lightMatrices[2], vec4(posWorld, 1.f));
+        p = p / p.w;
+        const float actualDepth = gclamp(p.z, 0.f, 1.f);
+        const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_BLACK>(shadowMap, vec2(p.x, p.y) * 0.5f + 0.5f).x;
+        const float sunStrength = (actualDepth > shadowMapDepth ? 1.f : 0.f) * light->sunStrengthExposed;
+        const float VoL = dot(-V, ld3(g->sunDirection));
+        const float gg = s.phaseFunctionG;
+        const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
+        const vec3 scatteringCoefficient = sa.xyz();
+        const vec3 inscattering = (sunStrength * phase * ld3(light->sunColor) + vec3(0.02f)) * scatteringCoefficient;
+        const float transmittance = computeLuminance(scatteringCoefficient + sa.w);
+        const vec4 r(inscattering, transmittance);
+        if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(scattering.ptr, texel, r);
+        current = vec4(roundToHalf(r.x), roundToHalf(r.y), roundToHalf(r.z), roundToHalf(r.w));
+    }
+    // volumeLightingReprojection.comp
+    const vec3 posUnjittered = froxelWorldPosition(x, y, z, target, 0.f, g, s.maxDistance, nullptr, false);
+    vec4 ndcPrevious = mulMat4(g->viewProjectionPrevious, vec4(posUnjittered, 1.f));
+    ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
+    const vec3 camPrev = ld3(g->cameraPositionPrevious);
+    const vec3 V_history = normalize(camPrev - posUnjittered);
+    const float historyDistance = distance(posUnjittered, camPrev);
+    const float historyDepth = historyDistance * dot(-V_history, ld3(g->cameraForwardPrevious));
+    const vec3 historyUV(ndcPrevious.x * 0.5f + 0.5f, ndcPrevious.y * 0.5f + 0.5f, depthToFroxelUVZ(historyDepth, s.maxDistance));
+    vec4 history = sampleLinear3D<F_RGBA16F, CLAMP>(historyVolume, historyUV);
+    float alpha = 0.95f;
+    if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
+    if (g->cameraCut) history = current;
+    Texel<F_RGBA16F>::store(target.ptr, texel, current * (1.f - alpha) + history * alpha);
+}
+
 PLR_DI vec3 integrateInscattering(vec3 inscattering, vec3 ext, float length) {
     const vec3 e(det_expf(-ext.x * length), det_expf(-ext.y * length), det_expf(-ext.z * length));
     const vec3 num = inscattering - inscattering * e;
@@ -487,6 +559,7 @@ static void cover3(const PassCtx& c, const ImgView& vol, int wg, int* cx, int* c
     *cx = std::min((int)(c.dispatch[0] * (unsigned)wg), vol.w); *cy = std::min((int)(c.dispatch[1] * (unsigned)wg), vol.h); *cz = std::min((int)(c.dispatch[2] * (unsigned)wg), vol.d);
 }
 static unsigned blocksFor(int cx, int cy, int cz) { return (unsigned)(((long long)cx * cy * cz + 255) / 256); }
+static bool tooManyFroxels(int cx, int cy, int cz) { return (long long)cx * cy * cz >= (1ll << 31); }
 
 static int launchMaterial(const PassCtx& c) {
     if (int rc = c.needGlobal()) return rc;
@@ -496,6 +569,7 @@ static int launchMaterial(const PassCtx& c) {
     int cx, cy, cz;
     cover3(c, c.storage[0], 4, &cx, &cy, &cz);
     if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    if (tooManyFroxels(cx, cy, cz)) return c.fail(-6, "froxelVolumeMaterial: more than 2^31 froxels");
     froxelVolumeMaterialKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], (const VolSettings*)c.ubuf[2].ptr, c.global, cx, cy, cz);
     PLR_CHECK_LAUNCH(c);
     return 0;
@@ -511,6 +585,7 @@ static int launchScattering(const PassCtx& c) {
     int cx, cy, cz;
     cover3(c, c.storage[0], 4, &cx, &cy, &cz);
     if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    if (tooManyFroxels(cx, cy, cz)) return c.fail(-6, "froxelLightScattering: more than 2^31 froxels");
     froxelLightScatteringKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], c.sampled[2], (const ShadowCascadeInfo*)c.sbuf[3].ptr,
                                                                             (const LightBuffer*)c.sbuf[4].ptr, (const VolSettings*)c.ubuf[5].ptr, c.global, cx, cy, cz);
     PLR_CHECK_LAUNCH(c);
@@ -525,6 +600,7 @@ static int launchReprojection(const PassCtx& c) {
     int cx, cy, cz;
     cover3(c, c.storage[0], 4, &cx, &cy, &cz);
     if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    if (tooManyFroxels(cx, cy, cz)) return c.fail(-6, "volumeLightingReprojection: more than 2^31 froxels");
     volumeLightingReprojectionKernel<<<blocksFor(cx, cy, cz), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], c.sampled[2], (const VolSettings*)c.ubuf[3].ptr, c.global, cx, cy, cz);
     PLR_CHECK_LAUNCH(c);
     return 0;
@@ -541,6 +617,37 @@ static int launchIntegration(const PassCtx& c) {
     return 0;
 }
 
+// material -> scattering -> reprojection as recorded by Volumetrics::computeVolumetricLighting: one launch when the three executions bind one
+// chain of equally sized volumes over the same dispatch (anything else: kUseGeneralKernel, the three launches)
+static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
+    if (count != 3) return kUseGeneralKernel;
+    const PassCtx &m = *ctxs[0], &sc = *ctxs[1], &r = *ctxs[2];
+    if (!m.global || !m.hasStorage(0) || m.storage[0].fmt != F_RGBA16F || !m.hasSampled(1) || m.sampled[1].fmt != F_R8 || !m.hasUbuf(2) || m.ubuf[2].size < sizeof(VolSettings)) return kUseGeneralKernel;
+    if (!sc.hasStorage(0) || sc.storage[0].fmt != F_RGBA16F || !sc.hasSampled(1) || sc.sampled[1].fmt != F_D16 || !sc.hasSampled(2) || !sc.hasSbuf(3) ||
+        sc.sbuf[3].size < sizeof(ShadowCascadeInfo) || !sc.hasSbuf(4) || sc.sbuf[4].size < sizeof(LightBuffer) || !sc.hasUbuf(5))
+        return kUseGeneralKernel;
+    if (!r.hasStorage(0) || r.storage[0].fmt != F_RGBA16F || !r.hasSampled(1) || !r.hasSampled(2) || r.sampled[2].fmt != F_RGBA16F || !r.hasUbuf(3)) return kUseGeneralKernel;
+    const ImgView &mat = m.storage[0], &scat = sc.storage[0], &tgt = r.storage[0], &hist = r.sampled[2];
+    auto sameSize = [](const ImgView& a, const ImgView& b) { return a.w == b.w && a.h == b.h && a.d == b.d; };
+    if (sc.sampled[2].ptr != mat.ptr || r.sampled[1].ptr != scat.ptr || !sameSize(mat, scat) || !sameSize(mat, tgt) || !sameSize(sc.sampled[2], mat) || !sameSize(r.sampled[1], scat))
+        return kUseGeneralKernel;
+    if (sc.ubuf[5].ptr != m.ubuf[2].ptr || r.ubuf[3].ptr != m.ubuf[2].ptr) return kUseGeneralKernel; // one settings buffer
+    if (tgt.ptr == hist.ptr || tgt.ptr == mat.ptr || tgt.ptr == scat.ptr || mat.ptr == scat.ptr) return kUseGeneralKernel;
+    for (int k = 0; k < 3; k++)
+        if (m.dispatch[k] != sc.dispatch[k] || m.dispatch[k] != r.dispatch[k] || m.base[k] || sc.base[k] || r.base[k]) return kUseGeneralKernel;
+    int cx, cy, cz;
+    cover3(m, mat, 4, &cx, &cy, &cz);
+    if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
+    if (tooManyFroxels(cx, cy, cz)) return kUseGeneralKernel;
+    const bool elide = (m.elidableStorage & 1u) && (sc.elidableStorage & 1u);
+    auto kernel = elide ? froxelFrontFusedKernel<false> : froxelFrontFusedKernel<true>;
+    kernel<<<blocksFor(cx, cy, cz), 256, 0, m.stream>>>(mat, m.sampled[1], scat, sc.sampled[1], (const ShadowCascadeInfo*)sc.sbuf[3].ptr, (const LightBuffer*)sc.sbuf[4].ptr, tgt, hist,
+                                                       (const VolSettings*)m.ubuf[2].ptr, m.global, cx, cy, cz);
+    PLR_CHECK_LAUNCH(m);
+    if (elide) { m.elidedStorage = 1u; sc.elidedStorage = 1u; }
+    return 0;
+}
+
 } // namespace froxel
 
 static int froxel_material_launch(const PassCtx& c) { return froxel::launchMaterial(c); }
@@ -551,5 +658,8 @@ PLR_REGISTER_SHADER("froxelVolumeMaterial.comp", froxel_material_launch);
 PLR_REGISTER_SHADER("froxelLightScattering.comp", froxel_scattering_launch);
 PLR_REGISTER_SHADER("volumeLightingReprojection.comp", froxel_reprojection_launch);
 PLR_REGISTER_SHADER("volumetricLightingIntegration.comp", froxel_integration_launch);
+static int froxel_fused_front(const PassCtx* const* ctxs, size_t count) { return froxel::launchFusedFront(ctxs, count); }
+PLR_REGISTER_FUSION("froxelVolumeMaterial + froxelLightScattering + volumeLightingReprojection", froxel_fused_front, "froxelVolumeMaterial.comp", "froxelLightScattering.comp",
+                    "volumeLightingReprojection.comp");
 
 } // namespace plr

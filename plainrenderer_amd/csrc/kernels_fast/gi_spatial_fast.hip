@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     uint32_t sampleParityX = 0u, sampleParityY = 0u;
     const uint32_t ywi = (uint32_t)inYSH.w;
     const float yW = (float)inYSH.w, yH = (float)inYSH.h, yWm1 = yW - 1.f, yHm1 = yH - 1.f, dWm1 = dW - 1.f, dHm1 = dH - 1.f;
-    const float halfW = 0.5f * yW, halfH = 0.5f * yH, cu0 = u0 - 0.5f, cv0 = v0 - 0.5f;
-    const float k0c = k0 + 0.5f * (k1 + k2); // q = k0 + v k1 + u k2 in centred coordinates
+    // screen coordinates in the loop are centred and doubled: su = 2 u - 1 = clip.x / clip.w (no halving), "on screen" is |su| <= 1
+    const float halfW = 0.5f * yW, halfH = 0.5f * yH, su0 = 2.f * u0 - 1.f, sv0 = 2.f * v0 - 1.f;
+    // nf * q with q = k0 + v k1 + u k2 in those coordinates: the near * far factor of the plane distance is folded into the three constants
+    const float k0n = nf * (k0 + 0.5f * (k1 + k2)), k1n = nf * 0.5f * k1, k2n = nf * 0.5f * k2;
+    const float halfDW = 0.5f * dW, halfDH = 0.5f * dH;
     const uint2* yshTexels = (const uint2*)inYSH.ptr;
     const uint32_t* cocgTexels = (const uint32_t*)inCoCg.ptr;
     // Samples are processed four at a time, branch-free, so that the gathers of a group are in flight together (a per-sample branch
@@ -205,6 +208,10 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // scene (waves near discs that leave the screen pay for both paths, and the extra registers cost two waves of occupancy).
     // (Measured: SQ_INSTS_VALU 1897 -> 1700 per wave on the bench frame, duration unchanged at ~106 us: with the instruction diet the kernel
     // sits on the gather path instead - 32 wave-wide 16-byte gathers per pixel at ~60 cycles each per CU.)
+    // (Round 3, measured and not kept: the first filter execution of a frame storing the per-pixel frame - centre, tangent, bitangent, 36 bytes - for the
+    // second one to load instead of recomputing it: 270 instructions fewer, and SLOWER - 98 us against 94 us for the loading execution, 105 us for
+    // the storing one, non-temporal accesses included. Three more vector loads per pixel cost more than the arithmetic they replace: what this
+    // kernel waits for is its vector-memory path.)
     // Two copies of the sample loop. A wave whose pixels' discs provably stay on screen (see `safe` above) runs the copy without the
     // mirroring, the off-screen test and the shrinking lengthModifier - a fifth of the per-sample instructions; those conditions could
     // not have fired, so a pixel's result is the same whichever copy its wave ran.
@@ -222,27 +229,28 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 if (SAFE) { ox = samples[96 + i0 + k]; oy = samples[128 + i0 + k]; }
                 else { const float d = samples[i0 + k] * lengthModifier; ox = samples[32 + i0 + k] * d; oy = samples[64 + i0 + k] * d; }
                 const float clipX = P0.x + ox * PT.x + oy * PB.x, clipY = P0.y + ox * PT.y + oy * PB.y, clipW = P0.z + ox * PT.z + oy * PB.z;
-                const float invW = rcpf(clipW) * 0.5f;
-                // screen coordinates relative to the centre (cu = u - 0.5): the on-screen tests are |c| <= 0.5 without a subtraction each
+                const float invW = rcpf(clipW);
                 float cu = clipX * invW, cv = clipY * invW;
                 off[k] = false;
-                if (!SAFE) {
+                uint32_t tx, ty;
+                if (SAFE) {
+                    // `safe` leaves a margin of 1e-3 of the screen: cu * halfW + halfW lies strictly inside (0, width) - no clamp, and trunc == floor
+                    tx = (uint32_t)(int)(cu * halfW + halfW); ty = (uint32_t)(int)(cv * halfH + halfH);
+                } else {
                     // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
-                    cu = fabsf(cu) > 0.5f ? cu0 - ox : cu;
-                    cv = fabsf(cv) > 0.5f ? cv0 - oy : cv;
-                    off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 0.5f; // still off-screen: weight 0, shrink the disc (:100-105)
-                }
-                su[k] = cu; sv[k] = cv;
-                // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
-                const uint32_t tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * yW + halfW, 0.f, yWm1), ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * yH + halfH, 0.f, yHm1);
-                if (!SAFE) {
+                    cu = fabsf(cu) > 1.f ? su0 - 2.f * ox : cu;
+                    cv = fabsf(cv) > 1.f ? sv0 - 2.f * oy : cv;
+                    off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 1.f; // still off-screen: weight 0, shrink the disc (:100-105)
+                    // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
+                    tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfW + halfW, 0.f, yWm1); ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfH + halfH, 0.f, yHm1);
                     off[k] = off[k] || (ty - validY0) >= validRowCount; // a row no neighbouring band has sent counts as off-screen (band rendering)
                     lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
                 }
+                su[k] = cu; sv[k] = cv;
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
                 if (SIG) { const uint32_t o = off[k] ? 1u : 0u; sampleParityX |= ((tx + o) & 1u) << (i0 + k); sampleParityY |= ((ty + o) & 1u) << (i0 + k); }
                 di[k] = SAME_GRID ? ti[k]
-                                  : (uint32_t)(int)__builtin_amdgcn_fmed3f((cv + 0.5f) * dH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f((cu + 0.5f) * dW, 0.f, dWm1);
+                                  : (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfDH + halfDH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfDW + halfDW, 0.f, dWm1);
             }
             if (PACKED) {
                 uint4 t4[4];
@@ -251,8 +259,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const float qden = u2f(t4[k].w); // den / 4; <= 0: texel had a NaN component (skip)
-                    const float q = k0c + sv[k] * k1 + su[k] * k2;
-                    const float num = fabsf(c0x4 * qden + nf * q); // |c0 * den + nf * q|
+                    const float num = fabsf(c0x4 * qden + (k0n + sv[k] * k1n + su[k] * k2n)); // |c0 * den + nf * q|
                     // num and den are finite here (den < 0 marks a texel to skip, masked below): the hardware maximum replaces the NaN-aware one
                     float weight = __builtin_amdgcn_fmed3f(qden * rcpf(__builtin_fmaxf(num, 0.0004f * qden)), 0.f, 1.f);
                     weight *= weight;
@@ -279,8 +286,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 // depthLinear = nf / den with den = far + (1 - depth) * (near - far) > 0; the distance to the tangent plane is
                 // |c0 + depthLinear * q| = |c0 * den + nf * q| / den, so weight = clamp(0.25 * den / max(|c0 * den + nf * q|, 1e-4 * den))^2: one reciprocal
                 const float den = farP + (1.f - dep[k]) * nmf;
-                const float q = k0c + sv[k] * k1 + su[k] * k2;
-                const float num = fabsf(c0 * den + nf * q);
+                const float num = fabsf(c0 * den + (k0n + sv[k] * k1n + su[k] * k2n));
                 float weight = __builtin_amdgcn_fmed3f((0.25f * den) * rcpf(gmax(num, 0.0001f * den)), 0.f, 1.f);
                 weight *= weight;
                 vec4 sY(halfBitsToFloat(yt[k].x & 0xffffu), halfBitsToFloat(yt[k].x >> 16), halfBitsToFloat(yt[k].y & 0xffffu), halfBitsToFloat(yt[k].y >> 16));

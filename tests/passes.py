@@ -704,10 +704,11 @@ def orc_light_matrix(info_bytes, apex_min_max, global_packed, cascade_count, pad
 ATMOSPHERE_DEFAULT = struct.pack("<14f", 0.0058, 0.0135, 0.0331, 6371.0, 0.0058, 0.0135, 0.0331, 100.0, 0.000650, 0.001881, 0.000085, 0.006, 1.11 * 0.006, 0.76)  # Sky.h:6-15
 
 
-def gpu_sky_luts(be, atmosphere_bytes, light_bytes, global_packed, t_res=128, m_res=32, sky_w=200, sky_h=100):
-    """Sky::updateTransmissionLut + Sky::updateSkyLut (Techniques/Sky.cpp:260-316): bindings as recorded there"""
-    t = be.createImage(image_desc_2d(t_res, t_res, F.R11G11B10_uFloat))
-    m = be.createImage(image_desc_2d(m_res, m_res, F.R11G11B10_uFloat))
+def gpu_sky_luts(be, atmosphere_bytes, light_bytes, global_packed, t_res=128, m_res=32, sky_w=200, sky_h=100, given_transmission=None, given_multiscatter=None):
+    """Sky::updateTransmissionLut + Sky::updateSkyLut (Techniques/Sky.cpp:260-316): bindings as recorded there.
+    given_transmission / given_multiscatter: packed texels to upload instead of recording that LUT's pass (a later pass alone on known inputs)"""
+    t = be.createImage(image_desc_2d(t_res, t_res, F.R11G11B10_uFloat), None if given_transmission is None else np.ascontiguousarray(given_transmission))
+    m = be.createImage(image_desc_2d(m_res, m_res, F.R11G11B10_uFloat), None if given_multiscatter is None else np.ascontiguousarray(given_multiscatter))
     s = be.createImage(image_desc_2d(sky_w, sky_h, F.R11G11B10_uFloat))
     atm = be.createUniformBuffer(64, atmosphere_bytes)
     light = be.createStorageBuffer(20, light_bytes)
@@ -717,10 +718,12 @@ def gpu_sky_luts(be, atmosphere_bytes, light_bytes, global_packed, t_res=128, m_
     gb = global_binding(be)
     gb.set(global_packed)
     be.newFrame()
-    be.setComputePassExecution(ComputePassExecution(pt, RenderPassResources(storageImages=[ImageResource(t, 0, 0)], uniformBuffers=[UniformBufferResource(atm, 1)]), b"",
-                                                    (t_res // 8, t_res // 8, 1)))
-    be.setComputePassExecution(ComputePassExecution(pm, RenderPassResources(storageImages=[ImageResource(m, 0, 0)], sampledImages=[ImageResource(t, 0, 1)],
-                                                                            uniformBuffers=[UniformBufferResource(atm, 3)]), b"", (m_res // 8, m_res // 8, 1)))
+    if given_transmission is None:
+        be.setComputePassExecution(ComputePassExecution(pt, RenderPassResources(storageImages=[ImageResource(t, 0, 0)], uniformBuffers=[UniformBufferResource(atm, 1)]), b"",
+                                                        (t_res // 8, t_res // 8, 1)))
+    if given_multiscatter is None:
+        be.setComputePassExecution(ComputePassExecution(pm, RenderPassResources(storageImages=[ImageResource(m, 0, 0)], sampledImages=[ImageResource(t, 0, 1)],
+                                                                                uniformBuffers=[UniformBufferResource(atm, 3)]), b"", (m_res // 8, m_res // 8, 1)))
     be.setComputePassExecution(ComputePassExecution(ps, RenderPassResources(storageImages=[ImageResource(s, 0, 0)], sampledImages=[ImageResource(t, 0, 1), ImageResource(m, 0, 2)],
                                                                             uniformBuffers=[UniformBufferResource(atm, 4)], storageBuffers=[StorageBufferResource(light, True, 5)]),
                                                     b"", (sky_w // 8, sky_h // 8, 1)))
@@ -844,8 +847,10 @@ def _desc3d(w, h, d, fmt):
     return ImageDescription(width=w, height=h, depth=d, type=ImageType.Type3D, format=fmt, usageFlags=3, mipCount=MipCount.One)
 
 
-def gpu_volumetrics(be, fw, fh, fd, noise_u8, history_u16, shadow_map_u16, shadow_res, shadow_info, light_bytes, settings_bytes, global_packed):
-    """Volumetrics::computeVolumetricLighting (Techniques/Volumetrics.cpp:119-243): material -> scattering -> reprojection -> integration"""
+def gpu_volumetrics(be, fw, fh, fd, noise_u8, history_u16, shadow_map_u16, shadow_res, shadow_info, light_bytes, settings_bytes, global_packed, intermediates=True):
+    """Volumetrics::computeVolumetricLighting (Techniques/Volumetrics.cpp:119-243): material -> scattering -> reprojection -> integration.
+    intermediates=False: the material / scattering volumes are not downloaded (None in their place) - with pass fusion level 2 the fused per-froxel
+    launch does not write them"""
     global_binding(be).set(global_packed)
     mk = lambda data=None: be.createImage(_desc3d(fw, fh, fd, F.RGBA16_sFloat), data)
     material, scattering, target, history, integration = mk(), mk(), mk(), mk(np.ascontiguousarray(history_u16)), mk()
@@ -874,7 +879,7 @@ def gpu_volumetrics(be, fw, fh, fd, noise_u8, history_u16, shadow_map_u16, shado
                                                                             uniformBuffers=[UniformBufferResource(ub, 2)]), b"", (math.ceil(fw / 8.0), math.ceil(fh / 8.0), 1)))
     be.prepareForDrawcallRecording()
     be.renderFrame()
-    return [be.downloadImage(i, 0, np.uint16).copy() for i in (material, scattering, target, integration)]
+    return [be.downloadImage(i, 0, np.uint16).copy() if (intermediates or i in (target, integration)) else None for i in (material, scattering, target, integration)]
 
 
 def orc_volumetrics(fw, fh, fd, noise_u8, history_u16, shadow_map_u16, shadow_res, shadow_info, light_bytes, settings_bytes, global_packed):

@@ -158,6 +158,38 @@ def test_gpu_sky_luts_bit_exact(backend, sun):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sun", [(0.35, -0.8, 0.45), (0.9, -0.05, 0.1)])
+def test_gpu_fast_sky_luts_within_one_code(backend, sun):
+    """the PLR_MATH_FAST sky LUT kernels (kernels_fast/sky_fast.hip: a lane per march step, DPP prefix sums instead of the serial march) against the
+    oracle. Outputs are R11G11B10; the statement is per kernel: EVERY texel within one code per channel of the oracle's LUT when the pass reads the
+    LUTs the oracle reads (the later passes run alone on the oracle's transmission / multiscatter LUTs). The chain as the frame records it (the
+    sky LUT built from the FAST transmission LUT, whose texels are themselves up to one code - 3 % in blue - from the oracle's) is reported and
+    held to three codes."""
+    import parity
+    atm, light, gp = _sky_inputs(sun)
+    b = passes.orc_sky_luts(atm, light, gp)
+    backend.setMathMode(True)
+    try:
+        chain = passes.gpu_sky_luts(backend, atm, light, gp)
+        multiscatter_alone = passes.gpu_sky_luts(backend, atm, light, gp, given_transmission=b[0])[1]
+        sky_alone = passes.gpu_sky_luts(backend, atm, light, gp, given_transmission=b[0], given_multiscatter=b[1])[2]
+    finally:
+        backend.setMathMode(False)
+    def report(x, y, what):
+        d = parity.r11g11b10_code_diff(x.reshape(-1), y.reshape(-1))
+        zero_mismatch = int((((x == 0) != (y == 0))).sum())  # a ray that grazes the earth: transmission 0 on one side only
+        print("PRODUCER sky %-28s max_code_diff=%d differing=%.5f over_one=%.6f zero_mismatch=%d" % (what, int(d.max()), float((d != 0).any(axis=1).mean()),
+                                                                                                  float((d > 1).any(axis=1).mean()), zero_mismatch), flush=True)
+        return d
+    assert report(chain[0], b[0], "transmission").max() <= 1
+    assert report(multiscatter_alone, b[1], "multiscatter (oracle inputs)").max() <= 1
+    assert report(sky_alone, b[2], "sky (oracle inputs)").max() <= 1
+    assert report(chain[1], b[1], "multiscatter (fast chain)").max() <= 1
+    d = report(chain[2], b[2], "sky (fast chain)")
+    assert d.max() <= 3 and float((d > 1).any(axis=1).mean()) <= 0.01
+
+
+@pytest.mark.gpu
 def test_gpu_frame_with_compute_sky_luts(backend):
     """the frame graph with the three sky LUT passes recorded where Sky::updateTransmissionLut / updateSkyLut sit (RenderFrontend.cpp:348-350):
     the LUTs the exposure, trace and shade passes read are this frame's compute results (the sky LUT uses this frame's exposure)"""
@@ -224,6 +256,43 @@ def test_gpu_volumetrics_bit_exact(backend):
     b = passes.orc_volumetrics(*args)
     for x, y, what in zip(a, b, ("material", "scattering", "reprojection", "integration")):
         assert np.array_equal(x, y), what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [0, 1, 2])
+def test_gpu_fast_volumetrics_exact_front_and_integration_within_half_float_tolerance(backend, fusion):
+    """PLR_MATH_FAST: the three per-froxel passes keep the exact-order arithmetic (everything in them is discrete in the froxel position: the
+    shadow-map texel, the 8-bit sub-texel weights of the noise and history samples) and equal the oracle bit for bit - as three launches (pass
+    fusion off), as ONE launch that carries the texel from pass to pass in registers (fusion 1), and as that launch without the stores of the
+    material / scattering volumes (fusion 2: nothing else binds them). The front-to-back integration (kernels_fast/froxel_fast.hip: hardware exp,
+    one exponential per slice, loads ahead of the running sums) meets the half-float bound of tests/parity.py on every value - it has no decision
+    to flip."""
+    import parity
+    from plainrenderer_amd import pixfmt
+    args = _volumetric_inputs()
+    level = backend.getPassFusion()[0]
+    backend.setMathMode(True)
+    backend.setPassFusion(fusion)
+    try:
+        a = passes.gpu_volumetrics(backend, *args, intermediates=fusion < 2)
+        fused = backend.getPassFusion()[1]
+        if fusion == 2:  # the elided volumes cannot be read back: the backend says so instead of returning stale bytes
+            with pytest.raises(Exception):
+                passes.gpu_volumetrics(backend, *args, intermediates=True)
+    finally:
+        backend.setMathMode(False)
+        backend.setPassFusion(level)
+    assert fused == (3 if fusion else 0)
+    b = passes.orc_volumetrics(*args)
+    for x, y, what in zip(a[:3], b[:3], ("material", "scattering", "reprojection")):
+        assert x is None or np.array_equal(x, y), what
+    assert a[2] is not None
+    got, ref = pixfmt.unpack_half(a[3]).reshape(-1, 4), pixfmt.unpack_half(b[3]).reshape(-1, 4)
+    # inscattering (rgb) and transmittance (a) live on different scales: each against its own
+    bad = parity.half_violations(got[:, :3], ref[:, :3], floor_frac=2.0 ** -10) | parity.half_violations(got[:, 3:], ref[:, 3:], floor_frac=2.0 ** -10)
+    print("PRODUCER froxel fusion=%d fused_executions=%d integration violations=%d max_err=%.3g scale=%.3g" % (fusion, fused, int(bad.sum()), float(np.abs(got - ref).max()),
+                                                                                                          float(np.abs(ref).max())), flush=True)
+    assert not bad.any()
 
 
 @pytest.mark.gpu

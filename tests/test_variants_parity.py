@@ -124,3 +124,4 @@ def test_gpu_spatial_filter_on_a_full_resolution_grid_meets_the_bound(backend, v
     report("spatial%d full-res" % filter_index, sample_flip_rate=float(flipped.sum() / (32.0 * x.size)), clean_violations=int((bad & clean).sum()))
     assert not (bad & clean).any()
     assert flipped.sum() <= 1e-3 * 32 * x.size
+
