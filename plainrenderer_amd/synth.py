@@ -40,7 +40,11 @@ class Instances:
 
 
 class SynthScene:
-    def __init__(self, grid=16, cell=8.0, seed_id=100, device="cpu"):
+    def __init__(self, grid=16, cell=8.0, seed_id=100, device=None):
+        # device None: the GPU when there is one (the ray-marched G-buffer and shadow maps of a test scene take seconds on the host cores, and the GPU test
+        # suite builds dozens of them), else the CPU. The scene is the same up to the last bit of the torch kernels' sin / sqrt.
+        if device is None:
+            device = "cuda:0" if torch.cuda.is_available() else "cpu"
         self.grid, self.cell, self.device = grid, cell, torch.device(device)
         r = np.random.default_rng(SEED_BASE + seed_id)
         n = grid * grid

@@ -13,6 +13,10 @@ if os.path.join(ROOT, "oracle") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle splits the rows of a pass over std::threads (default 1); its results do not depend on the count (test_oracle_is_thread_count_invariant).
+    # Single-threaded, the oracle frames of the full-size parity tests were 3/4 of the GPU suite's 18 minutes.
+    import pyoracle
+    pyoracle.set_threads(max(1, min(os.cpu_count() or 1, 128)))
 
 
 @pytest.fixture(scope="session")

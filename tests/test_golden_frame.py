@@ -33,10 +33,21 @@ def load():
     return d, inputs, settings
 
 
-def test_oracle_replays_golden_frames():
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_oracle_replays_golden_frames(threads):
+    """... whatever number of std::threads it splits a pass's rows over (orc_set_threads; tests/conftest.py sets the host's core count for the suite:
+    single-threaded, the oracle frames of the full-size parity tests were three quarters of the GPU suite's run time)"""
+    import pyoracle
     from oracle_frame import OracleFrame
     d, inputs, settings = load()
-    ora = OracleFrame(inputs, gen.W, gen.H, gen.LUT, settings)
+    pyoracle.set_threads(threads)
+    try:
+        _replay(OracleFrame(inputs, gen.W, gen.H, gen.LUT, settings), d)
+    finally:
+        pyoracle.set_threads(max(1, min(os.cpu_count() or 1, 128)))
+
+
+def _replay(ora, d):
     for f in range(gen.N_FRAMES):
         ora.frame(d["f%d_globals" % f].tobytes(), d["f%d_weights" % f], d["f%d_frustum" % f].tobytes(), float(d["f%d_influence" % f][0]))
         assert ora.light == d["f%d_light" % f].tobytes(), "light buffer, frame %d" % f
