@@ -34,11 +34,12 @@ PLR_DI vec3 historyTap(const ImgView& im, float u, float v) {
     return top + (bot - top) * b;
 }
 
-// texelFetch of the motion buffer with the out-of-range test as a select instead of a branch per pixel row
+// texelFetch of the motion buffer with the out-of-range test as a mask on the loaded word (snorm 0 decodes to 0.0): neither a branch per pixel row
+// nor a select the compiler could turn back into one around the load
 PLR_DI vec4 motionFetch(const ImgView& im, int x, int y) {
     const bool inside = (uint32_t)x < (uint32_t)im.w && (uint32_t)y < (uint32_t)im.h;
-    const vec4 t = Texel<F_RG16SN>::load(im.ptr, fastm::texelIndex((uint32_t)clampi(x, im.w), (uint32_t)clampi(y, im.h), (uint32_t)im.w));
-    return vec4(inside ? t.x : 0.f, inside ? t.y : 0.f, inside ? t.z : 0.f, inside ? t.w : 0.f);
+    const uint32_t u = ((const uint32_t*)im.ptr)[fastm::texelIndex((uint32_t)clampi(x, im.w), (uint32_t)clampi(y, im.h), (uint32_t)im.w)] & (inside ? 0xffffffffu : 0u);
+    return vec4(decodeSnorm16((int32_t)(int16_t)(u & 0xffffu)), decodeSnorm16((int32_t)(int16_t)(u >> 16)), 0.f, inside ? 1.f : 0.f);
 }
 
 PLR_DI vec3 clipAABB(vec3 target, vec3 bbMin, vec3 bbMax) {
@@ -251,7 +252,7 @@ PLR_DI int waveMinI(int v) {
 }
 
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
-__global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
+__global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
                                                                  int coverW, int coverH, int yBase, TwoRanges ranges) {
     static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");
@@ -279,8 +280,10 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
     };
     auto loadRow = [&](int y) -> Column { return decodeRow(fetchRow(y)); };
     auto loadDepth = [&](int y) -> float { // raw depth, 0 outside the image (texelFetch)
-        const float dv = dep[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
-        return (xInDepth && y >= 0 && y < depthBuffer.h) ? dv : 0.f;
+        // the out-of-image case is a bit mask on the loaded word, not a select: a select lets the compiler sink the load into a branch of its own,
+        // with an s_waitcnt vmcnt(0) inside - the six depth rows of a strip were six serial round trips
+        const uint32_t bits = ((const uint32_t*)dep)[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
+        return u2f(bits & ((xInDepth && y >= 0 && y < depthBuffer.h) ? 0xffffffffu : 0u));
     };
 
     const ResolveWeights rw = *rwp;
@@ -301,15 +304,16 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
 #pragma unroll
             for (int j = 0; j < kStripRows + 2; j++) dw[j] = loadDepth(rowFirst - 1 + j); // all six depth rows at once
         }
+        // three passes over the strip's rows without a branch between them (a row below the dispatch is computed like the others and masked at the
+        // end): the four motion fetches depend on the depths only and go out together - with a wave-uniform `continue` per row the compiler kept
+        // each row's fetch and its s_waitcnt vmcnt(0) in a block of its own, four more serial round trips per strip
+        int ox[kStripRows], oy[kStripRows];
 #pragma unroll
         for (int j = 0; j < kStripRows; j++) {
-            const int py = rowFirst + j;
-            mvx[j] = mvy[j] = wa[j] = wb[j] = 0.f; fi[j] = fj[j] = 0;
-            if (py >= coverH) continue; // wave-uniform
             // closest (largest reverse-Z) depth of the 3x3, scanned x outer / y inner by the reference loop with a strict comparison from 0: the first
             // column whose maximum is the overall maximum (> 0), and in it the first row that reaches it. Every lane finds (maximum, first row) of its own
             // column; the neighbours' pairs come over DPP: 18 compares / selects / shifts instead of 36 on the nine depths
-            int ox = 0, oy = 0;
+            ox[j] = oy[j] = 0;
             if (DILATE) {
                 float cd = dw[j]; int cy = -1;
                 if (dw[j + 1] > cd) { cd = dw[j + 1]; cy = 0; }
@@ -317,16 +321,24 @@ __global__ __launch_bounds__(256) void temporalFilterStripKernel(ImgView current
                 const float ld = fromLeft(cd), rd = fromRight(cd);
                 const int ly = __builtin_bit_cast(int, fromLeft(__builtin_bit_cast(float, cy))), ry = __builtin_bit_cast(int, fromRight(__builtin_bit_cast(float, cy)));
                 float closest = 0.f;
-                if (ld > closest) { closest = ld; ox = -1; oy = ly; }
-                if (cd > closest) { closest = cd; ox = 0; oy = cy; }
-                if (rd > closest) { closest = rd; ox = 1; oy = ry; }
+                if (ld > closest) { closest = ld; ox[j] = -1; oy[j] = ly; }
+                if (cd > closest) { closest = cd; ox[j] = 0; oy[j] = cy; }
+                if (rd > closest) { closest = rd; ox[j] = 1; oy[j] = ry; }
             }
-            const vec4 m = motionFetch(motionBuffer, px + ox, py + oy);
-            mvx[j] = m.x; mvy[j] = m.y;
-            const float rpx = ((float)px + 0.5f) * tsx + m.x, rpy = ((float)py + 0.5f) * tsy + m.y;
+        }
+        vec4 m[kStripRows];
+#pragma unroll
+        for (int j = 0; j < kStripRows; j++) m[j] = motionFetch(motionBuffer, px + ox[j], rowFirst + j + oy[j]);
+#pragma unroll
+        for (int j = 0; j < kStripRows; j++) {
+            const int py = rowFirst + j;
+            const bool rowLive = py < coverH; // wave-uniform
+            mvx[j] = rowLive ? m[j].x : 0.f; mvy[j] = rowLive ? m[j].y : 0.f;
+            const float rpx = ((float)px + 0.5f) * tsx + m[j].x, rpy = ((float)py + 0.5f) * tsy + m[j].y;
             linearCoord(rpx * (float)hw, &fi[j], &wa[j]);
             linearCoord(rpy * (float)hh, &fj[j], &wb[j]);
-            if (isOutputLane) { iLo = min(iLo, fi[j]); iHi = min(iHi, -fi[j]); jLo = min(jLo, fj[j]); jHi = min(jHi, -fj[j]); }
+            if (!rowLive) { fi[j] = fj[j] = 0; wa[j] = wb[j] = 0.f; }
+            if (isOutputLane && rowLive) { iLo = min(iLo, fi[j]); iHi = min(iHi, -fi[j]); jLo = min(jLo, fj[j]); jHi = min(jHi, -fj[j]); }
         }
     }
     // bounding box of the footprints (texels i0 - 1 .. i0 + 2 of every pixel), staged if it fits
