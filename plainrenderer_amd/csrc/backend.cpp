@@ -231,6 +231,7 @@ struct Backend {
     bool pinnedBusy = false;
     uint32_t globalUbo = PLR_INVALID_INDEX;
     ImgView* bindlessDev = nullptr;
+    std::vector<ImgView> bindlessHost;   // what bindlessDev holds (PassCtx::bindlessHost)
     uint32_t bindlessCapacity = 0;
     bool bindlessDirty = true;
     uint64_t allocated = 0;
@@ -797,14 +798,15 @@ static int flushFills() {
 static int flushBindless() {
     if (!g->bindlessDirty) return PLR_OK;
     const uint32_t n = (uint32_t)g->images.size();
-    if (n == 0) { g->bindlessDirty = false; return PLR_OK; }
+    if (n == 0) { g->bindlessHost.clear(); g->bindlessDirty = false; return PLR_OK; }
     if (g->bindlessCapacity < n) {
         HIP_TRY(hipStreamSynchronize(g->stream));
         if (g->bindlessDev) hipFree(g->bindlessDev);
         g->bindlessCapacity = std::max(n * 2, 64u);
         HIP_TRY(hipMalloc((void**)&g->bindlessDev, sizeof(ImgView) * g->bindlessCapacity));
     }
-    std::vector<ImgView> table(n);
+    std::vector<ImgView>& table = g->bindlessHost;
+    table.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         if (g->images[i].dev) table[i] = makeView(g->images[i], 0);
         else { table[i].ptr = nullptr; table[i].w = table[i].h = table[i].d = 0; table[i].fmt = -1; }
@@ -949,6 +951,7 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     x.ctx.elidedStorage = 0;
     x.ctx.frameSerial = g->frameSerial;
     x.ctx.bindless = g->bindlessDev;
+    x.ctx.bindlessHost = g->bindlessHost.size() == g->images.size() ? g->bindlessHost.data() : nullptr;
     x.ctx.bindlessCount = (uint32_t)g->images.size();
     x.ctx.spec = &p.spec;
     x.ctx.err = &g_err;

@@ -32,6 +32,8 @@ struct PassCtx {
     // first pass): launchers that must decide on the host from a UBO field (the screen resolution) read it here; null if the host never filled it
     const GlobalUbo* globalHost = nullptr;
     const ImgView* bindless = nullptr;    // set 2 (device array of mip-0 views, indexed by global texture index)
+    const ImgView* bindlessHost = nullptr; // host copy of the same array (bindlessCount entries): a launcher that knows the index on the host - the frame's
+                                          // noise texture, from globalHost - passes the view as a kernel argument instead of two dependent loads per wave
     uint32_t bindlessCount = 0;
     ImgView sampled[kMaxBindings];
     ImgView storage[kMaxBindings];
@@ -67,6 +69,14 @@ struct PassCtx {
     // decision signatures (plr_debug_set_decision_signature, plr.h): when set, the kernels that support it write one word per output pixel
     uint32_t* debugSig = nullptr;
     size_t debugSigWords = 0;
+    // the frame's noise texture (noise.inc: global texture noiseTextureIndices[frameIndexMod4]) resolved on the host; false if the host does not know
+    // the global buffer's contents or the texture table (the kernel then chases the three pointers itself)
+    bool hostNoiseView(ImgView* out) const {
+        if (!globalHost || !bindlessHost || bindlessCount == 0) return false;
+        const uint32_t slot = (uint32_t)globalHost->noiseTextureIndices[globalHost->frameIndexMod4 & 3u];
+        *out = bindlessHost[slot < bindlessCount - 1u ? slot : bindlessCount - 1u];
+        return out->ptr != nullptr && out->w > 0 && out->h > 0;
+    }
     uint32_t* sigFor(size_t pixels) const { return debugSig && debugSigWords >= pixels ? debugSig : nullptr; }
 
     bool hasSampled(int b) const { return (sampledMask >> b) & 1u; }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
                                                                  uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
                                                                  uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig,
-                                                                 uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges) {
+                                                                 uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges, ImgView hostNoiseTex) {
     __shared__ RayInfo sharedRays[4][64];
     uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
@@ -235,8 +235,10 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         const vec3 ray = ld3(g->cameraForward) + (-g->cameraTanFovHalf * (v * 2.f - 1.f)) * ld3(g->cameraUp) +
                          (g->cameraTanFovHalf * g->cameraAspectRatio * (u * 2.f - 1.f)) * ld3(g->cameraRight);
         const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
-        const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
-        const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
+        // the launcher resolves the frame's noise texture on the host when it can (PassCtx::hostNoiseView): frame index -> texture index -> view
+        // are three dependent round trips in front of the ray direction otherwise
+        ImgView noiseTex = hostNoiseTex;
+        if (!noiseTex.ptr) noiseTex = bindless[min((uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u], bindlessCount - 1u)]; // uniform
         // exact UNORM8 decode (c / 255, an IEEE quotient in this file): a noise value of 255 must be exactly 1 - then sinTheta is exactly 0 and L = N, and
         // for a horizontal N the sky LUT's v coordinate sits on its sqrt-steep horizon, where 2e-4 rad of direction is half a LUT row
         const uint32_t nzTexel = ((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)];
@@ -373,7 +375,9 @@ static int launchImpl(const PassCtx& c) {
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
-                       tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
+                       tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges, hostNoise
+    ImgView hostNoise{};
+    if (!c.hostNoiseView(&hostNoise)) hostNoise = ImgView{};
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     // the spatial filter that reads this pass's output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;

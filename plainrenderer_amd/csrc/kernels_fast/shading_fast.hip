@@ -171,6 +171,7 @@ struct ShadeParams {
     uint32_t cascadeCount;
     int coverW, coverH, yBase;
     uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
+    ImgView noiseTex; // the frame's noise texture when the launcher could resolve it on the host (PassCtx::hostNoiseView), else ptr == nullptr
 };
 
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
@@ -312,8 +313,9 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     const float NoV = fmax1(fabsf(dot(N, V)), 0.0001f);
     const vec3 f0 = vmix(vec3(0.04f), albedo, metalic);
 
-    const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
-    const ImgView noiseTex = P.bindless[min(noiseSlot, P.bindlessCount - 1u)];
+    // frame index -> texture index -> view -> texel is four dependent round trips in front of the PCF taps when the kernel chases them itself
+    ImgView noiseTex = P.noiseTex;
+    if (!noiseTex.ptr) noiseTex = P.bindless[min((uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u], P.bindlessCount - 1u)]; // uniform
     const vec2 noiseTexel = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
 
     int cascadeIndex = 0;
@@ -620,6 +622,7 @@ static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, 
     P.light = (const LightBuffer*)c.sbuf[7].ptr; P.shadowInfo = (const ShadowCascadeInfo*)c.sbuf[8].ptr;
     P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
+    if (!c.hostNoiseView(&P.noiseTex)) P.noiseTex = ImgView{};
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
     P.sig = c.sigFor((size_t)P.color.w * (size_t)P.color.h);

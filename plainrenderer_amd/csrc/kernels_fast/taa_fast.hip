@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     const int hw = historySrc.w, hh = historySrc.h;
 
     // ---- phase A: where do the strip's pixels reproject to? (motion vector at the closest depth of the 3x3, temporalFilter.comp:93-117)
-    const uint32_t raw0 = fetchRow(rowFirst - 1), raw1 = fetchRow(rowFirst); // the resolve's first two colour rows: in flight through phase A
+    // all six colour rows of the strip's resolve: in flight through phase A (rows clamp to the image, so rows below the dispatch load something valid)
+    uint32_t raw[kStripRows + 2];
+#pragma unroll
+    for (int j = 0; j < kStripRows + 2; j++) raw[j] = fetchRow(rowFirst - 1 + j);
     float mvx[kStripRows], mvy[kStripRows], wa[kStripRows], wb[kStripRows]; // motion, sub-texel weights of the footprint
     int fi[kStripRows], fj[kStripRows];                                     // i0, j0 of the footprint (texels i0 - 1 .. i0 + 2)
     int iLo = 0x7fffffff, iHi = 0x7fffffff, jLo = 0x7fffffff, jHi = 0x7fffffff; // min of i0, min of -i0, ...: one kind of reduction
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
 
     // ---- phase B: the resolve. Three-row window: C[0] = row y-1, C[1] = row y, C[2] = row y+1; L / R = the neighbour lanes' columns
     Column C[3], L[3], R[3];
-    C[0] = decodeRow(raw0); C[1] = decodeRow(raw1);
+    C[0] = decodeRow(raw[0]); C[1] = decodeRow(raw[1]);
     L[0] = shiftFromLeft(C[0]); R[0] = shiftFromRight(C[0]);
     L[1] = shiftFromLeft(C[1]); R[1] = shiftFromRight(C[1]);
 
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     for (int j = 0; j < kStripRows; j++) {
         const int py = rowFirst + j;
         if (py >= coverH) break; // wave-uniform
-        C[2] = loadRow(py + 1);
+        C[2] = decodeRow(raw[j + 2]);
         L[2] = shiftFromLeft(C[2]); R[2] = shiftFromRight(C[2]);
 
         // n[x+1][y+1] of the reference: x = -1 -> L, 0 -> C, +1 -> R; y = -1..1 -> window row 0..2
