@@ -24,7 +24,8 @@ namespace plr {
 namespace fastshade {
 
 #ifndef PLR_SHADE_WAVES
-#define PLR_SHADE_WAVES 4 // 128 VGPRs, no scratch (5 waves = 96 VGPRs spills after the load-pairing rewrite)
+#define PLR_SHADE_WAVES 5 // <= 96 VGPRs. Measured with the uniform blocks on scalar loads (PLR_SHADE_UNIFORM_PARAMS below), fused upscale + shade at 4K: 5 waves (90 VGPRs, no
+                          // scratch) 216 us; 4 waves (the allocator then takes 106) 243 us; 6 waves (80 VGPRs, 9 spilled) 253 us
 #endif
 
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -173,6 +174,15 @@ struct ShadeParams {
     uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
     ImgView noiseTex; // the frame's noise texture when the launcher could resolve it on the host (PassCtx::hostNoiseView), else ptr == nullptr
 };
+
+// The four uniform blocks a shade kernel reads are ALSO passed as top-level `const T* __restrict__` kernel arguments, and the kernel puts those into
+// its copy of ShadeParams. A pointer inside a by-value struct carries no aliasing information, so every load of a uniform field was a VECTOR
+// load (a register per dword and lane for a value all lanes share); through a noalias argument the compiler proves the memory is not written by
+// the kernel and issues scalar loads into SGPRs.
+#define PLR_SHADE_UNIFORM_PARAMS const GlobalUbo* __restrict__ gUniform, const LightBuffer* __restrict__ lightUniform, const ShadowCascadeInfo* __restrict__ shadowUniform, \
+                                 const VolumetricLightingSettings* __restrict__ volUniform
+#define PLR_SHADE_ADOPT_UNIFORMS(P) do { (P).g = gUniform; (P).light = lightUniform; (P).shadowInfo = shadowUniform; (P).vol = volUniform; } while (0)
+#define PLR_SHADE_UNIFORM_ARGS(P) (P).g, (P).light, (P).shadowInfo, (P).vol
 
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
     x = clampi(x, normalTexture.w);
@@ -415,7 +425,8 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
 }
 
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
-__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P) {
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P, PLR_SHADE_UNIFORM_PARAMS) {
+    PLR_SHADE_ADOPT_UNIFORMS(P);
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= P.coverW || py >= P.coverH) return;
@@ -472,7 +483,8 @@ struct GiTexel { float depthLinear, y0, y1, y2, y3, co, cg, pad; };
 static_assert(sizeof(GiTexel) == 32, "two 16-byte LDS reads per texel");
 
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA>
-__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(ShadeParams P, FusedUpscale U) {
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(ShadeParams P, FusedUpscale U, PLR_SHADE_UNIFORM_PARAMS) {
+    PLR_SHADE_ADOPT_UNIFORMS(P);
     __shared__ GiTexel tile[kGiTileH][kGiTileW];
     const int t = (int)threadIdx.x;
     const int X0 = (int)(blockIdx.x * 64u), Y0 = P.yBase + (int)(blockIdx.y * 4u); // both even
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
     if (P.sig) P.sig[idx] = sigWord | (upSig << 8); // decision signature of the fused launch: the shade's word | the upscale's word << 8
 }
 
-typedef void (*ShadeKernel)(ShadeParams);
+typedef void (*ShadeKernel)(ShadeParams, const GlobalUbo*, const LightBuffer*, const ShadowCascadeInfo*, const VolumetricLightingSettings*);
 template <int D, int M, bool G> static ShadeKernel pickIndirect(int tech) {
     return tech == 0 ? (ShadeKernel)deferredShadingFastKernel<D, M, G, 0> : (ShadeKernel)deferredShadingFastKernel<D, M, G, 1>;
 }
@@ -576,7 +588,7 @@ template <int D> static ShadeKernel pickMulti(int m, bool aa, int tech) {
         default: return pickAA<D, 3>(aa, tech);
     }
 }
-typedef void (*FusedKernel)(ShadeParams, FusedUpscale);
+typedef void (*FusedKernel)(ShadeParams, FusedUpscale, const GlobalUbo*, const LightBuffer*, const ShadowCascadeInfo*, const VolumetricLightingSettings*);
 template <int D, int M> static FusedKernel pickFusedAA(bool aa) { return aa ? (FusedKernel)upscaleAndShadeKernel<D, M, true> : (FusedKernel)upscaleAndShadeKernel<D, M, false>; }
 template <int D> static FusedKernel pickFusedMulti(int m, bool aa) {
     switch (m) {
@@ -643,7 +655,7 @@ static int launchDeferredShadingFast(const PassCtx& c) {
         default: k = pickMulti<3>(multi, aa, tech); break;
     }
     if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
+    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, PLR_SHADE_UNIFORM_ARGS(P));
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -688,7 +700,7 @@ static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
         case 2: k = pickFusedMulti<2>(multi, aa); break;
         default: k = pickFusedMulti<3>(multi, aa); break;
     }
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U);
+    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U, PLR_SHADE_UNIFORM_ARGS(P));
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
