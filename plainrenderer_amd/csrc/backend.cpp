@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <set>
+#include <unordered_map>
+#include <unordered_set>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -275,6 +277,9 @@ struct Backend {
     void* globalCopies[2] = {nullptr, nullptr}; // rotating device copies of the global uniform buffer: a tail that still reads frame N's must not see frame N + 1's fill
     uint32_t globalCopyIndex = 0;
     std::set<std::string> fusedNames;    // stable storage for the timing labels of fused launches
+    // content versions of image allocations (backend.h contentVersionOf): key = allocation base; absent = not seen yet (gets a version on first query)
+    std::unordered_map<const void*, uint64_t> contentVersion;
+    std::unordered_set<const void*> externallyWritable; // allocations whose address was handed out: never cached
 };
 
 // A thread that calls plr_setup owns its backend: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
@@ -330,6 +335,30 @@ static bool hazardWithTail(const std::vector<Access>& access) {
     return false;
 }
 
+// ---- content versions (backend.h contentVersionOf)
+static uint64_t nextContentVersion() { static std::atomic<uint64_t> counter{0}; return ++counter; }
+static void touchAllocation(const void* base) { if (g && base) g->contentVersion[base] = nextContentVersion(); }
+static void touchAccesses(const std::vector<Access>& access) {
+    for (const Access& a : access) if (a.write && a.key != kBindlessKey) touchAllocation(a.key);
+}
+uint64_t contentVersionOf(const void* base) {
+    if (!g || !base || g->externallyWritable.count(base)) return 0;
+    bool ours = false;
+    for (const ImageRes& im : g->images) if (im.dev == base) { ours = true; break; }
+    if (!ours) for (const ImageRes& im : g->transient) if (im.dev == base) { ours = true; break; }
+    if (!ours) return 0;
+    auto it = g->contentVersion.find(base);
+    if (it == g->contentVersion.end()) it = g->contentVersion.emplace(base, nextContentVersion()).first;
+    return it->second;
+}
+
+// a raw device address was written (plr_write / copy_device_memory): the image allocation it lies in, if any, has new contents
+static void touchAddress(const void* p) {
+    auto inside = [&](const ImageRes& im) { return im.dev && (const uint8_t*)p >= (const uint8_t*)im.dev && (const uint8_t*)p < (const uint8_t*)im.dev + im.bytes; };
+    for (const ImageRes& im : g->images) if (inside(im)) { touchAllocation(im.dev); return; }
+    for (const ImageRes& im : g->transient) if (inside(im)) { touchAllocation(im.dev); return; }
+}
+
 static uint32_t mipCountFromResolution(uint32_t w, uint32_t h, uint32_t d) {
     // Common/Utilities/MathUtils.cpp:17-19
     uint32_t m = std::max(std::max(w, h), d);
@@ -367,11 +396,12 @@ static int allocImage(ImageRes& im, const plr_image_desc& d) {
     HIP_TRY(hipMalloc(&im.dev, im.bytes));
     HIP_TRY(hipMemsetAsync(im.dev, 0, im.bytes, g->stream));
     g->allocated += im.bytes;
+    touchAllocation(im.dev);
     return PLR_OK;
 }
 
 static void freeImage(ImageRes& im) {
-    if (im.dev) { hipFree(im.dev); g->allocated -= im.bytes; }
+    if (im.dev) { hipFree(im.dev); g->allocated -= im.bytes; g->contentVersion.erase(im.dev); g->externallyWritable.erase(im.dev); }
     im.dev = nullptr; im.bytes = 0; im.mips.clear();
 }
 
@@ -534,6 +564,7 @@ int plr_copy_device_memory(void* dst, const void* src, size_t size) {
     if (size == 0) return PLR_OK;
     if (!dst || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, g->stream));
+    touchAddress(dst);
     return PLR_OK;
 }
 int plr_read_device_memory(void* dst_host, const void* src, size_t size) {
@@ -550,6 +581,7 @@ int plr_write_device_memory(void* dst, const void* src_host, size_t size) {
     if (!dst || !src_host) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_write_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src_host, size, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    touchAddress(dst);
     return PLR_OK;
 }
 
@@ -968,6 +1000,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     g->currentPassName = p.name.c_str();
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
+    touchAccesses(x.access); // the images it writes have new contents from here on (contentVersionOf)
     int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
     if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
     if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
@@ -1017,6 +1050,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
             if (int trc = beginSegment(label)) return trc;
         }
         g->currentPassName = label ? label : f.label.c_str();
+        for (size_t k = 0; k < n; k++) touchAccesses(g->executions[i + k].access);
         const int rc = f.fn(ctxs, n);
         if (rc == kUseGeneralKernel) {
             if (timed) { g->segments.pop_back(); g->eventsUsed -= 1; } // the opening event stays recorded on the stream; its slot is reused
@@ -1118,6 +1152,8 @@ static int launchAll(bool timed) {
             tailOpen = false;
             g->curStream = g->stream;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
+            if (x.callbackAccessKnown) touchAccesses(x.access);
+            else g->contentVersion.clear(); // may have written anything: every image gets a new version at its next query
             const int crc = x.callback(x.callbackUser, (void*)g->stream);
             if (crc) return setErr(crc, "host callback '" + std::string(x.callbackName) + "' failed with code " + std::to_string(crc));
             if (timed) if (int rc = endSegment()) return rc;
@@ -1488,6 +1524,7 @@ int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* dat
     if (size != mi->bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "upload size " + std::to_string(size) + " != mip size " + std::to_string(mi->bytes));
     HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset, data, size, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    touchAllocation(im->dev);
     return PLR_OK;
 }
 
@@ -1503,6 +1540,7 @@ int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t r
     if (size == 0) return PLR_OK;
     HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset + rowBytes * row_begin, data, size, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
+    touchAllocation(im->dev);
     return PLR_OK;
 }
 
@@ -1543,6 +1581,7 @@ int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, voi
     if (rc) return rc;
     *out_ptr = (uint8_t*)im->dev + mi->offset;
     if (out_size) *out_size = mi->bytes;
+    g->externallyWritable.insert(im->dev); // the caller may write through the pointer at any time: nothing derived from this image is cached any more
     return PLR_OK;
 }
 

@@ -162,6 +162,14 @@ struct ConsumerLinkRegistrar {
 // a launcher that did (part of) another pass's work / found its own pre-pass already done reports it: plr_get_pass_fusion's counter
 void countFusedExecutions(uint32_t n);
 
+// Content version of an image allocation (allocationBase = the address of its mip 0), for launchers that keep DERIVED copies of an input in their
+// scratch memory (the deferred shade: PCF tap table by noise-texel position, kernels_fast/shading_fast.hip). The value changes whenever the backend
+// knows the contents may have changed: creation / resize, plr_upload_image*, plr_write / copy_device_memory into it, an execution or a host callback
+// that binds it for writing (counted when that execution is launched, i.e. in recorded order), a host callback recorded without a resource list
+// (then every version changes). 0 = do not cache: the allocation's address was handed out (plr_get_image_device_pointer) and may be written
+// behind the backend's back, or the address is not an image of this backend.
+uint64_t contentVersionOf(const void* allocationBase);
+
 inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // records the message plr_last_error() returns on this thread; returns code

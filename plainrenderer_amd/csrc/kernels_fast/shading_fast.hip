@@ -17,7 +17,9 @@
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
 #include "upscale_quad.h"
+#include "pcf_taps.h"
 #include <type_traits>
+#include <map>
 
 namespace plr {
 
@@ -137,28 +139,41 @@ PLR_DI float sRGBToLinear1(float c) {
     return c <= 0.004045f ? lin : pw;
 }
 
-// bilinear RGBA16F fetch with clamp-to-edge; the two texels of a row come from one 16-byte load (a load instruction costs the
-// texture addresser the same whatever its width)
+// one RGBA16F texel's four channels times a weight, accumulated: the halves go straight into v_fma_mix_f32 (fp16 operands are converted inside the
+// instruction: no v_cvt_f32_f16 per channel, no shift for the upper half - the operand select does it)
+PLR_DI _Float16 halfLo(uint32_t w) { return __builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+PLR_DI _Float16 halfHi(uint32_t w) { return __builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+PLR_DI vec4 accumulateTexel(vec4 acc, uint32_t xy, uint32_t zw, float w) {
+    return vec4(__builtin_fmaf((float)halfLo(xy), w, acc.x), __builtin_fmaf((float)halfHi(xy), w, acc.y), __builtin_fmaf((float)halfLo(zw), w, acc.z),
+                __builtin_fmaf((float)halfHi(zw), w, acc.w));
+}
+// Column pair of a clamp-to-edge linear fetch: texels x0 = clamp(i0), x1 = clamp(i0 + 1) always lie in the pair (xb, xb + 1) with xb = clamp(i0, 0, w - 2),
+// which one 16-byte load fetches (a load instruction costs the texture addresser the same whatever its width). Inside the image the pair IS
+// (x0, x1); at the left edge (i0 < 0) both are texel 0 = the pair's first -> weight 0; at the right edge (i0 >= w - 1) both are texel w - 1 = the
+// pair's second -> weight 1. One med3 on the weight replaces a select per fetched dword (round 3: 8 selects per LUT fetch, 32 per froxel fetch).
+PLR_DI void edgePair(int i0, float a, int w, int* xb, float* a2) {
+    *xb = clampTo(i0, w - 2);
+    *a2 = __builtin_amdgcn_fmed3f(a + (float)(i0 - *xb), 0.f, 1.f);
+}
+
+// bilinear RGBA16F fetch with clamp-to-edge, weights as the sampler contract states them (image.h sampleLinear2D): w00 = (1-a)(1-b), ...
 PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
     int i0, j0; float a, b;
     linearCoord(u * (float)im.w, &i0, &a);
     linearCoord(v * (float)im.h, &j0, &b);
-    const int x0 = clampi(i0, im.w), x1 = clampi(i0 + 1, im.w), y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
-    const int xb = clampTo(x0, im.w - 2);
-    auto rowPair = [&](int y, vec4* t0, vec4* t1) {
-        const uint2* row = (const uint2*)im.ptr + __umul24((uint32_t)y, (uint32_t)im.w);
-        uint4 q; // the launcher sends images narrower than two texels to the general kernel
-        __builtin_memcpy(&q, row + xb, 16);
-        const uint2 lo = make_uint2(q.x, q.y), hi = make_uint2(q.z, q.w);
-        const uint2 e0 = x0 == xb ? lo : hi, e1 = x1 == xb ? lo : hi;
-        *t0 = vec4(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
-        *t1 = vec4(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
-    };
-    vec4 t00, t10, t01, t11;
-    rowPair(y0, &t00, &t10);
-    rowPair(y1, &t01, &t11);
-    const vec4 top = t00 + (t10 - t00) * a, bot = t01 + (t11 - t01) * a;
-    return top + (bot - top) * b;
+    int xb; float a2;
+    edgePair(i0, a, im.w, &xb, &a2); // the launcher sends images narrower than two texels to the general kernel
+    const int y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
+    uint4 q0, q1;
+    __builtin_memcpy(&q0, (const uint2*)im.ptr + __umul24((uint32_t)y0, (uint32_t)im.w) + xb, 16);
+    __builtin_memcpy(&q1, (const uint2*)im.ptr + __umul24((uint32_t)y1, (uint32_t)im.w) + xb, 16);
+    const float a0 = 1.f - a2, b0 = 1.f - b;
+    vec4 r(0.f);
+    r = accumulateTexel(r, q0.x, q0.y, a0 * b0);
+    r = accumulateTexel(r, q0.z, q0.w, a2 * b0);
+    r = accumulateTexel(r, q1.x, q1.y, a0 * b);
+    r = accumulateTexel(r, q1.z, q1.w, a2 * b);
+    return r;
 }
 
 struct ShadeParams {
@@ -173,6 +188,10 @@ struct ShadeParams {
     int coverW, coverH, yBase;
     uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
     ImgView noiseTex; // the frame's noise texture when the launcher could resolve it on the host (PassCtx::hostNoiseView), else ptr == nullptr
+    const float4* pcfTaps; // [256][6] float4 = [noise byte][tap] {x, y}: unit-disc tap offsets (pcf_taps.h)
+    // the same rows re-indexed by the POSITION of the frame's noise texel and transposed, [6][pcfPositions] float4, or null (shadeDerivedTables below)
+    const float4* pcfTapsByPosition;
+    uint32_t pcfPositions;
 };
 
 // The four uniform blocks a shade kernel reads are ALSO passed as top-level `const T* __restrict__` kernel arguments, and the kernel puts those into
@@ -184,30 +203,27 @@ struct ShadeParams {
 #define PLR_SHADE_ADOPT_UNIFORMS(P) do { (P).g = gUniform; (P).light = lightUniform; (P).shadowInfo = shadowUniform; (P).vol = volUniform; } while (0)
 #define PLR_SHADE_UNIFORM_ARGS(P) (P).g, (P).light, (P).shadowInfo, (P).vol
 
-PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
-    x = clampi(x, normalTexture.w);
-    y = clampi(y, normalTexture.h);
-    const vec3 raw = fastm::unorm8x4(((const uint32_t*)normalTexture.ptr)[fastm::texelIndex((uint32_t)x, (uint32_t)y, (uint32_t)normalTexture.w)]).xyz() * 2.f - 1.f;
-    const vec3 N = nrm(raw);
-    return anyNan(N) ? raw : N;
-}
-
-// 12-tap rotated-disc PCF (lightingFunctions / shadow sampling of the shader). Per tap the shader evaluates
+// 12-tap rotated-disc PCF (calcShadow, triangle.frag:92-120). Per tap the shader evaluates
 //   d = sqrt((i + noise/2) / 12), angle = 2 pi (i / 12 + noise), uv = base + (cos, sin)(angle) * 0.03 * lightSpaceScale * d,
 //   nearest fetch with a black border, shadow += actualDepth >= texel.
 // The light-space position (matrix product, perspective division) is the shader's, operation by operation (see the file header), and so
 // is the comparison: a D16 texel t decodes to fl(t / 65535) (IEEE quotient), so "actualDepth >= texel" is "t <= T" with
 // T = max{t : fl(t / 65535) <= actualDepth}, found once per pixel from the guess floor(actualDepth * 65535) (off by at most one) and two
-// correctly rounded quotients. The taps themselves are restructured for issue count (the kernel is bound by VALU issue): the twelve
-// directions are the noise rotation turned by multiples of 30 degrees, so they come from four products (c0, s0 times cos 30 / sin 30) and
-// four sums; the texel-space scale is folded into the per-tap radius; the border test is two unsigned compares on the floored texel
-// coordinate. (A tap position differs from the shader's by ~1e-5 texels - hardware sin / cos - which picks another texel for ~1e-5 of the taps.)
-PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMatrix, vec2 lightSpaceScale, float noise) {
+// correctly rounded quotients.
+// Round 4, the taps (the kernel is bound by VALU issue; 12 taps were a quarter of its instructions):
+//  * (cos, sin)(angle) d comes from the tap table (pcf_taps.h: the oracle's arithmetic for the 256 noise values): a tap position is two fused
+//    multiply-adds instead of a square root, four products and its share of a hardware sine / cosine and their rotation;
+//  * the cascade - shadow map, light matrix, scale - is WAVE-UNIFORM here (the caller loops over the cascades present in its wave, almost always
+//    one): matrix and scale sit in scalar registers instead of sixteen gathered vector registers, and the map is read through a buffer
+//    resource whose range check implements the black border for the rows (an offset outside [0, 2 w h) returns 0 = "lit"); columns outside
+//    [0, w) get the offset ~0. No index clamps, one compare for the border instead of two and a select, 32-bit offsets.
+// `taps` = the pixel's row of the tap table (two taps per float4); m = lightMatrices[cascade] (uniform).
+struct PcfTapRow { float4 q[kPcfTaps / 2]; };
+PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* __restrict__ m, float lssX, float lssY, const PcfTapRow& taps) {
     float cxy0, cxy1; // tap centre, uv
     uint32_t depthThreshold;
     {
 #pragma clang fp contract(off)
-        const float* m = lightMatrix;
         const float x = ((m[0] * pos.x + m[4] * pos.y) + m[8] * pos.z) + m[12];
         const float y = ((m[1] * pos.x + m[5] * pos.y) + m[9] * pos.z) + m[13];
         const float z = ((m[2] * pos.x + m[6] * pos.y) + m[10] * pos.z) + m[14];
@@ -221,35 +237,26 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
         const float q1 = divRNr((float)(t0 + 1u), 65535.f, r16), q0 = divRNr((float)t0, 65535.f, r16);
         depthThreshold = q1 <= actualDepth ? t0 + 1u : (q0 <= actualDepth ? t0 : t0 - 1u); // t0 = 0 always passes its own test: no wrap
     }
-    const float fw = (float)shadowMap.w, fh = (float)shadowMap.h;
-    const float bxw = cxy0 * fw, byh = cxy1 * fh; // tap centre in texels
-    const float sxw = 0.03f * lightSpaceScale.x * fw, syh = 0.03f * lightSpaceScale.y * fh;
-    const float s0 = __builtin_amdgcn_sinf(noise), c0 = __builtin_amdgcn_cosf(noise); // v_sin/v_cos take revolutions: angle = noise * 2 pi
-    // directions i * 30 degrees + noise rotation
-    const float k = 0.8660254f;
-    const float ck = c0 * k, sh = s0 * 0.5f, ch = c0 * 0.5f, sk = s0 * k;
-    const uint16_t* sm = (const uint16_t*)shadowMap.ptr;
-    const uint32_t w = (uint32_t)shadowMap.w, h = (uint32_t)shadowMap.h;
-    const int wm1 = shadowMap.w - 1, hm1 = shadowMap.h - 1;
+    const int w = shadowMap.w, h = shadowMap.h; // uniform
+    const float fw = (float)w, fh = (float)h;
+    // tap centre in texels, kept inside +-1e6 (a NaN becomes -1e6): the texel coordinates then fit the 24-bit multiply below, and a centre that
+    // far outside the map has all its taps on the border either way
+    const float bxw = fastm::clampCoord(cxy0 * fw), byh = fastm::clampCoord(cxy1 * fh);
+    const float sxw = 0.03f * lssX * fw, syh = 0.03f * lssY * fh; // uniform
+    const __amdgpu_buffer_rsrc_t map = __builtin_amdgcn_make_buffer_rsrc(shadowMap.ptr, 0, w * h * 2, 0x00020000); // raw buffer, 32-bit data format
     uint32_t lit = 0u;
-    // (a second copy of the tap loop without the border test and the index clamps, for waves whose discs lie inside the map, was measured: 249 us
-    //  against 245 us for the fused launch at 4K - the six half-rate instructions per tap are not what the kernel waits for)
-    auto tap = [&](int i, float cx, float cy) {
-        const float d = sqrtv(((float)i + 0.5f * noise) * (1.f / 12.f));
-        const float tu = bxw + cx * (sxw * d), tv = byh + cy * (syh * d);
-        const int xi = floorToInt(tu), yi = floorToInt(tv);
-        const bool inside = (uint32_t)xi < w && (uint32_t)yi < h; // black border outside: depth 0, always "lit"
-        const uint32_t x = (uint32_t)clampTo(xi, wm1), y = (uint32_t)clampTo(yi, hm1);
-        const uint32_t texel = sm[fastm::texelIndex(x, y, w)];
-        lit += ((inside ? texel : 0u) <= depthThreshold) ? 1u : 0u;
+    auto tap = [&](float ox, float oy) {
+        const int xi = floorToInt(__builtin_fmaf(ox, sxw, bxw)), yi = floorToInt(__builtin_fmaf(oy, syh, byh));
+        const int t = __mul24(yi, w) + xi; // v_mad_i32_i24; rows outside [0, h) give offsets outside [0, 2 w h): the range check returns 0
+        const uint32_t off = (uint32_t)xi < (uint32_t)w ? (uint32_t)(t + t) : 0xffffffffu;
+        const uint32_t texel = __builtin_amdgcn_raw_buffer_load_b16(map, (int)off, 0, 0);
+        lit += texel <= depthThreshold ? 1u : 0u;
     };
-    // taps i and i + 6 point in opposite directions
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const float cx = i == 0 ? c0 : i == 1 ? ck - sh : i == 2 ? ch - sk : i == 3 ? -s0 : i == 4 ? -ch - sk : -ck - sh;
-        const float cy = i == 0 ? s0 : i == 1 ? sk + ch : i == 2 ? sh + ck : i == 3 ? c0 : i == 4 ? ck - sh : ch - sk;
-        tap(i, cx, cy);
-        tap(i + 6, -cx, -cy);
+    for (int k = 0; k < kPcfTaps / 2; k++) {
+        const float4 q = taps.q[k];
+        tap(q.x, q.y);
+        tap(q.z, q.w);
     }
     return (float)lit * (1.f / 12.f);
 }
@@ -283,10 +290,11 @@ struct PixelInputs {
     uint2 ysh;                         // indirectDiffuse_Y_SH texel (RGBA16F)
     uint32_t cocg;                     // indirectDiffuse_CoCg texel (RG16F)
 };
+// normalize() of the decoded G-buffer normal; the all-zero texel (the only one whose normalisation is NaN: the exact kernel then keeps the raw
+// vector) stays zero through the clamp of the squared length - one v_max instead of three compares and three selects
 PLR_DI vec3 decodeNormal(uint32_t texel) {
     const vec3 raw = fastm::unorm8x4(texel).xyz() * 2.f - 1.f;
-    const vec3 N = nrm(raw);
-    return anyNan(N) ? raw : N;
+    return raw * rsqf(fmax1(dot(raw, raw), 1e-30f));
 }
 
 // one geometry pixel (depth != 0) of the deferred shade: returns the R11G11B10 colour; *sigWord = decision signature (oracle/oracle.h)
@@ -326,21 +334,46 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     // frame index -> texture index -> view -> texel is four dependent round trips in front of the PCF taps when the kernel chases them itself
     ImgView noiseTex = P.noiseTex;
     if (!noiseTex.ptr) noiseTex = P.bindless[min((uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u], P.bindlessCount - 1u)]; // uniform
-    const vec2 noiseTexel = fastm::unorm8x2(((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)]);
+    const uint32_t noiseIndex = fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w);
+    const uint32_t noiseWord = ((const uint16_t*)noiseTex.ptr)[noiseIndex];
+    const vec2 noiseTexel = fastm::unorm8x2(noiseWord);
+    const uint32_t noiseByte = noiseWord & 0xffu;
 
     int cascadeIndex = 0;
 #pragma unroll
     for (int cascade = 0; cascade < 3; cascade++) cascadeIndex += (cascade < (int)P.cascadeCount - 1 && pixelDepth >= P.shadowInfo->splits[cascade]) ? 1 : 0;
-    const vec2 lss(P.shadowInfo->lightSpaceScale[cascadeIndex][0], P.shadowInfo->lightSpaceScale[cascadeIndex][1]);
-    // one instance of the PCF loop: the cascade only selects which image view and matrix it reads
-    ImgView shadowMap = P.shadowMaps[0]; // field-wise selects (the cascade differs between the pixels of a wave)
+    // The PCF runs once per cascade PRESENT in the wave (the cascade is a function of the view depth: a 64-pixel row segment almost always has one),
+    // with the cascade in a scalar register: see calcShadow
+    // The pixel's twelve tap offsets. Indexed by the noise VALUE, the 64 lanes of a wave read 64 scattered 96-byte rows: six loads of ~55 cache lines
+    // each, a third of all the L1 accesses of a kernel that the ablation of round 4 showed to be bound by exactly those (profiles/r04_shade_ablation.txt).
+    // Indexed by the noise texel's POSITION and transposed, lane l reads 16 bytes next to lane l - 1's: four cache lines per load.
+    // One code path for both tables: a uniform base and row stride (scalar registers) and one 32-bit byte offset per lane.
+    PcfTapRow tapRow;
+    {
+        const bool byPosition = P.pcfTapsByPosition != nullptr; // uniform
+        const uint8_t* base = byPosition ? (const uint8_t*)P.pcfTapsByPosition : (const uint8_t*)P.pcfTaps;
+        const uint32_t rowStride = byPosition ? P.pcfPositions * 16u : 16u;
+        const uint32_t laneOffset = byPosition ? noiseIndex * 16u : noiseByte * (uint32_t)(kPcfTaps / 2 * 16);
 #pragma unroll
-    for (int i = 1; i < 4; i++) {
-        shadowMap.ptr = cascadeIndex == i ? P.shadowMaps[i].ptr : shadowMap.ptr;
-        shadowMap.w = cascadeIndex == i ? P.shadowMaps[i].w : shadowMap.w;
-        shadowMap.h = cascadeIndex == i ? P.shadowMaps[i].h : shadowMap.h;
+        for (int k = 0; k < kPcfTaps / 2; k++) __builtin_memcpy(&tapRow.q[k], base + (size_t)((uint32_t)k * rowStride) + laneOffset, 16);
     }
-    const float sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[cascadeIndex], lss, noiseTexel.x);
+    float sunShadow = 0.f;
+    for (bool pending = true; pending;) {
+        int c = __builtin_amdgcn_readfirstlane(cascadeIndex);
+        const bool mine = cascadeIndex == c;
+        // the optimiser would otherwise replace c by the (per-lane) cascadeIndex inside the branch it guards - equal there, but in a vector register
+        asm volatile("" : "+s"(c));
+        if (mine) {
+            const ImgView& m0 = P.shadowMaps[0];
+            ImgView shadowMap; // uniform selects (s_cselect): the struct is a kernel argument, a dynamic index would copy it to scratch memory
+            shadowMap.ptr = c == 0 ? m0.ptr : c == 1 ? P.shadowMaps[1].ptr : c == 2 ? P.shadowMaps[2].ptr : P.shadowMaps[3].ptr;
+            shadowMap.w = c == 0 ? m0.w : c == 1 ? P.shadowMaps[1].w : c == 2 ? P.shadowMaps[2].w : P.shadowMaps[3].w;
+            shadowMap.h = c == 0 ? m0.h : c == 1 ? P.shadowMaps[1].h : c == 2 ? P.shadowMaps[2].h : P.shadowMaps[3].h;
+            shadowMap.d = 1; shadowMap.fmt = F_D16;
+            sunShadow = calcShadow(passPos, shadowMap, P.shadowInfo->lightMatrices[c], P.shadowInfo->lightSpaceScale[c][0], P.shadowInfo->lightSpaceScale[c][1], tapRow);
+            pending = false;
+        }
+    }
     *sigWord = (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u; // cascade, lit PCF taps, geometry (oracle/oracle.h)
     const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
     const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
@@ -401,24 +434,29 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
         linearCoord(nu * (float)vol.w, &i0, &a);
         linearCoord(nv * (float)vol.h, &j0, &b);
         linearCoord(z * (float)vol.d, &k0, &c);
-        const int x0 = clampi(i0, vol.w), x1 = clampi(i0 + 1, vol.w);
+        int xb; float a2;
+        edgePair(i0, a, vol.w, &xb, &a2); // the texel pair of every row in one 16-byte load, the x edge in the weight (bilinearLut above)
         const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
         const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
         const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
-        const int xb = clampTo(x0, vol.w - 2);
-        auto rowLerp = [&](uint32_t rowBase) { // texels x0, x1 of one row, lerped by a; one 16-byte load when the row has two texels
-            const uint2* row = (const uint2*)vol.ptr + rowBase;
-            uint4 q;
-            __builtin_memcpy(&q, row + xb, 16);
-            const uint2 tl = make_uint2(q.x, q.y), th = make_uint2(q.z, q.w);
-            const uint2 e0 = x0 == xb ? tl : th, e1 = x1 == xb ? tl : th;
-            const vec4 t0(halfBitsToFloat(e0.x & 0xffffu), halfBitsToFloat(e0.x >> 16), halfBitsToFloat(e0.y & 0xffffu), halfBitsToFloat(e0.y >> 16));
-            const vec4 t1(halfBitsToFloat(e1.x & 0xffffu), halfBitsToFloat(e1.x >> 16), halfBitsToFloat(e1.y & 0xffffu), halfBitsToFloat(e1.y >> 16));
-            return t0 + (t1 - t0) * a;
-        };
-        const vec4 l0 = rowLerp(z0 + y0), l1 = rowLerp(z0 + y1), h0 = rowLerp(z1 + y0), h1 = rowLerp(z1 + y1);
-        const vec4 lo = l0 + (l1 - l0) * b, hi = h0 + (h1 - h0) * b;
-        const vec4 it = lo + (hi - lo) * c;
+        const uint2* texels = (const uint2*)vol.ptr + xb;
+        uint4 q00, q10, q01, q11; // [z][y]
+        __builtin_memcpy(&q00, texels + (z0 + y0), 16);
+        __builtin_memcpy(&q01, texels + (z0 + y1), 16);
+        __builtin_memcpy(&q10, texels + (z1 + y0), 16);
+        __builtin_memcpy(&q11, texels + (z1 + y1), 16);
+        // the sampler contract's weights and summation order (image.h sampleLinear3D): eight texels x four channels = 32 v_fma_mix_f32 on the fp16 words
+        const float a0 = 1.f - a2, b0 = 1.f - b, c0 = 1.f - c;
+        const float wab00 = a0 * b0, wab10 = a2 * b0, wab01 = a0 * b, wab11 = a2 * b;
+        vec4 it(0.f);
+        it = accumulateTexel(it, q00.x, q00.y, wab00 * c0);
+        it = accumulateTexel(it, q00.z, q00.w, wab10 * c0);
+        it = accumulateTexel(it, q01.x, q01.y, wab01 * c0);
+        it = accumulateTexel(it, q01.z, q01.w, wab11 * c0);
+        it = accumulateTexel(it, q10.x, q10.y, wab00 * c);
+        it = accumulateTexel(it, q10.z, q10.w, wab10 * c);
+        it = accumulateTexel(it, q11.x, q11.y, wab01 * c);
+        it = accumulateTexel(it, q11.z, q11.w, wab11 * c);
         outColor = outColor * it.w + it.xyz();
     }
     return packR11G11B10(outColor);
@@ -599,6 +637,69 @@ template <int D> static FusedKernel pickFusedMulti(int m, bool aa) {
     }
 }
 
+// ---- tables the shade derives from its inputs, in the pass's scratch memory: [tap table by noise value 24 KB | kNoiseSlots x tap table by noise position]
+// The by-position table of a noise texture is rebuilt when the texture's content version changes (backend.h contentVersionOf: creation, uploads,
+// any execution that writes it); a texture whose address was handed out (version 0), one with more than kMaxNoisePositions texels, or a frame
+// whose noise texture the host cannot name takes the by-value table. Four slots: the reference cycles four noise textures (frameIndexMod4).
+constexpr int kNoiseSlots = 4;
+constexpr uint32_t kMaxNoisePositions = 4096;
+constexpr size_t kNoiseSlotBytes = (size_t)kMaxNoisePositions * (kPcfTaps / 2) * sizeof(float4);
+__global__ void pcfTapsByPositionKernel(const uint16_t* __restrict__ noiseTexels, uint32_t positions, const float4* __restrict__ byValue, float4* __restrict__ byPosition) {
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= positions) return;
+    const uint32_t noiseByte = noiseTexels[pos] & 0xffu; // RG8 texel, .r
+    // The shadow test counts lit taps: their order is free. Tap i of this texel points at angle 2 pi (noise + i / 12); slot j of the row gets the tap
+    // whose direction is nearest to 2 pi j / 12, i = j - round(12 noise) (mod 12). The j-th shadow-map load of a wave then reads, for every lane, a
+    // texel on the SAME side of its tap centre - a strip along one direction instead of a whole disc - and touches fewer cache lines.
+    const float2* taps = (const float2*)byValue + noiseByte * kPcfTaps;
+    const int turn = (int)((float)noiseByte * (12.f / 255.f) + 0.5f);
+#pragma unroll
+    for (int k = 0; k < kPcfTaps / 2; k++) {
+        const int i0 = ((2 * k - turn) % kPcfTaps + kPcfTaps) % kPcfTaps, i1 = ((2 * k + 1 - turn) % kPcfTaps + kPcfTaps) % kPcfTaps;
+        byPosition[(uint32_t)k * positions + pos] = make_float4(taps[i0].x, taps[i0].y, taps[i1].x, taps[i1].y);
+    }
+}
+struct ShadeDerived {
+    const void* scratchBase = nullptr; // the allocation the entries below describe (a re-allocated scratch starts empty)
+    struct Slot { const void* noise = nullptr; int w = 0, h = 0; uint64_t version = 0, lastUse = 0; } slots[kNoiseSlots];
+    uint64_t useCounter = 0;
+};
+static thread_local std::map<const void*, ShadeDerived> g_shadeDerived; // key = the pass's scratch slot (one backend per host thread)
+static int shadeDerivedTables(const PassCtx& c, ShadeParams* P) {
+    const size_t total = kPcfTapTableBytes + kNoiseSlots * kNoiseSlotBytes;
+    uint8_t* scratch = (uint8_t*)c.scratch(total);
+    if (!scratch) return c.fail(-2, "deferredShading: cannot allocate scratch memory");
+    ShadeDerived& d = g_shadeDerived[(const void*)c.scratchSlot];
+    if (d.scratchBase != scratch) {
+        d = ShadeDerived{};
+        d.scratchBase = scratch;
+        const hipError_t e = buildPcfTapTable((float2*)scratch, c.stream);
+        if (e != hipSuccess) return c.fail(-2, std::string("deferredShading: PCF tap table: ") + hipGetErrorString(e));
+    }
+    P->pcfTaps = (const float4*)scratch;
+    P->pcfTapsByPosition = nullptr;
+    P->pcfPositions = 0;
+    const ImgView& noise = P->noiseTex;
+    if (!noise.ptr || noise.fmt != F_RG8) return 0;
+    const uint64_t version = contentVersionOf(noise.ptr);
+    const uint64_t positions = (uint64_t)noise.w * (uint64_t)noise.h;
+    if (version == 0 || positions > kMaxNoisePositions) return 0;
+    ShadeDerived::Slot* slot = nullptr;
+    for (auto& s : d.slots) if (s.noise == noise.ptr && s.w == noise.w && s.h == noise.h && s.version == version) slot = &s;
+    if (!slot) {
+        slot = &d.slots[0];
+        for (auto& s : d.slots) if (s.lastUse < slot->lastUse) slot = &s; // least recently used
+        float4* dst = (float4*)(scratch + kPcfTapTableBytes + (size_t)(slot - d.slots) * kNoiseSlotBytes);
+        pcfTapsByPositionKernel<<<divUp((unsigned)positions, 256u), 256, 0, c.stream>>>((const uint16_t*)noise.ptr, (uint32_t)positions, (const float4*)scratch, dst);
+        PLR_CHECK_LAUNCH(c);
+        slot->noise = noise.ptr; slot->w = noise.w; slot->h = noise.h; slot->version = version;
+    }
+    slot->lastUse = ++d.useCounter;
+    P->pcfTapsByPosition = (const float4*)(scratch + kPcfTapTableBytes + (size_t)(slot - d.slots) * kNoiseSlotBytes);
+    P->pcfPositions = (uint32_t)positions;
+    return 0;
+}
+
 // validates the bindings of a deferred shade execution and fills the kernel parameters; 0, kUseGeneralKernel or an error
 static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, int* multi, bool* aa, int* tech) {
     if (int rc = c.needGlobal()) return rc;
@@ -635,6 +736,7 @@ static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, 
     P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
     if (!c.hostNoiseView(&P.noiseTex)) P.noiseTex = ImgView{};
+    if (int rc = shadeDerivedTables(c, &P)) return rc;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
     P.sig = c.sigFor((size_t)P.color.w * (size_t)P.color.h);

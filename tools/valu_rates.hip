@@ -135,6 +135,69 @@ KERNEL(k_cvti, A_CVTI) KERNEL(k_cvtub, A_CVTUB) KERNEL(k_add3, A_ADD3) KERNEL(k_
 KERNEL(k_mulsgpr, A_MULSGPR) KERNEL(k_fma2s, A_FMA2S) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_cmpcnd64, A_CMPCND64) KERNEL(k_cndvccset, A_CND_VCCSET)
 PK_KERNEL(k_pkfma, A_PKFMA) PK_KERNEL(k_pkmul, A_PKMUL) PK_KERNEL(k_pkadd, A_PKADD) PK_KERNEL(k_pkmov, A_PKMOV)
 
+// ---- round 4 additions: 64-bit address arithmetic, the conversions / integer forms the big kernels actually use, VOP3 encodings with modifiers, f16 scalar ops
+#define A_LSHLADD64(k) "v_lshl_add_u64 %" #k ", %" #k ", 2, %8"
+#define A_MAD64B(k) "v_mad_u64_u32 %" #k ", s[4:5], %9, %9, %" #k
+#define A_MAD64(k) "v_mad_u64_u32 %" #k ", s[4:5], %9, %9, %" #k
+#define A_CVTFLR(k) "v_cvt_flr_i32_f32 %" #k ", %" #k
+#define A_MULU24(k) "v_mul_u32_u24 %" #k ", %" #k ", %8"
+#define A_ASHR(k) "v_ashrrev_i32 %" #k ", 8, %" #k
+#define A_SUBU(k) "v_sub_u32 %" #k ", %" #k ", %8"
+#define A_CVTFI(k) "v_cvt_f32_i32 %" #k ", %" #k
+#define A_CVTUB0(k) "v_cvt_f32_ubyte0 %" #k ", %" #k
+#define A_FMAMIXHI(k) "v_fma_mix_f32 %" #k ", %8, %9, %" #k " op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define A_FMAMIXLO(k) "v_fma_mixlo_f16 %" #k ", %" #k ", %8, %9"
+#define A_CMPU(k) "v_cmp_ge_u32 vcc, %" #k ", %8"
+#define A_MULABS(k) "v_mul_f32_e64 %" #k ", |%" #k "|, %8"
+#define A_FMANEG(k) "v_fma_f32 %" #k ", -%" #k ", %8, %9"
+#define A_FMAINL(k) "v_fma_f32 %" #k ", %" #k ", %8, 1.0"
+#define A_FMALIT(k) "v_fma_f32 %" #k ", %" #k ", %8, 0x40490fdb"
+#define A_MULLIT(k) "v_mul_f32 %" #k ", 0x40490fdb, %" #k
+#define A_ADDSGPR(k) "v_add_f32 %" #k ", s6, %" #k
+#define A_ANDSGPR(k) "v_and_b32 %" #k ", s6, %" #k
+#define A_FMAC_S(k) "v_fmac_f32 %" #k ", s6, %8"
+#define A_MULF16(k) "v_mul_f16 %" #k ", %" #k ", %8"
+#define A_FMAF16(k) "v_fma_f16 %" #k ", %" #k ", %8, %9"
+#define A_PKMULF16(k) "v_pk_mul_f16 %" #k ", %" #k ", %8"
+#define A_SDWA_CVT(k) "v_cvt_f32_f16_sdwa %" #k ", %" #k " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+#define A_SDWA_MUL(k) "v_mul_f32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD"
+#define A_MAX3(k) "v_max3_f32 %" #k ", %" #k ", %8, %9"
+#define A_SUBREV(k) "v_subrev_f32 %" #k ", %8, %" #k
+#define A_MULLEG(k) "v_mul_legacy_f32 %" #k ", %" #k ", %8"
+#define A_ADDCO(k) "v_add_co_u32 %" #k ", vcc, %" #k ", %8"
+#define A_RNDNE(k) "v_rndne_f32 %" #k ", %" #k
+#define A_TRUNC(k) "v_trunc_f32 %" #k ", %" #k
+#define A_CVTPKU8(k) "v_cvt_pk_u8_f32 %" #k ", %" #k ", 1, %8"
+#define A_NOT(k) "v_not_b32 %" #k ", %" #k
+#define A_BCNT(k) "v_bcnt_u32_b32 %" #k ", %" #k ", %8"
+#define A_MBCNT(k) "v_mbcnt_lo_u32_b32 %" #k ", %" #k ", %8"
+#define A_READLANE(k) "v_readfirstlane_b32 s4, %" #k
+#define A_LSHLREV16(k) "v_lshlrev_b32 %" #k ", 16, %" #k
+#define A_MULPOW2(k) "v_mul_u32_u24 %" #k ", 16, %" #k
+#define A_DSREAD32(k) "ds_read_b32 %" #k ", %8\ns_waitcnt lgkmcnt(0)"
+#define A_DSREAD64x(k) "ds_read_b32 %" #k ", %8 offset:" #k "00"
+KERNEL(k_cvtflr, A_CVTFLR) KERNEL(k_mulu24, A_MULU24) KERNEL(k_ashr, A_ASHR) KERNEL(k_subu, A_SUBU) KERNEL(k_cvtfi, A_CVTFI)
+KERNEL(k_cvtub0, A_CVTUB0) KERNEL(k_fmamixhi, A_FMAMIXHI) KERNEL(k_fmamixlo, A_FMAMIXLO) KERNEL(k_cmpu, A_CMPU) KERNEL(k_mulabs, A_MULABS) KERNEL(k_fmaneg, A_FMANEG)
+KERNEL(k_fmainl, A_FMAINL) KERNEL(k_mullit, A_MULLIT) KERNEL(k_addsgpr, A_ADDSGPR) KERNEL(k_andsgpr, A_ANDSGPR) KERNEL(k_fmacs, A_FMAC_S)
+KERNEL(k_mulf16, A_MULF16) KERNEL(k_fmaf16, A_FMAF16) KERNEL(k_pkmulf16, A_PKMULF16) KERNEL(k_sdwacvt, A_SDWA_CVT) KERNEL(k_sdwamul, A_SDWA_MUL) KERNEL(k_max3, A_MAX3)
+KERNEL(k_subrev, A_SUBREV) KERNEL(k_mulleg, A_MULLEG) KERNEL(k_addco, A_ADDCO) KERNEL(k_rndne, A_RNDNE) KERNEL(k_trunc, A_TRUNC) KERNEL(k_cvtpku8, A_CVTPKU8)
+KERNEL(k_not, A_NOT) KERNEL(k_bcnt, A_BCNT) KERNEL(k_mbcnt, A_MBCNT) KERNEL(k_readlane, A_READLANE) KERNEL(k_lshl16, A_LSHLREV16) KERNEL(k_mulpow2, A_MULPOW2)
+
+#define U64_KERNEL(NAME, ASM)                                                                                         \
+    __global__ __launch_bounds__(256) void NAME(float* out, unsigned long long* clk, float bIn, float cIn) {         \
+        unsigned long long r[8];                                                                                      \
+        for (int k = 0; k < 8; k++) r[k] = (unsigned long long)(bIn * (float)(threadIdx.x + k + 1));                  \
+        unsigned long long b = (unsigned long long)(bIn * 3.f); unsigned c = (unsigned)(cIn * 8.f);                   \
+        unsigned long long t0 = __builtin_readcyclecounter();                                                         \
+        BODY8(ASM)                                                                                                    \
+        unsigned long long t1 = __builtin_readcyclecounter();                                                         \
+        unsigned long long s = 0;                                                                                     \
+        for (int k = 0; k < 8; k++) s += r[k];                                                                        \
+        if (s == 123456ull) out[0] = 1.f;                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;                                                    \
+    }
+U64_KERNEL(k_lshladd64, A_LSHLADD64) U64_KERNEL(k_mad64, A_MAD64B)
+
 typedef void (*kern_t)(float*, unsigned long long*, float, float);
 struct Test { const char* name; kern_t k; int instrPerSlot; };
 
@@ -161,13 +224,20 @@ int main() {
         {"v_cmp + v_cndmask (vcc) pair", k_cmpcnd, 2}, {"v_cmp_e64 + v_cndmask_e64 (s[4:5]) pair", k_cmpcnd64, 2}, {"v_cndmask_b32 vcc, no dst dependency", k_cndvccset, 1},
         {"v_mov_b32_dpp wave_shr:1", k_dpp_wshr, 1}, {"v_mov_b32_dpp wave_shl:1 bound_ctrl", k_dpp_wshl, 1}, {"v_fmac_f32_dpp row_shr:1", k_dpp_fmac, 1},
         {"v_mov_b32_dpp row_shr:1", k_dpp_shr, 1}, {"v_add_f32_dpp quad_perm", k_dpp_add, 1}, {"v_mov_b32_dpp row_bcast:15", k_dpp_bcast, 1},
+        {"v_lshl_add_u64", k_lshladd64, 1}, {"v_mad_u64_u32", k_mad64, 1}, {"v_cvt_flr_i32_f32", k_cvtflr, 1}, {"v_mul_u32_u24", k_mulu24, 1}, {"v_ashrrev_i32", k_ashr, 1}, {"v_sub_u32", k_subu, 1},
+        {"v_cvt_f32_i32", k_cvtfi, 1}, {"v_cvt_f32_ubyte0", k_cvtub0, 1}, {"v_fma_mix_f32 (f16 hi src)", k_fmamixhi, 1}, {"v_fma_mixlo_f16", k_fmamixlo, 1}, {"v_cmp_ge_u32", k_cmpu, 1},
+        {"v_mul_f32_e64 |abs|", k_mulabs, 1}, {"v_fma_f32 neg src", k_fmaneg, 1}, {"v_fma_f32 inline 1.0", k_fmainl, 1}, {"v_mul_f32 literal", k_mullit, 1},
+        {"v_add_f32 (sgpr src)", k_addsgpr, 1}, {"v_and_b32 (sgpr src)", k_andsgpr, 1}, {"v_fmac_f32 (sgpr src)", k_fmacs, 1}, {"v_mul_f16", k_mulf16, 1}, {"v_fma_f16", k_fmaf16, 1},
+        {"v_pk_mul_f16", k_pkmulf16, 1}, {"v_cvt_f32_f16_sdwa WORD_1", k_sdwacvt, 1}, {"v_mul_f32_sdwa", k_sdwamul, 1}, {"v_max3_f32", k_max3, 1}, {"v_subrev_f32", k_subrev, 1},
+        {"v_mul_legacy_f32", k_mulleg, 1}, {"v_add_co_u32", k_addco, 1}, {"v_rndne_f32", k_rndne, 1}, {"v_trunc_f32", k_trunc, 1}, {"v_cvt_pk_u8_f32", k_cvtpku8, 1}, {"v_not_b32", k_not, 1},
+        {"v_bcnt_u32_b32", k_bcnt, 1}, {"v_mbcnt_lo", k_mbcnt, 1}, {"v_readfirstlane_b32", k_readlane, 1}, {"v_lshlrev_b32 by 16", k_lshl16, 1}, {"v_mul_u32_u24 by 16", k_mulpow2, 1},
         {"v_permlane32_swap", k_permlane, 1}, {"ds_bpermute_b32 (+wait)", k_bperm, 1}, {"ds_swizzle_b32 (+wait)", k_swiz, 1},
     };
     const int wavesPerSimd = 8;
     const int blocks = cus * wavesPerSimd; // 256 threads = 4 waves = one per SIMD; 8 blocks per CU -> 8 waves per SIMD
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    printf("%-30s %10s %12s %14s\n", "instruction", "ms", "cyc/instr", "Ginstr/s chip");
+    printf("%-30s %10s %12s %14s %12s\n", "instruction", "ms", "cyc@2.4GHz", "Ginstr/s chip", "memtime");
     for (auto& t : tests) {
         t.k<<<blocks, 256>>>(out, clk, 1.0001f, 0.5f);
         CHECK(hipDeviceSynchronize());
@@ -179,7 +249,10 @@ int main() {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         const double instrPerSimd = (double)ITER * 8 * wavesPerSimd * t.instrPerSlot;
         const double secPerInstr = ms * 1e-3 / instrPerSimd;
-        printf("%-30s %10.3f %12.2f %14.1f\n", t.name, ms, secPerInstr * 2.4e9, instrPerSimd * cus * 4 / (ms * 1e-3) / 1e9);
+        unsigned long long ticks = 0;
+        CHECK(hipMemcpy(&ticks, clk, sizeof(ticks), hipMemcpyDeviceToHost));
+        // ticks: s_memtime delta of one wave over its ITER x 8 x instrPerSlot instructions (constant 100 MHz reference on gfx950, not the shader clock)
+        printf("%-30s %10.3f %12.2f %14.1f %12llu\n", t.name, ms, secPerInstr * 2.4e9, instrPerSimd * cus * 4 / (ms * 1e-3) / 1e9, ticks);
     }
     return 0;
 }
