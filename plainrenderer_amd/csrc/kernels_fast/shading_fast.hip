@@ -192,6 +192,7 @@ struct ShadeParams {
     // the same rows re-indexed by the POSITION of the frame's noise texel and transposed, [6][pcfPositions] float4, or null (shadeDerivedTables below)
     const float4* pcfTapsByPosition;
     uint32_t pcfPositions;
+    const uint2* lutEnergyFootprint; // [(h - 1)][(w - 1)] of the BRDF LUT: .y of the 2 x 2 texels at (x, y), or null (lutEnergy below)
 };
 
 // The four uniform blocks a shade kernel reads are ALSO passed as top-level `const T* __restrict__` kernel arguments, and the kernel puts those into
@@ -261,13 +262,34 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* __restr
     return (float)lit * (1.f / 12.f);
 }
 
+// BRDF LUT, .y (the reflected energy) at (u, v): the multiscattering lobe looks it up twice per pixel. From the LUT itself that is two 16-byte loads
+// (two rows) of which 4 of 32 bytes are used; the footprint copy (shadeDerivedTables) holds, per texel pair (xb, yb), the four .y halves of the 2 x 2
+// footprint in 8 bytes: ONE load, and the y edge goes into the weight like the x edge (edgePair). Same texels, same weights.
+PLR_DI float lutEnergy(const ShadeParams& P, float u, float v) {
+    const ImgView& im = P.brdfLut;
+    if (!P.lutEnergyFootprint) return bilinearLut(im, u, v).y; // uniform
+    int i0, j0; float a, b;
+    linearCoord(u * (float)im.w, &i0, &a);
+    linearCoord(v * (float)im.h, &j0, &b);
+    int xb, yb; float a2, b2;
+    edgePair(i0, a, im.w, &xb, &a2);
+    edgePair(j0, b, im.h, &yb, &b2);
+    const uint2 q = P.lutEnergyFootprint[__umul24((uint32_t)yb, (uint32_t)(im.w - 1)) + (uint32_t)xb];
+    const float a0 = 1.f - a2, b0 = 1.f - b2;
+    float e = (float)halfLo(q.x) * (a0 * b0);
+    e = __builtin_fmaf((float)halfHi(q.x), a2 * b0, e);
+    e = __builtin_fmaf((float)halfLo(q.y), a0 * b2, e);
+    e = __builtin_fmaf((float)halfHi(q.y), a2 * b2, e);
+    return e;
+}
+
 template <int MULTISCATTER>
-PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, float NoL, vec3 f0, vec3 singleScatteringLobe, vec3 brdfLut) {
+PLR_DI vec3 specularMultiscatteringLobe(const ShadeParams& P, float r, float NoL, vec3 f0, vec3 singleScatteringLobe, vec3 brdfLut) {
     const float energyOutgoing = brdfLut.y;
     const vec3 fresnelAverage = f0 + (1.f - f0) * (1.f / 21.f);
     if (MULTISCATTER == 0) {
         const float energyAverage = ReflectedEnergyAverage(r);
-        const float energyIncoming = bilinearLut(brdfLutTex, r, NoL).y;
+        const float energyIncoming = lutEnergy(P, r, NoL);
         const float unscaled = (1.f - energyIncoming) * (1.f - energyOutgoing) * rcpf(3.1415f * (1.f - energyAverage));
         const vec3 den = 1.f - fresnelAverage * (1.f - energyAverage);
         const vec3 scaling = (fresnelAverage * fresnelAverage * energyAverage) * vec3(rcpf(den.x), rcpf(den.y), rcpf(den.z));
@@ -394,7 +416,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     diffuseDirect = diffuseDirect * ((1.f - F_Schlick(f0, vec3(1.f), NoV)) * (1.f - F_Schlick(f0, vec3(1.f), NoL)));
 
     const vec3 singleScatteringLobe = GGXSingleScattering(r, f0, NoH, NoV, VoH, NoL);
-    const vec3 multiScatteringLobe = specularMultiscatteringLobe<MULTISCATTER>(P.brdfLut, r, NoL, f0, singleScatteringLobe, brdfLut);
+    const vec3 multiScatteringLobe = specularMultiscatteringLobe<MULTISCATTER>(P, r, NoL, f0, singleScatteringLobe, brdfLut);
     const vec3 specularDirect = directLighting * (singleScatteringLobe + multiScatteringLobe);
 
     vec3 lightingIndirect;
@@ -415,7 +437,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
         const float NoL_indirect = fmax1(dot(N, L_indirect), 0.f);
         const float VoH_indirect = fmax1(dot(V, H_indirect), 0.f);
         const vec3 single_i = GGXSingleScattering(r_indirect, f0, NoH_indirect, NoV, VoH_indirect, NoL_indirect);
-        const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P.brdfLut, r_indirect, NoL_indirect, f0, single_i, brdfLut);
+        const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P, r_indirect, NoL_indirect, f0, single_i, brdfLut);
         const vec3 specularIndirect = (single_i + multi_i) * YCoCgToLinear(vec3(irradiance_Y_SH.x, cc.x, cc.y));
         lightingIndirect = diffuseIndirect + specularIndirect;
     } else {
@@ -644,6 +666,13 @@ template <int D> static FusedKernel pickFusedMulti(int m, bool aa) {
 constexpr int kNoiseSlots = 4;
 constexpr uint32_t kMaxNoisePositions = 4096;
 constexpr size_t kNoiseSlotBytes = (size_t)kMaxNoisePositions * (kPcfTaps / 2) * sizeof(float4);
+__global__ void lutEnergyFootprintKernel(ImgView lut, uint2* __restrict__ out) {
+    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)), y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= lut.w - 1 || y >= lut.h - 1) return;
+    const uint2* t = (const uint2*)lut.ptr;
+    auto energy = [&](int tx, int ty) { return t[(size_t)ty * (size_t)lut.w + tx].x >> 16; }; // RGBA16F texel: .y = upper half of the first word
+    out[(size_t)y * (size_t)(lut.w - 1) + x] = make_uint2(energy(x, y) | (energy(x + 1, y) << 16), energy(x, y + 1) | (energy(x + 1, y + 1) << 16));
+}
 __global__ void pcfTapsByPositionKernel(const uint16_t* __restrict__ noiseTexels, uint32_t positions, const float4* __restrict__ byValue, float4* __restrict__ byPosition) {
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= positions) return;
@@ -663,10 +692,15 @@ struct ShadeDerived {
     const void* scratchBase = nullptr; // the allocation the entries below describe (a re-allocated scratch starts empty)
     struct Slot { const void* noise = nullptr; int w = 0, h = 0; uint64_t version = 0, lastUse = 0; } slots[kNoiseSlots];
     uint64_t useCounter = 0;
+    const void* lut = nullptr; int lutW = 0, lutH = 0; uint64_t lutVersion = 0; // what the energy footprint was derived from
 };
 static thread_local std::map<const void*, ShadeDerived> g_shadeDerived; // key = the pass's scratch slot (one backend per host thread)
 static int shadeDerivedTables(const PassCtx& c, ShadeParams* P) {
-    const size_t total = kPcfTapTableBytes + kNoiseSlots * kNoiseSlotBytes;
+    // [tap table by value | noise slots | BRDF LUT energy footprint (size follows the LUT: a larger LUT re-allocates the scratch and everything is rebuilt)]
+    const ImgView& lut = P->brdfLut;
+    const size_t footprintOffset = kPcfTapTableBytes + kNoiseSlots * kNoiseSlotBytes;
+    const size_t footprintBytes = (size_t)(lut.w - 1) * (size_t)std::max(lut.h - 1, 1) * sizeof(uint2); // (the launcher sends LUTs narrower than two texels to the general kernel)
+    const size_t total = footprintOffset + footprintBytes;
     uint8_t* scratch = (uint8_t*)c.scratch(total);
     if (!scratch) return c.fail(-2, "deferredShading: cannot allocate scratch memory");
     ShadeDerived& d = g_shadeDerived[(const void*)c.scratchSlot];
@@ -679,6 +713,15 @@ static int shadeDerivedTables(const PassCtx& c, ShadeParams* P) {
     P->pcfTaps = (const float4*)scratch;
     P->pcfTapsByPosition = nullptr;
     P->pcfPositions = 0;
+    P->lutEnergyFootprint = nullptr;
+    if (const uint64_t lutVersion = lut.h >= 2 ? contentVersionOf(lut.ptr) : 0) { // 0: the LUT may change behind the backend's back - the kernel reads the LUT itself
+        if (d.lut != lut.ptr || d.lutW != lut.w || d.lutH != lut.h || d.lutVersion != lutVersion) {
+            lutEnergyFootprintKernel<<<dim3(divUp((unsigned)(lut.w - 1), 64u), divUp((unsigned)(lut.h - 1), 4u)), 256, 0, c.stream>>>(lut, (uint2*)(scratch + footprintOffset));
+            PLR_CHECK_LAUNCH(c);
+            d.lut = lut.ptr; d.lutW = lut.w; d.lutH = lut.h; d.lutVersion = lutVersion;
+        }
+        P->lutEnergyFootprint = (const uint2*)(scratch + footprintOffset);
+    }
     const ImgView& noise = P->noiseTex;
     if (!noise.ptr || noise.fmt != F_RG8) return 0;
     const uint64_t version = contentVersionOf(noise.ptr);

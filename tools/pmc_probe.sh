@@ -6,7 +6,7 @@ RE=$1; shift
 i=0
 for C in "$@"; do
   i=$((i+1))
-  timeout 420 rocprofv3 --pmc $C --kernel-include-regex "$RE" -d $OUT/p$i -o pmc --output-format csv -- python $REPO/bench.py --steps 3 --warmup 2 --profile-frames 0 --no-cpu-baseline > /dev/null 2> $OUT/p$i.err
+  timeout 150 rocprofv3 --pmc $C --kernel-include-regex "$RE" -d $OUT/p$i -o pmc --output-format csv -- python $REPO/bench.py --steps 3 --warmup 2 --profile-frames 0 --no-cpu-baseline > /dev/null 2> $OUT/p$i.err
   python $REPO/tools/pmc_summary.py $(ls $OUT/p$i/*counter_collection.csv | head -1) $OUT/p$i.csv && cat $OUT/p$i.csv
   rm -rf $OUT/p$i
 done
