@@ -120,6 +120,35 @@ def pmc_traffic(pass_name):
     return (total, src) if found else (None, None)
 
 
+def pmc_counters(pass_name):
+    """Per-launch SQ / TCP counters of the pass's kernel(s) from the newest committed profiles/*_sq_counters.csv (tools/profile_round.sh: rocprofv3 --pmc
+    passes of this same command at the default workload, means per dispatch by tools/pmc_summary.py) -> ({counter: value}, source note) or (None, None)"""
+    import glob
+    prefixes = PASS_KERNEL.get(pass_name)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.csv")))
+    if not prefixes or not files:
+        return None, None
+    digest, header, acc = None, None, {}
+    for line in open(files[-1]):
+        line = line.strip()
+        if line.startswith("# kernel source digest:"):
+            digest = line.split(":", 1)[1].strip()
+        elif line.startswith("kernel,"):
+            header = line.split(",")
+        elif header and any(line.startswith(p) for p in prefixes):
+            cols = line.split(",")
+            for k, v in zip(header[2:], cols[2:]):
+                try:
+                    acc[k] = acc.get(k, 0.0) + float(v)
+                except ValueError:
+                    pass
+    src = os.path.basename(files[-1]) + (" (kernel sources unchanged since)" if digest == kernel_source_digest() else " (kernel sources CHANGED since: stale)" if digest else "")
+    return (acc, src) if acc else (None, None)
+
+
+SIMDS, CUS, SHADER_CLOCK_GHZ = 1024, 256, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz
+
+
 def build_scene(args, device, w, h, band=None):
     """band = (row_begin, row_end) of this rank in the w x h frame, or None for the whole frame"""
     from plainrenderer_amd import synth
@@ -403,6 +432,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1000.0 / args.steps
+    # the timed frames must be fast-set frames: an execution that fell back to the general (exact-order, port-shaped) kernel of its shader is reported
+    # by the backend (plr_get_general_kernel_executions) and voids the measurement
+    general_count, general_names = be.getGeneralKernelExecutions()
+    if general_count and not args.exact:
+        raise SystemExit("bench.py: %d execution(s) of the timed frame ran the general (exact-set) kernel instead of a fast-set kernel: %s" % (general_count, general_names))
 
     # per-GPU pixels: the band's rows (a band renders w x rows of the frame)
     bh = h if band is None else band[1] - band[0]
@@ -431,8 +465,22 @@ def main():
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         default_workload = (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None
         traffic, traffic_src = pmc_traffic(name) if default_workload else (None, None)
+        # Secondary rooflines for the resource that actually binds a gather / ALU kernel: the VALU issue floor - instructions x 2 cycles
+        # per wave64 instruction on a SIMD-32 (MI355X_MICROARCH.md, Wave scheduling) / 1024 SIMDs / 2.4 GHz - and the L1 floor - one cache-line access per
+        # cycle and CU (the rate the shade ablation of round 4 ran into, profiles/r04_shade_ablation.txt) - each as a fraction of the measured launch time
+        counters, counters_src = pmc_counters(name) if default_workload else (None, None)
+        valu_roofline = l1_roofline = None
+        if counters and counters.get("SQ_INSTS_VALU"):
+            t_valu_ms = counters["SQ_INSTS_VALU"] * 2.0 / SIMDS / (SHADER_CLOCK_GHZ * 1e9) * 1e3
+            valu_roofline = {"bound": "valu issue", "valu_instructions_per_launch": int(counters["SQ_INSTS_VALU"]), "cycles_per_instruction_at_peak": 2, "simds": SIMDS,
+                             "clock_GHz": SHADER_CLOCK_GHZ, "floor_ms": round(t_valu_ms, 4), "frac": round(t_valu_ms / avg_ms, 4), "source": counters_src}
+        if counters and counters.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            t_l1_ms = counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / CUS / (SHADER_CLOCK_GHZ * 1e9) * 1e3
+            l1_roofline = {"bound": "L1 (TCP) cache-line accesses", "accesses_per_launch": int(counters["TCP_TOTAL_CACHE_ACCESSES_sum"]), "accesses_per_cycle_per_cu_at_peak": 1,
+                           "cus": CUS, "floor_ms": round(t_l1_ms, 4), "frac": round(t_l1_ms / avg_ms, 4), "source": counters_src}
         roofline = {"bound": "hbm", "kernel": name, "hip_kernel": (PASS_KERNEL.get(name) or PASS_KERNEL.get(name.split(" + ")[-1]) or [None])[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                    "valu_roofline": valu_roofline, "l1_roofline": l1_roofline}
     if args.pass_table and rank == 0:
         tot = sum(r[1] * r[2] for r in table)
         sys.stderr.write("%-36s %9s %7s %9s %8s\n" % ("pass", "avg ms", "launch", "GB/s", "% frame"))
@@ -463,6 +511,7 @@ def main():
                        # what the timed frames do besides the workload's size: camera translation per frame (static G-buffer, moving view for the reprojections),
                        # backend scheduling switches (include/plr.h): pass fusion level, asynchronous frame tail (bloom chain + tonemap beside the next frame)
                        "input_producers_as_compute": bool(args.producers), "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
+                       "general_kernel_executions_in_last_timed_frame": general_count,
                        "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point (%s) "
                                        "+ one 512 B histogram all-reduce per frame" % (w, h, world, h // world, "torch.distributed from Python" if args.python_exchange else
                                                                                         "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else

@@ -226,6 +226,11 @@ int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions);
 int plr_set_pass_fusion(int enabled);
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions);
 int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions);
+/* In PLR_MATH_FAST an execution outside the configuration its fast kernel was built for - or of a shader without one - runs the general
+ * (exact-order) kernel of the shader. That is correct but slow, so it is not silent: out_count = executions of the last plr_render_frame that
+ * took the general kernel, out_names (optional) = "<pass name> [<shader>], ..." truncated to names_capacity. bench.py refuses to report a
+ * frame whose count is not zero. (Executions covered by a fused launch are not counted: a fused launcher is fast-set code.) */
+int plr_get_general_kernel_executions(uint32_t* out_count, char* out_names, size_t names_capacity);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
 int plr_get_last_frame_gpu_time(float* out_ms);
 /* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */
@@ -236,10 +241,16 @@ int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t r
 int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size);
 int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size);
 int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size);
-/* device address / byte size of one mip level (HBM resident; lets a caller fill inputs device-to-device) */
+/* Raw interop. The three calls below first make the launch stream wait for the frame's asynchronous tail (async_tail executions run on a second
+ * stream): work the caller orders on plr_get_stream() afterwards - presenting or reading the swapchain, a collective on an image - is behind
+ * everything recorded so far, tail included. Call them AFTER plr_render_frame for that guarantee; a pointer or stream obtained earlier and used
+ * after a later plr_render_frame is ordered behind the launch stream only (call plr_get_stream again, or plr_wait_for_gpu_idle).
+ * plr_get_image_device_pointer: device address / byte size of one mip level (HBM resident; lets a caller fill inputs device-to-device). Fails
+ * for an image the last frame's fused launch left unwritten (pass fusion level 2), like plr_download_image. An image whose address was
+ * handed out may be written behind the backend's back from then on: launchers stop caching tables derived from it (backend.h contentVersionOf). */
 int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, void** out_ptr, size_t* out_size);
 int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size);
-/* the hipStream_t all passes are launched on */
+/* the hipStream_t the passes are launched on (async_tail executions: a second stream, joined as described above) */
 int plr_get_stream(void** out_hip_stream);
 /* raw copies ordered on the launch stream of the calling thread's backend: device-to-device (asynchronous), device-to-host and
  * host-to-device (both return when the copy is done). For exchange callbacks that move rows between two backends of one process. */

@@ -266,6 +266,10 @@ struct Backend {
     GlobalUbo globalShadow{};            // host copy of the global uniform buffer as of the last flushed fill (PassCtx::globalHost)
     bool globalShadowValid = false;
     uint32_t lastFused = 0;              // executions of the last frame that ran inside a fused launch
+    // executions of the last frame that ran the GENERAL (exact-order) kernel of their shader although the math mode is PLR_MATH_FAST - no fast kernel is
+    // registered for the shader, or its launcher declined the bindings (kUseGeneralKernel) - and their names (plr_get_general_kernel_executions)
+    uint32_t lastGeneral = 0;
+    std::string lastGeneralNames;
     uint64_t frameSerial = 0;            // serial of the running launchAll call, unique in the process (PassCtx::frameSerial)
     // asynchronous frame tail (plr_compute_pass_execution::async_tail, plr.h): executions launched on tailStream that the main stream has not
     // waited for yet, as the union of what they touch; tailDone is recorded behind the last of them
@@ -285,18 +289,25 @@ struct Backend {
 // A thread that calls plr_setup owns its backend: a process that drives several GPUs (or several bands on one GPU, as the partition tests do)
 // uses one thread per backend. A thread that never called plr_setup ADOPTS the process's first backend - the reference's single process-global
 // gRenderBackend (RenderBackend.cpp:39): a host that sets up on one thread and records from a worker thread works as it does there (calls must
-// not overlap in time, as in the reference). The adoption ends when that backend is shut down (epoch check).
+// not overlap in time, as in the reference). The adoption ends when that backend is shut down (epoch check). Adopting makes the backend's device
+// the thread's current one. A thread that has had a backend of its own does not adopt: after its plr_shutdown it gets PLR_ERR_NOT_INITIALISED
+// again instead of silently operating on another thread's backend.
 static thread_local Backend* g = nullptr;
 static thread_local std::string g_err;
 static thread_local bool g_adopted = false;
+static thread_local bool g_ownedOnce = false; // this thread has set up (and possibly shut down) a backend of its own: it never adopts another thread's
 static thread_local uint64_t g_adoptedEpoch = 0;
 static std::atomic<Backend*> g_first{nullptr};
 static std::atomic<uint64_t> g_firstEpoch{0};
 static bool resolveBackend() {
     if (g && g_adopted && g_adoptedEpoch != g_firstEpoch.load()) { g = nullptr; g_adopted = false; }
-    if (!g) {
+    if (!g && !g_ownedOnce) {
         Backend* first = g_first.load();
-        if (first) { g = first; g_adopted = true; g_adoptedEpoch = g_firstEpoch.load(); }
+        if (first) {
+            g = first; g_adopted = true; g_adoptedEpoch = g_firstEpoch.load();
+            // the current device is per thread: allocations, events and launches of this thread must go to the backend's GPU, not to device 0
+            (void)hipSetDevice(first->device);
+        }
     }
     return g != nullptr;
 }
@@ -485,6 +496,7 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
         return setErr(PLR_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e) + " (this backend has no CPU fallback)");
     if (device_ordinal < 0 || device_ordinal >= count) return setErr(PLR_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
+    g_ownedOnce = true;
     g = new Backend();
     {
         Backend* none = nullptr;
@@ -669,6 +681,9 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
             writesDefaultImage = writesDefaultImage || r.storage_images[i].image.type == PLR_IMAGE_DEFAULT;
         }
         for (uint32_t i = 0; i < r.storage_buffer_count; i++) x.access.push_back({g->sbufs[r.storage_buffers[i].buffer].dev, r.storage_buffers[i].read_only == 0});
+        // uniform buffers are read: a fill of one (plr_set_uniform_buffer_data, applied at the next plr_render_frame) must wait for an asynchronous
+        // tail that still reads it (flushFills; ADVICE r03: without these entries a tail execution with a UBO of its own raced with the next fill)
+        for (uint32_t i = 0; i < r.uniform_buffer_count; i++) x.access.push_back({g->ubufs[r.uniform_buffers[i].buffer].dev, false});
         x.access.push_back({g->passes[e->handle].get(), true}); // the pass's scratch memory: executions of one pass never overlap
         if (g->passes[e->handle]->readsBindless) x.access.push_back({kBindlessKey, false});
         if (writesDefaultImage) x.access.push_back({kBindlessKey, true});
@@ -1002,7 +1017,13 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
     touchAccesses(x.access); // the images it writes have new contents from here on (contentVersionOf)
     int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
-    if (rc == kUseGeneralKernel) rc = p.fn(x.ctx);
+    if (rc == kUseGeneralKernel) {
+        if (g->mathMode == PLR_MATH_FAST) { // not silently: the caller can ask
+            g->lastGeneral++;
+            if (g->lastGeneralNames.size() < 2048) g->lastGeneralNames += (g->lastGeneralNames.empty() ? "" : ", ") + p.name + " [" + p.shader + "]";
+        }
+        rc = p.fn(x.ctx);
+    }
     if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
     if (timed) if (int trc = endSegment()) return trc;
     return PLR_OK;
@@ -1128,6 +1149,8 @@ static int launchAll(bool timed) {
     g->orderEventsUsed = 0;
     g->lastOverlapped = 0;
     g->lastFused = 0;
+    g->lastGeneral = 0;
+    g->lastGeneralNames.clear();
     for (ImageRes& im : g->images) im.elided = false;
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
     const bool tailAllowed = g->asyncTail && !g->overlap;
@@ -1189,9 +1212,15 @@ static int launchAll(bool timed) {
                 if (int rc = tryFusedLaunch(i, runEnd, stream, globalPtr, timed, &covered)) return rc;
                 const size_t count = covered ? covered : 1;
                 if (async) {
+                    // the union of what the pending tail touches, one entry per (allocation, strongest access): a host that never joins the tail
+                    // (no download, no shared resource) would otherwise grow this list by a frame's worth of entries per frame
+                    auto note = [&](const Access& a) {
+                        for (Access& t : g->tailPending) if (t.key == a.key) { t.write = t.write || a.write; return; }
+                        g->tailPending.push_back(a);
+                    };
                     for (size_t k = i; k < i + count; k++)
-                        for (const Access& a : g->executions[k].access) g->tailPending.push_back(a);
-                    g->tailPending.push_back(Access{(const void*)globalPtr, false});
+                        for (const Access& a : g->executions[k].access) note(a);
+                    note(Access{(const void*)globalPtr, false});
                     tailDirty = true;
                     g->lastAsync += (uint32_t)count;
                 } else tailOpen = false; // the main stream moves on: a later tail execution must be ordered behind this one
@@ -1288,8 +1317,24 @@ int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions) {
     return PLR_OK;
 }
 
+int plr_get_general_kernel_executions(uint32_t* out_count, char* out_names, size_t names_capacity) {
+    NEED_INIT();
+    if (out_count) *out_count = g->lastGeneral;
+    if (out_names && names_capacity) {
+        const size_t n = std::min(names_capacity - 1, g->lastGeneralNames.size());
+        std::memcpy(out_names, g->lastGeneralNames.data(), n);
+        out_names[n] = 0;
+    }
+    return PLR_OK;
+}
 int plr_set_async_tail(int enabled) {
     NEED_INIT_JOINED();
+    if (enabled && !g->asyncTail) {
+        // the rotating copies of the global uniform buffer were not refreshed while the tail was off: drop them, the kernels read the buffer itself
+        // until its next fill makes a new copy
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        for (void*& c : g->globalCopies) { if (c) hipFree(c); c = nullptr; }
+    }
     g->asyncTail = enabled != 0;
     return PLR_OK;
 }
@@ -1575,10 +1620,13 @@ int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data
 }
 
 int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, void** out_ptr, size_t* out_size) {
-    NEED_INIT();
+    NEED_INIT_JOINED(); // what the caller then orders on plr_get_stream() is behind the asynchronous tail as well
     ImageRes* im; MipInfo* mi;
     int rc = imageMip(image, mip_level, &im, &mi);
     if (rc) return rc;
+    if (im->elided)
+        return setErr(PLR_ERR_UNSUPPORTED, "this image was not written in the last frame: the fused launch that consumes it kept it in registers (pass fusion level 2); "
+                                           "plr_set_pass_fusion(1) keeps intermediates");
     *out_ptr = (uint8_t*)im->dev + mi->offset;
     if (out_size) *out_size = mi->bytes;
     g->externallyWritable.insert(im->dev); // the caller may write through the pointer at any time: nothing derived from this image is cached any more
@@ -1586,14 +1634,14 @@ int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, voi
 }
 
 int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size) {
-    NEED_INIT();
+    NEED_INIT_JOINED();
     if (buffer >= g->sbufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid buffer handle");
     *out_ptr = g->sbufs[buffer].dev;
     if (out_size) *out_size = g->sbufs[buffer].size;
     return PLR_OK;
 }
 
-int plr_get_stream(void** out_hip_stream) { NEED_INIT(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
+int plr_get_stream(void** out_hip_stream) { NEED_INIT_JOINED(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
 
 int plr_get_supported_shaders(const char** out_names, uint32_t capacity) {
     const auto& r = registry();

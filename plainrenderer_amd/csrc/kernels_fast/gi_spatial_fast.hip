@@ -421,7 +421,10 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         // rows the filter can read: the dispatched rows and a margin (samples further away read whatever an earlier frame packed there, exactly like
         // the stale image rows they would read unpacked), inside the rows declared valid (band rendering: a sample on any other row has weight 0);
         // minus the rows the producer of the input packed itself (fused_gi.h)
-        const int margin = 128;
+        // (the margin follows the declared valid rows: a band's GI halo grows with the frame height, 64 trace rows per 2160 - ADVICE r03: with a fixed 128
+        //  a frame taller than 4320 rows read stale packed texels on valid halo rows beyond it)
+        const bool banded = validLo > 0 || validHi < (int)c.sampled[2].h;
+        const int margin = banded ? std::max({128, y0 - validLo, validHi - h}) : 128;
         const int p0 = std::max({y0 - margin, 0, validLo}), p1 = std::min({h + margin, (int)c.sampled[2].h, validHi});
         std::pair<int, int> todo[2];
         const int nTodo = p1 > p0 ? unpackedRows(c, packed, p0, p1, todo) : 0;

@@ -382,7 +382,8 @@ static int launchImpl(const PassCtx& c) {
     // the spatial filter that reads this pass's output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;
     const SpatialPackTarget* pack = !sig && spatialPackTargetOfConsumer(c, 0, 1, &packTarget) == 0 ? &packTarget : nullptr;
-    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32))) pack = nullptr;
+    // (a dispatch narrower than the image would mark whole rows as packed that it only wrote in part: ADVICE r03)
+    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32) || groupsX * 8 < out.w)) pack = nullptr;
     if (pack) {
         // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
         if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;

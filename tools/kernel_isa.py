@@ -51,7 +51,7 @@ for m in re.finditer(r'^([0-9a-f]+) <(\S+)>:\n(.*?)(?=^\n|\Z)', asm, re.M | re.S
     if want not in dem: continue
     ins = []  # (address, text)
     for l in body.split("\n"):
-        mm = re.match(r"\s+(\S.*?)\s+// ([0-9A-F]+):.*?(<\S+\+0x[0-9a-f]+>)?$", l)
+        mm = re.match(r"\s+(\S.*?)\s*// ([0-9A-F]+):.*?(<\S+\+0x[0-9a-f]+>)?$", l)
         if mm: ins.append((int(mm.group(2), 16), mm.group(1) + (" " + mm.group(3) if mm.group(3) else "")))
     if not ins: continue
     blk = [b for b in meta.split("- .agpr_count") if re.search(r"\.name:\s+" + re.escape(name) + r"\s", b)]

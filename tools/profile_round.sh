@@ -10,12 +10,21 @@ export TMPDIR=/tmp
 cd /tmp
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())" > $OUT/source_digest.txt
 python $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 python $REPO/tools/summarize_profile.py $(ls $OUT/kt/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex "plr::" -d $OUT/pmc_$C -o pmc --output-format csv -- python $REPO/bench.py --steps 4 --warmup 2 --profile-frames 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
+  timeout 300 rocprofv3 --pmc $C --kernel-include-regex "plr::" -d $OUT/pmc_$C -o pmc --output-format csv -- python $REPO/bench.py --steps 4 --warmup 2 --profile-frames 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
   python $REPO/tools/pmc_summary.py $(ls $OUT/pmc_$C/*counter_collection.csv | head -1) $OUT/pmc_$C.csv
   rm -rf $OUT/pmc_$C
+done
+# SQ / TA / TCP / TCC counters of every plr:: kernel (one group per pass; a rocprofv3 pass that hangs is cut off): bench.py's valu_roofline / l1_roofline
+i=0
+for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
+         "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 200 rocprofv3 --pmc $C --kernel-include-regex "plr::" -d $OUT/pmc_sq$i -o pmc --output-format csv -- python $REPO/bench.py --steps 3 --warmup 2 --profile-frames 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq$i.err
+  python $REPO/tools/pmc_summary.py $(ls $OUT/pmc_sq$i/*counter_collection.csv | head -1) $OUT/pmc_sq$i.csv
+  rm -rf $OUT/pmc_sq$i
 done
 python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --pass-table 2> $OUT/pass_table.txt > /dev/null
 # the other single-GPU frame sizes of BASELINE.json as bench lines (config 1: 1080p, config 5 unpartitioned: 8K)
