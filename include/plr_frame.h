@@ -49,7 +49,12 @@ typedef struct plrf_settings {
  * of every item plrf_get_exchange_items reports for that exchange id; PLRF_EXCHANGE_HISTOGRAM instead sums the 128-bin luminance
  * histogram over all bands in place (plrf_get_histogram_exchange). */
 enum plrf_exchange_id { PLRF_EXCHANGE_HISTOGRAM = 0, PLRF_EXCHANGE_GI_TRACE = 1, PLRF_EXCHANGE_GI_TEMPORAL = 2, PLRF_EXCHANGE_GI_HISTORY = 3,
-                        PLRF_EXCHANGE_POST = 4, PLRF_EXCHANGE_COUNT = 5 };
+                        PLRF_EXCHANGE_POST = 4,
+                        /* only with run_light_matrix: the depth range of the whole frame for the cascade fit (lightMatrix.comp:76-78 reads the apex of the
+                         * depth pyramid; a band has none). plrf_get_depth_apex_exchange names two floats {min, max} in device memory holding the band's
+                         * range: replace them IN PLACE by the minimum of all bands' first and the maximum of all bands' second float (exact: the result
+                         * equals the unpartitioned pyramid's apex bit for bit) */
+                        PLRF_EXCHANGE_DEPTH_APEX = 5, PLRF_EXCHANGE_COUNT = 6 };
 /* phase bits or-ed into exchange_id when band_overlap_exchange is on (ids 1..4; the histogram is always one call): after the producer's
  * edge rows are launched the callback gets id | PLRF_EXCHANGE_BEGIN and must only START the transfers (stream-ordered after what is already
  * on hip_stream); the producer's interior rows are launched next and run beside the transfers; before the first consumer of the halo rows
@@ -68,6 +73,7 @@ int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, 
 /* items of the frame being launched (valid inside the callback and until the next plrf_frame); *inout_count = capacity in, count out */
 int plrf_get_exchange_items(void* pipeline, int exchange_id, plrf_exchange_item* out_items, uint32_t* inout_count);
 int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes);
+int plrf_get_depth_apex_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes); /* 8 bytes: float min, float max */
 
 /* ---- the same exchange, natively over RCCL (csrc/frontend/band_exchange.cpp): one process per GPU, one band per process ----
  * plrf_rccl_attach creates this rank's communicator (ncclCommInitRank with the id rank 0 obtained from plrf_rccl_get_unique_id and handed to

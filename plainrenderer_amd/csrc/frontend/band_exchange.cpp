@@ -131,6 +131,18 @@ struct RcclExchange {
             // 128 bin counts, each < 2^32 pixels in total: the unsigned sum is exact, so every band derives the same exposure
             return nccl(ncclAllReduce(ptr, ptr, bytes / 4, ncclUint32, ncclSum, comm, launchStream), "ncclAllReduce(histogram)");
         }
+        if (id == PLRF_EXCHANGE_DEPTH_APEX) {
+            // SURVEY 8e, collective 2: {min, max} of the bands' depth ranges -> the apex of the unpartitioned depth pyramid (min / max are exact)
+            void* ptr = nullptr;
+            size_t bytes = 0;
+            if (int rc = plrf_get_depth_apex_exchange(fp, &ptr, &bytes)) return xfail(rc, plrf_last_error());
+            float* f = (float*)ptr;
+            if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
+            const int r0 = nccl(ncclAllReduce(f, f, 1, ncclFloat, ncclMin, comm, launchStream), "ncclAllReduce(depth min)");
+            const int r1 = nccl(ncclAllReduce(f + 1, f + 1, 1, ncclFloat, ncclMax, comm, launchStream), "ncclAllReduce(depth max)");
+            const int grc = nccl(ncclGroupEnd(), "ncclGroupEnd");
+            return r0 ? r0 : (r1 ? r1 : grc);
+        }
         if (phase == PLRF_EXCHANGE_BEGIN) {
             if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
             if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;

@@ -140,5 +140,13 @@ int plrf_get_histogram_exchange(void* p, void** outPtr, size_t* outBytes) {
         *outBytes = 128 * sizeof(uint32_t);
     })
 }
+int plrf_get_depth_apex_exchange(void* p, void** outPtr, size_t* outBytes) {
+    PLRF_TRY({
+        FramePipeline* fp = (FramePipeline*)p;
+        size_t size = 0;
+        if (plr_get_image_device_pointer(RenderBackend::toC(fp->depthApexImage()), 0, outPtr, &size) != PLR_OK) throw std::runtime_error(plr_last_error());
+        *outBytes = 2 * sizeof(float);
+    })
+}
 
 } // extern "C"

@@ -627,6 +627,8 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     m_minMaxDepthPyramid = perTilePyramid(s)
         ? m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::Manual, bandPyramidMipCount), nullptr, 0)
         : m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::RG32_sFloat, ImageUsageFlags::Storage | ImageUsageFlags::Sampled, MipCount::FullChain), nullptr, 0);
+    // band rendering: the depth range of the whole frame (lightMatrix.comp's "lowest mip"), reduced from the band's per-tile pyramids and all-reduced
+    m_bandDepthApex = m_be.createImage(desc2D(1, 1, ImageFormat::RG32_sFloat), nullptr, 0);
     m_depthHalfRes = m_be.createImage(desc2D(W / 2, H / 2, ImageFormat::R16_sFloat), nullptr, 0);
     m_brdfLut = m_be.createImage(desc2D(s.brdfLutRes, s.brdfLutRes, ImageFormat::RGBA16_sFloat), nullptr, 0);
     m_skyLut = m_be.createImage(desc2D(200, 100, ImageFormat::R11G11B10_uFloat), nullptr, 0);          // Sky.cpp sky LUT
@@ -704,6 +706,10 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         d.shaderDescription.srcPathRelative = "lightMatrix.comp";
         d.shaderDescription.specialisationConstants = {spec(0, (uint32_t)s.shading.sunShadowCascadeCount)};
         m_lightMatrixPass = m_be.createComputePass(d);
+        d.name = "Depth pyramid apex of the band";
+        d.shaderDescription.srcPathRelative = "depthPyramidApex.comp"; // no reference shader: see kernels/hiz.hip
+        d.shaderDescription.specialisationConstants = {};
+        m_depthApexPass = m_be.createComputePass(d);
     }
     {
         // Sky::init (Techniques/Sky.cpp:5-64, 196-258): LUT sizes 128^2, 32^2, 200x100; the transmission and sky LUT images are the ones the
@@ -962,12 +968,36 @@ void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:
     m_be.setComputePassExecution(exe);
 }
 
+// band rendering / a frame too large for one pyramid: the top level of the per-tile pyramid (one texel per 64 x 64 pixels), the band's rows of it, reduced to
+// one texel; with an exchange callback the bands' texels are then combined (min on .r, max on .g) - SURVEY 8e's second collective
+void FramePipeline::computeDepthApexOfTiles() {
+    ComputePassExecution exe;
+    exe.genericInfo.handle = m_depthApexPass;
+    const uint32_t top = bandPyramidMipCount - 1;
+    const uint32_t levelRows = std::max((settings.height / 2) >> top, 1u);
+    RowRange rows{0, levelRows};
+    if (settings.band.enabled()) {
+        rows = scaleRows(bandRows(0), 64); // 64 full-resolution rows per texel of that level
+        rows.end = std::min(rows.end, levelRows);
+    }
+    exe.dispatchCount[0] = 1; exe.dispatchCount[2] = 1;
+    exe.dispatchBase[1] = rows.begin;
+    exe.dispatchCount[1] = rows.end - rows.begin;
+    exe.genericInfo.resources.sampledImages = {ImageResource(m_minMaxDepthPyramid, top, 0)};
+    exe.genericInfo.resources.storageImages = {ImageResource(m_bandDepthApex, 0, 1)};
+    m_be.setComputePassExecution(exe);
+    if (settings.band.enabled() && m_exchangeFn) {
+        m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[ExchangeDepthApex], "Exchange: depth range all-reduce (min, max)", {m_bandDepthApex}, {});
+    }
+}
+
 void FramePipeline::computeSunLightMatrices() { // RenderFrontend.cpp:840-872
     ComputePassExecution exe;
     exe.genericInfo.handle = m_lightMatrixPass;
     exe.dispatchCount[0] = exe.dispatchCount[1] = exe.dispatchCount[2] = 1;
     const uint32_t depthPyramidMipCount = mipCountFromResolution(settings.width / 2, settings.height / 2, 1);
-    exe.genericInfo.resources.storageImages = {ImageResource(m_minMaxDepthPyramid, depthPyramidMipCount - 1, 1)};
+    if (perTilePyramid(settings)) exe.genericInfo.resources.storageImages = {ImageResource(m_bandDepthApex, 0, 1)};
+    else exe.genericInfo.resources.storageImages = {ImageResource(m_minMaxDepthPyramid, depthPyramidMipCount - 1, 1)};
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sunShadowInfoBuffer, false, 0)};
     struct LightMatrixPushConstants { float highestCascadePaddingSize; float highestCascadeMinFarPlane; } pc;
     pc.highestCascadePaddingSize = settings.sdfTrace.traceInfluenceRadius;
@@ -1161,7 +1191,10 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     if (settings.runSkyLuts) updateSkyLut();
     // [renderDepthPrepass: input]
     if (settings.runHiZ) computeDepthPyramid(currentRenderTarget.depthBuffer);
-    if (settings.runLightMatrix && settings.runHiZ && !perTilePyramid(settings)) computeSunLightMatrices(); // needs the apex of the full chain
+    if (settings.runLightMatrix && settings.runHiZ) {
+        if (perTilePyramid(settings)) computeDepthApexOfTiles(); // no apex in a per-tile pyramid: reduce (and, across bands, all-reduce) it
+        computeSunLightMatrices();
+    }
     // [renderSunShadowCascades: input]
     if (settings.runGI && settings.shading.indirectLightingTech == IndirectLightingTech::SDFTrace) {
         if (settings.sdfTrace.halfResTrace) downscaleDepth(currentRenderTarget);

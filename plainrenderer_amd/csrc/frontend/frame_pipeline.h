@@ -79,7 +79,8 @@ struct BandSettings {
 };
 // phase bits or-ed into the exchange id a callback receives (0: start the exchange and wait for it)
 enum ExchangePhase : int { ExchangeBegin = 0x100, ExchangeEnd = 0x200, ExchangeIdMask = 0xff };
-enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeCount = 5 };
+// ExchangeDepthApex (only with runLightMatrix): all-reduce of the band's depth range, min on .r / max on .g of a 1 x 1 RG32F image (depthApexImage())
+enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeDepthApex = 5, ExchangeCount = 6 };
 // one image whose rows next to the band must be refreshed from the neighbours: this band sends its first / last haloRows owned
 // rows up / down and receives [rowBegin - haloRows, rowBegin) and [rowEnd, rowEnd + haloRows) (clipped to the image)
 struct ExchangeItem { ImageHandle image; uint32_t mip = 0; uint32_t rowBegin = 0, rowEnd = 0, haloRows = 0, rowBytes = 0, imageRows = 0; };
@@ -251,7 +252,7 @@ struct FramePipelineSettings {
     bool runExposure = true, runHiZ = true, runGI = true, runShading = true, runTAA = true, runBloom = true, runTonemap = true;
     BandSettings band; // width/height stay the WHOLE frame's
     // input producers recorded as compute passes instead of being uploaded by the caller
-    bool runLightMatrix = false; // lightMatrix.comp after the depth pyramid (RenderFrontend.cpp:353, 840-872); needs the pyramid apex: not in band mode
+    bool runLightMatrix = false; // lightMatrix.comp after the depth pyramid (RenderFrontend.cpp:353, 840-872); in band mode the apex it reads is the all-reduced depth range of the bands (ExchangeDepthApex)
     bool runVolumetrics = false; // froxelVolumeMaterial / froxelLightScattering / volumeLightingReprojection / volumetricLightingIntegration (Volumetrics.cpp:119-243)
     bool runSkyLuts = false;     // skyTransmissionLut / skyMultiscatterLut / skyLut.comp (Techniques/Sky.cpp:260-316) instead of uploaded LUTs
     float volumetricsMaxDistance = 30.f; // VolumetricsSettings::maxDistance, the last cascade's minimum far plane
@@ -281,6 +282,7 @@ public:
     void setExchangeCallback(ExchangeCallback fn, void* user) { m_exchangeFn = fn; m_exchangeUser = user; }
     const std::vector<ExchangeItem>& exchangeItems(int exchangeId) const { return m_exchangeItems[exchangeId]; }
     StorageBufferHandle histogramBuffer() const { return m_histogramBuffer; }
+    ImageHandle depthApexImage() const { return m_bandDepthApex; }
     RenderBackend& backend() { return m_be; }
     FramePipelineSettings settings;
 
@@ -294,6 +296,7 @@ private:
     void computeTonemapping(ImageHandle src);
     bool asyncPostTail() const { return true; } // bloom chain + tonemap as the frame's asynchronous tail (plr.h async_tail)
     void computeBRDFLut();
+    void computeDepthApexOfTiles();
     void computeSunLightMatrices();
     void updateTransmissionLut();
     void computeVolumetricLighting(float deltaTime);
@@ -318,13 +321,13 @@ private:
 
     UniformBufferHandle m_globalUniformBuffer, m_volumetricsInfoBuffer;
     FrameRenderTargets m_frameRenderTargets[2];
-    ImageHandle m_postProcessBuffers[2], m_worldSpaceNormalImage, m_albedoImage, m_specularImage, m_minMaxDepthPyramid, m_depthHalfRes, m_brdfLut, m_skyLut,
+    ImageHandle m_postProcessBuffers[2], m_worldSpaceNormalImage, m_albedoImage, m_specularImage, m_minMaxDepthPyramid, m_bandDepthApex, m_depthHalfRes, m_brdfLut, m_skyLut,
         m_transmissionLut, m_volumetricIntegrationVolume;
     ImageHandle m_shadowMaps[4], m_noiseTextures[4];
     std::vector<ImageHandle> m_sdfVolumes;
     StorageBufferHandle m_histogramPerTileBuffer, m_histogramBuffer, m_lightBuffer, m_sunShadowInfoBuffer, m_depthPyramidSyncBuffer;
     RenderPassHandle m_histogramPerTilePass, m_histogramResetPass, m_histogramCombinePass, m_preExposeLightsPass, m_depthPyramidPass, m_depthDownscalePass,
-        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass, m_skyTransmissionLutPass, m_skyMultiscatterLutPass, m_skyLutPass;
+        m_deferredShadingPass, m_tonemappingPass, m_brdfLutPass, m_lightMatrixPass, m_depthApexPass, m_skyTransmissionLutPass, m_skyMultiscatterLutPass, m_skyLutPass;
     ImageHandle m_skyMultiscatterLut, m_scatteringTransmittanceVolume, m_volumetricLightingHistory[2], m_volumeMaterialVolume, m_perlinNoise3D;
     RenderPassHandle m_froxelVolumeMaterialPass, m_froxelScatteringTransmittancePass, m_volumetricLightingIntegration, m_volumetricLightingReprojection;
     VolumetricsState m_volumetricsState;

@@ -378,6 +378,10 @@ static int launchPreExposeLights(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("preExposeLights.comp", launchPreExposeLights);
+// Also the fast set's kernel: a single wave (preExposeLightsWave: lane-parallel histogram scan with wave reductions), the same device function the fused frame
+// front runs in its last block. Stand-alone it is what band rendering launches behind the histogram all-reduce. Its output is two floats every later
+// pass multiplies with: it keeps the exact set's arithmetic in both math modes on purpose.
+PLR_REGISTER_SHADER_FAST("preExposeLights.comp", launchPreExposeLights);
 
 int prepareExposureChain(const PassCtx* const* ctxs, ExposureChainPlan* out) {
     const PassCtx &reset = *ctxs[0], &comb = *ctxs[1], &expo = *ctxs[2];

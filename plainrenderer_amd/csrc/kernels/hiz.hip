@@ -168,4 +168,42 @@ static int launchDepthHiZPyramid(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("depthHiZPyramid.comp", launchDepthHiZPyramid);
 
+
+// ------------------------------------------------------------------------------------------------ depthPyramidApex.comp (band rendering; no reference shader)
+// A band builds per-tile pyramids (six levels): nobody computes the apex lightMatrix.comp:76-78 reads. This pass reduces the rows of a pyramid
+// level that belong to the band - .r = min, .g = max, the pyramid's own rule (depthHiZPyramid.comp:52-124: the sky is already mapped out of .r
+// by level 0) - into a 1 x 1 RG32F image; the bands' results are then combined by an all-reduce (min on .r, max on .g: SURVEY 8e, collective 2).
+// min / max are associative and exact, so the combined value equals the apex of the unpartitioned chain bit for bit.
+// Bindings: sampled 0 = pyramid level (RG32F), storage 1 = apex (RG32F, 1 x 1); the dispatch's rows are texel rows of that level.
+__global__ __launch_bounds__(256) void depthPyramidApexKernel(ImgView level, int row0, int row1, float2* __restrict__ apex) {
+    __shared__ float smin[4], smax[4];
+    const float2* t = (const float2*)level.ptr;
+    const int n = (row1 - row0) * level.w;
+    float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
+    for (int i = (int)threadIdx.x; i < n; i += 256) {
+        const float2 v = t[(size_t)row0 * (size_t)level.w + (size_t)i];
+        mn = fminf(mn, v.x);
+        mx = fmaxf(mx, v.y);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63u) == 0u) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) apex[0] = make_float2(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])), fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+}
+static int launchDepthPyramidApex(const PassCtx& c) {
+    if (int rc = c.needSampled(0, F_RG32F, "depthPyramidApex pyramid level")) return rc;
+    if (int rc = c.needStorage(1, F_RG32F, "depthPyramidApex apex")) return rc;
+    const ImgView& level = c.sampled[0];
+    const PassCtx::RowSpan rs = c.rowSpan(level.h, 1);
+    if (rs.y1 <= rs.y0) return c.fail(-1, "depthPyramidApex: no rows to reduce");
+    depthPyramidApexKernel<<<1, 256, 0, c.stream>>>(level, rs.y0, rs.y1, (float2*)c.storage[1].ptr);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+PLR_REGISTER_SHADER("depthPyramidApex.comp", launchDepthPyramidApex);
+PLR_REGISTER_SHADER_FAST("depthPyramidApex.comp", launchDepthPyramidApex); // comparisons only: one kernel serves both math modes
+
 } // namespace plr

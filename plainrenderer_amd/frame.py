@@ -34,7 +34,7 @@ class PlrfExchangeItem(C.Structure):
 
 
 EXCHANGE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
-EXCHANGE_HISTOGRAM, EXCHANGE_GI_TRACE, EXCHANGE_GI_TEMPORAL, EXCHANGE_GI_HISTORY, EXCHANGE_POST = range(5)
+EXCHANGE_HISTOGRAM, EXCHANGE_GI_TRACE, EXCHANGE_GI_TEMPORAL, EXCHANGE_GI_HISTORY, EXCHANGE_POST, EXCHANGE_DEPTH_APEX = range(6)
 EXCHANGE_BEGIN, EXCHANGE_END, EXCHANGE_ID_MASK = 0x100, 0x200, 0xff  # phase bits (band_overlap_exchange)
 
 
@@ -174,6 +174,12 @@ class FramePipeline:
     def histogram_exchange(self):
         ptr, size = C.c_void_p(), C.c_size_t()
         self._check(self.lib.plrf_get_histogram_exchange(self.handle, C.byref(ptr), C.byref(size)))
+        return ptr.value, size.value
+
+    def depth_apex_exchange(self):
+        """(device pointer, 8): the band's {min, max} depth range, to be all-reduced in place (EXCHANGE_DEPTH_APEX)"""
+        ptr, size = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.plrf_get_depth_apex_exchange(self.handle, C.byref(ptr), C.byref(size)))
         return ptr.value, size.value
 
     def submitted_globals(self):

@@ -167,6 +167,16 @@ class DistTransport:
             t = self._tensor(ptr, nbytes).view(self.torch.int32)  # bin counts < 2^31: the int32 sum is the uint32 sum
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
+    def all_reduce_depth_apex(self, ptr, nbytes, stream_ptr):
+        """{min, max} of the bands' depth ranges, in place (SURVEY 8e collective 2): min on the first float, max on the second"""
+        with self._on_stream(stream_ptr):
+            t = self._tensor(ptr, nbytes).view(self.torch.float32)
+            lo, hi = t[0:1].clone(), t[1:2].clone()
+            self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+            self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+            t[0:1].copy_(lo)
+            t[1:2].copy_(hi)
+
 
 class LocalGroup:
     """shared state of the bands of one process (LocalTransport)"""
@@ -231,6 +241,17 @@ class LocalTransport:
         self._call(self.g.lib.plr_write_device_memory(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes)), "plr_write_device_memory")
 
 
+    def all_reduce_depth_apex(self, ptr, nbytes, stream_ptr):
+        host = np.zeros(2, np.float32)
+        self._call(self.g.lib.plr_read_device_memory(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(8)), "plr_read_device_memory")
+        self.g.slots[self.rank] = host
+        self.g.barrier.wait()
+        both = np.stack(self.g.slots)
+        total = np.array([both[:, 0].min(), both[:, 1].max()], np.float32)
+        self.g.barrier.wait()
+        self._call(self.g.lib.plr_write_device_memory(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), C.c_size_t(8)), "plr_write_device_memory")
+
+
 class Exchange:
     """the exchange callback of one band: glue between the C++ host's exchange points and a transport"""
 
@@ -255,6 +276,11 @@ class Exchange:
         if exchange_id == self._hist_id:
             ptr, nbytes = self.fp.histogram_exchange()
             self.t.all_reduce_histogram(ptr, nbytes, stream_ptr)
+            return
+        from .frame import EXCHANGE_DEPTH_APEX
+        if exchange_id == EXCHANGE_DEPTH_APEX:
+            ptr, nbytes = self.fp.depth_apex_exchange()
+            self.t.all_reduce_depth_apex(ptr, nbytes, stream_ptr)
             return
         items = [Rows.from_item(it) for it in self.fp.exchange_items(exchange_id)]
 

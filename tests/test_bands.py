@@ -143,14 +143,14 @@ def _make_inputs():
     return SyntheticInputs(scene, cams[1], cams[0], W, H, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
 
 
-def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1):
-    """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame"""
+def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1, extra=None):
+    """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame; extra = more FramePipeline settings"""
     from plainrenderer_amd import RenderBackend
     from plainrenderer_amd.frame import FramePipeline
     try:
         be = RenderBackend(W, H, device=0)
         be.setMathMode(not exact)
-        kw = dict(FP_ARGS, sdf_half_res_trace=half_res)
+        kw = dict(FP_ARGS, sdf_half_res_trace=half_res, **(extra or {}))
         if band is not None:
             b0, b1 = tiling.band_rows(H, band[1], band[0])
             kw.update(band_row_begin=b0, band_row_end=b1, **(halos or {}))
@@ -167,7 +167,8 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1)
                                color=be.downloadImage(fp.image("color%d" % cur), 0, np.uint32).reshape(H, W).copy(),
                                swap=be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(H, W, 4).copy(),
                                hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
-                               light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes()))
+                               light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes(),
+                               shadow=be.downloadStorageBuffer(fp.storage_buffer("sunShadowInfo"), 304, dtype=np.uint8).tobytes()))
         res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1])
         fp.destroy()
         be.shutdown()
@@ -179,10 +180,10 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1)
         raise
 
 
-def _run_full(inputs, exact, half_res=1):
+def _run_full(inputs, exact, half_res=1, extra=None):
     # on its own thread = its own backend: the session-wide test backend may already live on the main thread
     out = {}
-    t = threading.Thread(target=_run, args=(inputs, exact), kwargs=dict(out=out, half_res=half_res))
+    t = threading.Thread(target=_run, args=(inputs, exact), kwargs=dict(out=out, half_res=half_res, extra=extra))
     t.start()
     t.join(timeout=600)
     assert "full" in out, "the unpartitioned frame did not finish"
@@ -191,11 +192,11 @@ def _run_full(inputs, exact, half_res=1):
     return out["full"]
 
 
-def _run_bands(inputs, n, exact, halos, half_res=1):
+def _run_bands(inputs, n, exact, halos, half_res=1, extra=None):
     from plainrenderer_amd import backend
     group = tiling.LocalGroup(n, backend._load())
     out = {}
-    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res)) for i in range(n)]
+    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res, extra)) for i in range(n)]
     for t in threads:
         t.start()
     for t in threads:
@@ -238,6 +239,27 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
     B, E = 0x100, 0x200
     expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if overlap else [0, 1, 2, 3, 4]
     assert bands[0]["calls"][:len(expected)] == expected
+
+
+@pytest.mark.gpu
+def test_gpu_light_matrices_of_bands_equal_the_unpartitioned_ones():
+    # SURVEY 8e, collective 2: lightMatrix.comp fits the shadow cascades to the depth range of the FRAME (the apex of the depth
+    # pyramid). A band reduces its rows of the per-tile pyramid and the bands' ranges are all-reduced (min, max): every band must end up with the
+    # cascade splits and light matrices of the unpartitioned frame, bit for bit, and so must the frames shaded with them
+    inputs = _make_inputs()
+    extra = dict(run_light_matrix=1)
+    full = _run_full(inputs, True, extra=extra)
+    halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H)
+    bands = _run_bands(inputs, 3, True, halos, extra=extra)
+    from plainrenderer_amd.frame import EXCHANGE_DEPTH_APEX
+    for i in range(3):
+        assert EXCHANGE_DEPTH_APEX in bands[i]["calls"], "band %d never all-reduced its depth range" % i
+        for f in range(N_FRAMES):
+            assert bands[i]["frames"][f]["shadow"] == full["frames"][f]["shadow"], "cascade fit of band %d differs in frame %d" % (i, f)
+    assert full["frames"][0]["shadow"] != bytes(304)
+    mism = _compare(full, bands, 3)
+    # (three bands of 64 rows with whole-image halos: the GI of a band two bands away is not exchanged, so only the direct light is held to bits here)
+    assert max(v for (f, i, k), v in mism.items() if k == "color") < 0.05, mism
 
 
 @pytest.mark.gpu
