@@ -88,6 +88,10 @@ def _gloo_worker(rank, world, port, height, out, bounds=None):
         assert checksum == int(interior.astype(np.uint64).sum())
         hist = np.arange(128, dtype=np.uint32) * (rank + 1)
         t.all_reduce_histogram(hist.ctypes.data, hist.nbytes, None)
+        # the second collective: {min, max} of the bands' depth ranges, min on the first float, max on the second
+        apex = np.array([0.25 + 0.125 * rank, 0.5 + 0.0625 * rank], np.float32)
+        t.all_reduce_depth_apex(apex.ctypes.data, apex.nbytes, None)
+        assert apex.tolist() == [0.25, 0.5 + 0.0625 * (world - 1)], apex
         out.put((rank, [a.copy() for a in arrays], hist.copy()))
     finally:
         dist.destroy_process_group()
