@@ -241,10 +241,12 @@ int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t r
 int plr_download_image(plr_image_handle image, uint32_t mip_level, void* out_data, size_t size);
 int plr_download_storage_buffer(plr_storage_buffer_handle buffer, void* out_data, size_t offset, size_t size);
 int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data, size_t offset, size_t size);
-/* Raw interop. The three calls below first make the launch stream wait for the frame's asynchronous tail (async_tail executions run on a second
- * stream): work the caller orders on plr_get_stream() afterwards - presenting or reading the swapchain, a collective on an image - is behind
- * everything recorded so far, tail included. Call them AFTER plr_render_frame for that guarantee; a pointer or stream obtained earlier and used
- * after a later plr_render_frame is ordered behind the launch stream only (call plr_get_stream again, or plr_wait_for_gpu_idle).
+/* Raw interop. async_tail executions run on a second stream: plr_get_stream() first makes the launch stream wait for that tail, so work the
+ * caller orders on the returned stream - presenting or reading the swapchain, a collective on an image - is behind everything recorded so far,
+ * tail included. Call it AFTER plr_render_frame for that guarantee (a stream obtained earlier and used after a later plr_render_frame is ordered
+ * behind the launch stream only: ask again, or plr_wait_for_gpu_idle). The two pointer getters imply NO ordering - an address is stable for the
+ * life of the resource and may be asked for at any time; order the accesses on plr_get_stream(), or inside a host callback execution that lists
+ * the resource (plr_set_host_callback_execution_on), which the backend orders against the tail itself.
  * plr_get_image_device_pointer: device address / byte size of one mip level (HBM resident; lets a caller fill inputs device-to-device). Fails
  * for an image the last frame's fused launch left unwritten (pass fusion level 2), like plr_download_image. An image whose address was
  * handed out may be written behind the backend's back from then on: launchers stop caching tables derived from it (backend.h contentVersionOf). */

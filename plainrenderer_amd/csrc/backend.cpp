@@ -1620,7 +1620,9 @@ int plr_download_uniform_buffer(plr_uniform_buffer_handle buffer, void* out_data
 }
 
 int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, void** out_ptr, size_t* out_size) {
-    NEED_INIT_JOINED(); // what the caller then orders on plr_get_stream() is behind the asynchronous tail as well
+    // No ordering is implied by asking for an address (the C++ host does it at record time, every frame, for its exchange items: a join here would
+    // serialise the asynchronous tail of every band frame - measured, +60 us per band). A caller orders its ACCESSES: on plr_get_stream(), which joins.
+    NEED_INIT();
     ImageRes* im; MipInfo* mi;
     int rc = imageMip(image, mip_level, &im, &mi);
     if (rc) return rc;
@@ -1634,7 +1636,7 @@ int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, voi
 }
 
 int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size) {
-    NEED_INIT_JOINED();
+    NEED_INIT();
     if (buffer >= g->sbufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid buffer handle");
     *out_ptr = g->sbufs[buffer].dev;
     if (out_size) *out_size = g->sbufs[buffer].size;

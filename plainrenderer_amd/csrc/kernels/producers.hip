@@ -94,6 +94,8 @@ static int launchLightMatrix(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("lightMatrix.comp", launchLightMatrix);
+// one invocation by definition (local_size 1x1x1), and its output - cascade splits and matrices - feeds discrete decisions of the shade: both math modes
+PLR_REGISTER_SHADER_FAST("lightMatrix.comp", launchLightMatrix);
 
 
 // ====================================================================================================================

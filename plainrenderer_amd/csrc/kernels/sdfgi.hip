@@ -36,6 +36,9 @@ static int launchDepthDownscale(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("depthDownscale.comp", launchDepthDownscale);
+// Stand-alone the pass is a stream of one nearest fetch and one half conversion per output texel: nothing for a second kernel to restructure, so this one
+// serves both math modes. (The default frame never launches it: the fused frame front writes the half-resolution depth from the pyramid's quad blocks.)
+PLR_REGISTER_SHADER_FAST("depthDownscale.comp", launchDepthDownscale);
 
 // ------------------------------------------------------------------------------------------------
 // sdfCameraFrustumCulling.comp:36-62 as one block doing an ordered stream compaction.

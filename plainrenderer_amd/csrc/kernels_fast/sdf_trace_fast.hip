@@ -18,6 +18,7 @@
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
 #include "fused_gi.h"
+#include <cstdlib>
 
 namespace plr {
 namespace fasttrace {
@@ -28,8 +29,18 @@ PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
 #ifndef PLR_TRACE_OCC
 #define PLR_TRACE_OCC
 #endif
+// The volume texels live in global memory, but their address comes out of the LDS-staged instance table, so the compiler cannot tell and emits
+// flat_load (which also counts on lgkmcnt). PLR_TRACE_GLOBAL_VOLUMES=1 types the pointer address_space(1): global_load with partial vmcnt waits.
+#ifndef PLR_TRACE_GLOBAL_VOLUMES
+#define PLR_TRACE_GLOBAL_VOLUMES 1 // measured, six runs each (profiles/r04_trace_variants.txt): 98.6 +- 0.4 us against 100.1 +- 0.5 us with flat loads
+#endif
+#if PLR_TRACE_GLOBAL_VOLUMES
+typedef const __attribute__((address_space(1))) uint16_t* VolumeTexels;
+#else
+typedef const uint16_t* VolumeTexels;
+#endif
 struct Volume {
-    const uint16_t* p;
+    VolumeTexels p;
     int w, h, d;
     float fw, fh, fd;
 };
@@ -116,7 +127,10 @@ PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mx, float* tOut) {
     return hx || hy || hz;
 }
 
-PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Volume& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
+// A ray against one instance, in two steps (SDF.inc:101-184). enterInstance: the ray in the instance's local frame and its entry into the volume's
+// box (SDF.inc:104-125) - cheap, no memory access. marchInstance: the sphere trace from that entry point.
+struct LocalRay { vec3 start, dir; float entryDistance; };
+PLR_DI bool enterInstance(const SDFInstance& inst, vec3 rayStartWorld, vec3 rayDirectionWorld, LocalRay* out) {
     const float* m = inst.worldToLocal;
     const vec3 localExtends = ld3(inst.localExtends);
     vec3 rayStartLocal(m[0] * rayStartWorld.x + m[4] * rayStartWorld.y + m[8] * rayStartWorld.z + m[12],
@@ -130,45 +144,78 @@ PLR_DI void traceInstance(const SDFInstance& inst, vec3 rayStartWorld, const Vol
     const vec3 sdfMaxLocal = localExtends * 0.5f;
     float hitDistanceLocal = 0.f;
     const bool inside = fabsf(rayStartLocal.x) <= sdfMaxLocal.x && fabsf(rayStartLocal.y) <= sdfMaxLocal.y && fabsf(rayStartLocal.z) <= sdfMaxLocal.z;
+    bool enters = true;
     if (!inside) {
         float t;
-        if (rayAABBIntersection(rayStartLocal, rayDirection, sdfMaxLocal, &t)) {
-            rayStartLocal += t * rayDirection;
-            hitDistanceLocal = t;
-        } else return;
+        enters = rayAABBIntersection(rayStartLocal, rayDirection, sdfMaxLocal, &t);
+        rayStartLocal += t * rayDirection;
+        hitDistanceLocal = t;
     }
-    const float localToGlobalScale = rsqf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-    if (localToGlobalScale * hitDistanceLocal > tr.closestHitDistance) return;
-    const vec3 invExt(rcpf(localExtends.x), rcpf(localExtends.y), rcpf(localExtends.z));
-    const vec3 voxel(localExtends.x * rcpf(sdf.fw), localExtends.y * rcpf(sdf.fh), localExtends.z * rcpf(sdf.fd));
-    const float distanceThreshold = __builtin_amdgcn_sqrtf(dot(voxel, voxel)) * 0.25f;
-    const vec3 lim = sdfMaxLocal + 0.01f;
-    vec3 pos = rayStartLocal;
-    float dLast = 0.f, d = 0.f;
-    const bool thick = sdf.w >= 2 && sdf.h >= 2 && sdf.d >= 2; // uniform: the instance record is shared by the wave
+    out->start = rayStartLocal; out->dir = rayDirection; out->entryDistance = hitDistanceLocal;
+    return enters;
+}
+
+// the state one lane carries through a march; `go` = this lane is still marching
+struct MarchState {
+    VolumeTexels p; int w, h, d;
+    vec3 pos, dir, fpScale, fpBias, lim, invExt;
+    float distanceThreshold, localToGlobalScale, hitDistanceLocal, dv, dLast;
+    bool thick;
+};
+PLR_DI bool beginMarch(const SDFInstance& inst, const ImgView& view, const LocalRay& ray, float closestHitDistance, MarchState* st) {
+    const float* m = inst.worldToLocal;
+    const vec3 localExtends = ld3(inst.localExtends);
+    st->localToGlobalScale = rsqf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    if (st->localToGlobalScale * ray.entryDistance > closestHitDistance) return false;
+    const float fw = (float)view.w, fh = (float)view.h, fd = (float)view.d;
+    st->p = (VolumeTexels)(const uint16_t*)view.ptr; st->w = view.w; st->h = view.h; st->d = view.d;
+    st->invExt = vec3(rcpf(localExtends.x), rcpf(localExtends.y), rcpf(localExtends.z));
+    const vec3 voxel(localExtends.x * rcpf(fw), localExtends.y * rcpf(fh), localExtends.z * rcpf(fd));
+    st->distanceThreshold = __builtin_amdgcn_sqrtf(dot(voxel, voxel)) * 0.25f;
+    st->lim = localExtends * 0.5f + 0.01f;
+    st->pos = ray.start; st->dir = ray.dir;
+    st->hitDistanceLocal = ray.entryDistance;
+    st->dLast = 0.f; st->dv = 0.f;
+    st->thick = view.w >= 2 && view.h >= 2 && view.d >= 2;
     // uvw = pos / extends + 0.5 and the sampler's fixed-point texel coordinate (uvw * n - 0.5) * 256 + 0.5 as one multiply-add per axis
-    const vec3 fpScale(invExt.x * 256.f * sdf.fw, invExt.y * 256.f * sdf.fh, invExt.z * 256.f * sdf.fd);
-    const vec3 fpBias(128.f * sdf.fw - 127.5f, 128.f * sdf.fh - 127.5f, 128.f * sdf.fd - 127.5f);
-    for (int i = 0; i < 128; i++) {
-        if (fabsf(pos.x) > lim.x || fabsf(pos.y) > lim.y || fabsf(pos.z) > lim.z) break;
-        dLast = d;
-        d = thick ? sampleSDFInterior(sdf, vec3(pos.x * fpScale.x + fpBias.x, pos.y * fpScale.y + fpBias.y, pos.z * fpScale.z + fpBias.z))
-                  : sampleSDF(sdf, pos.x * invExt.x + 0.5f, pos.y * invExt.y + 0.5f, pos.z * invExt.z + 0.5f);
-        if (d < distanceThreshold) {
-            tr.hit = true;
-            const float distanceGlobal = hitDistanceLocal * localToGlobalScale;
-            if (distanceGlobal < tr.closestHitDistance) {
-                tr.closestHitDistance = distanceGlobal;
-                const float lastStepSizeLocal = d * rcpf(1.f - (d - dLast));
-                tr.albedoSrgb = ld3(inst.meanAlbedo);
-                tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeLocal * localToGlobalScale);
-            }
-            break;
+    st->fpScale = vec3(st->invExt.x * 256.f * fw, st->invExt.y * 256.f * fh, st->invExt.z * 256.f * fd);
+    st->fpBias = vec3(128.f * fw - 127.5f, 128.f * fh - 127.5f, 128.f * fd - 127.5f);
+    return true;
+}
+// one step of SDF.inc:139-181 for a marching lane; false = this lane's march is over (left the box, or hit: then tr is updated)
+PLR_DI bool marchStep(MarchState& st, const SDFInstance& inst, vec3 rayStartWorld, vec3 rayDirectionWorld, TraceResult& tr) {
+    if (fabsf(st.pos.x) > st.lim.x || fabsf(st.pos.y) > st.lim.y || fabsf(st.pos.z) > st.lim.z) return false;
+    Volume sdf;
+    sdf.p = st.p; sdf.w = st.w; sdf.h = st.h; sdf.d = st.d; sdf.fw = (float)st.w; sdf.fh = (float)st.h; sdf.fd = (float)st.d;
+    st.dLast = st.dv;
+    st.dv = st.thick ? sampleSDFInterior(sdf, vec3(st.pos.x * st.fpScale.x + st.fpBias.x, st.pos.y * st.fpScale.y + st.fpBias.y, st.pos.z * st.fpScale.z + st.fpBias.z))
+                     : sampleSDF(sdf, st.pos.x * st.invExt.x + 0.5f, st.pos.y * st.invExt.y + 0.5f, st.pos.z * st.invExt.z + 0.5f);
+    if (st.dv < st.distanceThreshold) {
+        tr.hit = true;
+        const float distanceGlobal = st.hitDistanceLocal * st.localToGlobalScale;
+        if (distanceGlobal < tr.closestHitDistance) {
+            tr.closestHitDistance = distanceGlobal;
+            const float lastStepSizeLocal = st.dv * rcpf(1.f - (st.dv - st.dLast));
+            tr.albedoSrgb = ld3(inst.meanAlbedo);
+            tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeLocal * st.localToGlobalScale);
         }
-        const float step = fabsf(d);
-        pos = pos + rayDirection * step;
-        hitDistanceLocal += step;
+        return false;
     }
+    const float step = fabsf(st.dv);
+    st.pos = st.pos + st.dir * step;
+    st.hitDistanceLocal += step;
+    return true;
+}
+
+// the whole of one instance for all lanes of a wave that share it (the instance record is wave-uniform): the form of rounds 1-3, kept for the
+// launcher's A/B switch (PLR_TRACE_PER_LANE=0)
+PLR_DI void traceInstance(const SDFInstance& inst, const ImgView& view, vec3 rayStartWorld, vec3 rayDirectionWorld, TraceResult& tr) {
+    LocalRay ray;
+    if (!enterInstance(inst, rayStartWorld, rayDirectionWorld, &ray)) return;
+    MarchState st;
+    if (!beginMarch(inst, view, ray, tr.closestHitDistance, &st)) return;
+    for (int i = 0; i < 128; i++)
+        if (!marchStep(st, inst, rayStartWorld, rayDirectionWorld, tr)) break;
 }
 
 struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
@@ -179,7 +226,7 @@ struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
 
 // SIG: also write the decision signature of every pixel (plr_debug_set_decision_signature; bit layout in oracle/oracle.h)
 // PACK: also write the packed texel the spatial filter gathers (fused_gi.h); 0 = no, else the format of packDepth (F_R16F / F_D32)
-template <bool STRICT_CUTOFF, bool SIG, int PACK>
+template <bool STRICT_CUTOFF, bool SIG, int PACK, bool PER_LANE = false>
 __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
@@ -261,16 +308,48 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         tr.closestHitDistance = 10000.f;
         tr.hitPos = vec3(0.f);
         tr.albedoSrgb = vec3(0.f);
-        for (int i = 0; i < objectCount; i++) {
-            const SDFInstance& inst = staged[i].inst;
-            const ImgView view = staged[i].view;
-            const uint32_t instIndex = staged[i].instIndex;
-            Volume vol;
-            vol.p = (const uint16_t*)view.ptr; vol.w = view.w; vol.h = view.h; vol.d = view.d;
-            vol.fw = (float)view.w; vol.fh = (float)view.h; vol.fd = (float)view.d;
-            const float before = tr.closestHitDistance;
-            traceInstance(inst, rayOrigin, vol, L, tr);
-            if (SIG && tr.closestHitDistance != before) raySig = (instIndex + 1u) << 11;
+        if (!PER_LANE) {
+            for (int i = 0; i < objectCount; i++) {
+                const float before = tr.closestHitDistance;
+                traceInstance(staged[i].inst, staged[i].view, rayOrigin, L, tr);
+                if (SIG && tr.closestHitDistance != before) raySig = (staged[i].instIndex + 1u) << 11;
+            }
+        } else {
+            // Round 4 experiment, NOT the default - it lost: 120.9 us against 100.3 us for the lockstep walk at 4K (98 VGPRs = 4 waves
+            // per SIMD instead of 80 = 6, and the box tests run twice). The premise was wrong for this scene: a wave marches ~6 steps in total
+            // (33 vector loads per wave, profiles/r03_trace_counters.txt), so there are no long per-instance marches to de-serialise; what the
+            // kernel loses is occupancy at its tail (3.2 resident waves per SIMD on average of 6 possible, profiles/r04*_sq_counters.csv).
+            // Walking the tile's instances in wave lockstep costs sum_i max_lanes(steps of instance i): every instance is marched for as long as
+            // its slowest ray needs, by a wave whose other rays mostly miss its box (the bench scene: up to six boxes per tile, one or two per ray).
+            // Here every lane first collects the instances whose box its ray ENTERS (the box test needs no memory access), then the wave marches in
+            // rounds: in round r every lane marches ITS r-th candidate. A round lasts as long as its slowest lane, and there are as many rounds as the
+            // busiest ray has candidates - not as many as the tile has instances. Per ray the instances are still visited in list order with the same
+            // arithmetic, so the result is the ray's result of the lockstep walk, bit for bit.
+            uint64_t candLo = 0ull, candHi = 0ull; // kMaxObjectsPerTile = 100 <= 128 bits
+            for (int i = 0; i < objectCount; i++) {
+                LocalRay ray;
+                const bool enters = enterInstance(staged[i].inst, rayOrigin, L, &ray);
+                if (i < 64) candLo |= enters ? (1ull << i) : 0ull;
+                else candHi |= enters ? (1ull << (i - 64)) : 0ull;
+            }
+            while (__builtin_amdgcn_ballot_w64((candLo | candHi) != 0ull) != 0ull) {
+                MarchState st;
+                bool go = false;
+                int mine = 0; // this lane's candidate of the round (0 for lanes without one: they do not march)
+                if ((candLo | candHi) != 0ull) {
+                    if (candLo) { mine = __builtin_ctzll(candLo); candLo &= candLo - 1ull; }
+                    else { mine = 64 + __builtin_ctzll(candHi); candHi &= candHi - 1ull; }
+                    LocalRay ray;
+                    enterInstance(staged[mine].inst, rayOrigin, L, &ray); // the same statements as in the collection pass: the same bits
+                    go = beginMarch(staged[mine].inst, staged[mine].view, ray, tr.closestHitDistance, &st);
+                }
+                const float before = tr.closestHitDistance;
+                for (int step = 0; step < 128; step++) {
+                    if (go) go = marchStep(st, staged[mine].inst, rayOrigin, L, tr);
+                    if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+                }
+                if (SIG && tr.closestHitDistance != before) raySig = (staged[mine].instIndex + 1u) << 11;
+            }
         }
         vec3 hitColor;
         if (tr.hit) {
@@ -388,7 +467,11 @@ static int launchImpl(const PassCtx& c) {
         // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
         if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
         if (pack->depth.fmt == F_R16F) {
-            if (strict) sdfDiffuseTraceFastKernel<true, false, F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+            // A/B switch for the measurement in DESIGN.md: PLR_TRACE_PER_LANE=1 runs the per-lane candidate rounds instead of the lockstep instance walk
+            // (this variant only). Measured at 4K: 120.9 us against 100.3 us - not the default.
+            static const bool perLane = std::getenv("PLR_TRACE_PER_LANE") && std::atoi(std::getenv("PLR_TRACE_PER_LANE")) == 1;
+            if (strict && perLane) sdfDiffuseTraceFastKernel<true, false, F_R16F, true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
+            else if (strict) sdfDiffuseTraceFastKernel<true, false, F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
             else sdfDiffuseTraceFastKernel<false, false, F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
         } else if (pack->depth.fmt == F_D32) {
             if (strict) sdfDiffuseTraceFastKernel<true, false, F_D32><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
