@@ -97,7 +97,7 @@ template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
                                                                int coverW, int coverH, int yBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
-                                                               uint32_t validY0, uint32_t validRowCount) {
+                                                               uint32_t validY0, uint32_t validRowCount, int rowMissShrinks) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
@@ -243,8 +243,11 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 1.f; // still off-screen: weight 0, shrink the disc (:100-105)
                     // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
                     tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfW + halfW, 0.f, yWm1); ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfH + halfH, 0.f, yHm1);
-                    off[k] = off[k] || (ty - validY0) >= validRowCount; // a row no neighbouring band has sent counts as off-screen (band rendering)
-                    lengthModifier = off[k] ? lengthModifier * 0.98f : lengthModifier;
+                    // a row no neighbouring band has sent (band rendering) gets weight 0 like an off-screen sample; whether it also shrinks the disc for the
+                    // samples after it, as an off-screen one does (:100-105), is the launcher's choice (rowMissShrinks; measured in profiles/r04_config5_series.txt)
+                    const bool rowMiss = (ty - validY0) >= validRowCount;
+                    lengthModifier = (off[k] || (rowMiss && rowMissShrinks)) ? lengthModifier * 0.98f : lengthModifier;
+                    off[k] = off[k] || rowMiss;
                 }
                 su[k] = cu; sv[k] = cv;
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
@@ -446,8 +449,9 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
     }
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
+    static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels/gi_filters.hip)
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, tilesY, chunkRows, sig, \
-                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0)
+                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), rowMissShrinks
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
         if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \
