@@ -232,7 +232,7 @@ int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions
  * frame whose count is not zero. (Executions covered by a fused launch are not counted: a fused launcher is fast-set code.) */
 int plr_get_general_kernel_executions(uint32_t* out_count, char* out_names, size_t names_capacity);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
-int plr_get_last_frame_gpu_time(float* out_ms);
+int plr_get_last_frame_gpu_time(float* out_ms); /* of a frame rendered with plr_set_pass_timing(1): untimed frames are not bracketed by events (6 us each on the launch stream) */
 /* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */
 int plr_replay_frame(uint32_t count, float* out_total_gpu_ms);
 int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size);

@@ -153,7 +153,8 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     }
     UniformBufferDescription ub;
     ub.size = sizeof(float) * 9;
-    m_taaResolveWeightBuffer = be.createUniformBuffer(ub);
+    for (auto& b : m_taaResolveWeightBuffers) b = be.createUniformBuffer(ub);
+    m_taaResolveWeightBuffer = m_taaResolveWeightBuffers[0];
 }
 void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
                                 RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone) const {
@@ -168,6 +169,10 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     exe.genericInfo.resources.sampledImages = {ImageResource(colorSrc, 0, 0), ImageResource(historySrc, 0, 3), ImageResource(currentFrame.motionBuffer, 0, 4),
                                                ImageResource(currentFrame.depthBuffer, 0, 5)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_taaResolveWeightBuffer, 6)};
+    // experiment switch (profiles/r04_cross_frame_overlap.txt): the resolve as part of the frame's asynchronous tail, i.e. beside the NEXT frame's
+    // exposure chain / depth pyramid / culling / trace, which read nothing it writes. Whole-frame rendering only.
+    static const bool onTail = std::getenv("PLR_TAA_ON_TAIL") && std::atoi(std::getenv("PLR_TAA_ON_TAIL")) != 0;
+    exe.asyncTail = onTail && !edgesDone && rows.begin == 0 && rows.end == 0xffffffffu;
     recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone);
 }
 void TAA::computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
@@ -1362,6 +1367,7 @@ void FramePipeline::updateGlobalShaderInfo(float deltaTime, float time) { // Ren
 
 void FramePipeline::frame(const CameraExtrinsic& camera, float deltaTime, float time) { // Runtime/main.cpp:79-90
     m_frameIndex.markNewFrame();
+    m_taa.rotateWeightBuffer(); // before the passes are recorded: they bind the buffer this frame's weights are written to
     m_lastDeltaTime = deltaTime; // Timer::getDeltaTimeFloat() of this frame (Volumetrics.cpp:124)
     // RenderFrontend::prepareNewFrame, RenderFrontend.cpp:198-278
     m_be.updateShaderCode();

@@ -143,7 +143,10 @@ public:
     void jitterInPixels(const FrameIndexCounter& fi, float out[2]) const;
     void updateTaaResolveWeights(RenderBackend& be, const float cameraJitterInPixels[2]);
     ImageHandle m_historyBuffers[2];
-    UniformBufferHandle m_taaResolveWeightBuffer;
+    UniformBufferHandle m_taaResolveWeightBuffer;      // the one this frame's passes bind and this frame's weights go to
+    UniformBufferHandle m_taaResolveWeightBuffers[2];   // rotated per frame (rotateWeightBuffer): a resolve that still runs when the next frame is submitted keeps its weights
+    uint32_t m_weightBufferIndex = 0;
+    void rotateWeightBuffer() { m_weightBufferIndex ^= 1u; m_taaResolveWeightBuffer = m_taaResolveWeightBuffers[m_weightBufferIndex]; }
 private:
     RenderPassHandle m_temporalFilterPass, m_temporalSupersamplingPass, m_colorToLuminancePass;
 };
