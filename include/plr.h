@@ -109,6 +109,13 @@ typedef struct plr_compute_pass_execution {
      * The C++ host mirror flags the bloom chain + tonemap: ten short, dependent launches that leave the chip mostly idle, and that nothing reads
      * before the next frame's TAA resolve. */
     uint32_t async_tail;
+    /* extension (band rendering, round 4): workgroup rows (dispatch_base units) [dispatch_base[1], first_rows[0]) and [first_rows[1], dispatch_base[1] +
+     * dispatch_count[1]) - the rows a neighbouring GPU needs - are to be produced FIRST, and the backend's edge signal is raised as soon as they are
+     * complete in memory, while the rest of the SAME launch is still running: a halo exchange can start on another stream (hipStreamWaitValue32 on
+     * plr_get_edge_signal) without the pass being split into an edge and an interior launch (two launches with two tails: +36 us per band for the
+     * trace at 8K). {0, 0} = off. A kernel that cannot order its rows raises the signal when the whole launch has finished, so waiting for the
+     * signal is always correct; results do not depend on it. */
+    uint32_t first_rows[2];
 } plr_compute_pass_execution;
 
 /* extension: host function executed in recording order while plr_render_frame launches the recorded passes; it may enqueue
@@ -225,6 +232,10 @@ int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions);
  * other: the side-stream scheduler launches pass by pass. */
 int plr_set_pass_fusion(int enabled);
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions);
+/* the edge signal of the most recently launched execution with first_rows (valid inside the host callback recorded right behind it): a 32-bit word in
+ * signal memory that reaches *out_value (monotonic, compare with >=) once that execution's first rows are complete. *out_signal = NULL: the platform
+ * has no stream memory operations - order behind the launch stream instead. */
+int plr_get_edge_signal(void** out_signal, uint32_t* out_value);
 int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions);
 /* In PLR_MATH_FAST an execution outside the configuration its fast kernel was built for - or of a shader without one - runs the general
  * (exact-order) kernel of the shader. That is correct but slow, so it is not silent: out_count = executions of the last plr_render_frame that

@@ -40,7 +40,10 @@ typedef struct plrf_settings {
     uint32_t run_volumetrics; /* the four froxel passes produce volumetricIntegrationVolume (reference default VolumetricsSettings; noise volume "perlinNoise3D" is an input) */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
     uint32_t band_overlap_exchange; /* default 1: producers of exchanged images run their edge rows first and the exchange callback is called twice,
-                                       with PLRF_EXCHANGE_BEGIN (start, do not wait) and PLRF_EXCHANGE_END (wait); 0: one call per exchange */
+                                       with PLRF_EXCHANGE_BEGIN (start, do not wait) and PLRF_EXCHANGE_END (wait); 0: one call per exchange.
+                                       2 (default): as 1, but the producer is ONE launch that writes the edge rows first and raises plr_get_edge_signal when they
+                                       are complete (plr.h first_rows) - the BEGIN callback may wait for that signal on its own stream instead of ordering
+                                       behind the launch stream; 1: an edge launch and an interior launch with the BEGIN callback between them (round 3) */
 } plrf_settings;
 
 /* ---- band rendering: halo exchange hooks ----
@@ -73,6 +76,8 @@ int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, 
 /* items of the frame being launched (valid inside the callback and until the next plrf_frame); *inout_count = capacity in, count out */
 int plrf_get_exchange_items(void* pipeline, int exchange_id, plrf_exchange_item* out_items, uint32_t* inout_count);
 int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes);
+/* non-zero: this pipeline records rows-first producers (band_overlap_exchange 2): a BEGIN callback may wait for plr_get_edge_signal */
+int plrf_band_rows_first(void* pipeline);
 int plrf_get_depth_apex_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes); /* 8 bytes: float min, float max */
 
 /* ---- the same exchange, natively over RCCL (csrc/frontend/band_exchange.cpp): one process per GPU, one band per process ----

@@ -85,6 +85,7 @@ struct ComputePassExecution {
     uint32_t dispatchBase[3] = {0, 0, 0}; // extension: first workgroup (band rendering), see plr.h
     uint32_t validRows[2] = {0, 0};       // extension: rows of the input images that hold valid data (band rendering), see plr.h
     bool asyncTail = false;               // extension: part of the frame's asynchronous tail (plr_compute_pass_execution::async_tail), see plr.h
+    uint32_t firstRows[2] = {0, 0};       // extension: workgroup rows to produce first + edge signal (plr_compute_pass_execution::first_rows), see plr.h
 };
 struct SpecialisationConstant {
     uint32_t location;
@@ -155,6 +156,7 @@ public:
         for (int i = 0; i < 3; i++) { e.dispatch_count[i] = execution.dispatchCount[i]; e.dispatch_base[i] = execution.dispatchBase[i]; }
         e.valid_rows[0] = execution.validRows[0]; e.valid_rows[1] = execution.validRows[1];
         e.async_tail = execution.asyncTail ? 1u : 0u;
+        e.first_rows[0] = execution.firstRows[0]; e.first_rows[1] = execution.firstRows[1];
         check(plr_set_compute_pass_execution(&e));
     }
     void setHostCallbackExecution(plr_host_callback callback, void* user, const char* name) { check(plr_set_host_callback_execution(callback, user, name)); }

@@ -110,7 +110,7 @@ class _PassResources(C.Structure):
 
 class _ComputePassExecution(C.Structure):
     _fields_ = [("handle", C.c_uint32), ("resources", _PassResources), ("push_constants", C.c_void_p),
-                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3), ("valid_rows", C.c_uint32 * 2), ("async_tail", C.c_uint32)]
+                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3), ("valid_rows", C.c_uint32 * 2), ("async_tail", C.c_uint32), ("first_rows", C.c_uint32 * 2)]
 
 
 class _SpecConstant(C.Structure):
@@ -224,7 +224,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_verify_r11g11b10_fast", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_get_general_kernel_executions", "plr_set_async_tail", "plr_get_async_tail", "plr_set_host_callback_execution", "plr_set_host_callback_execution_on", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_verify_r11g11b10_fast", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_get_general_kernel_executions", "plr_get_edge_signal", "plr_set_async_tail", "plr_get_async_tail", "plr_set_host_callback_execution", "plr_set_host_callback_execution_on", "plr_upload_image_rows",
 ]
 
 
@@ -300,6 +300,7 @@ class RenderBackend:
         e.dispatch_base = (C.c_uint32 * 3)(*[int(x) for x in getattr(exe, "dispatchBase", (0, 0, 0))])
         e.valid_rows = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "validRows", (0, 0))])
         e.async_tail = int(bool(getattr(exe, "asyncTail", False)))
+        e.first_rows = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "firstRows", (0, 0))])
         self._check(self.lib.plr_set_compute_pass_execution(C.byref(e)))
 
     def prepareForDrawcallRecording(self):
@@ -530,6 +531,16 @@ class RenderBackend:
         e, n = C.c_int(), C.c_uint32()
         self._check(self.lib.plr_get_pass_fusion(C.byref(e), C.byref(n)))
         return e.value, n.value
+
+    def getEdgeSignal(self):
+        """-> (device address of the edge signal word or None, value the last rows-first execution raises it to, value it holds now)"""
+        p, v = C.c_void_p(), C.c_uint32()
+        self._check(self.lib.plr_get_edge_signal(C.byref(p), C.byref(v)))
+        if not p.value:
+            return None, v.value, None
+        now = C.c_uint32()
+        self._check(self.lib.plr_read_device_memory(C.byref(now), p, C.c_size_t(4)))
+        return p.value, v.value, now.value
 
     def getGeneralKernelExecutions(self):
         """-> (count, names): executions of the last frame that ran the general (exact-order) kernel although the math mode is fast"""

@@ -50,6 +50,14 @@ struct PassCtx {
     // fused sequence this context is part of, so a fused launcher that consumes it inside its own kernel may leave it unwritten
     uint32_t elidableStorage = 0;
     mutable uint32_t elidedStorage = 0;   // set by the fused launcher: the storage bindings it really left unwritten (the backend flags those images)
+    // rows to produce first + edge signal (plr.h first_rows; band rendering): workgroup rows [base[1], firstRows[0]) and [firstRows[1], base[1] + dispatch[1])
+    // come first and edgeSignal is raised to edgeValue when they are complete. A launcher that orders its blocks accordingly (TwoRanges::setEdgeFirst)
+    // sets edgeSignalHonoured; otherwise the backend raises the signal behind the launch. edgeSignal == nullptr: nothing to do.
+    uint32_t firstRows[2] = {0, 0};
+    uint32_t* edgeSignal = nullptr;
+    uint32_t* edgeCounter = nullptr;
+    uint32_t edgeValue = 0;
+    mutable bool edgeSignalHonoured = false;
     uint32_t validRows[2] = {0, 0};       // rows of the input images that hold valid data (band rendering, plr.h); {0, 0} = all
     // [lo, hi) for an input image of imageH rows
     void validRowRange(int imageH, int* lo, int* hi) const {
@@ -123,7 +131,67 @@ typedef int (*LaunchFn)(const PassCtx&);
 // below the first one's, `single` is called once with the second range in extraBaseY / extraCountY; kUseGeneralKernel otherwise (two launches)
 int launchOverTwoRowRanges(const PassCtx* const* ctxs, size_t count, LaunchFn single);
 // the remap a kernel applies to its block row when a launch covers two row ranges: rows of the second range start `gap` block rows further down
-struct TwoRanges { int split = 0x7fffffff, gap = 0; };
+// ... or, exclusively, when the launch produces its EDGE rows first (PassCtx::firstRows): block rows [0, edgeTop) and the last edgeBottom of `total`
+// are taken by the first edgeTop + edgeBottom block rows of the grid, the interior by the rest; every wave of an edge block reports in (edgeDone) and
+// the last one raises the signal - while the interior blocks of the same launch are still running.
+struct TwoRanges {
+    int split = 0x7fffffff, gap = 0;
+    int edgeTop = 0, edgeBottom = 0, total = 0;
+    uint32_t* edgeCounter = nullptr;
+    uint32_t* edgeSignal = nullptr;
+    uint32_t edgeValue = 0, edgeWaves = 0;
+    // block row of the image region this block of the grid works on
+    __device__ __forceinline__ int blockRow(int r) const {
+        if (edgeTop + edgeBottom == 0) return r + (r >= split ? gap : 0);
+        if (r < edgeTop) return r;
+        if (r < edgeTop + edgeBottom) return total - edgeBottom + (r - edgeTop);
+        return r - edgeBottom;
+    }
+    __device__ __forceinline__ bool isEdge(int r) const { return r < edgeTop + edgeBottom; }
+    // edgeDone: called once by EVERY wave of the block at the end of its work (all its stores issued), on every path out of the kernel. An edge block's outputs
+    // are stored WRITE-THROUGH (storeOut below with through = isEdge(): `sc1` stores reach memory, MI355X_MICROARCH.md "stores of each flavour"), so a
+    // wave only has to wait for its own stores and arrive; an agent-scope release per wave - a write-back of the XCD's whole L2 each time - made a
+    // band's trace take 2.5 ms (measured, round 4). The last arrival of the launch resets the counter for the next launch and raises the signal at
+    // system scope (the command processor polls it: hipStreamWaitValue32); the exchange's send kernel starts after that, with clean caches.
+    // Arrivals are per BLOCK (the block's waves meet at a barrier: every wave calls this exactly once) and sharded over kEdgeShards counters on separate
+    // cache lines by block column, each of which forwards one arrival to the top counter when its last block is in: one word takes ~88 atomics per
+    // microsecond (MI355X_MICROARCH.md, dequeue), and 15 000 edge waves of a band arriving on ONE word made the pass 130 us longer (measured, round 4).
+    static constexpr uint32_t kEdgeShards = 32, kEdgeShardStride = 16; // counters[(1 + shard) * 16], counters[0] = top
+    __device__ __forceinline__ void edgeDone(int r) const {
+        if (edgeTop + edgeBottom == 0 || r >= edgeTop + edgeBottom) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t shard = blockIdx.x % kEdgeShards;
+            const uint32_t inShard = (uint32_t)(edgeTop + edgeBottom) * (gridDim.x / kEdgeShards + (shard < gridDim.x % kEdgeShards ? 1u : 0u));
+            uint32_t* mine = edgeCounter + (1u + shard) * kEdgeShardStride;
+            if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inShard - 1u) {
+                __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t shards = gridDim.x < kEdgeShards ? gridDim.x : kEdgeShards;
+                if (__hip_atomic_fetch_add(edgeCounter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) {
+                    __hip_atomic_store(edgeCounter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(edgeSignal, edgeValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
+    // host: turn PassCtx::firstRows into the edge-first order for blocks of blockRowsPx pixel rows over pixel rows [y0, y1) (wgRows pixel rows per workgroup
+    // row), blocksX blocks per row of wavesPerBlock waves; false (and nothing set) if the edges are not whole block rows - the backend then signals itself
+    bool setEdgeFirst(const struct PassCtx& c, int y0, int y1, int blockRowsPx, int wgRows, unsigned blocksX, unsigned wavesPerBlock);
+};
+// output stores of a kernel that may run rows-first: plain, or write-through (relaxed agent-scope atomic stores = `global_store ... sc1`) for an edge block
+__device__ __forceinline__ void storeOut(uint32_t* p, uint32_t v, bool through) {
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ void storeOut(uint2* p, uint2 v, bool through) {
+    if (through) __hip_atomic_store((uint64_t*)p, (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ void storeOut(uint4* p, uint4 v, bool through) {
+    if (through) {
+        __hip_atomic_store((uint64_t*)p, (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((uint64_t*)p + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else *p = v;
+}
 // block rows of the two ranges for blocks of blockRows pixel rows: 0 = fine (*blocks = total block rows, *end = end row of the launch), else not expressible
 int twoRangeBlocks(const PassCtx& c, int imageH, int blockRows, int wgRows, TwoRanges* out, int* blocks, int* y0, int* end);
 // a PLR_MATH_FAST launcher returns this when the recorded execution is outside the configuration its kernel was built for;

@@ -83,6 +83,7 @@ struct RcclExchange {
     uint32_t frameHeight = 0;
     std::vector<uint32_t> bounds; // world + 1 row boundaries, or empty: the equal partition
     hipStream_t commStream = nullptr;
+    uint32_t lastSignalValue = 0; // the edge signal value the previous BEGIN waited for: a BEGIN whose producer raised no new one orders behind the launch stream
     hipEvent_t ready[PLRF_EXCHANGE_COUNT] = {}, done[PLRF_EXCHANGE_COUNT] = {};
     uint64_t bytesSent = 0, bytesReceived = 0, exchanges = 0; // of the last frame (reset by the histogram exchange, the first of a frame)
 
@@ -144,8 +145,19 @@ struct RcclExchange {
             return r0 ? r0 : (r1 ? r1 : grc);
         }
         if (phase == PLRF_EXCHANGE_BEGIN) {
-            if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
-            if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
+            // When may the transfers start? Rows-first producers (band_overlap_exchange 2): as soon as the launch that is still running has written its edge
+            // rows - the communication stream waits for the backend's edge signal (a word the kernel's last edge wave stores, hipStreamWaitValue32),
+            // NOT for the launch stream. Otherwise (split producers, or no stream memory operations): an event behind the edge launch.
+            void* signal = nullptr;
+            uint32_t value = 0;
+            const bool rowsFirst = plrf_band_rows_first(fp) != 0 && plr_get_edge_signal(&signal, &value) == PLR_OK && signal != nullptr && value != lastSignalValue;
+            if (rowsFirst) {
+                lastSignalValue = value;
+                if (int rc = hip(hipStreamWaitValue32(commStream, signal, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32")) return rc;
+            } else {
+                if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
+                if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
+            }
             if (int rc = post(id, commStream)) return rc;
             return hip(hipEventRecord(done[id], commStream), "hipEventRecord");
         }

@@ -32,7 +32,7 @@ int plrf_default_settings(plrf_settings* o, uint32_t width, uint32_t height) {
     o->indirect_lighting_tech = (uint32_t)d.shading.indirectLightingTech; o->use_geometry_aa = d.shading.useGeometryAA;
     o->sun_shadow_cascade_count = (uint32_t)d.shading.sunShadowCascadeCount;
     o->run_exposure = o->run_hiz = o->run_gi = o->run_shading = o->run_taa = o->run_bloom = o->run_tonemap = 1;
-    o->run_light_matrix = d.runLightMatrix; o->volumetrics_max_distance = d.volumetricsMaxDistance; o->run_sky_luts = d.runSkyLuts; o->run_volumetrics = d.runVolumetrics; o->band_taa_history_halo = d.band.taaHistoryHalo; o->band_overlap_exchange = d.band.overlapExchange;
+    o->run_light_matrix = d.runLightMatrix; o->volumetrics_max_distance = d.volumetricsMaxDistance; o->run_sky_luts = d.runSkyLuts; o->run_volumetrics = d.runVolumetrics; o->band_taa_history_halo = d.band.taaHistoryHalo; o->band_overlap_exchange = d.band.overlapExchange ? (d.band.rowsFirst ? 2u : 1u) : 0u;
     o->sdf_debug_mode = (uint32_t)d.sdfDebug.visualisationMode; o->sdf_debug_tile_usage_with_hiz = d.sdfDebug.showCameraTileUsageWithHiZ;
     o->sdf_debug_use_influence_radius = d.sdfDebug.useInfluenceRadiusForDebug;
     o->taa_use_separate_supersampling = d.taa.useSeparateSupersampling; o->taa_supersample_use_tonemapping = d.taa.supersampleUseTonemapping;
@@ -61,7 +61,7 @@ int plrf_create(const plrf_settings* s, void** out) {
         f.runBloom = s->run_bloom; f.runTonemap = s->run_tonemap;
         f.band.rowBegin = s->band_row_begin; f.band.rowEnd = s->band_row_end; f.band.giHalo = s->band_gi_halo; f.band.giHistoryHalo = s->band_gi_history_halo;
         f.band.colorHalo = s->band_color_halo; f.band.postHalo = s->band_post_halo;
-        f.runLightMatrix = s->run_light_matrix; f.volumetricsMaxDistance = s->volumetrics_max_distance; f.runSkyLuts = s->run_sky_luts; f.runVolumetrics = s->run_volumetrics; f.band.taaHistoryHalo = s->band_taa_history_halo; f.band.overlapExchange = s->band_overlap_exchange != 0;
+        f.runLightMatrix = s->run_light_matrix; f.volumetricsMaxDistance = s->volumetrics_max_distance; f.runSkyLuts = s->run_sky_luts; f.runVolumetrics = s->run_volumetrics; f.band.taaHistoryHalo = s->band_taa_history_halo; f.band.overlapExchange = s->band_overlap_exchange != 0; f.band.rowsFirst = s->band_overlap_exchange >= 2;
         f.sdfDebug.visualisationMode = (SDFVisualisationMode)s->sdf_debug_mode; f.sdfDebug.showCameraTileUsageWithHiZ = s->sdf_debug_tile_usage_with_hiz;
         f.sdfDebug.useInfluenceRadiusForDebug = s->sdf_debug_use_influence_radius;
         f.taa.useSeparateSupersampling = s->taa_use_separate_supersampling; f.taa.supersampleUseTonemapping = s->taa_supersample_use_tonemapping;
@@ -139,6 +139,10 @@ int plrf_get_histogram_exchange(void* p, void** outPtr, size_t* outBytes) {
         if (plr_get_storage_buffer_device_pointer(fp->histogramBuffer().index, outPtr, &size) != PLR_OK) throw std::runtime_error(plr_last_error());
         *outBytes = 128 * sizeof(uint32_t);
     })
+}
+int plrf_band_rows_first(void* p) {
+    const FramePipeline* fp = (const FramePipeline*)p;
+    return fp && fp->settings.band.enabled() && fp->settings.band.overlapExchange && fp->settings.band.rowsFirst ? 1 : 0;
 }
 int plrf_get_depth_apex_exchange(void* p, void** outPtr, size_t* outBytes) {
     PLRF_TRY({

@@ -96,7 +96,7 @@ static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h, RowRang
     exe.dispatchCount[2] = 1;
 }
 
-void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo, const std::function<void()>& edgesDone) {
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo, const std::function<void()>& edgesDone, bool rowsFirst) {
     const uint32_t r0 = std::min(rows.begin, h), r1 = std::min(rows.end, h);
     if (!edgesDone || halo == 0 || r1 <= r0) {
         dispatch8(exe, w, h, rows);
@@ -110,6 +110,16 @@ void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32
     // split points on 16-row boundaries of the image; no edge on a side without a neighbouring band (first / last rows of the image)
     const uint32_t topEnd = r0 == 0 ? r0 : std::min((r0 + halo + 15u) & ~15u, r1);
     const uint32_t bottomBegin = r1 >= h ? r1 : std::max((r1 > halo ? r1 - halo : 0u) & ~15u, topEnd);
+    if (rowsFirst && (topEnd > r0 || bottomBegin < r1)) {
+        // one launch: the kernel takes the edge rows first and the backend raises its edge signal when they are written (plr.h first_rows, workgroup rows of 8)
+        ComputePassExecution e = exe;
+        dispatch8(e, w, h, RowRange{r0, r1});
+        e.firstRows[0] = topEnd / 8u;
+        e.firstRows[1] = bottomBegin / 8u;
+        be.setComputePassExecution(e);
+        edgesDone();
+        return;
+    }
     auto part = [&](uint32_t a, uint32_t b) {
         if (b <= a) return;
         ComputePassExecution e = exe;
@@ -157,7 +167,7 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     m_taaResolveWeightBuffer = m_taaResolveWeightBuffers[0];
 }
 void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                                RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone) const {
+                                RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone, bool rowsFirst) const {
     // TAA.cpp:139-166
     const size_t frameIndexMod2 = fi.mod2();
     const ImageHandle historySrc = m_historyBuffers[frameIndexMod2];
@@ -173,7 +183,7 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     // exposure chain / depth pyramid / culling / trace, which read nothing it writes. Whole-frame rendering only.
     static const bool onTail = std::getenv("PLR_TAA_ON_TAIL") && std::atoi(std::getenv("PLR_TAA_ON_TAIL")) != 0;
     exe.asyncTail = onTail && !edgesDone && rows.begin == 0 && rows.end == 0xffffffffu;
-    recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone);
+    recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone, rowsFirst);
 }
 void TAA::computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
                                        ImageHandle target, RowRange rows) const { // TAA.cpp:85-137
@@ -490,7 +500,7 @@ void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps,
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
                                                 StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
-    if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); });
+    if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); }, band->rowsFirst);
     else recordRows(be, exe, td.width, td.height, band ? band->traceRows : RowRange{});
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTrace); // spatial pass 0 reads neighbouring bands' rays
 }
@@ -526,7 +536,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
                                                    ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
                                                    ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
-        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); });
+        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); }, band->rowsFirst);
         else recordRows(be, exe, td.width, td.height, rows);
     }
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
@@ -1220,6 +1230,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             gb.upscaleRows = bandRows(settings.band.colorHalo);
             gb.user = this;
             gb.giHalo = settings.band.giHalo; gb.giHistoryHalo = settings.band.giHistoryHalo;
+            gb.rowsFirst = settings.band.rowsFirst;
             // registers the images of a GI exchange and records its callback: phase 0 = whole exchange, ExchangeBegin after the producer's
             // edge rows, ExchangeEnd (items already registered) before the consumer
             static const auto giExchange = [](FramePipeline* self, int id, int phase) {
@@ -1270,7 +1281,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
                 if (bloomOn) addExchangeItem(ExchangePost, m_postProcessBuffers[1], 1, settings.band.postHalo);
                 addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
                 exchangePoint(ExchangePost | ExchangeBegin, "Exchange: resolved colour halo rows (start)");
-            });
+            }, settings.band.rowsFirst);
             postExchangeStarted = true;
         } else m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
         currentSrc = m_postProcessBuffers[1];

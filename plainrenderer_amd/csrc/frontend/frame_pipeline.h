@@ -73,6 +73,9 @@ struct BandSettings {
     // interior rows are recorded, and the callback with ExchangeEnd (wait) sits where the first consumer of the halo rows is recorded.
     // Off: one callback per exchange point (start and wait), the producer in one dispatch.
     bool overlapExchange = true;
+    // with overlapExchange: the producer of an exchanged image is ONE execution that produces the edge rows first and raises the backend's edge signal
+    // (plr.h first_rows) instead of an edge and an interior execution; false = the split recording of round 3
+    bool rowsFirst = true;
     bool enabled() const { return rowEnd > rowBegin; }
     // default giHalo for a frame of `height` rows: 64 trace rows per 2160 rows of frame height (plrf_default_settings)
     static uint32_t giHaloForHeight(uint32_t height) { return 64u * ((height + 2159u) / 2160u); }
@@ -134,7 +137,7 @@ class TAA {
 public:
     void init(RenderBackend& be, int imageWidth, int imageHeight, const TAASettings& settings);
     void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                               RowRange rows = {}, uint32_t edgeRows = 0, const std::function<void()>& edgesDone = nullptr) const;
+                               RowRange rows = {}, uint32_t edgeRows = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false) const;
     ImageHandle historyDst(const FrameIndexCounter& fi) const { return m_historyBuffers[(fi.mod2() + 1) % 2]; }
     // TAASettings::useSeparateSupersampling (TAA.cpp:85-137): luminance of the current frame, then a 2-frame blend with contrast / depth rejection
     void computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
@@ -174,9 +177,11 @@ struct GiBand {
     void (*exchangeBegin)(void* user, int exchangeId) = nullptr; // overlap: records the start of the exchange; null = no overlap
     void (*exchangeWhole)(void* user, int exchangeId) = nullptr; // overlap: an exchange that is not split (start and wait in one callback)
     uint32_t giHalo = 0, giHistoryHalo = 0;                      // trace-resolution halo rows of exchanges 1/2 and 3
+    bool rowsFirst = false;                                      // BandSettings::rowsFirst
 };
 // records exe over `rows` of a w x h image; with edgesDone the first / last `halo` rows are recorded first, then edgesDone(), then the rest
-void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo = 0, const std::function<void()>& edgesDone = nullptr);
+// rowsFirst: ONE execution over all the rows with first_rows = the edges (plr.h), then edgesDone()
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false);
 
 struct SDFTraceDependencies {
     FrameRenderTargets currentFrame, previousFrame;

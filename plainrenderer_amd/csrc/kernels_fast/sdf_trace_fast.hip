@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
     __shared__ RayInfo sharedRays[4][64];
     uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
+    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
     const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + blockRow * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
     // a wave only reads the slice it wrote: no block barrier (the four waves of a tile finish their rays at different times)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (!active) return;
+    if (!active) { ranges.edgeDone((int)blockIdx.y); return; } // (wave-uniform: a wave is one 8 x 8 group)
 
     float weightTotal = 1.f;
     vec3 color(mine.cr, mine.cg, mine.cb);
@@ -406,11 +406,13 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         const size_t idx = (size_t)py * (size_t)outYSH.w + px;
         const uint2 yBits = make_uint2(floatToHalfBits(ysh.x) | (floatToHalfBits(ysh.y) << 16), floatToHalfBits(ysh.z) | (floatToHalfBits(ysh.w) << 16));
         const uint32_t cBits = floatToHalfBits(YCoCg.y) | (floatToHalfBits(YCoCg.z) << 16);
-        ((uint2*)outYSH.ptr)[idx] = yBits;
-        ((uint32_t*)outCoCg.ptr)[idx] = cBits;
+        const bool through = ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
+        storeOut((uint2*)outYSH.ptr + idx, yBits, through);
+        storeOut((uint32_t*)outCoCg.ptr + idx, cBits, through);
         if (PACK) packedOut[idx] = packGiTexel(yBits, cBits, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
         if (SIG) sig[idx] = raySig | (takeMask << 3);
     }
+    ranges.edgeDone((int)blockIdx.y); // rows-first launch of a band (plr.h first_rows): this wave's rows are written
 }
 
 static int launchImpl(const PassCtx& c) {
@@ -448,6 +450,8 @@ static int launchImpl(const PassCtx& c) {
         blockRowsTotal += (int)divUp(c.extraCountY, 2u);
         groupsY = (int)(c.extraBaseY + c.extraCountY);
     }
+    // band rendering, rows-first (plr.h first_rows): the edge rows' blocks come first and raise the backend's edge signal (blocks of 16 pixel rows, 4 waves)
+    if (!c.extraCountY) ranges.setEdgeFirst(c, groupY0 * 8, groupsY * 8, 16, 8, divUp((unsigned)groupsX, 2u), 4u);
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
     const dim3 grid(divUp((unsigned)groupsX, 2u), (unsigned)blockRowsTotal);

@@ -366,9 +366,11 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
                                                                   ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
                                                                   ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase,
                                                                   uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges) {
-    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
+    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
     const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = yBase + blockRow * 4 + (int)(threadIdx.x >> 6);
+    // (the pixel's work as a lambda: every wave, also one with nothing to do, reports in at the end - TwoRanges::edgeDone, rows-first launches of a band)
+    auto pixel = [&]() {
     if (px >= coverW || py >= coverH) return;
     // texel size as the shader has it: the correctly rounded 1 / size (Newton step on v_rcp_f32). With the raw approximation a reprojected coordinate
     // lands on the other side of a 1/256 sub-texel weight step for a few pixels in 10^5, which is visible against the half-float quantum
@@ -403,11 +405,15 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
     const vec2 result_CoCg = current_CoCg * (1.f - alpha) + history_CoCg * alpha;
     const uint2 py4 = make_uint2(floatToHalfBits(result_Y_SH.x) | (floatToHalfBits(result_Y_SH.y) << 16), floatToHalfBits(result_Y_SH.z) | (floatToHalfBits(result_Y_SH.w) << 16));
     const uint32_t pc = floatToHalfBits(result_CoCg.x) | (floatToHalfBits(result_CoCg.y) << 16);
-    ((uint2*)targetYSH.ptr)[idx] = py4;
-    ((uint32_t*)targetCoCg.ptr)[idx] = pc;
-    ((uint2*)historyOutYSH.ptr)[idx] = py4;
-    ((uint32_t*)historyOutCoCg.ptr)[idx] = pc;
+    const bool through = ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
+    storeOut((uint2*)targetYSH.ptr + idx, py4, through);
+    storeOut((uint32_t*)targetCoCg.ptr + idx, pc, through);
+    storeOut((uint2*)historyOutYSH.ptr + idx, py4, through);
+    storeOut((uint32_t*)historyOutCoCg.ptr + idx, pc, through);
     if (PACK) packedOut[idx] = packGiTexel(py4, pc, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
+    };
+    pixel();
+    ranges.edgeDone((int)blockIdx.y);
 }
 
 static int launchTemporalGi(const PassCtx& c) {
@@ -434,6 +440,7 @@ static int launchTemporalGi(const PassCtx& c) {
     const int w = std::min((int)(c.dispatch[0] * 8u), out.w);
     if (w <= 0 || h <= y0) return 0;
     const dim3 grid(divUp((unsigned)w, 64u), (unsigned)blockRows);
+    if (!c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4, 8, grid.x, 4u); // band rendering, rows-first (plr.h first_rows): blocks of 4 rows, 4 waves
     // the spatial filter that reads the history output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;
     const SpatialPackTarget* pack = spatialPackTargetOfConsumer(c, 2, 3, &packTarget) == 0 ? &packTarget : nullptr;

@@ -259,8 +259,10 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     __shared__ uint2 stage[4][kStageTexels]; // per wave: {luminance bits, packed texel}
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
-    const int blockRow = (int)blockIdx.y + ((int)blockIdx.y >= ranges.split ? ranges.gap : 0); // a launch over two row ranges (backend.h)
+    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
     const int rowFirst = yBase + (blockRow * 4 + wave) * kStripRows;
+    // (the strip's work as a lambda: every wave, also one below the dispatch, reports in at the end - TwoRanges::edgeDone, rows-first launches of a band)
+    auto strip = [&]() {
     if (rowFirst >= coverH) return; // wave-uniform
     const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
     const int xc = clampi(px, current.w);
@@ -521,13 +523,17 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
         if (TONEMAP) color = tonemapReverseF(color);
         const uint32_t packed = packR11G11B10(color);
         if (isOutputLane) {
-            if (px < historyDst.w && py < historyDst.h) ((uint32_t*)historyDst.ptr)[fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)historyDst.w)] = packed;
-            ((uint32_t*)output.ptr)[fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)output.w)] = packed;
+            const bool through = ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
+            if (px < historyDst.w && py < historyDst.h) storeOut((uint32_t*)historyDst.ptr + fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)historyDst.w), packed, through);
+            storeOut((uint32_t*)output.ptr + fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)output.w), packed, through);
         }
         // slide the window down one row
         C[0] = C[1]; L[0] = L[1]; R[0] = R[1];
         C[1] = C[2]; L[1] = L[2]; R[1] = R[2];
     }
+    };
+    strip();
+    ranges.edgeDone((int)blockIdx.y);
 }
 
 typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
@@ -583,6 +589,7 @@ static int launch(const PassCtx& c) {
     const bool sameSize = c.sampled[0].w == out.w && c.sampled[0].h == out.h && c.sampled[3].w == out.w && c.sampled[3].h == out.h && c.sampled[5].w == out.w &&
                           c.sampled[5].h == out.h && out.w >= 4;
     if (c.extraCountY && !(strip && sameSize && expressible)) return kUseGeneralKernel; // two ranges: strip kernel only (else two launches)
+    if (strip && sameSize && !c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4 * kStripRows, 8, divUp((unsigned)w, (unsigned)kStripW), 4u); // band, rows-first (plr.h first_rows)
     if (strip && sameSize)
         strip<<<dim3(divUp((unsigned)w, (unsigned)kStripW), (unsigned)stripBlocks), 256, 0, c.stream>>>(
             c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, ranges);

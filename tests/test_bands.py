@@ -173,7 +173,7 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1,
                                hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
                                light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes(),
                                shadow=be.downloadStorageBuffer(fp.storage_buffer("sunShadowInfo"), 304, dtype=np.uint8).tobytes()))
-        res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1])
+        res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1], edge_signal=be.getEdgeSignal())
         fp.destroy()
         be.shutdown()
         out[band[0] if band is not None else "full"] = res
@@ -317,6 +317,28 @@ def test_gpu_middle_band_launches_both_edges_at_once():
         for f in range(N_FRAMES):
             for k in ("post", "color", "swap"):
                 assert np.array_equal(over[i]["frames"][f][k][b0:b1], plain[i]["frames"][f][k][b0:b1]), "band %d frame %d %s" % (i, f, k)
+
+
+@pytest.mark.gpu
+def test_gpu_rows_first_producers_raise_the_edge_signal_and_change_no_bit():
+    """band_overlap_exchange 2 (the default): a producer of an exchanged image is ONE launch that writes the rows its neighbours need first and raises
+    the backend's edge signal when they are complete (plr.h first_rows) - no edge / interior split. Same bits as the plain exchange; the signal word
+    holds the value of the last rows-first launch (three per frame and band: trace, temporal GI filter, TAA resolve)."""
+    inputs = _make_inputs()
+    small = dict(band_gi_halo=8, band_gi_history_halo=8, band_post_halo=16, band_taa_history_halo=8)
+    first = _run_bands(inputs, 3, False, dict(small, band_overlap_exchange=2))
+    plain = _run_bands(inputs, 3, False, dict(small, band_overlap_exchange=0))
+    B, E = 0x100, 0x200
+    assert first[1]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E]
+    for i in range(3):
+        ptr, value, now = first[i]["edge_signal"]
+        assert ptr is not None, "no stream memory operations on this platform?"
+        assert value == 3 * N_FRAMES and now == value, (i, value, now)  # every rows-first launch raised the signal to its value, in order
+        assert plain[i]["edge_signal"][1] == 0
+        b0, b1 = tiling.band_rows(H, 3, i)
+        for f in range(N_FRAMES):
+            for k in ("post", "color", "swap"):
+                assert np.array_equal(first[i]["frames"][f][k][b0:b1], plain[i]["frames"][f][k][b0:b1]), "band %d frame %d %s" % (i, f, k)
 
 
 @pytest.mark.gpu
