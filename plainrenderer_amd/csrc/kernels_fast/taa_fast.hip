@@ -251,7 +251,9 @@ PLR_DI int waveMinI(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
+// BANDED: the launch may cover two row ranges or run its edge rows first (band rendering, backend.h TwoRanges); a whole-frame launch carries none of that code
+// (it cost the 128-register kernel four more spilled dwords)
+template <bool CLIP, bool DILATE, int TECH, bool TONEMAP, bool BANDED>
 __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
                                                                  int coverW, int coverH, int yBase, TwoRanges ranges) {
@@ -259,11 +261,9 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     __shared__ uint2 stage[4][kStageTexels]; // per wave: {luminance bits, packed texel}
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
-    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
+    const int blockRow = BANDED ? ranges.blockRow((int)blockIdx.y) : (int)blockIdx.y; // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
     const int rowFirst = yBase + (blockRow * 4 + wave) * kStripRows;
-    // (the strip's work as a lambda: every wave, also one below the dispatch, reports in at the end - TwoRanges::edgeDone, rows-first launches of a band)
-    auto strip = [&]() {
-    if (rowFirst >= coverH) return; // wave-uniform
+    if (rowFirst >= coverH) { if (BANDED) ranges.edgeDone((int)blockIdx.y); return; } // wave-uniform (every wave of a rows-first launch reports in: TwoRanges::edgeDone)
     const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
     const int xc = clampi(px, current.w);
     const bool xInDepth = px >= 0 && px < depthBuffer.w;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
         if (TONEMAP) color = tonemapReverseF(color);
         const uint32_t packed = packR11G11B10(color);
         if (isOutputLane) {
-            const bool through = ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
+            const bool through = BANDED && ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
             if (px < historyDst.w && py < historyDst.h) storeOut((uint32_t*)historyDst.ptr + fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)historyDst.w), packed, through);
             storeOut((uint32_t*)output.ptr + fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)output.w), packed, through);
         }
@@ -531,9 +531,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
         C[0] = C[1]; L[0] = L[1]; R[0] = R[1];
         C[1] = C[2]; L[1] = L[2]; R[1] = R[2];
     }
-    };
-    strip();
-    ranges.edgeDone((int)blockIdx.y);
+    if (BANDED) ranges.edgeDone((int)blockIdx.y);
 }
 
 typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
@@ -571,11 +569,12 @@ static int launch(const PassCtx& c) {
     if (!k) return c.fail(-6, "temporalFilter: historySampleTech must be 0..4");
     TaaStripKernel strip = nullptr;
     if (tech == 0 || tech == 4) {
-#define PLR_STRIP(T) (clip ? (dilate ? (tonemap ? temporalFilterStripKernel<true, true, T, true> : temporalFilterStripKernel<true, true, T, false>)   \
-                                     : (tonemap ? temporalFilterStripKernel<true, false, T, true> : temporalFilterStripKernel<true, false, T, false>)) \
-                           : (dilate ? (tonemap ? temporalFilterStripKernel<false, true, T, true> : temporalFilterStripKernel<false, true, T, false>)  \
-                                     : (tonemap ? temporalFilterStripKernel<false, false, T, true> : temporalFilterStripKernel<false, false, T, false>)))
-        strip = tech == 0 ? PLR_STRIP(0) : PLR_STRIP(4);
+#define PLR_STRIP(T, B) (clip ? (dilate ? (tonemap ? temporalFilterStripKernel<true, true, T, true, B> : temporalFilterStripKernel<true, true, T, false, B>)   \
+                                        : (tonemap ? temporalFilterStripKernel<true, false, T, true, B> : temporalFilterStripKernel<true, false, T, false, B>)) \
+                              : (dilate ? (tonemap ? temporalFilterStripKernel<false, true, T, true, B> : temporalFilterStripKernel<false, true, T, false, B>)  \
+                                        : (tonemap ? temporalFilterStripKernel<false, false, T, true, B> : temporalFilterStripKernel<false, false, T, false, B>)))
+        const bool banded = c.extraCountY != 0 || c.firstRows[0] != 0 || c.firstRows[1] != 0;
+        strip = banded ? (tech == 0 ? PLR_STRIP(0, true) : PLR_STRIP(4, true)) : (tech == 0 ? PLR_STRIP(0, false) : PLR_STRIP(4, false));
 #undef PLR_STRIP
     }
     const ImgView& out = c.storage[1];
