@@ -28,9 +28,9 @@ SGPR = re.compile(r"[ ,]s\d+\b|[ ,]s\[|[ ,]vcc|[ ,]exec")
 
 KERNELS = [  # (object substring, demangled-name substring, label, waves per launch at 4K are read from the counters)
     ("shading_fast", "upscaleAndShadeKernel<2, 0, true>", "indirectLightUpscale + deferred shade"),
-    ("taa_fast", "temporalFilterStripKernel<true, true, 4, true>", "temporalFilter (TAA)"),
+    ("taa_fast", "temporalFilterStripKernel<true, true, 4, true, false>", "temporalFilter (TAA)"),
     ("gi_spatial_fast", "spatialFilterFastKernel<3, 64, true, true, false>", "filterIndirectDiffuseSpatial (x2 per frame)"),
-    ("sdf_trace_fast", "sdfDiffuseTraceFastKernel<true, false, 3>", "sdfDiffuseTrace"),
+    ("sdf_trace_fast", "sdfDiffuseTraceFastKernel<true, false, 3, false>", "sdfDiffuseTrace"),
     ("stream_fast", "temporalGiFilterFastKernel<3>", "filterIndirectDiffuseTemporal"),
     ("stream_fast", "applyBloomTonemapKernel<true>", "applyBloom + tonemapping"),
 ]
