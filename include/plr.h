@@ -293,6 +293,11 @@ int plr_debug_verify_r11g11b10_fast(uint64_t* out4);
 /* the PLR_MATH_FAST sky LUT lookup (polynomial acos / atan, device/fastmath.h) for n directions (3 floats each) -> n x 3 floats; the oracle's
  * orc_kat_sky_lut takes the same arguments */
 int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, float* out_rgb, int64_t n);
+/* the PLR_MATH_FAST deferred shade reads the twelve PCF taps of calcShadow (triangle.frag:100-110) from a table indexed by the pixel's 8-bit noise
+ * value (kernels_fast/pcf_taps.h) instead of evaluating sqrt / sin / cos per pixel: this copies the table the kernel uses to out_xy (host memory,
+ * 256 x 12 x 2 floats = unit-disc offsets (cos(angle) d, sin(angle) d) of noise byte k, tap i at [(k * 12 + i) * 2]). The oracle's orc_kat_pcf_taps
+ * evaluates the shader's expressions for the same 3072 entries; the two must agree bit for bit. */
+int plr_debug_pcf_tap_table(float* out_xy, size_t floats);
 /* sampler probe: evaluates one of the global samplers of resources/shaders/global.inc:35-42 on an image, with the device sampler code the pass
  * kernels are built from. filter: 0 nearest, 1 linear, 2 textureGather (component 0); address: 0 clamp-to-edge, 1 repeat, 2 border white,
  * 3 border black. coords: n x 2 (2D) or n x 3 (3D image) normalised coordinates, out: n x 4 floats; both host memory.

@@ -87,3 +87,22 @@ extern "C" void orc_kat_sky_lut(const orc_image* lut, const float* dirs, float* 
         out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
     }
 }
+
+// The twelve PCF taps of calcShadow (triangle.frag:100-110) as functions of the pixel's noise texel alone, for all 256 values of an R8 UNORM
+// texel: out[(k * 12 + i) * 2] = (cos(angle) d, sin(angle) d) with d = sqrt((i + noise / 2) / 12), angle = noise 2 pi + 2 pi i / 12 - the
+// shader's expressions in the shader's order (the same statements as shading.cpp's calcShadow, before the multiplication by offsetScale).
+extern "C" void orc_kat_pcf_taps(float* out) {
+    const float sampleCount = 12.f;
+    for (int k = 0; k < 256; k++) {
+        const float noise = decodeUnorm8((uint8_t)k);
+        for (int i = 0; (float)i < sampleCount; i++) {
+            float d = ((float)i + 0.5f * noise) / sampleCount;
+            d = std::sqrt(d);
+            const float angle = noise * 2.f * pi + 2.f * pi * (float)i / sampleCount;
+            float sa, ca;
+            det_sincosf(angle, &sa, &ca);
+            out[(k * 12 + i) * 2] = ca * d;
+            out[(k * 12 + i) * 2 + 1] = sa * d;
+        }
+    }
+}

@@ -195,6 +195,12 @@ def kat_sampling(fn, data, in_per, out_per):
     return out
 
 
+def kat_pcf_taps():
+    out = np.zeros((256, 12, 2), np.float32)
+    lib().orc_kat_pcf_taps(_p(out))
+    return out
+
+
 def kat_sky_lut(image, dirs):
     a = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
     out = np.zeros((a.shape[0], 3), np.float32)

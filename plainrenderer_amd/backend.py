@@ -215,7 +215,7 @@ def _load():
 
 
 EXPORTED_SYMBOLS = [
-    "plr_setup", "plr_shutdown", "plr_recreate_swapchain", "plr_last_error", "plr_wait_for_gpu_idle", "plr_update_shader_code",
+    "plr_debug_pcf_tap_table", "plr_setup", "plr_shutdown", "plr_recreate_swapchain", "plr_last_error", "plr_wait_for_gpu_idle", "plr_update_shader_code",
     "plr_resize_images", "plr_new_frame", "plr_set_compute_pass_execution", "plr_prepare_for_drawcall_recording",
     "plr_set_uniform_buffer_data", "plr_set_storage_buffer_data", "plr_set_global_descriptor_set_resources",
     "plr_update_compute_pass_shader_description", "plr_render_frame", "plr_get_image_global_texture_array_index",
@@ -506,6 +506,12 @@ class RenderBackend:
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
         out = np.empty_like(d)
         self._check(self.lib.plr_debug_sky_lut_eval(_ImageHandle(sky_lut.type, sky_lut.index), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int64(d.shape[0])))
+        return out
+
+    def debugPcfTapTable(self):
+        """-> (256, 12, 2) float32: the PCF tap table of the PLR_MATH_FAST deferred shade (noise byte, tap) -> unit-disc offset"""
+        out = np.empty((256, 12, 2), np.float32)
+        self._check(self.lib.plr_debug_pcf_tap_table(out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size)))
         return out
 
     def debugVerifyHistogramThresholds(self, min_luminance, max_luminance):

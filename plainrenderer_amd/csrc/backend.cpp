@@ -6,6 +6,7 @@
 // executions launched in order on one HIP stream (in-order execution gives the reference's
 // write->read barrier rule, RenderBackend.cpp:632-767, for free).
 #include "backend.h"
+#include "kernels_fast/pcf_taps.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1631,6 +1632,19 @@ int plr_debug_sky_lut_eval(plr_image_handle sky_lut, const float* directions, fl
     if (!im || !directions || !out_rgb || n <= 0) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_sky_lut_eval: invalid argument");
     HIP_TRY(hipStreamSynchronize(g->stream));
     return launchSkyLutProbe(makeView(*im, 0), directions, out_rgb, n);
+}
+
+int plr_debug_pcf_tap_table(float* out_xy, size_t floats) {
+    NEED_INIT_JOINED();
+    if (!out_xy || floats != kPcfTapTableBytes / sizeof(float)) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_debug_pcf_tap_table: out_xy must hold 256 x 12 x 2 floats");
+    void* table = nullptr;
+    HIP_TRY(hipMalloc(&table, kPcfTapTableBytes));
+    hipError_t e = buildPcfTapTable((float2*)table, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_xy, table, kPcfTapTableBytes, hipMemcpyDeviceToHost);
+    hipFree(table);
+    HIP_TRY(e);
+    return PLR_OK;
 }
 
 int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filter, int address, const float* coords, float* out, int64_t n) {

@@ -202,16 +202,18 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const uint32_t* cocgTexels = (const uint32_t*)inCoCg.ptr;
     // Samples are processed four at a time, branch-free, so that the gathers of a group are in flight together (a per-sample branch
     // makes the compiler wait for each sample's loads in turn); only lengthModifier chains the samples, and it depends on coordinates
-    // alone. With the loads overlapped the kernel is bound by VALU issue: SQ_INSTS_VALU = 1960 per wave (two of them per sample the
-    // quarter-rate v_rcp_f32) x 4 cycles x 31.6 waves per SIMD = 96% of the measured duration; replacing every gather by the pixel's
-    // own texel does not change the time. A wave-uniform "whole group on screen" shortcut was tried and gave nothing on the bench
-    // scene (waves near discs that leave the screen pay for both paths, and the extra registers cost two waves of occupancy).
-    // (Measured: SQ_INSTS_VALU 1897 -> 1700 per wave on the bench frame, duration unchanged at ~106 us: with the instruction diet the kernel
-    // sits on the gather path instead - 32 wave-wide 16-byte gathers per pixel at ~60 cycles each per CU.)
-    // (Round 3, measured and not kept: the first filter execution of a frame storing the per-pixel frame - centre, tangent, bitangent, 36 bytes - for the
-    // second one to load instead of recomputing it: 270 instructions fewer, and SLOWER - 98 us against 94 us for the loading execution, 105 us for
-    // the storing one, non-temporal accesses included. Three more vector loads per pixel cost more than the arithmetic they replace: what this
-    // kernel waits for is its vector-memory path.)
+    // alone.
+    // What bounds it (profiles/r04b_sq_counters.csv + profiles/r04b_isa_mix.txt, 3840x2160, 94.4 us per launch serialised): no single
+    // unit. Per wave 1681 VALU instructions, of which half are full rate: priced with the measured issue rates (profiles/r04_valu_rates.txt)
+    // they take 83 us of the 94 (0.88), at the 2-cycle peak 45 us (VALU roofline 0.47). The packed gathers (32 x 16 bytes per pixel) make
+    // 137.5 k L1 cache-line accesses per CU in 227 k cycles (0.61 per cycle, L1 hit 62 %, L2 hit 93 %), the texture addresser is busy 65 - 67 %
+    // of the time and a wave waits on some counter 62 % of its life: VALU issue and the gather path overlap, neither hides completely under
+    // the other. Earlier readings for the record, each true of the kernel it was taken on: round 2, 1960 VALU per wave, time unchanged when
+    // every gather read the pixel's own texel (issue bound); round 3 after the instruction diet, 1897 -> 1700 per wave with the time unchanged
+    // at ~106 us (gather bound, before texel packing halved the gathers).
+    // Measured and not kept: a wave-uniform "whole group on screen" shortcut (waves near discs that leave the screen pay for both paths, two
+    // waves of occupancy lost); the first filter execution of a frame storing the per-pixel frame (36 bytes) for the second one to load -
+    // 270 instructions fewer and slower (98 us loading, 105 us storing, against 94 us).
     // Two copies of the sample loop. A wave whose pixels' discs provably stay on screen (see `safe` above) runs the copy without the
     // mirroring, the off-screen test and the shrinking lengthModifier - a fifth of the per-sample instructions; those conditions could
     // not have fired, so a pixel's result is the same whichever copy its wave ran.

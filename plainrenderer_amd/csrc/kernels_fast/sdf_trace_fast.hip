@@ -282,10 +282,9 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         const vec3 ray = ld3(g->cameraForward) + (-g->cameraTanFovHalf * (v * 2.f - 1.f)) * ld3(g->cameraUp) +
                          (g->cameraTanFovHalf * g->cameraAspectRatio * (u * 2.f - 1.f)) * ld3(g->cameraRight);
         const vec3 pWorld = ld3(g->cameraPosition) + ray * depthLinear;
-        // the launcher resolves the frame's noise texture on the host when it can (PassCtx::hostNoiseView): frame index -> texture index -> view
-        // are three dependent round trips in front of the ray direction otherwise
-        ImgView noiseTex = hostNoiseTex;
-        if (!noiseTex.ptr) noiseTex = bindless[min((uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u], bindlessCount - 1u)]; // uniform
+        // the launcher resolves the frame's noise texture on the host (PassCtx::hostNoiseView): frame index -> texture index -> view are three
+        // dependent round trips in front of the ray direction otherwise
+        const ImgView noiseTex = hostNoiseTex;
         // exact UNORM8 decode (c / 255, an IEEE quotient in this file): a noise value of 255 must be exactly 1 - then sinTheta is exactly 0 and L = N, and
         // for a horizontal N the sky LUT's v coordinate sits on its sqrt-steep horizon, where 2e-4 rad of direction is half a LUT row
         const uint32_t nzTexel = ((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)];
@@ -429,6 +428,8 @@ static int launchImpl(const PassCtx& c) {
     if (int rc = c.needSbuf(9, sizeof(ShadowCascadeInfo), "sdfDiffuseTrace sunShadowInfo")) return rc;
     if (int rc = c.needSampled(10, F_D16, "sdfDiffuseTrace shadowMap")) return rc;
     if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "sdfDiffuseTrace: global texture array (set 2) is empty");
+    ImgView hostNoise{};
+    if (!c.hostNoiseView(&hostNoise)) return kUseGeneralKernel; // a host that does not know the global buffer's contents gets the kernel that chases the pointers
     const bool strict = c.specBool(0, false);
     const int cascade = c.specInt(1, 3);
     if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
@@ -459,8 +460,6 @@ static int launchImpl(const PassCtx& c) {
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
                        (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
                        tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges, hostNoise
-    ImgView hostNoise{};
-    if (!c.hostNoiseView(&hostNoise)) hostNoise = ImgView{};
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     // the spatial filter that reads this pass's output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;

@@ -187,7 +187,7 @@ struct ShadeParams {
     uint32_t cascadeCount;
     int coverW, coverH, yBase;
     uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
-    ImgView noiseTex; // the frame's noise texture when the launcher could resolve it on the host (PassCtx::hostNoiseView), else ptr == nullptr
+    ImgView noiseTex; // the frame's noise texture, resolved on the host (PassCtx::hostNoiseView)
     const float4* pcfTaps; // [256][6] float4 = [noise byte][tap] {x, y}: unit-disc tap offsets (pcf_taps.h)
     // the same rows re-indexed by the POSITION of the frame's noise texel and transposed, [6][pcfPositions] float4, or null (shadeDerivedTables below)
     const float4* pcfTapsByPosition;
@@ -354,8 +354,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     const vec3 f0 = vmix(vec3(0.04f), albedo, metalic);
 
     // frame index -> texture index -> view -> texel is four dependent round trips in front of the PCF taps when the kernel chases them itself
-    ImgView noiseTex = P.noiseTex;
-    if (!noiseTex.ptr) noiseTex = P.bindless[min((uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u], P.bindlessCount - 1u)]; // uniform
+    const ImgView noiseTex = P.noiseTex;
     const uint32_t noiseIndex = fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w);
     const uint32_t noiseWord = ((const uint16_t*)noiseTex.ptr)[noiseIndex];
     const vec2 noiseTexel = fastm::unorm8x2(noiseWord);
@@ -778,7 +777,9 @@ static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, 
     P.light = (const LightBuffer*)c.sbuf[7].ptr; P.shadowInfo = (const ShadowCascadeInfo*)c.sbuf[8].ptr;
     P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
-    if (!c.hostNoiseView(&P.noiseTex)) P.noiseTex = ImgView{};
+    // frame index -> texture index -> view are three dependent round trips in front of every pixel's shadow taps when a kernel chases them itself; this
+    // kernel takes the view from the host, and a host that does not know the global buffer's contents (PassCtx::hostNoiseView) gets the general kernel
+    if (!c.hostNoiseView(&P.noiseTex)) return kUseGeneralKernel;
     if (int rc = shadeDerivedTables(c, &P)) return rc;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)

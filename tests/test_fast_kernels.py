@@ -101,3 +101,24 @@ def test_fast_brdf_lut_within_a_half_float_step(backend, brdf):
     print("PARITY brdf_lut_fast brdf=%d res=%d equal=%.5f within_1_step=%.5f max_steps=%.2f" % (brdf, res, (steps == 0).mean(), (steps <= 1).mean(), steps.max()))
     assert steps[..., :3].max() <= 1.0 and (steps == 0).mean() >= 0.99  # measured: no texel further than one step, > 99.8 % equal
     assert (got[..., 3] == 0).all()
+
+
+# ------------------------------------------------------------------ PCF tap table of the deferred shade
+def test_kat_pcf_taps_of_the_oracle_against_float64():
+    """the oracle's restatement of triangle.frag:100-110 per noise value: unit-disc offsets (cos, sin)(noise 2 pi + 2 pi i / 12) * sqrt((i + noise / 2) / 12)"""
+    taps = passes.orc.kat_pcf_taps().astype(np.float64)
+    noise = (np.arange(256) / 255.0)[:, None]
+    i = np.arange(12)[None, :]
+    d = np.sqrt((i + 0.5 * noise) / 12.0)
+    angle = noise * 2 * np.pi + 2 * np.pi * i / 12.0
+    assert np.abs(taps[..., 0] - np.cos(angle) * d).max() < 2e-6 and np.abs(taps[..., 1] - np.sin(angle) * d).max() < 2e-6
+    assert np.abs(np.hypot(taps[..., 0], taps[..., 1]) - d).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_pcf_tap_table_is_the_oracles_bit_for_bit(backend):
+    """the table the PLR_MATH_FAST shade reads its twelve shadow taps from holds, for all 256 noise values, the bits the shader's own
+    sqrt / sin / cos expressions give (software sin / cos of detmath.h, IEEE sqrt and divide)"""
+    got = backend.debugPcfTapTable()
+    ref = passes.orc.kat_pcf_taps()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "%d of 6144 table floats differ" % int((got.view(np.uint32) != ref.view(np.uint32)).sum())

@@ -125,3 +125,51 @@ def test_gpu_spatial_filter_on_a_full_resolution_grid_meets_the_bound(backend, v
     assert not (bad & clean).any()
     assert flipped.sum() <= 1e-3 * 32 * x.size
 
+
+
+class _GlobalBufferTheHostCannotRead(passes.GlobalBinding):
+    """A global uniform buffer that was filled - and the fill flushed by a frame - BEFORE it became the global one: the backend's host copy of the global
+    data (PassCtx::globalHost) does not cover it, so the launchers cannot resolve the frame's noise texture on the host (PassCtx::hostNoiseView)."""
+
+    def set(self, packed340):
+        be = self.be
+        ubo = be.createUniformBuffer(340)
+        be.setUniformBufferData(ubo, packed340)
+        be.newFrame()
+        be.prepareForDrawcallRecording()
+        be.renderFrame()  # an empty frame: flushes the fill while the other buffer is still the global one
+        be.setGlobalDescriptorSetResources(passes.RenderPassResources(uniformBuffers=[passes.UniformBufferResource(ubo, 0)]))
+
+
+@pytest.mark.gpu
+def test_gpu_a_global_buffer_unknown_to_the_host_gets_the_general_kernels_loudly(backend, vs, monkeypatch):
+    """the fast shade and trace kernels take the noise texture's view from the host. When the host does not know the global buffer's
+    contents they do not chase the pointers in a branch nothing tests: the launchers hand the execution to the general kernels, the backend counts
+    it (plr_get_general_kernel_executions), and the results are the exact set's bit for bit."""
+    c = vs.cap["shade"]
+    shade_args = (vs.gb, W, H, vs.ora.brdf_lut, 512, c["light"], vs.inputs.shadow_info, vs.inputs.shadow_maps, vs.inputs.shadow_res, c["gi"][0], c["gi"][1], vs.inputs.froxel,
+                  vs.inputs.froxel_dims, vs.inputs.vol_settings, vs.inputs.sky, vs.gp)
+    var = (int(vs.settings.diffuse_brdf), 0, True, 0, 3)
+    t = vs.cap["trace"]
+    trace_args = (vs.gb["depth"], vs.gb["normal"], W, H, TW, TH, vs.inputs.sky, 200, 100, t["light"], vs.inputs.instance_bytes_patched, t["tiles"], 5.0, vs.inputs.shadow_info,
+                  vs.inputs.shadow_maps[t["cascade"]], vs.inputs.shadow_res, vs.gp)
+    backend.setMathMode(False)
+    shade_exact = passes.gpu_deferred_shading(backend, *shade_args, *var)
+    trace_exact = passes.gpu_sdf_trace(backend, *trace_args, strict=True, cascade=t["cascade"])
+    backend.setMathMode(True)
+    try:
+        shade_fast = passes.gpu_deferred_shading(backend, *shade_args, *var)
+        assert backend.getGeneralKernelExecutions()[0] == 0, backend.getGeneralKernelExecutions()
+        assert not np.array_equal(shade_fast, shade_exact), "the two kernel sets round differently somewhere on a 2-Mpixel frame"
+        unknown = _GlobalBufferTheHostCannotRead(backend)
+        monkeypatch.setattr(passes, "global_binding", lambda be: unknown)
+        shade_got = passes.gpu_deferred_shading(backend, *shade_args, *var)
+        n, names = backend.getGeneralKernelExecutions()
+        assert n == 1 and "shad" in names.lower(), (n, names)
+        trace_got = passes.gpu_sdf_trace(backend, *trace_args, strict=True, cascade=t["cascade"])
+        n, names = backend.getGeneralKernelExecutions()
+        assert n == 1 and "trace" in names.lower(), (n, names)
+    finally:
+        backend.setMathMode(True)  # the module's mode (build_state); the fixture's teardown switches it off
+    assert np.array_equal(shade_got, shade_exact)
+    assert np.array_equal(trace_got[0], trace_exact[0]) and np.array_equal(trace_got[1], trace_exact[1])
