@@ -80,6 +80,8 @@ PASS_KERNEL = {  # pass label -> kernel name prefixes in the rocprofv3 summaries
     "Depth min/max pyramid": ["plr::hizBase", "plr::hizTail"], "Tonemap": ["plr::faststream::tonemapping"], "Apply bloom": ["plr::faststream::applyBloom"],
     "Histogram per tile": ["plr::fasthist::histogramPerTile"], "Apply bloom + Tonemap": ["plr::faststream::applyBloomTonemap"],
     "Histogram per tile + Histogram reset + Histogram combine tiles + Pre-expose lights + Depth min/max pyramid + Depth downscale": ["plr::fasthist::histogramAndPyramid", "plr::exposureChainAndPyramidTail"],
+    "Histogram per tile + Histogram reset + Histogram combine tiles + Pre-expose lights + Depth min/max pyramid + Depth downscale + SDF camera frustum culling + SDF camera tile culling":
+        ["plr::fasthist::histogramAndPyramid", "plr::exposureChainAndPyramidTail"],
     "SDF camera frustum culling + SDF camera tile culling": ["plr::frustumAndTileCulling"], "Bloom Upsample mip 0": ["plr::fastbloom::bloomUpsampleQuad"],
 }
 

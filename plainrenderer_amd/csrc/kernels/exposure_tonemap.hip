@@ -348,19 +348,35 @@ __global__ __launch_bounds__(128) void histogramResetCombineKernel(const uint32_
     histogramCombineExposeBlock<false>(blockIdx.x, gridDim.x, perTile, histogram, nBins, nTiles, scratch, nullptr, ImgView{}, nullptr, 0.f, 0.f, nullptr, nullptr, totals, &isLast);
 }
 
-// launch 2 of the fused frame front (kernels_fast/fused_front.h): block 0 finishes the depth pyramid, the others are the exposure chain's
+// launch 2 of the fused frame front (kernels_fast/fused_front.h): block 0 finishes the depth pyramid, the next chainBlocks are the exposure chain's, and -
+// CULL - the rest are the camera culling's (device/culling_device.h), 16 tiles each. A culling tile needs one texel of the pyramid level block 0 is
+// writing in this very launch (the first tail level): it evaluates that texel itself from the level below, which launch 1 finished - the same footprint,
+// the same bits - instead of waiting for block 0.
+template <bool CULL>
 __global__ __launch_bounds__(1024) void exposureChainAndPyramidTailKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
                                                                           ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
                                                                           const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog, HizParams tail,
-                                                                          int tailFirst, int tailTexelsA) {
+                                                                          int tailFirst, int tailTexelsA, uint32_t chainBlocks, FusedCullParams cull, uint32_t cullBlocks) {
     extern __shared__ float2 pyramidTailLds[];
     __shared__ float term[kMaxExposureBins];
     __shared__ uint32_t counted[kMaxExposureBins];
     __shared__ uint32_t totals[kFusedExposureMaxBins];
     __shared__ uint32_t isLast;
     if (blockIdx.x == 0) { fasthiz::hizTailBlock<1024>(tail, tailFirst, tailTexelsA, pyramidTailLds); return; }
-    histogramCombineExposeBlock(blockIdx.x - 1u, gridDim.x - 1u, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog, maxLuminanceLog, term, counted,
-                                totals, &isLast);
+    const uint32_t b = blockIdx.x - 1u;
+    if (CULL && b >= chainBlocks) {
+        // the frustum-culled list lives in the dynamic LDS block 0 uses for the pyramid (the launcher sizes it for both uses)
+        const int w = tail.w[tailFirst], h = tail.h[tailFirst], sw = tail.w[tailFirst - 1], sh = tail.h[tailFirst - 1];
+        const float2* __restrict__ below = tail.level[tailFirst - 1];
+        frustumAndTileCullingBlock<true, 1024>(cull, b - chainBlocks, cullBlocks, (uint32_t*)pyramidTailLds, counted, &isLast, [&](vec2 uv) {
+            // sampleNearest2D<F_RG32F, CLAMP> of level tailFirst at uv (device/image.h), the texel evaluated instead of loaded (depthHiZPyramid.comp:52-124)
+            const int x = clampi((int)floorf(saneCoord(uv.x * (float)w)), w), y = clampi((int)floorf(saneCoord(uv.y * (float)h)), h);
+            const MinMax m = footprint<false>(2 * x, 2 * y, sw, sh, sh & 1, sw & 1, [&](int sx, int sy) { return below[(size_t)sy * (size_t)sw + (size_t)sx]; });
+            return make_float2(m.mn, m.mx);
+        });
+        return;
+    }
+    histogramCombineExposeBlock(b, chainBlocks, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog, maxLuminanceLog, term, counted, totals, &isLast);
 }
 
 static int launchPreExposeLights(const PassCtx& c) {
@@ -411,12 +427,19 @@ static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
     PLR_CHECK_LAUNCH(*ctxs[1]);
     return 0;
 }
-int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream) {
+int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull) {
     // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
-    if (hipFuncSetAttribute((const void*)exposureChainAndPyramidTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+    const void* kernel = cull ? (const void*)exposureChainAndPyramidTailKernel<true> : (const void*)exposureChainAndPyramidTailKernel<false>;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
         return setLastError(-2, "exposure chain + pyramid tail: cannot raise the dynamic LDS limit");
-    exposureChainAndPyramidTailKernel<<<e.blocks + 1u, 1024, h.tailLdsBytes, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
-                                                                                        e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst, h.tailTexelsA);
+    const uint32_t cullBlocks = cull ? divUp(cull->domainX * cull->domainY, 16u) : 0u;
+    const size_t lds = cull ? std::max(h.tailLdsBytes, (size_t)kFusedCullMaxInstances * 4u) : h.tailLdsBytes;
+    if (cull) exposureChainAndPyramidTailKernel<true><<<1u + e.blocks + cullBlocks, 1024, lds, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
+                                                                                                      e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst,
+                                                                                                      h.tailTexelsA, e.blocks, *cull, cullBlocks);
+    else exposureChainAndPyramidTailKernel<false><<<1u + e.blocks, 1024, lds, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
+                                                                                       e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst, h.tailTexelsA,
+                                                                                       e.blocks, FusedCullParams{}, 0u);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : setLastError(-2, std::string("exposure chain + pyramid tail launch failed: ") + hipGetErrorString(err));
 }

@@ -10,6 +10,7 @@
 // (ascending instance index) without changing which instances survive.
 #include "../backend.h"
 #include "../device/shading_common.h"
+#include "../device/culling_device.h"
 
 namespace plr {
 
@@ -42,24 +43,6 @@ PLR_REGISTER_SHADER_FAST("depthDownscale.comp", launchDepthDownscale);
 
 // ------------------------------------------------------------------------------------------------
 // sdfCameraFrustumCulling.comp:36-62 as one block doing an ordered stream compaction.
-struct FrustumUbo { float points[6][4]; float normals[6][4]; };
-struct CulledList { uint32_t count; uint32_t indices[1]; };
-
-// the shader's test for one instance (:44-58)
-PLR_DI bool insideFrustum(const BoundingBox& bb, const FrustumUbo* __restrict__ frustum, float influenceRange) {
-    const vec3 bbMin = ld3(bb.bbMin), bbMax = ld3(bb.bbMax);
-    const vec3 center = (bbMax + bbMin) * 0.5f;
-    const vec3 ext = bbMax - bbMin;
-    float radius = gmax(gmax(ext.x, ext.y), ext.z) * 0.5f;
-    radius += influenceRange;
-    bool inside = true;
-    for (int i = 0; i < 6; i++) {
-        const bool outsidePlane = dot(center - ld3(frustum->points[i]), ld3(frustum->normals[i])) > radius;
-        inside = inside && !outsidePlane;
-    }
-    return inside;
-}
-
 __global__ __launch_bounds__(1024) void frustumCullingKernel(const uint32_t* __restrict__ instanceBuffer, const FrustumUbo* __restrict__ frustum,
                                                              uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs,
                                                              const float* __restrict__ influenceRangeP, uint32_t threadLimit, uint32_t capacity) {
@@ -110,72 +93,6 @@ static int launchFrustumCulling(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("sdfCameraFrustumCulling.comp", launchFrustumCulling);
 
-// ------------------------------------------------------------------------------------------------
-// sdfCulling.inc:17-20: tile stride from the FULL screen resolution (reproduced as is)
-PLR_DI uint32_t tileIndexFromTileUV(int tx, int ty, const GlobalUbo* g) {
-    const uint32_t tileCountX = (uint32_t)ceilf((float)g->screenResolution[0] / (float)kCullingTileSize);
-    return (uint32_t)tx + (uint32_t)ty * tileCountX;
-}
-
-PLR_DI vec3 VFromiUV(int x, int y, const GlobalUbo* g) {
-    const vec2 pixelCoor(((float)x / (float)g->screenResolution[0] - 0.5f) * 2.f, ((float)y / (float)g->screenResolution[1] - 0.5f) * 2.f);
-    return calculateViewDirectionFromPixel(pixelCoor, ld3(g->cameraForward), ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
-}
-
-// sdfCameraTileCulling.comp:42-99, one wave per tile: 64 instances are tested per step and appended in list order.
-// LIST(i) returns entry i of the frustum-culled list, listCount its length.
-template <bool USE_HIZ, class List>
-PLR_DI void cullTile(List list, uint32_t listCount, uint32_t lane, uint32_t tileLinear, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
-                     float influenceRange, const ImgView& depthMinMax, const GlobalUbo* __restrict__ g, uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX,
-                     uint32_t domainY, uint32_t tileRow0, uint32_t tileCapacity) {
-    if (tileLinear >= domainX * domainY) return;
-    const int tx = (int)(tileLinear % domainX), ty = (int)(tileRow0 + tileLinear / domainX);
-    const uint32_t tileIndex = tileIndexFromTileUV(tx, ty, g);
-    if (tileIndex >= tileCapacity) return;
-    CulledInstancesPerTile* tile = tiles + tileIndex;
-    const int ts = (int)kCullingTileSize;
-    const vec3 cameraToPixel = -VFromiUV(tx * ts + ts / 2, ty * ts + ts / 2, g);
-    vec3 V_ll = -VFromiUV(tx * ts, ty * ts, g);
-    vec3 V_ur = -VFromiUV(tx * ts + ts, ty * ts + ts, g);
-    V_ll /= dot(cameraToPixel, V_ll);
-    V_ur /= dot(cameraToPixel, V_ur);
-    const float coneRadiusPerMeter = distance(V_ll, V_ur) * 0.5f;
-    float depthMin = g->nearPlane, depthMax = g->farPlane;
-    if (USE_HIZ) {
-        const vec2 uv((float)tx / (float)tileCountX, (float)ty / (float)tileCountY);
-        const vec4 mm = sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv);
-        depthMin = linearizeDepth(mm.y, g->nearPlane, g->farPlane);
-        depthMax = linearizeDepth(mm.x, g->nearPlane, g->farPlane);
-    }
-    const vec3 camFwd = ld3(g->cameraForward), camPos = ld3(g->cameraPosition);
-    depthMin *= dot(cameraToPixel, camFwd);
-    depthMax *= dot(cameraToPixel, camFwd);
-    uint32_t count = 0;
-    for (uint32_t chunk = 0; chunk < listCount && count < kMaxObjectsPerTile; chunk += 64u) {
-        const uint32_t i = chunk + lane;
-        bool pass = false;
-        uint32_t inst = 0;
-        if (i < listCount) {
-            inst = list(i);
-            const BoundingBox bb = bbs[inst];
-            const vec3 bbMin = ld3(bb.bbMin), bbMax = ld3(bb.bbMax);
-            const vec3 center = (bbMax + bbMin) * 0.5f;
-            const vec3 ext = (bbMax - bbMin) * 0.5f;
-            float radius = gmax(gmax(ext.x, ext.y), ext.z);
-            radius += influenceRange;
-            float projection = dot(center - camPos, cameraToPixel);
-            projection = gclamp(projection, depthMin, depthMax);
-            const float d = distance(center, projection * cameraToPixel + camPos);
-            pass = d < radius + coneRadiusPerMeter * projection;
-        }
-        const unsigned long long mask = __ballot(pass);
-        const uint32_t pos = count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pass && pos < kMaxObjectsPerTile) tile->indices[pos] = inst;
-        count = min(count + (uint32_t)__popcll(mask), kMaxObjectsPerTile);
-    }
-    if (lane == 0) tile->objectCount = count;
-}
-
 template <bool USE_HIZ>
 __global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
                                                          const float* __restrict__ influenceRangeP, ImgView depthMinMax, const GlobalUbo* __restrict__ g,
@@ -183,63 +100,16 @@ __global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restr
                                                          uint32_t tileCapacity, uint32_t listCapacity) {
     const uint32_t culledInstanceCount = min(culled[0], listCapacity);
     cullTile<USE_HIZ>([&](uint32_t i) { return culled[1 + i]; }, culledInstanceCount, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6), bbs, tiles, *influenceRangeP,
-                      depthMinMax, g, tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity);
+                      [&](vec2 uv) { return sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv); }, g, tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity);
 }
 
-// ---- pass fusion (backend.h): sdfCameraFrustumCulling + sdfCameraTileCulling recorded back to back, as one launch. Every block repeats the
-// (tiny) frustum test of all instances into LDS with the same ordered compaction and culls its four tiles against that list; block 0 also
-// stores the list, and the block that takes the last ticket stores its length - after every block has read the initial length.
-constexpr uint32_t kFusedCullMaxInstances = 4096;
-struct CullScratch { uint32_t ticket; };
+// ---- pass fusion (backend.h): the two culling passes as one launch (device/culling_device.h)
 template <bool USE_HIZ>
-__global__ __launch_bounds__(256) void frustumAndTileCullingKernel(const uint32_t* __restrict__ instanceBuffer, const FrustumUbo* __restrict__ frustum, uint32_t* __restrict__ culled,
-                                                                   const BoundingBox* __restrict__ bbsFrustum, const float* __restrict__ influenceFrustumP, uint32_t threadLimit,
-                                                                   uint32_t capacity, CullScratch* __restrict__ scratch, const BoundingBox* __restrict__ bbs,
-                                                                   CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP, ImgView depthMinMax,
-                                                                   const GlobalUbo* __restrict__ g, uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX, uint32_t domainY,
-                                                                   uint32_t tileRow0, uint32_t tileCapacity, uint32_t listCapacity) {
+__global__ __launch_bounds__(256) void frustumAndTileCullingKernel(FusedCullParams p, ImgView depthMinMax) {
     __shared__ uint32_t list[kFusedCullMaxInstances];
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t base;
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t instanceCount = min(instanceBuffer[0], threadLimit);
-    const float influenceFrustum = *influenceFrustumP;
-    const uint32_t base0 = culled[0]; // entries the list already holds (the host zeroes the count every frame)
-    if (t == 0) base = base0;
-    __syncthreads();
-    for (uint32_t chunk = 0; chunk < instanceCount; chunk += 256u) {
-        const uint32_t instanceIndex = chunk + t;
-        const bool inside = instanceIndex < instanceCount && insideFrustum(bbsFrustum[instanceIndex], frustum, influenceFrustum);
-        const unsigned long long mask = __ballot(inside);
-        const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) waveTotals[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t waveBase = base, total = 0;
-        for (uint32_t w = 0; w < 4u; w++) {
-            if (w < wave) waveBase += waveTotals[w];
-            total += waveTotals[w];
-        }
-        const uint32_t pos = waveBase + before;
-        if (inside && pos < capacity) {
-            if (pos < kFusedCullMaxInstances) list[pos] = instanceIndex;
-            if (blockIdx.x == 0) culled[1 + pos] = instanceIndex;
-        }
-        __syncthreads();
-        if (t == 0) base += total;
-        __syncthreads();
-    }
-    const uint32_t finalCount = base;
-    const uint32_t listCount = min(finalCount, listCapacity);
-    // entries below base0 were in the global list before this launch (block 0 does not touch them)
-    cullTile<USE_HIZ>([&](uint32_t i) { return i < base0 ? culled[1 + i] : list[i]; }, listCount, lane, blockIdx.x * 4u + wave, bbs, tiles, *influenceRangeP, depthMinMax, g,
-                      tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity);
-    __syncthreads();
-    // every block read culled[0] (base0) before this barrier; the ticket is release / acquire at agent scope so that the last block's store of
-    // the new count is ordered after all of those reads
-    if (t == 0 && __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-        culled[0] = finalCount;
-        __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    frustumAndTileCullingBlock<USE_HIZ, 256>(p, blockIdx.x, gridDim.x, list, waveTotals, &base, [&](vec2 uv) { return sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv); });
 }
 
 static int launchTileCulling(const PassCtx& c) {
@@ -271,9 +141,7 @@ static int launchTileCulling(const PassCtx& c) {
 }
 PLR_REGISTER_SHADER("sdfCameraTileCulling.comp", launchTileCulling);
 
-static int launchFusedCulling(const PassCtx* const* ctxs, size_t count) {
-    if (count != 2) return kUseGeneralKernel;
-    const PassCtx &fc = *ctxs[0], &tc = *ctxs[1];
+int prepareFusedCulling(const PassCtx& fc, const PassCtx& tc, FusedCullParams* out, bool* useHiZOut, ImgView* hizOut) {
     if (!fc.hasSbuf(0) || !fc.hasUbuf(1) || !fc.hasSbuf(2) || !fc.hasSbuf(3) || !fc.hasUbuf(4) || fc.ubuf[1].size < sizeof(FrustumUbo) || fc.sbuf[2].size < 8) return kUseGeneralKernel;
     if (!tc.global || !tc.hasSbuf(0) || !tc.hasSbuf(1) || !tc.hasSbuf(2) || !tc.hasUbuf(3) || tc.push.size() < 8) return kUseGeneralKernel;
     if (tc.sbuf[0].ptr != fc.sbuf[2].ptr) return kUseGeneralKernel; // the tile pass must read the list the frustum pass writes
@@ -288,18 +156,28 @@ static int launchFusedCulling(const PassCtx* const* ctxs, size_t count) {
     const PassCtx::RowSpan rs = tc.rowSpan((int)tileCount[1]);
     const uint32_t tcx = std::min(tileCount[0], tc.dispatch[0] * 8u), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0;
     if (tcx == 0 || rs.y1 <= rs.y0) return kUseGeneralKernel; // nothing to cull for: let the frustum pass run on its own
-    const uint32_t tileCapacity = (uint32_t)(tc.sbuf[2].size / sizeof(CulledInstancesPerTile));
-    const uint32_t listCapacity = (uint32_t)(tc.sbuf[0].size / 4u) - 1u;
     CullScratch* scratch = (CullScratch*)tc.scratch(sizeof(CullScratch)); // zero-initialised, returned to zero by the kernel
     if (!scratch) return tc.fail(-2, "sdfCameraTileCulling: cannot allocate scratch memory");
-    const dim3 grid(divUp(tcx * tcy, 4u));
-    const ImgView hiz = useHiZ ? tc.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
-#define PLR_FUSED_CULL_ARGS (const uint32_t*)fc.sbuf[0].ptr, (const FrustumUbo*)fc.ubuf[1].ptr, (uint32_t*)fc.sbuf[2].ptr, (const BoundingBox*)fc.sbuf[3].ptr, (const float*)fc.ubuf[4].ptr, \
-                            threadLimit, capacity, scratch, (const BoundingBox*)tc.sbuf[1].ptr, (CulledInstancesPerTile*)tc.sbuf[2].ptr, (const float*)tc.ubuf[3].ptr, hiz, tc.global,     \
-                            tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity
-    if (useHiZ) frustumAndTileCullingKernel<true><<<grid, 256, 0, tc.stream>>>(PLR_FUSED_CULL_ARGS);
-    else frustumAndTileCullingKernel<false><<<grid, 256, 0, tc.stream>>>(PLR_FUSED_CULL_ARGS);
-#undef PLR_FUSED_CULL_ARGS
+    out->instanceBuffer = (const uint32_t*)fc.sbuf[0].ptr; out->frustum = (const FrustumUbo*)fc.ubuf[1].ptr; out->culled = (uint32_t*)fc.sbuf[2].ptr;
+    out->bbsFrustum = (const BoundingBox*)fc.sbuf[3].ptr; out->influenceFrustumP = (const float*)fc.ubuf[4].ptr; out->threadLimit = threadLimit; out->capacity = capacity;
+    out->scratch = scratch; out->bbs = (const BoundingBox*)tc.sbuf[1].ptr; out->tiles = (CulledInstancesPerTile*)tc.sbuf[2].ptr; out->influenceRangeP = (const float*)tc.ubuf[3].ptr;
+    out->g = tc.global; out->tileCountX = tileCount[0]; out->tileCountY = tileCount[1]; out->domainX = tcx; out->domainY = tcy; out->tileRow0 = tileRow0;
+    out->tileCapacity = (uint32_t)(tc.sbuf[2].size / sizeof(CulledInstancesPerTile)); out->listCapacity = (uint32_t)(tc.sbuf[0].size / 4u) - 1u;
+    *useHiZOut = useHiZ;
+    *hizOut = useHiZ ? tc.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
+    return 0;
+}
+
+static int launchFusedCulling(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx& tc = *ctxs[1];
+    FusedCullParams p;
+    bool useHiZ = false;
+    ImgView hiz;
+    if (int rc = prepareFusedCulling(*ctxs[0], tc, &p, &useHiZ, &hiz)) return rc;
+    const dim3 grid(divUp(p.domainX * p.domainY, 4u));
+    if (useHiZ) frustumAndTileCullingKernel<true><<<grid, 256, 0, tc.stream>>>(p, hiz);
+    else frustumAndTileCullingKernel<false><<<grid, 256, 0, tc.stream>>>(p, hiz);
     PLR_CHECK_LAUNCH(tc);
     return 0;
 }

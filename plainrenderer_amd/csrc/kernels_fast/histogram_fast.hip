@@ -165,9 +165,9 @@ static int launch(const PassCtx& c) {
     return 0;
 }
 
-// the six passes of the frame front as two launches (fused_front.h)
+// the six passes of the frame front - eight with the camera culling's two behind them - as two launches (fused_front.h)
 static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
-    if (count != 6) return kUseGeneralKernel;
+    if (count != 6 && count != 8) return kUseGeneralKernel;
     HistParams hp;
     if (int rc = prepare(*ctxs[0], &hp)) return rc;
     if (hp.gridX == 0 || hp.gridY == 0) return kUseGeneralKernel;
@@ -177,11 +177,20 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     fasthiz::Plan zp;
     if (int rc = fasthiz::prepare(*ctxs[4], ctxs[5], &zp)) return rc;
     if (zp.perTile) return kUseGeneralKernel; // a per-tile pyramid has no chain tail for launch 2 to host: its passes fuse on their own (hiz_fast.hip)
+    FusedCullParams cull;
+    if (count == 8) {
+        // launch 2 hosts the culling when its tiles sample exactly the pyramid level launch 2 starts with: whole, and not the pyramid's first level
+        bool useHiZ = false;
+        ImgView hiz;
+        if (int rc = prepareFusedCulling(*ctxs[6], *ctxs[7], &cull, &useHiZ, &hiz)) return rc;
+        const int l = zp.tailFirst;
+        if (!useHiZ || l < 1 || l >= zp.tail.count || hiz.ptr != (const void*)zp.tail.level[l] || hiz.w != zp.tail.w[l] || hiz.h != zp.tail.h[l]) return kUseGeneralKernel;
+    }
     // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
     histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX);
     PLR_CHECK_LAUNCH(*ctxs[0]);
-    return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream);
+    return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr);
 }
 
 // ---- exhaustive verification (plr_debug_verify_histogram_thresholds)
@@ -200,6 +209,9 @@ __global__ void verifyKernel(const uint32_t* __restrict__ thresholds, const uint
 static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
 PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
 static int fused_frame_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
+static int fused_frame_front_and_culling(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
+PLR_REGISTER_FUSION("frame front: histogram + exposure chain || depth pyramid || camera culling", fused_frame_front_and_culling, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+                    "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 PLR_REGISTER_FUSION("frame front: histogram + exposure chain || depth pyramid", fused_frame_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
                     "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp");
 } // namespace plr
