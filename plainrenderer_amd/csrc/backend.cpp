@@ -1131,9 +1131,47 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     x.ctx.passName = p.name.c_str();
 }
 
+// images a launcher left unwritten (PassCtx::elidedStorage): a host download must not return last frame's bytes silently
+static void noteElidedImages(const PassCtx& cx) {
+    for (int b = 0; b < kMaxBindings && cx.elidedStorage; b++)
+        if ((cx.elidedStorage >> b) & 1u)
+            for (ImageRes& im : g->images) if (im.dev && im.dev == cx.storage[b].ptr) im.elided = true;
+}
+
+// Pass fusion level 2 for a producer whose consumer takes its output through another channel (PassCtx::consumer: the spatial GI filter gathers the packed
+// texels its producer writes, fused_gi.h): a storage image of the producer is elidable when nothing can ever read what the producer would have written to it:
+//  * behind the producer, nothing but the consumer touches it in this frame (a later "write" may read as well: a storage binding, an exchange callback);
+//  * the frame's first access to it is a write by a producer of a consumer link - this execution itself or another (the trace): those launchers only store to
+//    their outputs, so the next frame, recorded alike, overwrites the image before anything reads it.
+// (A host that asks for the image gets the loud "not written" error, as for a fused launch.)
+static void markElidableBehindConsumer(Execution& x) {
+    const size_t index = (size_t)(&x - g->executions.data());
+    for (const Execution& y : g->executions) if (y.callback && !y.callbackAccessKnown) return; // a host callback that may read anything
+    auto linkProducer = [](const Execution& y) {
+        if (y.callback) return false;
+        for (const ConsumerLink& link : consumerLinks()) if (link.producer == g->passes[y.pass]->shader) return true;
+        return false;
+    };
+    for (int b = 0; b < kMaxBindings; b++) {
+        if (!x.ctx.hasStorage(b)) continue;
+        const void* key = nullptr;
+        for (const Access& a : x.access) if (a.write && a.key == x.ctx.storage[b].ptr) key = a.key;
+        if (!key) continue;
+        bool ok = true, first = true;
+        for (size_t j = 0; j < g->executions.size() && ok; j++)
+            for (const Access& a : g->executions[j].access) {
+                if (a.key != key) continue;
+                if (first) { first = false; if (!a.write || !linkProducer(g->executions[j])) ok = false; }
+                if (j > index && &g->executions[j].ctx != x.ctx.consumer) ok = false;
+            }
+        if (ok) x.ctx.elidableStorage |= 1u << b;
+    }
+}
+
 static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {
     PassRes& p = *g->passes[x.pass];
     prepareCtx(x, stream, globalPtr);
+    if (g->fusion >= 2 && g->mathMode == PLR_MATH_FAST && !g->debugSig && x.ctx.consumer) markElidableBehindConsumer(x);
     g->currentPassName = p.name.c_str();
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
@@ -1152,6 +1190,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     // a kernel that did not order its rows (general kernel, edges that are not whole block rows): the signal is raised behind the whole launch
     if (signalled && !x.ctx.edgeSignalHonoured) HIP_TRY(hipStreamWriteValue32(stream, g->edgeSignal, x.ctx.edgeValue, 0));
     if (timed) if (int trc = endSegment()) return trc;
+    noteElidedImages(x.ctx);
     return PLR_OK;
 }
 
@@ -1206,12 +1245,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         }
         if (rc) { g_err = "fused launch '" + f.label + "': " + g_err; return rc; }
         if (timed) if (int trc = endSegment()) return trc;
-        for (size_t k = 0; k < n; k++) { // images the launcher left unwritten: a host download must not return last frame's bytes silently
-            const PassCtx& cx = g->executions[i + k].ctx;
-            for (int b = 0; b < kMaxBindings && cx.elidedStorage; b++)
-                if ((cx.elidedStorage >> b) & 1u)
-                    for (ImageRes& im : g->images) if (im.dev && im.dev == cx.storage[b].ptr) im.elided = true;
-        }
+        for (size_t k = 0; k < n; k++) noteElidedImages(g->executions[i + k].ctx);
         *covered = n;
         g->lastFused += (uint32_t)n;
         return PLR_OK;

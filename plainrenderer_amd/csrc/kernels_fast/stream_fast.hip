@@ -361,7 +361,9 @@ PLR_DI vec2 bilinearRG16SN(const ImgView& im, float u, float v, bool repeat) {
 }
 
 // PACK: also write the packed texel of the history output for the spatial filter that reads it next (fused_gi.h); 0 = no, else the depth format
-template <int PACK>
+// PACKED_ONLY: that packed texel is all anybody will read of this pass's result (PassCtx::elidableStorage on all four outputs, backend.cpp
+// markElidableBehindConsumer): the four image stores (24 of the pass's 72 bytes per pixel) are left out
+template <int PACK, bool PACKED_ONLY = false>
 __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                                   ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
                                                                   ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase,
@@ -406,10 +408,12 @@ __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView target
     const uint2 py4 = make_uint2(floatToHalfBits(result_Y_SH.x) | (floatToHalfBits(result_Y_SH.y) << 16), floatToHalfBits(result_Y_SH.z) | (floatToHalfBits(result_Y_SH.w) << 16));
     const uint32_t pc = floatToHalfBits(result_CoCg.x) | (floatToHalfBits(result_CoCg.y) << 16);
     const bool through = ranges.isEdge((int)blockIdx.y); // rows a neighbouring GPU is waiting for: written through (backend.h TwoRanges)
-    storeOut((uint2*)targetYSH.ptr + idx, py4, through);
-    storeOut((uint32_t*)targetCoCg.ptr + idx, pc, through);
-    storeOut((uint2*)historyOutYSH.ptr + idx, py4, through);
-    storeOut((uint32_t*)historyOutCoCg.ptr + idx, pc, through);
+    if (!PACKED_ONLY) {
+        storeOut((uint2*)targetYSH.ptr + idx, py4, through);
+        storeOut((uint32_t*)targetCoCg.ptr + idx, pc, through);
+        storeOut((uint2*)historyOutYSH.ptr + idx, py4, through);
+        storeOut((uint32_t*)historyOutCoCg.ptr + idx, pc, through);
+    }
     if (PACK) packedOut[idx] = packGiTexel(py4, pc, Texel<PACK == 0 ? F_R16F : PACK>::load(packDepth.ptr, idx).x, g->nearPlane, g->farPlane);
     };
     pixel();
@@ -447,7 +451,13 @@ static int launchTemporalGi(const PassCtx& c) {
     if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32) || w != out.w)) pack = nullptr;
 #define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, \
                           pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
-    if (pack) {
+    // a launch that packs every texel of the consumer's input, and whose four output images nothing else will read (fusion level 2): packed texels only
+    const bool packedOnly = pack && (c.elidableStorage & 15u) == 15u && y0 == 0 && h == out.h && !c.extraCountY && !c.firstRows[0] && !c.firstRows[1];
+    if (packedOnly) {
+        if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F, true><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
+        else temporalGiFilterFastKernel<F_D32, true><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
+        c.elidedStorage = 15u;
+    } else if (pack) {
         if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
         else temporalGiFilterFastKernel<F_D32><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
     } else temporalGiFilterFastKernel<0><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);

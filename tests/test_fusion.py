@@ -1,7 +1,8 @@
 """Pass fusion (include/plr.h plr_set_pass_fusion, csrc/backend.h): the backend covers certain ADJACENT recorded executions with fewer kernel
 launches. The boundary and the results are unchanged: every frame of a fused run equals the unfused run byte for byte. At level 2 (the default)
-the fused upscale + deferred shade keeps the upscaled GI texels in registers when no other pass reads them: those two images are then not
-written, a download of them fails loudly, and everything else still equals the unfused run."""
+the fused upscale + deferred shade keeps the upscaled GI texels in registers when no other pass reads them, and the temporal GI filter writes only the
+packed texels the spatial filter behind it gathers: those images are then not written, a download of them fails loudly, and everything else still equals
+the unfused run."""
 import numpy as np
 import pytest
 
@@ -40,7 +41,12 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
                     if half_res:  # the half-res trace has an upscale pass: its output is consumed inside the fused upscale + shade launch
                         with pytest.raises(RuntimeError, match="not written in the last frame"):
                             backend.downloadImage(fp.image("giFullResYSH"), 0, np.uint8)
-                    names = [n for n in names if n != "giFullResYSH"]
+                    # the temporal GI filter's four outputs: the spatial filter behind it gathers the packed texels the temporal kernel writes for it, and nothing else
+                    # reads them before the next frame overwrites them (backend.cpp markElidableBehindConsumer)
+                    for gone in ("giYSH0", "giHistoryYSH1"):
+                        with pytest.raises(RuntimeError, match="not written in the last frame"):
+                            backend.downloadImage(fp.image(gone), 0, np.uint8)
+                    names = [n for n in names if n not in ("giFullResYSH", "giYSH0", "giHistoryYSH1")]
                 imgs = [backend.downloadImage(fp.image(name), 0, np.uint8).copy() for name in names]
                 out.append(imgs + [backend.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).copy(),
                                    backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint8).copy()])
