@@ -26,6 +26,7 @@ extern "C" void orc_math_eval(int fn, const float* a, const float* b, float* out
             case 11: { const vec3 v = normalize(vec3(x, y, 1.f)); r = v.x; break; }
             case 12: r = gmin(x, y); break;
             case 13: r = gmax(x, y); break;
+            case 14: r = decodeUnorm8((uint8_t)x); break; // UNORM8 decode: the IEEE quotient c / 255 (the device's three-instruction form must equal it)
             default: break;
         }
         out[i] = r;

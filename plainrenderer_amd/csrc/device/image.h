@@ -107,6 +107,13 @@ PLR_DI uint32_t packR11G11B10(vec3 c) {
 }
 
 PLR_DI float decodeUnorm8(uint32_t c) { return (float)c / 255.0f; }
+// The same value in three instructions where the file is built with IEEE division (ten): the product with the rounded reciprocal and one Newton step on it.
+// The residual c - 255 q is exact in an FMA, and the corrected quotient equals the correctly rounded c / 255 for all 256 codes (plr_debug_math_eval fn 14,
+// tests/test_gpu_foundations.py; also holds with the reciprocal one ulp off either way).
+PLR_DI float decodeUnorm8Newton(uint32_t c) {
+    const float x = (float)c, r = 0x1.010102p-8f, q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-255.f, q, x), r, q);
+}
 PLR_DI uint32_t encodeUnorm8(float v) {
     if (v != v) return 0u;
     return (uint32_t)__float2int_rn(gclamp(v, 0.f, 1.f) * 255.0f);

@@ -27,6 +27,7 @@ __global__ void mathEvalKernel(int fn, const float* __restrict__ a, const float*
         case 11: { const vec3 v = normalize(vec3(x, y, 1.f)); r = v.x; break; }
         case 12: r = gmin(x, y); break;
         case 13: r = gmax(x, y); break;
+        case 14: r = decodeUnorm8Newton((uint32_t)x); break; // the oracle's fn 14 is the IEEE quotient x / 255
         default: break;
     }
     out[i] = r;

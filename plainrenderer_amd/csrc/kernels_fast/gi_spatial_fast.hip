@@ -93,11 +93,19 @@ __global__ __launch_bounds__(256) void spatialPackAroundKernel(ImgView inYSH, Im
 }
 
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
+// Per-launch constants the launcher works out on the host: this chip has no scalar float unit, so uniform float arithmetic (image sizes as floats, their
+// correctly rounded reciprocals, the norms of three rows of viewProjection: three square roots) is otherwise repeated by every lane
+struct SpatialFrameConsts {
+    float tsx, tsy;    // 1 / output size: the IEEE quotient, as the shader's vec2(1) / textureSize
+    float dW, dH;      // depth texture size
+    float nW, nH;      // normal texture size
+    float3 vpRowNorms; // |x row|, |y row|, |w row| of the xyz part of viewProjection
+};
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
                                                                int coverW, int coverH, int yBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
-                                                               uint32_t validY0, uint32_t validRowCount, int rowMissShrinks) {
+                                                               uint32_t validY0, uint32_t validRowCount, int rowMissShrinks, SpatialFrameConsts fc) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float nf = nearP * farP, nmf = nearP - farP;
     const vec3 fwd = ld3(g->cameraForward), up = ld3(g->cameraUp), right = ld3(g->cameraRight), camPos = ld3(g->cameraPosition);
     const float tanH = g->cameraTanFovHalf, tanA = g->cameraTanFovHalf * g->cameraAspectRatio;
-    const float dW = (float)depthTexture.w, dH = (float)depthTexture.h;
+    const float dW = fc.dW, dH = fc.dH;
     const int dwi = depthTexture.w, dhi = depthTexture.h;
 
     const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
@@ -128,13 +136,14 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             const float len = root(dot(a, a));
             return a * quot(1.f, len, rcpf(len));
         };
-        const float fw = (float)outYSH.w, fh = (float)outYSH.h;
-        tsx = quot(1.f, fw, rcpf(fw)); tsy = quot(1.f, fh, rcpf(fh));
+        tsx = fc.tsx; tsy = fc.tsy;
         u0 = ((float)px + 0.5f) * tsx; v0 = ((float)py + 0.5f) * tsy;
         const float tanH = g->cameraTanFovHalf, aspect = g->cameraAspectRatio;
         auto pixelToWorldExact = [&](float u, float v) -> vec3 {
-            const int x = min(max((int)floorf(u * dW), 0), dwi - 1), y = min(max((int)floorf(v * dH), 0), dhi - 1);
-            const float depth = Texel<DEPTH_FMT>::load(depthTexture.ptr, (size_t)y * (size_t)dwi + (size_t)x).x;
+            // texel index: floor and conversion in one instruction, the clamp in one (device/image.h; same integers as min(max((int)floorf(.), 0), n - 1)),
+            // a 32-bit texel index (image sides stay below 2^24)
+            const int x = clampTo(floorToInt(u * dW), dwi - 1), y = clampTo(floorToInt(v * dH), dhi - 1);
+            const float depth = Texel<DEPTH_FMT>::load(depthTexture.ptr, __umul24((uint32_t)y, (uint32_t)dwi) + (uint32_t)x).x;
             const float den = farP + (-depth + 1.f) * (nearP - farP);                 // linearizeDepth (linearDepth.inc:5-8)
             const float depthLinear = quot(nearP * farP, den, rcpf(den));
             const float ndx = u * 2.f - 1.f, ndy = v * 2.f - 1.f;
@@ -146,16 +155,19 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             return camPos + vec3(quot(cameraToPixel.x, d, rd), quot(cameraToPixel.y, d, rd), quot(cameraToPixel.z, d, rd)) * depthLinear;
         };
         pCenter = pixelToWorldExact(u0, v0);
-        const vec3 pRight = pixelToWorldExact(u0 + 1.f * tsx, v0 + 0.f * tsy);
-        const vec3 pUp = pixelToWorldExact(u0 + 0.f * tsx, v0 + 1.f * tsy);
+        // uv + vec2(1, 0) * texelSize and uv + vec2(0, 1) * texelSize (:37-38): 1 * t = t and v + 0 * t = v exactly for the positive finite values here
+        const vec3 pRight = pixelToWorldExact(u0 + tsx, v0);
+        const vec3 pUp = pixelToWorldExact(u0, v0 + tsy);
         T = radiusWorld * unit(pCenter - pRight);
         B = radiusWorld * unit(pCenter - pUp);
     }
     const int nwi = normalTexture.w, nhi = normalTexture.h;
     vec3 N;
     {
-        const int x = min(max((int)floorf(u0 * (float)nwi), 0), nwi - 1), y = min(max((int)floorf(v0 * (float)nhi), 0), nhi - 1);
-        N = 2.f * Texel<F_RGBA8>::load(normalTexture.ptr, (size_t)y * (size_t)nwi + (size_t)x).xyz() - 1.f;
+        const int x = clampTo(floorToInt(u0 * fc.nW), nwi - 1), y = clampTo(floorToInt(v0 * fc.nH), nhi - 1);
+        const uint32_t t = ((const uint32_t*)normalTexture.ptr)[__umul24((uint32_t)y, (uint32_t)nwi) + (uint32_t)x];
+        // c / 255 as the three-instruction form (this file is built with IEEE division: ten instructions per channel otherwise; the same values, device/image.h)
+        N = 2.f * vec3(decodeUnorm8Newton(t & 0xffu), decodeUnorm8Newton((t >> 8) & 0xffu), decodeUnorm8Newton((t >> 16) & 0xffu)) - 1.f;
     }
     // clip.xyw = P0 + ox * PT + oy * PB
     const float* vp = g->viewProjection;
@@ -176,8 +188,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     bool safe;
     {
         const float dm = radiusWorld * 1.4143f * 1.01f;
-        const float sx = __builtin_amdgcn_sqrtf(vp[0] * vp[0] + vp[4] * vp[4] + vp[8] * vp[8]), sy = __builtin_amdgcn_sqrtf(vp[1] * vp[1] + vp[5] * vp[5] + vp[9] * vp[9]);
-        const float sw = __builtin_amdgcn_sqrtf(vp[3] * vp[3] + vp[7] * vp[7] + vp[11] * vp[11]);
+        // norms of the x, y and w rows of viewProjection: per-frame constants, from the launcher (three square roots and a dozen multiply-adds per LANE otherwise -
+        // this chip has no scalar float unit to take uniform arithmetic)
+        const float sx = fc.vpRowNorms.x, sy = fc.vpRowNorms.y, sw = fc.vpRowNorms.z;
         const float wMin = (P0.z - sw * dm) * 0.999f;
         safe = wMin > 0.f && fabsf(P0.x) + sx * dm <= wMin && fabsf(P0.y) + sy * dm <= wMin;
         // band rendering: only part of the input rows is valid (PassCtx::validRows). A sample's v moves by at most 0.5 (|dy| + |y / w| |dw|) / w <=
@@ -451,9 +464,18 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
     }
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
+    // per-frame constants of the "can a sample of this pixel leave the screen" test, from the host's copy of the global buffer (a host the backend cannot read
+    // the buffer of gets the general kernel, counted: plr_get_general_kernel_executions)
+    if (!c.globalHost) return kUseGeneralKernel;
+    const float* hvp = c.globalHost->viewProjection;
+    auto rowNorm = [&](int r) { return (float)std::sqrt((double)hvp[r] * hvp[r] + (double)hvp[4 + r] * hvp[4 + r] + (double)hvp[8 + r] * hvp[8 + r]); };
+    SpatialFrameConsts fc;
+    fc.tsx = 1.f / (float)out.w; fc.tsy = 1.f / (float)out.h; // IEEE single-precision quotients (this file's host code is built without fast-math)
+    fc.dW = (float)c.sampled[4].w; fc.dH = (float)c.sampled[4].h; fc.nW = (float)c.sampled[5].w; fc.nH = (float)c.sampled[5].h;
+    fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
     static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels/gi_filters.hip)
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, tilesY, chunkRows, sig, \
-                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), rowMissShrinks
+                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), rowMissShrinks, fc
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
         if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \

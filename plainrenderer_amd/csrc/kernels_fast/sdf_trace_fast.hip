@@ -288,8 +288,10 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
         // exact UNORM8 decode (c / 255, an IEEE quotient in this file): a noise value of 255 must be exactly 1 - then sinTheta is exactly 0 and L = N, and
         // for a horizontal N the sky LUT's v coordinate sits on its sqrt-steep horizon, where 2e-4 rad of direction is half a LUT row
         const uint32_t nzTexel = ((const uint16_t*)noiseTex.ptr)[fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w)];
-        const vec2 nz(decodeUnorm8(nzTexel & 0xffu), decodeUnorm8(nzTexel >> 8));
-        const vec3 N = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, vec2(u, v)).xyz() * 2.f - 1.f;
+        const vec2 nz(decodeUnorm8Newton(nzTexel & 0xffu), decodeUnorm8Newton(nzTexel >> 8)); // = c / 255 for every code, in three instructions instead of the IEEE division's ten
+        const uint32_t nTexel = ((const uint32_t*)normalTexture.ptr)[fastm::texelIndex((uint32_t)clampTo(floorToInt(u * (float)normalTexture.w), normalTexture.w - 1),
+                                                                                          (uint32_t)clampTo(floorToInt(v * (float)normalTexture.h), normalTexture.h - 1), (uint32_t)normalTexture.w)];
+        const vec3 N = vec3(decodeUnorm8Newton(nTexel & 0xffu), decodeUnorm8Newton((nTexel >> 8) & 0xffu), decodeUnorm8Newton((nTexel >> 16) & 0xffu)) * 2.f - 1.f;
         mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
         const vec3 rayOrigin = pWorld + N * 0.2f;
         {

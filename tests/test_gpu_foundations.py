@@ -28,6 +28,15 @@ def test_gpu_detmath_bit_identical(backend, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_three_instruction_unorm8_decode_is_the_ieee_quotient_for_all_codes(backend, oracle):
+    """device/image.h decodeUnorm8Newton (spatial GI filter, trace: files built with IEEE division, where c / 255 is ten instructions) against the oracle's c / 255"""
+    codes = np.arange(256, dtype=np.float32)
+    g = backend.debugMathEval(14, codes)
+    o = oracle.math_eval(14, codes)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32)) and np.array_equal(o, (codes / np.float32(255.0)).astype(np.float32))
+
+
+@pytest.mark.gpu
 def test_gpu_min_max_match_the_comparison_form_on_special_operands(backend, oracle):
     """detmath.h gmin / gmax on the device are `x == y ? x : minNum(x, y)`; the oracle's are the GLSL comparison form with the NaN rule.
     All pairs of special values (zeros of both signs, infinities, NaN, denormals, ordinary numbers) plus random pairs."""
