@@ -182,6 +182,8 @@ struct Plan {
 };
 // c: the depthHiZPyramid execution; down: the depthDownscale execution fused into it, or null. 0 / kUseGeneralKernel
 int prepare(const PassCtx& c, const PassCtx* down, Plan* out);
+// launch 1 of a plan: the quad blocks (levels 0..3 and, with a downscale pass fused in, the half-resolution depth); 0 / < 0 (kernels_fast/hiz_fast.hip)
+int launchQuadBlocks(const PassCtx& c, const Plan& plan);
 
 } // namespace fasthiz
 } // namespace plr

@@ -11,6 +11,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/culling_device.h"
+#include "../device/hiz_fast_device.h"
 
 namespace plr {
 
@@ -181,6 +182,43 @@ static int launchFusedCulling(const PassCtx* const* ctxs, size_t count) {
     PLR_CHECK_LAUNCH(tc);
     return 0;
 }
+// ---- pass fusion, per-tile pyramid (band rendering; frames beyond the shader's 11 levels): depthHiZPyramid + depthDownscale + the two culling passes recorded back to
+// back as TWO launches - the pyramid's quad blocks, then one grid whose first blocks finish the tiles' levels 4 and 5 (hizTileTailThread) and whose other blocks are
+// the culling's. A culling tile needs one texel of level 4, which the tail threads of this very launch are writing: it evaluates that texel itself from level 3
+// (the same footprint, the same bits), as the culling blocks of the whole-frame front do (kernels/exposure_tonemap.hip).
+__global__ __launch_bounds__(256) void tileTailAndCullingKernel(fasthiz::TileTailParams t, uint32_t tailBlocks, FusedCullParams cull, uint32_t cullBlocks) {
+    __shared__ uint32_t list[kFusedCullMaxInstances];
+    __shared__ uint32_t waveTotals[4];
+    __shared__ uint32_t base;
+    if (blockIdx.x < tailBlocks) { fasthiz::hizTileTailThread(t, (int)(blockIdx.x * 256u + threadIdx.x)); return; }
+    frustumAndTileCullingBlock<true, 256>(cull, blockIdx.x - tailBlocks, cullBlocks, list, waveTotals, &base, [&](vec2 uv) {
+        // sampleNearest2D<F_RG32F, CLAMP> of level 4 at uv (device/image.h), the texel evaluated instead of loaded (depthHiZPyramid.comp:52-124)
+        const int x = clampi((int)floorf(saneCoord(uv.x * (float)t.w4)), t.w4), y = clampi((int)floorf(saneCoord(uv.y * (float)t.h4)), t.h4);
+        const MinMax m = footprint<false>(2 * x, 2 * y, t.w3, t.h3, t.h3 & 1, t.w3 & 1, [&](int sx, int sy) { return t.level3[(size_t)sy * (size_t)t.w3 + (size_t)sx]; });
+        return make_float2(m.mn, m.mx);
+    });
+}
+
+static int launchTilePyramidAndCulling(const PassCtx* const* ctxs, size_t count) {
+    if (count != 4) return kUseGeneralKernel;
+    fasthiz::Plan plan;
+    if (int rc = fasthiz::prepare(*ctxs[0], ctxs[1], &plan)) return rc;
+    if (!plan.perTile) return kUseGeneralKernel; // the whole-frame chain has its own home for the culling blocks (the frame front's launch 2)
+    FusedCullParams cull;
+    bool useHiZ = false;
+    ImgView hiz;
+    if (int rc = prepareFusedCulling(*ctxs[2], *ctxs[3], &cull, &useHiZ, &hiz)) return rc;
+    const fasthiz::TileTailParams& t = plan.tileTail;
+    if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel; // the tiles must sample the level this launch finishes
+    if (int rc = fasthiz::launchQuadBlocks(*ctxs[0], plan)) return rc;
+    const int n = t.w4 * (t.row4End - t.row4Begin) + t.w5 * (t.row5End - t.row5Begin);
+    const uint32_t tailBlocks = n > 0 ? divUp((unsigned)n, 256u) : 0u, cullBlocks = divUp(cull.domainX * cull.domainY, 4u);
+    tileTailAndCullingKernel<<<tailBlocks + cullBlocks, 256, 0, ctxs[0]->stream>>>(t, tailBlocks, cull, cullBlocks);
+    PLR_CHECK_LAUNCH(*ctxs[0]);
+    return 0;
+}
+PLR_REGISTER_FUSION("depthHiZPyramid + depthDownscale + sdfCameraFrustumCulling + sdfCameraTileCulling (per-tile pyramid)", launchTilePyramidAndCulling, "depthHiZPyramid.comp",
+                    "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 PLR_REGISTER_FUSION("sdfCameraFrustumCulling + sdfCameraTileCulling", launchFusedCulling, "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 
 // ------------------------------------------------------------------------------------------------ trace

@@ -97,15 +97,20 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     return 0;
 }
 
+int launchQuadBlocks(const PassCtx& c, const Plan& plan) {
+    const dim3 grid((unsigned)plan.gridX, (unsigned)plan.gridY);
+    if (plan.downscale) hizQuadKernel<4, true><<<grid, 256, 0, c.stream>>>(plan.quad);
+    else hizQuadKernel<4, false><<<grid, 256, 0, c.stream>>>(plan.quad);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
 static int launchImpl(const PassCtx& c, const PassCtx* down) {
     Plan plan;
     if (int rc = prepare(c, down, &plan)) return rc;
     // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
     if (!plan.perTile && hipFuncSetAttribute((const void*)hizTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return kUseGeneralKernel;
-    const dim3 grid((unsigned)plan.gridX, (unsigned)plan.gridY);
-    if (down) hizQuadKernel<4, true><<<grid, 256, 0, c.stream>>>(plan.quad);
-    else hizQuadKernel<4, false><<<grid, 256, 0, c.stream>>>(plan.quad);
-    PLR_CHECK_LAUNCH(c);
+    if (int rc = launchQuadBlocks(c, plan)) return rc;
     if (plan.perTile) {
         const TileTailParams& t = plan.tileTail;
         const int n = t.w4 * (t.row4End - t.row4Begin) + t.w5 * (t.row5End - t.row5Begin);
