@@ -26,8 +26,11 @@ namespace fasttrace {
 PLR_DI float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 PLR_DI float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// Seven waves per SIMD (72 VGPRs, no scratch) instead of the six the allocator settles on by itself (80): the kernel waits on a chain of dependent fetches and
+// occupancy is what hides it - measured 99.0 -> 95.0 us; at eight (64 VGPRs) it spills 36 bytes and takes 109 us, at five (an experiment that cost two more
+// registers) 108 us (profiles/r04_not_kept.txt, profiles/r04_trace_variants.txt)
 #ifndef PLR_TRACE_OCC
-#define PLR_TRACE_OCC
+#define PLR_TRACE_OCC __attribute__((amdgpu_waves_per_eu(7, 7)))
 #endif
 // The volume texels live in global memory, but their address comes out of the LDS-staged instance table, so the compiler cannot tell and emits
 // flat_load (which also counts on lgkmcnt). PLR_TRACE_GLOBAL_VOLUMES=1 types the pointer address_space(1): global_load with partial vmcnt waits.
