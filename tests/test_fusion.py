@@ -121,3 +121,38 @@ def test_gpu_async_frame_tail_changes_nothing_but_the_schedule(backend, w, h):
             assert np.array_equal(a, b), "%s differs with the asynchronous tail, frame %d" % (what, f)
     for a, b, what in zip(results["async, no host sync between frames"][0], results["in order"][-1], names + ["histogram"]):
         assert np.array_equal(a, b), "%s differs after %d back-to-back frames with the asynchronous tail" % (what, n_frames)
+
+
+@pytest.mark.gpu
+def test_gpu_trace_through_bricked_volumes_changes_no_bit(backend, monkeypatch):
+    """North star "SDF bricks", built in the form the trace could use (csrc/device/sdf_bricks.h): PLR_TRACE_BRICKS=1 makes the fast trace march through copies of
+    the SDF volumes laid out in 128-byte bricks of 7 x 4 x 2 cells (a fetch touches 1.9 cache lines instead of 4). Same texels, same results: four frames of
+    temporal feedback equal the default run byte for byte. (Measured slower - profiles/r04_not_kept.txt - and therefore not the default. Mode 2 makes a launch
+    that cannot take the variant an error, so the equality below is about the variant.)"""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h, n_frames = 1280, 720, 4
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=513)
+    names = ["swapchain", "post1", "giHistoryYSH0", "giHistoryCoCg0", "taaHistory0", "color0", "color1"]
+    inputs, results = None, {}
+    try:
+        backend.setMathMode(True)
+        for mode in ("0", "2"):
+            monkeypatch.setenv("PLR_TRACE_BRICKS", mode)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                out.append([backend.downloadImage(fp.image(name), 0, np.uint8).copy() for name in names])
+            results[mode] = out
+            fp.destroy()
+    finally:
+        monkeypatch.delenv("PLR_TRACE_BRICKS", raising=False)
+        backend.setMathMode(False)
+    assert len(np.unique(results["0"][-1][2])) > 16, "the GI history is not a constant image"
+    for f in range(n_frames):
+        for a, b, what in zip(results["0"][f], results["2"][f], names):
+            assert np.array_equal(a, b), "%s differs with bricked volumes, frame %d" % (what, f)
