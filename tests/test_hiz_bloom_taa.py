@@ -267,3 +267,33 @@ def test_gpu_temporal_supersampling_bit_exact(backend, w, h, tonemap):
     # the test data exercises both outcomes of every rejection test
     same = a == cur
     assert 0.05 < same.mean() < 0.95
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tonemap", [(256, 144, True), (1280, 720, True), (256, 144, False), (97, 61, True)])
+def test_gpu_fast_temporal_supersampling_same_decisions_within_one_code(backend, w, h, tonemap):
+    """PLR_MATH_FAST kernels of the optional TAA stage (kernels_fast/supersampling_fast.hip): the luminance image is bit exact (its R8 rounding is a discrete
+    result), and the supersampled colour takes the oracle's decisions by construction (decision arithmetic in the exact set's form), so EVERY channel of EVERY
+    pixel is within one R11G11B10 code - no outliers. 97 x 61 is not a multiple of four wide: colorToLuminance then runs the general kernel, said loudly."""
+    import parity
+    from test_exposure_tonemap import _global
+    cur, last, motion, depth, depth_last = _supersampling_inputs(w, h)
+    g = _global(w, h, time=1.0)
+    lc_o = passes.orc_color_to_luminance(cur, w, h)
+    ll = passes.orc_color_to_luminance(last, w, h)
+    b = passes.orc_temporal_supersampling(cur, last, motion, depth, depth_last, lc_o, ll, w, h, g, tonemap)
+    backend.setMathMode(True)
+    try:
+        lc_g = passes.gpu_color_to_luminance(backend, cur, w, h)
+        n_general, names = backend.getGeneralKernelExecutions()
+        assert n_general == (0 if w % 4 == 0 else 1), (n_general, names)
+        a = passes.gpu_temporal_supersampling(backend, cur, last, motion, depth, depth_last, lc_o, ll, w, h, g, tonemap)
+        assert backend.getGeneralKernelExecutions()[0] == 0, backend.getGeneralKernelExecutions()
+    finally:
+        backend.setMathMode(False)
+    assert np.array_equal(lc_g, lc_o)
+    d = parity.r11g11b10_code_diff(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1))
+    print("SUPERSAMPLING fast %dx%d tonemap=%d max_code_diff=%d differing=%.3g" % (w, h, tonemap, int(d.max()), float((d != 0).any(axis=1).mean())))
+    assert d.max() <= 1
+    taken = np.asarray(a).reshape(h, w) != cur  # both outcomes of the rejection tests occur
+    assert 0.05 < taken.mean() < 0.95
