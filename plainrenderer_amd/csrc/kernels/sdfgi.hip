@@ -594,5 +594,8 @@ static int launchSdfDebugVisualisation(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("sdfDebugVisualisation.comp", launchSdfDebugVisualisation);
+// Also what PLR_MATH_FAST runs: a debug view's job is to show what the march DOES (mode 4 colours by step count, mode 3 by the SDF's normal, mode 2 by the tile
+// lists): the exact-order march is the instrument, a restructured one would visualise itself. It is not on the frame's path (SDFGI.cpp:334-369 replaces the frame).
+PLR_REGISTER_SHADER_FAST("sdfDebugVisualisation.comp", launchSdfDebugVisualisation);
 
 } // namespace plr
