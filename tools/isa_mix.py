@@ -30,7 +30,7 @@ KERNELS = [  # (object substring, demangled-name substring, label, waves per lau
     ("shading_fast", "upscaleAndShadeKernel<2, 0, true>", "indirectLightUpscale + deferred shade"),
     ("taa_fast", "temporalFilterStripKernel<true, true, 4, true, false>", "temporalFilter (TAA)"),
     ("gi_spatial_fast", "spatialFilterFastKernel<3, 64, true, true, false>", "filterIndirectDiffuseSpatial (x2 per frame)"),
-    ("sdf_trace_fast", "sdfDiffuseTraceFastKernel<true, false, 3, false>", "sdfDiffuseTrace"),
+    ("sdf_trace_fast", "sdfDiffuseTraceFastKernel<true, false, 3, false, false>", "sdfDiffuseTrace"),
     ("stream_fast", "temporalGiFilterFastKernel<3, true>", "filterIndirectDiffuseTemporal (packed texels only)"),
     ("stream_fast", "applyBloomTonemapKernel<true>", "applyBloom + tonemapping"),
 ]
