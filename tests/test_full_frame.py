@@ -149,3 +149,48 @@ def test_gpu_frame_wider_than_the_shader_pyramid_limit_builds_per_tile_levels(ba
     sw = backend.downloadImage(fp.image("swapchain"), 0, np.uint8)
     assert sw.reshape(h, w, 4)[..., :3].max() > 0
     fp.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_with_an_empty_sdf_scene(backend):
+    """Edge case of the GI path: no SDF instances at all (SDFGI.cpp:260-313 with an empty scene). Culling writes empty tile lists, every ray of the trace reaches
+    the sky, the denoisers and the shade run on sky light only. The exact set must equal the oracle frame bit for bit as with any other scene; the fast set must run
+    its own kernels (no loud fallback) and agree with the exact set to one code almost everywhere (a flipped filter sample is the only decision left)."""
+    import struct
+    import parity
+    from oracle_frame import OracleFrame
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    n_frames = 3
+    cams = _cameras(n_frames)
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=515)
+    post, tiles_total = {}, None
+    try:
+        for fast in (False, True):
+            backend.setMathMode(fast)
+            fp = FramePipeline(backend, W, H, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            inputs = SyntheticInputs(scene, cams[1], cams[0], W, H, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.volumes = []
+            inputs.instance_bytes = struct.pack("<IIII", 0, 0, 0, 0) + bytes(96)  # instanceCount = 0 (+ one zeroed record: the buffer's minimum size)
+            inputs.bb_bytes = bytes(32)
+            inputs.upload(fp)
+            ora = OracleFrame(inputs, W, H, LUT_RES, fp.settings) if not fast else None
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                if fast:
+                    assert backend.getGeneralKernelExecutions()[0] == 0, backend.getGeneralKernelExecutions()
+                else:
+                    frustum = backend.downloadUniformBuffer(fp.uniform_buffer("sdfCameraFrustum"), 192).tobytes()
+                    influence = float(backend.downloadUniformBuffer(fp.uniform_buffer("sdfInfluenceRange"), 4, dtype=np.float32)[0])
+                    ora.frame(fp.submitted_globals(), fp.resolve_weights(), frustum, influence)
+                    assert packed_close(backend.downloadImage(fp.image("post1"), 0, np.uint32), ora.post1, 0.0), "TAA+bloom output, frame %d" % f
+                    tiles = backend.downloadStorageBuffer(fp.storage_buffer("sdfCulledTiles"), ora.tiles.nbytes, dtype=np.uint32).reshape(-1, passes.TILE_UINTS)
+                    tiles_total = int(tiles[:, 0].sum())
+            post[fast] = backend.downloadImage(fp.image("post1"), 0, np.uint32).copy()
+            fp.destroy()
+    finally:
+        backend.setMathMode(False)
+    assert tiles_total == 0, "an empty scene culls to empty tile lists"
+    d = parity.r11g11b10_code_diff(post[True], post[False])
+    lit = pixfmt.unpack_r11g11b10(post[False])
+    assert np.isfinite(lit).all() and lit.max() > 0
+    assert (d.max(axis=1) <= 1).mean() >= 0.999, "fast vs exact kernel set on an empty SDF scene: %.5f of the pixels within one code, worst %d" % ((d.max(axis=1) <= 1).mean(), int(d.max()))
