@@ -194,3 +194,43 @@ def test_gpu_frame_with_an_empty_sdf_scene(backend):
     lit = pixfmt.unpack_r11g11b10(post[False])
     assert np.isfinite(lit).all() and lit.max() > 0
     assert (d.max(axis=1) <= 1).mean() >= 0.999, "fast vs exact kernel set on an empty SDF scene: %.5f of the pixels within one code, worst %d" % ((d.max(axis=1) <= 1).mean(), int(d.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(322, 182), (72, 40)])
+def test_gpu_frame_at_sizes_no_tile_divides(backend, w, h):
+    """Ragged sizes (a window resize away in the reference, RenderFrontend.cpp:229-275): widths and heights that are no multiple of 8, 32 or 64, and a frame smaller than
+    one 64-pixel tile row in places. The exact set equals the oracle frame; the fast set runs - with its general-kernel fallbacks COUNTED where a fast kernel was not built
+    for the size - and stays within one code of the exact set on almost every pixel."""
+    import parity
+    from oracle_frame import OracleFrame
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    n_frames = 3
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=516)
+    post, fallbacks = {}, None
+    try:
+        for fast in (False, True):
+            backend.setMathMode(fast)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            ora = OracleFrame(inputs, w, h, LUT_RES, fp.settings) if not fast else None
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                if fast:
+                    fallbacks = backend.getGeneralKernelExecutions()
+                else:
+                    frustum = backend.downloadUniformBuffer(fp.uniform_buffer("sdfCameraFrustum"), 192).tobytes()
+                    influence = float(backend.downloadUniformBuffer(fp.uniform_buffer("sdfInfluenceRange"), 4, dtype=np.float32)[0])
+                    ora.frame(fp.submitted_globals(), fp.resolve_weights(), frustum, influence)
+                    assert packed_close(backend.downloadImage(fp.image("post1"), 0, np.uint32), ora.post1, 0.0), "TAA+bloom output, frame %d (%dx%d)" % (f, w, h)
+            post[fast] = backend.downloadImage(fp.image("post1"), 0, np.uint32).copy()
+            fp.destroy()
+    finally:
+        backend.setMathMode(False)
+    print("RAGGED %dx%d general-kernel executions in the fast frame: %d (%s)" % (w, h, fallbacks[0], fallbacks[1]))
+    d = parity.r11g11b10_code_diff(post[True], post[False])
+    lit = pixfmt.unpack_r11g11b10(post[True])
+    assert np.isfinite(lit).all() and lit.max() > 0
+    assert (d.max(axis=1) <= 1).mean() >= 0.99, "fast vs exact kernel set at %dx%d: %.5f of the pixels within one code" % (w, h, (d.max(axis=1) <= 1).mean())
