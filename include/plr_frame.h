@@ -39,9 +39,9 @@ typedef struct plrf_settings {
     uint32_t band_taa_history_halo; /* rows of the TAA history exchanged between bands (default 32) */
     uint32_t run_volumetrics; /* the four froxel passes produce volumetricIntegrationVolume (reference default VolumetricsSettings; noise volume "perlinNoise3D" is an input) */
     uint32_t run_sky_luts; /* sky transmission / multiscatter / sky LUT compute passes with the reference's default AtmosphereSettings */
-    uint32_t band_overlap_exchange; /* default 1: producers of exchanged images run their edge rows first and the exchange callback is called twice,
-                                       with PLRF_EXCHANGE_BEGIN (start, do not wait) and PLRF_EXCHANGE_END (wait); 0: one call per exchange.
-                                       2 (default): as 1, but the producer is ONE launch that writes the edge rows first and raises plr_get_edge_signal when they
+    uint32_t band_overlap_exchange; /* 0: one call per exchange. 1: producers of exchanged images run their edge rows first and the exchange callback is called
+                                       twice, with PLRF_EXCHANGE_BEGIN (start, do not wait) and PLRF_EXCHANGE_END (wait).
+                                       2 (the default): as 1, but the producer is ONE launch that writes the edge rows first and raises plr_get_edge_signal when they
                                        are complete (plr.h first_rows) - the BEGIN callback may wait for that signal on its own stream instead of ordering
                                        behind the launch stream; 1: an edge launch and an interior launch with the BEGIN callback between them (round 3) */
 } plrf_settings;
