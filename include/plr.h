@@ -94,7 +94,8 @@ typedef struct plr_compute_pass_execution {
     uint32_t dispatch_count[3];
     /* extension (no reference counterpart): first workgroup of the dispatch, vkCmdDispatchBase semantics. Zero for the
      * reference's recorder code. A band renderer (one GPU per range of screen rows) sets [1] so a pass covers only its rows;
-     * [0] is honoured by histogramCombineTiles (first tile), [2] must be 0. */
+     * [0] is honoured by histogramCombineTiles (first tile) and is an error (PLR_ERR_UNSUPPORTED) for every other pass - the kernels cover whole rows;
+     * [2] must be 0. */
     uint32_t dispatch_base[3];
     /* extension (band rendering): rows [valid_rows[0], valid_rows[1]) of the pass's INPUT images hold valid data - the band's own rows plus the
      * halo rows received from the neighbouring GPUs; {0, 0} = every row (the reference's recorder code). Honoured by filterIndirectDiffuseSpatial,

@@ -727,6 +727,12 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
         if (writesDefaultImage) x.access.push_back({kBindlessKey, true});
     }
     if (e->dispatch_base[2] != 0) { g->executions.pop_back(); return setErr(PLR_ERR_INVALID_ARGUMENT, "dispatch_base[2] must be 0"); }
+    // no kernel of the path takes a first workgroup COLUMN (the partition is by rows); the one pass whose x axis is not pixels does: not silently ignored
+    if (e->dispatch_base[0] != 0 && g->passes[e->handle]->shader != "histogramCombineTiles.comp") {
+        const std::string shader = g->passes[e->handle]->shader;
+        g->executions.pop_back();
+        return setErr(PLR_ERR_UNSUPPORTED, "dispatch_base[0] is honoured by histogramCombineTiles.comp only (first tile); " + shader + " covers whole rows");
+    }
     return PLR_OK;
 }
 

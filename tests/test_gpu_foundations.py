@@ -123,3 +123,22 @@ def test_gpu_a_thread_without_its_own_backend_uses_the_process_global_one(backen
     assert np.array_equal(got["bytes"], np.arange(8 * 4 * 4, dtype=np.uint8)) and got["fusion"] == backend.getPassFusion()[0]
     assert "another thread set up" in got["shutdown"], "only the thread that called plr_setup shuts the backend down"
     backend.getPassFusion()  # the owner's backend is alive
+
+
+@pytest.mark.gpu
+def test_gpu_a_first_workgroup_column_is_refused_not_ignored(backend):
+    """plr_compute_pass_execution::dispatch_base has vkCmdDispatchBase semantics; the kernels of the path cover whole rows, so a non-zero [0] (which they would
+    otherwise ignore silently) is PLR_ERR_UNSUPPORTED for every pass but histogramCombineTiles, whose x axis is the tile index"""
+    from plainrenderer_amd.backend import ComputePassExecution, ImageResource, RenderPassResources, PlrError
+    from util import F, image_desc_2d
+    src = backend.createImage(image_desc_2d(64, 32, F.R11G11B10_uFloat), np.zeros(64 * 32, np.uint32))
+    dst = backend.createImage(image_desc_2d(64, 32, F.RGBA8))
+    p = backend.createComputePass("tonemapping.comp", [], "Tonemap")
+    backend.newFrame()
+    exe = ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(dst, 0, 0)], sampledImages=[ImageResource(src, 0, 1)]), b"", (4, 4, 1))
+    exe.dispatchBase = (4, 0, 0)
+    with pytest.raises(PlrError, match="dispatch_base"):
+        backend.setComputePassExecution(exe)
+    exe.dispatchBase = (0, 2, 0)  # a first workgroup ROW is the band renderer's bread and butter
+    backend.setComputePassExecution(exe)
+    backend.newFrame()  # drop the recording (nothing is rendered: the test is about what the recorder accepts)
