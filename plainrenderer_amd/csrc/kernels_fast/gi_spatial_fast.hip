@@ -346,6 +346,9 @@ int spatialFilterPackTarget(const PassCtx& c, SpatialPackTarget* out) {
     if (!c.hasSampled(2) || !c.hasSampled(3) || !c.hasSampled(4) || c.sampled[2].fmt != F_RGBA16F || c.sampled[3].fmt != F_RG16F) return kUseGeneralKernel;
     const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h && c.sampled[3].w == c.sampled[2].w && c.sampled[3].h == c.sampled[2].h;
     if (!sameGrid || (c.sampled[4].fmt != F_R16F && c.sampled[4].fmt != F_D32)) return kUseGeneralKernel;
+    // every reason for which THIS pass's launcher hands the execution to the general kernel must also be a "no" here: a producer that was promised a packed-texel
+    // consumer may leave the unpacked image unwritten (fusion level 2), and the general kernel reads the image
+    if (!c.global || !c.globalHost) return kUseGeneralKernel;
     uint8_t* scratch = spatialScratch(c, true);
     if (!scratch) return c.fail(-2, "filterIndirectDiffuseSpatial: cannot allocate scratch memory");
     out->packed = (uint4*)(scratch + kSpatialTableBytes);
