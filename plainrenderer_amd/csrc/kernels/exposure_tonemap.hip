@@ -356,7 +356,7 @@ template <bool CULL>
 __global__ __launch_bounds__(1024) void exposureChainAndPyramidTailKernel(const uint32_t* __restrict__ perTile, uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles,
                                                                           ExposureScratch* __restrict__ scratch, LightBuffer* __restrict__ light, ImgView transmissionLut,
                                                                           const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog, HizParams tail,
-                                                                          int tailFirst, int tailTexelsA, uint32_t chainBlocks, FusedCullParams cull, uint32_t cullBlocks) {
+                                                                          int tailFirst, int tailTexelsA, uint32_t chainBlocks, FusedCullParams cull, uint32_t cullBlocks, int cullLevel) {
     extern __shared__ float2 pyramidTailLds[];
     __shared__ float term[kMaxExposureBins];
     __shared__ uint32_t counted[kMaxExposureBins];
@@ -365,13 +365,22 @@ __global__ __launch_bounds__(1024) void exposureChainAndPyramidTailKernel(const 
     if (blockIdx.x == 0) { fasthiz::hizTailBlock<1024>(tail, tailFirst, tailTexelsA, pyramidTailLds); return; }
     const uint32_t b = blockIdx.x - 1u;
     if (CULL && b >= chainBlocks) {
-        // the frustum-culled list lives in the dynamic LDS block 0 uses for the pyramid (the launcher sizes it for both uses)
-        const int w = tail.w[tailFirst], h = tail.h[tailFirst], sw = tail.w[tailFirst - 1], sh = tail.h[tailFirst - 1];
+        // the frustum-culled list lives in the dynamic LDS block 0 uses for the pyramid (the launcher sizes it for both uses).
+        // The level the tiles sample is tailFirst (4K: the quad blocks made four levels) or tailFirst + 1 (1080p: three): the first is one footprint over the level
+        // launch 1 finished, the second a footprint of such footprints - at most 81 texels of a level that is in memory, against waiting for block 0.
+        const int w1 = tail.w[tailFirst], h1 = tail.h[tailFirst], sw = tail.w[tailFirst - 1], sh = tail.h[tailFirst - 1];
         const float2* __restrict__ below = tail.level[tailFirst - 1];
-        frustumAndTileCullingBlock<true, 1024>(cull, b - chainBlocks, cullBlocks, (uint32_t*)pyramidTailLds, counted, &isLast, [&](vec2 uv) {
-            // sampleNearest2D<F_RG32F, CLAMP> of level tailFirst at uv (device/image.h), the texel evaluated instead of loaded (depthHiZPyramid.comp:52-124)
-            const int x = clampi((int)floorf(saneCoord(uv.x * (float)w)), w), y = clampi((int)floorf(saneCoord(uv.y * (float)h)), h);
+        auto firstTailLevelAt = [&](int x, int y) {
             const MinMax m = footprint<false>(2 * x, 2 * y, sw, sh, sh & 1, sw & 1, [&](int sx, int sy) { return below[(size_t)sy * (size_t)sw + (size_t)sx]; });
+            return make_float2(m.mn, m.mx);
+        };
+        const bool second = cullLevel == tailFirst + 1;
+        const int w = tail.w[cullLevel], h = tail.h[cullLevel];
+        frustumAndTileCullingBlock<true, 1024>(cull, b - chainBlocks, cullBlocks, (uint32_t*)pyramidTailLds, counted, &isLast, [&](vec2 uv) {
+            // sampleNearest2D<F_RG32F, CLAMP> of level cullLevel at uv (device/image.h), the texel evaluated instead of loaded (depthHiZPyramid.comp:52-124)
+            const int x = clampi((int)floorf(saneCoord(uv.x * (float)w)), w), y = clampi((int)floorf(saneCoord(uv.y * (float)h)), h);
+            if (!second) return firstTailLevelAt(x, y);
+            const MinMax m = footprint<false>(2 * x, 2 * y, w1, h1, h1 & 1, w1 & 1, [&](int sx, int sy) { return firstTailLevelAt(sx, sy); });
             return make_float2(m.mn, m.mx);
         });
         return;
@@ -427,7 +436,7 @@ static int launchFusedExposureChain(const PassCtx* const* ctxs, size_t count) {
     PLR_CHECK_LAUNCH(*ctxs[1]);
     return 0;
 }
-int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull) {
+int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull, int cullLevel) {
     // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
     const void* kernel = cull ? (const void*)exposureChainAndPyramidTailKernel<true> : (const void*)exposureChainAndPyramidTailKernel<false>;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
@@ -436,10 +445,10 @@ int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz:
     const size_t lds = cull ? std::max(h.tailLdsBytes, (size_t)kFusedCullMaxInstances * 4u) : h.tailLdsBytes;
     if (cull) exposureChainAndPyramidTailKernel<true><<<1u + e.blocks + cullBlocks, 1024, lds, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
                                                                                                       e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst,
-                                                                                                      h.tailTexelsA, e.blocks, *cull, cullBlocks);
+                                                                                                      h.tailTexelsA, e.blocks, *cull, cullBlocks, cullLevel);
     else exposureChainAndPyramidTailKernel<false><<<1u + e.blocks, 1024, lds, stream>>>(e.perTile, e.histogram, e.nBins, e.nTiles, (ExposureScratch*)e.scratch, (LightBuffer*)e.light,
                                                                                        e.transmissionLut, e.global, e.minLuminanceLog, e.maxLuminanceLog, h.tail, h.tailFirst, h.tailTexelsA,
-                                                                                       e.blocks, FusedCullParams{}, 0u);
+                                                                                       e.blocks, FusedCullParams{}, 0u, 0);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? 0 : setLastError(-2, std::string("exposure chain + pyramid tail launch failed: ") + hipGetErrorString(err));
 }

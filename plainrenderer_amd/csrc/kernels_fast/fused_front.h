@@ -26,7 +26,8 @@ struct ExposureChainPlan {
     float minLuminanceLog = 0.f, maxLuminanceLog = 0.f;
 };
 int prepareExposureChain(const PassCtx* const* ctxs3, ExposureChainPlan* out);                                        // 0 / kUseGeneralKernel / < 0
-// cull: the camera culling's two passes hosted by the same launch (validated by prepareFusedCulling; its tiles must sample pyramid level h.tailFirst), or null
-int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull = nullptr); // 0 / < 0
+// cull: the camera culling's two passes hosted by the same launch (validated by prepareFusedCulling), or null; cullLevel: the pyramid level its tiles sample,
+// h.tailFirst or h.tailFirst + 1
+int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull = nullptr, int cullLevel = 0); // 0 / < 0
 
 } // namespace plr

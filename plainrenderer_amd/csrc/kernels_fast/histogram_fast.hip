@@ -178,19 +178,22 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (int rc = fasthiz::prepare(*ctxs[4], ctxs[5], &zp)) return rc;
     if (zp.perTile) return kUseGeneralKernel; // a per-tile pyramid has no chain tail for launch 2 to host: its passes fuse on their own (hiz_fast.hip)
     FusedCullParams cull;
+    int cullLevel = -1;
     if (count == 8) {
-        // launch 2 hosts the culling when its tiles sample exactly the pyramid level launch 2 starts with: whole, and not the pyramid's first level
+        // launch 2 hosts the culling when its tiles sample the pyramid level launch 2 starts with or the one above it (not a level the quad blocks make)
         bool useHiZ = false;
         ImgView hiz;
         if (int rc = prepareFusedCulling(*ctxs[6], *ctxs[7], &cull, &useHiZ, &hiz)) return rc;
-        const int l = zp.tailFirst;
-        if (!useHiZ || l < 1 || l >= zp.tail.count || hiz.ptr != (const void*)zp.tail.level[l] || hiz.w != zp.tail.w[l] || hiz.h != zp.tail.h[l]) return kUseGeneralKernel;
+        if (!useHiZ || zp.tailFirst < 1) return kUseGeneralKernel;
+        for (int l = zp.tailFirst; l <= zp.tailFirst + 1 && l < zp.tail.count; l++)
+            if (hiz.ptr == (const void*)zp.tail.level[l] && hiz.w == zp.tail.w[l] && hiz.h == zp.tail.h[l]) cullLevel = l;
+        if (cullLevel < 0) return kUseGeneralKernel;
     }
     // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
     histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX);
     PLR_CHECK_LAUNCH(*ctxs[0]);
-    return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr);
+    return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr, cullLevel);
 }
 
 // ---- exhaustive verification (plr_debug_verify_histogram_thresholds)
