@@ -49,15 +49,17 @@ struct FusionEntry {
     std::vector<std::string> shaders;
     FusedLaunchFn fn;
     bool writesSignatures = false;
+    bool takesFills = false; // handles PassCtx::pendingFillSlot of its first execution itself (backend.h)
 };
 static std::vector<FusionEntry>& fusions() {
     static std::vector<FusionEntry> r;
     return r;
 }
-FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures) {
+FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures, bool takesFills) {
     FusionEntry e;
     e.label = label;
     e.writesSignatures = writesSignatures;
+    e.takesFills = takesFills;
     for (const char* sname : shaders) e.shaders.push_back(sname);
     e.fn = fn;
     // longer sequences first: a chain of three is tried before a pair that is its prefix
@@ -287,6 +289,9 @@ struct Backend {
     // waited for yet, as the union of what they touch; tailDone is recorded behind the last of them
     hipStream_t tailStream = nullptr;
     hipEvent_t tailDone = nullptr, tailStart = nullptr;
+    uint8_t* pendingFillSlot = nullptr;     // this frame's fill table, not applied yet (applyPendingFillsNow)
+    hipEvent_t pendingFillEvent = nullptr;  // its slot's completion event, recorded behind the launch that applies it
+
     std::vector<Access> tailPending;
     bool asyncTail = true;               // plr_set_async_tail
     uint32_t lastAsync = 0;              // executions of the last frame that ran on the tail stream
@@ -853,26 +858,19 @@ int plr_create_compute_pass(const plr_compute_pass_desc* desc, plr_pass_handle* 
 // front of every frame's first pass, on the launch stream (profiles/r04_frame_timeline.txt: 34 us of copies + two event records between the last
 // kernel of frame N and the first of frame N + 1). Now the frame's fills are ONE kernel: the host writes a table {destination, offset, size} and the
 // payloads into a pinned slot, the kernel reads the slot over PCIe (a kilobyte: one round trip) and stores to every destination, in call order.
-struct FillEntry { uint64_t dst; uint32_t srcOffset, size; };
-constexpr size_t kFillTableHeader = 16;         // uint32 count, padding, uint64 done (written by the kernel: the serial of the fill it has consumed)
 constexpr uint32_t kFillKernelMaxBytes = 65536; // larger fills (scene set-up) keep the copy engine
-__global__ __launch_bounds__(256) void applyFillsKernel(uint8_t* __restrict__ slot, uint64_t serial) {
-    const uint32_t count = *(const uint32_t*)slot;
-    const FillEntry* entries = (const FillEntry*)(slot + kFillTableHeader);
-    for (uint32_t i = 0; i < count; i++) {
-        const FillEntry f = entries[i];
-        uint8_t* dst = (uint8_t*)f.dst;
-        const uint8_t* src = slot + f.srcOffset;
-        if ((((uint32_t)f.dst | f.srcOffset | f.size) & 3u) == 0u)
-            for (uint32_t w = threadIdx.x; w < f.size / 4u; w += blockDim.x) ((uint32_t*)dst)[w] = ((const uint32_t*)src)[w];
-        else
-            for (uint32_t k = threadIdx.x; k < f.size; k += blockDim.x) dst[k] = src[k];
-        __syncthreads(); // call order: a later fill of the same bytes wins
-    }
-    // every read of the slot is done (the barrier above): tell the host it may re-use it
-    // (relaxed: the slot was only READ, and every value read has been consumed by a store above - a release here is a system-scope write-back of the
-    //  XCD's L2 in front of every frame, measured at +7 us per frame)
-    if (threadIdx.x == 0) __hip_atomic_store((uint64_t*)(slot + 8), serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ __launch_bounds__(256) void applyFillsKernel(uint8_t* __restrict__ slot, uint64_t serial) { applyFillsBlock(slot, serial); } // backend.h
+
+// The small fills of a frame are not applied by a launch of their own when the frame's first launch can host them: flushFills leaves the table pending, and whoever
+// launches first either takes it (a fused launcher registered for that: the frame front's first kernel touches no host-filled buffer, so one more block of it applies
+// the table - one dependent launch less in front of every frame) or applies it now.
+static int applyPendingFillsNow() {
+    if (!g->pendingFillSlot) return PLR_OK;
+    applyFillsKernel<<<1, 256, 0, g->stream>>>(g->pendingFillSlot, 0);
+    HIP_TRY(hipGetLastError());
+    g->pendingFillSlot = nullptr;
+    if (g->pendingFillEvent) { HIP_TRY(hipEventRecord(g->pendingFillEvent, g->stream)); g->pendingFillEvent = nullptr; }
+    return PLR_OK;
 }
 
 static int flushFills() {
@@ -958,9 +956,13 @@ static int flushFills() {
         applyFillsKernel<<<1, 256, 0, g->stream>>>(host, slot.serial);
         HIP_TRY(hipGetLastError());
     } else {
-        if (count) { *(uint32_t*)host = count; applyFillsKernel<<<1, 256, 0, g->stream>>>(host, 0); HIP_TRY(hipGetLastError()); }
-        HIP_TRY(hipEventRecord(slot.free, g->stream)); // a copy-engine transfer read the slot too (set-up frames): an event covers both
-        slot.eventPending = true;
+        if (int rc = applyPendingFillsNow()) return rc; // (fills flushed twice without a launch in between)
+        slot.eventPending = true; // its event is recorded behind whatever reads the slot last
+        if (count && !usedCopyEngine) { *(uint32_t*)host = count; g->pendingFillSlot = host; g->pendingFillEvent = slot.free; } // applied by the frame's first launch
+        else {
+            if (count) { *(uint32_t*)host = count; applyFillsKernel<<<1, 256, 0, g->stream>>>(host, 0); HIP_TRY(hipGetLastError()); }
+            HIP_TRY(hipEventRecord(slot.free, g->stream)); // a copy-engine transfer read the slot too (set-up frames): an event covers both
+        }
     }
     slot.busy = true;
     g->fills.clear();
@@ -1176,6 +1178,7 @@ static void markElidableBehindConsumer(Execution& x) {
 
 static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* globalPtr, bool timed) {
     PassRes& p = *g->passes[x.pass];
+    if (int frc = applyPendingFillsNow()) return frc; // the frame's fills, if its first launch is this one
     prepareCtx(x, stream, globalPtr);
     if (g->fusion >= 2 && g->mathMode == PLR_MATH_FAST && !g->debugSig && x.ctx.consumer) markElidableBehindConsumer(x);
     g->currentPassName = p.name.c_str();
@@ -1244,7 +1247,22 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         }
         g->currentPassName = label ? label : f.label.c_str();
         for (size_t k = 0; k < n; k++) touchAccesses(g->executions[i + k].access);
+        // the frame's pending fills: a launcher registered for it gets the table with its first execution (and either hosts it in its first kernel or applies it
+        // itself before launching), for every other launcher they are applied now
+        Execution& first = g->executions[i];
+        first.ctx.pendingFillSlot = nullptr; first.ctx.pendingFillsTaken = false; first.ctx.applyPendingFillsNow = nullptr;
+        if (g->pendingFillSlot) {
+            if (f.takesFills && stream == g->stream) { first.ctx.pendingFillSlot = g->pendingFillSlot; first.ctx.applyPendingFillsNow = &applyPendingFillsNow; }
+            else if (int frc = applyPendingFillsNow()) return frc;
+        }
         const int rc = f.fn(ctxs, n);
+        if (first.ctx.pendingFillSlot) {
+            if (rc == 0 && first.ctx.pendingFillsTaken) { // applied by a block of the launcher's first kernel: the slot is free behind this launch
+                g->pendingFillSlot = nullptr;
+                if (g->pendingFillEvent) { HIP_TRY(hipEventRecord(g->pendingFillEvent, g->stream)); g->pendingFillEvent = nullptr; }
+            } else if (rc == 0 && g->pendingFillSlot) { g_err = "fused launch '" + f.label + "' neither took nor applied the frame's pending fills"; return PLR_ERR_HIP; }
+            first.ctx.pendingFillSlot = nullptr; first.ctx.applyPendingFillsNow = nullptr;
+        }
         if (rc == kUseGeneralKernel) {
             if (timed) { g->segments.pop_back(); g->eventsUsed -= 1; } // the opening event stays recorded on the stream; its slot is reused
             continue;
@@ -1341,6 +1359,7 @@ static int launchAll(bool timed) {
             }
             tailOpen = false;
             g->curStream = g->stream;
+            if (int rc = applyPendingFillsNow()) return rc;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
             if (x.callbackAccessKnown) touchAccesses(x.access);
             else g->contentVersion.clear(); // may have written anything: every image gets a new version at its next query
@@ -1357,6 +1376,7 @@ static int launchAll(bool timed) {
                 // executions flagged async_tail (plr.h) go to the tail stream: behind everything launched before them, beside everything launched
                 // after them that shares no resource with them - the next frame's passes included
                 const bool async = tailAllowed && g->executions[i].asyncTail;
+                if (async) if (int rc = applyPendingFillsNow()) return rc; // (a frame whose first launch is a tail launch: the fills go in front of the tail's start)
                 size_t runEnd = i + 1; // [i, runEnd): executions of the same kind (a fused launch never mixes the two)
                 while (runEnd < last && (tailAllowed && g->executions[runEnd].asyncTail) == async) runEnd++;
                 hipStream_t stream = g->stream;
@@ -1396,6 +1416,7 @@ static int launchAll(bool timed) {
             }
             continue;
         }
+        if (int rc = applyPendingFillsNow()) return rc; // side streams start behind the launch stream's work so far: the fills belong to it
         int mainAfter[kMaxStreams];
         planStreams(i, last, plan, 1 + g->activeSideStreams, mainAfter);
         static const bool debugPlan = std::getenv("PLR_STREAM_DEBUG") != nullptr;
@@ -1464,6 +1485,7 @@ int plr_render_frame(int /*present_to_screen*/) {
     if (frameTimed) HIP_TRY(hipEventRecord(g->frameStart, g->stream));
     rc = launchAll(g->passTiming);
     if (rc) return rc;
+    if (int frc = applyPendingFillsNow()) return frc; // a frame without a launch
     if (frameTimed) HIP_TRY(hipEventRecord(g->frameEnd, g->stream));
     g->frameRecorded = frameTimed;
     g->timedExecutions = g->passTiming ? g->segments.size() : 0;
@@ -1540,6 +1562,7 @@ int plr_replay_frame(uint32_t count, float* out_total_gpu_ms) {
     rc = flushBindless();
     if (rc) return rc;
     HIP_TRY(hipEventRecord(g->frameStart, g->stream));
+    if (int frc = applyPendingFillsNow()) return frc; // (a replayed frame re-launches its first launch: the table is applied once, in front)
     for (uint32_t i = 0; i < count; i++) {
         rc = launchAll(false);
         if (rc) return rc;

@@ -48,6 +48,12 @@ struct PassCtx {
     uint32_t extraBaseY = 0, extraCountY = 0;
     // pass fusion with elision (plr_set_pass_fusion(2)): bit b set = the image at storage binding b is touched by no execution of this frame outside the
     // fused sequence this context is part of, so a fused launcher that consumes it inside its own kernel may leave it unwritten
+    // the frame's buffer fills still waiting to be applied (backend.cpp flushFills): a fused launcher registered with PLR_REGISTER_FUSION_TAKES_FILLS either lets a
+    // block of its FIRST kernel apply them (applyFillsBlock; only if that kernel touches none of the destinations) and sets pendingFillsTaken, or calls
+    // applyPendingFillsNow() before its first launch. Null: nothing pending.
+    uint8_t* pendingFillSlot = nullptr;
+    mutable bool pendingFillsTaken = false;
+    int (*applyPendingFillsNow)() = nullptr;
     uint32_t elidableStorage = 0;
     mutable uint32_t elidedStorage = 0;   // set by the fused launcher: the storage bindings it really left unwritten (the backend flags those images)
     // rows to produce first + edge signal (plr.h first_rows; band rendering): workgroup rows [base[1], firstRows[0]) and [firstRows[1], base[1] + dispatch[1])
@@ -211,13 +217,39 @@ struct ShaderRegistrar {
 // not what it was built for (the executions then run one by one), 0 when it launched everything, < 0 on error. Results must not depend on
 // whether a sequence was fused (tests/test_fusion.py compares bytes).
 typedef int (*FusedLaunchFn)(const PassCtx* const* ctxs, size_t count);
+// The frame's buffer fills as a table in pinned host memory (backend.cpp flushFills): {count, padding, done} header, entries, payloads. One block applies it.
+struct FillEntry { uint64_t dst; uint32_t srcOffset, size; };
+constexpr size_t kFillTableHeader = 16; // uint32 count, padding, uint64 done (written by the kernel: the serial of the fill it has consumed)
+#ifdef __HIPCC__
+__device__ inline void applyFillsBlock(uint8_t* __restrict__ slot, uint64_t serial) {
+    const uint32_t count = *(const uint32_t*)slot;
+    const FillEntry* entries = (const FillEntry*)(slot + kFillTableHeader);
+    for (uint32_t i = 0; i < count; i++) {
+        const FillEntry f = entries[i];
+        uint8_t* dst = (uint8_t*)f.dst;
+        const uint8_t* src = slot + f.srcOffset;
+        if ((((uint32_t)f.dst | f.srcOffset | f.size) & 3u) == 0u)
+            for (uint32_t w = threadIdx.x; w < f.size / 4u; w += blockDim.x) ((uint32_t*)dst)[w] = ((const uint32_t*)src)[w];
+        else
+            for (uint32_t k = threadIdx.x; k < f.size; k += blockDim.x) dst[k] = src[k];
+        __syncthreads(); // call order: a later fill of the same bytes wins
+    }
+    // every read of the slot is done (the barrier above): tell the host it may re-use it
+    // (relaxed: the slot was only READ, and every value read has been consumed by a store above - a release here is a system-scope write-back of the
+    //  XCD's L2 in front of every frame, measured at +7 us per frame)
+    if (threadIdx.x == 0) __hip_atomic_store((uint64_t*)(slot + 8), serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+
 struct FusionRegistrar {
     // writesSignatures: the fused kernels write the decision signatures of all their passes (plr_debug_set_decision_signature) - such a sequence
     // stays fused while a signature buffer is set; all others run pass by pass then
-    FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures = false);
+    FusionRegistrar(const char* label, std::initializer_list<const char*> shaders, FusedLaunchFn fn, bool writesSignatures = false, bool takesFills = false);
 };
 #define PLR_REGISTER_FUSION(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn)
 #define PLR_REGISTER_FUSION_WITH_SIGNATURES(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn, true)
+// the launcher handles PassCtx::pendingFillSlot of its first execution (see there)
+#define PLR_REGISTER_FUSION_TAKES_FILLS(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn, false, true)
 
 // Fusion ACROSS the recorded order: when an execution of `producer` is launched, PassCtx::consumer points at the first later execution of
 // `consumer` that samples one of its storage images. The producer's fast launcher may then do part of the consumer's work on the rows it

@@ -108,11 +108,14 @@ __global__ __launch_bounds__(256) void histogramPerTileFastKernel(HistParams p) 
 
 // launch 1 of the fused frame front (fused_front.h): the per-tile histogram's blocks and the depth pyramid's quad blocks in one grid, four to one
 // while both last (the first kind is bound by VALU / LDS, the second by HBM: interleaved, every CU hosts both)
+// fillSlot: the frame's pending buffer fills (backend.h PassCtx::pendingFillSlot), applied by one more block - this kernel reads and writes none of their destinations
+// (the launcher checks), and everything that does is launched behind it
 template <bool DOWNSCALE>
-__global__ __launch_bounds__(256) void histogramAndPyramidKernel(HistParams p, fasthiz::QuadParams q, uint32_t histBlocks, uint32_t hizBlocks, uint32_t hizGridX) {
+__global__ __launch_bounds__(256) void histogramAndPyramidKernel(HistParams p, fasthiz::QuadParams q, uint32_t histBlocks, uint32_t hizBlocks, uint32_t hizGridX, uint8_t* fillSlot) {
     __shared__ uint32_t localHistogram[kBins];
     __shared__ float thr[kBins];
     const uint32_t b = blockIdx.x;
+    if (b == histBlocks + hizBlocks) { applyFillsBlock(fillSlot, 0); return; } // (only launched when fillSlot is set)
     const uint32_t paired = min(hizBlocks, histBlocks / 4u), remHist = histBlocks - 4u * paired;
     bool isHiz;
     uint32_t index;
@@ -191,7 +194,24 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     }
     // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
-    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX);
+    // the frame's pending fills ride in launch 1 when it touches none of their destinations (uniform / storage buffers the host writes per frame: the frustum, the
+    // culled-instance count, filter weights, the rotating copy of the global buffer ... - launch 1 reads the colour and depth images and the light buffer)
+    uint8_t* fillSlot = nullptr;
+    if (ctxs[0]->pendingFillSlot) {
+        const uint8_t* slot = ctxs[0]->pendingFillSlot;
+        const uint32_t nFills = *(const uint32_t*)slot;
+        const FillEntry* entries = (const FillEntry*)(slot + kFillTableHeader); // pinned host memory: readable here
+        auto touches = [&](const void* base, size_t bytes) {
+            for (uint32_t i = 0; i < nFills; i++)
+                if (entries[i].dst < (uint64_t)(uintptr_t)base + bytes && (uint64_t)(uintptr_t)base < entries[i].dst + entries[i].size) return true;
+            return false;
+        };
+        const bool disjoint = !touches(hp.light, sizeof(LightBuffer)) && !touches(hp.perTile, (size_t)hp.tilesX * (hp.tileY0 + hp.gridY) * kBins * 4u) &&
+                              !touches(hp.thresholds, kBins * 4u);
+        if (disjoint) { fillSlot = ctxs[0]->pendingFillSlot; ctxs[0]->pendingFillsTaken = true; }
+        else if (int rc = ctxs[0]->applyPendingFillsNow()) return rc;
+    }
+    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks + (fillSlot ? 1u : 0u), 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX, fillSlot);
     PLR_CHECK_LAUNCH(*ctxs[0]);
     return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr, cullLevel);
 }
@@ -213,9 +233,9 @@ static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
 PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
 static int fused_frame_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
 static int fused_frame_front_and_culling(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
-PLR_REGISTER_FUSION("frame front: histogram + exposure chain || depth pyramid || camera culling", fused_frame_front_and_culling, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+PLR_REGISTER_FUSION_TAKES_FILLS("frame front: histogram + exposure chain || depth pyramid || camera culling", fused_frame_front_and_culling, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
                     "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
-PLR_REGISTER_FUSION("frame front: histogram + exposure chain || depth pyramid", fused_frame_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+PLR_REGISTER_FUSION_TAKES_FILLS("frame front: histogram + exposure chain || depth pyramid", fused_frame_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
                     "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp");
 } // namespace plr
 
