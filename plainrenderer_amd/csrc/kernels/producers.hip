@@ -366,14 +366,19 @@ PLR_DI float depthToFroxelUVZ(float depth, float maxDistance) {
     return det_logf(linear * (det_expf(kFroxelK) - 1.f) + 1.f) / kFroxelK;
 }
 
-PLR_DI vec3 froxelWorldPosition(int x, int y, int z, const ImgView& vol, float jitter, const GlobalUbo* g, float maxDistance, vec3* Vout, bool ndcForm2) {
-    const vec3 uv(((float)x + 0.5f + jitter) / (float)vol.w, ((float)y + 0.5f + jitter) / (float)vol.h, ((float)z + 0.5f + jitter) / (float)vol.d);
+// the froxel's view ray scaled to unit depth, V / dot(-V, forward): the part of the world position that depends on (x, y) only
+PLR_DI vec3 froxelRayPerDepth(int x, int y, const ImgView& vol, float jitter, const GlobalUbo* g, vec3* Vout, bool ndcForm2) {
+    const vec2 uv(((float)x + 0.5f + jitter) / (float)vol.w, ((float)y + 0.5f + jitter) / (float)vol.h);
     const vec2 ndc = ndcForm2 ? vec2(2.f * uv.x - 1.f, 2.f * uv.y - 1.f) : vec2(2.f * (uv.x - 0.5f), 2.f * (uv.y - 0.5f));
     const vec3 fwd = ld3(g->cameraForward);
     const vec3 V = calculateViewDirectionFromPixel(ndc, fwd, ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
-    const vec3 posWorld = ld3(g->cameraPosition) - V / dot(-V, fwd) * froxelUVToDepth(uv.z, maxDistance);
     if (Vout) *Vout = V;
-    return posWorld;
+    return V / dot(-V, fwd);
+}
+// the part that depends on z only
+PLR_DI float froxelSliceDepth(int z, const ImgView& vol, float jitter, float maxDistance) { return froxelUVToDepth(((float)z + 0.5f + jitter) / (float)vol.d, maxDistance); }
+PLR_DI vec3 froxelWorldPosition(int x, int y, int z, const ImgView& vol, float jitter, const GlobalUbo* g, float maxDistance, vec3* Vout, bool ndcForm2) {
+    return ld3(g->cameraPosition) - froxelRayPerDepth(x, y, vol, jitter, g, Vout, ndcForm2) * froxelSliceDepth(z, vol, jitter, maxDistance);
 }
 
 PLR_DI size_t idx3(const ImgView& im, int x, int y, int z) { return ((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x; }
@@ -473,62 +478,113 @@ __global__ __launch_bounds__(256) void volumeLightingReprojectionKernel(ImgView 
 // grid: for uv >= 0.25 both are exact by Sterbenz, below it the product by two is exact), and both passes use the same jitter. The reprojection
 // pass evaluates the position without jitter: its chain stays its own.
 // The arithmetic is the exact set's: sub-texel weights of the noise / history samples and the shadow-map texel are discrete in the position.
+// sampleLinear3D<F_R8, REPEAT>(noise, uvw).x (device/image.h) with the wrap of a power-of-two extent as a mask: the signed modulo of repeati is a software
+// sequence of some 38 instructions, six of them per sample - a quarter of the column walk's slice step. Same texels, same values, same weights, same term order.
+PLR_DI float sampleNoiseRepeat(const ImgView& im, vec3 uvw) {
+    int i0, j0, k0; float a, b, c;
+    linearCoord(uvw.x * (float)im.w, &i0, &a);
+    linearCoord(uvw.y * (float)im.h, &j0, &b);
+    linearCoord(uvw.z * (float)im.d, &k0, &c);
+    int x0, x1, y0, y1, z0, z1;
+    if ((((im.w & (im.w - 1)) | (im.h & (im.h - 1)) | (im.d & (im.d - 1))) == 0)) { // wave-uniform (two's complement: the mask is the non-negative remainder)
+        x0 = i0 & (im.w - 1); x1 = (i0 + 1) & (im.w - 1); y0 = j0 & (im.h - 1); y1 = (j0 + 1) & (im.h - 1); z0 = k0 & (im.d - 1); z1 = (k0 + 1) & (im.d - 1);
+    } else {
+        x0 = repeati(i0, im.w); x1 = repeati(i0 + 1, im.w); y0 = repeati(j0, im.h); y1 = repeati(j0 + 1, im.h); z0 = repeati(k0, im.d); z1 = repeati(k0 + 1, im.d);
+    }
+    // (decodeUnorm8Newton: c / 255 correctly rounded for all 256 codes in three instructions instead of the IEEE division's ten, tests/test_gpu_foundations.py)
+    auto T = [&](int x, int y, int z) { return decodeUnorm8Newton(((const uint8_t*)im.ptr)[((size_t)z * (size_t)im.h + (size_t)y) * (size_t)im.w + (size_t)x]); };
+    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
+    float r = 0.f;
+    r = r + T(x0, y0, z0) * ((a0 * b0) * c0);
+    r = r + T(x1, y0, z0) * ((a * b0) * c0);
+    r = r + T(x0, y1, z0) * ((a0 * b) * c0);
+    r = r + T(x1, y1, z0) * ((a * b) * c0);
+    r = r + T(x0, y0, z1) * ((a0 * b0) * c);
+    r = r + T(x1, y0, z1) * ((a * b0) * c);
+    r = r + T(x0, y1, z1) * ((a0 * b) * c);
+    r = r + T(x1, y1, z1) * ((a * b) * c);
+    return r;
+}
 PLR_DI float roundToHalf(float v) { return halfBitsToFloat(floatToHalfBits(v)); } // what a texel of an RGBA16F volume gives back
+// Round 4: a thread walks a COLUMN SEGMENT of kFroxelSegment slices at one (x, y). A good third of the three shaders' arithmetic depends on (x, y) or on z alone -
+// per (x, y) the two view rays (two normalisations, ten IEEE divisions) and the phase function (a software pow and a division), per z the slice depths (an
+// exponential and two divisions each) - and is evaluated once per column / once per block and slice (LDS) by the same functions in the same order: the
+// bits stay (tests/test_producers.py, tests/test_fusion.py). A wave still covers 64 consecutive x of one slice per step: loads and stores coalesce as before.
+// Slices per thread, measured at 4K (480 x 270 x 64 froxels): 8 -> 128 us, 16 -> 133, 32 -> 143, 64 (a whole column) -> 177: the column set-up is ~740 instructions against ~600
+// per slice, but the shorter segment keeps twice the waves in flight behind the eight dependent loads of the history sample.
+constexpr int kFroxelSegment = 8;
 template <bool STORE_INTERMEDIATES>
 __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, ImgView noiseTexture, ImgView scattering, ImgView shadowMap, const ShadowCascadeInfo* __restrict__ shadowInfo,
                                                               const LightBuffer* __restrict__ light, ImgView target, ImgView historyVolume, const VolSettings* __restrict__ sp,
                                                               const GlobalUbo* __restrict__ g, int cx, int cy, int cz) {
-    int x, y, z;
-    if (!froxelOfThread(target, cx, cy, cz, &x, &y, &z)) return;
+    __shared__ float sliceDepth[2][kFroxelSegment]; // [0]: with the frame's jitter (material, scattering), [1]: without (reprojection)
     const VolSettings s = *sp;
+    const int z0 = (int)blockIdx.y * kFroxelSegment;
+    if (threadIdx.x < 2u * kFroxelSegment) {
+        const int k = (int)threadIdx.x & (kFroxelSegment - 1), plain = (int)threadIdx.x / kFroxelSegment;
+        sliceDepth[plain][k] = froxelSliceDepth(z0 + k, target, plain ? 0.f : s.sampleOffset, s.maxDistance);
+    }
+    __syncthreads();
+    const uint32_t column = blockIdx.x * 256u + threadIdx.x;
+    if (column >= (uint32_t)cx * (uint32_t)cy) return;
+    const int y = (int)(column / (uint32_t)cx), x = (int)(column - (uint32_t)y * (uint32_t)cx);
     const float kPi = PLR_GLSL_PI;
-    const size_t texel = idx3(target, x, y, z); // the launcher checked: all three volumes have the target's size
-    // froxelVolumeMaterial.comp
+    const vec3 camPos = ld3(g->cameraPosition);
     vec3 V;
-    const vec3 posWorld = froxelWorldPosition(x, y, z, target, s.sampleOffset, g, s.maxDistance, &V, true);
-    vec4 sa;
-    {
-        const vec3 noiseSample = posWorld * 0.5f + ld3(s.windSampleOffset);
-        const float noise = sampleLinear3D<F_R8, REPEAT>(noiseTexture, noiseSample).x;
-        float densityMultiplier = s.baseDensity;
-        densityMultiplier += s.densityNoiseRange * (noise - 0.5f);
-        densityMultiplier = gmax(densityMultiplier, 0.f);
-        const vec4 m(ld3(s.scatteringCoefficients) * densityMultiplier, s.absorptionCoefficient * densityMultiplier);
-        if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(material.ptr, texel, m);
-        sa = vec4(roundToHalf(m.x), roundToHalf(m.y), roundToHalf(m.z), roundToHalf(m.w));
+    const vec3 rayJittered = froxelRayPerDepth(x, y, target, s.sampleOffset, g, &V, true);
+    const vec3 rayPlain = froxelRayPerDepth(x, y, target, 0.f, g, nullptr, false);
+    const float VoL = dot(-V, ld3(g->sunDirection));
+    const float gg = s.phaseFunctionG;
+    const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
+    const int zn = min(kFroxelSegment, cz - z0);
+    for (int k = 0; k < zn; k++) {
+        const int z = z0 + k;
+        const size_t texel = idx3(target, x, y, z); // the launcher checked: all three volumes have the target's size
+        // froxelVolumeMaterial.comp
+        const vec3 posWorld = camPos - rayJittered * sliceDepth[0][k];
+        vec4 sa;
+        {
+            const vec3 noiseSample = posWorld * 0.5f + ld3(s.windSampleOffset);
+            const float noise = sampleNoiseRepeat(noiseTexture, noiseSample);
+            float densityMultiplier = s.baseDensity;
+            densityMultiplier += s.densityNoiseRange * (noise - 0.5f);
+            densityMultiplier = gmax(densityMultiplier, 0.f);
+            const vec4 m(ld3(s.scatteringCoefficients) * densityMultiplier, s.absorptionCoefficient * densityMultiplier);
+            if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(material.ptr, texel, m);
+            sa = vec4(roundToHalf(m.x), roundToHalf(m.y), roundToHalf(m.z), roundToHalf(m.w));
+        }
+        // froxelLightScattering.comp
+        vec4 current;
+        {
+            vec4 p = mulMat4(shadowInfo->lightMatrices[2], vec4(posWorld, 1.f));
+            if (p.w != 1.f) p = p / p.w; // (a quotient by one is its numerator: under the orthographic cascade matrix four IEEE divisions are not run)
+            const float actualDepth = gclamp(p.z, 0.f, 1.f);
+            const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_BLACK>(shadowMap, vec2(p.x, p.y) * 0.5f + 0.5f).x;
+            const float sunStrength = (actualDepth > shadowMapDepth ? 1.f : 0.f) * light->sunStrengthExposed;
+            const vec3 scatteringCoefficient = sa.xyz();
+            const vec3 inscattering = (sunStrength * phase * ld3(light->sunColor) + vec3(0.02f)) * scatteringCoefficient;
+            const float transmittance = computeLuminance(scatteringCoefficient + sa.w);
+            const vec4 r(inscattering, transmittance);
+            if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(scattering.ptr, texel, r);
+            current = vec4(roundToHalf(r.x), roundToHalf(r.y), roundToHalf(r.z), roundToHalf(r.w));
+        }
+        // volumeLightingReprojection.comp
+        const vec3 posUnjittered = camPos - rayPlain * sliceDepth[1][k];
+        vec4 ndcPrevious = mulMat4(g->viewProjectionPrevious, vec4(posUnjittered, 1.f));
+        ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
+        const vec3 camPrev = ld3(g->cameraPositionPrevious);
+        // normalize(camPrev - pos) and distance(pos, camPrev) take the root of the same sum of squares (the second difference is the first one's negative)
+        const vec3 toCamPrev = camPrev - posUnjittered;
+        const float historyDistance = sqrtf(dot(toCamPrev, toCamPrev));
+        const vec3 V_history = toCamPrev * (1.0f / historyDistance);
+        const float historyDepth = historyDistance * dot(-V_history, ld3(g->cameraForwardPrevious));
+        const vec3 historyUV(ndcPrevious.x * 0.5f + 0.5f, ndcPrevious.y * 0.5f + 0.5f, depthToFroxelUVZ(historyDepth, s.maxDistance));
+        vec4 history = sampleLinear3D<F_RGBA16F, CLAMP>(historyVolume, historyUV);
+        float alpha = 0.95f;
+        if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
+        if (g->cameraCut) history = current;
+        Texel<F_RGBA16F>::store(target.ptr, texel, current * (1.f - alpha) + history * alpha);
     }
-    // froxelLightScattering.comp
-    vec4 current;
-    {
-        vec4 p = mulMat4(shadowInfo->lightMatrices[2], vec4(posWorld, 1.f));
-        p = p / p.w;
-        const float actualDepth = gclamp(p.z, 0.f, 1.f);
-        const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_BLACK>(shadowMap, vec2(p.x, p.y) * 0.5f + 0.5f).x;
-        const float sunStrength = (actualDepth > shadowMapDepth ? 1.f : 0.f) * light->sunStrengthExposed;
-        const float VoL = dot(-V, ld3(g->sunDirection));
-        const float gg = s.phaseFunctionG;
-        const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
-        const vec3 scatteringCoefficient = sa.xyz();
-        const vec3 inscattering = (sunStrength * phase * ld3(light->sunColor) + vec3(0.02f)) * scatteringCoefficient;
-        const float transmittance = computeLuminance(scatteringCoefficient + sa.w);
-        const vec4 r(inscattering, transmittance);
-        if (STORE_INTERMEDIATES) Texel<F_RGBA16F>::store(scattering.ptr, texel, r);
-        current = vec4(roundToHalf(r.x), roundToHalf(r.y), roundToHalf(r.z), roundToHalf(r.w));
-    }
-    // volumeLightingReprojection.comp
-    const vec3 posUnjittered = froxelWorldPosition(x, y, z, target, 0.f, g, s.maxDistance, nullptr, false);
-    vec4 ndcPrevious = mulMat4(g->viewProjectionPrevious, vec4(posUnjittered, 1.f));
-    ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
-    const vec3 camPrev = ld3(g->cameraPositionPrevious);
-    const vec3 V_history = normalize(camPrev - posUnjittered);
-    const float historyDistance = distance(posUnjittered, camPrev);
-    const float historyDepth = historyDistance * dot(-V_history, ld3(g->cameraForwardPrevious));
-    const vec3 historyUV(ndcPrevious.x * 0.5f + 0.5f, ndcPrevious.y * 0.5f + 0.5f, depthToFroxelUVZ(historyDepth, s.maxDistance));
-    vec4 history = sampleLinear3D<F_RGBA16F, CLAMP>(historyVolume, historyUV);
-    float alpha = 0.95f;
-    if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
-    if (g->cameraCut) history = current;
-    Texel<F_RGBA16F>::store(target.ptr, texel, current * (1.f - alpha) + history * alpha);
 }
 
 PLR_DI vec3 integrateInscattering(vec3 inscattering, vec3 ext, float length) {
@@ -643,8 +699,8 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (tooManyFroxels(cx, cy, cz)) return kUseGeneralKernel;
     const bool elide = (m.elidableStorage & 1u) && (sc.elidableStorage & 1u);
     auto kernel = elide ? froxelFrontFusedKernel<false> : froxelFrontFusedKernel<true>;
-    kernel<<<blocksFor(cx, cy, cz), 256, 0, m.stream>>>(mat, m.sampled[1], scat, sc.sampled[1], (const ShadowCascadeInfo*)sc.sbuf[3].ptr, (const LightBuffer*)sc.sbuf[4].ptr, tgt, hist,
-                                                       (const VolSettings*)m.ubuf[2].ptr, m.global, cx, cy, cz);
+    kernel<<<dim3(blocksFor(cx, cy, 1), divUp((unsigned)cz, (unsigned)kFroxelSegment)), 256, 0, m.stream>>>(mat, m.sampled[1], scat, sc.sampled[1], (const ShadowCascadeInfo*)sc.sbuf[3].ptr,
+                                                                                                            (const LightBuffer*)sc.sbuf[4].ptr, tgt, hist, (const VolSettings*)m.ubuf[2].ptr, m.global, cx, cy, cz);
     PLR_CHECK_LAUNCH(m);
     if (elide) { m.elidedStorage = 1u; sc.elidedStorage = 1u; }
     return 0;

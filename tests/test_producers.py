@@ -213,7 +213,7 @@ def test_gpu_frame_with_compute_sky_luts(backend):
 
 
 # ------------------------------------------------------------------ volumetric froxel lighting
-def _volumetric_inputs(seed=970):
+def _volumetric_inputs(seed=970, fd=16, noise_n=8):
     from util import light_buffer_bytes
     rng = np.random.default_rng(0x504C4149 + seed)
     cam = Camera.look((15.0, -7.0, -6.0), (0.0, 0.16, 1.0), aspect=W / H)
@@ -226,8 +226,8 @@ def _volumetric_inputs(seed=970):
     cam.fill_global(g, W, H)
     scene = synth.SynthScene(grid=2, cell=8.0, seed_id=seed)
     info, maps = scene.shadow_cascades(cam, sun, 2.0, 60.0, 64)
-    fw, fh, fd = (W + 7) // 8, (H + 7) // 8, 16
-    noise = rng.integers(0, 256, size=(8, 8, 8), dtype=np.uint8)
+    fw, fh = (W + 7) // 8, (H + 7) // 8
+    noise = rng.integers(0, 256, size=(noise_n, noise_n, noise_n), dtype=np.uint8)
     from plainrenderer_amd import pixfmt
     hist = pixfmt.pack_half(np.stack([rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0, 0.01, (fd, fh, fw)), rng.uniform(0.001, 0.01, (fd, fh, fw))], -1)
                             .astype(np.float32))
@@ -293,6 +293,28 @@ def test_gpu_fast_volumetrics_exact_front_and_integration_within_half_float_tole
     print("PRODUCER froxel fusion=%d fused_executions=%d integration violations=%d max_err=%.3g scale=%.3g" % (fusion, fused, int(bad.sum()), float(np.abs(got - ref).max()),
                                                                                                           float(np.abs(ref).max())), flush=True)
     assert not bad.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fd,noise_n", [(37, 8), (16, 6), (5, 12)])
+def test_gpu_fast_froxel_columns_ragged_depth_and_any_noise_extent(backend, fd, noise_n):
+    """The fused per-froxel launch walks column segments of 8 slices per thread (kernels/producers.hip, froxelFrontFusedKernel): a depth that is not a multiple of the
+    segment (37 = 4 x 8 + 5; 5 < one segment), and a noise volume whose extent is not a power of two (the wrap falls back from the mask to the
+    modulo) - bit-identical to the oracle like the default shapes."""
+    args = _volumetric_inputs(fd=fd, noise_n=noise_n)
+    level = backend.getPassFusion()[0]
+    backend.setMathMode(True)
+    backend.setPassFusion(1)
+    try:
+        a = passes.gpu_volumetrics(backend, *args)
+        fused = backend.getPassFusion()[1]
+    finally:
+        backend.setMathMode(False)
+        backend.setPassFusion(level)
+    assert fused == 3
+    b = passes.orc_volumetrics(*args)
+    for x, y, what in zip(a[:3], b[:3], ("material", "scattering", "reprojection")):
+        assert np.array_equal(x, y), what
 
 
 @pytest.mark.gpu
