@@ -233,6 +233,13 @@ int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions);
  * other: the side-stream scheduler launches pass by pass. */
 int plr_set_pass_fusion(int enabled);
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions);
+/* Fusion across the caller's pass order (default on; only with pass fusion on). The caller records in the reference's order
+ * (RenderFrontend.cpp:342-405), and with the sky LUT / light matrix passes recorded as compute they sit BETWEEN the members of the fused frame front.
+ * Before launching, the backend moves such an execution in front of or behind the group when the resources recorded with the executions say the result
+ * cannot change: no allocation shared (with a write on either side) with the group members it moves across, nor with an execution it overtakes. Host
+ * callbacks are never crossed. The order of the recorded executions is changed in place; results are byte-identical with the setting off
+ * (tests/test_fusion.py). */
+int plr_set_pass_fusion_reorder(int enabled);
 /* the edge signal of the most recently launched execution with first_rows (valid inside the host callback recorded right behind it): a 32-bit word in
  * signal memory that reaches *out_value (monotonic, compare with >=) once that execution's first rows are complete. *out_signal = NULL: the platform
  * has no stream memory operations - order behind the launch stream instead. */

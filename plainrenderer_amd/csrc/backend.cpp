@@ -31,6 +31,9 @@ struct ShaderEntry { std::string name; LaunchFn fn = nullptr; LaunchFn fast = nu
 static bool shaderReadsBindless(const std::string& shader) {
     return shader == "deferredShading.comp" || shader == "sdfDiffuseTrace.comp" || shader == "sdfDebugVisualisation.comp";
 }
+// storage-image bindings a shader only reads (imageLoad): recorded as reads, so that readers of the same image are not ordered against each other
+// lightMatrix.comp:57-138 loads the apex texel of the depth pyramid through binding 1 and writes the cascade buffer only
+static bool storageBindingIsReadOnly(const std::string& shader, uint32_t binding) { return shader == "lightMatrix.comp" && binding == 1; }
 static std::vector<ShaderEntry>& registry() {
     static std::vector<ShaderEntry> r;
     return r;
@@ -294,6 +297,7 @@ struct Backend {
 
     std::vector<Access> tailPending;
     bool asyncTail = true;               // plr_set_async_tail
+    bool fusionReorder = true;           // plr_set_pass_fusion_reorder
     uint32_t lastAsync = 0;              // executions of the last frame that ran on the tail stream
     void* globalCopies[2] = {nullptr, nullptr}; // rotating device copies of the global uniform buffer: a tail that still reads frame N's must not see frame N + 1's fill
     uint32_t globalCopyIndex = 0;
@@ -720,8 +724,9 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
         bool writesDefaultImage = false;
         for (uint32_t i = 0; i < r.sampled_image_count; i++) x.access.push_back({resolveImage(r.sampled_images[i].image)->dev, false});
         for (uint32_t i = 0; i < r.storage_image_count; i++) {
-            x.access.push_back({resolveImage(r.storage_images[i].image)->dev, true});
-            writesDefaultImage = writesDefaultImage || r.storage_images[i].image.type == PLR_IMAGE_DEFAULT;
+            const bool written = !storageBindingIsReadOnly(g->passes[e->handle]->shader, r.storage_images[i].binding);
+            x.access.push_back({resolveImage(r.storage_images[i].image)->dev, written});
+            writesDefaultImage = writesDefaultImage || (written && r.storage_images[i].image.type == PLR_IMAGE_DEFAULT);
         }
         for (uint32_t i = 0; i < r.storage_buffer_count; i++) x.access.push_back({g->sbufs[r.storage_buffers[i].buffer].dev, r.storage_buffers[i].read_only == 0});
         // uniform buffers are read: a fill of one (plr_set_uniform_buffer_data, applied at the next plr_render_frame) must wait for an asynchronous
@@ -1292,6 +1297,69 @@ static size_t fusionWindow(size_t i, size_t last) {
 }
 
 
+// ---- fusion across the caller's pass order. A fused launch needs its executions back to back, and the caller records in ITS order: with the input
+// producers recorded as compute passes (RenderFrontend.cpp:342-405) the sky LUT passes and the light matrix sit between the members of the frame front
+// (histogram chain, pyramid, culling), which then ran as six launches instead of two. The executions in between are moved out of the way when the
+// recorded resources say that nothing changes: an execution is hoisted in front of the group if it shares no resource (with a write on either side) with
+// the members recorded before it, or sunk behind the group if it shares none with the members recorded after it; executions moved to the same side keep
+// their order, and one that moves in front of an earlier one that moves behind must not share a resource with it either. Host callbacks and rows-first
+// executions end the search.
+// The order is changed in place (a replayed frame keeps it); what is launched is the same set of executions on the same resources.
+static bool executionsConflict(const Execution& a, const Execution& b) {
+    for (const Access& x : a.access)
+        for (const Access& y : b.access) {
+            if (x.key != y.key || !(x.write || y.write)) continue;
+            if (x.key == kBindlessKey && x.write && y.write) continue; // two writers of two images of the global array: their own keys decide
+            return true;
+        }
+    return false;
+}
+static void gatherFusionGroups() {
+    if (!g->fusion || g->mathMode != PLR_MATH_FAST || g->overlap || g->debugSig) return;
+    if (!g->fusionReorder) return;
+    std::vector<Execution>& ex = g->executions;
+    constexpr size_t kMaxMoved = 8;
+    for (size_t i = 0; i < ex.size(); i++) {
+        if (ex[i].callback) continue;
+        for (const FusionEntry& f : fusions()) { // longest first
+            const size_t m = f.shaders.size();
+            if (m < 2 || g->passes[ex[i].pass]->shader != f.shaders[0] || ex[i].firstRows[0] || ex[i].firstRows[1]) continue;
+            std::vector<size_t> members{i}, moved;
+            for (size_t j = i + 1; j < ex.size() && members.size() < m && moved.size() <= kMaxMoved; j++) {
+                const Execution& y = ex[j];
+                // a rows-first execution belongs to the callback recorded behind it (edge signal): it is neither fused nor moved
+                if (y.callback || y.asyncTail != ex[i].asyncTail || y.firstRows[0] || y.firstRows[1]) break;
+                if (g->passes[y.pass]->shader == f.shaders[members.size()]) members.push_back(j);
+                else moved.push_back(j);
+            }
+            if (members.size() != m || moved.size() > kMaxMoved) continue;
+            if (moved.empty()) break; // back to back already (and the longest pattern that starts here)
+            std::vector<size_t> front, back;
+            bool legal = true;
+            for (size_t s : moved) {
+                bool hoist = true, sink = true;
+                for (size_t k : members) {
+                    if (!executionsConflict(ex[s], ex[k])) continue;
+                    if (k < s) hoist = false; else sink = false;
+                }
+                for (size_t b : back) if (executionsConflict(ex[s], ex[b])) hoist = false; // b was recorded before s and stays behind the group
+                if (hoist) front.push_back(s);
+                else if (sink) back.push_back(s);
+                else { legal = false; break; }
+            }
+            if (!legal) continue;
+            std::vector<Execution> order;
+            order.reserve(members.size() + moved.size());
+            for (size_t s : front) order.push_back(std::move(ex[s]));
+            for (size_t k : members) order.push_back(std::move(ex[k]));
+            for (size_t s : back) order.push_back(std::move(ex[s]));
+            for (size_t k = 0; k < order.size(); k++) ex[i + k] = std::move(order[k]);
+            i += front.size() + members.size() - 1; // the executions behind the group are looked at next
+            break;
+        }
+    }
+}
+
 // PassCtx::consumer of every execution (backend.h PLR_REGISTER_CONSUMER_LINK)
 static void linkConsumers(const GlobalUbo* globalPtr) {
     const size_t n = g->executions.size();
@@ -1343,6 +1411,7 @@ static int launchAll(bool timed) {
     g->lastAsync = 0;
     bool tailOpen = false, tailDirty = false; // tailOpen: the tail stream is ordered behind the main stream's work so far; tailDirty: tailDone is stale
     auto closeTail = [&]() -> int { if (tailDirty) { HIP_TRY(hipEventRecord(g->tailDone, g->tailStream)); tailDirty = false; } return PLR_OK; };
+    gatherFusionGroups();
     linkConsumers(globalPtr);
     std::vector<PlanNode> plan(n);
     std::vector<hipEvent_t> done(n, nullptr);
@@ -1500,6 +1569,11 @@ int plr_render_frame(int /*present_to_screen*/) {
 int plr_set_pass_fusion(int enabled) {
     NEED_INIT();
     g->fusion = std::min(std::max(enabled, 0), 2);
+    return PLR_OK;
+}
+int plr_set_pass_fusion_reorder(int enabled) {
+    NEED_INIT();
+    g->fusionReorder = enabled != 0;
     return PLR_OK;
 }
 int plr_get_pass_fusion(int* out_enabled, uint32_t* out_fused_executions) {

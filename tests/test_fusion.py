@@ -67,6 +67,57 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1280, 720), (648, 360)])
+def test_gpu_fusion_across_the_callers_pass_order_changes_no_byte(backend, w, h):
+    """With the input producers recorded as compute passes (RenderFrontend.cpp:342-405 order) the transmission / multiscatter / sky LUT passes and the
+    light matrix sit between the members of the fused frame front. plr_set_pass_fusion_reorder (default on) moves them in front of / behind the group where
+    the recorded resources allow it: more executions run inside fused launches, and every image and buffer of every frame equals the run with the
+    reordering off - and the run without any fusion."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    n_frames = 3
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=511)
+    inputs = None
+    results, fused_counts = {}, {}
+    names = ["swapchain", "post1", "pyramid", "depthHalfRes", "skyLut", "skyMultiscatterLut", "transmissionLut", "volumetricIntegrationVolume", "taaHistory0", "taaHistory1",
+             "giHistoryYSH0", "giHistoryCoCg0"]
+    try:
+        backend.setMathMode(True)
+        for mode, (fusion, reorder) in {"reordered": (2, True), "recorded order": (2, False), "unfused": (0, False)}.items():
+            backend.setPassFusion(fusion)
+            backend.setPassFusionReorder(reorder)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64, run_sky_luts=1, run_light_matrix=1, run_volumetrics=1)
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                fused_counts[mode] = backend.getPassFusion()[1]
+                if mode == "reordered":
+                    general, which = backend.getGeneralKernelExecutions()
+                    assert general == 0, which
+                out.append([backend.downloadImage(fp.image(name), 0, np.uint8).copy() for name in names] +
+                           [backend.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint8).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("sunShadowInfo"), 304, dtype=np.uint8).copy()])
+            results[mode] = out
+            fp.destroy()
+    finally:
+        backend.setPassFusion(2)
+        backend.setPassFusionReorder(True)
+        backend.setMathMode(False)
+    print("FUSION reorder: executions inside fused launches %s" % fused_counts, flush=True)
+    assert fused_counts["unfused"] == 0
+    assert fused_counts["reordered"] >= fused_counts["recorded order"] + 4, fused_counts  # the frame front as one group (8 executions) instead of two pairs of it
+    what = names + ["light buffer", "histogram", "sun shadow info"]
+    for mode in ("reordered", "recorded order"):
+        for f in range(n_frames):
+            for a, b, name in zip(results[mode][f], results["unfused"][f], what):
+                assert np.array_equal(a, b), "%s differs (%s), frame %d (%dx%d)" % (name, mode, f, w, h)
+
+
+@pytest.mark.gpu
 def test_gpu_fusion_is_off_in_exact_mode_and_when_a_callback_separates_the_passes(backend):
     """PLR_MATH_EXACT runs every pass on its own (the bit-exact kernel set has no fused launchers)"""
     from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
