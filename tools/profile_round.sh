@@ -34,10 +34,11 @@ python $REPO/bench.py --width 7680 --height 4320 --steps 150 --no-cpu-baseline >
 python $REPO/bench.py --producers --steps 100 --warmup 10 --no-cpu-baseline --pass-table 2> $OUT/pass_table_producers.txt > $OUT/bench_producers.json
 python $REPO/bench.py --producers --exact --steps 30 --warmup 5 --no-cpu-baseline --pass-table 2> $OUT/pass_table_producers_exact.txt > /dev/null
 # 2x2 tiles against row bands at 8K on four GPUs, by proxy (the pipeline partitions by rows only): a stand-alone frame of the size of one
-# partition plus a 256-pixel GI halo on every side that has a neighbour - interior row band 7680 x (1080 + 512), corner tile (3840 + 256) x (2160 + 256)
+# partition plus a 256-pixel GI halo on every side that has a neighbour - interior row band 7680 x (1080 + 512) -> 1600 rows (the fast pyramid of a frame
+# beyond 11 levels wants a height that is a multiple of 16; 1592 runs the general pyramid kernel and bench.py refuses the line), corner tile (3840 + 256) x (2160 + 256)
 { echo "# stand-alone frames of the partition's size + halo (proxy, see DESIGN section 6): ms per frame";
-  for WH in "7680 1592" "4096 2416" "7680 1080" "3840 2160"; do set -- $WH;
-    python $REPO/bench.py --width $1 --height $2 --steps 150 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 x $2', d['ms_per_step'])"; done; } > $OUT/tile_vs_band_proxy.txt
+  for WH in "7680 1600" "4096 2416" "7680 1088" "3840 2160"; do set -- $WH;
+    python $REPO/bench.py --width $1 --height $2 --steps 150 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; t=sys.stdin.read(); print('$1 x $2', json.loads(t)['ms_per_step'] if t.strip() else 'no bench line (see bench.py: general-kernel fallback or error)')"; done; } > $OUT/tile_vs_band_proxy.txt
 rm -rf $OUT/kt
 # ---- parity evidence FROM THIS BUILD: the full-size suite at the benchmarked size, config 5 at 8K, the band cost table; every
 # report carries the kernel source digest the PMC summary was stamped with, and the run fails if the sources changed in between
