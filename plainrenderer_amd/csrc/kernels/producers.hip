@@ -513,21 +513,46 @@ PLR_DI float roundToHalf(float v) { return halfBitsToFloat(floatToHalfBits(v)); 
 // Slices per thread, measured at 4K (480 x 270 x 64 froxels): 8 -> 128 us, 16 -> 133, 32 -> 143, 64 (a whole column) -> 177: the column set-up is ~740 instructions against ~600
 // per slice, but the shorter segment keeps twice the waves in flight behind the eight dependent loads of the history sample.
 constexpr int kFroxelSegment = 8;
-template <bool STORE_INTERMEDIATES>
+constexpr int kFroxelMaxSegments = 32; // INTEGRATE: a column's segments share a block
+// INTEGRATE: volumetricLightingIntegration.comp:15-45 in the same launch (the fourth pass of Volumetrics::computeVolumetricLighting). The front-to-back sums of a
+// column are a scan over exactly the texels this launch produces, so the block holds ALL segments of its columns (thread = (column, segment), columnsPerBlock x
+// segments <= 256): a thread accumulates its segment's totals while it walks it, the block exchanges them through LDS, and a second walk over the thread's own
+// eight texels - read back from the target volume it has just written - adds the segments in front of it. Arithmetic of the integration: the fast set's
+// (kernels_fast/froxel_fast.hip: one hardware exponential per slice, no decision in this pass; within the half-float bound of tests/parity.py), the three per-froxel
+// passes keep the exact set's. What it saves: a launch whose 2 k waves walked 64 dependent slices each (27 us for 130 MB), and the read of the volume from HBM.
+PLR_DI float froxelFastExp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504089f); }
+struct FroxelSliceTerm { float r, g, b, e; }; // a slice's added inscattering and its transmittance factor
+PLR_DI FroxelSliceTerm froxelSliceTerm(vec4 texel, float segmentLength) { // texel: (inscattering, extinction) as the volume stores it; the slice's extent in depth
+    const float e = froxelFastExp(-texel.w * segmentLength);
+    const float kk = (1.f - e) * __builtin_amdgcn_rcpf(__builtin_fmaxf(texel.w, 0.00001f)); // integrateInscattering: (s - s e) / max(ext, 1e-5)
+    return {texel.x * kk, texel.y * kk, texel.z * kk, e};
+}
+template <bool STORE_INTERMEDIATES, bool INTEGRATE>
 __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, ImgView noiseTexture, ImgView scattering, ImgView shadowMap, const ShadowCascadeInfo* __restrict__ shadowInfo,
                                                               const LightBuffer* __restrict__ light, ImgView target, ImgView historyVolume, const VolSettings* __restrict__ sp,
-                                                              const GlobalUbo* __restrict__ g, int cx, int cy, int cz) {
-    __shared__ float sliceDepth[2][kFroxelSegment]; // [0]: with the frame's jitter (material, scattering), [1]: without (reprojection)
+                                                              const GlobalUbo* __restrict__ g, int cx, int cy, int cz, ImgView integrationVolume, int columnsPerBlock, int segments) {
+    // [0]: with the frame's jitter (material, scattering), [1]: without (reprojection); the block's own segment, or (INTEGRATE) every slice of the volume
+    __shared__ float sliceDepth[2][INTEGRATE ? kFroxelMaxSegments * kFroxelSegment : kFroxelSegment];
+    __shared__ float segmentTotals[INTEGRATE ? 4 : 1][INTEGRATE ? 256 : 1];
+    __shared__ float sliceLength[INTEGRATE ? kFroxelMaxSegments * kFroxelSegment : 1]; // froxelUVToDepth((z + 1) / d) - froxelUVToDepth(z / d), the integration's (hardware exponentials)
     const VolSettings s = *sp;
-    const int z0 = (int)blockIdx.y * kFroxelSegment;
-    if (threadIdx.x < 2u * kFroxelSegment) {
-        const int k = (int)threadIdx.x & (kFroxelSegment - 1), plain = (int)threadIdx.x / kFroxelSegment;
-        sliceDepth[plain][k] = froxelSliceDepth(z0 + k, target, plain ? 0.f : s.sampleOffset, s.maxDistance);
+    const int segment = INTEGRATE ? (int)(threadIdx.x / (uint32_t)columnsPerBlock) : (int)blockIdx.y;
+    const int columnInBlock = INTEGRATE ? (int)threadIdx.x - segment * columnsPerBlock : (int)threadIdx.x;
+    const int z0 = segment * kFroxelSegment, depthBase = INTEGRATE ? 0 : z0;
+    for (int e = (int)threadIdx.x; e < 2 * (INTEGRATE ? cz : kFroxelSegment); e += 256) {
+        const int n = INTEGRATE ? cz : kFroxelSegment, plain = e >= n ? 1 : 0, k = e - plain * n;
+        sliceDepth[plain][k] = froxelSliceDepth(depthBase + k, target, plain ? 0.f : s.sampleOffset, s.maxDistance);
+    }
+    if (INTEGRATE) {
+        const float invZ = __builtin_amdgcn_rcpf((float)target.d), depthScale = s.maxDistance * (1.f / 19.0855369f); // froxelUVToDepth(uv) = (e^(3 uv) - 1) / (e^3 - 1) * maxDistance
+        for (int z = (int)threadIdx.x; z < cz; z += 256)
+            sliceLength[z] = (froxelFastExp(3.f * ((float)(z + 1) * invZ)) - 1.f) * depthScale - (froxelFastExp(3.f * ((float)z * invZ)) - 1.f) * depthScale;
     }
     __syncthreads();
-    const uint32_t column = blockIdx.x * 256u + threadIdx.x;
-    if (column >= (uint32_t)cx * (uint32_t)cy) return;
-    const int y = (int)(column / (uint32_t)cx), x = (int)(column - (uint32_t)y * (uint32_t)cx);
+    const uint32_t column = blockIdx.x * (uint32_t)(INTEGRATE ? columnsPerBlock : 256) + (uint32_t)columnInBlock;
+    const bool valid = column < (uint32_t)cx * (uint32_t)cy && (!INTEGRATE || segment < segments);
+    if (!INTEGRATE && !valid) return;
+    const int y = valid ? (int)(column / (uint32_t)cx) : 0, x = valid ? (int)(column - (uint32_t)y * (uint32_t)cx) : 0;
     const float kPi = PLR_GLSL_PI;
     const vec3 camPos = ld3(g->cameraPosition);
     vec3 V;
@@ -536,12 +561,13 @@ __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, 
     const float VoL = dot(-V, ld3(g->sunDirection));
     const float gg = s.phaseFunctionG;
     const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
-    const int zn = min(kFroxelSegment, cz - z0);
+    const int zn = valid ? min(kFroxelSegment, cz - z0) : 0;
+    float segR = 0.f, segG = 0.f, segB = 0.f, segT = 1.f;
     for (int k = 0; k < zn; k++) {
         const int z = z0 + k;
         const size_t texel = idx3(target, x, y, z); // the launcher checked: all three volumes have the target's size
         // froxelVolumeMaterial.comp
-        const vec3 posWorld = camPos - rayJittered * sliceDepth[0][k];
+        const vec3 posWorld = camPos - rayJittered * sliceDepth[0][z - depthBase];
         vec4 sa;
         {
             const vec3 noiseSample = posWorld * 0.5f + ld3(s.windSampleOffset);
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, 
             current = vec4(roundToHalf(r.x), roundToHalf(r.y), roundToHalf(r.z), roundToHalf(r.w));
         }
         // volumeLightingReprojection.comp
-        const vec3 posUnjittered = camPos - rayPlain * sliceDepth[1][k];
+        const vec3 posUnjittered = camPos - rayPlain * sliceDepth[1][z - depthBase];
         vec4 ndcPrevious = mulMat4(g->viewProjectionPrevious, vec4(posUnjittered, 1.f));
         ndcPrevious = vec4(ndcPrevious.x / ndcPrevious.w, ndcPrevious.y / ndcPrevious.w, ndcPrevious.z / ndcPrevious.w, ndcPrevious.w);
         const vec3 camPrev = ld3(g->cameraPositionPrevious);
@@ -583,7 +609,34 @@ __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, 
         float alpha = 0.95f;
         if (historyUV.x > 1.f || historyUV.y > 1.f || historyUV.z > 1.f || historyUV.x < 0.f || historyUV.y < 0.f || historyUV.z < 0.f) alpha = 0.f;
         if (g->cameraCut) history = current;
-        Texel<F_RGBA16F>::store(target.ptr, texel, current * (1.f - alpha) + history * alpha);
+        const vec4 result = current * (1.f - alpha) + history * alpha;
+        Texel<F_RGBA16F>::store(target.ptr, texel, result);
+        if (INTEGRATE) {
+            const FroxelSliceTerm t = froxelSliceTerm(vec4(roundToHalf(result.x), roundToHalf(result.y), roundToHalf(result.z), roundToHalf(result.w)), sliceLength[z]);
+            segR += t.r; segG += t.g; segB += t.b; segT *= t.e;
+        }
+    }
+    if (INTEGRATE) {
+        segmentTotals[0][threadIdx.x] = segR; segmentTotals[1][threadIdx.x] = segG; segmentTotals[2][threadIdx.x] = segB; segmentTotals[3][threadIdx.x] = segT;
+        __syncthreads();
+        float totalR = 0.f, totalG = 0.f, totalB = 0.f, transmittance = 1.f;
+        for (int before = 0; before < segment && valid; before++) { // the segments in front of this one, front to back
+            const int t = before * columnsPerBlock + columnInBlock;
+            totalR += segmentTotals[0][t]; totalG += segmentTotals[1][t]; totalB += segmentTotals[2][t]; transmittance *= segmentTotals[3][t];
+        }
+        uint2 mine[kFroxelSegment];
+#pragma unroll
+        for (int k = 0; k < kFroxelSegment; k++) // the thread's own stores, read back (same thread, same addresses: program order)
+            mine[k] = k < zn ? ((const uint2*)target.ptr)[idx3(target, x, y, z0 + k)] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < kFroxelSegment; k++) {
+            if (k >= zn) continue;
+            const vec4 texel(halfBitsToFloat(mine[k].x & 0xffffu), halfBitsToFloat(mine[k].x >> 16), halfBitsToFloat(mine[k].y & 0xffffu), halfBitsToFloat(mine[k].y >> 16));
+            const FroxelSliceTerm t = froxelSliceTerm(texel, sliceLength[z0 + k]);
+            totalR += t.r; totalG += t.g; totalB += t.b; transmittance *= t.e;
+            ((uint2*)integrationVolume.ptr)[idx3(integrationVolume, x, y, z0 + k)] =
+                make_uint2(floatToHalfBits(totalR) | (floatToHalfBits(totalG) << 16), floatToHalfBits(totalB) | (floatToHalfBits(transmittance) << 16));
+        }
     }
 }
 
@@ -678,7 +731,7 @@ static int launchIntegration(const PassCtx& c) {
 // material -> scattering -> reprojection as recorded by Volumetrics::computeVolumetricLighting: one launch when the three executions bind one
 // chain of equally sized volumes over the same dispatch (anything else: kUseGeneralKernel, the three launches)
 static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
-    if (count != 3) return kUseGeneralKernel;
+    if (count != 3 && count != 4) return kUseGeneralKernel;
     const PassCtx &m = *ctxs[0], &sc = *ctxs[1], &r = *ctxs[2];
     if (!m.global || !m.hasStorage(0) || m.storage[0].fmt != F_RGBA16F || !m.hasSampled(1) || m.sampled[1].fmt != F_R8 || !m.hasUbuf(2) || m.ubuf[2].size < sizeof(VolSettings)) return kUseGeneralKernel;
     if (!sc.hasStorage(0) || sc.storage[0].fmt != F_RGBA16F || !sc.hasSampled(1) || sc.sampled[1].fmt != F_D16 || !sc.hasSampled(2) || !sc.hasSbuf(3) ||
@@ -698,9 +751,24 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (cx <= 0 || cy <= 0 || cz <= 0) return 0;
     if (tooManyFroxels(cx, cy, cz)) return kUseGeneralKernel;
     const bool elide = (m.elidableStorage & 1u) && (sc.elidableStorage & 1u);
-    auto kernel = elide ? froxelFrontFusedKernel<false> : froxelFrontFusedKernel<true>;
-    kernel<<<dim3(blocksFor(cx, cy, 1), divUp((unsigned)cz, (unsigned)kFroxelSegment)), 256, 0, m.stream>>>(mat, m.sampled[1], scat, sc.sampled[1], (const ShadowCascadeInfo*)sc.sbuf[3].ptr,
-                                                                                                            (const LightBuffer*)sc.sbuf[4].ptr, tgt, hist, (const VolSettings*)m.ubuf[2].ptr, m.global, cx, cy, cz);
+    ImgView integration{};
+    int columnsPerBlock = 256, segments = (int)divUp((unsigned)cz, (unsigned)kFroxelSegment);
+    if (count == 4) {
+        // + volumetricLightingIntegration.comp over the same columns, all slices: the scan over the column happens inside the block
+        const PassCtx& in = *ctxs[3];
+        if (!in.hasStorage(0) || in.storage[0].fmt != F_RGBA16F || !in.hasSampled(1) || !in.hasUbuf(2)) return kUseGeneralKernel;
+        integration = in.storage[0];
+        if (in.sampled[1].ptr != tgt.ptr || !sameSize(in.sampled[1], tgt) || !sameSize(integration, tgt) || in.ubuf[2].ptr != m.ubuf[2].ptr || integration.ptr == tgt.ptr ||
+            integration.ptr == hist.ptr || integration.ptr == mat.ptr || integration.ptr == scat.ptr)
+            return kUseGeneralKernel;
+        const int iw = std::min((int)(in.dispatch[0] * 8u), integration.w), ih = std::min((int)(in.dispatch[1] * 8u), integration.h);
+        if (iw != cx || ih != cy || in.dispatch[2] == 0 || in.base[0] || in.base[1] || in.base[2] || cz != tgt.d || segments > kFroxelMaxSegments) return kUseGeneralKernel;
+        columnsPerBlock = 256 / segments;
+    }
+    const dim3 grid = count == 4 ? dim3(divUp((unsigned)(cx * cy), (unsigned)columnsPerBlock)) : dim3(blocksFor(cx, cy, 1), (unsigned)segments);
+    auto kernel = count == 4 ? (elide ? froxelFrontFusedKernel<false, true> : froxelFrontFusedKernel<true, true>) : (elide ? froxelFrontFusedKernel<false, false> : froxelFrontFusedKernel<true, false>);
+    kernel<<<grid, 256, 0, m.stream>>>(mat, m.sampled[1], scat, sc.sampled[1], (const ShadowCascadeInfo*)sc.sbuf[3].ptr, (const LightBuffer*)sc.sbuf[4].ptr, tgt, hist,
+                                       (const VolSettings*)m.ubuf[2].ptr, m.global, cx, cy, cz, integration, columnsPerBlock, segments);
     PLR_CHECK_LAUNCH(m);
     if (elide) { m.elidedStorage = 1u; sc.elidedStorage = 1u; }
     return 0;
@@ -717,6 +785,9 @@ PLR_REGISTER_SHADER("froxelLightScattering.comp", froxel_scattering_launch);
 PLR_REGISTER_SHADER("volumeLightingReprojection.comp", froxel_reprojection_launch);
 PLR_REGISTER_SHADER("volumetricLightingIntegration.comp", froxel_integration_launch);
 static int froxel_fused_front(const PassCtx* const* ctxs, size_t count) { return froxel::launchFusedFront(ctxs, count); }
+static int froxel_fused_front_and_integration(const PassCtx* const* ctxs, size_t count) { return froxel::launchFusedFront(ctxs, count); }
+PLR_REGISTER_FUSION("froxelVolumeMaterial + froxelLightScattering + volumeLightingReprojection + volumetricLightingIntegration", froxel_fused_front_and_integration,
+                    "froxelVolumeMaterial.comp", "froxelLightScattering.comp", "volumeLightingReprojection.comp", "volumetricLightingIntegration.comp");
 PLR_REGISTER_FUSION("froxelVolumeMaterial + froxelLightScattering + volumeLightingReprojection", froxel_fused_front, "froxelVolumeMaterial.comp", "froxelLightScattering.comp",
                     "volumeLightingReprojection.comp");
 
