@@ -27,6 +27,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/xcd.h"
+#include "../device/buffer_fetch.h"
 #include "fused_gi.h"
 #include <cstdlib>
 #include <map>
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // mirroring, the off-screen test and the shrinking lengthModifier - a fifth of the per-sample instructions; those conditions could
     // not have fired, so a pixel's result is the same whichever copy its wave ran.
     float rY0 = 0.f, rY1 = 0.f, rY2 = 0.f, rY3 = 0.f;
+    const BufferDesc packedTexels = texelBuffer(packed, 16u);
     auto sampleLoop = [&](auto safeTag) {
 #pragma clang fp contract(fast)
         constexpr bool SAFE = decltype(safeTag)::value;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             if (PACKED) {
                 uint4 t4[4];
     #pragma unroll
-                for (int k = 0; k < 4; k++) t4[k] = packed[ti[k]];
+                for (int k = 0; k < 4; k++) t4[k] = fetch128(packedTexels, ti[k]); // (device/buffer_fetch.h: no address arithmetic per gather)
     #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const float qden = u2f(t4[k].w); // den / 4; <= 0: texel had a NaN component (skip)

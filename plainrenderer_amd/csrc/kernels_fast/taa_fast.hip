@@ -12,6 +12,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
+#include "../device/buffer_fetch.h"
 
 namespace plr {
 namespace fasttaa {
@@ -39,6 +40,13 @@ PLR_DI vec3 historyTap(const ImgView& im, float u, float v) {
 PLR_DI vec4 motionFetch(const ImgView& im, int x, int y) {
     const bool inside = (uint32_t)x < (uint32_t)im.w && (uint32_t)y < (uint32_t)im.h;
     const uint32_t u = ((const uint32_t*)im.ptr)[fastm::texelIndex((uint32_t)clampi(x, im.w), (uint32_t)clampi(y, im.h), (uint32_t)im.w)] & (inside ? 0xffffffffu : 0u);
+    return vec4(decodeSnorm16((int32_t)(int16_t)(u & 0xffffu)), decodeSnorm16((int32_t)(int16_t)(u >> 16)), 0.f, inside ? 1.f : 0.f);
+}
+
+// the same through a buffer descriptor of the image's texels (device/buffer_fetch.h: no address arithmetic on the VALU)
+PLR_DI vec4 motionFetch(BufferDesc texels, const ImgView& im, int x, int y) {
+    const bool inside = (uint32_t)x < (uint32_t)im.w && (uint32_t)y < (uint32_t)im.h;
+    const uint32_t u = fetch32(texels, fastm::texelIndex((uint32_t)clampi(x, im.w), (uint32_t)clampi(y, im.h), (uint32_t)im.w)) & (inside ? 0xffffffffu : 0u);
     return vec4(decodeSnorm16((int32_t)(int16_t)(u & 0xffffu)), decodeSnorm16((int32_t)(int16_t)(u >> 16)), 0.f, inside ? 1.f : 0.f);
 }
 
@@ -267,10 +275,10 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
     const int xc = clampi(px, current.w);
     const bool xInDepth = px >= 0 && px < depthBuffer.w;
-    const uint32_t* cur = (const uint32_t*)current.ptr;
-    const float* dep = (const float*)depthBuffer.ptr;
+    // the strip's texel fetches go through buffer descriptors (device/buffer_fetch.h): the index is scaled by the addresser, not by a v_lshl_add_u64 per fetch
+    const BufferDesc cur = texelBuffer(current.ptr, 4u), dep = texelBuffer(depthBuffer.ptr, 4u), mot = texelBuffer(motionBuffer.ptr, 4u);
 
-    auto fetchRow = [&](int y) -> uint32_t { return cur[fastm::texelIndex((uint32_t)xc, (uint32_t)clampi(y, current.h), (uint32_t)current.w)]; };
+    auto fetchRow = [&](int y) -> uint32_t { return fetch32(cur, fastm::texelIndex((uint32_t)xc, (uint32_t)clampi(y, current.h), (uint32_t)current.w)); };
     auto decodeRow = [&](uint32_t texel) -> Column {
         const vec3 c = unpackR11G11B10(texel);
         const float l = lum(c);
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     auto loadDepth = [&](int y) -> float { // raw depth, 0 outside the image (texelFetch)
         // the out-of-image case is a bit mask on the loaded word, not a select: a select lets the compiler sink the load into a branch of its own,
         // with an s_waitcnt vmcnt(0) inside - the six depth rows of a strip were six serial round trips
-        const uint32_t bits = ((const uint32_t*)dep)[fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w)];
+        const uint32_t bits = fetch32(dep, fastm::texelIndex((uint32_t)clampi(px, depthBuffer.w), (uint32_t)clampi(y, depthBuffer.h), (uint32_t)depthBuffer.w));
         return u2f(bits & ((xInDepth && y >= 0 && y < depthBuffer.h) ? 0xffffffffu : 0u));
     };
 
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     const float tsx = 1.f / (float)output.w, tsy = 1.f / (float)output.h;
     const float resX = (float)g->screenResolution[0], resY = (float)g->screenResolution[1];
     const bool cameraCut = g->cameraCut != 0u;
-    const uint32_t* hist = (const uint32_t*)historySrc.ptr;
+    const BufferDesc hist = texelBuffer(historySrc.ptr, 4u);
     const int hw = historySrc.w, hh = historySrc.h;
 
     // ---- phase A: where do the strip's pixels reproject to? (motion vector at the closest depth of the 3x3, temporalFilter.comp:93-117)
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
         }
         vec4 m[kStripRows];
 #pragma unroll
-        for (int j = 0; j < kStripRows; j++) m[j] = motionFetch(motionBuffer, px + ox[j], rowFirst + j + oy[j]);
+        for (int j = 0; j < kStripRows; j++) m[j] = motionFetch(mot, motionBuffer, px + ox[j], rowFirst + j + oy[j]);
 #pragma unroll
         for (int j = 0; j < kStripRows; j++) {
             const int py = rowFirst + j;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
             tx[k] = 0u;
             if (k * 64 < stageN) { // wave-uniform
                 const int r = (int)(((float)e + 0.5f) * invW), x = e - r * stageW; // exact for e < 1024, stageW <= 128
-                if (e < stageN) tx[k] = hist[__umul24((uint32_t)clampi(orgJ + r, hh), (uint32_t)hw) + (uint32_t)clampi(orgI + x, hw)]; // clamp-to-edge resolved here
+                if (e < stageN) tx[k] = fetch32(hist, __umul24((uint32_t)clampi(orgJ + r, hh), (uint32_t)hw) + (uint32_t)clampi(orgI + x, hw)); // clamp-to-edge resolved here
             }
         }
 #pragma unroll
@@ -430,16 +438,15 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
         if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                uint4 v;
-                __builtin_memcpy(&v, hist + fastm::texelIndex((uint32_t)(i0 - 1), (uint32_t)clampi(j0 - 1 + r, hh), (uint32_t)hw), 16);
+                const uint4 v = fetch128(hist, fastm::texelIndex((uint32_t)(i0 - 1), (uint32_t)clampi(j0 - 1 + r, hh), (uint32_t)hw)); // four texels of a row (16 bytes from a 4-byte element)
                 t[r][0] = v.x; t[r][1] = v.y; t[r][2] = v.z; t[r][3] = v.w;
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const size_t row = (size_t)clampi(j0 - 1 + r, hh) * (size_t)hw;
+                const uint32_t row = __umul24((uint32_t)clampi(j0 - 1 + r, hh), (uint32_t)hw);
 #pragma unroll
-                for (int c = 0; c < 4; c++) t[r][c] = hist[row + clampi(i0 - 1 + c, hw)];
+                for (int c = 0; c < 4; c++) t[r][c] = fetch32(hist, row + (uint32_t)clampi(i0 - 1 + c, hw));
             }
         }
 #pragma unroll
