@@ -15,11 +15,12 @@ typedef int BufferDesc __attribute__((ext_vector_type(4)));
 typedef int BufferWords2 __attribute__((ext_vector_type(2)));
 typedef int BufferWords4 __attribute__((ext_vector_type(4)));
 
+__device__ short plrStructBufferLoadShort(BufferDesc rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i16");
 __device__ int plrStructBufferLoad1(BufferDesc rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.i32");
 __device__ BufferWords2 plrStructBufferLoad2(BufferDesc rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2i32");
 __device__ BufferWords4 plrStructBufferLoad4(BufferDesc rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4i32");
 
-// elementBytes: 4, 8 or 16 (the stride field has 14 bits)
+// elementBytes: 2, 4, 8 or 16 (the stride field has 14 bits)
 __device__ __forceinline__ BufferDesc texelBuffer(const void* base, uint32_t elementBytes) {
     const uint64_t a = (uint64_t)(uintptr_t)base;
     BufferDesc d;
@@ -29,6 +30,7 @@ __device__ __forceinline__ BufferDesc texelBuffer(const void* base, uint32_t ele
     d.w = 0x00020000;
     return d;
 }
+__device__ __forceinline__ uint32_t fetch16(BufferDesc b, uint32_t index) { return (uint32_t)(uint16_t)plrStructBufferLoadShort(b, (int)index, 0, 0, 0); }
 __device__ __forceinline__ uint32_t fetch32(BufferDesc b, uint32_t index) { return (uint32_t)plrStructBufferLoad1(b, (int)index, 0, 0, 0); }
 __device__ __forceinline__ uint2 fetch64(BufferDesc b, uint32_t index) { const BufferWords2 v = plrStructBufferLoad2(b, (int)index, 0, 0, 0); return make_uint2((uint32_t)v.x, (uint32_t)v.y); }
 __device__ __forceinline__ uint4 fetch128(BufferDesc b, uint32_t index) {

@@ -16,6 +16,7 @@
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/fastmath.h"
+#include "../device/buffer_fetch.h"
 #include "upscale_quad.h"
 #include "pcf_taps.h"
 #include <type_traits>
@@ -164,9 +165,8 @@ PLR_DI vec4 bilinearLut(const ImgView& im, float u, float v) {
     int xb; float a2;
     edgePair(i0, a, im.w, &xb, &a2); // the launcher sends images narrower than two texels to the general kernel
     const int y0 = clampi(j0, im.h), y1 = clampi(j0 + 1, im.h);
-    uint4 q0, q1;
-    __builtin_memcpy(&q0, (const uint2*)im.ptr + __umul24((uint32_t)y0, (uint32_t)im.w) + xb, 16);
-    __builtin_memcpy(&q1, (const uint2*)im.ptr + __umul24((uint32_t)y1, (uint32_t)im.w) + xb, 16);
+    const BufferDesc texels = texelBuffer(im.ptr, 8u); // (device/buffer_fetch.h: the pair's index goes to the addresser as it is)
+    const uint4 q0 = fetch128(texels, __umul24((uint32_t)y0, (uint32_t)im.w) + (uint32_t)xb), q1 = fetch128(texels, __umul24((uint32_t)y1, (uint32_t)im.w) + (uint32_t)xb);
     const float a0 = 1.f - a2, b0 = 1.f - b;
     vec4 r(0.f);
     r = accumulateTexel(r, q0.x, q0.y, a0 * b0);
@@ -356,7 +356,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     // frame index -> texture index -> view -> texel is four dependent round trips in front of the PCF taps when the kernel chases them itself
     const ImgView noiseTex = P.noiseTex;
     const uint32_t noiseIndex = fastm::texelIndex((uint32_t)fastm::repeatIndex(px, noiseTex.w), (uint32_t)fastm::repeatIndex(py, noiseTex.h), (uint32_t)noiseTex.w);
-    const uint32_t noiseWord = ((const uint16_t*)noiseTex.ptr)[noiseIndex];
+    const uint32_t noiseWord = fetch16(texelBuffer(noiseTex.ptr, 2u), noiseIndex);
     const vec2 noiseTexel = fastm::unorm8x2(noiseWord);
     const uint32_t noiseByte = noiseWord & 0xffu;
 
@@ -375,8 +375,13 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
         const uint8_t* base = byPosition ? (const uint8_t*)P.pcfTapsByPosition : (const uint8_t*)P.pcfTaps;
         const uint32_t rowStride = byPosition ? P.pcfPositions * 16u : 16u;
         const uint32_t laneOffset = byPosition ? noiseIndex * 16u : noiseByte * (uint32_t)(kPcfTaps / 2 * 16);
+        // raw buffer loads: the lane's byte offset in a VGPR, the row's in an SGPR - no 64-bit address per row on the VALU (device/buffer_fetch.h)
+        const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < kPcfTaps / 2; k++) __builtin_memcpy(&tapRow.q[k], base + (size_t)((uint32_t)k * rowStride) + laneOffset, 16);
+        for (int k = 0; k < kPcfTaps / 2; k++) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(table, (int)laneOffset, (int)((uint32_t)k * rowStride), 0);
+            __builtin_memcpy(&tapRow.q[k], &q, 16);
+        }
     }
     float sunShadow = 0.f;
     for (bool pending = true; pending;) {
@@ -460,12 +465,9 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
         const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
         const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
         const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
-        const uint2* texels = (const uint2*)vol.ptr + xb;
-        uint4 q00, q10, q01, q11; // [z][y]
-        __builtin_memcpy(&q00, texels + (z0 + y0), 16);
-        __builtin_memcpy(&q01, texels + (z0 + y1), 16);
-        __builtin_memcpy(&q10, texels + (z1 + y0), 16);
-        __builtin_memcpy(&q11, texels + (z1 + y1), 16);
+        const BufferDesc texels = texelBuffer(vol.ptr, 8u);
+        const uint32_t x0 = (uint32_t)xb;
+        const uint4 q00 = fetch128(texels, z0 + y0 + x0), q01 = fetch128(texels, z0 + y1 + x0), q10 = fetch128(texels, z1 + y0 + x0), q11 = fetch128(texels, z1 + y1 + x0); // [z][y]
         // the sampler contract's weights and summation order (image.h sampleLinear3D): eight texels x four channels = 32 v_fma_mix_f32 on the fp16 words
         const float a0 = 1.f - a2, b0 = 1.f - b, c0 = 1.f - c;
         const float wab00 = a0 * b0, wab10 = a2 * b0, wab01 = a0 * b, wab11 = a2 * b;
@@ -553,11 +555,11 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
     if (t < kGiTileW * kGiTileH) {
         const int r = t / kGiTileW, c = t - r * kGiTileW;
         const int hw = U.srcYSH.w, hh = U.srcYSH.h;
-        const size_t i = (size_t)clampi(m0 + r, hh) * (size_t)hw + (size_t)clampi(k0 + c, hw); // clamp-to-edge, as the sampler
-        const uint2 ys = ((const uint2*)U.srcYSH.ptr)[i];
-        const uint32_t cc = ((const uint32_t*)U.srcCoCg.ptr)[i];
+        const uint32_t i = fastm::texelIndex((uint32_t)clampi(k0 + c, hw), (uint32_t)clampi(m0 + r, hh), (uint32_t)hw); // clamp-to-edge, as the sampler
+        const uint2 ys = fetch64(texelBuffer(U.srcYSH.ptr, 8u), i);
+        const uint32_t cc = fetch32(texelBuffer(U.srcCoCg.ptr, 4u), i);
         GiTexel e;
-        e.depthLinear = fastquad::linearDepthRounded(halfBitsToFloat(((const uint16_t*)U.halfResDepth.ptr)[i]), nf, nmf, farP);
+        e.depthLinear = fastquad::linearDepthRounded(halfBitsToFloat(fetch16(texelBuffer(U.halfResDepth.ptr, 2u), i)), nf, nmf, farP);
         e.y0 = halfBitsToFloat(ys.x & 0xffffu); e.y1 = halfBitsToFloat(ys.x >> 16); e.y2 = halfBitsToFloat(ys.y & 0xffffu); e.y3 = halfBitsToFloat(ys.y >> 16);
         e.co = halfBitsToFloat(cc & 0xffffu); e.cg = halfBitsToFloat(cc >> 16); e.pad = 0.f;
         tile[r][c] = e;
@@ -568,15 +570,15 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
     const int cpx = covered ? px : 0, cpy = covered ? py : 0;
     const uint32_t idx = fastm::texelIndex((uint32_t)cpx, (uint32_t)cpy, (uint32_t)P.color.w);
     PixelInputs in;
-    in.depth = ((const float*)P.depth.ptr)[idx];
-    in.albedo = ((const uint32_t*)P.albedo.ptr)[idx];
-    in.specular = ((const uint32_t*)P.specular.ptr)[idx];
+    in.depth = u2f(fetch32(texelBuffer(P.depth.ptr, 4u), idx));
+    in.albedo = fetch32(texelBuffer(P.albedo.ptr, 4u), idx);
+    in.specular = fetch32(texelBuffer(P.specular.ptr, 4u), idx);
     const uint32_t* normals = (const uint32_t*)P.normal.ptr;
-    in.normal = normals[idx]; // the launcher guarantees the normal image has the colour target's size
+    in.normal = fetch32(texelBuffer(P.normal.ptr, 4u), idx); // the launcher guarantees the normal image has the colour target's size
     in.normalH = in.normalV = in.normal;
     if (GEOMETRIC_AA) {
-        in.normalH = normals[fastm::texelIndex((uint32_t)clampi(cpx ^ 1, P.normal.w), (uint32_t)cpy, (uint32_t)P.normal.w)];
-        in.normalV = normals[fastm::texelIndex((uint32_t)cpx, (uint32_t)clampi(cpy ^ 1, P.normal.h), (uint32_t)P.normal.w)];
+        in.normalH = fetch32(texelBuffer(P.normal.ptr, 4u), fastm::texelIndex((uint32_t)clampi(cpx ^ 1, P.normal.w), (uint32_t)cpy, (uint32_t)P.normal.w));
+        in.normalV = fetch32(texelBuffer(P.normal.ptr, 4u), fastm::texelIndex((uint32_t)cpx, (uint32_t)clampi(cpy ^ 1, P.normal.h), (uint32_t)P.normal.w));
     }
     const ViewRay vr = exactViewRay(g, cpx, cpy);
     __syncthreads();
