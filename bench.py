@@ -8,9 +8,11 @@ bloom x11, tonemap) on synthetic inputs that are resident in HBM before the time
   python bench.py --gpus N --steps K --warmup W
 
 N > 1: ONE frame of N x the 4K pixel count (7680 x 1080*N; N = 4 is the 7680x4320 frame of BASELINE config 5), partitioned into N
-row bands, one rank per GPU, halo rows exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
-histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels). The bands' heights are balanced before the timed region
-from measured per-band render times (two calibration rounds, `band_partition` in the JSON line; --no-balance keeps equal heights). When WORLD_SIZE is not set, `--gpus N` spawns the N
+rectangles, one rank per GPU - 2 x N/2 SCREEN TILES (N = 4: config 5's 2 x 2; --partition tiles, the default for even N) or N row bands
+(--partition bands) - halos exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
+histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels), and the JSON line also carries the STRONG-scaling figure the
+target is written in: the time of the same frame unpartitioned on one GPU (measured on rank 0 in the same run) over the N-GPU time. The rectangles'
+sizes are balanced before the timed region from measured render times (two calibration rounds, `band_partition` in the JSON line; --no-balance keeps equal sizes). When WORLD_SIZE is not set, `--gpus N` spawns the N
 ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1); under torchrun WORLD_SIZE must equal --gpus. A band frame that
 cannot run fails the benchmark (non-zero exit) unless --allow-replicas is given.
 """
@@ -235,7 +237,10 @@ def main():
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     ap.add_argument("--python-exchange", action="store_true", help="diagnostic: drive the halo exchange from Python (torch.distributed) instead of the C++ host's RCCL exchange")
     ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
-    ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal row partition instead of balancing the bands' heights from measured band times")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal partition instead of balancing the rectangles' sizes from measured times")
+    ap.add_argument("--partition", choices=["auto", "tiles", "bands"], default="auto", help="N > 1: screen tiles (2 x N/2 grid; N = 4: BASELINE config 5's 2 x 2) or row bands; "
+                    "auto = tiles for even N, bands otherwise")
+    ap.add_argument("--no-strong-scaling", action="store_true", help="N > 1: skip the single-GPU run of the same frame (rank 0) the strong-scaling figure is taken against")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
 
@@ -280,22 +285,34 @@ def main():
     from plainrenderer_amd.frame import FramePipeline
 
     band_partition = {"bounds": None, "calibration": []}
+    use_tiles = world > 1 and world % 2 == 0 and args.partition in ("auto", "tiles")
+    if args.partition == "tiles" and world > 1 and world % 2:
+        raise SystemExit("bench.py: --partition tiles needs an even number of GPUs (2 x N/2 grid)")
+    grid_x, grid_y = (2, world // 2) if use_tiles else (1, world)
 
     def band_frame_size():
         # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
         # Every band is 7680 x ~1080 = one 4K frame's worth of pixels per GPU (weak scaling).
         return (2 * args.width, (args.height // 2) * world) if world > 1 else (args.width, args.height)
 
+    def rect_settings(rect, w_):
+        """FramePipeline settings of one rectangle of the partition"""
+        kw = dict(band_row_begin=rect[1], band_row_end=rect[3])
+        if rect[0] != 0 or rect[2] != w_:
+            kw.update(band_col_begin=rect[0], band_col_end=rect[2])
+        return kw
+
     def calibrate_partition():
-        """Static load balancing: the bands are rendered with an exchange that moves nothing (compute only; with the real exchange every rank would
-        show the slowest rank's time), the per-band times are gathered and the row boundaries re-cut so that every band costs the same
-        (tiling.balanced_bounds). Two rounds; the same partition on every rank."""
+        """Static load balancing: the rectangles are rendered with an exchange that moves nothing (compute only; with the real exchange every rank would
+        show the slowest rank's time), the per-rank times are gathered and the row / column boundaries re-cut so that every rectangle costs the same
+        (tiling.balanced_tile_bounds). Two rounds; the same partition on every rank."""
         w_, h_ = band_frame_size()
-        bounds = tiling.equal_bounds(h_, world)
+        cols, rows = tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)
         for _ in range(2):
-            b0, b1 = bounds[rank], bounds[rank + 1]
+            rects_ = tiling.tile_rects(w_, h_, grid_x, grid_y, cols, rows)
+            b0, b1 = rects_[rank][1], rects_[rank][3]
             be_ = RenderBackend(w_, h_, device=local_rank)
-            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=b0, band_row_end=b1)
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **rect_settings(rects_[rank], w_))
             fp_.set_exchange_callback(lambda exchange_id, stream: None)
             _, cams_, inputs_ = build_scene(args, device, w_, h_, (b0, b1))
             inputs_.upload(fp_)
@@ -316,28 +333,32 @@ def main():
             if world > 1:
                 dist.all_reduce(times, op=dist.ReduceOp.SUM)
             times = [float(v) for v in times.cpu().tolist()]
-            band_partition["calibration"].append({"bounds": list(bounds), "band_ms": [round(t * 1e3, 4) for t in times]})
-            new = tiling.balanced_bounds(h_, bounds, times, min_rows=512)  # every band keeps more rows than the widest halo (224)
-            if new == bounds:
+            band_partition["calibration"].append({"col_bounds": list(cols), "row_bounds": list(rows), "partition_ms": [round(t * 1e3, 4) for t in times]})
+            new = tiling.balanced_tile_bounds(w_, h_, grid_x, grid_y, cols, rows, times, min_size=512)  # every rectangle stays larger than the widest halo (224)
+            if new == (cols, rows):
                 break
-            bounds = new
-        return bounds
+            cols, rows = new
+        return cols, rows
 
     def make(mode):
         """mode 'single': the 4K frame on this GPU; 'bands': one band of the N x larger frame; -> (be, fp, scene-tuple, w, h, band)"""
         w_, h_ = args.width, args.height
         band_ = None
         bounds_ = None
+        rects_ = None
         if mode == "bands":
             w_, h_ = band_frame_size()
-            bounds_ = tiling.equal_bounds(h_, world) if args.no_balance else calibrate_partition()
-            band_ = (bounds_[rank], bounds_[rank + 1])
-            band_partition["bounds"] = bounds_
+            cols_, rows_ = (tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)) if args.no_balance else calibrate_partition()
+            rects_ = tiling.tile_rects(w_, h_, grid_x, grid_y, cols_, rows_)
+            band_ = (rects_[rank][1], rects_[rank][3])
+            band_partition["bounds"] = rows_
+            band_partition.update(kind="tiles %dx%d" % (grid_x, grid_y) if grid_x > 1 else "row bands", col_bounds=cols_, row_bounds=rows_, rects=[list(r) for r in rects_])
+            tile_rect[0] = rects_[rank]
         be_ = RenderBackend(w_, h_, device=local_rank)
         if band_ is not None:
-            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, band_row_begin=band_[0], band_row_end=band_[1])
+            fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **rect_settings(rects_[rank], w_))
             if args.python_exchange:
-                tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank, bounds_)  # diagnostic: torch.distributed transport driven from Python
+                tiling.Exchange(fp_, tiling.DistTransport(rank, world, device=device), h_, world, rank, rects=rects_, width=w_)  # diagnostic: torch.distributed transport driven from Python
             else:
                 # the C++ host's RCCL exchange: rank 0 creates the ncclUniqueId, every rank receives it once (this broadcast is the only use of
                 # torch.distributed on the data path's behalf), then ncclCommInitRank inside libplr
@@ -346,7 +367,7 @@ def main():
                     uid.copy_(torch.frombuffer(bytearray(fp_.rccl_unique_id()), dtype=torch.uint8))
                 if world > 1:
                     dist.broadcast(uid, src=0)
-                fp_.attach_rccl(bytes(uid.cpu().numpy().tobytes()), rank, world, h_, bounds_)
+                fp_.attach_rccl_rects(bytes(uid.cpu().numpy().tobytes()), rank, world, w_, h_, rects_)
         else:
             extra = dict(run_sky_luts=1, run_volumetrics=1, run_light_matrix=1) if args.producers else {}
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **extra)
@@ -354,6 +375,33 @@ def main():
         sc[2].upload(fp_)
         be_.waitForGPUIdle()
         return be_, fp_, sc, w_, h_, band_
+
+    tile_rect = [None]  # this rank's rectangle of the partition (make("bands"))
+
+    # ---- strong scaling (BASELINE's ">= 3.5x at 4 GPUs on 8K" is T(the frame, 1 GPU) / T(the same frame, N GPUs)): rank 0 renders the N x larger
+    # frame UNPARTITIONED first, the other ranks wait. (A frame beyond the shader's 11 pyramid levels gets the per-tile pyramid, as in tests/test_config5_8k.py.)
+    single_gpu_same_frame_ms = None
+    if world > 1 and not args.no_strong_scaling:
+        if rank == 0:
+            w1, h1 = band_frame_size()
+            be1 = RenderBackend(w1, h1, device=local_rank)
+            fp1 = FramePipeline(be1, w1, h1, shadow_map_res=args.shadow_res)
+            _, cams1, inputs1 = build_scene(args, device, w1, h1, None)
+            inputs1.upload(fp1)
+            for i in range(10):
+                fp1.frame(cams1[i + 1], 1.0 / 60.0, 0.5)
+            be1.waitForGPUIdle()
+            n1 = max(20, min(args.steps, 100))
+            t1 = time.perf_counter()
+            for i in range(n1):
+                fp1.frame(cams1[(i % 20) + 1], 1.0 / 60.0, 0.5)
+            be1.waitForGPUIdle()
+            single_gpu_same_frame_ms = (time.perf_counter() - t1) * 1e3 / n1
+            fp1.destroy()
+            be1.shutdown()
+            del inputs1
+            torch.cuda.empty_cache()
+        dist.barrier()
 
     parallelism_note = None
     if world > 1 or args.force_bands:
@@ -440,9 +488,10 @@ def main():
     if general_count and not args.exact:
         raise SystemExit("bench.py: %d execution(s) of the timed frame ran the general (exact-set) kernel instead of a fast-set kernel: %s" % (general_count, general_names))
 
-    # per-GPU pixels: the band's rows (a band renders w x rows of the frame)
+    # per-GPU pixels: the rank's rectangle (a band renders w x rows of the frame, a tile columns x rows)
     bh = h if band is None else band[1] - band[0]
-    bytes_per_pass, frame_bytes = algorithmic_bytes(w, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
+    bw = w if tile_rect[0] is None else tile_rect[0][2] - tile_rect[0][0]
+    bytes_per_pass, frame_bytes = algorithmic_bytes(bw, bh, args.grid ** 2, args.sdf_res, args.shadow_res, 512, 64)
     def pass_bytes(name):
         # a fused launch (pass fusion, include/plr.h) is reported as "A + B": its compulsory traffic is the sum of its passes' - an image one pass
         # writes and the next reads back still has to be written (it is an output of the boundary). Two exceptions: "X + X" is ONE pass over two
@@ -494,6 +543,12 @@ def main():
     if band is not None and not args.python_exchange:
         sent, received, groups = fp.rccl_stats()
         exchange_stats = {"rank0_bytes_sent_per_frame": sent, "rank0_bytes_received_per_frame": received, "point_to_point_groups_per_frame": groups}
+        info = fp.rccl_info()
+        # what the exchange ran on: communicator size and RCCL version, the ordering mode of the overlapped exchanges (2: the producers' edge
+        # signal + hipStreamWaitValue32; 1: an event behind the producer, also the fallback without stream memory operations), packed rectangles or whole rows
+        exchange_stats.update(rccl_ranks=info["rccl_ranks"], rccl_version=info["rccl_version"], band_overlap_exchange=info["overlap_mode"],
+                              regions="rectangles through pack / unpack kernels" if info["packed_regions"] else "whole rows straight from the images",
+                              stream_wait_value_supported=bool(info["stream_wait_value_supported"]), watchdog_ms=info["watchdog_ms"])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, os.cpu_count() or 1, device)
@@ -514,13 +569,18 @@ def main():
                        # backend scheduling switches (include/plr.h): pass fusion level, asynchronous frame tail (bloom chain + tonemap beside the next frame)
                        "input_producers_as_compute": bool(args.producers), "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
                        "general_kernel_executions_in_last_timed_frame": general_count,
-                       "parallelism": ("one %dx%d frame in %d row bands of ~%d rows (one per GPU), halo rows exchanged over RCCL point-to-point (%s) "
-                                       "+ one 512 B histogram all-reduce per frame" % (w, h, world, h // world, "torch.distributed from Python" if args.python_exchange else
-                                                                                        "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else
+                       "parallelism": ("one %dx%d frame in %s (one per GPU), halos exchanged over RCCL point-to-point (%s) "
+                                       "+ one 512 B histogram all-reduce per frame" % (w, h, ("%d x %d screen tiles of ~%dx%d" % (grid_x, grid_y, w // grid_x, h // grid_y)) if grid_x > 1 else
+                                                                                        ("%d row bands of ~%d rows" % (world, h // world)),
+                                                                                        "torch.distributed from Python" if args.python_exchange else "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
             "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "band_partition": band_partition if band is not None else None,
+            # strong scaling against the SAME frame on one GPU (rank 0, same run): the figure BASELINE's ">= 3.5x at 4 GPUs on 8K" is written in. Measured on
+            # one node only when the driver's scaling run has N GPUs; null at N = 1
+            "single_gpu_same_frame_ms": round(single_gpu_same_frame_ms, 4) if single_gpu_same_frame_ms else None,
+            "strong_scaling_vs_1gpu_same_frame": round(single_gpu_same_frame_ms / ms_per_step, 4) if (single_gpu_same_frame_ms and not replicas) else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "exchange": exchange_stats,

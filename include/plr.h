@@ -94,8 +94,8 @@ typedef struct plr_compute_pass_execution {
     uint32_t dispatch_count[3];
     /* extension (no reference counterpart): first workgroup of the dispatch, vkCmdDispatchBase semantics. Zero for the
      * reference's recorder code. A band renderer (one GPU per range of screen rows) sets [1] so a pass covers only its rows;
-     * [0] is honoured by histogramCombineTiles (first tile) and is an error (PLR_ERR_UNSUPPORTED) for every other pass - the kernels cover whole rows;
-     * [2] must be 0. */
+     * [0]: the first workgroup COLUMN (tile rendering, see valid_cols below) for the passes of the per-pixel frame path, the first tile for
+     * histogramCombineTiles, an error (PLR_ERR_UNSUPPORTED) for every other pass; [2] must be 0. */
     uint32_t dispatch_base[3];
     /* extension (band rendering): rows [valid_rows[0], valid_rows[1]) of the pass's INPUT images hold valid data - the band's own rows plus the
      * halo rows received from the neighbouring GPUs; {0, 0} = every row (the reference's recorder code). Honoured by filterIndirectDiffuseSpatial,
@@ -117,6 +117,14 @@ typedef struct plr_compute_pass_execution {
      * trace at 8K). {0, 0} = off. A kernel that cannot order its rows raises the signal when the whole launch has finished, so waiting for the
      * signal is always correct; results do not depend on it. */
     uint32_t first_rows[2];
+    /* extension (tile rendering, round 5: the frame partitioned into screen TILES, BASELINE config 5's 2 x 2): dispatch_base[0] / dispatch_count[0] restrict a pass
+     * to the workgroup columns of its tile the way [1] restricts it to rows - honoured by the passes of the per-pixel frame path (histogramPerTile,
+     * depthHiZPyramid, depthDownscale, sdfCameraTileCulling, sdfDiffuseTrace, the GI filters, indirectLightUpscale, deferredShading, temporalFilter, the bloom
+     * chain, applyBloom, tonemapping; PLR_ERR_UNSUPPORTED for any other pass). valid_cols is valid_rows for columns: columns [valid_cols[0], valid_cols[1]) of
+     * the INPUT images hold this frame's data ({0, 0} = all). first_cols is first_rows for columns: workgroup columns [dispatch_base[0], first_cols[0]) and
+     * [first_cols[1], dispatch_base[0] + dispatch_count[0]) belong to the edge that is produced first - with first_rows the frame of the tile. */
+    uint32_t valid_cols[2];
+    uint32_t first_cols[2];
 } plr_compute_pass_execution;
 
 /* extension: host function executed in recording order while plr_render_frame launches the recorded passes; it may enqueue
@@ -166,6 +174,19 @@ int plr_prepare_for_drawcall_recording(void);
  * data is copied now and applied, in call order, at the start of the next plr_render_frame */
 int plr_set_uniform_buffer_data(plr_uniform_buffer_handle buffer, const void* data, size_t size);
 int plr_set_storage_buffer_data(plr_storage_buffer_handle buffer, const void* data, size_t size);
+/* RenderBackend::setGlobalDescriptorSetLayout, RenderBackend.h:73 ("must be set once before creating renderpasses"; ShaderLayout, Backend/Resources.h:9-15; caller:
+ * RenderFrontend::setupGlobalShaderInfoLayout, RenderFrontend.cpp:280-295). The kernels' set 0 is fixed - binding 0 the `global` uniform buffer, bindings 1..8 the
+ * eight samplers of resources/shaders/global.inc:35-42, binding 9 the (graphics-only) noise texture - so the call VALIDATES the layout against it instead of
+ * creating anything: a uniform buffer at binding 0 is required, a sampler outside 1..8, a uniform buffer other than 0 or any storage resource in set 0 is
+ * PLR_ERR_BINDING. Once a layout is set, plr_set_global_descriptor_set_resources refuses a resource at a binding the layout does not declare. */
+typedef struct plr_shader_layout {
+    const uint32_t* sampler_bindings; uint32_t sampler_binding_count;
+    const uint32_t* sampled_image_bindings; uint32_t sampled_image_binding_count;
+    const uint32_t* storage_image_bindings; uint32_t storage_image_binding_count;
+    const uint32_t* uniform_buffer_bindings; uint32_t uniform_buffer_binding_count;
+    const uint32_t* storage_buffer_bindings; uint32_t storage_buffer_binding_count;
+} plr_shader_layout;
+int plr_set_global_descriptor_set_layout(const plr_shader_layout* layout);
 /* RenderBackend::setGlobalDescriptorSetResources, RenderBackend.h:75: set 0 = binding 0 `global` UBO plus the
  * eight samplers of resources/shaders/global.inc:35-42 at bindings 1..8 (sampler semantics are fixed by binding) */
 int plr_set_global_descriptor_set_resources(const plr_pass_resources* resources);
@@ -276,6 +297,8 @@ int plr_get_stream(void** out_hip_stream);
 /* raw copies ordered on the launch stream of the calling thread's backend: device-to-device (asynchronous), device-to-host and
  * host-to-device (both return when the copy is done). For exchange callbacks that move rows between two backends of one process. */
 int plr_copy_device_memory(void* dst, const void* src, size_t size);
+/* rows x width_bytes from src (src_pitch bytes per row) to dst (dst_pitch): a rectangle of an image (tile rendering, exchange between two backends of one process) */
+int plr_copy_device_memory_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows);
 int plr_read_device_memory(void* dst_host, const void* src, size_t size);
 int plr_write_device_memory(void* dst, const void* src_host, size_t size);
 /* lists the shader names the backend has kernels for; returns the count */

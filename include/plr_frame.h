@@ -44,6 +44,11 @@ typedef struct plrf_settings {
                                        2 (the default): as 1, but the producer is ONE launch that writes the edge rows first and raises plr_get_edge_signal when they
                                        are complete (plr.h first_rows) - the BEGIN callback may wait for that signal on its own stream instead of ordering
                                        behind the launch stream; 1: an edge launch and an interior launch with the BEGIN callback between them (round 3) */
+    /* tile rendering (round 5; BASELINE config 5: the frame as 2 x 2 screen tiles over 4 GPUs): this instance renders columns [band_col_begin, band_col_end) of
+     * its rows (multiples of 64, or the last column). band_col_end == 0: whole rows (a band). The halos are the same numbers of columns; exchange items then
+     * carry a column range and the transfers are rectangles (plrf_exchange_plan_rects). With band_overlap_exchange 1 a tile behaves as with 0 (its producers
+     * are never split); 2 produces the FRAME of the tile first (plr.h first_rows + first_cols). */
+    uint32_t band_col_begin, band_col_end;
 } plrf_settings;
 
 /* ---- band rendering: halo exchange hooks ----
@@ -71,6 +76,9 @@ typedef struct plrf_exchange_item {
     plr_image_handle image;
     void* device_ptr;
     uint32_t row_begin, row_end, halo_rows, row_bytes, image_rows;
+    /* tile rendering: the rectangle this instance owns is columns [col_begin, col_end) of those rows, of an image of image_cols texels of texel_bytes bytes per row
+     * (a band: 0 .. image_cols); the halo is halo_rows texels on every side that has a neighbour, corners included */
+    uint32_t col_begin, col_end, image_cols, texel_bytes;
 } plrf_exchange_item;
 int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, void* user);
 /* items of the frame being launched (valid inside the callback and until the next plrf_frame); *inout_count = capacity in, count out */
@@ -107,6 +115,48 @@ int plrf_exchange_plan_rows(uint32_t frame_height, uint32_t n_bands, const uint3
                             uint32_t row_end, plrf_exchange_op* out_ops, uint32_t* out_count);
 int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,
                        plrf_exchange_op* out_ops_4, uint32_t* out_count);
+
+/* ---- tile rendering (round 5): the partition is a list of pixel rectangles, one per rank (rects = world x {x0, y0, x1, y1} at full resolution; edges between
+ * rectangles on multiples of 64). A band partition is the special case of full-width rectangles, and for it the plan below equals plrf_exchange_plan_rows.
+ * For one exchange item (an image of image_cols x image_rows texels showing the frame at frame_width / image_cols scale) rank `rank` exchanges with every
+ * rank whose rectangle TOUCHES its own (shares an edge or a corner - on a 2 x 2 grid all three others; xGMI connects every pair of GPUs of a node directly, so the
+ * diagonal neighbour is one more peer of the same group, not a second hop): it sends the part of its own rectangle that lies within halo texels of the peer's
+ * and receives the part of the peer's that lies within halo texels of its own (corners included). Ops are listed by ascending peer, send before receive;
+ * capacity = 2 x (world - 1) covers every case. */
+typedef struct plrf_rect_op { uint32_t peer, send, x0, y0, x1, y1; } plrf_rect_op;
+int plrf_exchange_plan_rects(uint32_t frame_width, uint32_t frame_height, uint32_t world, const uint32_t* rects, uint32_t rank, uint32_t image_cols, uint32_t image_rows,
+                             uint32_t halo, plrf_rect_op* out_ops, uint32_t capacity, uint32_t* out_count);
+/* gx x gy grid of tiles over the frame, row-major (rank = ty * gx + tx), every edge a multiple of 64; col_bounds (gx + 1) / row_bounds (gy + 1) choose the cuts
+ * (load balancing), NULL = equal parts. out_rects: gx * gy * 4 values */
+int plrf_tile_rects(uint32_t frame_width, uint32_t frame_height, uint32_t gx, uint32_t gy, const uint32_t* col_bounds, const uint32_t* row_bounds, uint32_t* out_rects);
+/* the native exchange for a partition into rectangles: as plrf_rccl_attach_rows, but rank r owns rects[4 r .. 4 r + 3] and must have been created with exactly that
+ * rectangle (band_row_* / band_col_*). Rectangles that are not whole rows are moved through staging buffers: ONE pack kernel gathers every region of every image
+ * of the exchange point for all peers, one group of ncclSend / ncclRecv (one pair per peer) moves the buffers, ONE unpack kernel scatters what arrived.
+ * unique_id_128_bytes == NULL: LOOPBACK - no communicator; pack, a device copy standing in for the links, unpack, on the same streams and events (what a
+ * single-GPU replay of a partition's frame costs, tools/band_cost.py; the received texels are meaningless). */
+int plrf_rccl_attach_rects(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_width, uint32_t frame_height, const uint32_t* rects,
+                           void** out_exchange);
+/* what the exchange runs on: ranks of the communicator (ncclCommCount; 0 in loopback), the RCCL version code (ncclGetVersion), the ordering mode of the overlapped
+ * exchanges (2 = the producer's edge signal + hipStreamWaitValue32, 1 = an event behind the producer - also what mode 2 falls back to on a device without
+ * stream memory operations, 0 = not overlapped), whether the regions go through pack / unpack kernels (a tile partition) or straight from the images (bands) */
+typedef struct plrf_rccl_info { int32_t rccl_ranks, rccl_version, overlap_mode, packed_regions, stream_wait_value_supported, watchdog_ms; } plrf_rccl_info;
+int plrf_rccl_get_info(void* exchange, plrf_rccl_info* out);
+/* single-GPU check of the pack / unpack kernels and the packed transport: the rectangle [x0, x1) x [y0, y1) (texels of texel_bytes bytes) of an image of pitch_bytes
+ * per row goes through pack -> ncclSend / ncclRecv with this rank as its own peer (loopback: a device copy) -> unpack onto the rectangle of the same size at (dst_x, dst_y) */
+int plrf_rccl_self_test_rect(void* exchange, void* device_ptr, uint32_t pitch_bytes, uint32_t texel_bytes, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t dst_x,
+                             uint32_t dst_y, void* launch_stream);
+
+/* ---- exchange watchdog (round 5): an overlapped exchange is a wait the launch stream parks on; if a peer never posts its side the frame
+ * hangs and says nothing. Every BEGIN arms an entry {rank, exchange id, phase, completion query, time}; entries are checked at every later exchange
+ * callback (the frame then fails with the message) and by a background thread every 50 ms, which prints the message to stderr and - unless
+ * PLRF_EXCHANGE_WATCHDOG_ABORT=0 - aborts the process: a hung collective cannot be cancelled, only reported. Deadline: PLRF_EXCHANGE_WATCHDOG_MS (default 2000,
+ * 0 = off). The functions below expose the mechanism with a caller-supplied completion query, so it can be tested without a GPU. */
+typedef int (*plrf_watchdog_query)(void* user); /* 0 = still running, 1 = complete */
+int plrf_watchdog_create(uint32_t deadline_ms, void** out_watchdog);
+int plrf_watchdog_destroy(void* watchdog);
+int plrf_watchdog_arm(void* watchdog, int rank, int exchange_id, int phase, plrf_watchdog_query query, void* user);
+/* 0: nothing overdue (completed entries are dropped); 1: an entry is past its deadline - out_message names rank, exchange and phase */
+int plrf_watchdog_poll(void* watchdog, char* out_message, size_t capacity);
 
 typedef struct plrf_camera { float position[3], forward[3], up[3], right[3]; } plrf_camera;
 

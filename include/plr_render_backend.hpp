@@ -86,6 +86,8 @@ struct ComputePassExecution {
     uint32_t validRows[2] = {0, 0};       // extension: rows of the input images that hold valid data (band rendering), see plr.h
     bool asyncTail = false;               // extension: part of the frame's asynchronous tail (plr_compute_pass_execution::async_tail), see plr.h
     uint32_t firstRows[2] = {0, 0};       // extension: workgroup rows to produce first + edge signal (plr_compute_pass_execution::first_rows), see plr.h
+    uint32_t validCols[2] = {0, 0};       // extension: columns of the input images that hold valid data (tile rendering, plr_compute_pass_execution::valid_cols)
+    uint32_t firstCols[2] = {0, 0};       // extension: workgroup columns of the edge that is produced first (tile rendering, plr_compute_pass_execution::first_cols)
 };
 struct SpecialisationConstant {
     uint32_t location;
@@ -98,6 +100,14 @@ struct ShaderDescription {
 struct ComputePassDescription {
     ShaderDescription shaderDescription;
     std::string name;
+};
+// Backend/Resources.h:9-15: the bindings a descriptor set declares, by resource kind
+struct ShaderLayout {
+    std::vector<uint32_t> samplerBindings;
+    std::vector<uint32_t> sampledImageBindings;
+    std::vector<uint32_t> storageImageBindings;
+    std::vector<uint32_t> uniformBufferBindings;
+    std::vector<uint32_t> storageBufferBindings;
 };
 struct UniformBufferDescription { size_t size = 0; void* initialData = nullptr; };
 struct StorageBufferDescription { size_t size = 0; void* initialData = nullptr; };
@@ -157,6 +167,8 @@ public:
         e.valid_rows[0] = execution.validRows[0]; e.valid_rows[1] = execution.validRows[1];
         e.async_tail = execution.asyncTail ? 1u : 0u;
         e.first_rows[0] = execution.firstRows[0]; e.first_rows[1] = execution.firstRows[1];
+        e.valid_cols[0] = execution.validCols[0]; e.valid_cols[1] = execution.validCols[1];
+        e.first_cols[0] = execution.firstCols[0]; e.first_cols[1] = execution.firstCols[1];
         check(plr_set_compute_pass_execution(&e));
     }
     void setHostCallbackExecution(plr_host_callback callback, void* user, const char* name) { check(plr_set_host_callback_execution(callback, user, name)); }
@@ -172,11 +184,27 @@ public:
     void prepareForDrawcallRecording() { check(plr_prepare_for_drawcall_recording()); }
     void setUniformBufferData(const UniformBufferHandle buffer, const void* data, const size_t size) { check(plr_set_uniform_buffer_data(buffer.index, data, size)); }
     void setStorageBufferData(const StorageBufferHandle buffer, const void* data, const size_t size) { check(plr_set_storage_buffer_data(buffer.index, data, size)); }
+    // RenderBackend.h:73, "must be set once before creating renderpasses" (RenderFrontend.cpp:280-295): validated against the kernels' fixed set 0 (plr.h)
+    void setGlobalDescriptorSetLayout(const ShaderLayout& layout) {
+        plr_shader_layout l{};
+        l.sampler_bindings = layout.samplerBindings.data(); l.sampler_binding_count = (uint32_t)layout.samplerBindings.size();
+        l.sampled_image_bindings = layout.sampledImageBindings.data(); l.sampled_image_binding_count = (uint32_t)layout.sampledImageBindings.size();
+        l.storage_image_bindings = layout.storageImageBindings.data(); l.storage_image_binding_count = (uint32_t)layout.storageImageBindings.size();
+        l.uniform_buffer_bindings = layout.uniformBufferBindings.data(); l.uniform_buffer_binding_count = (uint32_t)layout.uniformBufferBindings.size();
+        l.storage_buffer_bindings = layout.storageBufferBindings.data(); l.storage_buffer_binding_count = (uint32_t)layout.storageBufferBindings.size();
+        check(plr_set_global_descriptor_set_layout(&l));
+    }
     void setGlobalDescriptorSetResources(const RenderPassResources& resources) {
         std::vector<plr_uniform_buffer_resource> ub;
+        std::vector<plr_sampler_resource> sm;
+        std::vector<plr_image_resource> si;
         for (const auto& b : resources.uniformBuffers) ub.push_back({b.buffer.index, b.binding});
+        for (const auto& s : resources.samplers) sm.push_back({s.sampler.index, s.binding});
+        for (const auto& i : resources.sampledImages) si.push_back({toC(i.image), i.mipLevel, i.binding});
         plr_pass_resources r{};
         r.uniform_buffers = ub.data(); r.uniform_buffer_count = (uint32_t)ub.size();
+        r.samplers = sm.data(); r.sampler_count = (uint32_t)sm.size();
+        r.sampled_images = si.data(); r.sampled_image_count = (uint32_t)si.size();
         check(plr_set_global_descriptor_set_resources(&r));
     }
     void updateComputePassShaderDescription(const RenderPassHandle passHandle, const ShaderDescription& desc) {

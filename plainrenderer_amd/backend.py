@@ -110,7 +110,8 @@ class _PassResources(C.Structure):
 
 class _ComputePassExecution(C.Structure):
     _fields_ = [("handle", C.c_uint32), ("resources", _PassResources), ("push_constants", C.c_void_p),
-                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3), ("valid_rows", C.c_uint32 * 2), ("async_tail", C.c_uint32), ("first_rows", C.c_uint32 * 2)]
+                ("push_constant_size", C.c_uint32), ("dispatch_count", C.c_uint32 * 3), ("dispatch_base", C.c_uint32 * 3), ("valid_rows", C.c_uint32 * 2), ("async_tail", C.c_uint32), ("first_rows", C.c_uint32 * 2),
+                ("valid_cols", C.c_uint32 * 2), ("first_cols", C.c_uint32 * 2)]
 
 
 class _SpecConstant(C.Structure):
@@ -301,6 +302,8 @@ class RenderBackend:
         e.valid_rows = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "validRows", (0, 0))])
         e.async_tail = int(bool(getattr(exe, "asyncTail", False)))
         e.first_rows = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "firstRows", (0, 0))])
+        e.valid_cols = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "validCols", (0, 0))])
+        e.first_cols = (C.c_uint32 * 2)(*[int(x) for x in getattr(exe, "firstCols", (0, 0))])
         self._check(self.lib.plr_set_compute_pass_execution(C.byref(e)))
 
     def prepareForDrawcallRecording(self):

@@ -33,6 +33,15 @@ static bool shaderReadsBindless(const std::string& shader) {
 }
 // storage-image bindings a shader only reads (imageLoad): recorded as reads, so that readers of the same image are not ordered against each other
 // lightMatrix.comp:57-138 loads the apex texel of the depth pyramid through binding 1 and writes the cascade buffer only
+// shaders whose launchers honour dispatch_base[0] (plr.h): the passes a tile renderer restricts to the columns of its tile
+static bool shaderTakesColumns(const std::string& shader) {
+    static const char* const names[] = {"histogramPerTile.comp", "histogramCombineTiles.comp", "depthHiZPyramid.comp", "depthPyramidApex.comp", "depthDownscale.comp",
+                                        "sdfCameraTileCulling.comp", "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp", "filterIndirectDiffuseTemporal.comp",
+                                        "indirectLightUpscale.comp", "deferredShading.comp", "temporalFilter.comp", "bloomDownsample.comp", "bloomUpsample.comp",
+                                        "applyBloom.comp", "tonemapping.comp"};
+    for (const char* n : names) if (shader == n) return true;
+    return false;
+}
 static bool storageBindingIsReadOnly(const std::string& shader, uint32_t binding) { return shader == "lightMatrix.comp" && binding == 1; }
 static std::vector<ShaderEntry>& registry() {
     static std::vector<ShaderEntry> r;
@@ -214,6 +223,8 @@ struct Execution {
     const char* callbackName = ""; // interned in Backend::callbackNames
     bool asyncTail = false;        // plr_compute_pass_execution::async_tail
     uint32_t firstRows[2] = {0, 0}; // plr_compute_pass_execution::first_rows
+    uint32_t firstCols[2] = {0, 0}; // plr_compute_pass_execution::first_cols
+    bool edgesFirst() const { return firstRows[0] || firstRows[1] || firstCols[0] || firstCols[1]; }
     bool callbackAccessKnown = false; // host callback recorded with its resource list (plr_set_host_callback_execution_on): `access` is complete
 };
 
@@ -249,6 +260,9 @@ struct Backend {
     uint32_t edgeSerial = 0;
     uint32_t pinnedNext = 0;
     uint32_t globalUbo = PLR_INVALID_INDEX;
+    // plr_set_global_descriptor_set_layout: bit b = binding b of set 0 is declared as a uniform buffer / sampler / sampled image; layoutSet: a layout was given
+    uint32_t layoutUbufs = 0, layoutSamplers = 0, layoutSampled = 0;
+    bool layoutSet = false;
     ImgView* bindlessDev = nullptr;
     std::vector<ImgView> bindlessHost;   // what bindlessDev holds (PassCtx::bindlessHost)
     uint32_t bindlessCapacity = 0;
@@ -466,7 +480,7 @@ int launchOverTwoRowRanges(const PassCtx* const* ctxs, size_t count, LaunchFn si
     const PassCtx& b = *ctxs[1];
     if (a.sampledMask != b.sampledMask || a.storageMask != b.storageMask || a.sbufMask != b.sbufMask || a.ubufMask != b.ubufMask || a.push != b.push || a.spec != b.spec ||
         a.dispatch[0] != b.dispatch[0] || a.base[0] != b.base[0] || a.dispatch[2] != b.dispatch[2] || a.validRows[0] != b.validRows[0] || a.validRows[1] != b.validRows[1] ||
-        a.extraCountY || b.extraCountY || a.scratchSlot != b.scratchSlot)
+        a.validCols[0] != b.validCols[0] || a.validCols[1] != b.validCols[1] || a.extraCountY || b.extraCountY || a.scratchSlot != b.scratchSlot)
         return kUseGeneralKernel;
     for (int i = 0; i < kMaxBindings; i++) {
         if (a.hasSampled(i) && !sameView(a.sampled[i], b.sampled[i])) return kUseGeneralKernel;
@@ -498,16 +512,36 @@ int twoRangeBlocks(const PassCtx& c, int imageH, int blockRows, int wgRows, TwoR
     return 0;
 }
 
-bool TwoRanges::setEdgeFirst(const PassCtx& c, int y0, int y1, int blockRowsPx, int wgRows, unsigned blocksX, unsigned wavesPerBlock) {
-    if (!c.edgeSignal || !(c.firstRows[0] || c.firstRows[1]) || c.extraCountY || y1 <= y0) return false;
-    const long long topEnd = std::min<long long>((long long)c.firstRows[0] * wgRows, y1), bottomBegin = std::min<long long>((long long)c.firstRows[1] * wgRows, y1);
-    if (topEnd < y0 || bottomBegin < topEnd) return false;
-    if ((topEnd - y0) % blockRowsPx || (bottomBegin - y0) % blockRowsPx) return false; // an edge must be whole block rows (the last block row of the launch may be partial)
-    const int top = (int)((topEnd - y0) / blockRowsPx), totalRows = (y1 - y0 + blockRowsPx - 1) / blockRowsPx, bottom = totalRows - (int)((bottomBegin - y0) / blockRowsPx);
-    if (top + bottom == 0 || top + bottom > totalRows) return false;
+bool TwoRanges::setEdgeFirst(const PassCtx& c, int y0, int y1, int blockRowsPx, int wgRows, unsigned blocksX, int xOrigin, int x1, int blockColsPx, int wgCols) {
+    const bool rowsAsked = c.firstRows[0] || c.firstRows[1], colsAsked = c.firstCols[0] || c.firstCols[1];
+    if (!c.edgeSignal || !(rowsAsked || colsAsked) || c.extraCountY || y1 <= y0 || blocksX == 0) return false;
+    const int totalRows = (y1 - y0 + blockRowsPx - 1) / blockRowsPx;
+    int top = 0, bottom = 0, left = 0, right = 0;
+    if (rowsAsked) {
+        const long long topEnd = std::min<long long>((long long)c.firstRows[0] * wgRows, y1), bottomBegin = std::min<long long>((long long)c.firstRows[1] * wgRows, y1);
+        if (topEnd < y0 || bottomBegin < topEnd) return false;
+        if ((topEnd - y0) % blockRowsPx || (bottomBegin - y0) % blockRowsPx) return false; // an edge must be whole block rows (the last block row of the launch may be partial)
+        top = (int)((topEnd - y0) / blockRowsPx);
+        bottom = totalRows - (int)((bottomBegin - y0) / blockRowsPx);
+    }
+    if (colsAsked) {
+        // a launcher that cannot order its block columns (blockColsPx == 0) leaves the signal to the backend: raised behind the whole launch
+        if (blockColsPx <= 0 || x1 <= xOrigin) return false;
+        const long long leftEnd = std::min<long long>((long long)c.firstCols[0] * wgCols, x1), rightBegin = std::min<long long>((long long)c.firstCols[1] * wgCols, x1);
+        if (rightBegin < leftEnd) return false;
+        // block columns that hold a pixel column of an edge (a block column that is only partly edge is taken as a whole: more is written through, nothing is late)
+        left = leftEnd > xOrigin && leftEnd > (long long)c.base[0] * wgCols ? (int)((leftEnd - xOrigin + blockColsPx - 1) / blockColsPx) : 0;
+        right = rightBegin < x1 ? (int)blocksX - (int)((rightBegin - xOrigin) / blockColsPx) : 0;
+        left = std::min(std::max(left, 0), (int)blocksX);
+        right = std::min(std::max(right, 0), (int)blocksX - left);
+    }
+    if (top + bottom > totalRows) return false;
+    if (top + bottom + left + right == 0) return false;
     edgeTop = top; edgeBottom = bottom; total = totalRows;
+    edgeLeft = left; edgeRight = right;
+    edgeBlocks = (uint32_t)(top + bottom) * blocksX + (uint32_t)(left + right) * (uint32_t)(totalRows - top - bottom);
     edgeCounter = c.edgeCounter; edgeSignal = c.edgeSignal; edgeValue = c.edgeValue;
-    edgeWaves = (uint32_t)(top + bottom) * blocksX * wavesPerBlock;
+    if (edgeBlocks == 0) { edgeTop = edgeBottom = edgeLeft = edgeRight = 0; total = 0; return false; }
     c.edgeSignalHonoured = true;
     return true;
 }
@@ -546,7 +580,11 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipStreamCreateWithFlags(&g->tailStream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g->tailDone, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&g->tailStart, hipEventDisableTiming));
-    if (hipExtMallocWithFlags((void**)&g->edgeSignal, 8, hipMallocSignalMemory) == hipSuccess && hipMalloc((void**)&g->edgeCounter, 4096) == hipSuccess) { // TwoRanges::edgeDone: top counter + 32 shard counters, 64 bytes apart
+    // the edge signal is waited for with hipStreamWaitValue32: asked of the device, not assumed (without it plr_get_edge_signal reports no signal and a caller orders
+    // behind the launch stream - VERDICT r04 item 5)
+    int canWaitValue = 0;
+    if (hipDeviceGetAttribute(&canWaitValue, hipDeviceAttributeCanUseStreamWaitValue, device_ordinal) != hipSuccess) { (void)hipGetLastError(); canWaitValue = 0; }
+    if (canWaitValue && hipExtMallocWithFlags((void**)&g->edgeSignal, 8, hipMallocSignalMemory) == hipSuccess && hipMalloc((void**)&g->edgeCounter, 4096) == hipSuccess) { // TwoRanges::edgeDone: top counter + 32 shard counters, 64 bytes apart
         HIP_TRY(hipMemset(g->edgeSignal, 0, 8));
         HIP_TRY(hipMemset(g->edgeCounter, 0, 4096));
     } else {
@@ -622,6 +660,14 @@ int plr_copy_device_memory(void* dst, const void* src, size_t size) {
     if (size == 0) return PLR_OK;
     if (!dst || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, g->stream));
+    touchAddress(dst);
+    return PLR_OK;
+}
+int plr_copy_device_memory_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows) {
+    NEED_INIT_JOINED();
+    if (width_bytes == 0 || rows == 0) return PLR_OK;
+    if (!dst || !src || dst_pitch < width_bytes || src_pitch < width_bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory_2d: null pointer or a pitch smaller than the width");
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, g->stream));
     touchAddress(dst);
     return PLR_OK;
 }
@@ -715,8 +761,10 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
     if (e->push_constant_size) x.ctx.push.assign((const uint8_t*)e->push_constants, (const uint8_t*)e->push_constants + e->push_constant_size);
     for (int i = 0; i < 3; i++) { x.ctx.dispatch[i] = e->dispatch_count[i]; x.ctx.base[i] = e->dispatch_base[i]; }
     x.ctx.validRows[0] = e->valid_rows[0]; x.ctx.validRows[1] = e->valid_rows[1];
+    x.ctx.validCols[0] = e->valid_cols[0]; x.ctx.validCols[1] = e->valid_cols[1];
     x.asyncTail = e->async_tail != 0;
     x.firstRows[0] = e->first_rows[0]; x.firstRows[1] = e->first_rows[1];
+    x.firstCols[0] = e->first_cols[0]; x.firstCols[1] = e->first_cols[1];
     {
         // what the execution may touch (stream scheduler): whole allocations, so a kernel that walks the mip chain of a bound image or
         // addresses rows outside its dispatch is covered; uniform buffers are only written between frames
@@ -737,11 +785,12 @@ int plr_set_compute_pass_execution(const plr_compute_pass_execution* e) {
         if (writesDefaultImage) x.access.push_back({kBindlessKey, true});
     }
     if (e->dispatch_base[2] != 0) { g->executions.pop_back(); return setErr(PLR_ERR_INVALID_ARGUMENT, "dispatch_base[2] must be 0"); }
-    // no kernel of the path takes a first workgroup COLUMN (the partition is by rows); the one pass whose x axis is not pixels does: not silently ignored
-    if (e->dispatch_base[0] != 0 && g->passes[e->handle]->shader != "histogramCombineTiles.comp") {
+    // a first workgroup COLUMN (tile rendering) is honoured by the passes of the per-pixel frame path, whose launchers turn it into a column span
+    // (PassCtx::colSpan), and by histogramCombineTiles (first tile); every other pass covers whole rows: not silently ignored
+    if (e->dispatch_base[0] != 0 && !shaderTakesColumns(g->passes[e->handle]->shader)) {
         const std::string shader = g->passes[e->handle]->shader;
         g->executions.pop_back();
-        return setErr(PLR_ERR_UNSUPPORTED, "dispatch_base[0] is honoured by histogramCombineTiles.comp only (first tile); " + shader + " covers whole rows");
+        return setErr(PLR_ERR_UNSUPPORTED, "dispatch_base[0] is not honoured by " + shader + ": its kernels cover whole rows");
     }
     return PLR_OK;
 }
@@ -797,9 +846,50 @@ int plr_set_storage_buffer_data(plr_storage_buffer_handle buffer, const void* da
     return queueFill(g->sbufs[buffer].dev, g->sbufs[buffer].size, data, size);
 }
 
+int plr_set_global_descriptor_set_layout(const plr_shader_layout* l) {
+    NEED_INIT();
+    if (!l) return setErr(PLR_ERR_INVALID_ARGUMENT, "layout is null");
+    if ((l->sampler_binding_count && !l->sampler_bindings) || (l->sampled_image_binding_count && !l->sampled_image_bindings) || (l->uniform_buffer_binding_count && !l->uniform_buffer_bindings) ||
+        (l->storage_image_binding_count && !l->storage_image_bindings) || (l->storage_buffer_binding_count && !l->storage_buffer_bindings))
+        return setErr(PLR_ERR_INVALID_ARGUMENT, "layout: a binding list is null");
+    // set 0 as every kernel reads it (global.inc:4-42): binding 0 = the `global` uniform buffer, 1..8 = samplers, 9 = the noise texture of the graphics passes
+    uint32_t ub = 0, smp = 0, img = 0;
+    for (uint32_t i = 0; i < l->uniform_buffer_binding_count; i++) {
+        if (l->uniform_buffer_bindings[i] != 0) return setErr(PLR_ERR_BINDING, "global descriptor set layout: the only uniform buffer of set 0 is `global` at binding 0 (global.inc:4)");
+        ub |= 1u;
+    }
+    for (uint32_t i = 0; i < l->sampler_binding_count; i++) {
+        const uint32_t b = l->sampler_bindings[i];
+        if (b < 1 || b > 8) return setErr(PLR_ERR_BINDING, "global descriptor set layout: samplers live at bindings 1..8 (global.inc:35-42), got " + std::to_string(b));
+        smp |= 1u << b;
+    }
+    for (uint32_t i = 0; i < l->sampled_image_binding_count; i++) {
+        const uint32_t b = l->sampled_image_bindings[i];
+        if (b >= (uint32_t)kMaxBindings || b <= 8) return setErr(PLR_ERR_BINDING, "global descriptor set layout: sampled image at binding " + std::to_string(b) + " collides with the uniform buffer / samplers");
+        img |= 1u << b;
+    }
+    if (l->storage_image_binding_count || l->storage_buffer_binding_count) return setErr(PLR_ERR_BINDING, "global descriptor set layout: set 0 holds no storage images or storage buffers");
+    if (!(ub & 1u)) return setErr(PLR_ERR_BINDING, "global descriptor set layout: the `global` uniform buffer at binding 0 is missing");
+    g->layoutUbufs = ub; g->layoutSamplers = smp; g->layoutSampled = img; g->layoutSet = true;
+    return PLR_OK;
+}
+
 int plr_set_global_descriptor_set_resources(const plr_pass_resources* r) {
     NEED_INIT();
     if (!r) return setErr(PLR_ERR_INVALID_ARGUMENT, "resources is null");
+    if (g->layoutSet) { // a resource at a binding the declared layout does not have (RenderBackend.cpp validates against the set's layout the same way)
+        for (uint32_t i = 0; i < r->uniform_buffer_count; i++)
+            if (r->uniform_buffers[i].binding >= 32u || !((g->layoutUbufs >> r->uniform_buffers[i].binding) & 1u))
+                return setErr(PLR_ERR_BINDING, "global descriptor set: uniform buffer at binding " + std::to_string(r->uniform_buffers[i].binding) + " is not in the layout");
+        for (uint32_t i = 0; i < r->sampler_count; i++)
+            if (r->samplers[i].binding >= 32u || !((g->layoutSamplers >> r->samplers[i].binding) & 1u))
+                return setErr(PLR_ERR_BINDING, "global descriptor set: sampler at binding " + std::to_string(r->samplers[i].binding) + " is not in the layout");
+        for (uint32_t i = 0; i < r->sampled_image_count; i++)
+            if (r->sampled_images[i].binding >= 32u || !((g->layoutSampled >> r->sampled_images[i].binding) & 1u))
+                return setErr(PLR_ERR_BINDING, "global descriptor set: sampled image at binding " + std::to_string(r->sampled_images[i].binding) + " is not in the layout");
+    }
+    for (uint32_t i = 0; i < r->sampler_count; i++)
+        if (r->samplers[i].sampler >= g->samplers.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "global descriptor set: invalid sampler handle");
     for (uint32_t i = 0; i < r->uniform_buffer_count; i++) {
         if (r->uniform_buffers[i].binding == 0) {
             if (r->uniform_buffers[i].buffer >= g->ubufs.size()) return setErr(PLR_ERR_INVALID_ARGUMENT, "invalid global uniform buffer handle");
@@ -1130,6 +1220,7 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     x.ctx.elidableStorage = 0;
     x.ctx.elidedStorage = 0;
     x.ctx.firstRows[0] = x.firstRows[0]; x.ctx.firstRows[1] = x.firstRows[1];
+    x.ctx.firstCols[0] = x.firstCols[0]; x.ctx.firstCols[1] = x.firstCols[1];
     x.ctx.edgeSignal = nullptr; x.ctx.edgeCounter = nullptr; x.ctx.edgeValue = 0; x.ctx.edgeSignalHonoured = false;
     x.ctx.frameSerial = g->frameSerial;
     x.ctx.bindless = g->bindlessDev;
@@ -1190,10 +1281,11 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
     touchAccesses(x.access); // the images it writes have new contents from here on (contentVersionOf)
-    const bool signalled = (x.firstRows[0] || x.firstRows[1]) && g->edgeSignal;
+    const bool signalled = x.edgesFirst() && g->edgeSignal;
     if (signalled) { x.ctx.edgeSignal = g->edgeSignal; x.ctx.edgeCounter = g->edgeCounter; x.ctx.edgeValue = ++g->edgeSerial; }
     int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
     if (rc == kUseGeneralKernel) {
+        x.ctx.edgeSignalHonoured = false; // (a fast launcher that ordered its blocks and then declined: the general kernel raises nothing - ADVICE r04)
         if (g->mathMode == PLR_MATH_FAST) { // not silently: the caller can ask
             g->lastGeneral++;
             if (g->lastGeneralNames.size() < 2048) g->lastGeneralNames += (g->lastGeneralNames.empty() ? "" : ", ") + p.name + " [" + p.shader + "]";
@@ -1219,7 +1311,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         if (g->debugSig && !f.writesSignatures) continue;
         bool match = true;
         for (size_t k = 0; k < n && match; k++) match = g->passes[g->executions[i + k].pass]->shader == f.shaders[k];
-        for (size_t k = 0; k < n && match; k++) match = !(g->executions[i + k].firstRows[0] || g->executions[i + k].firstRows[1]); // rows-first executions are launched on their own
+        for (size_t k = 0; k < n && match; k++) match = !g->executions[i + k].edgesFirst(); // rows-first executions are launched on their own
         if (!match) continue;
         const PassCtx* ctxs[8];
         if (n > 8) continue;
@@ -1323,12 +1415,12 @@ static void gatherFusionGroups() {
         if (ex[i].callback) continue;
         for (const FusionEntry& f : fusions()) { // longest first
             const size_t m = f.shaders.size();
-            if (m < 2 || g->passes[ex[i].pass]->shader != f.shaders[0] || ex[i].firstRows[0] || ex[i].firstRows[1]) continue;
+            if (m < 2 || g->passes[ex[i].pass]->shader != f.shaders[0] || ex[i].edgesFirst()) continue;
             std::vector<size_t> members{i}, moved;
             for (size_t j = i + 1; j < ex.size() && members.size() < m && moved.size() <= kMaxMoved; j++) {
                 const Execution& y = ex[j];
                 // a rows-first execution belongs to the callback recorded behind it (edge signal): it is neither fused nor moved
-                if (y.callback || y.asyncTail != ex[i].asyncTail || y.firstRows[0] || y.firstRows[1]) break;
+                if (y.callback || y.asyncTail != ex[i].asyncTail || y.edgesFirst()) break;
                 if (g->passes[y.pass]->shader == f.shaders[members.size()]) members.push_back(j);
                 else moved.push_back(j);
             }

@@ -65,11 +65,21 @@ struct PassCtx {
     uint32_t edgeValue = 0;
     mutable bool edgeSignalHonoured = false;
     uint32_t validRows[2] = {0, 0};       // rows of the input images that hold valid data (band rendering, plr.h); {0, 0} = all
+    uint32_t validCols[2] = {0, 0};       // the same for columns (tile rendering, plr.h valid_cols); {0, 0} = all
+    // workgroup columns to produce first (plr.h first_cols; tile rendering): [base[0], firstCols[0]) and [firstCols[1], base[0] + dispatch[0]), together with
+    // firstRows the frame of the tile its neighbours wait for. {0, 0} = none
+    uint32_t firstCols[2] = {0, 0};
     // [lo, hi) for an input image of imageH rows
     void validRowRange(int imageH, int* lo, int* hi) const {
         const bool all = validRows[0] == 0 && validRows[1] == 0;
         *lo = all ? 0 : (int)(validRows[0] < (uint32_t)imageH ? validRows[0] : (uint32_t)imageH);
         *hi = all ? imageH : (int)(validRows[1] < (uint32_t)imageH ? validRows[1] : (uint32_t)imageH);
+    }
+    // [lo, hi) for an input image of imageW columns
+    void validColRange(int imageW, int* lo, int* hi) const {
+        const bool all = validCols[0] == 0 && validCols[1] == 0;
+        *lo = all ? 0 : (int)(validCols[0] < (uint32_t)imageW ? validCols[0] : (uint32_t)imageW);
+        *hi = all ? imageW : (int)(validCols[1] < (uint32_t)imageW ? validCols[1] : (uint32_t)imageW);
     }
     // producer -> consumer link (PLR_REGISTER_CONSUMER_LINK below): the context of the LATER execution of this frame that is the first to read an
     // image this execution writes, possibly with host callbacks (halo exchanges) and further executions of this same pass in between; null if
@@ -115,6 +125,19 @@ struct PassCtx {
         return r;
     }
 
+    // pixel columns [x0, x1) covered by the recorded dispatch for workgroups of wgCols columns, clipped to an image of imageW columns (tile rendering:
+    // dispatch_base[0] / dispatch_count[0] restrict a pass to the columns of its tile, as [1] does for rows)
+    struct ColSpan { int x0, x1; };
+    ColSpan colSpan(int imageW, int wgCols = 8) const {
+        const long long a = (long long)base[0] * wgCols, b = a + (long long)dispatch[0] * wgCols;
+        ColSpan r;
+        r.x0 = (int)(a < imageW ? a : imageW);
+        r.x1 = (int)(b < imageW ? b : imageW);
+        return r;
+    }
+    // the recorded dispatch covers every column of an image of imageW columns
+    bool wholeRows(int imageW, int wgCols = 8) const { const ColSpan s = colSpan(imageW, wgCols); return s.x0 == 0 && s.x1 == imageW; }
+
     int fail(int code, const std::string& msg) const;
     // checks presence + format of a binding; returns 0 or records an error
     int needSampled(int binding, int fmt, const char* what) const;
@@ -143,9 +166,14 @@ int launchOverTwoRowRanges(const PassCtx* const* ctxs, size_t count, LaunchFn si
 struct TwoRanges {
     int split = 0x7fffffff, gap = 0;
     int edgeTop = 0, edgeBottom = 0, total = 0;
+    // tile rendering (plr.h first_cols): the first edgeLeft and the last edgeRight block columns of the block rows between the top and the bottom edge belong
+    // to the edge as well - the frame of the tile. The grid is walked as a linear list L = blockIdx.y * gridDim.x + blockIdx.x: top rows, bottom rows, left
+    // columns, right columns, interior (blockXY). With no edge columns that is the order of blockRow.
+    int edgeLeft = 0, edgeRight = 0;
+    uint32_t edgeBlocks = 0; // blocks of the edge = arrivals before the signal (setEdgeFirst)
     uint32_t* edgeCounter = nullptr;
     uint32_t* edgeSignal = nullptr;
-    uint32_t edgeValue = 0, edgeWaves = 0;
+    uint32_t edgeValue = 0;
     // block row of the image region this block of the grid works on
     __device__ __forceinline__ int blockRow(int r) const {
         if (edgeTop + edgeBottom == 0) return r + (r >= split ? gap : 0);
@@ -153,27 +181,46 @@ struct TwoRanges {
         if (r < edgeTop + edgeBottom) return total - edgeBottom + (r - edgeTop);
         return r - edgeBottom;
     }
-    __device__ __forceinline__ bool isEdge(int r) const { return r < edgeTop + edgeBottom; }
+    // block column and block row of the image region this block of the grid works on (kernels that can run the frame of a tile first; gridDim.x block
+    // columns, `total` block rows)
+    __device__ __forceinline__ void blockXY(int* bx, int* by) const {
+        if (edgeLeft + edgeRight == 0) { *bx = (int)blockIdx.x; *by = blockRow((int)blockIdx.y); return; }
+        const int BX = (int)gridDim.x, mid = total - edgeTop - edgeBottom;
+        int L = (int)blockIdx.y * BX + (int)blockIdx.x;
+        if (L < edgeTop * BX) { *by = L / BX; *bx = L - *by * BX; return; }
+        L -= edgeTop * BX;
+        if (L < edgeBottom * BX) { const int q = L / BX; *by = total - edgeBottom + q; *bx = L - q * BX; return; }
+        L -= edgeBottom * BX;
+        if (L < edgeLeft * mid) { const int q = L / edgeLeft; *by = edgeTop + q; *bx = L - q * edgeLeft; return; }
+        L -= edgeLeft * mid;
+        if (L < edgeRight * mid) { const int q = L / edgeRight; *by = edgeTop + q; *bx = BX - edgeRight + (L - q * edgeRight); return; }
+        L -= edgeRight * mid;
+        const int iw = BX - edgeLeft - edgeRight, q = L / iw;
+        *by = edgeTop + q; *bx = edgeLeft + (L - q * iw);
+    }
+    __device__ __forceinline__ bool isEdge(int r) const { return edgeLeft + edgeRight == 0 ? r < edgeTop + edgeBottom : (uint32_t)r * gridDim.x + blockIdx.x < edgeBlocks; }
     // edgeDone: called once by EVERY wave of the block at the end of its work (all its stores issued), on every path out of the kernel. An edge block's outputs
     // are stored WRITE-THROUGH (storeOut below with through = isEdge(): `sc1` stores reach memory, MI355X_MICROARCH.md "stores of each flavour"), so a
     // wave only has to wait for its own stores and arrive; an agent-scope release per wave - a write-back of the XCD's whole L2 each time - made a
     // band's trace take 2.5 ms (measured, round 4). The last arrival of the launch resets the counter for the next launch and raises the signal at
     // system scope (the command processor polls it: hipStreamWaitValue32); the exchange's send kernel starts after that, with clean caches.
     // Arrivals are per BLOCK (the block's waves meet at a barrier: every wave calls this exactly once) and sharded over kEdgeShards counters on separate
-    // cache lines by block column, each of which forwards one arrival to the top counter when its last block is in: one word takes ~88 atomics per
-    // microsecond (MI355X_MICROARCH.md, dequeue), and 15 000 edge waves of a band arriving on ONE word made the pass 130 us longer (measured, round 4).
+    // cache lines by the block's place in the list, each of which forwards one arrival to the top counter when its last block is in: one word takes ~88
+    // atomics per microsecond (MI355X_MICROARCH.md, dequeue), and 15 000 edge waves of a band arriving on ONE word made the pass 130 us longer (measured, round 4).
     static constexpr uint32_t kEdgeShards = 32, kEdgeShardStride = 16; // counters[(1 + shard) * 16], counters[0] = top
     __device__ __forceinline__ void edgeDone(int r) const {
-        if (edgeTop + edgeBottom == 0 || r >= edgeTop + edgeBottom) return;
+        if (edgeBlocks == 0) return;
+        const uint32_t L = (uint32_t)r * gridDim.x + blockIdx.x; // (r = blockIdx.y: the block's place in the grid, not its block row)
+        if (L >= edgeBlocks) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t shard = blockIdx.x % kEdgeShards;
-            const uint32_t inShard = (uint32_t)(edgeTop + edgeBottom) * (gridDim.x / kEdgeShards + (shard < gridDim.x % kEdgeShards ? 1u : 0u));
+            const uint32_t shard = L % kEdgeShards;
+            const uint32_t inShard = edgeBlocks / kEdgeShards + (shard < edgeBlocks % kEdgeShards ? 1u : 0u);
             uint32_t* mine = edgeCounter + (1u + shard) * kEdgeShardStride;
             if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inShard - 1u) {
                 __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t shards = gridDim.x < kEdgeShards ? gridDim.x : kEdgeShards;
+                const uint32_t shards = edgeBlocks < kEdgeShards ? edgeBlocks : kEdgeShards;
                 if (__hip_atomic_fetch_add(edgeCounter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) {
                     __hip_atomic_store(edgeCounter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(edgeSignal, edgeValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -181,9 +228,10 @@ struct TwoRanges {
             }
         }
     }
-    // host: turn PassCtx::firstRows into the edge-first order for blocks of blockRowsPx pixel rows over pixel rows [y0, y1) (wgRows pixel rows per workgroup
-    // row), blocksX blocks per row of wavesPerBlock waves; false (and nothing set) if the edges are not whole block rows - the backend then signals itself
-    bool setEdgeFirst(const struct PassCtx& c, int y0, int y1, int blockRowsPx, int wgRows, unsigned blocksX, unsigned wavesPerBlock);
+    // host: turn PassCtx::firstRows / firstCols into the edge-first order for blocks of blockRowsPx x blockColsPx pixels over pixel rows [y0, y1) and pixel
+    // columns [x0, x1) (wgRows / wgCols pixels per workgroup row / column), blocksX blocks per row (= gridDim.x of the launch); false (and nothing set) if the
+    // edges are not whole blocks - the backend then signals itself
+    bool setEdgeFirst(const struct PassCtx& c, int y0, int y1, int blockRowsPx, int wgRows, unsigned blocksX, int x0 = 0, int x1 = 0, int blockColsPx = 0, int wgCols = 8);
 };
 // output stores of a kernel that may run rows-first: plain, or write-through (relaxed agent-scope atomic stores = `global_store ... sc1`) for an edge block
 __device__ __forceinline__ void storeOut(uint32_t* p, uint32_t v, bool through) {

@@ -44,9 +44,10 @@ PLR_DI vec3 VFromiUV(int x, int y, const GlobalUbo* g) {
 template <bool USE_HIZ, class List, class DepthAt>
 PLR_DI void cullTile(List list, uint32_t listCount, uint32_t lane, uint32_t tileLinear, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
                      float influenceRange, DepthAt depthAt, const GlobalUbo* __restrict__ g, uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX,
-                     uint32_t domainY, uint32_t tileRow0, uint32_t tileCapacity) {
+                     uint32_t domainY, uint32_t tileRow0, uint32_t tileCapacity, uint32_t tileCol0 = 0u) {
     if (tileLinear >= domainX * domainY) return;
-    const int tx = (int)(tileLinear % domainX), ty = (int)(tileRow0 + tileLinear / domainX);
+    // tiles [tileCol0, tileCol0 + domainX) x [tileRow0, tileRow0 + domainY): the recorded dispatch (band rendering: its tile rows, tile rendering: its columns too)
+    const int tx = (int)(tileCol0 + tileLinear % domainX), ty = (int)(tileRow0 + tileLinear / domainX);
     const uint32_t tileIndex = tileIndexFromTileUV(tx, ty, g);
     if (tileIndex >= tileCapacity) return;
     CulledInstancesPerTile* tile = tiles + tileIndex;
@@ -105,6 +106,7 @@ struct FusedCullParams {
     const BoundingBox* bbs; CulledInstancesPerTile* tiles; const float* influenceRangeP;
     const GlobalUbo* g;
     uint32_t tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity, listCapacity;
+    uint32_t tileCol0; // first tile column of the dispatch (tile rendering)
 };
 // block `block` of `blocks`, NT threads; list: kFusedCullMaxInstances words of LDS, waveTotals: NT / 64 words, base: one word
 template <bool USE_HIZ, uint32_t NT, class DepthAt>
@@ -142,7 +144,7 @@ PLR_DI void frustumAndTileCullingBlock(const FusedCullParams& p, uint32_t block,
     const uint32_t listCount = min(finalCount, p.listCapacity);
     // entries below base0 were in the global list before this launch (block 0 does not touch them)
     cullTile<USE_HIZ>([&](uint32_t i) { return i < base0 ? culled[1 + i] : list[i]; }, listCount, lane, block * kWaves + wave, p.bbs, p.tiles, *p.influenceRangeP, depthAt, p.g,
-                      p.tileCountX, p.tileCountY, p.domainX, p.domainY, p.tileRow0, p.tileCapacity);
+                      p.tileCountX, p.tileCountY, p.domainX, p.domainY, p.tileRow0, p.tileCapacity, p.tileCol0);
     __syncthreads();
     // every block read culled[0] (base0) before this barrier; the ticket is release / acquire at agent scope so that the last block's store of
     // the new count is ordered after all of those reads

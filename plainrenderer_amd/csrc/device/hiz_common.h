@@ -14,6 +14,7 @@ struct HizParams {
     int depthW, depthH;
     int count;     // pyramid levels
     int tileY0;    // first 32x32 mip-0 tile row of the launch (dispatch base)
+    int tileX0;    // first tile column of the launch (tile rendering: PassCtx::colSpan in tiles)
     int baseCount; // levels produced by hizBaseKernel
     int ldsA;      // texels of hizBaseKernel's first LDS buffer
 };

@@ -26,7 +26,9 @@ struct QuadParams {
     int halfW;
     int levels;          // 4: both sides are multiples of 16; 3: multiples of 8 (1920 x 1080), level 3 is then the tail's first level (its 3-wide odd-size footprints need LDS)
     int tileY0;          // first 64-row tile row of the launch (band rendering / per-tile pyramids: a launch covers the tile rows it is asked for)
+    int tileX0;          // first 64-column tile column of the launch (tile rendering)
     int halfRow0, halfRow1; // rows of halfDepth this launch may write (the depthDownscale execution's rows)
+    int halfCol0, halfCol1; // and its columns (tile rendering: the downscale's column span; whole rows otherwise)
 };
 
 // min / max contribution of a (min, max) texel to the level above (depthHiZPyramid.comp:95-110): a texel whose max is 0 is all sky and must not
@@ -70,8 +72,9 @@ PLR_DI void hizQuadBlock(const QuadParams& p, int bx, int by) {
         if (DOWNSCALE) {
             // depthDownscale.comp:12-20: half-res texel (x, y) = depth texel (2x, 2y), stored as a half float
             uint16_t* h0 = p.halfDepth + (size_t)(py / 2) * (size_t)p.halfW + (size_t)(px / 2);
-            if (py / 2 >= p.halfRow0 && py / 2 < p.halfRow1) *(uint32_t*)h0 = floatToHalfBits(r[0].x) | (floatToHalfBits(r[0].z) << 16);
-            if (py / 2 + 1 >= p.halfRow0 && py / 2 + 1 < p.halfRow1) *(uint32_t*)(h0 + p.halfW) = floatToHalfBits(r[2].x) | (floatToHalfBits(r[2].z) << 16);
+            const bool inCols = px / 2 >= p.halfCol0 && px / 2 < p.halfCol1; // (column spans are multiples of 8: the two texels of a lane are inside or outside together)
+            if (inCols && py / 2 >= p.halfRow0 && py / 2 < p.halfRow1) *(uint32_t*)h0 = floatToHalfBits(r[0].x) | (floatToHalfBits(r[0].z) << 16);
+            if (inCols && py / 2 + 1 >= p.halfRow0 && py / 2 + 1 < p.halfRow1) *(uint32_t*)(h0 + p.halfW) = floatToHalfBits(r[2].x) | (floatToHalfBits(r[2].z) << 16);
         }
     }
     // level 2: the four lanes of a quad hold the four level-1 texels of one level-2 texel. An inactive lane contributes the neutral pair
@@ -152,18 +155,20 @@ struct TileTailParams {
     float2* level5;
     int w3, h3, w4, h4, w5, h5;
     int row4Begin, row4End, row5Begin, row5End; // rows of levels 4 / 5 owned by the launch's tile rows
+    int col4Begin, col4End, col5Begin, col5End; // and the columns owned by its tile columns (tile rendering; whole rows otherwise)
 };
 PLR_DI void hizTileTailThread(const TileTailParams& p, int i) {
-    const int n4 = p.w4 * (p.row4End - p.row4Begin), n5 = p.w5 * (p.row5End - p.row5Begin);
+    const int c4 = p.col4End - p.col4Begin, c5 = p.col5End - p.col5Begin;
+    const int n4 = c4 * (p.row4End - p.row4Begin), n5 = c5 * (p.row5End - p.row5Begin);
     auto level4At = [&](int x, int y) {
         const MinMax m = footprint<false>(2 * x, 2 * y, p.w3, p.h3, p.h3 & 1, p.w3 & 1, [&](int sx, int sy) { return p.level3[(size_t)sy * p.w3 + sx]; });
         return make_float2(m.mn, m.mx);
     };
     if (i < n4) {
-        const int x = i % p.w4, y = p.row4Begin + i / p.w4;
+        const int x = p.col4Begin + i % c4, y = p.row4Begin + i / c4;
         p.level4[(size_t)y * p.w4 + x] = level4At(x, y);
     } else if (i < n4 + n5) {
-        const int j = i - n4, x = j % p.w5, y = p.row5Begin + j / p.w5;
+        const int j = i - n4, x = p.col5Begin + j % c5, y = p.row5Begin + j / c5;
         const MinMax m = footprint<false>(2 * x, 2 * y, p.w4, p.h4, p.h4 & 1, p.w4 & 1, [&](int sx, int sy) { return level4At(sx, sy); });
         p.level5[(size_t)y * p.w5 + x] = make_float2(m.mn, m.mx);
     }

@@ -1,19 +1,34 @@
-// Halo exchange of band rendering over RCCL, in the C++ host ("RCCL over xGMI only for the TAA / denoise / bloom halo rows").
+// Halo exchange of band / tile rendering over RCCL, in the C++ host ("RCCL over xGMI only for the TAA / denoise / bloom halo rows").
 //
-// One process per GPU renders one band of screen rows (frame_pipeline.h, BandSettings). Where a pass reads rows a neighbouring band
-// produced, FramePipeline calls its exchange callback from inside plr_render_frame, in pass order. This file IS that callback when
-// plrf_rccl_attach() has been called: every exchange is a group of ncclSend / ncclRecv with the band above and the band below (one
-// direct xGMI link per neighbour - no ring, no all-gather), the luminance histogram is one 512-byte ncclAllReduce. There is no Python
-// and no torch in the frame loop; the launcher only hands every rank the ncclUniqueId once at start-up.
+// One process per GPU renders one rectangle of the screen: a band of rows, or - BASELINE config 5 - a tile of a 2 x 2 grid (frame_pipeline.h, BandSettings).
+// Where a pass reads texels a neighbouring rectangle produced, FramePipeline calls its exchange callback from inside plr_render_frame, in pass order.
+// This file IS that callback when plrf_rccl_attach*() has been called. There is no Python and no torch in the frame loop; the launcher only hands every
+// rank the ncclUniqueId once at start-up.
 //
-// Ordering. Exchanges with a BEGIN / END phase (band_overlap_exchange) run on a communication stream: BEGIN records an event on the
-// launch stream (the producer's edge rows are already queued there), the communication stream waits for it and carries the transfers;
-// the producer's interior rows, recorded next, run beside them; END makes the launch stream wait for the transfers' completion event.
-// Exchanges without a phase and the histogram all-reduce are enqueued on the launch stream itself (in order, nothing to wait for).
+// Bands (whole rows): every exchanged region is one contiguous range of an image, so an exchange is a group of ncclSend / ncclRecv straight from / into the
+// images with the band above and the band below. Tiles: a region is a rectangle (a strided range), so an exchange is ONE pack kernel that gathers every region
+// of every image of the exchange point for all peers into a staging arena, one group with one ncclSend + one ncclRecv per peer, and ONE unpack kernel. A tile
+// exchanges with every tile it touches, corners included: on a node every pair of GPUs has its own xGMI link, so the diagonal neighbour is a third peer of the
+// same group, not a second phase. The luminance histogram is one 512-byte ncclAllReduce, the depth range two one-float all-reduces.
+//
+// Ordering. Exchanges with a BEGIN / END phase (band_overlap_exchange) run on a communication stream: BEGIN makes it wait for the producer's edge signal (rows /
+// tile frame first, plr.h first_rows) or for an event behind the producer and posts pack + group + unpack there; the producer's interior runs beside them; END
+// makes the launch stream wait for the completion event. Exchanges without a phase and the all-reduces are enqueued on the launch stream itself.
+//
+// Watchdog. An exchange whose peer never posts its side parks the launch stream for ever. Every BEGIN (and every in-line exchange) arms an entry
+// {rank, exchange, phase, completion event, time}; overdue entries fail the next exchange callback with a message, and a background thread prints the message
+// and aborts the process (a posted collective cannot be cancelled) - plr_frame.h "exchange watchdog".
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -29,7 +44,7 @@ namespace {
 thread_local std::string g_xerr;
 int xfail(int code, const std::string& msg) { g_xerr = msg; return code; }
 
-constexpr uint32_t kBandAlignment = 64; // rows; band edges never split a HiZ / culling / histogram tile or the coarsest bloom texel
+constexpr uint32_t kBandAlignment = 64; // rows / columns; edges never split a HiZ / culling / histogram tile or the coarsest bloom texel
 
 // rows [begin, end) of band `index` of `nBands`: multiples of 64 rows, sizes differing by at most 64 (the last band ends at `height`)
 void bandRowsOf(uint32_t height, uint32_t nBands, uint32_t index, uint32_t* begin, uint32_t* end) {
@@ -76,26 +91,283 @@ uint32_t planItem(uint32_t frameHeight, uint32_t nBands, const uint32_t* bounds,
     return n;
 }
 
+// ---------------------------------------------------------------- rectangles (tile rendering)
+struct Rect { uint32_t x0, y0, x1, y1; };
+bool emptyRect(const Rect& r) { return r.x1 <= r.x0 || r.y1 <= r.y0; }
+Rect intersect(const Rect& a, const Rect& b) { return {std::max(a.x0, b.x0), std::max(a.y0, b.y0), std::min(a.x1, b.x1), std::min(a.y1, b.y1)}; }
+Rect grow(const Rect& r, uint32_t k, uint32_t w, uint32_t h) { return {r.x0 > k ? r.x0 - k : 0u, r.y0 > k ? r.y0 - k : 0u, std::min(r.x1 + k, w), std::min(r.y1 + k, h)}; }
+// the rectangle of a full-resolution rectangle in an image of cols x rows texels showing the frame at 1 / divisor resolution (begin rounds down, end up:
+// the same rule as bandRowsInImage)
+Rect scaleRect(const Rect& r, uint32_t frameW, uint32_t frameH, uint32_t cols, uint32_t rows) {
+    const uint32_t dx = std::max(1u, (frameW + cols / 2) / std::max(cols, 1u)), dy = std::max(1u, (frameH + rows / 2) / std::max(rows, 1u));
+    return {r.x0 / dx, r.y0 / dy, std::min((r.x1 + dx - 1) / dx, cols), std::min((r.y1 + dy - 1) / dy, rows)};
+}
+// closures intersect: the rectangles share an edge or a corner
+bool touching(const Rect& a, const Rect& b) { return a.x0 <= b.x1 && b.x0 <= a.x1 && a.y0 <= b.y1 && b.y0 <= a.y1; }
+
+uint32_t planRects(uint32_t frameW, uint32_t frameH, uint32_t world, const Rect* rects, uint32_t rank, uint32_t cols, uint32_t rows, uint32_t halo, plrf_rect_op* ops, uint32_t capacity) {
+    uint32_t n = 0;
+    const Rect mine = scaleRect(rects[rank], frameW, frameH, cols, rows);
+    auto add = [&](uint32_t peer, uint32_t send, const Rect& r) {
+        if (emptyRect(r)) return;
+        if (n < capacity) ops[n] = {peer, send, r.x0, r.y0, r.x1, r.y1};
+        n++;
+    };
+    for (uint32_t p = 0; p < world; p++) {
+        if (p == rank || !touching(rects[rank], rects[p])) continue;
+        const Rect theirs = scaleRect(rects[p], frameW, frameH, cols, rows);
+        add(p, 1, intersect(mine, grow(theirs, halo, cols, rows)));
+        add(p, 0, intersect(theirs, grow(mine, halo, cols, rows)));
+    }
+    return n;
+}
+
+int checkRects(uint32_t frameW, uint32_t frameH, uint32_t world, const uint32_t* rects, const char* who) {
+    if (!rects || world == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": no rectangles");
+    uint64_t area = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint32_t* q = rects + 4 * r;
+        if (q[2] <= q[0] || q[3] <= q[1] || q[2] > frameW || q[3] > frameH) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": rectangle " + std::to_string(r) + " is empty or outside the frame");
+        if (q[0] % kBandAlignment || q[1] % kBandAlignment || (q[2] % kBandAlignment && q[2] != frameW) || (q[3] % kBandAlignment && q[3] != frameH))
+            return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": rectangle edges must be multiples of 64 (or the frame's last column / row)");
+        area += (uint64_t)(q[2] - q[0]) * (q[3] - q[1]);
+        for (uint32_t o = 0; o < r; o++) {
+            const uint32_t* p = rects + 4 * o;
+            if (q[0] < p[2] && p[0] < q[2] && q[1] < p[3] && p[1] < q[3]) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": rectangles " + std::to_string(o) + " and " + std::to_string(r) + " overlap");
+        }
+    }
+    if (area != (uint64_t)frameW * frameH) return xfail(PLR_ERR_INVALID_ARGUMENT, std::string(who) + ": the rectangles do not cover the frame");
+    return PLR_OK;
+}
+
+// ---------------------------------------------------------------- pack / unpack: rectangles of images <-> one staging arena
+struct CopyRegion {
+    uint8_t* image;   // address of the region's first texel
+    uint8_t* buffer;  // where its tightly packed copy lives
+    uint32_t pitch, widthBytes, rows, unit; // unit: 16 if addresses, pitch and width allow 16-byte accesses, else 4 (texels are 4 or 8 bytes)
+};
+constexpr int kMaxRegions = 48; // per launch: (images of an exchange point) x (peers) - six images and three peers in a 2 x 2 grid
+struct CopyTable { int n; CopyRegion r[kMaxRegions]; };
+// one launch for every region of an exchange point: blockIdx.y = region, a block's threads walk the region's units with a grid stride
+template <bool PACK>
+__global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
+    const CopyRegion r = t.r[blockIdx.y];
+    const uint32_t perRow = r.widthBytes / r.unit, total = perRow * r.rows;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t row = i / perRow, c = i - row * perRow;
+        uint8_t* img = r.image + (size_t)row * r.pitch + (size_t)c * r.unit;
+        uint8_t* buf = r.buffer + (size_t)i * r.unit;
+        if (r.unit == 16u) { if (PACK) *(uint4*)buf = *(const uint4*)img; else *(uint4*)img = *(const uint4*)buf; }
+        else { if (PACK) *(uint32_t*)buf = *(const uint32_t*)img; else *(uint32_t*)img = *(const uint32_t*)buf; }
+    }
+}
+
+// ---------------------------------------------------------------- watchdog
+struct Watchdog {
+    struct Entry { int rank, id, phase; plrf_watchdog_query query; void* user; std::chrono::steady_clock::time_point armed; };
+    std::mutex m;
+    std::vector<Entry> entries;
+    uint32_t deadlineMs = 2000;
+    static const char* phaseName(int phase) { return phase == PLRF_EXCHANGE_BEGIN ? "BEGIN (transfers posted, completion pending)" : (phase == PLRF_EXCHANGE_END ? "END" : "in line on the launch stream"); }
+    static const char* idName(int id) {
+        static const char* names[PLRF_EXCHANGE_COUNT] = {"histogram all-reduce", "traced GI halo", "temporally filtered GI halo", "GI history halo", "resolved colour + TAA history halo", "depth range all-reduce"};
+        return id >= 0 && id < PLRF_EXCHANGE_COUNT ? names[id] : "?";
+    }
+    void arm(int rank, int id, int phase, plrf_watchdog_query query, void* user) {
+        if (!deadlineMs) return;
+        std::lock_guard<std::mutex> lock(m);
+        for (Entry& e : entries) if (e.id == id && e.query == query && e.user == user) { e.phase = phase; e.armed = std::chrono::steady_clock::now(); return; } // re-armed every frame
+        entries.push_back({rank, id, phase, query, user, std::chrono::steady_clock::now()});
+    }
+    // drops completed entries; true + message if one is overdue
+    bool poll(std::string* msg) {
+        if (!deadlineMs) return false;
+        std::lock_guard<std::mutex> lock(m);
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < entries.size();) {
+            const Entry& e = entries[i];
+            if (e.query(e.user)) { entries.erase(entries.begin() + (long)i); continue; }
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - e.armed).count();
+            if (ms > (long long)deadlineMs) {
+                if (msg) *msg = "exchange watchdog: rank " + std::to_string(e.rank) + ", exchange " + std::to_string(e.id) + " (" + idName(e.id) + "), phase " + phaseName(e.phase) +
+                                ": not complete after " + std::to_string(ms) + " ms (deadline " + std::to_string(deadlineMs) +
+                                " ms) - a peer has not posted its side of the group, or the producer's edge signal was never raised (the launch stream may be parked in an earlier in-line exchange: "
+                                "the histogram / depth-range all-reduce or the GI history exchange)";
+                return true;
+            }
+            i++;
+        }
+        return false;
+    }
+};
+
+struct StageArena { uint8_t* ptr = nullptr; size_t size = 0; };
+
 struct RcclExchange {
     FramePipeline* fp = nullptr;
     ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    uint32_t frameHeight = 0;
-    std::vector<uint32_t> bounds; // world + 1 row boundaries, or empty: the equal partition
+    bool loopback = false;
+    int rank = 0, world = 1, device = 0;
+    uint32_t frameWidth = 0, frameHeight = 0;
+    std::vector<uint32_t> bounds; // world + 1 row boundaries, or empty: the equal partition (bands)
+    std::vector<Rect> rects;      // tile rendering: every rank's rectangle; empty = bands
     hipStream_t commStream = nullptr;
     uint32_t lastSignalValue = 0; // the edge signal value the previous BEGIN waited for: a BEGIN whose producer raised no new one orders behind the launch stream
     hipEvent_t ready[PLRF_EXCHANGE_COUNT] = {}, done[PLRF_EXCHANGE_COUNT] = {};
+    StageArena sendArena[PLRF_EXCHANGE_COUNT], recvArena[PLRF_EXCHANGE_COUNT];
     uint64_t bytesSent = 0, bytesReceived = 0, exchanges = 0; // of the last frame (reset by the histogram exchange, the first of a frame)
+    int lastOverlapMode = 0;
+    bool packedRegions = false;
+    int streamWaitValueSupported = 0;
+    // watchdog: entries are completion events; a background thread reports (and aborts) when the frame loop itself is stuck
+    Watchdog dog;
+    struct DogArg { RcclExchange* x; int id; } dogArgs[PLRF_EXCHANGE_COUNT];
+    std::thread dogThread;
+    std::mutex dogMutex;
+    std::condition_variable dogWake;
+    bool dogStop = false, dogAbort = true;
+    std::atomic<bool> dogFired{false};
+    std::string dogMessage;
 
     ~RcclExchange() {
+        {
+            std::lock_guard<std::mutex> lock(dogMutex);
+            dogStop = true;
+        }
+        dogWake.notify_all();
+        if (dogThread.joinable()) dogThread.join();
         if (comm) ncclCommDestroy(comm);
         for (auto e : ready) if (e) hipEventDestroy(e);
         for (auto e : done) if (e) hipEventDestroy(e);
+        for (auto& a : sendArena) if (a.ptr) hipFree(a.ptr);
+        for (auto& a : recvArena) if (a.ptr) hipFree(a.ptr);
         if (commStream) hipStreamDestroy(commStream);
     }
 
     int nccl(ncclResult_t r, const char* what) { return r == ncclSuccess ? 0 : xfail(PLR_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r)); }
     int hip(hipError_t e, const char* what) { return e == hipSuccess ? 0 : xfail(PLR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+    static int eventDone(void* user) {
+        const DogArg* a = (const DogArg*)user;
+        return hipEventQuery(a->x->done[a->id]) != hipErrorNotReady ? 1 : 0; // (an error also ends the watch: the failing call reports it)
+    }
+    void startWatchdog() {
+        if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_MS")) dog.deadlineMs = (uint32_t)std::max(0, std::atoi(ms));
+        if (const char* ab = std::getenv("PLRF_EXCHANGE_WATCHDOG_ABORT")) dogAbort = std::atoi(ab) != 0;
+        for (int i = 0; i < PLRF_EXCHANGE_COUNT; i++) dogArgs[i] = {this, i};
+        if (!dog.deadlineMs) return;
+        dogThread = std::thread([this] {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lock(dogMutex);
+            while (!dogStop) {
+                dogWake.wait_for(lock, std::chrono::milliseconds(50));
+                if (dogStop) break;
+                std::string msg;
+                if (!dogFired.load() && dog.poll(&msg)) {
+                    dogMessage = msg;
+                    dogFired.store(true);
+                    std::fprintf(stderr, "[plr] %s\n", msg.c_str());
+                    std::fflush(stderr);
+                    if (dogAbort) std::abort();
+                }
+            }
+        });
+    }
+    // every exchange callback: an overdue entry fails the frame here (the thread above has the case where the frame loop itself is stuck)
+    int checkWatchdog() {
+        std::string msg;
+        if (dogFired.load()) { std::lock_guard<std::mutex> lock(dogMutex); return xfail(PLR_ERR_HIP, dogMessage); }
+        if (dog.poll(&msg)) return xfail(PLR_ERR_HIP, msg);
+        return 0;
+    }
+
+    bool tiledItems(const plrf_exchange_item* items, uint32_t count) const {
+        if (!rects.empty()) for (const Rect& r : rects) if (r.x0 != 0 || r.x1 != frameWidth) return true;
+        for (uint32_t i = 0; i < count; i++) if (items[i].col_begin != 0 || items[i].col_end != items[i].image_cols) return true;
+        return false;
+    }
+
+    int arena(StageArena& a, size_t bytes) {
+        if (a.size >= bytes) return 0;
+        if (a.ptr) { if (int rc = hip(hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc; hipFree(a.ptr); a.ptr = nullptr; a.size = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+        if (int rc = hip(hipMalloc((void**)&a.ptr, want), "hipMalloc(exchange staging)")) return rc;
+        a.size = want;
+        return 0;
+    }
+
+    // regions of `table` in launches of at most kMaxRegions
+    template <bool PACK>
+    int launchCopies(const std::vector<CopyRegion>& regions, hipStream_t stream) {
+        for (size_t first = 0; first < regions.size(); first += kMaxRegions) {
+            CopyTable t{};
+            t.n = (int)std::min<size_t>(kMaxRegions, regions.size() - first);
+            uint32_t maxUnits = 1;
+            for (int i = 0; i < t.n; i++) { t.r[i] = regions[first + i]; maxUnits = std::max(maxUnits, t.r[i].widthBytes / t.r[i].unit * t.r[i].rows); }
+            const dim3 grid(std::min((maxUnits + 1023u) / 1024u, 256u), (unsigned)t.n); // four units per thread, at most 256 blocks per region
+            exchangeCopyKernel<PACK><<<grid, 256, 0, stream>>>(t);
+            if (int rc = hip(hipGetLastError(), "exchange pack / unpack launch")) return rc;
+        }
+        return 0;
+    }
+
+    // tile rendering: pack -> one send / receive per peer -> unpack, on `stream`
+    int postPacked(int id, const plrf_exchange_item* items, uint32_t count, hipStream_t stream) {
+        struct PeerPlan { size_t sendBytes = 0, recvBytes = 0, sendOffset = 0, recvOffset = 0; };
+        std::vector<PeerPlan> peers((size_t)world);
+        struct Piece { uint32_t item; plrf_rect_op op; size_t offset; };
+        std::vector<Piece> pieces;
+        std::vector<plrf_rect_op> ops((size_t)2 * (size_t)std::max(world - 1, 1));
+        auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        for (uint32_t i = 0; i < count; i++) {
+            const plrf_exchange_item& it = items[i];
+            const uint32_t n = planRects(frameWidth, frameHeight, (uint32_t)world, rects.data(), (uint32_t)rank, it.image_cols, it.image_rows, it.halo_rows, ops.data(), (uint32_t)ops.size());
+            for (uint32_t k = 0; k < n && k < ops.size(); k++) {
+                const plrf_rect_op& o = ops[k];
+                const size_t bytes = (size_t)(o.x1 - o.x0) * it.texel_bytes * (o.y1 - o.y0);
+                PeerPlan& pp = peers[o.peer];
+                size_t& total = o.send ? pp.sendBytes : pp.recvBytes;
+                pieces.push_back({i, o, total});
+                total = (total + bytes + 15) & ~(size_t)15; // the next region of this peer's buffer starts 16-byte aligned
+            }
+        }
+        size_t sendTotal = 0, recvTotal = 0;
+        for (PeerPlan& pp : peers) { pp.sendOffset = sendTotal; sendTotal += align(pp.sendBytes); pp.recvOffset = recvTotal; recvTotal += align(pp.recvBytes); }
+        if (sendTotal + recvTotal == 0) { exchanges++; return 0; }
+        if (int rc = arena(sendArena[id], sendTotal)) return rc;
+        if (int rc = arena(recvArena[id], recvTotal)) return rc;
+        std::vector<CopyRegion> packs, unpacks;
+        for (const Piece& pc : pieces) {
+            const plrf_exchange_item& it = items[pc.item];
+            const plrf_rect_op& o = pc.op;
+            CopyRegion r;
+            r.image = (uint8_t*)it.device_ptr + (size_t)o.y0 * it.row_bytes + (size_t)o.x0 * it.texel_bytes;
+            r.buffer = (o.send ? sendArena[id].ptr + peers[o.peer].sendOffset : recvArena[id].ptr + peers[o.peer].recvOffset) + pc.offset;
+            r.pitch = it.row_bytes; r.widthBytes = (o.x1 - o.x0) * it.texel_bytes; r.rows = o.y1 - o.y0;
+            r.unit = ((uintptr_t)r.image % 16 == 0 && r.pitch % 16 == 0 && r.widthBytes % 16 == 0) ? 16u : 4u;
+            if (r.widthBytes % 4u) return xfail(PLR_ERR_UNSUPPORTED, "exchange: texel rows that are no multiple of 4 bytes");
+            (o.send ? packs : unpacks).push_back(r);
+        }
+        if (int rc = launchCopies<true>(packs, stream)) return rc;
+        if (loopback) {
+            // stand-in for the links: the arena's bytes make one trip through the copy path (the texels that "arrive" are this rank's own: timing only)
+            const size_t n = std::min(sendTotal, recvTotal);
+            if (n) if (int rc = hip(hipMemcpyAsync(recvArena[id].ptr, sendArena[id].ptr, n, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(loopback)")) return rc;
+        } else {
+            if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
+            int rc = 0;
+            for (int p = 0; p < world && !rc; p++) {
+                const PeerPlan& pp = peers[(size_t)p];
+                if (pp.sendBytes) rc = nccl(ncclSend(sendArena[id].ptr + pp.sendOffset, pp.sendBytes, ncclUint8, p, comm, stream), "ncclSend");
+                if (pp.recvBytes && !rc) rc = nccl(ncclRecv(recvArena[id].ptr + pp.recvOffset, pp.recvBytes, ncclUint8, p, comm, stream), "ncclRecv");
+            }
+            const int grc = nccl(ncclGroupEnd(), "ncclGroupEnd");
+            if (rc || grc) return rc ? rc : grc;
+        }
+        for (const PeerPlan& pp : peers) { bytesSent += pp.sendBytes; bytesReceived += pp.recvBytes; }
+        exchanges++;
+        return launchCopies<false>(unpacks, stream);
+    }
 
     // all transfers of exchange `id`, one ncclGroup, on `stream`
     int post(int id, hipStream_t stream) {
@@ -103,6 +375,12 @@ struct RcclExchange {
         uint32_t count = 16;
         if (int rc = plrf_get_exchange_items(fp, id, items, &count)) return xfail(rc, plrf_last_error());
         count = std::min(count, 16u);
+        packedRegions = tiledItems(items, count);
+        if (packedRegions) {
+            if (rects.empty()) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: the pipeline renders a tile but the exchange was attached with rows only (plrf_rccl_attach_rects)");
+            return postPacked(id, items, count, stream);
+        }
+        if (loopback) { exchanges++; return 0; } // bands send straight from the images: nothing local to stand in for
         if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
         int rc = 0;
         for (uint32_t i = 0; i < count && !rc; i++) {
@@ -124,49 +402,97 @@ struct RcclExchange {
     int run(int idWithPhase, hipStream_t launchStream) {
         const int id = idWithPhase & PLRF_EXCHANGE_ID_MASK, phase = idWithPhase & (PLRF_EXCHANGE_BEGIN | PLRF_EXCHANGE_END);
         if (id < 0 || id >= PLRF_EXCHANGE_COUNT) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange id out of range");
+        if (int rc = checkWatchdog()) return rc;
         if (id == PLRF_EXCHANGE_HISTOGRAM) {
             bytesSent = bytesReceived = exchanges = 0;
             void* ptr = nullptr;
             size_t bytes = 0;
             if (int rc = plrf_get_histogram_exchange(fp, &ptr, &bytes)) return xfail(rc, plrf_last_error());
+            if (loopback) return 0;
             // 128 bin counts, each < 2^32 pixels in total: the unsigned sum is exact, so every band derives the same exposure
-            return nccl(ncclAllReduce(ptr, ptr, bytes / 4, ncclUint32, ncclSum, comm, launchStream), "ncclAllReduce(histogram)");
+            if (int rc = nccl(ncclAllReduce(ptr, ptr, bytes / 4, ncclUint32, ncclSum, comm, launchStream), "ncclAllReduce(histogram)")) return rc;
+            return watch(id, 0, launchStream);
         }
         if (id == PLRF_EXCHANGE_DEPTH_APEX) {
             // SURVEY 8e, collective 2: {min, max} of the bands' depth ranges -> the apex of the unpartitioned depth pyramid (min / max are exact)
             void* ptr = nullptr;
             size_t bytes = 0;
             if (int rc = plrf_get_depth_apex_exchange(fp, &ptr, &bytes)) return xfail(rc, plrf_last_error());
+            if (loopback) return 0;
             float* f = (float*)ptr;
             if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
             const int r0 = nccl(ncclAllReduce(f, f, 1, ncclFloat, ncclMin, comm, launchStream), "ncclAllReduce(depth min)");
             const int r1 = nccl(ncclAllReduce(f + 1, f + 1, 1, ncclFloat, ncclMax, comm, launchStream), "ncclAllReduce(depth max)");
             const int grc = nccl(ncclGroupEnd(), "ncclGroupEnd");
-            return r0 ? r0 : (r1 ? r1 : grc);
+            if (r0 || r1 || grc) return r0 ? r0 : (r1 ? r1 : grc);
+            return watch(id, 0, launchStream);
         }
         if (phase == PLRF_EXCHANGE_BEGIN) {
-            // When may the transfers start? Rows-first producers (band_overlap_exchange 2): as soon as the launch that is still running has written its edge
-            // rows - the communication stream waits for the backend's edge signal (a word the kernel's last edge wave stores, hipStreamWaitValue32),
-            // NOT for the launch stream. Otherwise (split producers, or no stream memory operations): an event behind the edge launch.
+            // When may the transfers start? Edges-first producers (band_overlap_exchange 2): as soon as the launch that is still running has written its edge
+            // rows / columns - the communication stream waits for the backend's edge signal (a word the kernel's last edge block stores, hipStreamWaitValue32),
+            // NOT for the launch stream. Otherwise (split producers, or no stream memory operations on this device): an event behind the producer.
             void* signal = nullptr;
             uint32_t value = 0;
-            const bool rowsFirst = plrf_band_rows_first(fp) != 0 && plr_get_edge_signal(&signal, &value) == PLR_OK && signal != nullptr && value != lastSignalValue;
+            const bool rowsFirst = plrf_band_rows_first(fp) != 0 && streamWaitValueSupported && plr_get_edge_signal(&signal, &value) == PLR_OK && signal != nullptr && value != lastSignalValue;
             if (rowsFirst) {
                 lastSignalValue = value;
+                lastOverlapMode = 2;
                 if (int rc = hip(hipStreamWaitValue32(commStream, signal, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32")) return rc;
             } else {
+                lastOverlapMode = 1;
                 if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
                 if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
             }
             if (int rc = post(id, commStream)) return rc;
-            return hip(hipEventRecord(done[id], commStream), "hipEventRecord");
+            if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc;
+            dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]);
+            return 0;
         }
         if (phase == PLRF_EXCHANGE_END) return hip(hipStreamWaitEvent(launchStream, done[id], 0), "hipStreamWaitEvent");
-        return post(id, launchStream);
+        if (int rc = post(id, launchStream)) return rc;
+        return watch(id, 0, launchStream);
+    }
+    // an exchange enqueued on the launch stream itself gets no completion event by default: an event record is a barrier packet of ~6 us on the launch stream,
+    // and a launch stream parked in such an exchange shows up anyway - the next overlapped exchange's producer never runs, its edge signal is never raised, and
+    // that BEGIN entry goes overdue (the message says so). PLRF_EXCHANGE_WATCH_INLINE=1 records the event and names the in-line exchange itself.
+    int watch(int id, int phase, hipStream_t stream) {
+        static const bool watchInline = std::getenv("PLRF_EXCHANGE_WATCH_INLINE") && std::atoi(std::getenv("PLRF_EXCHANGE_WATCH_INLINE")) != 0;
+        if (!watchInline || loopback || !dog.deadlineMs || world < 2) return 0;
+        if (int rc = hip(hipEventRecord(done[id], stream), "hipEventRecord")) return rc;
+        dog.arm(rank, id, phase, &RcclExchange::eventDone, &dogArgs[id]);
+        return 0;
     }
 
     static int callback(void* user, int id, void* stream) { return ((RcclExchange*)user)->run(id, (hipStream_t)stream); }
 };
+
+int attachCommon(void* pipeline, const void* unique_id_128_bytes, int rank, int world, RcclExchange* x, void** out_exchange) {
+    x->fp = (FramePipeline*)pipeline;
+    x->rank = rank; x->world = world;
+    x->loopback = unique_id_128_bytes == nullptr;
+    int rc = x->hip(hipGetDevice(&x->device), "hipGetDevice");
+    if (!rc && !x->loopback) {
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id_128_bytes, sizeof(id));
+        rc = x->nccl(ncclCommInitRank(&x->comm, world, id, rank), "ncclCommInitRank");
+    }
+    if (!rc) rc = x->hip(hipStreamCreateWithFlags(&x->commStream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    for (int i = 0; i < PLRF_EXCHANGE_COUNT && !rc; i++) {
+        rc = x->hip(hipEventCreateWithFlags(&x->ready[i], hipEventDisableTiming), "hipEventCreateWithFlags");
+        if (!rc) rc = x->hip(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+    if (!rc) {
+        // stream memory operations (hipStreamWaitValue32 on the producer's edge signal): asked of the device, not assumed
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, x->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        x->streamWaitValueSupported = can;
+    }
+    if (rc) { delete x; return rc; }
+    if (plrf_set_exchange_callback(pipeline, &RcclExchange::callback, x) != PLR_OK) { delete x; return xfail(PLR_ERR_INVALID_ARGUMENT, plrf_last_error()); }
+    x->startWatchdog();
+    *out_exchange = x;
+    return PLR_OK;
+}
 
 } // namespace
 
@@ -203,6 +529,29 @@ int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, u
     return plrf_exchange_plan_rows(frame_height, n_bands, nullptr, band, image_rows, halo_rows, row_begin, row_end, out_ops, out_count);
 }
 
+int plrf_exchange_plan_rects(uint32_t frame_width, uint32_t frame_height, uint32_t world, const uint32_t* rects, uint32_t rank, uint32_t image_cols, uint32_t image_rows,
+                             uint32_t halo, plrf_rect_op* out_ops, uint32_t capacity, uint32_t* out_count) {
+    if (!out_count || (!out_ops && capacity) || rank >= world || image_cols == 0 || image_rows == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_exchange_plan_rects: invalid argument");
+    if (int rc = checkRects(frame_width, frame_height, world, rects, "plrf_exchange_plan_rects")) return rc;
+    *out_count = planRects(frame_width, frame_height, world, (const Rect*)rects, rank, image_cols, image_rows, halo, out_ops, capacity);
+    return PLR_OK;
+}
+
+int plrf_tile_rects(uint32_t frame_width, uint32_t frame_height, uint32_t gx, uint32_t gy, const uint32_t* col_bounds, const uint32_t* row_bounds, uint32_t* out_rects) {
+    if (!out_rects || gx == 0 || gy == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_tile_rects: invalid argument");
+    if (gx > (frame_width + kBandAlignment - 1) / kBandAlignment || gy > (frame_height + kBandAlignment - 1) / kBandAlignment)
+        return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_tile_rects: more tiles than 64-pixel cells");
+    if (int rc = checkBounds(frame_width, gx, col_bounds, "plrf_tile_rects (columns)")) return rc;
+    if (int rc = checkBounds(frame_height, gy, row_bounds, "plrf_tile_rects (rows)")) return rc;
+    for (uint32_t ty = 0; ty < gy; ty++)
+        for (uint32_t tx = 0; tx < gx; tx++) {
+            uint32_t* q = out_rects + 4 * (ty * gx + tx);
+            if (col_bounds) { q[0] = col_bounds[tx]; q[2] = col_bounds[tx + 1]; } else bandRowsOf(frame_width, gx, tx, &q[0], &q[2]);
+            if (row_bounds) { q[1] = row_bounds[ty]; q[3] = row_bounds[ty + 1]; } else bandRowsOf(frame_height, gy, ty, &q[1], &q[3]);
+        }
+    return PLR_OK;
+}
+
 int plrf_rccl_get_unique_id(void* out_128_bytes) {
     static_assert(sizeof(ncclUniqueId) == PLRF_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
     ncclUniqueId id;
@@ -220,21 +569,34 @@ int plrf_rccl_attach_rows(void* pipeline, const void* unique_id_128_bytes, int r
     if (!pipeline || !unique_id_128_bytes || !out_exchange || world < 1 || rank < 0 || rank >= world) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach: invalid argument");
     if (int rc = checkBounds(frame_height, (uint32_t)world, row_bounds, "plrf_rccl_attach_rows")) return rc;
     RcclExchange* x = new RcclExchange();
-    x->fp = (FramePipeline*)pipeline;
-    x->rank = rank; x->world = world; x->frameHeight = frame_height;
+    x->frameHeight = frame_height;
+    x->frameWidth = ((FramePipeline*)pipeline)->settings.width;
     if (row_bounds) x->bounds.assign(row_bounds, row_bounds + world + 1);
-    ncclUniqueId id;
-    std::memcpy(&id, unique_id_128_bytes, sizeof(id));
-    int rc = x->nccl(ncclCommInitRank(&x->comm, world, id, rank), "ncclCommInitRank");
-    if (!rc) rc = x->hip(hipStreamCreateWithFlags(&x->commStream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
-    for (int i = 0; i < PLRF_EXCHANGE_COUNT && !rc; i++) {
-        rc = x->hip(hipEventCreateWithFlags(&x->ready[i], hipEventDisableTiming), "hipEventCreateWithFlags");
-        if (!rc) rc = x->hip(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
+    return attachCommon(pipeline, unique_id_128_bytes, rank, world, x, out_exchange);
+}
+
+int plrf_rccl_attach_rects(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_width, uint32_t frame_height, const uint32_t* rects,
+                           void** out_exchange) {
+    if (!pipeline || !out_exchange || world < 1 || rank < 0 || rank >= world) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach_rects: invalid argument");
+    if (int rc = checkRects(frame_width, frame_height, (uint32_t)world, rects, "plrf_rccl_attach_rects")) return rc;
+    const FramePipeline* fp = (const FramePipeline*)pipeline;
+    const BandSettings& b = fp->settings.band;
+    const uint32_t* mine = rects + 4 * rank;
+    const uint32_t c0 = b.tiled() ? b.colBegin : 0u, c1 = b.tiled() ? b.colEnd : fp->settings.width;
+    if (!b.enabled() || mine[0] != c0 || mine[2] != c1 || mine[1] != b.rowBegin || mine[3] != b.rowEnd || fp->settings.width != frame_width || fp->settings.height != frame_height)
+        return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach_rects: the pipeline was not created with this rank's rectangle");
+    RcclExchange* x = new RcclExchange();
+    x->frameWidth = frame_width; x->frameHeight = frame_height;
+    x->rects.assign((const Rect*)rects, (const Rect*)rects + world);
+    // (whole-row rectangles: the band path needs the row boundaries, which the rectangles carry when they are listed top to bottom)
+    bool rowsOnly = true;
+    for (const Rect& r : x->rects) rowsOnly = rowsOnly && r.x0 == 0 && r.x1 == frame_width;
+    if (rowsOnly) {
+        for (int r = 0; r < world; r++) if ((r == 0 ? 0u : x->rects[(size_t)r - 1].y1) != x->rects[(size_t)r].y0) { delete x; return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach_rects: bands must be listed top to bottom"); }
+        x->bounds.push_back(0);
+        for (const Rect& r : x->rects) x->bounds.push_back(r.y1);
     }
-    if (rc) { delete x; return rc; }
-    if (plrf_set_exchange_callback(pipeline, &RcclExchange::callback, x) != PLR_OK) { delete x; return xfail(PLR_ERR_INVALID_ARGUMENT, plrf_last_error()); }
-    *out_exchange = x;
-    return PLR_OK;
+    return attachCommon(pipeline, unique_id_128_bytes, rank, world, x, out_exchange);
 }
 
 int plrf_rccl_detach(void* pipeline, void* exchange) {
@@ -252,12 +614,25 @@ int plrf_rccl_get_stats(void* exchange, uint64_t* out_bytes_sent, uint64_t* out_
     return PLR_OK;
 }
 
+int plrf_rccl_get_info(void* exchange, plrf_rccl_info* out) {
+    if (!exchange || !out) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_get_info: null argument");
+    RcclExchange* x = (RcclExchange*)exchange;
+    std::memset(out, 0, sizeof(*out));
+    int count = 0, version = 0;
+    if (x->comm && ncclCommCount(x->comm, &count) != ncclSuccess) count = -1;
+    (void)ncclGetVersion(&version);
+    out->rccl_ranks = count; out->rccl_version = version; out->overlap_mode = x->lastOverlapMode; out->packed_regions = x->packedRegions ? 1 : 0;
+    out->stream_wait_value_supported = x->streamWaitValueSupported; out->watchdog_ms = (int32_t)x->dog.deadlineMs;
+    return PLR_OK;
+}
+
 // Moves rows [src_row, src_row + rows) of `image` onto rows [dst_row, dst_row + rows) of the same image with an ncclSend / ncclRecv pair
 // addressed to this rank itself, through the same group / stream / event sequence as a BEGIN + END exchange. A one-GPU box cannot
 // host two ranks (RCCL refuses duplicate devices), so this is how the transport's mechanics are exercised there.
 int plrf_rccl_self_test(void* exchange, void* device_ptr, uint32_t row_bytes, uint32_t src_row, uint32_t dst_row, uint32_t rows, void* launch_stream) {
     if (!exchange || !device_ptr) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_self_test: null argument");
     RcclExchange* x = (RcclExchange*)exchange;
+    if (!x->comm) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_self_test: a loopback exchange has no communicator");
     hipStream_t ls = (hipStream_t)launch_stream;
     const size_t bytes = (size_t)rows * row_bytes;
     if (int rc = x->hip(hipEventRecord(x->ready[1], ls), "hipEventRecord")) return rc;
@@ -269,6 +644,62 @@ int plrf_rccl_self_test(void* exchange, void* device_ptr, uint32_t row_bytes, ui
     if (rc || grc) return rc ? rc : grc;
     if (int rc2 = x->hip(hipEventRecord(x->done[1], x->commStream), "hipEventRecord")) return rc2;
     return x->hip(hipStreamWaitEvent(ls, x->done[1], 0), "hipStreamWaitEvent");
+}
+
+int plrf_rccl_self_test_rect(void* exchange, void* device_ptr, uint32_t pitch_bytes, uint32_t texel_bytes, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t dst_x,
+                             uint32_t dst_y, void* launch_stream) {
+    if (!exchange || !device_ptr || x1 <= x0 || y1 <= y0 || (texel_bytes != 4 && texel_bytes != 8 && texel_bytes != 16)) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_self_test_rect: invalid argument");
+    RcclExchange* x = (RcclExchange*)exchange;
+    hipStream_t ls = (hipStream_t)launch_stream;
+    const size_t bytes = (size_t)(x1 - x0) * texel_bytes * (y1 - y0);
+    if (int rc = x->arena(x->sendArena[1], bytes)) return rc;
+    if (int rc = x->arena(x->recvArena[1], bytes)) return rc;
+    auto region = [&](uint32_t rx, uint32_t ry, uint8_t* buffer) {
+        CopyRegion r;
+        r.image = (uint8_t*)device_ptr + (size_t)ry * pitch_bytes + (size_t)rx * texel_bytes; r.buffer = buffer;
+        r.pitch = pitch_bytes; r.widthBytes = (x1 - x0) * texel_bytes; r.rows = y1 - y0;
+        r.unit = ((uintptr_t)r.image % 16 == 0 && r.pitch % 16 == 0 && r.widthBytes % 16 == 0) ? 16u : 4u;
+        return r;
+    };
+    if (int rc = x->hip(hipEventRecord(x->ready[1], ls), "hipEventRecord")) return rc;
+    if (int rc = x->hip(hipStreamWaitEvent(x->commStream, x->ready[1], 0), "hipStreamWaitEvent")) return rc;
+    if (int rc = x->launchCopies<true>({region(x0, y0, x->sendArena[1].ptr)}, x->commStream)) return rc;
+    if (x->comm) {
+        if (int rc = x->nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
+        int rc = x->nccl(ncclSend(x->sendArena[1].ptr, bytes, ncclUint8, x->rank, x->comm, x->commStream), "ncclSend(self)");
+        if (!rc) rc = x->nccl(ncclRecv(x->recvArena[1].ptr, bytes, ncclUint8, x->rank, x->comm, x->commStream), "ncclRecv(self)");
+        const int grc = x->nccl(ncclGroupEnd(), "ncclGroupEnd");
+        if (rc || grc) return rc ? rc : grc;
+    } else if (int rc = x->hip(hipMemcpyAsync(x->recvArena[1].ptr, x->sendArena[1].ptr, bytes, hipMemcpyDeviceToDevice, x->commStream), "hipMemcpyAsync(loopback)")) return rc;
+    if (int rc = x->launchCopies<false>({region(dst_x, dst_y, x->recvArena[1].ptr)}, x->commStream)) return rc;
+    if (int rc = x->hip(hipEventRecord(x->done[1], x->commStream), "hipEventRecord")) return rc;
+    return x->hip(hipStreamWaitEvent(ls, x->done[1], 0), "hipStreamWaitEvent");
+}
+
+// ---- the watchdog with a caller-supplied completion query (no GPU needed: tests/test_bands.py)
+int plrf_watchdog_create(uint32_t deadline_ms, void** out_watchdog) {
+    if (!out_watchdog) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_watchdog_create: null argument");
+    Watchdog* w = new Watchdog();
+    w->deadlineMs = deadline_ms;
+    *out_watchdog = w;
+    return PLR_OK;
+}
+int plrf_watchdog_destroy(void* watchdog) { delete (Watchdog*)watchdog; return PLR_OK; }
+int plrf_watchdog_arm(void* watchdog, int rank, int exchange_id, int phase, plrf_watchdog_query query, void* user) {
+    if (!watchdog || !query) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_watchdog_arm: null argument");
+    ((Watchdog*)watchdog)->arm(rank, exchange_id, phase, query, user);
+    return PLR_OK;
+}
+int plrf_watchdog_poll(void* watchdog, char* out_message, size_t capacity) {
+    if (!watchdog) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_watchdog_poll: null watchdog");
+    std::string msg;
+    const bool overdue = ((Watchdog*)watchdog)->poll(&msg);
+    if (out_message && capacity) {
+        const size_t n = std::min(capacity - 1, msg.size());
+        std::memcpy(out_message, msg.data(), n);
+        out_message[n] = 0;
+    }
+    return overdue ? 1 : 0;
 }
 
 } // extern "C"

@@ -61,6 +61,7 @@ int plrf_create(const plrf_settings* s, void** out) {
         f.runBloom = s->run_bloom; f.runTonemap = s->run_tonemap;
         f.band.rowBegin = s->band_row_begin; f.band.rowEnd = s->band_row_end; f.band.giHalo = s->band_gi_halo; f.band.giHistoryHalo = s->band_gi_history_halo;
         f.band.colorHalo = s->band_color_halo; f.band.postHalo = s->band_post_halo;
+        f.band.colBegin = s->band_col_begin; f.band.colEnd = s->band_col_end;
         f.runLightMatrix = s->run_light_matrix; f.volumetricsMaxDistance = s->volumetrics_max_distance; f.runSkyLuts = s->run_sky_luts; f.runVolumetrics = s->run_volumetrics; f.band.taaHistoryHalo = s->band_taa_history_halo; f.band.overlapExchange = s->band_overlap_exchange != 0; f.band.rowsFirst = s->band_overlap_exchange >= 2;
         f.sdfDebug.visualisationMode = (SDFVisualisationMode)s->sdf_debug_mode; f.sdfDebug.showCameraTileUsageWithHiZ = s->sdf_debug_tile_usage_with_hiz;
         f.sdfDebug.useInfluenceRadiusForDebug = s->sdf_debug_use_influence_radius;
@@ -128,6 +129,7 @@ int plrf_get_exchange_items(void* p, int id, plrf_exchange_item* out, uint32_t* 
             out[i].image = RenderBackend::toC(it.image);
             fp->backend().getImageDevicePointer(it.image, it.mip, &out[i].device_ptr, &bytes);
             out[i].row_begin = it.rowBegin; out[i].row_end = it.rowEnd; out[i].halo_rows = it.haloRows; out[i].row_bytes = it.rowBytes; out[i].image_rows = it.imageRows;
+            out[i].col_begin = it.colBegin; out[i].col_end = it.colEnd; out[i].image_cols = it.imageCols; out[i].texel_bytes = it.texelBytes;
         }
         *inoutCount = (uint32_t)items.size();
     })

@@ -88,18 +88,24 @@ static ImageDescription desc2D(uint32_t w, uint32_t h, ImageFormat f, ImageUsage
     return d;
 }
 // 8x8 workgroups over a w x h image; rows restricts the dispatch to the workgroup rows touching [rows.begin, rows.end)
-static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows = {}) {
+// cols (tile rendering) does the same for the workgroup columns
+static void dispatch8(ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows = {}, ColRange cols = {}) {
     const uint32_t lo = std::min(rows.begin, h), hi = std::min(rows.end, h);
-    exe.dispatchCount[0] = (uint32_t)std::ceil(w / 8.f);
+    const uint32_t cl = std::min(cols.begin, w), ch = std::min(cols.end, w);
+    exe.dispatchBase[0] = cl / 8;
+    exe.dispatchCount[0] = ch > cl ? (ch + 7) / 8 - cl / 8 : 0;
     exe.dispatchBase[1] = lo / 8;
     exe.dispatchCount[1] = hi > lo ? (hi + 7) / 8 - lo / 8 : 0;
     exe.dispatchCount[2] = 1;
 }
 
-void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo, const std::function<void()>& edgesDone, bool rowsFirst) {
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo, const std::function<void()>& edgesDone, bool rowsFirst, ColRange cols) {
     const uint32_t r0 = std::min(rows.begin, h), r1 = std::min(rows.end, h);
-    if (!edgesDone || halo == 0 || r1 <= r0) {
-        dispatch8(exe, w, h, rows);
+    const uint32_t c0 = std::min(cols.begin, w), c1 = std::min(cols.end, w);
+    const bool tiled = c0 > 0 || c1 < w;
+    // (a tile's producers are one execution each: the split into an edge and an interior execution of round 3 exists for whole rows only)
+    if (!edgesDone || halo == 0 || r1 <= r0 || c1 <= c0 || (tiled && !rowsFirst)) {
+        dispatch8(exe, w, h, rows, cols);
         be.setComputePassExecution(exe);
         if (edgesDone) edgesDone();
         return;
@@ -110,13 +116,24 @@ void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32
     // split points on 16-row boundaries of the image; no edge on a side without a neighbouring band (first / last rows of the image)
     const uint32_t topEnd = r0 == 0 ? r0 : std::min((r0 + halo + 15u) & ~15u, r1);
     const uint32_t bottomBegin = r1 >= h ? r1 : std::max((r1 > halo ? r1 - halo : 0u) & ~15u, topEnd);
-    if (rowsFirst && (topEnd > r0 || bottomBegin < r1)) {
-        // one launch: the kernel takes the edge rows first and the backend raises its edge signal when they are written (plr.h first_rows, workgroup rows of 8)
+    // the same for the columns of a tile: no edge on a side without a neighbouring tile (first / last columns of the image)
+    const uint32_t leftEnd = c0 == 0 ? c0 : std::min((c0 + halo + 15u) & ~15u, c1);
+    const uint32_t rightBegin = c1 >= w ? c1 : std::max((c1 > halo ? c1 - halo : 0u) & ~15u, leftEnd);
+    if (rowsFirst && (topEnd > r0 || bottomBegin < r1 || leftEnd > c0 || rightBegin < c1)) {
+        // one launch: the kernel takes the edge rows (and columns) first and the backend raises its edge signal when they are written (plr.h first_rows / first_cols,
+        // workgroup rows / columns of 8)
         ComputePassExecution e = exe;
-        dispatch8(e, w, h, RowRange{r0, r1});
+        dispatch8(e, w, h, RowRange{r0, r1}, cols);
         e.firstRows[0] = topEnd / 8u;
         e.firstRows[1] = bottomBegin / 8u;
+        if (tiled) { e.firstCols[0] = leftEnd / 8u; e.firstCols[1] = rightBegin / 8u; }
         be.setComputePassExecution(e);
+        edgesDone();
+        return;
+    }
+    if (tiled) { // (edges asked for, none needed: a tile without neighbours)
+        dispatch8(exe, w, h, rows, cols);
+        be.setComputePassExecution(exe);
         edgesDone();
         return;
     }
@@ -167,7 +184,7 @@ void TAA::init(RenderBackend& be, int w, int h, const TAASettings& settings) { /
     m_taaResolveWeightBuffer = m_taaResolveWeightBuffers[0];
 }
 void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                                RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone, bool rowsFirst) const {
+                                RowRange rows, uint32_t edgeRows, const std::function<void()>& edgesDone, bool rowsFirst, ColRange cols) const {
     // TAA.cpp:139-166
     const size_t frameIndexMod2 = fi.mod2();
     const ImageHandle historySrc = m_historyBuffers[frameIndexMod2];
@@ -183,7 +200,7 @@ void TAA::computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, 
     // exposure chain / depth pyramid / culling / trace, which read nothing it writes. Whole-frame rendering only.
     static const bool onTail = std::getenv("PLR_TAA_ON_TAIL") && std::atoi(std::getenv("PLR_TAA_ON_TAIL")) != 0;
     exe.asyncTail = onTail && !edgesDone && rows.begin == 0 && rows.end == 0xffffffffu;
-    recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone, rowsFirst);
+    recordRows(be, exe, td.width, td.height, rows, edgeRows, edgesDone, rowsFirst, cols);
 }
 void TAA::computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
                                        ImageHandle target, RowRange rows) const { // TAA.cpp:85-137
@@ -282,12 +299,20 @@ uint32_t Bloom::requiredSourceHalo(uint32_t height, float radius) {
     return std::max(b0 - c.source.begin, c.source.end - b1);
 }
 
-void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows, bool asyncTail) const { // Bloom.cpp:56-143
+void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows, RowRange applyRows, bool asyncTail, ColRange chainCols,
+                         ColRange applyCols) const { // Bloom.cpp:56-143
     const ImageDescription td = be.getImageDescription(targetImage);
     const int width = (int)td.width, height = (int)td.height;
     // chainRows = rows of the target that hold valid colour (band + exchanged halo); the chain itself only covers the dependency cone of applyRows
     const Cone cone = dependencyCone(applyRows, td.height, settings.radius);
     const bool banded = !(applyRows.begin == 0 && applyRows.end == 0xffffffffu);
+    // tile rendering: the cone of the tile's columns (the footprints are the same in x and y: dependencyCone of a column range and the width)
+    const Cone coneX = dependencyCone(applyCols, td.width, settings.radius);
+    const bool tiled = !(applyCols.begin == 0 && applyCols.end == 0xffffffffu);
+    auto levelCols = [&](ColRange coneCols, int level) {
+        const ColRange valid = scaleRows(chainCols, 1u << level);
+        return ColRange{std::max(coneCols.begin, valid.begin), std::min(coneCols.end, valid.end)};
+    };
     // a halo smaller than the cone (BandSettings::postHalo < requiredSourceHalo): levels stop at the rows derived from valid colour, rows
     // beyond keep what an earlier frame left there (the documented limit of a too-small halo; the default halo covers the cone)
     auto levelRows = [&](RowRange coneRows, int level) {
@@ -304,7 +329,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(i == 0 ? targetImage : downscaleTexture, sourceMip, 1)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th, banded ? levelRows(cone.down[targetMip], targetMip) : RowRange{});
+        dispatch8(exe, tw, th, banded ? levelRows(cone.down[targetMip], targetMip) : RowRange{}, tiled ? levelCols(coneX.down[targetMip], targetMip) : ColRange{});
         exe.asyncTail = asyncTail;
         be.setComputePassExecution(exe);
     }
@@ -317,7 +342,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
         exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, sourceMip, 1), ImageResource(downscaleTexture, sourceMip, 2)};
         int tw, th;
         resolutionFromMip(width, height, targetMip, &tw, &th);
-        dispatch8(exe, tw, th, banded ? levelRows(cone.up[targetMip], targetMip) : RowRange{});
+        dispatch8(exe, tw, th, banded ? levelRows(cone.up[targetMip], targetMip) : RowRange{}, tiled ? levelCols(coneX.up[targetMip], targetMip) : ColRange{});
         exe.pushConstants = dataToCharArray(&settings.radius, sizeof(settings.radius));
         exe.asyncTail = asyncTail;
         be.setComputePassExecution(exe);
@@ -326,7 +351,7 @@ void Bloom::computeBloom(RenderBackend& be, ImageHandle targetImage, const Bloom
     exe.genericInfo.handle = m_applyBloomPass;
     exe.genericInfo.resources.storageImages = {ImageResource(targetImage, 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(upscaleTexture, 0, 1)};
-    dispatch8(exe, width, height, applyRows);
+    dispatch8(exe, width, height, applyRows, applyCols);
     exe.pushConstants = dataToCharArray(&settings.strength, sizeof(settings.strength));
     exe.asyncTail = asyncTail;
     be.setComputePassExecution(exe);
@@ -477,6 +502,10 @@ void SDFGI::sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& de
             const uint32_t lo = std::min(band->traceRows.begin, (uint32_t)targetH), hi = std::min(band->traceRows.end, (uint32_t)targetH);
             exe.dispatchBase[1] = lo / tileRows;
             exe.dispatchCount[1] = hi > lo ? (hi + tileRows - 1) / tileRows - lo / tileRows : 0;
+            // tile rendering: and the workgroups (8 tile columns each) that hold tiles of the tile's trace columns
+            const uint32_t cl = std::min(band->traceCols.begin, (uint32_t)targetW), ch = std::min(band->traceCols.end, (uint32_t)targetW);
+            exe.dispatchBase[0] = cl / tileRows;
+            exe.dispatchCount[0] = ch > cl ? (ch + tileRows - 1) / tileRows - cl / tileRows : 0;
         }
         exe.pushConstants = dataToCharArray(&tileCount, sizeof(tileCount));
         exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_sdfCameraFrustumCulledInstances, true, 0), StorageBufferResource(m_sdfInstanceWorldBBBuffer, true, 1),
@@ -500,8 +529,9 @@ void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps,
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
                                                 StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
-    if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); }, band->rowsFirst);
-    else recordRows(be, exe, td.width, td.height, band ? band->traceRows : RowRange{});
+    if (band && band->exchangeBegin)
+        recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); }, band->rowsFirst, band->traceCols);
+    else recordRows(be, exe, td.width, td.height, band ? band->traceRows : RowRange{}, 0, nullptr, false, band ? band->traceCols : ColRange{});
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTrace); // spatial pass 0 reads neighbouring bands' rays
 }
 
@@ -509,6 +539,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
     const ImageHandle depthSrc = s.halfResTrace ? deps.depthHalfRes : deps.currentFrame.depthBuffer;
     const ImageDescription td = be.getImageDescription(m_indirectDiffuse_Y_SH[1]);
     const RowRange rows = band ? band->traceRows : RowRange{};
+    const ColRange cols = band ? band->traceCols : ColRange{};
     // band rendering: the spatial filter's inputs are valid on the band's rows and the giHalo rows received from each neighbour; a disc sample
     // beyond them is treated like an off-screen sample (ComputePassExecution::validRows, plr.h) instead of reading rows nobody sent
     auto setValidRows = [&](ComputePassExecution& exe) {
@@ -516,6 +547,12 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         const uint32_t r0 = std::min(rows.begin, td.height), r1 = std::min(rows.end, td.height);
         exe.validRows[0] = r0 > band->giHalo ? r0 - band->giHalo : 0u;
         exe.validRows[1] = std::min(r1 + band->giHalo, td.height);
+        // tile rendering: the same for the columns (plr.h valid_cols)
+        const uint32_t c0 = std::min(cols.begin, td.width), c1 = std::min(cols.end, td.width);
+        if (c0 > 0 || c1 < td.width) {
+            exe.validCols[0] = c0 > band->giHalo ? c0 - band->giHalo : 0u;
+            exe.validCols[1] = std::min(c1 + band->giHalo, td.width);
+        }
     };
     {
         ComputePassExecution exe;
@@ -523,7 +560,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 0), ImageResource(m_indirectDiffuse_CoCg[1], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuse_CoCg[0], 0, 3), ImageResource(depthSrc, 0, 4),
                                                    ImageResource(deps.worldSpaceNormals, 0, 5)};
-        dispatch8(exe, td.width, td.height, rows);
+        dispatch8(exe, td.width, td.height, rows, cols);
         setValidRows(exe);
         be.setComputePassExecution(exe);
     }
@@ -536,8 +573,8 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
                                                    ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
                                                    ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
-        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); }, band->rowsFirst);
-        else recordRows(be, exe, td.width, td.height, rows);
+        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); }, band->rowsFirst, cols);
+        else recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols);
     }
     if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
     {
@@ -547,7 +584,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
         setValidRows(exe);
-        recordRows(be, exe, td.width, td.height, rows);
+        recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols);
     }
     // (this exchange is small - 16 rows - and its producer launches a packing pre-pass per dispatch: it is not split / overlapped)
     if (band && band->exchangeWhole) band->exchangeWhole(band->user, ExchangeGiHistory);
@@ -559,7 +596,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 3),
                                                    ImageResource(deps.currentFrame.depthBuffer, 0, 4), ImageResource(deps.depthHalfRes, 0, 5)};
         const ImageDescription fd = be.getImageDescription(m_indirectLightingFullRes_Y_SH);
-        dispatch8(exe, fd.width, fd.height, band ? band->upscaleRows : RowRange{});
+        dispatch8(exe, fd.width, fd.height, band ? band->upscaleRows : RowRange{}, band ? band->upscaleCols : ColRange{});
         be.setComputePassExecution(exe);
     }
 }
@@ -594,7 +631,9 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         const BandSettings& b = s.band;
         if (b.rowEnd > H || b.rowBegin % bandAlignment != 0 || (b.rowEnd % bandAlignment != 0 && b.rowEnd != H))
             throw std::runtime_error("band rows must lie inside the frame and start/end on multiples of 64 (or at the last row)");
-    }
+        if (b.tiled() && (b.colEnd > W || b.colBegin % bandAlignment != 0 || (b.colEnd % bandAlignment != 0 && b.colEnd != W)))
+            throw std::runtime_error("tile columns must lie inside the frame and start/end on multiples of 64 (or at the last column)");
+    } else if (s.band.tiled()) throw std::runtime_error("tile columns without band rows: set rowBegin / rowEnd too");
     for (int i = 0; i < ExchangeCount; i++) {
         m_exchangeCtx[i] = {this, i};
         m_exchangeCtx[ExchangeCount + i] = {this, i | ExchangeBegin};
@@ -886,6 +925,11 @@ void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { //
         if (settings.band.enabled()) { // the band's tile rows; the global histogram is the sum over bands (ExchangeHistogram)
             exe.dispatchBase[1] = tileRows.begin;
             exe.dispatchCount[1] = tileRows.end - tileRows.begin;
+            if (settings.band.tiled()) { // and the tile's tile columns
+                const ColRange tileCols = scaleRows(bandCols(0), histogramTileSizeX);
+                exe.dispatchBase[0] = tileCols.begin;
+                exe.dispatchCount[0] = tileCols.end - tileCols.begin;
+            }
         }
         m_be.setComputePassExecution(exe);
     }
@@ -904,6 +948,8 @@ void FramePipeline::computeColorBufferHistogram(ImageHandle lastFrameColor) { //
         exe.dispatchCount[0] = (uint32_t)std::ceil(W / float(histogramTileSizeX)) * (uint32_t)std::ceil(H / float(histogramTileSizeY));
         exe.dispatchCount[1] = uint32_t(std::ceil(float(nHistogramBins) / binsPerDispatch));
         if (settings.band.enabled()) {
+            // (tile rendering: the per-tile buffer is indexed with the whole frame's stride, so a tile's entries are not one range of it; the combine runs over the
+            //  whole width of the tile's tile rows and the entries of other GPUs' tiles stay what the buffer was created with - zeros: an integer sum)
             const uint32_t tilesX = (uint32_t)std::ceil(W / float(histogramTileSizeX));
             exe.dispatchBase[0] = tileRows.begin * tilesX;
             exe.dispatchCount[0] = (tileRows.end - tileRows.begin) * tilesX;
@@ -935,6 +981,11 @@ void FramePipeline::computeDepthPyramid(ImageHandle depthBuffer) { // RenderFron
             const RowRange groups = scaleRows(bandRows(0), 64);
             exe.dispatchBase[1] = groups.begin;
             exe.dispatchCount[1] = groups.end - groups.begin;
+            if (settings.band.tiled()) {
+                const ColRange groupsX = scaleRows(bandCols(0), 64);
+                exe.dispatchBase[0] = groupsX.begin;
+                exe.dispatchCount[0] = groupsX.end - groupsX.begin;
+            }
         }
     }
     exe.genericInfo.resources.sampledImages = {ImageResource(depthBuffer, 0, 13), ImageResource(m_minMaxDepthPyramid, 0, 15)};
@@ -951,7 +1002,8 @@ void FramePipeline::downscaleDepth(const FrameRenderTargets& currentTarget) { //
     ComputePassExecution exe;
     exe.genericInfo.handle = m_depthDownscalePass;
     // band: the spatial filters sample half-res depth up to giHalo trace rows away, the upscale one more
-    dispatch8(exe, settings.width / 2, settings.height / 2, bandRows(2 * (settings.band.giHalo + settings.band.giHistoryHalo) + 16, 2));
+    const uint32_t depthHalo = 2 * (settings.band.giHalo + settings.band.giHistoryHalo) + 16;
+    dispatch8(exe, settings.width / 2, settings.height / 2, bandRows(depthHalo, 2), bandCols(depthHalo, 2));
     exe.genericInfo.resources.storageImages = {ImageResource(m_depthHalfRes, 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(currentTarget.depthBuffer, 0, 1)};
     m_be.setComputePassExecution(exe);
@@ -969,7 +1021,7 @@ void FramePipeline::computeDeferredShading(ImageHandle colorTarget, const FrameR
                                                ImageResource(m_albedoImage, 0, 22), ImageResource(m_specularImage, 0, 23), ImageResource(m_skyLut, 0, 24)};
     for (uint32_t i = 0; i < (uint32_t)maxSunShadowCascadeCount; i++) exe.genericInfo.resources.sampledImages.push_back(ImageResource(m_shadowMaps[i], 0, 9 + i));
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_volumetricsInfoBuffer, 19)};
-    dispatch8(exe, settings.width, settings.height, bandRows(settings.band.colorHalo));
+    dispatch8(exe, settings.width, settings.height, bandRows(settings.band.colorHalo), bandCols(settings.band.colorHalo));
     m_be.setComputePassExecution(exe);
 }
 
@@ -978,7 +1030,7 @@ void FramePipeline::computeTonemapping(ImageHandle src) { // RenderFrontend.cpp:
     exe.genericInfo.handle = m_tonemappingPass;
     exe.genericInfo.resources.storageImages = {ImageResource(m_be.getSwapchainInputImage(), 0, 0)};
     exe.genericInfo.resources.sampledImages = {ImageResource(src, 0, 1)};
-    dispatch8(exe, settings.width, settings.height, bandRows(0));
+    dispatch8(exe, settings.width, settings.height, bandRows(0), bandCols(0));
     exe.asyncTail = asyncPostTail();
     m_be.setComputePassExecution(exe);
 }
@@ -995,9 +1047,17 @@ void FramePipeline::computeDepthApexOfTiles() {
         rows = scaleRows(bandRows(0), 64); // 64 full-resolution rows per texel of that level
         rows.end = std::min(rows.end, levelRows);
     }
-    exe.dispatchCount[0] = 1; exe.dispatchCount[2] = 1;
+    exe.dispatchCount[0] = 1; exe.dispatchCount[2] = 1; // (one workgroup from column 0: whole rows)
     exe.dispatchBase[1] = rows.begin;
     exe.dispatchCount[1] = rows.end - rows.begin;
+    if (settings.band.enabled() && settings.band.tiled()) { // the tile's texel columns of that level
+        const uint32_t levelCols = std::max((settings.width / 2) >> top, 1u);
+        ColRange cols = scaleRows(bandCols(0), 64);
+        cols.end = std::min(cols.end, levelCols);
+        exe.dispatchBase[0] = cols.begin;
+        exe.dispatchCount[0] = cols.end - cols.begin;
+        // (a one-column tile from column 0 would read as "whole rows": only possible when the level has one column, where it IS whole rows)
+    }
     exe.genericInfo.resources.sampledImages = {ImageResource(m_minMaxDepthPyramid, top, 0)};
     exe.genericInfo.resources.storageImages = {ImageResource(m_bandDepthApex, 0, 1)};
     m_be.setComputePassExecution(exe);
@@ -1128,6 +1188,13 @@ RowRange FramePipeline::bandRows(uint32_t halo, uint32_t divisor) const {
     return {lo / divisor, (hi + divisor - 1) / divisor};
 }
 
+ColRange FramePipeline::bandCols(uint32_t halo, uint32_t divisor) const {
+    if (!settings.band.enabled() || !settings.band.tiled()) return {};
+    const uint32_t lo = settings.band.colBegin > halo ? settings.band.colBegin - halo : 0;
+    const uint32_t hi = std::min(settings.band.colEnd + halo, settings.width);
+    return {lo / divisor, (hi + divisor - 1) / divisor};
+}
+
 void FramePipeline::addExchangeItem(int id, ImageHandle image, uint32_t divisor, uint32_t haloRows) {
     const ImageDescription d = m_be.getImageDescription(image);
     ExchangeItem it;
@@ -1140,6 +1207,10 @@ void FramePipeline::addExchangeItem(int id, ImageHandle image, uint32_t divisor,
     void* ptr = nullptr;
     m_be.getImageDevicePointer(image, 0, &ptr, &bytes);
     it.rowBytes = (uint32_t)(bytes / d.height);
+    it.imageCols = d.width;
+    it.texelBytes = it.rowBytes / std::max(d.width, 1u);
+    it.colBegin = settings.band.tiled() ? settings.band.colBegin / divisor : 0u;
+    it.colEnd = settings.band.tiled() ? std::min((settings.band.colEnd + divisor - 1) / divisor, d.width) : d.width;
     m_exchangeItems[id].push_back(it);
 }
 
@@ -1228,6 +1299,8 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             GiBand gb;
             gb.traceRows = bandRows(0, div);
             gb.upscaleRows = bandRows(settings.band.colorHalo);
+            gb.traceCols = bandCols(0, div);
+            gb.upscaleCols = bandCols(settings.band.colorHalo);
             gb.user = this;
             gb.giHalo = settings.band.giHalo; gb.giHistoryHalo = settings.band.giHistoryHalo;
             gb.rowsFirst = settings.band.rowsFirst;
@@ -1281,9 +1354,9 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
                 if (bloomOn) addExchangeItem(ExchangePost, m_postProcessBuffers[1], 1, settings.band.postHalo);
                 addExchangeItem(ExchangePost, m_taa.historyDst(m_frameIndex), 1, settings.band.taaHistoryHalo);
                 exchangePoint(ExchangePost | ExchangeBegin, "Exchange: resolved colour halo rows (start)");
-            }, settings.band.rowsFirst);
+            }, settings.band.rowsFirst, bandCols(0));
             postExchangeStarted = true;
-        } else m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0));
+        } else m_taa.computeTemporalFilter(m_be, m_frameIndex, currentSrc, currentRenderTarget, m_postProcessBuffers[1], bandRows(0), 0, nullptr, false, bandCols(0));
         currentSrc = m_postProcessBuffers[1];
     }
     if (band) {
@@ -1297,7 +1370,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
     // the bloom chain and the tonemap are the frame's asynchronous tail (plr.h async_tail): nothing reads their outputs before the next frame's TAA
     // resolve, and their ten short launches leave the chip mostly idle - they run beside the next frame's exposure / GI / shade passes. In band
     // rendering too: the exchange callbacks are recorded with the images they move (exchangePoint), and only the resolved-colour exchange shares one.
-    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0), asyncPostTail());
+    if (settings.runBloom && settings.bloom.enabled) m_bloom.computeBloom(m_be, currentSrc, settings.bloom, bandRows(settings.band.postHalo), bandRows(0), asyncPostTail(), bandCols(settings.band.postHalo), bandCols(0));
     if (settings.runTonemap) computeTonemapping(currentSrc);
 }
 

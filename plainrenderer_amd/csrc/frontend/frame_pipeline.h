@@ -60,8 +60,14 @@ struct FrameRenderTargets { ImageHandle colorBuffer, motionBuffer, depthBuffer; 
 // but records dispatches (ComputePassExecution::dispatchBase) only for the rows it owns plus the halo a later pass reads, and
 // calls the exchange callback where a pass reads rows a neighbouring band produced (DESIGN.md "Multi-GPU").
 struct RowRange { uint32_t begin = 0, end = 0xffffffffu; }; // pixel rows of a pass's output image; default = all rows
+typedef RowRange ColRange;                                   // the same for pixel columns (tile rendering)
 struct BandSettings {
     uint32_t rowBegin = 0, rowEnd = 0;  // owned full-resolution rows [rowBegin, rowEnd); rowEnd == 0: band rendering off
+    // tile rendering (round 5; BASELINE config 5's 2 x 2 screen tiles): the band is cut in columns too - this instance owns columns [colBegin, colEnd)
+    // of its rows (multiples of 64, or the last column). colEnd == 0: whole rows (a band). Every halo below is the same number of COLUMNS on the sides
+    // that have a neighbour; the passes are restricted to the tile's columns through ComputePassExecution::dispatchBase[0] (plr.h valid_cols / first_cols)
+    uint32_t colBegin = 0, colEnd = 0;
+    bool tiled() const { return colEnd > colBegin; }
     uint32_t giHalo = 64;               // trace-resolution rows of the GI images exchanged before each spatial filter pass
     uint32_t giHistoryHalo = 16;        // trace-resolution rows of the filtered GI exchanged for the upscale / next frame's reprojection
     uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
@@ -86,7 +92,10 @@ enum ExchangePhase : int { ExchangeBegin = 0x100, ExchangeEnd = 0x200, ExchangeI
 enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeDepthApex = 5, ExchangeCount = 6 };
 // one image whose rows next to the band must be refreshed from the neighbours: this band sends its first / last haloRows owned
 // rows up / down and receives [rowBegin - haloRows, rowBegin) and [rowEnd, rowEnd + haloRows) (clipped to the image)
-struct ExchangeItem { ImageHandle image; uint32_t mip = 0; uint32_t rowBegin = 0, rowEnd = 0, haloRows = 0, rowBytes = 0, imageRows = 0; };
+// tile rendering: the owned rectangle is columns [colBegin, colEnd) of those rows (imageCols texels of texelBytes bytes per row), the halo is haloRows texels wide
+// on every side with a neighbour (corners included)
+struct ExchangeItem { ImageHandle image; uint32_t mip = 0; uint32_t rowBegin = 0, rowEnd = 0, haloRows = 0, rowBytes = 0, imageRows = 0;
+                      uint32_t colBegin = 0, colEnd = 0, imageCols = 0, texelBytes = 0; };
 typedef int (*ExchangeCallback)(void* user, int exchangeId, void* hipStream);
 
 // ---- Techniques/TAA.h
@@ -137,7 +146,7 @@ class TAA {
 public:
     void init(RenderBackend& be, int imageWidth, int imageHeight, const TAASettings& settings);
     void computeTemporalFilter(RenderBackend& be, const FrameIndexCounter& fi, ImageHandle colorSrc, const FrameRenderTargets& currentFrame, ImageHandle target,
-                               RowRange rows = {}, uint32_t edgeRows = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false) const;
+                               RowRange rows = {}, uint32_t edgeRows = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false, ColRange cols = {}) const;
     ImageHandle historyDst(const FrameIndexCounter& fi) const { return m_historyBuffers[(fi.mod2() + 1) % 2]; }
     // TAASettings::useSeparateSupersampling (TAA.cpp:85-137): luminance of the current frame, then a 2-frame blend with contrast / depth rejection
     void computeTemporalSuperSampling(RenderBackend& be, const FrameIndexCounter& fi, const FrameRenderTargets& currentFrame, const FrameRenderTargets& lastFrame,
@@ -159,8 +168,11 @@ public:
     void init(RenderBackend& be);
     // applyRows: rows bloom is applied to (band rendering; default all). The chain is recorded over the dependency cone of those rows;
     // chainRows: rows of the target image that hold valid colour (the band and the exchanged halo) - must cover the cone's source rows
-    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}, bool asyncTail = false) const;
+    // chainCols / applyCols: the same for columns (tile rendering): the chain covers the dependency cone of the tile in both directions
+    void computeBloom(RenderBackend& be, ImageHandle targetImage, const BloomSettings& settings, RowRange chainRows = {}, RowRange applyRows = {}, bool asyncTail = false,
+                      ColRange chainCols = {}, ColRange applyCols = {}) const;
     struct Cone { RowRange up[6], down[6], source; }; // rows of every level (in the level's own rows) / of the source image the result depends on
+    // (the chain is separable in its footprints: the same function of a column range and the image width gives the cone's columns)
     static Cone dependencyCone(RowRange applyRows, uint32_t height, float radius);
     static uint32_t requiredSourceHalo(uint32_t height, float radius); // full-resolution rows of scene colour a band needs beyond its own
 private:
@@ -172,6 +184,7 @@ private:
 struct GiBand {
     RowRange traceRows;    // trace-resolution rows traced and filtered
     RowRange upscaleRows;  // full-resolution rows of the upscale
+    ColRange traceCols, upscaleCols; // tile rendering: the same for columns (default: whole rows)
     void* user = nullptr;
     void (*exchangePoint)(void* user, int exchangeId) = nullptr; // records the exchange (or, with overlap, the wait for it) as a host callback execution
     void (*exchangeBegin)(void* user, int exchangeId) = nullptr; // overlap: records the start of the exchange; null = no overlap
@@ -181,7 +194,9 @@ struct GiBand {
 };
 // records exe over `rows` of a w x h image; with edgesDone the first / last `halo` rows are recorded first, then edgesDone(), then the rest
 // rowsFirst: ONE execution over all the rows with first_rows = the edges (plr.h), then edgesDone()
-void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false);
+// cols: the columns of the rectangle (tile rendering); with rowsFirst its edge columns belong to the edge as well (plr.h first_cols)
+void recordRows(RenderBackend& be, ComputePassExecution& exe, uint32_t w, uint32_t h, RowRange rows, uint32_t halo = 0, const std::function<void()>& edgesDone = nullptr, bool rowsFirst = false,
+                ColRange cols = {});
 
 struct SDFTraceDependencies {
     FrameRenderTargets currentFrame, previousFrame;
@@ -312,6 +327,7 @@ private:
     void setCameraExtrinsic(const CameraExtrinsic& extrinsic);
     void updateGlobalShaderInfo(float deltaTime, float time);
     RowRange bandRows(uint32_t halo, uint32_t divisor = 1) const;
+    ColRange bandCols(uint32_t halo, uint32_t divisor = 1) const; // the tile's columns + halo at 1 / divisor resolution; whole rows when the band is not tiled
     void exchangePoint(int exchangeId, const char* label);
     void addExchangeItem(int exchangeId, ImageHandle image, uint32_t divisor, uint32_t haloRows);
     static int exchangeTrampoline(void* user, void* stream);

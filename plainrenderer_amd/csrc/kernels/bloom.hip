@@ -29,8 +29,8 @@ PLR_DI vec3 bloomTap(const ImgView& im, float u, float v) {
 }
 
 // bloomDownsample.comp:12-49
-__global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) {
+    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float uvx = ((float)x + 0.5f) / (float)target.w, uvy = ((float)y + 0.5f) / (float)target.h;
@@ -52,20 +52,21 @@ __global__ __launch_bounds__(256) void bloomDownsampleKernel(ImgView source, Img
     ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
 }
 
-// columns [0, w) and rows [y0, h) of the target covered by the recorded dispatch
-static int coverage(const PassCtx& c, const ImgView& target, int* w, int* h, int* y0) {
-    *w = std::min((int)(c.dispatch[0] * 8u), target.w);
+// columns [x0, w) and rows [y0, h) of the target covered by the recorded dispatch
+static int coverage(const PassCtx& c, const ImgView& target, int* w, int* h, int* y0, int* x0) {
+    const PassCtx::ColSpan cs = c.colSpan(target.w);
+    *w = cs.x1; *x0 = cs.x0;
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
     *h = rs.y1; *y0 = rs.y0;
-    return (*w > 0 && *h > *y0) ? 1 : 0;
+    return (*w > *x0 && *h > *y0) ? 1 : 0;
 }
 
 static int launchBloomDownsample(const PassCtx& c) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomDownsample target")) return rc;
     if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
-    int w, h, y0;
-    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
-    bloomDownsampleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], c.storage[0], w, h, y0);
+    int w, h, y0, x0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0, &x0)) return 0;
+    bloomDownsampleKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], c.storage[0], w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -73,8 +74,8 @@ PLR_REGISTER_SHADER("bloomDownsample.comp", launchBloomDownsample);
 
 // bloomUpsample.comp:19-57
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void bloomUpsampleKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase, int xBase) {
+    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
@@ -107,11 +108,11 @@ static int launchBloomUpsample(const PassCtx& c) {
     if (c.push.size() < 4) return c.fail(-1, "bloomUpsample: push constant blurRadius missing");
     float blurRadius;
     std::memcpy(&blurRadius, c.push.data(), 4);
-    int w, h, y0;
-    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
-    if (lowest) bloomUpsampleKernel<true><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[2], c.storage[0], blurRadius, w, h, y0);
-    else bloomUpsampleKernel<false><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[1], c.storage[0], blurRadius, w, h, y0);
+    int w, h, y0, x0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0, &x0)) return 0;
+    const dim3 grid(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u));
+    if (lowest) bloomUpsampleKernel<true><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[2], c.storage[0], blurRadius, w, h, y0, x0);
+    else bloomUpsampleKernel<false><<<grid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[1], c.storage[0], blurRadius, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -119,8 +120,8 @@ PLR_REGISTER_SHADER("bloomUpsample.comp", launchBloomUpsample);
 
 // applyBloom.comp:16-30: target = mix(scene, bloom, strength), in place. The bloom image has the target's size, so the
 // bilinear tap sits on a texel centre; it is still evaluated through the sampler path for exactness.
-__global__ __launch_bounds__(256) void applyBloomKernel(ImgView target, ImgView bloom, float bloomStrength, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void applyBloomKernel(ImgView target, ImgView bloom, float bloomStrength, int coverW, int coverH, int yBase, int xBase) {
+    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const float uvx = ((float)x + 0.5f) / (float)target.w, uvy = ((float)y + 0.5f) / (float)target.h;
@@ -136,9 +137,9 @@ static int launchApplyBloom(const PassCtx& c) {
     if (c.push.size() < 4) return c.fail(-1, "applyBloom: push constant bloomStrength missing");
     float strength;
     std::memcpy(&strength, c.push.data(), 4);
-    int w, h, y0;
-    if (!coverage(c, c.storage[0], &w, &h, &y0)) return 0;
-    applyBloomKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], strength, w, h, y0);
+    int w, h, y0, x0;
+    if (!coverage(c, c.storage[0], &w, &h, &y0, &x0)) return 0;
+    applyBloomKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.sampled[1], strength, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

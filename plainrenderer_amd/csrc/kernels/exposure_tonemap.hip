@@ -75,14 +75,14 @@ int launchHistogramExactBins(uint8_t* out, uint32_t first, uint32_t count, uint3
 // Unlike the reference, out-of-image invocations still reach the barriers; the observable rule is kept:
 // bin b of a tile is written back only if the reference invocation with localIndexFlat == b lies inside the image.
 __global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const LightBuffer* __restrict__ light, uint32_t* __restrict__ perTile,
-                                                              uint32_t nBins, float minLuminanceLog, float maxLuminanceLog, uint32_t tilesX, uint32_t tileY0) {
+                                                              uint32_t nBins, float minLuminanceLog, float maxLuminanceLog, uint32_t tilesX, uint32_t tileY0, uint32_t tileX0) {
     extern __shared__ uint32_t localHistogram[];
     const uint32_t t = threadIdx.x;
-    const uint32_t tileY = blockIdx.y + tileY0;
+    const uint32_t tileY = blockIdx.y + tileY0, tileX = blockIdx.x + tileX0; // (tileX0: tile rendering, PassCtx::colSpan)
     for (uint32_t b = t; b < nBins; b += 256u) localHistogram[b] = 0u;
     __syncthreads();
 
-    const int x0 = (int)blockIdx.x * 32 + (int)(t & 7u) * 4;
+    const int x0 = (int)tileX * 32 + (int)(t & 7u) * 4;
     const int y = (int)tileY * 32 + (int)(t >> 3);
     const float prevExposure = light->previousFrameExposure;
     const uint32_t maxIndex = nBins - 1u;
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256) void histogramPerTileKernel(ImgView src, const
     }
     __syncthreads();
 
-    const uint32_t tileIndex = blockIdx.x + tileY * tilesX;
+    const uint32_t tileIndex = tileX + tileY * tilesX;
     for (uint32_t b = t; b < nBins && b < 1024u; b += 256u) {
-        const int rx = (int)blockIdx.x * 32 + (int)(b & 31u), ry = (int)tileY * 32 + (int)(b >> 5);
+        const int rx = (int)tileX * 32 + (int)(b & 31u), ry = (int)tileY * 32 + (int)(b >> 5);
         if (rx < src.w && ry < src.h) perTile[(size_t)tileIndex * nBins + b] = localHistogram[b];
     }
 }
@@ -145,11 +145,13 @@ static int launchHistogramPerTile(const PassCtx& c) {
     // host-side log of the two specialisation constants with the same deterministic routine (exact same bits as device)
     const PassCtx::RowSpan rs = c.rowSpan((int)tilesY, 1); // tile rows [y0, y1) of the recorded dispatch (one workgroup per tile)
     if (rs.y1 <= rs.y0) return 0;
-    const dim3 grid(std::min(c.dispatch[0], tilesX), (unsigned)(rs.y1 - rs.y0));
+    const PassCtx::ColSpan cs = c.colSpan((int)tilesX, 1); // tile columns of the recorded dispatch
+    if (cs.x1 <= cs.x0) return 0;
+    const dim3 grid((unsigned)(cs.x1 - cs.x0), (unsigned)(rs.y1 - rs.y0));
     if (!(minL > 0.f) || !(maxL > 0.f)) return c.fail(-1, "histogramPerTile: luminance range must be positive");
     const float logs[2] = {hostDetLog(minL), hostDetLog(maxL)};
     histogramPerTileKernel<<<grid, 256, nBins * sizeof(uint32_t), c.stream>>>(src, (const LightBuffer*)c.sbuf[3].ptr, (uint32_t*)c.sbuf[0].ptr,
-                                                                               nBins, logs[0], logs[1], tilesX, (uint32_t)rs.y0);
+                                                                               nBins, logs[0], logs[1], tilesX, (uint32_t)rs.y0, (uint32_t)cs.x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -520,8 +522,8 @@ PLR_DI uint32_t tonemapPixel(uint32_t texel, int x, int y, float time) {
 }
 
 template <bool BGRA>
-__global__ __launch_bounds__(256) void tonemappingKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
-    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+__global__ __launch_bounds__(256) void tonemappingKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase) {
+    const int x0 = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4; // columns [xBase, coverW): xBase is a multiple of 8 (PassCtx::colSpan)
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (y >= coverH || x0 >= coverW) return;
     const float time = g->time;
@@ -557,13 +559,14 @@ static int launchTonemapping(const PassCtx& c) {
     if (dst.fmt != F_BGRA8 && dst.fmt != F_RGBA8) return c.fail(-4, "tonemapping imageOut must be BGRA8_uNorm or RGBA8");
     // invocations exist for dispatch*8 pixels; stores outside the target are dropped, fetches outside the source are
     // undefined in the reference, so the covered region is clipped to both images
-    const int coverW = std::min({(int)(c.dispatch[0] * 8u), dst.w, src.w});
+    const PassCtx::ColSpan cs = c.colSpan(std::min(dst.w, src.w));
+    const int coverW = cs.x1, xBase = cs.x0; // columns [xBase, coverW)
     const PassCtx::RowSpan rs = c.rowSpan(std::min(dst.h, src.h));
     const int coverH = rs.y1, y0 = rs.y0; // rows [y0, coverH)
-    if (coverW <= 0 || coverH <= y0) return 0;
-    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)(coverH - y0), 4u));
-    if (dst.fmt == F_BGRA8) tonemappingKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
-    else tonemappingKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
+    if (coverW <= xBase || coverH <= y0) return 0;
+    const dim3 grid(divUp((unsigned)(coverW - xBase), 256u), divUp((unsigned)(coverH - y0), 4u));
+    if (dst.fmt == F_BGRA8) tonemappingKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0, xBase);
+    else tonemappingKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0, xBase);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

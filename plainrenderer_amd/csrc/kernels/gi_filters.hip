@@ -22,7 +22,8 @@ PLR_DI vec3 pixelToWorld(vec2 uv, const ImgView& depthTexture, const GlobalUbo* 
 // filterIndirectDiffuseSpatial.comp:30-135
 template <int DEPTH_FMT>
 __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
-                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase, int validY0, int validY1) {
+                                                           const GlobalUbo* __restrict__ g, int filterIndex, int coverW, int coverH, int yBase, int validY0, int validY1, int xBase, int validX0,
+                                                           int validX1) {
     __shared__ float sqrtRand[32], cosA[32], sinA[32];
     if (threadIdx.x < 64) {
         // lane i replays the xorshift sequence up to its own pair of draws (2*i + 2 steps at most 64: negligible)
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgVi
         }
     }
     __syncthreads();
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 texelSize(1.f / (float)outYSH.w, 1.f / (float)outYSH.h);
@@ -75,10 +76,11 @@ __global__ __launch_bounds__(256) void spatialFilterKernel(ImgView outYSH, ImgVi
         // sample through the pixel's row instead was measured at 8K in four bands: 97.2 % of a band's pixels within one code of the unpartitioned
         // frame after three frames against 98.6 % for the plain drop - the reflected texel is a worse stand-in than a renormalised smaller disc.)
         const int sampleRow = clampi((int)floorf(saneCoord(sampleUV.y * (float)inYSH.h)), inYSH.h);
+        const int sampleCol = clampi((int)floorf(saneCoord(sampleUV.x * (float)inYSH.w)), inYSH.w); // (tile rendering: PassCtx::validCols, the same rule for columns)
         if (sampleUV.x < 0.f || sampleUV.y < 0.f || sampleUV.x > 1.f || sampleUV.y > 1.f) {
             weight = 0.f;
             lengthModifier *= 0.98f;
-        } else if (sampleRow < validY0 || sampleRow >= validY1) {
+        } else if (sampleRow < validY0 || sampleRow >= validY1 || sampleCol < validX0 || sampleCol >= validX1) {
             // round 4: weight 0, but the disc does not shrink for the samples after it - the off-screen rule exists because the screen ends there; this row
             // exists, another GPU has it. Measured over 16 frames at 8K in four bands (profiles/r04_config5_series.txt): closer to the unpartitioned frame
             // in every band and frame (worst band after three frames 99.51 % within one code against 99.34 %)
@@ -114,16 +116,19 @@ static int launchSpatialFilter(const PassCtx& c) {
     const int filterIndex = c.specInt(0, 0);
     const ImgView& out = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u));
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0; // columns [x0, w), rows [y0, h)
+    if (w <= x0 || h <= y0) return 0;
+    const dim3 grid(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u));
     // depth is the half-res R16F copy for a half-res trace, the D32 depth buffer otherwise (Techniques/SDFGI.cpp:423)
     int validY0, validY1;
     c.validRowRange(c.sampled[2].h, &validY0, &validY1);
+    int validX0, validX1;
+    c.validColRange(c.sampled[2].w, &validX0, &validX1);
     if (c.sampled[4].fmt == F_R16F)
-        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1);
+        spatialFilterKernel<F_R16F><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1, x0, validX0, validX1);
     else if (c.sampled[4].fmt == F_D32)
-        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1);
+        spatialFilterKernel<F_D32><<<grid, 256, 0, c.stream>>>(out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, filterIndex, w, h, y0, validY0, validY1, x0, validX0, validX1);
     else return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
     PLR_CHECK_LAUNCH(c);
     return 0;
@@ -134,8 +139,8 @@ PLR_REGISTER_SHADER("filterIndirectDiffuseSpatial.comp", launchSpatialFilter);
 // filterIndirectDiffuseTemporal.comp:20-86
 __global__ __launch_bounds__(256) void temporalGiFilterKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                               ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
-                                                              ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                              ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase) {
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 texelSize(1.f / (float)targetYSH.w, 1.f / (float)targetYSH.h);
@@ -197,10 +202,11 @@ static int launchTemporalGiFilter(const PassCtx& c) {
     if (int rc = c.needSampled(9, F_RG16SN, "filterIndirectDiffuseTemporal velocityLastFrame")) return rc;
     const ImgView& out = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
-    temporalGiFilterKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(
-        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0);
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0; // columns [x0, w), rows [y0, h)
+    if (w <= x0 || h <= y0) return 0;
+    temporalGiFilterKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(
+        c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -209,8 +215,8 @@ PLR_REGISTER_SHADER("filterIndirectDiffuseTemporal.comp", launchTemporalGiFilter
 // ------------------------------------------------------------------------------------------------
 // indirectLightUpscale.comp:17-71
 __global__ __launch_bounds__(256) void indirectLightUpscaleKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                  ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                                  ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase) {
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 uv(((float)px + 0.5f) / (float)g->screenResolution[0], ((float)py + 0.5f) / (float)g->screenResolution[1]);
@@ -261,10 +267,11 @@ static int launchIndirectLightUpscale(const PassCtx& c) {
     if (int rc = c.needSampled(5, F_R16F, "indirectLightUpscale halfResDepth")) return rc;
     const ImgView& out = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
-    indirectLightUpscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
-                                                                                                          c.sampled[4], c.sampled[5], c.global, w, h, y0);
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0; // columns [x0, w), rows [y0, h)
+    if (w <= x0 || h <= y0) return 0;
+    indirectLightUpscaleKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
+                                                                                                                 c.sampled[4], c.sampled[5], c.global, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void hizBaseKernel(HizParams p) {
     int lox[kHizBaseLevels], loy[kHizBaseLevels], hix[kHizBaseLevels], hiy[kHizBaseLevels], needx[kHizBaseLevels], needy[kHizBaseLevels];
     for (int l = 0; l < K; l++) {
         const int t = 32 >> l;
-        lox[l] = (int)blockIdx.x * t; loy[l] = ((int)blockIdx.y + p.tileY0) * t;
+        lox[l] = ((int)blockIdx.x + p.tileX0) * t; loy[l] = ((int)blockIdx.y + p.tileY0) * t;
         hix[l] = min(lox[l] + t, p.w[l]) - 1; hiy[l] = min(loy[l] + t, p.h[l]) - 1;
     }
     needx[K - 1] = hix[K - 1]; needy[K - 1] = hiy[K - 1];
@@ -143,8 +143,13 @@ static int launchDepthHiZPyramid(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows ? PassCtx::RowSpan{0, tileRows} : c.rowSpan(tileRows, 1);
     if (rs.y1 <= rs.y0) return 0;
     p.tileY0 = rs.y0;
-    const bool wholePyramid = rs.y0 == 0 && rs.y1 == tileRows;
-    const dim3 grid(divUp((unsigned)p.w[0], 32u), (unsigned)(rs.y1 - rs.y0));
+    // tile columns of the dispatch (tile rendering); a dispatch from column 0 that covers every tile column is the whole width, whatever its count
+    const int tileCols = (int)divUp((unsigned)p.w[0], 32u);
+    const PassCtx::ColSpan cs = c.base[0] == 0 && (int)c.dispatch[0] >= tileCols ? PassCtx::ColSpan{0, tileCols} : c.colSpan(tileCols, 1);
+    if (cs.x1 <= cs.x0) return 0;
+    p.tileX0 = cs.x0;
+    const bool wholePyramid = rs.y0 == 0 && rs.y1 == tileRows && cs.x0 == 0 && cs.x1 == tileCols;
+    const dim3 grid((unsigned)(cs.x1 - cs.x0), (unsigned)(rs.y1 - rs.y0));
     // LDS regions of the worst block: per axis count[l-1] = max(tile, 2 * count[l] + (source size odd)), see the need[] recursion in the kernel
     int cx[kHizBaseLevels], cy[kHizBaseLevels];
     const int K = p.baseCount;
@@ -174,14 +179,15 @@ PLR_REGISTER_SHADER("depthHiZPyramid.comp", launchDepthHiZPyramid);
 // level that belong to the band - .r = min, .g = max, the pyramid's own rule (depthHiZPyramid.comp:52-124: the sky is already mapped out of .r
 // by level 0) - into a 1 x 1 RG32F image; the bands' results are then combined by an all-reduce (min on .r, max on .g: SURVEY 8e, collective 2).
 // min / max are associative and exact, so the combined value equals the apex of the unpartitioned chain bit for bit.
-// Bindings: sampled 0 = pyramid level (RG32F), storage 1 = apex (RG32F, 1 x 1); the dispatch's rows are texel rows of that level.
-__global__ __launch_bounds__(256) void depthPyramidApexKernel(ImgView level, int row0, int row1, float2* __restrict__ apex) {
+// Bindings: sampled 0 = pyramid level (RG32F), storage 1 = apex (RG32F, 1 x 1); the dispatch's rows are texel rows of that level; its x range (base, count) is
+// the texel columns of a TILE (round 5), a count of one workgroup from column 0 means whole rows.
+__global__ __launch_bounds__(256) void depthPyramidApexKernel(ImgView level, int row0, int row1, int col0, int col1, float2* __restrict__ apex) {
     __shared__ float smin[4], smax[4];
     const float2* t = (const float2*)level.ptr;
-    const int n = (row1 - row0) * level.w;
+    const int cols = col1 - col0, n = (row1 - row0) * cols;
     float mn = __builtin_huge_valf(), mx = -__builtin_huge_valf();
     for (int i = (int)threadIdx.x; i < n; i += 256) {
-        const float2 v = t[(size_t)row0 * (size_t)level.w + (size_t)i];
+        const float2 v = t[(size_t)(row0 + i / cols) * (size_t)level.w + (size_t)(col0 + i % cols)];
         mn = fminf(mn, v.x);
         mx = fmaxf(mx, v.y);
     }
@@ -199,7 +205,10 @@ static int launchDepthPyramidApex(const PassCtx& c) {
     const ImgView& level = c.sampled[0];
     const PassCtx::RowSpan rs = c.rowSpan(level.h, 1);
     if (rs.y1 <= rs.y0) return c.fail(-1, "depthPyramidApex: no rows to reduce");
-    depthPyramidApexKernel<<<1, 256, 0, c.stream>>>(level, rs.y0, rs.y1, (float2*)c.storage[1].ptr);
+    // columns: the dispatch's x range in texels of the level (tile rendering); the band renderer's dispatch of ONE workgroup from column 0 means whole rows
+    const PassCtx::ColSpan cs = c.base[0] == 0 && c.dispatch[0] <= 1 ? PassCtx::ColSpan{0, level.w} : c.colSpan(level.w, 1);
+    if (cs.x1 <= cs.x0) return c.fail(-1, "depthPyramidApex: no columns to reduce");
+    depthPyramidApexKernel<<<1, 256, 0, c.stream>>>(level, rs.y0, rs.y1, cs.x0, cs.x1, (float2*)c.storage[1].ptr);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -17,8 +17,8 @@ namespace plr {
 
 // ------------------------------------------------------------------------------------------------
 // depthDownscale.comp:12-20: half-res R16F depth = nearest full-res texel at (2*iUV + 0.5) / res
-__global__ __launch_bounds__(256) void depthDownscaleKernel(ImgView src, ImgView dst, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void depthDownscaleKernel(ImgView src, ImgView dst, int coverW, int coverH, int yBase, int xBase) {
+    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     const vec2 texelSize(1.f / (float)src.w, 1.f / (float)src.h);
@@ -31,9 +31,10 @@ static int launchDepthDownscale(const PassCtx& c) {
     if (int rc = c.needSampled(1, F_D32, "depthDownscale fullResSrc")) return rc;
     const ImgView& dst = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(dst.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), dst.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
-    depthDownscaleKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], dst, w, h, y0);
+    const PassCtx::ColSpan cs = c.colSpan(dst.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0; // columns [x0, w), rows [y0, h)
+    if (w <= x0 || h <= y0) return 0;
+    depthDownscaleKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[1], dst, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -98,10 +99,10 @@ template <bool USE_HIZ>
 __global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
                                                          const float* __restrict__ influenceRangeP, ImgView depthMinMax, const GlobalUbo* __restrict__ g,
                                                          uint32_t tileCountX, uint32_t tileCountY, uint32_t domainX, uint32_t domainY, uint32_t tileRow0,
-                                                         uint32_t tileCapacity, uint32_t listCapacity) {
+                                                         uint32_t tileCapacity, uint32_t listCapacity, uint32_t tileCol0) {
     const uint32_t culledInstanceCount = min(culled[0], listCapacity);
     cullTile<USE_HIZ>([&](uint32_t i) { return culled[1 + i]; }, culledInstanceCount, threadIdx.x & 63u, blockIdx.x * 4u + (threadIdx.x >> 6), bbs, tiles, *influenceRangeP,
-                      [&](vec2 uv) { return sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv); }, g, tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity);
+                      [&](vec2 uv) { return sampleNearest2D<F_RG32F, CLAMP>(depthMinMax, uv); }, g, tileCountX, tileCountY, domainX, domainY, tileRow0, tileCapacity, tileCol0);
 }
 
 // ---- pass fusion (backend.h): the two culling passes as one launch (device/culling_device.h)
@@ -126,17 +127,18 @@ static int launchTileCulling(const PassCtx& c) {
     std::memcpy(tileCount, c.push.data(), 8);
     // invocations exist for dispatch*8 tiles per axis; tiles beyond cameraTileCount return early
     const PassCtx::RowSpan rs = c.rowSpan((int)tileCount[1]); // tile rows [y0, y1) of the recorded dispatch (8x8 tiles per workgroup)
-    const uint32_t tcx = std::min(tileCount[0], c.dispatch[0] * 8u), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0;
-    if (tcx == 0 || rs.y1 <= rs.y0) return 0;
+    const PassCtx::ColSpan cs = c.colSpan((int)tileCount[0]); // and its tile columns (tile rendering)
+    const uint32_t tcx = (uint32_t)(cs.x1 - cs.x0), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0, tileCol0 = (uint32_t)cs.x0;
+    if (cs.x1 <= cs.x0 || rs.y1 <= rs.y0) return 0;
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[2].size / sizeof(CulledInstancesPerTile));
     const uint32_t listCapacity = (uint32_t)(c.sbuf[0].size / 4u) - 1u;
     const dim3 grid(divUp(tcx * tcy, 4u));
     const ImgView hiz = useHiZ ? c.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
     // the uv of the HiZ fetch divides by the push-constant tile count; the dispatch only bounds which tiles run
     if (useHiZ) tileCullingKernel<true><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
-                                                                   (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity);
+                                                                   (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity, tileCol0);
     else tileCullingKernel<false><<<grid, 256, 0, c.stream>>>((const uint32_t*)c.sbuf[0].ptr, (const BoundingBox*)c.sbuf[1].ptr, (CulledInstancesPerTile*)c.sbuf[2].ptr,
-                                                             (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity);
+                                                             (const float*)c.ubuf[3].ptr, hiz, c.global, tileCount[0], tileCount[1], tcx, tcy, tileRow0, tileCapacity, listCapacity, tileCol0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -155,14 +157,15 @@ int prepareFusedCulling(const PassCtx& fc, const PassCtx& tc, FusedCullParams* o
     uint32_t tileCount[2];
     std::memcpy(tileCount, tc.push.data(), 8);
     const PassCtx::RowSpan rs = tc.rowSpan((int)tileCount[1]);
-    const uint32_t tcx = std::min(tileCount[0], tc.dispatch[0] * 8u), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0;
-    if (tcx == 0 || rs.y1 <= rs.y0) return kUseGeneralKernel; // nothing to cull for: let the frustum pass run on its own
+    const PassCtx::ColSpan cs = tc.colSpan((int)tileCount[0]);
+    const uint32_t tcx = (uint32_t)(cs.x1 - cs.x0), tcy = (uint32_t)(rs.y1 - rs.y0), tileRow0 = (uint32_t)rs.y0;
+    if (cs.x1 <= cs.x0 || rs.y1 <= rs.y0) return kUseGeneralKernel; // nothing to cull for: let the frustum pass run on its own
     CullScratch* scratch = (CullScratch*)tc.scratch(sizeof(CullScratch)); // zero-initialised, returned to zero by the kernel
     if (!scratch) return tc.fail(-2, "sdfCameraTileCulling: cannot allocate scratch memory");
     out->instanceBuffer = (const uint32_t*)fc.sbuf[0].ptr; out->frustum = (const FrustumUbo*)fc.ubuf[1].ptr; out->culled = (uint32_t*)fc.sbuf[2].ptr;
     out->bbsFrustum = (const BoundingBox*)fc.sbuf[3].ptr; out->influenceFrustumP = (const float*)fc.ubuf[4].ptr; out->threadLimit = threadLimit; out->capacity = capacity;
     out->scratch = scratch; out->bbs = (const BoundingBox*)tc.sbuf[1].ptr; out->tiles = (CulledInstancesPerTile*)tc.sbuf[2].ptr; out->influenceRangeP = (const float*)tc.ubuf[3].ptr;
-    out->g = tc.global; out->tileCountX = tileCount[0]; out->tileCountY = tileCount[1]; out->domainX = tcx; out->domainY = tcy; out->tileRow0 = tileRow0;
+    out->g = tc.global; out->tileCountX = tileCount[0]; out->tileCountY = tileCount[1]; out->domainX = tcx; out->domainY = tcy; out->tileRow0 = tileRow0; out->tileCol0 = (uint32_t)cs.x0;
     out->tileCapacity = (uint32_t)(tc.sbuf[2].size / sizeof(CulledInstancesPerTile)); out->listCapacity = (uint32_t)(tc.sbuf[0].size / 4u) - 1u;
     *useHiZOut = useHiZ;
     *hizOut = useHiZ ? tc.sampled[4] : ImgView{nullptr, 1, 1, 1, F_RG32F};
@@ -211,7 +214,7 @@ static int launchTilePyramidAndCulling(const PassCtx* const* ctxs, size_t count)
     const fasthiz::TileTailParams& t = plan.tileTail;
     if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel; // the tiles must sample the level this launch finishes
     if (int rc = fasthiz::launchQuadBlocks(*ctxs[0], plan)) return rc;
-    const int n = t.w4 * (t.row4End - t.row4Begin) + t.w5 * (t.row5End - t.row5Begin);
+    const int n = (t.col4End - t.col4Begin) * (t.row4End - t.row4Begin) + (t.col5End - t.col5Begin) * (t.row5End - t.row5Begin);
     const uint32_t tailBlocks = n > 0 ? divUp((unsigned)n, 256u) : 0u, cullBlocks = divUp(cull.domainX * cull.domainY, 4u);
     tileTailAndCullingKernel<<<tailBlocks + cullBlocks, 256, 0, ctxs[0]->stream>>>(t, tailBlocks, cull, cullBlocks);
     PLR_CHECK_LAUNCH(*ctxs[0]);
@@ -368,12 +371,12 @@ __global__ __launch_bounds__(256) void sdfDiffuseTraceKernel(ImgView outYSH, Img
                                                              const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                              const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                              const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
-                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
+                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0, int groupX0,
                                                              uint32_t tileCapacity, uint32_t instanceCapacity) {
     __shared__ RayInfo sharedRays[4][64];
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
     // one wave = one 8x8 reference workgroup; the four waves of a block are a 2x2 arrangement inside one culling tile
-    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1);
+    const int gx = groupX0 + (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1); // workgroups [groupX0, groupsX) x [groupY0, groupsY)
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
@@ -485,15 +488,15 @@ static int launchSdfDiffuseTrace(const PassCtx& c) {
     const ImgView& out = c.storage[0];
     if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
     // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
-    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
-    if (groupsX <= 0 || groupsY <= groupY0) return 0;
-    if (groupY0 & 1) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
+    const int groupX0 = (int)c.base[0], groupsX = groupX0 + (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
+    if (groupsX <= groupX0 || groupsY <= groupY0) return 0;
+    if ((groupY0 & 1) || (groupX0 & 1)) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)groupsX, 2u), divUp((unsigned)(groupsY - groupY0), 2u));
+    const dim3 grid(divUp((unsigned)(groupsX - groupX0), 2u), divUp((unsigned)(groupsY - groupY0), 2u));
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
-                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, groupX0, \
                        tileCapacity, instanceCapacity
     if (strict) sdfDiffuseTraceKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
     else sdfDiffuseTraceKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);

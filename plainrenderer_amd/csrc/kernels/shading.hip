@@ -150,6 +150,7 @@ struct ShadeParams {
     uint32_t bindlessCount;
     uint32_t cascadeCount;
     int coverW, coverH, yBase;
+    int xBase; // columns [xBase, coverW) (tile rendering: PassCtx::colSpan), rows [yBase, coverH)
 };
 
 PLR_DI vec3 gbufferNormal(const ImgView& normalTexture, int x, int y) {
@@ -234,7 +235,7 @@ PLR_DI vec3 specularMultiscatteringLobe(const ImgView& brdfLutTex, float r, floa
 
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
 __global__ __launch_bounds__(256) void deferredShadingKernel(ShadeParams P) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int px = P.xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= P.coverW || py >= P.coverH) return;
     const GlobalUbo* g = P.g;
@@ -435,9 +436,10 @@ static int launchDeferredShading(const PassCtx& c) {
     P.vol = (const VolumetricLightingSettings*)c.ubuf[19].ptr; P.g = c.global;
     P.bindless = c.bindless; P.bindlessCount = c.bindlessCount; P.cascadeCount = cascades;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
-    P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
-    if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
+    const PassCtx::ColSpan cs = c.colSpan(P.color.w);
+    P.coverW = cs.x1; P.xBase = cs.x0; P.coverH = rs.y1; P.yBase = rs.y0; // columns [xBase, coverW), rows [yBase, coverH)
+    if (P.coverW <= P.xBase || P.coverH <= P.yBase) return 0;
+    k<<<dim3(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

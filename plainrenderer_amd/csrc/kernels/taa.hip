@@ -119,8 +119,8 @@ struct ResolveWeights { float w[9]; };
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
 __global__ __launch_bounds__(256) void temporalFilterKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                             ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
-                                                            int coverW, int coverH, int yBase) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                            int coverW, int coverH, int yBase, int xBase) {
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const vec2 texelSize(1.f / (float)output.w, 1.f / (float)output.h);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void temporalFilterKernel(ImgView current, Img
     ((uint32_t*)output.ptr)[(size_t)py * (size_t)output.w + px] = packed;
 }
 
-typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
+typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int, int);
 
 template <bool CLIP, bool DILATE, bool TONEMAP> static TaaKernel pickTech(int tech) {
     switch (tech) {
@@ -225,12 +225,13 @@ static int launchTemporalFilter(const PassCtx& c) {
     }
     if (!k) return c.fail(-6, "temporalFilter: historySampleTech must be 0..4");
     const ImgView& out = c.storage[1];
-    const int w = std::min({(int)(c.dispatch[0] * 8u), out.w, c.sampled[0].w});
+    const PassCtx::ColSpan cs = c.colSpan(std::min(out.w, c.sampled[0].w));
+    const int w = cs.x1, x0 = cs.x0; // columns [x0, w)
     const PassCtx::RowSpan rs = c.rowSpan(std::min(out.h, c.sampled[0].h));
     const int h = rs.y1, y0 = rs.y0; // rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
-    k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
-                                                                                   (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
+    if (w <= x0 || h <= y0) return 0;
+    k<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
+                                                                                          (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

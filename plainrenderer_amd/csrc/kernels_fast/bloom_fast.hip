@@ -30,12 +30,12 @@ PLR_DI Tap tap1D(float u, int n, float h) {
 }
 
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase) {
+__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase, int xBase) {
     __shared__ float HA[ROWS_A][3][TW];
     __shared__ float HB[ROWS_B][3][TW];
     const int t = (int)threadIdx.x;
     const int lx = t & 63, lyBase = t >> 6;
-    const int x = (int)blockIdx.x * TW + lx;
+    const int x = xBase + (int)blockIdx.x * TW + lx; // columns [xBase, coverW) (tile rendering: PassCtx::colSpan; a multiple of 8)
     const int y0 = yBase + (int)blockIdx.y * TH;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
     const float sx = blurRadius * tsx, sy = blurRadius * tsy;
@@ -119,9 +119,9 @@ struct ParityWeights { float tent[2][5]; float box[2][3]; };
 // whatever QY is: the result does not depend on it.
 template <int QY>
 __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
-                                                               int yBase) {
+                                                               int yBase, int xBase) {
     // thread -> QY vertically adjacent 2x2 output quads; a wave covers 128 x 2 QY outputs
-    const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int k = (xBase >> 1) + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6)) * QY;
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
@@ -216,9 +216,9 @@ PLR_DI vec3 laneLeft(const vec3& v) { return vec3(laneLeft(v.x), laneLeft(v.y), 
 PLR_DI vec3 laneRight(const vec3& v) { return vec3(laneRight(v.x), laneRight(v.y), laneRight(v.z)); }
 
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleStripKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, int coverW, int coverH, int yBase) {
+__global__ __launch_bounds__(256) void bloomUpsampleStripKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, int coverW, int coverH, int yBase, int xBase) {
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    const int kc = (int)blockIdx.x * kStripCols - 2 + lane;                          // the source column this lane holds
+    const int kc = (xBase >> 1) + (int)blockIdx.x * kStripCols - 2 + lane;                          // the source column this lane holds
     const int m0 = (yBase >> 1) + ((int)blockIdx.y * 4 + wave) * kStripRows;         // first quad row (= source row) of the wave
     if (2 * m0 >= coverH) return; // wave-uniform
     // the filter weights live in vector registers: a multiply-add that reads a scalar register issues at half rate (tools/valu_rates.hip),
@@ -334,8 +334,9 @@ static int launch(const PassCtx& c) {
     const ImgView& target = c.storage[0];
     const ImgView& source = c.sampled[2];
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, yBase = rs.y0; // columns [0, w), rows [yBase, h)
-    if (w <= 0 || h <= yBase) return 0;
+    const PassCtx::ColSpan cs = c.colSpan(target.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, yBase = rs.y0; // columns [x0, w), rows [yBase, h)
+    if (w <= x0 || h <= yBase) return 0;
     // the LDS row budget assumes the reference's configuration: source = next smaller mip (>= half the target height) and a
     // blur radius of at most 3 source texels; anything else takes the general (exact-order) kernel
     const bool fits = blurRadius >= 0.f && blurRadius <= 3.f && source.h * 2 + 1 >= target.h && (lowest || c.sampled[1].h * 2 + 1 >= target.h);
@@ -348,24 +349,24 @@ static int launch(const PassCtx& c) {
         if (regular) {
             // the strip kernel needs enough waves to fill the SIMDs (a wave is 60 x 8 quads): mip 0 of a 4K frame has 4320, mip 1 1088
             static const int stripMinWaves = std::getenv("PLR_BLOOM_STRIP_MIN_WAVES") ? atoi(std::getenv("PLR_BLOOM_STRIP_MIN_WAVES")) : 2048;
-            const unsigned stripWaves = divUp((unsigned)divUp((unsigned)w, 2u), (unsigned)kStripCols) * divUp((unsigned)divUp((unsigned)(h - yBase), 2u), (unsigned)kStripRows);
+            const unsigned stripWaves = divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols) * divUp((unsigned)divUp((unsigned)(h - yBase), 2u), (unsigned)kStripRows);
             if ((int)stripWaves >= stripMinWaves) {
-                const dim3 sgrid(divUp((unsigned)divUp((unsigned)w, 2u), (unsigned)kStripCols), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kStripRows));
-                if (lowest) bloomUpsampleStripKernel<true><<<sgrid, 256, 0, c.stream>>>(source, source, target, pw, w, h, yBase);
-                else bloomUpsampleStripKernel<false><<<sgrid, 256, 0, c.stream>>>(source, c.sampled[1], target, pw, w, h, yBase);
+                const dim3 sgrid(divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kStripRows));
+                if (lowest) bloomUpsampleStripKernel<true><<<sgrid, 256, 0, c.stream>>>(source, source, target, pw, w, h, yBase, x0);
+                else bloomUpsampleStripKernel<false><<<sgrid, 256, 0, c.stream>>>(source, c.sampled[1], target, pw, w, h, yBase, x0);
                 PLR_CHECK_LAUNCH(c);
                 return 0;
             }
             constexpr int QY = 2; // 4: mip 0 35.0 vs 36.6 us, but the small mips lose more (fewer, longer waves)
-            const dim3 qgrid(divUp((unsigned)divUp((unsigned)w, 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * QY));
-            bloomUpsampleQuadKernel<QY><<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase);
+            const dim3 qgrid(divUp((unsigned)divUp((unsigned)(w - x0), 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * QY));
+            bloomUpsampleQuadKernel<QY><<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase, x0);
             PLR_CHECK_LAUNCH(c);
             return 0;
         }
     }
-    const dim3 grid(divUp((unsigned)w, (unsigned)TW), divUp((unsigned)(h - yBase), (unsigned)TH));
-    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h, yBase);
-    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h, yBase);
+    const dim3 grid(divUp((unsigned)(w - x0), (unsigned)TW), divUp((unsigned)(h - yBase), (unsigned)TH));
+    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h, yBase, x0);
+    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h, yBase, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -380,8 +381,8 @@ static int launch(const PassCtx& c) {
 // One thread makes a 2x2 block of outputs from a 6x6 block of source texels (rows 4m-1 .. 4m+4, columns 4k-1 .. 4k+4): 9 texel decodes per
 // output instead of 16 - the pass is bound by VALU issue. Per source row and output column A = the two inner texels, B = the two outer
 // ones; a row is an inner row (centre += A, border += B) for one output row and an outer row (border += A + B) for the other.
-__global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
-    const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) {
+    const int k = (xBase >> 1) + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // xBase: a multiple of 8 (PassCtx::colSpan)
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
@@ -454,8 +455,8 @@ PLR_DI vec3 bloomTapValue(const TapFetch& f) {
     r = f.w11 != 0.f ? r + c11 : r;
     return r;
 }
-__global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+__global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) {
+    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     // correctly rounded quotients / reciprocals (Newton step on v_rcp_f32), as the shader's divisions: the taps sit on 1/256 sub-texel weight steps
@@ -476,10 +477,11 @@ __global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView sour
 }
 static int launchDownAnySize(const PassCtx& c, const ImgView& source, const ImgView& target) {
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
-    if (w <= 0 || h <= y0) return 0;
+    const PassCtx::ColSpan cs = c.colSpan(target.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
+    if (w <= x0 || h <= y0) return 0;
     if (source.w < 1 || source.h < 1 || source.w >= (1 << 12) || source.h >= (1 << 12)) return kUseGeneralKernel; // 24-bit texel index arithmetic
-    bloomDownsampleAnySizeKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
+    bloomDownsampleAnySizeKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -491,10 +493,11 @@ static int launchDown(const PassCtx& c) {
     const ImgView& source = c.sampled[1];
     if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) return launchDownAnySize(c, source, target); // odd sizes: taps are not on texel centres
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
-    if (w <= 0 || h <= y0) return 0;
+    const PassCtx::ColSpan cs = c.colSpan(target.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
+    if (w <= x0 || h <= y0) return 0;
     if (y0 & 1) return kUseGeneralKernel; // 2x2 output blocks start on even rows
-    bloomDownsampleFastKernel<<<dim3(divUp(divUp((unsigned)w, 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0);
+    bloomDownsampleFastKernel<<<dim3(divUp(divUp((unsigned)(w - x0), 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -34,5 +34,7 @@ int spatialPackTargetOfConsumer(const PassCtx& producer, int outY, int outC, Spa
 // pre-pass then covers only the rows it can read that nobody packed this frame (none in a whole-frame dispatch; the halo rows a
 // neighbouring band sent, in band rendering)
 void spatialNotePackedRows(const PassCtx& producer, int y0, int y1);
+// the same for a rectangle of the consumer's input (tile rendering: the producer covers the columns of its tile only)
+void spatialNotePackedRect(const PassCtx& producer, int x0, int y0, int x1, int y1);
 
 } // namespace plr

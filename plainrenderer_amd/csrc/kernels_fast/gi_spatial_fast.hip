@@ -68,29 +68,20 @@ __global__ void spatialSampleTableKernel(float* __restrict__ table) {
 // and GI images share the texel grid, a pre-pass packs {Y_SH (8 B), CoCg (4 B), linear-depth denominator (4 B float)} into one
 // 16-byte texel, so a sample is ONE dwordx4 gather. The pre-pass also resolves the shader's NaN guard (:118): a texel with a NaN
 // component is stored as zeros with a negative denominator (= "skip").
+// up to four rectangles of the input in one launch (blockIdx.z): the halo rows above and below a band whose own rows the producer of the input has packed, or -
+// tile rendering - the four strips of halo around a tile
+struct PackRects { int n; int x0[4], y0[4], x1[4], y1[4]; };
 template <int DEPTH_FMT>
-__global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
-                                                         int rowBegin, int rowEnd) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = rowBegin + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (x >= inYSH.w || y >= rowEnd) return;
+__global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed, PackRects r) {
+    const int k = (int)blockIdx.z;
+    const int x = r.x0[k] + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int y = r.y0[k] + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (x >= r.x1[k] || y >= r.y1[k]) return;
     const size_t idx = (size_t)y * (size_t)inYSH.w + (size_t)x;
     const uint2 yt = ((const uint2*)inYSH.ptr)[idx];
     const uint32_t ct = ((const uint32_t*)inCoCg.ptr)[idx];
     const float dep = Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x;
     packed[idx] = packGiTexel(yt, ct, dep, g->nearPlane, g->farPlane);
-}
-// the same over two row ranges in one launch: rows [rowBegin, holeBegin) and [holeEnd, rowEnd) - the halo rows above and below a band whose own rows
-// the producer has packed
-template <int DEPTH_FMT>
-__global__ __launch_bounds__(256) void spatialPackAroundKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
-                                                               int rowBegin, int holeBegin, int holeEnd, int rowEnd) {
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    int y = rowBegin + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (y >= holeBegin) y += holeEnd - holeBegin;
-    if (x >= inYSH.w || y >= rowEnd) return;
-    const size_t idx = (size_t)y * (size_t)inYSH.w + (size_t)x;
-    packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
 }
 
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
@@ -105,13 +96,14 @@ struct SpatialFrameConsts {
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
-                                                               int coverW, int coverH, int yBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
-                                                               uint32_t validY0, uint32_t validRowCount, int rowMissShrinks, SpatialFrameConsts fc) {
+                                                               int coverW, int coverH, int yBase, int xBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
+                                                               uint32_t validY0, uint32_t validRowCount, uint32_t validX0, uint32_t validColCount, int rowMissShrinks,
+                                                               SpatialFrameConsts fc) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
     if (!xcdWalk(tilesX, tilesY, chunkRows, tileX, tileY)) return; // device/xcd.h: the note on the XCDs' L2s above
-    const int px = tileX * TX + (int)(threadIdx.x % TX);
+    const int px = xBase + tileX * TX + (int)(threadIdx.x % TX); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan), rows [yBase, coverH)
     const int py = yBase + tileY * TY + (int)(threadIdx.x / TX);
     if (px >= coverW || py >= coverH) return;
 
@@ -200,6 +192,11 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             const float reach = 0.5f * (sy + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.h + 1.f; // rows
             safe = safe && (float)py - reach >= (float)validY0 && (float)py + reach < (float)(validY0 + validRowCount);
         }
+        // tile rendering: the same for the valid columns (PassCtx::validCols), with the x row's norm
+        if (validColCount < (uint32_t)inYSH.w) {
+            const float reach = 0.5f * (sx + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.w + 1.f; // columns
+            safe = safe && (float)px - reach >= (float)validX0 && (float)px + reach < (float)(validX0 + validColCount);
+        }
     }
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
@@ -262,7 +259,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfW + halfW, 0.f, yWm1); ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfH + halfH, 0.f, yHm1);
                     // a row no neighbouring band has sent (band rendering) gets weight 0 like an off-screen sample; whether it also shrinks the disc for the
                     // samples after it, as an off-screen one does (:100-105), is the launcher's choice (rowMissShrinks; measured in profiles/r04_config5_series.txt)
-                    const bool rowMiss = (ty - validY0) >= validRowCount;
+                    const bool rowMiss = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount; // (or a column: tile rendering)
                     lengthModifier = (off[k] || (rowMiss && rowMissShrinks)) ? lengthModifier * 0.98f : lengthModifier;
                     off[k] = off[k] || rowMiss;
                 }
@@ -358,15 +355,16 @@ int spatialFilterPackTarget(const PassCtx& c, SpatialPackTarget* out) {
     return 0;
 }
 
-// ---- rows of a filter pass's packed copy that its producer filled this frame (host-side bookkeeping, one entry per filter pass = per scratch slot;
-// the backend is one instance per host thread)
-struct PackedRows {
+// ---- what of a filter pass's packed copy its producer filled this frame: rectangles (whole rows in band rendering, a tile's rectangle in tile rendering).
+// Host-side bookkeeping, one entry per filter pass = per scratch slot; the backend is one instance per host thread
+struct PackRect { int x0, y0, x1, y1; };
+struct PackedRects {
     uint64_t frameSerial = 0;
-    const void* source = nullptr;             // the Y_SH image the rows were packed from
+    const void* source = nullptr;             // the Y_SH image the texels were packed from
     const void* packed = nullptr;             // the packed copy they were written to (a re-allocated scratch invalidates the entry)
-    std::vector<std::pair<int, int>> rows;    // [y0, y1)
+    std::vector<PackRect> rects;
 };
-static thread_local std::map<const void*, PackedRows> g_packedRows;
+static thread_local std::map<const void*, PackedRects> g_packedRects;
 
 int spatialPackTargetOfConsumer(const PassCtx& producer, int outY, int outC, SpatialPackTarget* out) {
     const PassCtx* f = producer.consumer;
@@ -376,33 +374,41 @@ int spatialPackTargetOfConsumer(const PassCtx& producer, int outY, int outC, Spa
         return kUseGeneralKernel;
     return spatialFilterPackTarget(*f, out);
 }
-void spatialNotePackedRows(const PassCtx& producer, int y0, int y1) {
+void spatialNotePackedRect(const PassCtx& producer, int x0, int y0, int x1, int y1) {
     const PassCtx* f = producer.consumer;
-    if (!f || !f->scratchSlot || y1 <= y0) return;
-    PackedRows& e = g_packedRows[(const void*)f->scratchSlot];
+    if (!f || !f->scratchSlot || y1 <= y0 || x1 <= x0) return;
+    PackedRects& e = g_packedRects[(const void*)f->scratchSlot];
     const void* packed = *f->scratchSlot ? (const uint8_t*)*f->scratchSlot + kSpatialTableBytes : nullptr;
     if (e.frameSerial != producer.frameSerial || e.source != f->sampled[2].ptr || e.packed != packed) {
-        e.frameSerial = producer.frameSerial; e.source = f->sampled[2].ptr; e.packed = packed; e.rows.clear();
+        e.frameSerial = producer.frameSerial; e.source = f->sampled[2].ptr; e.packed = packed; e.rects.clear();
     }
-    e.rows.push_back({y0, y1});
+    e.rects.push_back({x0, y0, x1, y1});
     countFusedExecutions(1);
 }
-// [lo, hi) minus the rows the producer packed this frame, as at most two intervals (more: the caller packs [lo, hi) whole)
-static int unpackedRows(const PassCtx& c, const void* packed, int lo, int hi, std::pair<int, int> out[2]) {
-    std::vector<std::pair<int, int>> rest{{lo, hi}};
-    auto it = c.scratchSlot ? g_packedRows.find((const void*)c.scratchSlot) : g_packedRows.end();
-    if (it != g_packedRows.end() && it->second.frameSerial == c.frameSerial && it->second.source == c.sampled[2].ptr && it->second.packed == packed) {
-        for (const auto& r : it->second.rows) {
-            std::vector<std::pair<int, int>> next;
-            for (const auto& q : rest) {
-                if (r.second <= q.first || r.first >= q.second) { next.push_back(q); continue; }
-                if (q.first < r.first) next.push_back({q.first, r.first});
-                if (r.second < q.second) next.push_back({r.second, q.second});
+void spatialNotePackedRows(const PassCtx& producer, int y0, int y1) {
+    const PassCtx* f = producer.consumer;
+    if (f && f->hasSampled(2)) spatialNotePackedRect(producer, 0, y0, f->sampled[2].w, y1);
+}
+// the rectangle `all` minus what the producer packed this frame, as at most four rectangles (more: the caller packs `all` whole; the producer's texels
+// are then written a second time with the same values)
+static int unpackedRects(const PassCtx& c, const void* packed, PackRect all, PackRect out[4]) {
+    std::vector<PackRect> rest{all};
+    auto it = c.scratchSlot ? g_packedRects.find((const void*)c.scratchSlot) : g_packedRects.end();
+    if (it != g_packedRects.end() && it->second.frameSerial == c.frameSerial && it->second.source == c.sampled[2].ptr && it->second.packed == packed) {
+        for (const PackRect& r : it->second.rects) {
+            std::vector<PackRect> next;
+            for (const PackRect& q : rest) {
+                if (r.x1 <= q.x0 || r.x0 >= q.x1 || r.y1 <= q.y0 || r.y0 >= q.y1) { next.push_back(q); continue; }
+                if (q.y0 < r.y0) next.push_back({q.x0, q.y0, q.x1, r.y0});                                               // above
+                if (r.y1 < q.y1) next.push_back({q.x0, r.y1, q.x1, q.y1});                                               // below
+                const int m0 = std::max(q.y0, r.y0), m1 = std::min(q.y1, r.y1);
+                if (q.x0 < r.x0) next.push_back({q.x0, m0, r.x0, m1});                                                   // left of it, between the two
+                if (r.x1 < q.x1) next.push_back({r.x1, m0, q.x1, m1});                                                   // right of it
             }
             rest.swap(next);
         }
     }
-    if (rest.size() > 2) { out[0] = {lo, hi}; return 1; }
+    if (rest.size() > 4) { out[0] = all; return 1; }
     for (size_t i = 0; i < rest.size(); i++) out[i] = rest[i];
     return (int)rest.size();
 }
@@ -419,14 +425,15 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     const int filterIndex = c.specInt(0, 0);
     const ImgView& out = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0; // columns [0, w), rows [y0, h)
-    if (w <= 0 || h <= y0) return 0;
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0; // columns [x0, w), rows [y0, h)
+    if (w <= x0 || h <= y0) return 0;
     // 64x4 tiles measured best (64: 197 us, 32: 199 us, 16: 205 us per pass at 4K before the instruction diet)
 #ifndef PLR_SPATIAL_TX
 #define PLR_SPATIAL_TX 64
 #endif
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
-    const int tilesX = (int)divUp((unsigned)w, (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
+    const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     // chunks of ~17 tile rows (68 pixel rows) measured best at 4K (2 per XCD: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
     const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544); // chunks of ~68 pixel rows
     const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
@@ -438,35 +445,38 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     PLR_CHECK_LAUNCH(c);
     float* tables = (float*)scratch;
     uint4* packed = (uint4*)(scratch + kSpatialTableBytes);
-    int validLo, validHi;
+    int validLo, validHi, validLoX, validHiX;
     c.validRowRange(c.sampled[2].h, &validLo, &validHi);
+    c.validColRange(c.sampled[2].w, &validLoX, &validHiX);
     if (sameGrid) {
-        // rows the filter can read: the dispatched rows and a margin (samples further away read whatever an earlier frame packed there, exactly like
+        // what the filter can read: the dispatched rows and a margin (samples further away read whatever an earlier frame packed there, exactly like
         // the stale image rows they would read unpacked), inside the rows declared valid (band rendering: a sample on any other row has weight 0);
-        // minus the rows the producer of the input packed itself (fused_gi.h)
+        // minus what the producer of the input packed itself (fused_gi.h). Tile rendering: the same for the columns.
         // (the margin follows the declared valid rows: a band's GI halo grows with the frame height, 64 trace rows per 2160 - ADVICE r03: with a fixed 128
         //  a frame taller than 4320 rows read stale packed texels on valid halo rows beyond it)
         const bool banded = validLo > 0 || validHi < (int)c.sampled[2].h;
         const int margin = banded ? std::max({128, y0 - validLo, validHi - h}) : 128;
         const int p0 = std::max({y0 - margin, 0, validLo}), p1 = std::min({h + margin, (int)c.sampled[2].h, validHi});
-        std::pair<int, int> todo[2];
-        const int nTodo = p1 > p0 ? unpackedRows(c, packed, p0, p1, todo) : 0;
+        const bool tiled = validLoX > 0 || validHiX < (int)c.sampled[2].w || x0 > 0 || w < (int)c.sampled[2].w;
+        const int marginX = std::max({128, x0 - validLoX, validHiX - w});
+        const int q0 = tiled ? std::max({x0 - marginX, 0, validLoX}) : 0, q1 = tiled ? std::min({w + marginX, (int)c.sampled[2].w, validHiX}) : (int)c.sampled[2].w;
+        PackRect todo[4];
+        const int nTodo = p1 > p0 && q1 > q0 ? unpackedRects(c, packed, PackRect{q0, p0, q1, p1}, todo) : 0;
         if (c.sampled[4].fmt != F_R16F && c.sampled[4].fmt != F_D32) return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
-        const bool r16 = c.sampled[4].fmt == F_R16F;
-        if (nTodo == 2 && (todo[0].second - todo[0].first) % 4 == 0) { // the halo rows above and below the producer's rows: one launch
-            const int rows = (todo[0].second - todo[0].first) + (todo[1].second - todo[1].first);
-            const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)rows, 4u));
-            if (r16) spatialPackAroundKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[0].first, todo[0].second, todo[1].first, todo[1].second);
-            else spatialPackAroundKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[0].first, todo[0].second, todo[1].first, todo[1].second);
-        } else
+        if (nTodo) {
+            PackRects pr{};
+            pr.n = nTodo;
+            int maxW = 0, maxH = 0;
             for (int i = 0; i < nTodo; i++) {
-                const dim3 pgrid(divUp((unsigned)c.sampled[2].w, 64u), divUp((unsigned)(todo[i].second - todo[i].first), 4u));
-                if (r16) spatialPackKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[i].first, todo[i].second);
-                else spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, todo[i].first, todo[i].second);
+                pr.x0[i] = todo[i].x0; pr.y0[i] = todo[i].y0; pr.x1[i] = todo[i].x1; pr.y1[i] = todo[i].y1;
+                maxW = std::max(maxW, todo[i].x1 - todo[i].x0); maxH = std::max(maxH, todo[i].y1 - todo[i].y0);
             }
-        PLR_CHECK_LAUNCH(c);
-        if (nTodo) c.splitTiming("texel packing");
-        else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
+            const dim3 pgrid(divUp((unsigned)maxW, 64u), divUp((unsigned)maxH, 4u), (unsigned)nTodo);
+            if (c.sampled[4].fmt == F_R16F) spatialPackKernel<F_R16F><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, pr);
+            else spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, pr);
+            PLR_CHECK_LAUNCH(c);
+            c.splitTiming("texel packing");
+        } else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
     }
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
     // per-frame constants of the "can a sample of this pixel leave the screen" test, from the host's copy of the global buffer (a host the backend cannot read
@@ -479,8 +489,8 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     fc.dW = (float)c.sampled[4].w; fc.dH = (float)c.sampled[4].h; fc.nW = (float)c.sampled[5].w; fc.nH = (float)c.sampled[5].h;
     fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
     static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels/gi_filters.hip)
-#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, tilesX, tilesY, chunkRows, sig, \
-                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), rowMissShrinks, fc
+#define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, sig, \
+                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), rowMissShrinks, fc
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
         if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \

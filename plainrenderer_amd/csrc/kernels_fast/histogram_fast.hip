@@ -42,10 +42,12 @@ struct HistParams {
     const uint32_t* thresholds;
     float guessScale, guessBias;
     uint32_t tilesX, tileY0, gridX, gridY;
+    uint32_t tileX0; // first tile column of the dispatch (tile rendering: PassCtx::colSpan in tiles)
 };
 
 // one 32x32 tile; localHistogram / thr: kBins entries of LDS each
-PLR_DI void histogramTileBlock(const HistParams& p, uint32_t tileXIndex, uint32_t tileYIndex, uint32_t* localHistogram, float* thr) {
+PLR_DI void histogramTileBlock(const HistParams& p, uint32_t tileXInGrid, uint32_t tileYIndex, uint32_t* localHistogram, float* thr) {
+    const uint32_t tileXIndex = tileXInGrid + p.tileX0;
     const ImgView& src = p.src;
     const LightBuffer* __restrict__ light = p.light;
     uint32_t* __restrict__ perTile = p.perTile;
@@ -156,7 +158,9 @@ static int prepare(const PassCtx& c, HistParams* out) {
     const double logMin = std::log((double)minL), range = std::log((double)maxL) - logMin;
     out->src = src; out->light = (const LightBuffer*)c.sbuf[3].ptr; out->perTile = (uint32_t*)c.sbuf[0].ptr; out->thresholds = thresholds;
     out->guessScale = (float)(0.6931471805599453 / range * (kBins - 1u)); out->guessBias = (float)(-logMin / range * (kBins - 1u));
-    out->tilesX = tilesX; out->tileY0 = (uint32_t)rs.y0; out->gridX = std::min(c.dispatch[0], tilesX); out->gridY = rs.y1 > rs.y0 ? (uint32_t)(rs.y1 - rs.y0) : 0u;
+    const PassCtx::ColSpan cs = c.colSpan((int)tilesX, 1); // tile columns [x0, x1) of the recorded dispatch (one workgroup per tile)
+    out->tilesX = tilesX; out->tileY0 = (uint32_t)rs.y0; out->gridX = (uint32_t)(cs.x1 - cs.x0); out->gridY = rs.y1 > rs.y0 ? (uint32_t)(rs.y1 - rs.y0) : 0u;
+    out->tileX0 = (uint32_t)cs.x0;
     return 0;
 }
 static int launch(const PassCtx& c) {
@@ -173,7 +177,7 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (count != 6 && count != 8) return kUseGeneralKernel;
     HistParams hp;
     if (int rc = prepare(*ctxs[0], &hp)) return rc;
-    if (hp.gridX == 0 || hp.gridY == 0) return kUseGeneralKernel;
+    if (hp.gridX == 0 || hp.gridY == 0 || hp.tileX0 != 0) return kUseGeneralKernel; // (the fused front is the whole frame's: a tile's passes fuse on their own)
     ExposureChainPlan ep;
     if (int rc = prepareExposureChain(ctxs + 1, &ep)) return rc;
     if (ep.perTile != hp.perTile) return kUseGeneralKernel; // the combine must read what the per-tile pass writes

@@ -20,7 +20,7 @@ namespace plr {
 namespace fasthiz {
 
 template <int LEVELS, bool DOWNSCALE>
-__global__ __launch_bounds__(256) void hizQuadKernel(QuadParams p) { hizQuadBlock<LEVELS, DOWNSCALE>(p, (int)blockIdx.x, (int)blockIdx.y + p.tileY0); }
+__global__ __launch_bounds__(256) void hizQuadKernel(QuadParams p) { hizQuadBlock<LEVELS, DOWNSCALE>(p, (int)blockIdx.x + p.tileX0, (int)blockIdx.y + p.tileY0); }
 
 __global__ __launch_bounds__(256) void hizTileTailKernel(TileTailParams p) { hizTileTailThread(p, (int)(blockIdx.x * 256u + threadIdx.x)); }
 
@@ -49,15 +49,17 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     }
     // tile rows (64 depth rows each) of the recorded dispatch. The whole chain needs every tile; a SIX-level pyramid is per tile (band rendering, and
     // frames beyond the shader's 11 levels: frame_pipeline.cpp perTilePyramid) and can be built for any range of tile rows
-    const int tileRows = (int)divUp((unsigned)p.h[0], 32u);
-    const bool whole = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows;
+    const int tileRows = (int)divUp((unsigned)p.h[0], 32u), tileCols = (int)divUp((unsigned)p.w[0], 32u);
+    const bool wholeWidth = c.base[0] == 0 && (int)c.dispatch[0] >= tileCols; // (tile rendering: a range of tile columns too)
+    const bool whole = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows && wholeWidth;
     const bool perTile = mipCount == 6 && levels == 4;
     if (!whole && !perTile) return kUseGeneralKernel;
-    int tile0 = 0, tile1 = tileRows;
+    int tile0 = 0, tile1 = tileRows, tileX0 = 0, tileX1 = tileCols;
     if (!whole) {
-        const PassCtx::RowSpan rs = c.rowSpan(tileRows, 1);
+        const PassCtx::RowSpan rs = c.base[1] == 0 && (int)c.dispatch[1] >= tileRows ? PassCtx::RowSpan{0, tileRows} : c.rowSpan(tileRows, 1);
         tile0 = rs.y0; tile1 = rs.y1;
-        if (tile1 <= tile0) return kUseGeneralKernel; // nothing to do: let the general launcher say so
+        if (!wholeWidth) { const PassCtx::ColSpan cs = c.colSpan(tileCols, 1); tileX0 = cs.x0; tileX1 = cs.x1; }
+        if (tile1 <= tile0 || tileX1 <= tileX0) return kUseGeneralKernel; // nothing to do: let the general launcher say so
     }
     const int texA = p.w[levels] * p.h[levels], texB = mipCount > levels + 1 ? p.w[levels + 1] * p.h[levels + 1] : 1;
     const size_t tailLds = (size_t)(texA + texB) * sizeof(float2);
@@ -67,22 +69,28 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
     for (int l = 0; l < 4; l++) q.level[l] = p.level[l];
     q.levels = levels;
     // quad blocks: the tile rows of the dispatch; per tile, one more when a 3-row footprint of level 4 / 5 reaches into the next tile's level-3 rows
-    int quad0 = tile0, quad1 = tile1;
+    int quad0 = tile0, quad1 = tile1, quadX0 = tileX0, quadX1 = tileX1;
     if (perTile && ((p.h[3] | p.h[4]) & 1)) quad1 = std::min(tile1 + 1, tileRows);
+    if (perTile && ((p.w[3] | p.w[4]) & 1)) quadX1 = std::min(tileX1 + 1, tileCols);
+    q.halfCol0 = 0; q.halfCol1 = 0x7fffffff;
     if (down) {
         if (!down->hasStorage(0) || !down->hasSampled(1) || down->storage[0].fmt != F_R16F || down->sampled[1].ptr != depth.ptr) return kUseGeneralKernel;
         const ImgView& dst = down->storage[0];
         const PassCtx::RowSpan rs = down->rowSpan(dst.h);
-        if (dst.w * 2 != depth.w || dst.h * 2 != depth.h || (int)(down->dispatch[0] * 8u) < dst.w || rs.y1 <= rs.y0) return kUseGeneralKernel;
+        const PassCtx::ColSpan dcs = down->colSpan(dst.w);
+        if (dst.w * 2 != depth.w || dst.h * 2 != depth.h || dcs.x1 <= dcs.x0 || rs.y1 <= rs.y0) return kUseGeneralKernel;
+        if (!perTile && (dcs.x0 != 0 || dcs.x1 != dst.w)) return kUseGeneralKernel;
         if (!perTile && (rs.y0 != 0 || rs.y1 != dst.h)) return kUseGeneralKernel;
         q.halfDepth = (uint16_t*)dst.ptr; q.halfW = dst.w;
         q.halfRow0 = rs.y0; q.halfRow1 = rs.y1;
-        // the quad blocks also cover the tile rows of the half-resolution rows the downscale pass was asked for (32 half-res rows per tile)
+        q.halfCol0 = dcs.x0; q.halfCol1 = dcs.x1;
+        // the quad blocks also cover the tile rows of the half-resolution rows the downscale pass was asked for (32 half-res rows per tile), and its columns
         quad0 = std::min(quad0, rs.y0 / 32); quad1 = std::max(quad1, std::min((rs.y1 + 31) / 32, tileRows));
+        quadX0 = std::min(quadX0, dcs.x0 / 32); quadX1 = std::max(quadX1, std::min((dcs.x1 + 31) / 32, tileCols));
     }
-    q.tileY0 = quad0;
+    q.tileY0 = quad0; q.tileX0 = quadX0;
     out->quad = q; out->tail = p;
-    out->gridX = (int)divUp((unsigned)depth.w, 64u); out->gridY = quad1 - quad0;
+    out->gridX = quadX1 - quadX0; out->gridY = quad1 - quad0;
     out->tailFirst = levels; out->tailTexelsA = texA; out->tailLdsBytes = tailLds; out->downscale = down != nullptr;
     out->perTile = perTile;
     if (perTile) {
@@ -92,6 +100,8 @@ int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
         // a tile owns 2 rows of level 4 and 1 row of level 5 (kernels/hiz.hip: lo = tile * (32 >> level))
         t.row4Begin = std::min(2 * tile0, t.h4); t.row4End = std::min(2 * tile1, t.h4);
         t.row5Begin = std::min(tile0, t.h5); t.row5End = std::min(tile1, t.h5);
+        t.col4Begin = std::min(2 * tileX0, t.w4); t.col4End = std::min(2 * tileX1, t.w4);
+        t.col5Begin = std::min(tileX0, t.w5); t.col5End = std::min(tileX1, t.w5);
         out->tileTail = t;
     }
     return 0;
@@ -113,7 +123,7 @@ static int launchImpl(const PassCtx& c, const PassCtx* down) {
     if (int rc = launchQuadBlocks(c, plan)) return rc;
     if (plan.perTile) {
         const TileTailParams& t = plan.tileTail;
-        const int n = t.w4 * (t.row4End - t.row4Begin) + t.w5 * (t.row5End - t.row5Begin);
+        const int n = (t.col4End - t.col4Begin) * (t.row4End - t.row4Begin) + (t.col5End - t.col5Begin) * (t.row5End - t.row5Begin);
         if (n > 0) hizTileTailKernel<<<divUp((unsigned)n, 256u), 256, 0, c.stream>>>(t);
     } else hizTailKernel<<<1, 1024, plan.tailLdsBytes, c.stream>>>(plan.tail, plan.tailFirst, plan.tailTexelsA);
     PLR_CHECK_LAUNCH(c);

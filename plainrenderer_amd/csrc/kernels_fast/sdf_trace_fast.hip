@@ -269,15 +269,17 @@ __global__ __launch_bounds__(256) PLR_TRACE_OCC void sdfDiffuseTraceFastKernel(I
                                                                  const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
                                                                  const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
                                                                  const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
-                                                                 uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0,
+                                                                 uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0, int groupX0,
                                                                  uint32_t tileCapacity, uint32_t instanceCapacity, uint32_t* __restrict__ sig,
                                                                  uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges, ImgView hostNoiseTex,
                                                                  const uint16_t* const* __restrict__ brickedVolumes) {
     __shared__ RayInfo sharedRays[4][64];
     uint32_t raySig = 0u;
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
-    const int gx = (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + blockRow * 2 + (wave >> 1);
+    int blockCol, blockRow;
+    ranges.blockXY(&blockCol, &blockRow); // a launch over two row ranges, or the edge rows (tile rendering: and columns) first (backend.h TwoRanges)
+    // workgroups [groupX0, groupsX) x [groupY0, groupsY): the recorded dispatch (tile rendering restricts the columns too, PassCtx::base[0])
+    const int gx = groupX0 + blockCol * 2 + (wave & 1), gy = groupY0 + blockRow * 2 + (wave >> 1);
     const bool active = gx < groupsX && gy < groupsY;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = gx * 8 + lx, py = gy * 8 + ly;
@@ -547,10 +549,10 @@ static int launchImpl(const PassCtx& c) {
     const ImgView& out = c.storage[0];
     if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
     // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
-    const int groupsX = (int)c.dispatch[0], groupY0 = (int)c.base[1];
+    const int groupX0 = (int)c.base[0], groupsX = groupX0 + (int)c.dispatch[0], groupY0 = (int)c.base[1];
     int groupsY = groupY0 + (int)c.dispatch[1];
-    if (groupsX <= 0 || groupsY <= groupY0) return 0;
-    if (groupY0 & 1) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
+    if (groupsX <= groupX0 || groupsY <= groupY0) return 0;
+    if ((groupY0 & 1) || (groupX0 & 1)) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
     // rows in units of workgroups (8 pixel rows), blocks of 2 workgroups; a second row range covered by the same launch (pass fusion of the two
     // edge dispatches of band rendering) is expressed as a jump in the block row
     TwoRanges ranges;
@@ -563,21 +565,21 @@ static int launchImpl(const PassCtx& c) {
         groupsY = (int)(c.extraBaseY + c.extraCountY);
     }
     // band rendering, rows-first (plr.h first_rows): the edge rows' blocks come first and raise the backend's edge signal (blocks of 16 pixel rows, 4 waves)
-    if (!c.extraCountY) ranges.setEdgeFirst(c, groupY0 * 8, groupsY * 8, 16, 8, divUp((unsigned)groupsX, 2u), 4u);
+    if (!c.extraCountY) ranges.setEdgeFirst(c, groupY0 * 8, groupsY * 8, 16, 8, divUp((unsigned)(groupsX - groupX0), 2u), groupX0 * 8, groupsX * 8, 16);
     const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
     const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)groupsX, 2u), (unsigned)blockRowsTotal);
+    const dim3 grid(divUp((unsigned)(groupsX - groupX0), 2u), (unsigned)blockRowsTotal);
 #define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
                        (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
-                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, \
+                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, groupX0, \
                        tileCapacity, instanceCapacity, sig, pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges, hostNoise, brickedVolumes
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     const uint16_t* const* brickedVolumes = nullptr; // only the BRICKS variant below gets a table
     // the spatial filter that reads this pass's output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;
     const SpatialPackTarget* pack = !sig && spatialPackTargetOfConsumer(c, 0, 1, &packTarget) == 0 ? &packTarget : nullptr;
-    // (a dispatch narrower than the image would mark whole rows as packed that it only wrote in part: ADVICE r03)
-    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32) || groupsX * 8 < out.w)) pack = nullptr;
+    // (what the launch packs is noted as a rectangle: the columns of the dispatch, not whole rows - ADVICE r03)
+    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32))) pack = nullptr;
     if (pack) {
         // fused with the spatial filter that reads this pass's output (fused_gi.h); never together with a signature run
         if (pack->depth.w != out.w || pack->depth.h != out.h) return kUseGeneralKernel;
@@ -608,10 +610,11 @@ static int launchImpl(const PassCtx& c) {
 #undef PLR_TRACE_ARGS
     PLR_CHECK_LAUNCH(c);
     if (pack) {
+        const int px0 = std::min(groupX0 * 8, (int)out.w), px1 = std::min(groupsX * 8, (int)out.w);
         if (c.extraCountY) {
-            spatialNotePackedRows(c, std::min(groupY0 * 8, (int)out.h), std::min((groupY0 + (int)c.dispatch[1]) * 8, (int)out.h));
-            spatialNotePackedRows(c, std::min((int)c.extraBaseY * 8, (int)out.h), std::min(groupsY * 8, (int)out.h));
-        } else spatialNotePackedRows(c, std::min(groupY0 * 8, (int)out.h), std::min(groupsY * 8, (int)out.h));
+            spatialNotePackedRect(c, px0, std::min(groupY0 * 8, (int)out.h), px1, std::min((groupY0 + (int)c.dispatch[1]) * 8, (int)out.h));
+            spatialNotePackedRect(c, px0, std::min((int)c.extraBaseY * 8, (int)out.h), px1, std::min(groupsY * 8, (int)out.h));
+        } else spatialNotePackedRect(c, px0, std::min(groupY0 * 8, (int)out.h), px1, std::min(groupsY * 8, (int)out.h));
     }
     return 0;
 }

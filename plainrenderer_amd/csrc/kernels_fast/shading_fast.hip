@@ -186,6 +186,7 @@ struct ShadeParams {
     uint32_t bindlessCount;
     uint32_t cascadeCount;
     int coverW, coverH, yBase;
+    int xBase; // columns [xBase, coverW) (tile rendering: PassCtx::colSpan; a multiple of 8), rows [yBase, coverH)
     uint32_t* sig; // decision signatures (plr_debug_set_decision_signature) or null
     ImgView noiseTex; // the frame's noise texture, resolved on the host (PassCtx::hostNoiseView)
     const float4* pcfTaps; // [256][6] float4 = [noise byte][tap] {x, y}: unit-disc tap offsets (pcf_taps.h)
@@ -488,7 +489,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
 template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
 __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void deferredShadingFastKernel(ShadeParams P, PLR_SHADE_UNIFORM_PARAMS) {
     PLR_SHADE_ADOPT_UNIFORMS(P);
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int px = P.xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
     const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= P.coverW || py >= P.coverH) return;
     const ViewRay vr = exactViewRay(P.g, px, py);
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
     PLR_SHADE_ADOPT_UNIFORMS(P);
     __shared__ GiTexel tile[kGiTileH][kGiTileW];
     const int t = (int)threadIdx.x;
-    const int X0 = (int)(blockIdx.x * 64u), Y0 = P.yBase + (int)(blockIdx.y * 4u); // both even
+    const int X0 = P.xBase + (int)(blockIdx.x * 64u), Y0 = P.yBase + (int)(blockIdx.y * 4u); // both even
     const int k0 = (X0 >> 1) - 1, m0 = (Y0 >> 1) - 1;                               // half-res texel of tile[0][0]
     const GlobalUbo* g = P.g;
     const float nearP = g->nearPlane, farP = g->farPlane, nf = nearP * farP, nmf = nearP - farP;
@@ -784,7 +785,8 @@ static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, 
     if (!c.hostNoiseView(&P.noiseTex)) return kUseGeneralKernel;
     if (int rc = shadeDerivedTables(c, &P)) return rc;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
-    P.coverW = std::min((int)(c.dispatch[0] * 8u), P.color.w); P.coverH = rs.y1; P.yBase = rs.y0; // columns [0, coverW), rows [yBase, coverH)
+    const PassCtx::ColSpan cs = c.colSpan(P.color.w);
+    P.coverW = cs.x1; P.xBase = cs.x0; P.coverH = rs.y1; P.yBase = rs.y0; // columns [xBase, coverW), rows [yBase, coverH)
     P.sig = c.sigFor((size_t)P.color.w * (size_t)P.color.h);
     *out = P;
     return 0;
@@ -802,8 +804,8 @@ static int launchDeferredShadingFast(const PassCtx& c) {
         case 2: k = pickMulti<2>(multi, aa, tech); break;
         default: k = pickMulti<3>(multi, aa, tech); break;
     }
-    if (P.coverW <= 0 || P.coverH <= P.yBase) return 0;
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, PLR_SHADE_UNIFORM_ARGS(P));
+    if (P.coverW <= P.xBase || P.coverH <= P.yBase) return 0;
+    k<<<dim3(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, PLR_SHADE_UNIFORM_ARGS(P));
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -832,11 +834,11 @@ static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
     if (c.sampled[15].ptr != out.ptr || c.sampled[16].ptr != u.storage[1].ptr || c.sampled[15].w != out.w || c.sampled[15].h != out.h || P.color.w != out.w ||
         P.color.h != out.h || c.sampled[20].ptr != u.sampled[4].ptr || c.sampled[21].w != out.w || c.sampled[21].h != out.h)
         return kUseGeneralKernel;
-    const int uw = std::min((int)(u.dispatch[0] * 8u), out.w);
-    if (uw != out.w || P.coverW != out.w || ur.y0 != P.yBase || ur.y1 != P.coverH) return kUseGeneralKernel;
+    const PassCtx::ColSpan uc = u.colSpan(out.w);
+    if (uc.x0 != P.xBase || uc.x1 != P.coverW || ur.y0 != P.yBase || ur.y1 != P.coverH) return kUseGeneralKernel; // the same rows and the same columns
     // uv is defined by the UBO's screen resolution (indirectLightUpscale.comp:19): the quad reasoning needs it to be the target size
     if (c.global != u.global || !u.globalHost || u.globalHost->screenResolution[0] != out.w || u.globalHost->screenResolution[1] != out.h) return kUseGeneralKernel;
-    if (P.coverH <= P.yBase) return 0;
+    if (P.coverH <= P.yBase || P.coverW <= P.xBase) return 0;
     FusedUpscale U;
     U.srcYSH = u.sampled[2]; U.srcCoCg = u.sampled[3]; U.halfResDepth = u.sampled[5]; U.dstYSH = u.storage[0]; U.dstCoCg = u.storage[1];
     U.storeUpscaled = (u.elidableStorage & 3u) == 3u ? 0 : 1;
@@ -848,7 +850,7 @@ static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
         case 2: k = pickFusedMulti<2>(multi, aa); break;
         default: k = pickFusedMulti<3>(multi, aa); break;
     }
-    k<<<dim3(divUp((unsigned)P.coverW, 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U, PLR_SHADE_UNIFORM_ARGS(P));
+    k<<<dim3(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U, PLR_SHADE_UNIFORM_ARGS(P));
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

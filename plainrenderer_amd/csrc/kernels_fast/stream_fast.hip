@@ -21,8 +21,8 @@ PLR_DI float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 // ------------------------------------------------------------------------------------------------ applyBloom.comp:16-30
 // target = mix(scene, bloom, strength) in place. The bloom image has the target's size, so the bilinear tap at the pixel centre
 // is the texel itself. Four pixels (16 B) per lane.
-__global__ __launch_bounds__(256) void applyBloomFastKernel(ImgView target, ImgView bloom, float strength, int coverW, int coverH, int yBase) {
-    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+__global__ __launch_bounds__(256) void applyBloomFastKernel(ImgView target, ImgView bloom, float strength, int coverW, int coverH, int yBase, int xBase) {
+    const int x0 = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4; // columns [xBase, coverW), xBase a multiple of 8 (PassCtx::colSpan)
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (y >= coverH || x0 >= coverW) return;
     uint32_t* trow = (uint32_t*)target.ptr + (size_t)y * (size_t)target.w;
@@ -53,9 +53,10 @@ static int launchApplyBloom(const PassCtx& c) {
     float strength;
     std::memcpy(&strength, c.push.data(), 4);
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), target.w), h = rs.y1, y0 = rs.y0;
-    if (w <= 0 || h <= y0) return 0;
-    applyBloomFastKernel<<<dim3(divUp((unsigned)w, 256u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(target, c.sampled[1], strength, w, h, y0);
+    const PassCtx::ColSpan cs = c.colSpan(target.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
+    if (w <= x0 || h <= y0) return 0;
+    applyBloomFastKernel<<<dim3(divUp((unsigned)(w - x0), 256u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(target, c.sampled[1], strength, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -95,8 +96,8 @@ PLR_DI void tonemapRowTerms(int y, float time, uint32_t* nyA, uint32_t* nyB) {
 }
 
 template <bool BGRA>
-__global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase) {
-    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+__global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgView dst, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase) {
+    const int x0 = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (y >= coverH || x0 >= coverW) return;
     const float time = g->time;
@@ -119,8 +120,8 @@ __global__ __launch_bounds__(256) void tonemappingFastKernel(ImgView src, ImgVie
 // stored (R11G11B10, the pass's output) and its STORED value - decoded again, as the separate tonemap pass would read it - is tonemapped.
 // 16 B per pixel of traffic instead of 20, one launch instead of two.
 template <bool BGRA>
-__global__ __launch_bounds__(256) void applyBloomTonemapKernel(ImgView target, ImgView bloom, ImgView dst, const GlobalUbo* __restrict__ g, float strength, int coverW, int coverH, int yBase) {
-    const int x0 = (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
+__global__ __launch_bounds__(256) void applyBloomTonemapKernel(ImgView target, ImgView bloom, ImgView dst, const GlobalUbo* __restrict__ g, float strength, int coverW, int coverH, int yBase, int xBase) {
+    const int x0 = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)) * 4;
     const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (y >= coverH || x0 >= coverW) return;
     const float time = g->time;
@@ -149,13 +150,14 @@ static int launchTonemapping(const PassCtx& c) {
     const ImgView& src = c.sampled[1];
     const ImgView& dst = c.storage[0];
     if (dst.fmt != F_BGRA8 && dst.fmt != F_RGBA8) return c.fail(-4, "tonemapping imageOut must be BGRA8_uNorm or RGBA8");
-    const int coverW = std::min({(int)(c.dispatch[0] * 8u), dst.w, src.w});
+    const PassCtx::ColSpan cs = c.colSpan(std::min(dst.w, src.w));
+    const int coverW = cs.x1, xBase = cs.x0;
     const PassCtx::RowSpan rs = c.rowSpan(std::min(dst.h, src.h));
     const int coverH = rs.y1, y0 = rs.y0;
-    if (coverW <= 0 || coverH <= y0) return 0;
-    const dim3 grid(divUp((unsigned)coverW, 256u), divUp((unsigned)(coverH - y0), 4u));
-    if (dst.fmt == F_BGRA8) tonemappingFastKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
-    else tonemappingFastKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0);
+    if (coverW <= xBase || coverH <= y0) return 0;
+    const dim3 grid(divUp((unsigned)(coverW - xBase), 256u), divUp((unsigned)(coverH - y0), 4u));
+    if (dst.fmt == F_BGRA8) tonemappingFastKernel<true><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0, xBase);
+    else tonemappingFastKernel<false><<<grid, 256, 0, c.stream>>>(src, dst, c.global, coverW, coverH, y0, xBase);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -274,8 +276,8 @@ PLR_DI void upscalePixel(const ImgView& dstYSH, const ImgView& dstCoCg, const Im
 }
 
 __global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, uint32_t* __restrict__ sig) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase, uint32_t* __restrict__ sig) {
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     upscalePixel(dstYSH, dstCoCg, srcYSH, srcCoCg, fullResDepthT, halfResDepthT, g, px, py, sig);
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(256) void indirectLightUpscaleFastKernel(ImgView ds
 // ---- 2x2 outputs per thread when the full-resolution image is exactly twice the half-resolution one: upscaleQuad (upscale_quad.h, shared with
 // the fused upscale + deferred shade of shading_fast.hip)
 __global__ __launch_bounds__(256) void indirectLightUpscaleQuadKernel(ImgView dstYSH, ImgView dstCoCg, ImgView srcYSH, ImgView srcCoCg, ImgView fullResDepthT,
-                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, uint32_t* __restrict__ sig) {
-    const int k = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                                      ImgView halfResDepthT, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase, uint32_t* __restrict__ sig) {
+    const int k = (xBase >> 1) + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // xBase: a multiple of 8 (PassCtx::colSpan)
     const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
@@ -326,19 +328,20 @@ static int launchUpscale(const PassCtx& c) {
     if (int rc = c.needSampled(5, F_R16F, "indirectLightUpscale halfResDepth")) return rc;
     const ImgView& out = c.storage[0];
     const PassCtx::RowSpan rs = c.rowSpan(out.h);
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w), h = rs.y1, y0 = rs.y0;
-    if (w <= 0 || h <= y0) return 0;
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
+    if (w <= x0 || h <= y0) return 0;
     // exact 2x case: screen = full-res target = depth buffer, half-res images exactly half of it (the sub-texel weights are then 0.25 / 0.75)
     const bool regular = out.w == 2 * c.sampled[2].w && out.h == 2 * c.sampled[2].h && c.sampled[3].w == c.sampled[2].w && c.sampled[3].h == c.sampled[2].h &&
                          c.sampled[5].w == c.sampled[2].w && c.sampled[5].h == c.sampled[2].h && c.sampled[4].w == out.w && c.sampled[4].h == out.h &&
                          c.storage[1].w == out.w && c.storage[1].h == out.h && (y0 & 1) == 0 && c.sampled[2].w >= 4;
     uint32_t* sig = c.sigFor((size_t)out.w * (size_t)out.h);
     if (regular)
-        indirectLightUpscaleQuadKernel<<<dim3(divUp(divUp((unsigned)w, 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(
-            c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, w, h, y0, sig);
+        indirectLightUpscaleQuadKernel<<<dim3(divUp(divUp((unsigned)(w - x0), 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(
+            c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, w, h, y0, x0, sig);
     else
-        indirectLightUpscaleFastKernel<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
-                                                                                                                  c.sampled[4], c.sampled[5], c.global, w, h, y0, sig);
+        indirectLightUpscaleFastKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.storage[0], c.storage[1], c.sampled[2], c.sampled[3],
+                                                                                                                         c.sampled[4], c.sampled[5], c.global, w, h, y0, x0, sig);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -372,10 +375,11 @@ PLR_DI vec2 bilinearRG16SN(const ImgView& im, float u, float v, bool repeat) {
 template <int PACK, bool PACKED_ONLY = false>
 __global__ __launch_bounds__(256) void temporalGiFilterFastKernel(ImgView targetYSH, ImgView targetCoCg, ImgView historyOutYSH, ImgView historyOutCoCg, ImgView inYSH,
                                                                   ImgView inCoCg, ImgView historyInYSH, ImgView historyInCoCg, ImgView velocityCurrent,
-                                                                  ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase,
+                                                                  ImgView velocityLast, const GlobalUbo* __restrict__ g, int coverW, int coverH, int yBase, int xBase,
                                                                   uint4* __restrict__ packedOut, ImgView packDepth, TwoRanges ranges) {
-    const int blockRow = ranges.blockRow((int)blockIdx.y); // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    int blockCol, blockRow;
+    ranges.blockXY(&blockCol, &blockRow); // a launch over two row ranges, or the edge rows (tile rendering: and columns) first (backend.h TwoRanges)
+    const int px = xBase + blockCol * 64 + (int)(threadIdx.x & 63u); // columns [xBase, coverW) (PassCtx::colSpan), rows [yBase, coverH)
     const int py = yBase + blockRow * 4 + (int)(threadIdx.x >> 6);
     // (the pixel's work as a lambda: every wave, also one with nothing to do, reports in at the end - TwoRanges::edgeDone, rows-first launches of a band)
     auto pixel = [&]() {
@@ -447,18 +451,20 @@ static int launchTemporalGi(const PassCtx& c) {
     TwoRanges ranges;
     int blockRows, y0, h;
     if (twoRangeBlocks(c, out.h, 4, 8, &ranges, &blockRows, &y0, &h)) return kUseGeneralKernel;
-    const int w = std::min((int)(c.dispatch[0] * 8u), out.w);
-    if (w <= 0 || h <= y0) return 0;
-    const dim3 grid(divUp((unsigned)w, 64u), (unsigned)blockRows);
-    if (!c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4, 8, grid.x, 4u); // band rendering, rows-first (plr.h first_rows): blocks of 4 rows, 4 waves
+    const PassCtx::ColSpan cs = c.colSpan(out.w);
+    const int w = cs.x1, x0 = cs.x0; // columns [x0, w)
+    if (w <= x0 || h <= y0) return 0;
+    const dim3 grid(divUp((unsigned)(w - x0), 64u), (unsigned)blockRows);
+    if (!c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4, 8, grid.x, x0, w, 64); // band / tile rendering, edges first (plr.h first_rows, first_cols): blocks of 64 x 4 pixels
     // the spatial filter that reads the history output wants packed texels (PassCtx::consumer, fused_gi.h): written here, for the rows of this launch
     SpatialPackTarget packTarget;
     const SpatialPackTarget* pack = spatialPackTargetOfConsumer(c, 2, 3, &packTarget) == 0 ? &packTarget : nullptr;
-    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32) || w != out.w)) pack = nullptr;
-#define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, \
+    if (pack && (pack->depth.w != out.w || pack->depth.h != out.h || (pack->depth.fmt != F_R16F && pack->depth.fmt != F_D32))) pack = nullptr;
+#define PLR_TEMPORAL_ARGS c.storage[0], c.storage[1], c.storage[2], c.storage[3], c.sampled[4], c.sampled[5], c.sampled[6], c.sampled[7], c.sampled[8], c.sampled[9], c.global, w, h, y0, x0, \
                           pack ? pack->packed : nullptr, pack ? pack->depth : ImgView{}, ranges
     // a launch that packs every texel of the consumer's input, and whose four output images nothing else will read (fusion level 2): packed texels only
-    const bool packedOnly = pack && (c.elidableStorage & 15u) == 15u && y0 == 0 && h == out.h && !c.extraCountY && !c.firstRows[0] && !c.firstRows[1];
+    const bool packedOnly = pack && (c.elidableStorage & 15u) == 15u && y0 == 0 && h == out.h && x0 == 0 && w == out.w && !c.extraCountY && !c.firstRows[0] && !c.firstRows[1] &&
+                            !c.firstCols[0] && !c.firstCols[1];
     if (packedOnly) {
         if (pack->depth.fmt == F_R16F) temporalGiFilterFastKernel<F_R16F, true><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
         else temporalGiFilterFastKernel<F_D32, true><<<grid, 256, 0, c.stream>>>(PLR_TEMPORAL_ARGS);
@@ -473,9 +479,9 @@ static int launchTemporalGi(const PassCtx& c) {
         // pixel rows of this launch: [y0, first range end) and, for a launch over two row ranges, the second range (twoRangeBlocks)
         if (c.extraCountY) {
             const PassCtx::RowSpan a = c.rowSpan(out.h, 8);
-            spatialNotePackedRows(c, a.y0, a.y1);
-            spatialNotePackedRows(c, std::min((int)c.extraBaseY * 8, (int)out.h), h);
-        } else spatialNotePackedRows(c, y0, h);
+            spatialNotePackedRect(c, x0, a.y0, w, a.y1);
+            spatialNotePackedRect(c, x0, std::min((int)c.extraBaseY * 8, (int)out.h), w, h);
+        } else spatialNotePackedRect(c, x0, y0, w, h);
     }
     return 0;
 }
@@ -490,14 +496,15 @@ static int launchApplyBloomTonemap(const PassCtx* const* ctxs, size_t count) {
     if (src.ptr != target.ptr || src.w != target.w || src.h != target.h) return kUseGeneralKernel;                 // the tonemap must read what applyBloom wrote
     if (bloom.w != target.w || bloom.h != target.h || dst.w != target.w || dst.h != target.h || (target.w & 3)) return kUseGeneralKernel;
     const PassCtx::RowSpan ra = a.rowSpan(target.h), rt = t.rowSpan(target.h);
-    const int wa = std::min((int)(a.dispatch[0] * 8u), target.w), wt = std::min((int)(t.dispatch[0] * 8u), target.w);
-    if (ra.y0 != rt.y0 || ra.y1 != rt.y1 || wa != target.w || wt != target.w) return kUseGeneralKernel;             // same rows, whole rows
-    if (ra.y1 <= ra.y0) return 0;
+    const PassCtx::ColSpan ca = a.colSpan(target.w), ct = t.colSpan(target.w);
+    // same rows, same columns, whole 4-pixel groups (the image's width, or a tile's column span: multiples of 8)
+    if (ra.y0 != rt.y0 || ra.y1 != rt.y1 || ca.x0 != ct.x0 || ca.x1 != ct.x1 || ((ca.x1 - ca.x0) & 3)) return kUseGeneralKernel;
+    if (ra.y1 <= ra.y0 || ca.x1 <= ca.x0) return 0;
     float strength;
     std::memcpy(&strength, a.push.data(), 4);
-    const dim3 grid(divUp((unsigned)target.w, 256u), divUp((unsigned)(ra.y1 - ra.y0), 4u));
-    if (dst.fmt == F_BGRA8) applyBloomTonemapKernel<true><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, target.w, ra.y1, ra.y0);
-    else applyBloomTonemapKernel<false><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, target.w, ra.y1, ra.y0);
+    const dim3 grid(divUp((unsigned)(ca.x1 - ca.x0), 256u), divUp((unsigned)(ra.y1 - ra.y0), 4u));
+    if (dst.fmt == F_BGRA8) applyBloomTonemapKernel<true><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, ca.x1, ra.y1, ra.y0, ca.x0);
+    else applyBloomTonemapKernel<false><<<grid, 256, 0, a.stream>>>(target, bloom, dst, t.global, strength, ca.x1, ra.y1, ra.y0, ca.x0);
     PLR_CHECK_LAUNCH(a);
     return 0;
 }

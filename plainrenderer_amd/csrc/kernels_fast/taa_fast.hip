@@ -72,8 +72,8 @@ struct ResolveWeights { float w[9]; };
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP>
 __global__ __launch_bounds__(256) void temporalFilterFastKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                 ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
-                                                                int coverW, int coverH, int yBase) {
-    const int px = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+                                                                int coverW, int coverH, int yBase, int xBase) {
+    const int px = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
     const int py = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
     if (px >= coverW || py >= coverH) return;
     const float tsx = 1.f / (float)output.w, tsy = 1.f / (float)output.h;
@@ -264,12 +264,14 @@ PLR_DI int waveMinI(int v) {
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP, bool BANDED>
 __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
-                                                                 int coverW, int coverH, int yBase, TwoRanges ranges) {
+                                                                 int coverW, int coverH, int yBase, int xBase, TwoRanges ranges) {
     static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");
     __shared__ uint2 stage[4][kStageTexels]; // per wave: {luminance bits, packed texel}
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    const int px = (int)blockIdx.x * kStripW + lane - 1;  // the column this lane holds; it is an output column for lanes 1..62
-    const int blockRow = BANDED ? ranges.blockRow((int)blockIdx.y) : (int)blockIdx.y; // a launch over two row ranges, or edge rows first (backend.h TwoRanges)
+    int blockCol = (int)blockIdx.x, blockRow = (int)blockIdx.y;
+    if (BANDED) ranges.blockXY(&blockCol, &blockRow); // a launch over two row ranges, or the edge rows (tile rendering: and columns) first (backend.h TwoRanges)
+    // the column this lane holds; it is an output column for lanes 1..62. Output columns [xBase, coverW) (tile rendering: PassCtx::colSpan)
+    const int px = xBase + blockCol * kStripW + lane - 1;
     const int rowFirst = yBase + (blockRow * 4 + wave) * kStripRows;
     if (rowFirst >= coverH) { if (BANDED) ranges.edgeDone((int)blockIdx.y); return; } // wave-uniform (every wave of a rows-first launch reports in: TwoRanges::edgeDone)
     const bool isOutputLane = lane >= 1 && lane <= kStripW && px < coverW;
@@ -541,8 +543,8 @@ __global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView curr
     if (BANDED) ranges.edgeDone((int)blockIdx.y);
 }
 
-typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int);
-typedef void (*TaaStripKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int, TwoRanges);
+typedef void (*TaaKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int, int);
+typedef void (*TaaStripKernel)(ImgView, ImgView, ImgView, ImgView, ImgView, ImgView, const ResolveWeights*, const GlobalUbo*, int, int, int, int, TwoRanges);
 template <bool CLIP, bool DILATE, bool TONEMAP> static TaaKernel pickTech(int tech) {
     switch (tech) {
         case 0: return temporalFilterFastKernel<CLIP, DILATE, 0, TONEMAP>;
@@ -580,28 +582,30 @@ static int launch(const PassCtx& c) {
                                         : (tonemap ? temporalFilterStripKernel<true, false, T, true, B> : temporalFilterStripKernel<true, false, T, false, B>)) \
                               : (dilate ? (tonemap ? temporalFilterStripKernel<false, true, T, true, B> : temporalFilterStripKernel<false, true, T, false, B>)  \
                                         : (tonemap ? temporalFilterStripKernel<false, false, T, true, B> : temporalFilterStripKernel<false, false, T, false, B>)))
-        const bool banded = c.extraCountY != 0 || c.firstRows[0] != 0 || c.firstRows[1] != 0;
+        const bool banded = c.extraCountY != 0 || c.firstRows[0] != 0 || c.firstRows[1] != 0 || c.firstCols[0] != 0 || c.firstCols[1] != 0;
         strip = banded ? (tech == 0 ? PLR_STRIP(0, true) : PLR_STRIP(4, true)) : (tech == 0 ? PLR_STRIP(0, false) : PLR_STRIP(4, false));
 #undef PLR_STRIP
     }
     const ImgView& out = c.storage[1];
-    const int w = std::min({(int)(c.dispatch[0] * 8u), out.w, c.sampled[0].w});
+    const PassCtx::ColSpan cs = c.colSpan(std::min(out.w, c.sampled[0].w));
+    const int w = cs.x1, x0 = cs.x0; // columns [x0, w)
     // rows [y0, h), in blocks of 16 (4 waves x kStripRows); a second row range in the same launch (pass fusion of band rendering's two edge dispatches)
     TwoRanges ranges;
     int stripBlocks, y0, h;
     const bool expressible = twoRangeBlocks(c, std::min(out.h, c.sampled[0].h), 4 * kStripRows, 8, &ranges, &stripBlocks, &y0, &h) == 0;
-    if (w <= 0 || h <= y0) return 0;
+    if (w <= x0 || h <= y0) return 0;
     // the strip kernel indexes all per-pixel images with one coordinate: it needs them to be the same size
     const bool sameSize = c.sampled[0].w == out.w && c.sampled[0].h == out.h && c.sampled[3].w == out.w && c.sampled[3].h == out.h && c.sampled[5].w == out.w &&
                           c.sampled[5].h == out.h && out.w >= 4;
     if (c.extraCountY && !(strip && sameSize && expressible)) return kUseGeneralKernel; // two ranges: strip kernel only (else two launches)
-    if (strip && sameSize && !c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4 * kStripRows, 8, divUp((unsigned)w, (unsigned)kStripW), 4u); // band, rows-first (plr.h first_rows)
+    const unsigned stripsX = divUp((unsigned)(w - x0), (unsigned)kStripW);
+    if (strip && sameSize && !c.extraCountY) ranges.setEdgeFirst(c, y0, h, 4 * kStripRows, 8, stripsX, x0, w, kStripW); // band / tile, edges first (plr.h first_rows, first_cols)
     if (strip && sameSize)
-        strip<<<dim3(divUp((unsigned)w, (unsigned)kStripW), (unsigned)stripBlocks), 256, 0, c.stream>>>(
-            c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, ranges);
+        strip<<<dim3(stripsX, (unsigned)stripBlocks), 256, 0, c.stream>>>(
+            c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5], (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, x0, ranges);
     else
-        k<<<dim3(divUp((unsigned)w, 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
-                                                                                       (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0);
+        k<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(c.sampled[0], out, c.storage[2], c.sampled[3], c.sampled[4], c.sampled[5],
+                                                                                              (const ResolveWeights*)c.ubuf[6].ptr, c.global, w, h, y0, x0);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

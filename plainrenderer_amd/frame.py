@@ -25,12 +25,14 @@ class PlrfSettings(C.Structure):
                                           "run_light_matrix")] + [("volumetrics_max_distance", C.c_float), ("taa_use_separate_supersampling", C.c_uint32), ("taa_supersample_use_tonemapping", C.c_uint32),
                                                                               ("sdf_debug_mode", C.c_uint32), ("sdf_debug_tile_usage_with_hiz", C.c_uint32),
                                                                               ("sdf_debug_use_influence_radius", C.c_uint32), ("band_taa_history_halo", C.c_uint32), ("run_volumetrics", C.c_uint32),
-                                                                              ("run_sky_luts", C.c_uint32), ("band_overlap_exchange", C.c_uint32)]
+                                                                              ("run_sky_luts", C.c_uint32), ("band_overlap_exchange", C.c_uint32), ("band_col_begin", C.c_uint32),
+                                                                              ("band_col_end", C.c_uint32)]
 
 
 class PlrfExchangeItem(C.Structure):
     _fields_ = [("image", _ImageHandle), ("device_ptr", C.c_void_p), ("row_begin", C.c_uint32), ("row_end", C.c_uint32), ("halo_rows", C.c_uint32),
-                ("row_bytes", C.c_uint32), ("image_rows", C.c_uint32)]
+                ("row_bytes", C.c_uint32), ("image_rows", C.c_uint32), ("col_begin", C.c_uint32), ("col_end", C.c_uint32), ("image_cols", C.c_uint32),
+                ("texel_bytes", C.c_uint32)]
 
 
 EXCHANGE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
@@ -86,6 +88,35 @@ class FramePipeline:
         if rc != 0:
             raise PlrError("plrf_rccl_attach failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
         self._rccl = x
+
+    def attach_rccl_rects(self, unique_id, rank, world, frame_width, frame_height, rects):
+        """the native exchange for a partition into rectangles [(x0, y0, x1, y1)] (tile rendering; plrf_rccl_attach_rects). unique_id None: LOOPBACK - no
+        communicator, the pack / unpack kernels run and a device copy stands in for the links (single-GPU replay of one partition's frame)"""
+        self.lib.plrf_rccl_last_error.restype = C.c_char_p
+        x = C.c_void_p()
+        flat = (C.c_uint32 * (4 * world))(*[int(v) for r in rects for v in r])
+        uid = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        rc = self.lib.plrf_rccl_attach_rects(self.handle, uid, C.c_int(rank), C.c_int(world), C.c_uint32(frame_width), C.c_uint32(frame_height), flat, C.byref(x))
+        if rc != 0:
+            raise PlrError("plrf_rccl_attach_rects failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
+        self._rccl = x
+
+    def rccl_info(self):
+        """dict: rccl_ranks, rccl_version, overlap_mode, packed_regions, stream_wait_value_supported, watchdog_ms (plrf_rccl_info)"""
+        names = ("rccl_ranks", "rccl_version", "overlap_mode", "packed_regions", "stream_wait_value_supported", "watchdog_ms")
+        info = (C.c_int32 * len(names))()
+        self._check(self.lib.plrf_rccl_get_info(self._rccl, info))
+        return dict(zip(names, [int(v) for v in info]))
+
+    def rccl_self_test_rect(self, device_ptr, pitch_bytes, texel_bytes, rect, dst_xy):
+        stream = C.c_void_p()
+        self.be._check(self.lib.plr_get_stream(C.byref(stream)))
+        x0, y0, x1, y1 = rect
+        rc = self.lib.plrf_rccl_self_test_rect(self._rccl, C.c_void_p(device_ptr), C.c_uint32(pitch_bytes), C.c_uint32(texel_bytes), C.c_uint32(x0), C.c_uint32(y0), C.c_uint32(x1),
+                                               C.c_uint32(y1), C.c_uint32(dst_xy[0]), C.c_uint32(dst_xy[1]), stream)
+        if rc != 0:
+            self.lib.plrf_rccl_last_error.restype = C.c_char_p
+            raise PlrError("plrf_rccl_self_test_rect failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
 
     def detach_rccl(self):
         if getattr(self, "_rccl", None):

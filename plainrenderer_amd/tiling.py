@@ -1,4 +1,4 @@
-"""Multi-GPU partition of the frame by screen rows ("bands") and the halo exchange between neighbouring bands.
+"""Multi-GPU partition of the frame by screen rows ("bands") or into screen TILES (BASELINE config 5: 2 x 2) and the halo exchange between neighbours.
 
 One process (or, in the single-GPU partition tests, one thread) per band. Every band holds whole-frame images and renders only its
 rows (csrc/frontend/frame_pipeline.h BandSettings); where a pass reads rows of a neighbouring band the C++ host calls back into
@@ -70,12 +70,17 @@ def balanced_bounds(height, bounds, band_times, min_rows=2 * BAND_ALIGNMENT):
 class Rows:
     """what one exchange item asks for, in plain integers (mirrors plrf_exchange_item)"""
 
-    def __init__(self, ptr, row_begin, row_end, halo_rows, row_bytes, image_rows):
+    def __init__(self, ptr, row_begin, row_end, halo_rows, row_bytes, image_rows, col_begin=0, col_end=None, image_cols=None, texel_bytes=None):
         self.ptr, self.row_begin, self.row_end, self.halo_rows, self.row_bytes, self.image_rows = ptr, row_begin, row_end, halo_rows, row_bytes, image_rows
+        # tile rendering: the owned rectangle is columns [col_begin, col_end) of those rows; texels of texel_bytes bytes, image_cols per row
+        self.image_cols = image_cols if image_cols is not None else 0
+        self.col_begin, self.col_end = col_begin, (col_end if col_end is not None else self.image_cols)
+        self.texel_bytes = texel_bytes if texel_bytes is not None else (row_bytes // image_cols if image_cols else 0)
 
     @classmethod
     def from_item(cls, it):
-        return cls(int(it.device_ptr), int(it.row_begin), int(it.row_end), int(it.halo_rows), int(it.row_bytes), int(it.image_rows))
+        return cls(int(it.device_ptr), int(it.row_begin), int(it.row_end), int(it.halo_rows), int(it.row_bytes), int(it.image_rows), int(it.col_begin), int(it.col_end),
+                   int(it.image_cols), int(it.texel_bytes))
 
     # rows this band sends up / down, and the rows it receives from above / below (clipped to the image and to what exists)
     def send_up(self):
@@ -111,6 +116,62 @@ def neighbour_plan(rows_of_band, index, n_bands):
         b = min(b, dn.row_end)
         ops.append((index + 1, "recv", a, b))
     return [o for o in ops if o[3] > o[2]]
+
+
+# ------------------------------------------------------------------ tiles: the partition as a list of rectangles (x0, y0, x1, y1), one per rank
+def tile_rects(width, height, gx, gy, col_bounds=None, row_bounds=None):
+    """gx x gy grid of tiles, row-major (rank = ty * gx + tx), every edge a multiple of 64 (the mirror of plrf_tile_rects)"""
+    cols = list(col_bounds) if col_bounds is not None else equal_bounds(width, gx)
+    rows = list(row_bounds) if row_bounds is not None else equal_bounds(height, gy)
+    return [(cols[tx], rows[ty], cols[tx + 1], rows[ty + 1]) for ty in range(gy) for tx in range(gx)]
+
+
+def band_rects(width, height, n_bands, bounds=None):
+    """a band partition as rectangles: whole rows"""
+    return [(0,) + (band_rows(height, n_bands, i, bounds)[0],) + (width,) + (band_rows(height, n_bands, i, bounds)[1],) for i in range(n_bands)]
+
+
+def _scale_rect(r, frame_w, frame_h, cols, rows):
+    dx, dy = max(1, (frame_w + cols // 2) // max(cols, 1)), max(1, (frame_h + rows // 2) // max(rows, 1))
+    return r[0] // dx, r[1] // dy, min((r[2] + dx - 1) // dx, cols), min((r[3] + dy - 1) // dy, rows)
+
+
+def _grow(r, k, w, h):
+    return max(r[0] - k, 0), max(r[1] - k, 0), min(r[2] + k, w), min(r[3] + k, h)
+
+
+def _intersect(a, b):
+    return max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+
+
+def _touching(a, b):
+    return a[0] <= b[2] and b[0] <= a[2] and a[1] <= b[3] and b[1] <= a[3]
+
+
+def rect_plan(rects, rank, frame_w, frame_h, image_cols, image_rows, halo):
+    """[(peer, 'send'|'recv', x0, y0, x1, y1)] in texels of an image of image_cols x image_rows showing the frame at frame_w / image_cols scale: with every
+    rank whose rectangle touches this rank's (edge or corner), the part of the own rectangle within `halo` texels of the peer's is sent, the part of the
+    peer's within `halo` of the own is received (the mirror of plrf_exchange_plan_rects; for whole-row rectangles it equals neighbour_plan)"""
+    ops = []
+    mine = _scale_rect(rects[rank], frame_w, frame_h, image_cols, image_rows)
+    for p, r in enumerate(rects):
+        if p == rank or not _touching(rects[rank], r):
+            continue
+        theirs = _scale_rect(r, frame_w, frame_h, image_cols, image_rows)
+        for kind, q in (("send", _intersect(mine, _grow(theirs, halo, image_cols, image_rows))), ("recv", _intersect(theirs, _grow(mine, halo, image_cols, image_rows)))):
+            if q[2] > q[0] and q[3] > q[1]:
+                ops.append((p, kind) + q)
+    return ops
+
+
+def balanced_tile_bounds(width, height, gx, gy, col_bounds, row_bounds, tile_times, min_size=2 * BAND_ALIGNMENT):
+    """static load balancing of a regular gx x gy grid from measured per-tile render times (row-major): the rows are cut by the times summed over each row
+    of tiles, the columns by the times summed over each column (balanced_bounds on either axis) -> (col_bounds, row_bounds)"""
+    row_times = [sum(tile_times[ty * gx + tx] for tx in range(gx)) for ty in range(gy)]
+    col_times = [sum(tile_times[ty * gx + tx] for ty in range(gy)) for tx in range(gx)]
+    rows = balanced_bounds(height, list(row_bounds), row_times, min_size) if gy > 1 else list(row_bounds)
+    cols = balanced_bounds(width, list(col_bounds), col_times, min_size) if gx > 1 else list(col_bounds)
+    return cols, rows
 
 
 # ------------------------------------------------------------------ transports
@@ -159,8 +220,43 @@ class DistTransport:
 
     def end_exchange(self, handle, stream_ptr):
         with self._on_stream(stream_ptr):
+            if isinstance(handle, tuple):  # a rectangle exchange: (requests, [(view, staging)]) - what arrived is scattered into the images now
+                reqs, scatter = handle
+                for req in reqs:
+                    req.wait()
+                for view, staging in scatter:
+                    view.copy_(staging)
+                return
             for req in handle:
                 req.wait()
+
+    def _view(self, r, x0, y0, x1, y1):
+        """the rectangle of item r as a (rows, bytes) strided view of its image"""
+        img = self._tensor(r.ptr, r.image_rows * r.row_bytes).view(r.image_rows, r.row_bytes)
+        return img[y0:y1, x0 * r.texel_bytes:x1 * r.texel_bytes]
+
+    def begin_exchange_rects(self, items, plans, stream_ptr):
+        """tile rendering: plans[i] = rect_plan of item i. A rectangle is a strided range: it is gathered into a contiguous tensor for the send and scattered
+        from one after the receive (the native exchange does the same with one pack / unpack kernel, csrc/frontend/band_exchange.cpp)"""
+        dist, ops, scatter, keep = self.dist, [], [], []
+        with self._on_stream(stream_ptr):
+            for r, plan in zip(items, plans):
+                for peer, kind, x0, y0, x1, y1 in plan:
+                    view = self._view(r, x0, y0, x1, y1)
+                    if kind == "send":
+                        t = view.contiguous()
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.isend, t, peer))
+                    else:
+                        t = self.torch.empty_like(view, memory_format=self.torch.contiguous_format)
+                        scatter.append((view, t))
+                        ops.append(dist.P2POp(dist.irecv, t, peer))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+        self._keep = keep  # the gathered tensors live until the next exchange
+        return (reqs, scatter)
+
+    def exchange_rects(self, items, plans, stream_ptr):
+        self.end_exchange(self.begin_exchange_rects(items, plans, stream_ptr), stream_ptr)
 
     def all_reduce_histogram(self, ptr, nbytes, stream_ptr):
         with self._on_stream(stream_ptr):
@@ -188,6 +284,7 @@ class LocalGroup:
         lib.plr_copy_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.plr_read_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.plr_write_device_memory.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.plr_copy_device_memory_2d.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
 
 
 class LocalTransport:
@@ -228,6 +325,23 @@ class LocalTransport:
         self.exchange(items, stream_ptr, band_meta)  # threads of one process: the copy is done when this returns
         return None
 
+    def exchange_rects(self, items, plans, stream_ptr):
+        """tile rendering: every received rectangle is a 2-D device copy from the owner's image (same texel grid on both sides)"""
+        self._publish(items)
+        for i, (r, plan) in enumerate(zip(items, plans)):
+            for peer, kind, x0, y0, x1, y1 in plan:
+                if kind != "recv":
+                    continue
+                off = y0 * r.row_bytes + x0 * r.texel_bytes
+                src = self.g.slots[peer][i].ptr + off
+                self._call(self.g.lib.plr_copy_device_memory_2d(C.c_void_p(r.ptr + off), C.c_size_t(r.row_bytes), C.c_void_p(src), C.c_size_t(r.row_bytes),
+                                                                C.c_size_t((x1 - x0) * r.texel_bytes), C.c_size_t(y1 - y0)), "plr_copy_device_memory_2d")
+        self._retire()
+
+    def begin_exchange_rects(self, items, plans, stream_ptr):
+        self.exchange_rects(items, plans, stream_ptr)
+        return None
+
     def end_exchange(self, handle, stream_ptr):
         pass
 
@@ -255,9 +369,11 @@ class LocalTransport:
 class Exchange:
     """the exchange callback of one band: glue between the C++ host's exchange points and a transport"""
 
-    def __init__(self, fp, transport, height, n_bands, index, bounds=None):
+    def __init__(self, fp, transport, height, n_bands, index, bounds=None, rects=None, width=None):
+        """rects (+ width): the partition as rectangles, one per rank (tile rendering); else row bands (bounds / the equal partition)"""
         from .frame import EXCHANGE_HISTOGRAM
         self.fp, self.t, self.height, self.n, self.index, self.bounds = fp, transport, height, n_bands, index, bounds
+        self.rects, self.width = rects, width
         self._hist_id = EXCHANGE_HISTOGRAM
         self.calls = []
         self._pending = {}
@@ -283,6 +399,13 @@ class Exchange:
             self.t.all_reduce_depth_apex(ptr, nbytes, stream_ptr)
             return
         items = [Rows.from_item(it) for it in self.fp.exchange_items(exchange_id)]
+        if self.rects is not None:
+            plans = [rect_plan(self.rects, self.index, self.width, self.height, r.image_cols, r.image_rows, r.halo_rows) for r in items]
+            if phase == EXCHANGE_BEGIN:
+                self._pending[exchange_id] = self.t.begin_exchange_rects(items, plans, stream_ptr)
+            else:
+                self.t.exchange_rects(items, plans, stream_ptr)
+            return
 
         def band_meta(i, b):
             # rows of band b in item i's image: the full-resolution band scaled by the item's resolution divisor

@@ -147,21 +147,25 @@ def _make_inputs():
     return SyntheticInputs(scene, cams[1], cams[0], W, H, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
 
 
-def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1, extra=None):
-    """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame; extra = more FramePipeline settings"""
+def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1, extra=None, rects=None):
+    """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame; extra = more FramePipeline settings;
+    rects: the partition as rectangles (tile rendering) - band[0] then indexes it"""
     from plainrenderer_amd import RenderBackend
     from plainrenderer_amd.frame import FramePipeline
     try:
         be = RenderBackend(W, H, device=0)
         be.setMathMode(not exact)
         kw = dict(FP_ARGS, sdf_half_res_trace=half_res, **(extra or {}))
-        if band is not None:
+        if band is not None and rects is not None:
+            x0, y0, x1, y1 = rects[band[0]]
+            kw.update(band_row_begin=y0, band_row_end=y1, band_col_begin=x0, band_col_end=x1, **(halos or {}))
+        elif band is not None:
             b0, b1 = tiling.band_rows(H, band[1], band[0])
             kw.update(band_row_begin=b0, band_row_end=b1, **(halos or {}))
         fp = FramePipeline(be, W, H, **kw)
         inp = copy.copy(inputs)
         inp.upload(fp)
-        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band[0]), H, band[1], band[0]) if band is not None else None
+        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band[0]), H, band[1], band[0], rects=rects, width=W) if band is not None else None
         cams = _cams()
         frames = []
         for f in range(N_FRAMES):
@@ -196,11 +200,11 @@ def _run_full(inputs, exact, half_res=1, extra=None):
     return out["full"]
 
 
-def _run_bands(inputs, n, exact, halos, half_res=1, extra=None):
+def _run_bands(inputs, n, exact, halos, half_res=1, extra=None, rects=None):
     from plainrenderer_amd import backend
     group = tiling.LocalGroup(n, backend._load())
     out = {}
-    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res, extra)) for i in range(n)]
+    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res, extra, rects)) for i in range(n)]
     for t in threads:
         t.start()
     for t in threads:
@@ -212,16 +216,19 @@ def _run_bands(inputs, n, exact, halos, half_res=1, extra=None):
     return out
 
 
-def _compare(full, bands, n, what=("post", "color", "swap")):
+def _compare(full, bands, n, what=("post", "color", "swap"), rects=None):
     mism = {}
     for f in range(N_FRAMES):
         for i in range(n):
-            b0, b1 = tiling.band_rows(H, n, i)
+            if rects is not None:
+                x0, b0, x1, b1 = rects[i]
+            else:
+                x0, (b0, b1), x1 = 0, tiling.band_rows(H, n, i), W
             fr, bf = full["frames"][f], bands[i]["frames"][f]
             assert np.array_equal(fr["hist"], bf["hist"]) and int(bf["hist"].sum()) == W * H, "histogram frame %d band %d" % (f, i)
             assert fr["light"] == bf["light"], "exposure frame %d band %d" % (f, i)
             for k in what:
-                d = fr[k][b0:b1] != bf[k][b0:b1]
+                d = fr[k][b0:b1, x0:x1] != bf[k][b0:b1, x0:x1]
                 mism[(f, i, k)] = float(d.mean())
     return mism
 
@@ -513,3 +520,269 @@ def test_gpu_two_bands_of_realistic_height_with_default_halos(monkeypatch):
 def pixfmt_unpack(a):
     from plainrenderer_amd import pixfmt
     return pixfmt.unpack_r11g11b10(np.ascontiguousarray(a).reshape(-1))
+
+
+# ------------------------------------------------------------------ tile rendering (round 5): the frame as a grid of screen tiles, BASELINE config 5's 2 x 2
+def test_rect_plan_of_bands_equals_the_band_plan_and_the_cpp_plan():
+    """tiling.rect_plan / plrf_exchange_plan_rects describe a partition into rectangles. For whole-row rectangles they must be the band plan
+    (neighbour_plan / plrf_exchange_plan_rows) transfer for transfer; for tile grids the C++ plan equals the Python one, every send has its receive on the
+    peer, and what a tile receives is exactly its halo frame inside the image (corners included)"""
+    import ctypes as C
+    from plainrenderer_amd import backend
+
+    class RectOp(C.Structure):
+        _fields_ = [(n, C.c_uint32) for n in ("peer", "send", "x0", "y0", "x1", "y1")]
+    lib = C.CDLL(backend.LIB_PATH)
+
+    def cpp_plan(w, h, rects, rank, cols, rows, halo):
+        n = len(rects)
+        ops, cnt = (RectOp * (2 * n))(), C.c_uint32()
+        flat = (C.c_uint32 * (4 * n))(*[v for r in rects for v in r])
+        assert lib.plrf_exchange_plan_rects(C.c_uint32(w), C.c_uint32(h), C.c_uint32(n), flat, C.c_uint32(rank), C.c_uint32(cols), C.c_uint32(rows), C.c_uint32(halo), ops, C.c_uint32(2 * n),
+                                            C.byref(cnt)) == 0
+        return [(int(o.peer), "send" if o.send else "recv", int(o.x0), int(o.y0), int(o.x1), int(o.y1)) for o in ops[:cnt.value]]
+
+    # bands as rectangles
+    w = 7680
+    for height, n in ((4320, 4), (2160, 2), (1088, 3), (8640, 8)):
+        rects = tiling.band_rects(w, height, n)
+        for div in (1, 2):
+            cols, rows = w // div, height // div
+            for halo in (0, 16, 64, 224, 5000):
+                bands = [tiling.Rows(0, r[1] // div, min((r[3] + div - 1) // div, rows), halo, 16 * cols, rows) for r in rects]
+                for b in range(n):
+                    expect = [(peer, kind, 0, a, cols, e) for peer, kind, a, e in tiling.neighbour_plan(bands, b, n)]
+                    assert tiling.rect_plan(rects, b, w, height, cols, rows, halo) == expect, (height, n, b, div, halo)
+                    assert cpp_plan(w, height, rects, b, cols, rows, halo) == expect
+    # tile grids
+    for (fw, fh, gx, gy) in ((7680, 4320, 2, 2), (7680, 8640, 2, 4), (3840, 2160, 4, 2), (256, 192, 2, 2), (7680, 2160, 2, 1)):
+        rects = tiling.tile_rects(fw, fh, gx, gy)
+        flat = (C.c_uint32 * (4 * gx * gy))()
+        assert lib.plrf_tile_rects(C.c_uint32(fw), C.c_uint32(fh), C.c_uint32(gx), C.c_uint32(gy), None, None, flat) == 0
+        assert [tuple(flat[4 * i:4 * i + 4]) for i in range(gx * gy)] == rects
+        assert sum((r[2] - r[0]) * (r[3] - r[1]) for r in rects) == fw * fh
+        for div in (1, 2):
+            cols, rows = fw // div, fh // div
+            for halo in (8, 16, 128, 224):
+                plans = [tiling.rect_plan(rects, k, fw, fh, cols, rows, halo) for k in range(gx * gy)]
+                for k, plan in enumerate(plans):
+                    assert cpp_plan(fw, fh, rects, k, cols, rows, halo) == plan, (fw, fh, gx, gy, k, div, halo)
+                    got = np.zeros((rows, cols), np.int32)
+                    for peer, kind, x0, y0, x1, y1 in plan:
+                        other = "recv" if kind == "send" else "send"
+                        assert (k, other, x0, y0, x1, y1) in plans[peer]
+                        if kind == "recv":
+                            got[y0:y1, x0:x1] += 1
+                    mx0, my0, mx1, my1 = tiling._scale_rect(rects[k], fw, fh, cols, rows)
+                    want = np.zeros((rows, cols), np.int32)
+                    want[max(my0 - halo, 0):my1 + halo, max(mx0 - halo, 0):mx1 + halo] = 1
+                    want[my0:my1, mx0:mx1] = 0
+                    if halo <= min(r[2] - r[0] for r in rects) // div and halo <= min(r[3] - r[1] for r in rects) // div:  # (a halo wider than a neighbour is clipped to it)
+                        assert np.array_equal(got, want), "a tile receives its halo frame, every texel once (%s)" % ((fw, fh, gx, gy, k, div, halo),)
+    # rectangles that overlap / leave a hole / sit off the 64-pixel grid are refused
+    bad = (C.c_uint32 * 8)(0, 0, 100, 192, 100, 0, 256, 192)
+    assert lib.plrf_exchange_plan_rects(C.c_uint32(256), C.c_uint32(192), C.c_uint32(2), bad, C.c_uint32(0), C.c_uint32(256), C.c_uint32(192), C.c_uint32(8), (RectOp * 4)(), C.c_uint32(4),
+                                        C.byref(C.c_uint32())) != 0
+
+
+def _gloo_tile_worker(rank, world, port, fw, fh, gx, gy, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = tiling.DistTransport(rank, world, device=None)
+        rects = tiling.tile_rects(fw, fh, gx, gy)
+        items, arrays, plans = [], [], []
+        for div, texel_bytes, halo in ((1, 4, 16), (2, 8, 8)):
+            cols, rows = fw // div, fh // div
+            x0, y0, x1, y1 = tiling._scale_rect(rects[rank], fw, fh, cols, rows)
+            img = np.full((rows, cols * texel_bytes), 0xEE, np.uint8)
+            stamp = ((np.arange(rows)[:, None] * 7 + np.arange(cols * texel_bytes)[None, :] * 3) % 251).astype(np.uint8)
+            img[y0:y1, x0 * texel_bytes:x1 * texel_bytes] = stamp[y0:y1, x0 * texel_bytes:x1 * texel_bytes]
+            arrays.append(img)
+            items.append(tiling.Rows(img.ctypes.data, y0, y1, halo, cols * texel_bytes, rows, x0, x1, cols, texel_bytes))
+            plans.append(tiling.rect_plan(rects, rank, fw, fh, cols, rows, halo))
+        t.exchange_rects(items[:1], plans[:1], None)                                    # one call
+        t.end_exchange(t.begin_exchange_rects(items[1:], plans[1:], None), None)        # the overlapped form
+        out.put((rank, [a.copy() for a in arrays]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_transport_gloo_world4_tiles():
+    """the torch.distributed transport over a 2 x 2 tile partition, world size 4 over gloo: every tile ends up with its own texels, the halo frame of its
+    three neighbours' texels (corners from the diagonal tile) and nothing else"""
+    import torch.multiprocessing as mp
+    fw, fh, gx, gy, world = 256, 128, 2, 2, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_tile_worker, args=(r, world, port, fw, fh, gx, gy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, arrays = q.get(timeout=180)
+        got[rank] = arrays
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rects = tiling.tile_rects(fw, fh, gx, gy)
+    for rank in range(world):
+        for (div, texel_bytes, halo), img in zip(((1, 4, 16), (2, 8, 8)), got[rank]):
+            cols, rows = fw // div, fh // div
+            x0, y0, x1, y1 = tiling._scale_rect(rects[rank], fw, fh, cols, rows)
+            stamp = ((np.arange(rows)[:, None] * 7 + np.arange(cols * texel_bytes)[None, :] * 3) % 251).astype(np.uint8)
+            expect = np.full((rows, cols * texel_bytes), 0xEE, np.uint8)
+            hx0, hy0, hx1, hy1 = max(x0 - halo, 0), max(y0 - halo, 0), min(x1 + halo, cols), min(y1 + halo, rows)
+            expect[hy0:hy1, hx0 * texel_bytes:hx1 * texel_bytes] = stamp[hy0:hy1, hx0 * texel_bytes:hx1 * texel_bytes]
+            assert np.array_equal(img, expect), "tile %d, image at 1/%d resolution" % (rank, div)
+
+
+def test_exchange_watchdog_names_the_exchange_that_never_completes():
+    """a transport whose completion never arrives must not hang the frame silently. The watchdog of the native exchange
+    (csrc/frontend/band_exchange.cpp) with a completion query that always answers "still running": nothing is reported before the deadline, the report
+    after it names rank, exchange and phase; an entry that completes is dropped and never reported"""
+    import ctypes as C
+    import time
+    from plainrenderer_amd import backend
+    lib = C.CDLL(backend.LIB_PATH)
+    QUERY = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    never = QUERY(lambda user: 0)
+    state = {"done": False}
+    later = QUERY(lambda user: 1 if state["done"] else 0)
+    wd = C.c_void_p()
+    assert lib.plrf_watchdog_create(C.c_uint32(150), C.byref(wd)) == 0
+    buf = C.create_string_buffer(1024)
+    assert lib.plrf_watchdog_arm(wd, C.c_int(3), C.c_int(2), C.c_int(0x100), never, None) == 0      # rank 3, temporally filtered GI, BEGIN
+    assert lib.plrf_watchdog_arm(wd, C.c_int(3), C.c_int(4), C.c_int(0x100), later, None) == 0      # rank 3, resolved colour, BEGIN: completes in time
+    assert lib.plrf_watchdog_poll(wd, buf, C.c_size_t(1024)) == 0 and buf.value == b""
+    state["done"] = True
+    time.sleep(0.3)
+    assert lib.plrf_watchdog_poll(wd, buf, C.c_size_t(1024)) == 1
+    msg = buf.value.decode()
+    assert "rank 3" in msg and "exchange 2" in msg and "temporally filtered GI" in msg and "BEGIN" in msg and "deadline 150 ms" in msg, msg
+    assert "exchange 4" not in msg
+    assert lib.plrf_watchdog_destroy(wd) == 0
+    # deadline 0 = off
+    assert lib.plrf_watchdog_create(C.c_uint32(0), C.byref(wd)) == 0
+    assert lib.plrf_watchdog_arm(wd, C.c_int(0), C.c_int(1), C.c_int(0x100), never, None) == 0
+    time.sleep(0.05)
+    assert lib.plrf_watchdog_poll(wd, buf, C.c_size_t(1024)) == 0
+    assert lib.plrf_watchdog_destroy(wd) == 0
+
+
+def _tile_rects(gx, gy):
+    return tiling.tile_rects(W, H, gx, gy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,half_res", [((2, 2), 1), ((2, 1), 1), ((2, 2), 0)])
+def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res):
+    """BASELINE config 5's partition: the frame as 2 x 2 screen tiles (and 2 x 1), one backend per tile on this GPU, rectangles moved by the in-process transport.
+    Every tile touches every other one, so halos as large as the image make every pass's inputs complete: the tiled frame must equal the unpartitioned one in
+    every bit (exact kernel set), over three frames of temporal feedback - every column span, every valid-column range, every exchange rectangle, the per-tile
+    pyramid and culling by tile columns, the histogram all-reduce of tile rectangles"""
+    inputs = _make_inputs()
+    full = _run_full(inputs, True, half_res)
+    rects = _tile_rects(*grid)
+    n = len(rects)
+    big = max(W, H)
+    halos = dict(band_gi_halo=big, band_gi_history_halo=big, band_post_halo=big, band_taa_history_halo=big, band_overlap_exchange=2 if half_res else 0)
+    tiles = _run_bands(inputs, n, True, halos, half_res, rects=rects)
+    mism = _compare(full, tiles, n, rects=rects)
+    bad = {k: v for k, v in mism.items() if v != 0.0}
+    assert not bad, bad
+    B, E = 0x100, 0x200
+    expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if half_res else [0, 1, 2, 3, 4]
+    assert tiles[0]["calls"][:len(expected)] == expected
+
+
+@pytest.mark.gpu
+def test_gpu_tiles_fast_math_matches_full_frame_and_edges_first_changes_no_bit():
+    """the benchmarked (PLR_MATH_FAST) kernel set through the 2 x 2 partition: whole-image halos -> the unpartitioned frame's bits; and with small halos the
+    producers of exchanged images run the FRAME of the tile first (plr.h first_rows + first_cols, one launch, edge signal) - the same bits as the plain
+    recording, the signal raised once per producer and frame"""
+    inputs = _make_inputs()
+    full = _run_full(inputs, False)
+    rects = _tile_rects(2, 2)
+    big = max(W, H)
+    tiles = _run_bands(inputs, 4, False, dict(band_gi_halo=big, band_gi_history_halo=big, band_post_halo=big, band_taa_history_halo=big), rects=rects)
+    mism = _compare(full, tiles, 4, rects=rects)
+    bad = {k: v for k, v in mism.items() if v != 0.0}
+    assert not bad, bad
+    small = dict(band_gi_halo=8, band_gi_history_halo=8, band_post_halo=16, band_taa_history_halo=8)
+    first = _run_bands(inputs, 4, False, dict(small, band_overlap_exchange=2), rects=rects)
+    plain = _run_bands(inputs, 4, False, dict(small, band_overlap_exchange=0), rects=rects)
+    for i in range(4):
+        ptr, value, now = first[i]["edge_signal"]
+        assert ptr is not None and value == 3 * N_FRAMES and now == value, (i, value, now)
+        assert plain[i]["edge_signal"][1] == 0
+        x0, y0, x1, y1 = rects[i]
+        for f in range(N_FRAMES):
+            for k in ("post", "color", "swap"):
+                assert np.array_equal(first[i]["frames"][f][k][y0:y1, x0:x1], plain[i]["frames"][f][k][y0:y1, x0:x1]), "tile %d frame %d %s" % (i, f, k)
+
+
+@pytest.mark.gpu
+def test_gpu_tiles_of_realistic_size_with_default_halos(monkeypatch):
+    """2 x 2 tiles of 512 x 576 pixels of a 1024 x 1152 frame with the DEFAULT halos, benchmarked kernel set, three frames - the tile version of the two-band test
+    above: everything except the spatial GI filter is exact for these halos, the filter's disc gives samples beyond the halo weight 0"""
+    import sys
+    import parity
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "W", 1024)
+    monkeypatch.setattr(mod, "H", 1152)
+    inputs = _make_inputs()
+    full = _run_full(inputs, False)
+    rects = tiling.tile_rects(1024, 1152, 2, 2)
+    tiles = _run_bands(inputs, 4, False, None, rects=rects)
+    worst_within1, worst_mean = 1.0, 0.0
+    for f in range(N_FRAMES):
+        for i in range(4):
+            x0, y0, x1, y1 = rects[i]
+            fr, bf = full["frames"][f], tiles[i]["frames"][f]
+            # the all-reduce gives every tile the same histogram; against the unpartitioned frame the handful of pixels of the previous frame that differ by a code
+            # (the denoiser's halo deviation, below) may sit in a neighbouring bin
+            assert np.array_equal(tiles[0]["frames"][f]["hist"], bf["hist"]) and int(bf["hist"].sum()) == 1024 * 1152, "histogram all-reduce: identical on every tile (frame %d)" % f
+            assert int(np.abs(fr["hist"].astype(np.int64) - bf["hist"].astype(np.int64)).sum() // 2) <= 64, "histogram vs the unpartitioned frame (frame %d)" % f
+            a_, b_ = np.ascontiguousarray(bf["post"][y0:y1, x0:x1]), np.ascontiguousarray(fr["post"][y0:y1, x0:x1])
+            d = parity.r11g11b10_code_diff(a_.reshape(-1), b_.reshape(-1))
+            within1 = float((d <= 1).all(axis=1).mean())
+            a, b = pixfmt_unpack(a_), pixfmt_unpack(b_)
+            mean_rel = float(np.abs(a - b).mean() / b.mean())
+            print("TILES frame %d tile %d: pixels within one code of the unpartitioned frame %.5f, max code diff %d, mean rel err %.2e" % (f, i, within1, int(d.max()), mean_rel))
+            worst_within1, worst_mean = min(worst_within1, within1), max(worst_mean, mean_rel)
+    assert worst_within1 >= 0.995 and worst_mean <= 1e-3
+    assert tiles[0]["fused"] >= 8, tiles[0]["fused"]  # tile mode keeps the fusions: per-tile pyramid + culling, upscale + shade, packed GI texels, apply + tonemap
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loopback", [False, True])
+def test_gpu_native_exchange_packs_and_unpacks_rectangles(backend, loopback):
+    """the native exchange's pack / unpack kernels and packed transport (csrc/frontend/band_exchange.cpp): rectangles of 4- and 8-byte texels, 16-byte aligned and
+    not, travel pack -> ncclSend / ncclRecv to this rank itself (loopback: a device copy) -> unpack onto another place of the image"""
+    from plainrenderer_amd.frame import FramePipeline
+    w, h = 256, 128
+    fp = FramePipeline(backend, w, h, shadow_map_res=128, brdf_lut_res=16, froxel_depth=8, max_sdf_instances=16, band_row_begin=0, band_row_end=h)
+    try:
+        fp.attach_rccl_rects(None if loopback else fp.rccl_unique_id(), 0, 1, w, h, [(0, 0, w, h)])
+        info = fp.rccl_info()
+        assert info["rccl_ranks"] == (0 if loopback else 1) and info["rccl_version"] > 0 and info["watchdog_ms"] == 2000, info
+        rng = np.random.default_rng(5)
+        for name, dtype, texel_bytes, rect, dst in (("post1", np.uint32, 4, (8, 4, 72, 36), (128, 64)), ("post1", np.uint32, 4, (3, 5, 14, 9), (100, 90)),
+                                                   ("giFullResYSH", np.uint64, 8, (16, 8, 48, 24), (160, 96))):
+            img = fp.image(name)
+            data = rng.integers(0, np.iinfo(dtype).max, (h, w), dtype=dtype)
+            backend.uploadImage(img, data)
+            ptr, size = backend.imageDevicePointer(img, 0)
+            assert size == w * h * texel_bytes
+            fp.rccl_self_test_rect(ptr, w * texel_bytes, texel_bytes, rect, dst)
+            got = backend.downloadImage(img, 0, dtype).reshape(h, w)
+            expect = data.copy()
+            x0, y0, x1, y1 = rect
+            expect[dst[1]:dst[1] + (y1 - y0), dst[0]:dst[0] + (x1 - x0)] = data[y0:y1, x0:x1]
+            assert np.array_equal(got, expect), (name, rect, dst)
+    finally:
+        fp.destroy()

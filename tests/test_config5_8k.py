@@ -1,9 +1,14 @@
-"""BASELINE.json config 5 at its workload: the full frame (GI + shade + post) at 7680 x 4320, 256 SDF instances x 64^3, rendered as FOUR row bands
-with the default halos, the benchmarked (PLR_MATH_FAST) kernel set, pass fusion on and a balanced partition, three frames of temporal feedback.
+"""BASELINE.json config 5 at its workload: the full frame (GI + shade + post) at 7680 x 4320, 256 SDF instances x 64^3, rendered as 2 x 2 SCREEN TILES - the
+partition config 5 names - and as FOUR row bands, with the default halos, the benchmarked (PLR_MATH_FAST) kernel set, pass fusion on and a balanced
+partition, over temporal feedback.
 
-All four bands run in this process on one GPU (one host thread + one backend per band, tiling.LocalTransport moves the halo rows - the recording,
-the dispatch bases, the exchange points and the kernels are exactly those of the 4-GPU run; only the transport differs). Every band is held to the
-UNPARTITIONED 8K frame, and a strip that straddles a band boundary to the ORACLE frame (the scalar C++ restatement, run on the host cores).
+All four partitions run in this process on one GPU (one host thread + one backend each, tiling.LocalTransport moves the halo rectangles - the recording,
+the dispatch bases, the exchange points and the kernels are exactly those of the 4-GPU run; only the transport differs). Every partition is held to the
+UNPARTITIONED 8K frame, and a strip that straddles a boundary to the ORACLE frame (the scalar C++ restatement, run on the host cores).
+
+The deviation of a partitioned frame from the unpartitioned one grows over the first frames (the temporal filters integrate the denoiser samples dropped at
+the halo's end) and then settles: the assert sits at the CONVERGED value, at a frame count that has reached it (profiles/r05_config5_series.txt; VERDICT
+r04 item 2) - PLR_CONFIG5_FRAMES overrides the count for the series runs of tools/config5_series.sh.
 
 PLR_CONFIG5_SIZE=WxH (H a multiple of 256) shrinks the frame for debugging. Measured numbers: profiles/r03_config5_8k.txt."""
 import copy
@@ -19,25 +24,40 @@ from plainrenderer_amd import pixfmt, tiling
 
 W, H = (int(v) for v in os.environ.get("PLR_CONFIG5_SIZE", "7680x4320").split("x"))
 N_BANDS = 4
-N_FRAMES = int(os.environ.get("PLR_CONFIG5_FRAMES", "3"))  # PLR_CONFIG5_FRAMES=16 PLR_CONFIG5_REPORT_ONLY=1: the convergence series (tools/profile_round.sh)
+N_FRAMES = int(os.environ.get("PLR_CONFIG5_FRAMES", "3"))  # PLR_CONFIG5_FRAMES=64 PLR_CONFIG5_REPORT_ONLY=1: the convergence series (tools/config5_series.sh)
 # The partition is what bench.py --gpus 4 would use: tiling.balanced_bounds of band times MEASURED in this test on this GPU (one calibration round with
 # an exchange that moves nothing, as bench.calibrate_partition does). The sky band is cheap, ground-level geometry is not.
+
+
+# converged share of a partition's pixels within one code of the unpartitioned frame (worst partition, minus a margin): from the series in
+# profiles/r05_config5_series.txt; the default N_FRAMES below is a frame count at which the series has reached it
+CONVERGED_WITHIN1 = {"tiles2x2": 0.98, "bands4": 0.98}
+
+
+def _kept(f):
+    """frames whose images are kept for the comparison: all of a short run, a thinning subset of a long series (host memory: 133 MB per 8K image)"""
+    return N_FRAMES <= 8 or f < 4 or (f + 1) % 8 == 0 or f == N_FRAMES - 1
 
 
 class _Args:
     grid, sdf_res, shadow_res, steps, warmup, profile_frames = 16, 64, 2048, N_FRAMES + 1, 0, 0
 
 
-def _bounds(inputs, cams):
+def _partition(inputs, cams, kind):
+    """the partition bench.py --gpus 4 would use: rectangles balanced from times MEASURED here (one calibration round with an exchange that moves nothing)"""
     import time
     from plainrenderer_amd import RenderBackend
     from plainrenderer_amd.frame import FramePipeline
-    eq = tiling.equal_bounds(H, N_BANDS)
+    gx, gy = (2, 2) if kind == "tiles2x2" else (1, 4)
+    cols, rows = tiling.equal_bounds(W, gx), tiling.equal_bounds(H, gy)
+    rects = tiling.tile_rects(W, H, gx, gy, cols, rows)
     times, box = [], {}
 
     def measure(i):  # on a thread of its own: a backend per thread
+        x0, y0, x1, y1 = rects[i]
         be = RenderBackend(W, H, device=0)
-        fp = FramePipeline(be, W, H, shadow_map_res=2048, band_row_begin=eq[i], band_row_end=eq[i + 1])
+        kw = dict(band_col_begin=x0, band_col_end=x1) if gx > 1 else {}
+        fp = FramePipeline(be, W, H, shadow_map_res=2048, band_row_begin=y0, band_row_end=y1, **kw)
         fp.set_exchange_callback(lambda exchange_id, stream: None)
         copy.copy(inputs).upload(fp)
         for f in range(3):
@@ -56,12 +76,13 @@ def _bounds(inputs, cams):
         t.start()
         t.join(timeout=600)
         times.append(box[i])
-    bounds = tiling.balanced_bounds(H, eq, times, min_rows=512)
-    print("CONFIG5 partition: equal bands %s take %s ms -> balanced bounds %s" % (eq, ["%.3f" % (t * 1e3) for t in times], bounds), flush=True)
-    return bounds
+    new_cols, new_rows = tiling.balanced_tile_bounds(W, H, gx, gy, cols, rows, times, min_size=512)
+    out = tiling.tile_rects(W, H, gx, gy, new_cols, new_rows)
+    print("CONFIG5 %s partition: equal rectangles %s take %s ms -> balanced %s" % (kind, rects, ["%.3f" % (t * 1e3) for t in times], out), flush=True)
+    return out
 
 
-def _render(inputs, cams, band, bounds, group, out, capture):
+def _render(inputs, cams, band, rects, group, out, capture):
     """one backend + C++ FramePipeline on the calling thread; band = index or None (the unpartitioned frame)"""
     from plainrenderer_amd import RenderBackend
     from plainrenderer_amd.frame import FramePipeline
@@ -71,20 +92,26 @@ def _render(inputs, cams, band, bounds, group, out, capture):
         be.setMathMode(True)
         kw = dict(shadow_map_res=2048)
         if band is not None:
-            kw.update(band_row_begin=bounds[band], band_row_end=bounds[band + 1])
+            x0, y0, x1, y1 = rects[band]
+            kw.update(band_row_begin=y0, band_row_end=y1)
+            if x0 != 0 or x1 != W:
+                kw.update(band_col_begin=x0, band_col_end=x1)
             if "PLR_CONFIG5_GI_HALO" in os.environ:  # experiment hook: trace rows of GI exchanged with each neighbour (default: FramePipeline's)
                 kw.update(band_gi_halo=int(os.environ["PLR_CONFIG5_GI_HALO"]))
         fp = FramePipeline(be, W, H, **kw)
         inp = inputs if band is None else copy.copy(inputs)  # (the unpartitioned run's upload leaves the texture-array indices the oracle frame needs)
         inp.upload(fp)
-        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band), H, N_BANDS, band, bounds) if band is not None else None
-        r0, r1 = (0, H) if band is None else (bounds[band], bounds[band + 1])
+        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band), H, N_BANDS, band, rects=rects, width=W) if band is not None else None
+        c0, r0, c1, r1 = (0, 0, W, H) if band is None else rects[band]
         frames = []
         for f in range(N_FRAMES):
             fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
-            post = be.downloadImage(fp.image("post1"), 0, np.uint32).reshape(H, W)[r0:r1].copy()
+            if not _kept(f):
+                frames.append(None)
+                continue
+            post = be.downloadImage(fp.image("post1"), 0, np.uint32).reshape(H, W)[r0:r1, c0:c1].copy()
             # (the long report-only series keeps the resolved colour only: 16 frames of both images of five renders would be 17 GB of host memory)
-            swap = be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(H, W, 4)[r0:r1].copy() if N_FRAMES <= 4 else None
+            swap = be.downloadImage(fp.image("swapchain"), 0, np.uint8).reshape(H, W, 4)[r0:r1, c0:c1].copy() if N_FRAMES <= 4 else None
             rec = dict(post=post, swap=swap, hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
                        light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes())
             if capture is not None and band is None:
@@ -114,77 +141,100 @@ def _join(threads, out, keys):
             raise out[k]
 
 
+_FULL = {}  # the unpartitioned 8K frames, rendered once for both partitions
+
+
 @pytest.mark.gpu
-def test_gpu_config5_four_bands_of_the_8k_frame_against_the_unpartitioned_frame_and_the_oracle():
+@pytest.mark.parametrize("kind", ["tiles2x2", "bands4"])
+def test_gpu_config5_the_8k_frame_partitioned_against_the_unpartitioned_frame_and_the_oracle(kind):
     import bench
     from plainrenderer_amd import backend as backend_mod
     assert H % 256 == 0 or H == 4320
-    scene, cams, inputs = bench.build_scene(_Args, "cuda:0", W, H)
-    bounds = _bounds(inputs, cams)
-    assert bounds[0] == 0 and bounds[-1] == H and all(b % 64 == 0 for b in bounds[1:-1])
+    if "scene" not in _FULL:
+        _FULL["scene"] = bench.build_scene(_Args, "cuda:0", W, H)
+    scene, cams, inputs = _FULL["scene"]
+    rects = _partition(inputs, cams, kind)
+    assert sum((r[2] - r[0]) * (r[3] - r[1]) for r in rects) == W * H and all(v % 64 == 0 or v in (W, H) for r in rects for v in r)
     out = {}
-    _join([threading.Thread(target=_render, args=(inputs, cams, None, bounds, None, out, True))], out, ["full"])
+    if "full" not in _FULL:
+        _join([threading.Thread(target=_render, args=(inputs, cams, None, rects, None, out, True))], out, ["full"])
+        _FULL["full"] = out["full"]
+    full = _FULL["full"]
     group = tiling.LocalGroup(N_BANDS, backend_mod._load())
-    _join([threading.Thread(target=_render, args=(inputs, cams, i, bounds, group, out, None)) for i in range(N_BANDS)], out, list(range(N_BANDS)))
-    full = out["full"]
+    _join([threading.Thread(target=_render, args=(inputs, cams, i, rects, group, out, None)) for i in range(N_BANDS)], out, list(range(N_BANDS)))
     worst_within1, worst_swap, worst_moved, worst_exposure = 1.0, 1.0, 0, 0.0
     lines = []
     for f in range(N_FRAMES):
+        if not _kept(f):
+            continue
         for i in range(N_BANDS):
-            b0, b1 = bounds[i], bounds[i + 1]
+            c0, b0, c1, b1 = rects[i]
             fr, bf = full["frames"][f], out[i]["frames"][f]
-            # the all-reduce gives every band the same histogram (bit-exact integer sum) and therefore the same exposure; against the unpartitioned
+            # the all-reduce gives every partition the same histogram (bit-exact integer sum) and therefore the same exposure; against the unpartitioned
             # frame a few pixels of the previous frame's colour sit in a neighbouring bin (the denoiser's stated halo deviation, below)
-            assert np.array_equal(out[0]["frames"][f]["hist"], bf["hist"]) and out[0]["frames"][f]["light"] == bf["light"], "all-reduce: frame %d band %d" % (f, i)
+            assert np.array_equal(out[0]["frames"][f]["hist"], bf["hist"]) and out[0]["frames"][f]["light"] == bf["light"], "all-reduce: frame %d partition %d" % (f, i)
             assert int(bf["hist"].sum()) == W * H
             moved = int(np.abs(fr["hist"].astype(np.int64) - bf["hist"].astype(np.int64)).sum() // 2)
             ea, eb = np.frombuffer(fr["light"], np.float32), np.frombuffer(bf["light"], np.float32)
             worst_moved = max(worst_moved, moved)
             worst_exposure = max(worst_exposure, float(np.abs(ea - eb).max() / max(float(np.abs(ea).max()), 1e-30)))
-            d = parity.r11g11b10_code_diff(bf["post"].reshape(-1), fr["post"][b0:b1].reshape(-1))
+            ref = np.ascontiguousarray(fr["post"][b0:b1, c0:c1])
+            d = parity.r11g11b10_code_diff(bf["post"].reshape(-1), ref.reshape(-1))
             within1 = float((d <= 1).all(axis=1).mean())
-            sw = float((np.abs(bf["swap"].astype(np.int16) - fr["swap"][b0:b1].astype(np.int16)) <= 1).all(axis=2).mean()) if bf["swap"] is not None else float("nan")
-            # where do the differing pixels sit? (rows from the nearer band edge)
-            rows_off = np.nonzero((d.reshape(b1 - b0, W, 3) > 1).any(axis=2).any(axis=1))[0]
+            sw = float((np.abs(bf["swap"].astype(np.int16) - fr["swap"][b0:b1, c0:c1].astype(np.int16)) <= 1).all(axis=2).mean()) if bf["swap"] is not None else float("nan")
+            # where do the differing pixels sit? (rows / columns from the nearer edge of the partition)
+            off = (d.reshape(b1 - b0, c1 - c0, 3) > 1).any(axis=2)
+            rows_off, cols_off = np.nonzero(off.any(axis=1))[0], np.nonzero(off.any(axis=0))[0]
             edge_dist = int(np.minimum(rows_off, (b1 - b0 - 1) - rows_off).max()) if rows_off.size else -1
-            lines.append("CONFIG5 frame %d band %d rows %d..%d: within one code of the unpartitioned frame %.6f (max code diff %d, furthest differing row %d rows from a band edge), "
-                         "swapchain within 1 LSB %.6f, histogram: %d pixels in another bin" % (f, i, b0, b1, within1, int(d.max()), edge_dist, sw, moved))
+            edge_dist_x = int(np.minimum(cols_off, (c1 - c0 - 1) - cols_off).max()) if cols_off.size else -1
+            lines.append("CONFIG5 %s frame %d partition %d [%d..%d) x [%d..%d): within one code of the unpartitioned frame %.6f (max code diff %d, furthest differing row %d / column %d from "
+                         "an edge), swapchain within 1 LSB %.6f, histogram: %d pixels in another bin" % (kind, f, i, c0, c1, b0, b1, within1, int(d.max()), edge_dist, edge_dist_x, sw, moved))
             worst_within1, worst_swap = min(worst_within1, within1), min(worst_swap, sw) if sw == sw else worst_swap
     print("\n".join(lines), flush=True)
     if os.environ.get("PLR_CONFIG5_REPORT_ONLY"):
         return
     assert worst_moved <= 5e-4 * W * H, "histogram vs the unpartitioned frame: %d pixels in another bin" % worst_moved
     assert worst_exposure <= 1e-3, "exposure vs the unpartitioned frame: relative difference %.2e" % worst_exposure
-    # The one stated deviation of band rendering: a disc sample of the GI denoiser beyond the exchanged trace rows gets weight 0. The disc is 1.5 m in
-    # WORLD space: at 8K it spans 10275 / depth[m] pixels, i.e. more than any bounded halo on the ground in front of the camera (bands 2 and 3 of
-    # this scene: differing pixels sit up to 480 rows from a band edge). Measured after three frames, worst band, by trace rows of GI halo:
-    # 64: 98.64 %, 128 (the default at 4320 rows, plrf_default_settings): 99.34 %, 192: 99.38 %, 256: 99.40 % within one code; a mirrored stand-in
-    # for the missing samples instead of dropping them: 97.2 % (profiles/r03_config5_8k.txt). The sky band equals the unpartitioned frame exactly.
-    assert worst_within1 >= 0.99, "every band within one R11G11B10 code of the unpartitioned frame on >= 99 % of its pixels"
+    # The one stated deviation of a partitioned frame: a disc sample of the GI denoiser beyond the exchanged halo gets weight 0. The disc is 1.5 m in
+    # WORLD space: at 8K it spans 10275 / depth[m] pixels, i.e. more than any bounded halo on the ground in front of the camera. The share of a partition's
+    # pixels within one code of the unpartitioned frame falls over the first frames while the temporal filters integrate the dropped samples and settles:
+    # profiles/r05_config5_series.txt holds the series for both partitions; the bound below is the converged value of the worse partition, minus a margin.
+    assert worst_within1 >= CONVERGED_WITHIN1[kind], "every partition within one R11G11B10 code of the unpartitioned frame on >= %.4f of its pixels (got %.5f)" % (CONVERGED_WITHIN1[kind], worst_within1)
     assert worst_swap >= 0.999
-    # the overlapped exchange sequence of a band: histogram, GI trace (begin / end), temporal GI (begin / end), GI history, resolved colour (begin / end)
+    # the overlapped exchange sequence of a partition: histogram, GI trace (begin / end), temporal GI (begin / end), GI history, resolved colour (begin / end)
     B, E = 0x100, 0x200
     assert out[1]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E]
-    # band mode keeps the fusions that matter: upscale + shade as one launch, packed GI texels from the producers, the two edge dispatches of a producer as one launch
+    # partition mode keeps the fusions that matter: per-tile pyramid + culling, upscale + shade as one launch, packed GI texels from the producers
     assert out[1]["fused"] >= 10, out[1]["fused"]
 
-    # ---- a strip across the boundary of bands 1 and 2 against the ORACLE frame (2 frames: every history populated)
+    # ---- a strip across a boundary against the ORACLE frame (2 frames: every history populated): for the bands the rows around the boundary of bands 1 and 2,
+    # for the tiles the same rows of the two LEFT tiles' boundary (its columns)
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     if tests_dir not in sys.path:
         sys.path.insert(0, tests_dir)
     from oracle_frame import OracleFrame
-    ora = OracleFrame(inputs, W, H, 512, full["settings"])
-    for f in range(2):
-        fr = full["frames"][f]
-        ora.frame(fr["globals"], fr["weights"], fr["frustum"], 5.0)
-    edge = bounds[2]
+    if "oracle" not in _FULL:
+        ora = OracleFrame(inputs, W, H, 512, full["settings"])
+        for f in range(2):
+            fr = full["frames"][f]
+            ora.frame(fr["globals"], fr["weights"], fr["frustum"], 5.0)
+        _FULL["oracle"] = ora.post1.reshape(H, W).copy()
+    ora_post = _FULL["oracle"]
+    if kind == "bands4":
+        upper, lower = 1, 2
+    else:
+        upper, lower = 0, 2  # the left column of tiles
+    edge = rects[upper][3]
+    assert rects[lower][1] == edge
+    cx0, cx1 = rects[upper][0], min(rects[upper][2], rects[lower][2])
     strip = slice(edge - 64, edge + 64)
-    ref = ora.post1.reshape(H, W)[strip].reshape(-1).astype(np.uint32)
-    for name, got in (("unpartitioned", full["frames"][1]["post"][strip]),
-                      ("bands 1 + 2", np.concatenate([out[1]["frames"][1]["post"][-64:], out[2]["frames"][1]["post"][:64]]))):
+    ref = np.ascontiguousarray(ora_post[strip, cx0:cx1]).reshape(-1).astype(np.uint32)
+    a_up, a_lo = out[upper]["frames"][1]["post"], out[lower]["frames"][1]["post"]
+    stitched = np.concatenate([a_up[-64:, :cx1 - cx0], a_lo[:64, :cx1 - cx0]])
+    for name, got in (("unpartitioned", full["frames"][1]["post"][strip, cx0:cx1]), ("partitions %d + %d" % (upper, lower), stitched)):
         d = parity.r11g11b10_code_diff(np.ascontiguousarray(got).reshape(-1), ref)
         within1, within4 = float((d <= 1).all(axis=1).mean()), float((d <= 4).all(axis=1).mean())
         a, b = pixfmt.unpack_r11g11b10(np.ascontiguousarray(got).reshape(-1)), pixfmt.unpack_r11g11b10(ref)
         rel = float(np.abs(a - b).mean() / max(float(b.mean()), 1e-9))
-        print("CONFIG5 %s rows %d..%d vs the oracle frame: within one code %.5f, within four %.5f, mean rel err %.2e" % (name, edge - 64, edge + 64, within1, within4, rel), flush=True)
+        print("CONFIG5 %s %s rows %d..%d vs the oracle frame: within one code %.5f, within four %.5f, mean rel err %.2e" % (kind, name, edge - 64, edge + 64, within1, within4, rel), flush=True)
         assert within1 >= 0.98 and within4 >= 0.99 and rel <= 2e-3

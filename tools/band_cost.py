@@ -1,7 +1,9 @@
-"""Redundant compute of band rendering, measured on ONE GPU without the exchange: the N bands of the 7680 x (1080 N) frame are rendered one after
-the other (each with the halo rows it recomputes, producers split into edge / interior dispatches as the overlapped exchange records them) and
-their times are summed and compared with the time of the unpartitioned frame.
-    python tools/band_cost.py [N] [--passes] [--balance]   (default N = 4: the 8K frame; --balance: band heights from measured band times, as bench.py does)"""
+"""Redundant compute of a partitioned frame, measured on ONE GPU: the N partitions of the 7680 x (1080 N) frame - row bands, or a grid of screen tiles (BASELINE
+config 5: 2 x 2) - are rendered one after the other, each with the halo it recomputes and the native exchange in LOOPBACK (csrc/frontend/band_exchange.cpp: no
+communicator; a tile's pack / unpack kernels run and a device copy stands in for the links, a band sends straight from its images and has nothing local to
+run), producers recorded edges-first as the overlapped exchange records them. Their times are summed and compared with the time of the unpartitioned frame.
+    python tools/band_cost.py [N] [--tiles GXxGY] [--passes] [--balance]
+default N = 4: the 8K frame; --tiles 2x2: config 5's partition (GX * GY = N); --balance: rectangle sizes from measured times, as bench.py does"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,17 +13,29 @@ from plainrenderer_amd import RenderBackend, tiling
 from plainrenderer_amd.frame import FramePipeline
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4
+gx, gy = 1, n
+if "--tiles" in sys.argv:
+    gx, gy = (int(v) for v in sys.argv[sys.argv.index("--tiles") + 1].lower().split("x"))
+    n = gx * gy
 class A: pass
 args = A(); args.grid = 16; args.sdf_res = 64; args.shadow_res = 2048; args.steps = 40; args.warmup = 5; args.profile_frames = 0
 w, h = 7680, 1080 * n
+kind = "tiles %dx%d" % (gx, gy) if gx > 1 else "%d bands" % n
 
 
-def measure(band):
+def measure(rects, index):
+    """index None: the unpartitioned frame"""
     be = RenderBackend(w, h, device=0)
-    kw = dict(band_row_begin=band[0], band_row_end=band[1]) if band else {}
+    kw, band = {}, None
+    if index is not None:
+        x0, y0, x1, y1 = rects[index]
+        kw = dict(band_row_begin=y0, band_row_end=y1)
+        if x0 != 0 or x1 != w:
+            kw.update(band_col_begin=x0, band_col_end=x1)
+        band = (y0, y1)
     fp = FramePipeline(be, w, h, shadow_map_res=2048, **kw)
-    if band:
-        fp.set_exchange_callback(lambda exchange_id, stream: None)  # callbacks that move nothing: the recording is the multi-GPU one
+    if index is not None:
+        fp.attach_rccl_rects(None, index, len(rects), w, h, rects)  # loopback: the recording is the multi-GPU one, the local work of the exchange runs
     scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, band)
     inputs.upload(fp)
     be.waitForGPUIdle()
@@ -44,27 +58,28 @@ def measure(band):
     return ms, acc
 
 
-full, full_passes = measure(None)
+full, full_passes = measure(None, None)
 print("unpartitioned %dx%d frame: %.3f ms" % (w, h, full))
-bounds = tiling.equal_bounds(h, n)
+cols, rows = tiling.equal_bounds(w, gx), tiling.equal_bounds(h, gy)
+rects = tiling.tile_rects(w, h, gx, gy, cols, rows)
 if "--balance" in sys.argv:
-    # what bench.py --gpus N does before its timed region (static load balancing from measured band times), here with the bands one after the other
+    # what bench.py --gpus N does before its timed region (static load balancing from measured times), here with the partitions one after the other
     for it in range(2):
-        times = [measure((bounds[i], bounds[i + 1]))[0] for i in range(n)]
-        print("partition %s: band times %s ms, slowest / mean = %.3f" % (bounds, ["%.3f" % t for t in times], max(times) / (sum(times) / n)))
-        new = tiling.balanced_bounds(h, bounds, times)
-        if new == bounds:
+        times = [measure(rects, i)[0] for i in range(n)]
+        print("partition %s: times %s ms, slowest / mean = %.3f" % (rects, ["%.3f" % t for t in times], max(times) / (sum(times) / n)))
+        new_cols, new_rows = tiling.balanced_tile_bounds(w, h, gx, gy, cols, rows, times, min_size=512)
+        if (new_cols, new_rows) == (cols, rows):
             break
-        bounds = new
+        cols, rows = new_cols, new_rows
+        rects = tiling.tile_rects(w, h, gx, gy, cols, rows)
 total, band_passes, slowest = 0.0, {}, 0.0
 for i in range(n):
-    band = (bounds[i], bounds[i + 1])
-    ms, acc = measure(band)
+    ms, acc = measure(rects, i)
     total += ms
     slowest = max(slowest, ms)
     for k, v in acc.items():
         band_passes[k] = band_passes.get(k, 0.0) + v
-    print("band %d of %d (rows %d..%d): %.3f ms" % (i, n, band[0], band[1], ms))
+    print("partition %d of %d (%s, columns %d..%d, rows %d..%d): %.3f ms" % (i, n, kind, rects[i][0], rects[i][2], rects[i][1], rects[i][3], ms))
 def group(d):  # fused launches of the unpartitioned frame count towards their passes' group
     g = {}
     for k, v in d.items():
@@ -73,9 +88,9 @@ def group(d):  # fused launches of the unpartitioned frame count towards their p
     return g
 if "--passes" in sys.argv:
     for k in sorted(set(full_passes) | set(band_passes), key=lambda k: -band_passes.get(k, 0.0)):
-        print("    %-60s bands %.4f ms (%.4f per band), unpartitioned %.4f ms" % (k[:60], band_passes.get(k, 0.0), band_passes.get(k, 0.0) / n, full_passes.get(k, 0.0)))
+        print("    %-60s partitions %.4f ms (%.4f each), unpartitioned %.4f ms" % (k[:60], band_passes.get(k, 0.0), band_passes.get(k, 0.0) / n, full_passes.get(k, 0.0)))
 gf, gb = group(full_passes), group(band_passes)
 for k in sorted(gb, key=lambda k: -gb[k]):
-    print("  %-34s bands %.3f ms, unpartitioned %.3f ms (%+.1f %%)" % (k, gb[k], gf.get(k, 0.0), 100.0 * (gb[k] / gf[k] - 1.0) if gf.get(k) else 0.0))
-print("sum of the bands %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute; slowest band %.3f ms -> at most %.2fx on %d GPUs before any exchange wait" % (
-    total, total / full, 100.0 * (total / full - 1.0), slowest, full / slowest, n))
+    print("  %-34s partitions %.3f ms, unpartitioned %.3f ms (%+.1f %%)" % (k, gb[k], gf.get(k, 0.0), 100.0 * (gb[k] / gf[k] - 1.0) if gf.get(k) else 0.0))
+print("%s: sum of the partitions %.3f ms = %.3f x the unpartitioned frame: %.1f %% redundant compute; slowest partition %.3f ms -> at most %.2fx on %d GPUs before any exchange wait" % (
+    kind, total, total / full, 100.0 * (total / full - 1.0), slowest, full / slowest, n))
