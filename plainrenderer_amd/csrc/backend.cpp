@@ -191,7 +191,13 @@ struct ImageRes {
     void* dev = nullptr;
     size_t bytes = 0;
     bool inUse = false; // transient pool bookkeeping
-    bool elided = false; // the last frame's fused launch consumed this image inside its kernel and did not write it (pass fusion level 2)
+    // a fused launch consumed this image inside its kernel and did not write it (pass fusion level 2): the allocation holds an OLDER frame's texels. The flag is
+    // persistent - cleared only when an execution really writes the image - and an execution (or host callback, or host download) that would READ the stale
+    // texels fails loudly (a next frame recorded differently used to read them silently). The one reader that may bind it: the consumer the
+    // eliding producer handed its result to through another channel (elidedReader, valid for the frame elidedSerial), or a member of the same fused launch
+    bool elided = false;
+    const void* elidedReader = nullptr;
+    uint64_t elidedSerial = 0;
 };
 
 struct BufferRes {
@@ -970,6 +976,9 @@ static int applyPendingFillsNow() {
 
 static int flushFills() {
     if (g->fills.empty()) return PLR_OK;
+    // a table left pending by an earlier flush (fills flushed twice without a launch in between: an early error return of a frame) goes first, before any
+    // kernel or copy of the newer fills is enqueued - call order
+    if (int rc = applyPendingFillsNow()) return rc;
     const void* globalDev = g->globalUbo != PLR_INVALID_INDEX ? g->ubufs[g->globalUbo].dev : nullptr;
     bool globalFilled = false;
     for (const auto& f : g->fills) globalFilled = globalFilled || (globalDev && f.dst == globalDev);
@@ -1051,7 +1060,6 @@ static int flushFills() {
         applyFillsKernel<<<1, 256, 0, g->stream>>>(host, slot.serial);
         HIP_TRY(hipGetLastError());
     } else {
-        if (int rc = applyPendingFillsNow()) return rc; // (fills flushed twice without a launch in between)
         slot.eventPending = true; // its event is recorded behind whatever reads the slot last
         if (count && !usedCopyEngine) { *(uint32_t*)host = count; g->pendingFillSlot = host; g->pendingFillEvent = slot.free; } // applied by the frame's first launch
         else {
@@ -1236,10 +1244,42 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
 }
 
 // images a launcher left unwritten (PassCtx::elidedStorage): a host download must not return last frame's bytes silently
-static void noteElidedImages(const PassCtx& cx) {
-    for (int b = 0; b < kMaxBindings && cx.elidedStorage; b++)
-        if ((cx.elidedStorage >> b) & 1u)
-            for (ImageRes& im : g->images) if (im.dev && im.dev == cx.storage[b].ptr) im.elided = true;
+static ImageRes* imageOfAllocation(const void* base) {
+    for (ImageRes& im : g->images) if (im.dev && im.dev == base) return &im;
+    for (ImageRes& im : g->transient) if (im.dev && im.dev == base) return &im;
+    return nullptr;
+}
+// after a launch: the storage images the execution binds are written now (stale flag cleared) - or, where the launcher said so, left unwritten (stale from here on)
+static void noteElidedImages(const Execution& x) {
+    const PassCtx& cx = x.ctx;
+    for (int b = 0; b < kMaxBindings; b++) {
+        if (!cx.hasStorage(b)) continue;
+        bool written = false;
+        for (const Access& a : x.access) if (a.write && a.key == cx.storage[b].ptr) written = true; // (mip 0 of an image the pass writes; a read-only storage binding is no write)
+        if (!written) continue;
+        ImageRes* im = imageOfAllocation(cx.storage[b].ptr);
+        if (!im) continue;
+        if ((cx.elidedStorage >> b) & 1u) { im->elided = true; im->elidedReader = (const void*)cx.consumer; im->elidedSerial = g->frameSerial; }
+        else im->elided = false;
+    }
+}
+// before a launch: does the execution read an image that holds stale texels? `group`: the executions launched together (a fused launch reads what its own members
+// elide in registers). Host callbacks with a resource list are checked for every image they touch (a halo exchange sends what it "writes")
+static int refuseStaleReads(const Execution& x, const Execution* group, size_t groupCount) {
+    for (const Access& a : x.access) {
+        if (a.key == kBindlessKey || (a.write && !x.callback)) continue;
+        const ImageRes* im = imageOfAllocation(a.key);
+        if (!im || !im->elided) continue;
+        if (im->elidedSerial == g->frameSerial && im->elidedReader == (const void*)&x.ctx) continue; // the consumer the producer packed its result for
+        bool insideGroup = false;
+        for (size_t k = 0; k < groupCount && !insideGroup; k++)
+            for (const Access& w : group[k].access) if (w.write && w.key == a.key) { insideGroup = true; break; }
+        if (insideGroup) continue;
+        const std::string who = x.callback ? std::string("host callback '") + x.callbackName + "'" : "pass '" + g->passes[x.pass]->name + "' (" + g->passes[x.pass]->shader + ")";
+        return setErr(PLR_ERR_UNSUPPORTED, who + " reads an image that was not written: an earlier fused launch kept its result in registers / packed texels (pass fusion level 2) "
+                                           "and this frame is recorded differently; plr_set_pass_fusion(1) keeps intermediates");
+    }
+    return PLR_OK;
 }
 
 // Pass fusion level 2 for a producer whose consumer takes its output through another channel (PassCtx::consumer: the spatial GI filter gathers the packed
@@ -1277,6 +1317,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     if (int frc = applyPendingFillsNow()) return frc; // the frame's fills, if its first launch is this one
     prepareCtx(x, stream, globalPtr);
     if (g->fusion >= 2 && g->mathMode == PLR_MATH_FAST && !g->debugSig && x.ctx.consumer) markElidableBehindConsumer(x);
+    if (int src = refuseStaleReads(x, &x, 1)) return src;
     g->currentPassName = p.name.c_str();
     g->curStream = stream;
     if (timed) if (int trc = beginSegment(p.name.c_str())) return trc;
@@ -1296,7 +1337,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     // a kernel that did not order its rows (general kernel, edges that are not whole block rows): the signal is raised behind the whole launch
     if (signalled && !x.ctx.edgeSignalHonoured) HIP_TRY(hipStreamWriteValue32(stream, g->edgeSignal, x.ctx.edgeValue, 0));
     if (timed) if (int trc = endSegment()) return trc;
-    noteElidedImages(x.ctx);
+    noteElidedImages(x);
     return PLR_OK;
 }
 
@@ -1352,6 +1393,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
             if (f.takesFills && stream == g->stream) { first.ctx.pendingFillSlot = g->pendingFillSlot; first.ctx.applyPendingFillsNow = &applyPendingFillsNow; }
             else if (int frc = applyPendingFillsNow()) return frc;
         }
+        for (size_t k = 0; k < n; k++) if (int src = refuseStaleReads(g->executions[i + k], &g->executions[i], n)) return src;
         const int rc = f.fn(ctxs, n);
         if (first.ctx.pendingFillSlot) {
             if (rc == 0 && first.ctx.pendingFillsTaken) { // applied by a block of the launcher's first kernel: the slot is free behind this launch
@@ -1366,7 +1408,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         }
         if (rc) { g_err = "fused launch '" + f.label + "': " + g_err; return rc; }
         if (timed) if (int trc = endSegment()) return trc;
-        for (size_t k = 0; k < n; k++) noteElidedImages(g->executions[i + k].ctx);
+        for (size_t k = 0; k < n; k++) noteElidedImages(g->executions[i + k]);
         *covered = n;
         g->lastFused += (uint32_t)n;
         return PLR_OK;
@@ -1496,7 +1538,6 @@ static int launchAll(bool timed) {
     g->lastFused = 0;
     g->lastGeneral = 0;
     g->lastGeneralNames.clear();
-    for (ImageRes& im : g->images) im.elided = false;
     const GlobalUbo* globalPtr = g->globalUbo != PLR_INVALID_INDEX ? (const GlobalUbo*)g->ubufs[g->globalUbo].dev : nullptr;
     const bool tailAllowed = g->asyncTail && !g->overlap;
     if (globalPtr && tailAllowed && g->globalCopies[g->globalCopyIndex]) globalPtr = (const GlobalUbo*)g->globalCopies[g->globalCopyIndex];
@@ -1522,6 +1563,7 @@ static int launchAll(bool timed) {
             g->curStream = g->stream;
             if (int rc = applyPendingFillsNow()) return rc;
             if (timed) if (int rc = beginSegment(x.callbackName)) return rc;
+            if (x.callbackAccessKnown) { if (int rc = refuseStaleReads(x, nullptr, 0)) return rc; }
             if (x.callbackAccessKnown) touchAccesses(x.access);
             else g->contentVersion.clear(); // may have written anything: every image gets a new version at its next query
             const int crc = x.callback(x.callbackUser, (void*)g->stream);

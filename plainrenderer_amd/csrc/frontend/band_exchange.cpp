@@ -380,7 +380,15 @@ struct RcclExchange {
             if (rects.empty()) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: the pipeline renders a tile but the exchange was attached with rows only (plrf_rccl_attach_rects)");
             return postPacked(id, items, count, stream);
         }
-        if (loopback) { exchanges++; return 0; } // bands send straight from the images: nothing local to stand in for
+        if (loopback) { // bands send straight from the images: nothing local to stand in for; the bytes a real exchange would move are still counted
+            for (uint32_t i = 0; i < count; i++) {
+                plrf_exchange_op ops[4];
+                const uint32_t n = planItem(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, items[i].image_rows, items[i].halo_rows, items[i].row_begin, items[i].row_end, ops);
+                for (uint32_t k = 0; k < n; k++) (ops[k].send ? bytesSent : bytesReceived) += (uint64_t)(ops[k].row_end - ops[k].row_begin) * items[i].row_bytes;
+            }
+            exchanges++;
+            return 0;
+        }
         if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
         int rc = 0;
         for (uint32_t i = 0; i < count && !rc; i++) {

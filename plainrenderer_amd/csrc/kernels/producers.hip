@@ -611,31 +611,36 @@ __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, 
         if (g->cameraCut) history = current;
         const vec4 result = current * (1.f - alpha) + history * alpha;
         Texel<F_RGBA16F>::store(target.ptr, texel, result);
-        if (INTEGRATE) {
-            const FroxelSliceTerm t = froxelSliceTerm(vec4(roundToHalf(result.x), roundToHalf(result.y), roundToHalf(result.z), roundToHalf(result.w)), sliceLength[z]);
-            segR += t.r; segG += t.g; segB += t.b; segT *= t.e;
-        }
     }
     if (INTEGRATE) {
-        segmentTotals[0][threadIdx.x] = segR; segmentTotals[1][threadIdx.x] = segG; segmentTotals[2][threadIdx.x] = segB; segmentTotals[3][threadIdx.x] = segT;
-        __syncthreads();
-        float totalR = 0.f, totalG = 0.f, totalB = 0.f, transmittance = 1.f;
-        for (int before = 0; before < segment && valid; before++) { // the segments in front of this one, front to back
-            const int t = before * columnsPerBlock + columnInBlock;
-            totalR += segmentTotals[0][t]; totalG += segmentTotals[1][t]; totalB += segmentTotals[2][t]; transmittance *= segmentTotals[3][t];
-        }
+        // The running totals of a column are accumulated strictly slice by slice, front to back - the association of the stand-alone integration kernel
+        // (kernels_fast/froxel_fast.hip): results must not depend on whether the passes were fused (backend.h; ADVICE r04: summing per-segment subtotals first
+        // associates differently from the third segment on and moved half-rounded texels). Every thread forms its segment's per-slice terms at once (the
+        // exponentials, in parallel), then the segments take turns in order: segment s starts from the totals segment s - 1 ended with, handed over through LDS.
         uint2 mine[kFroxelSegment];
 #pragma unroll
         for (int k = 0; k < kFroxelSegment; k++) // the thread's own stores, read back (same thread, same addresses: program order)
             mine[k] = k < zn ? ((const uint2*)target.ptr)[idx3(target, x, y, z0 + k)] : make_uint2(0u, 0u);
+        FroxelSliceTerm term[kFroxelSegment];
 #pragma unroll
         for (int k = 0; k < kFroxelSegment; k++) {
-            if (k >= zn) continue;
             const vec4 texel(halfBitsToFloat(mine[k].x & 0xffffu), halfBitsToFloat(mine[k].x >> 16), halfBitsToFloat(mine[k].y & 0xffffu), halfBitsToFloat(mine[k].y >> 16));
-            const FroxelSliceTerm t = froxelSliceTerm(texel, sliceLength[z0 + k]);
-            totalR += t.r; totalG += t.g; totalB += t.b; transmittance *= t.e;
-            ((uint2*)integrationVolume.ptr)[idx3(integrationVolume, x, y, z0 + k)] =
-                make_uint2(floatToHalfBits(totalR) | (floatToHalfBits(totalG) << 16), floatToHalfBits(totalB) | (floatToHalfBits(transmittance) << 16));
+            term[k] = froxelSliceTerm(texel, sliceLength[k < zn ? z0 + k : 0]);
+        }
+        for (int turn = 0; turn < segments; turn++) { // block-uniform trip count
+            if (turn == segment && valid) {
+                float totalR = 0.f, totalG = 0.f, totalB = 0.f, transmittance = 1.f;
+                if (turn > 0) { totalR = segmentTotals[0][columnInBlock]; totalG = segmentTotals[1][columnInBlock]; totalB = segmentTotals[2][columnInBlock]; transmittance = segmentTotals[3][columnInBlock]; }
+#pragma unroll
+                for (int k = 0; k < kFroxelSegment; k++) {
+                    if (k >= zn) continue;
+                    totalR += term[k].r; totalG += term[k].g; totalB += term[k].b; transmittance *= term[k].e;
+                    ((uint2*)integrationVolume.ptr)[idx3(integrationVolume, x, y, z0 + k)] =
+                        make_uint2(floatToHalfBits(totalR) | (floatToHalfBits(totalG) << 16), floatToHalfBits(totalB) | (floatToHalfBits(transmittance) << 16));
+                }
+                segmentTotals[0][columnInBlock] = totalR; segmentTotals[1][columnInBlock] = totalG; segmentTotals[2][columnInBlock] = totalB; segmentTotals[3][columnInBlock] = transmittance;
+            }
+            __syncthreads();
         }
     }
 }

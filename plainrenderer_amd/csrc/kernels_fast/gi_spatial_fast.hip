@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float c0x4 = 4.f * c0;
     // Can a sample of this pixel leave the screen? Its world offset is ox * T + oy * B with |ox| + |oy| <= sqrt(2) and |T| = |B| = radiusWorld,
     // so |offset| <= dm; the clip coordinates move by at most (row norm) * dm, and |x'| <= w', |y'| <= w' is what "on screen" means.
-    bool safe;
+    bool safe, safeInside = true; // safeInside: the disc provably stays inside the valid rows / columns too (band / tile rendering)
     {
         const float dm = radiusWorld * 1.4143f * 1.01f;
         // norms of the x, y and w rows of viewProjection: per-frame constants, from the launcher (three square roots and a dozen multiply-adds per LANE otherwise -
@@ -190,12 +190,12 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         // 0.5 (sy + sw) dm / wMin from the centre's: a disc whose rows provably stay inside the valid rows needs no per-sample row test either
         if (validRowCount < (uint32_t)inYSH.h) {
             const float reach = 0.5f * (sy + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.h + 1.f; // rows
-            safe = safe && (float)py - reach >= (float)validY0 && (float)py + reach < (float)(validY0 + validRowCount);
+            safeInside = (float)py - reach >= (float)validY0 && (float)py + reach < (float)(validY0 + validRowCount);
         }
         // tile rendering: the same for the valid columns (PassCtx::validCols), with the x row's norm
         if (validColCount < (uint32_t)inYSH.w) {
             const float reach = 0.5f * (sx + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.w + 1.f; // columns
-            safe = safe && (float)px - reach >= (float)validX0 && (float)px + reach < (float)(validX0 + validColCount);
+            safeInside = safeInside && (float)px - reach >= (float)validX0 && (float)px + reach < (float)(validX0 + validColCount);
         }
     }
     float resCo = 0.f, resCg = 0.f;
@@ -230,9 +230,13 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // not have fired, so a pixel's result is the same whichever copy its wave ran.
     float rY0 = 0.f, rY1 = 0.f, rY2 = 0.f, rY3 = 0.f;
     const BufferDesc packedTexels = texelBuffer(packed, 16u);
-    auto sampleLoop = [&](auto safeTag) {
+    // INSIDE (a SAFE copy only): the disc may reach rows / columns no neighbouring GPU has sent. Such a sample gets weight 0 and nothing else changes (the disc
+    // does not shrink for it: rowMissShrinks == 0), so the on-screen copy serves with one range test per sample - in the ground partitions of the 8K frame most
+    // waves' discs reach past the 128-row halo, and sending them all through the off-screen copy cost a band 25 us per pass (profiles/r05a_band_cost.txt)
+    auto sampleLoop = [&](auto safeTag, auto insideTag) {
 #pragma clang fp contract(fast)
         constexpr bool SAFE = decltype(safeTag)::value;
+        constexpr bool INSIDE = decltype(insideTag)::value;
         for (int i0 = 0; i0 < 32; i0 += 4) {
             float su[4], sv[4];
             uint32_t ti[4], di[4];
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 if (SAFE) {
                     // `safe` leaves a margin of 1e-3 of the screen: cu * halfW + halfW lies strictly inside (0, width) - no clamp, and trunc == floor
                     tx = (uint32_t)(int)(cu * halfW + halfW); ty = (uint32_t)(int)(cv * halfH + halfH);
+                    if (!INSIDE) off[k] = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount;
                 } else {
                     // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
                     cu = fabsf(cu) > 1.f ? su0 - 2.f * ox : cu;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     float weight = __builtin_amdgcn_fmed3f(qden * rcpf(__builtin_fmaxf(num, 0.0004f * qden)), 0.f, 1.f);
                     weight *= weight;
                     // a texel to skip has qden < 0: max(num, negative) = num >= 0, the quotient is <= 0 and the clamp has already made the weight 0
-                    if (!SAFE) weight = off[k] ? 0.f : weight;
+                    if (!SAFE || !INSIDE) weight = off[k] ? 0.f : weight;
                     rY0 += weight * halfBitsToFloat(t4[k].x & 0xffffu); rY1 += weight * halfBitsToFloat(t4[k].x >> 16);
                     rY2 += weight * halfBitsToFloat(t4[k].y & 0xffffu); rY3 += weight * halfBitsToFloat(t4[k].y >> 16);
                     resCo += weight * halfBitsToFloat(t4[k].z & 0xffffu);
@@ -321,8 +326,10 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             }
         }
     };
-    if (__builtin_amdgcn_ballot_w64(!safe) == 0ull) sampleLoop(std::true_type{});
-    else sampleLoop(std::false_type{});
+    if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
+    else if (__builtin_amdgcn_ballot_w64(!safeInside) == 0ull) sampleLoop(std::true_type{}, std::true_type{});
+    else if (rowMissShrinks == 0) sampleLoop(std::true_type{}, std::false_type{});
+    else sampleLoop(std::false_type{}, std::true_type{});
     const float inv = rcpf(gmax(weightTotal, 0.00001f));
     const size_t idx = (size_t)py * (size_t)outYSH.w + px;
     Texel<F_RGBA16F>::store(outYSH.ptr, idx, vec4(rY0 * inv, rY1 * inv, rY2 * inv, rY3 * inv));

@@ -128,3 +128,20 @@ def test_every_hot_path_shader_has_a_registered_kernel():
             "skyTransmissionLut.comp", "skyMultiscatterLut.comp", "skyLut.comp", "froxelVolumeMaterial.comp", "froxelLightScattering.comp",
             "volumeLightingReprojection.comp", "volumetricLightingIntegration.comp"}
     assert need <= have, sorted(need - have)
+
+
+def test_reference_frontend_setup_compiles_against_the_shim():
+    """VERDICT r04 item 6: RenderFrontend::setup calls setGlobalDescriptorSetLayout (RenderBackend.h:73, RenderFrontend.cpp:280-295) before it creates any pass.
+    tests/cpp/frontend_setup_excerpt.cpp restates that set-up sequence with the reference's type and member names; it must compile against
+    include/plr_render_backend.hpp with a plain host compiler, and link against libplr.so (every plr_* function the shim forwards to is exported)"""
+    import subprocess
+    import tempfile
+    from plainrenderer_amd import backend
+    src = os.path.join(ROOT, "tests", "cpp", "frontend_setup_excerpt.cpp")
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "excerpt")
+        lib_dir = os.path.dirname(backend.LIB_PATH)
+        p = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", src, "-o", exe, "-L" + lib_dir, "-lplr", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+    hdr = open(os.path.join(ROOT, "include", "plr_render_backend.hpp")).read()
+    assert "void setGlobalDescriptorSetLayout(const ShaderLayout& layout)" in hdr and "struct ShaderLayout" in hdr

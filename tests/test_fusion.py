@@ -86,9 +86,12 @@ def test_gpu_fusion_across_the_callers_pass_order_changes_no_byte(backend, w, h)
         for mode, (fusion, reorder) in {"reordered": (2, True), "recorded order": (2, False), "unfused": (0, False)}.items():
             backend.setPassFusion(fusion)
             backend.setPassFusionReorder(reorder)
-            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64, run_sky_luts=1, run_light_matrix=1, run_volumetrics=1)
+            # froxel depth 64 (the default: eight column segments in the fused per-froxel + integration launch) at the larger size, 16 (two segments) at the smaller:
+            # the integrated volume must not depend on whether the four froxel passes were fused, whatever the number of segments
+            froxel_depth = 64 if w >= 1280 else 16
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=froxel_depth, max_sdf_instances=64, run_sky_luts=1, run_light_matrix=1, run_volumetrics=1)
             if inputs is None:
-                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=froxel_depth, sun_direction=(0.35, -0.8, 0.45))
             inputs.upload(fp)
             out = []
             for f in range(n_frames):
@@ -207,3 +210,39 @@ def test_gpu_trace_through_bricked_volumes_changes_no_bit(backend, monkeypatch):
     for f in range(n_frames):
         for a, b, what in zip(results["0"][f], results["2"][f], names):
             assert np.array_equal(a, b), "%s differs with bricked volumes, frame %d" % (what, f)
+
+
+@pytest.mark.gpu
+def test_gpu_a_frame_recorded_differently_cannot_read_an_image_the_last_frame_left_unwritten(backend):
+    """at fusion level 2 the fused upscale + shade and the temporal GI filter leave images unwritten on the assumption that the next frame, recorded
+    alike, overwrites them before anything reads them. The stale flag is persistent: a NEXT frame that is recorded differently and samples such an image fails
+    loudly instead of reading an older frame's texels, the flag survives frames that do not touch the image, and a frame that writes it clears it"""
+    from plainrenderer_amd.backend import ComputePassExecution, ImageResource, RenderPassResources
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h = 648, 360
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(4)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=512)
+    backend.setMathMode(True)
+    backend.setPassFusion(2)
+    fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+    try:
+        SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45)).upload(fp)
+        fp.frame(cams[1], 1.0 / 60.0, 0.5)
+        probe = backend.createComputePass("tonemapping.comp", name="stale reader")
+        for stale in ("giFullResYSH", "giHistoryYSH1"):
+            for _ in range(2):  # the second time: the flag was not cleared by the failed frame, nor by a frame that does not touch the image
+                backend.newFrame()
+                exe = ComputePassExecution(handle=probe, resources=RenderPassResources(sampledImages=[ImageResource(fp.image(stale), 0, 1)],
+                                                                                          storageImages=[ImageResource(fp.image("swapchain"), 0, 0)]), dispatchCount=(1, 1, 1))
+                backend.setComputePassExecution(exe)
+                with pytest.raises(RuntimeError, match="reads an image that was not written"):
+                    backend.renderFrame()
+        # the same frame as before: writes (or elides again) before it reads - no complaint; at fusion level 1 the images are written and readable
+        fp.frame(cams[2], 1.0 / 60.0, 0.5)
+        backend.setPassFusion(1)
+        fp.frame(cams[3], 1.0 / 60.0, 0.5)
+        assert backend.downloadImage(fp.image("giFullResYSH"), 0, np.uint8).any()
+    finally:
+        fp.destroy()
+        backend.setPassFusion(2)
+        backend.setMathMode(False)

@@ -126,19 +126,39 @@ def test_gpu_a_thread_without_its_own_backend_uses_the_process_global_one(backen
 
 
 @pytest.mark.gpu
-def test_gpu_a_first_workgroup_column_is_refused_not_ignored(backend):
-    """plr_compute_pass_execution::dispatch_base has vkCmdDispatchBase semantics; the kernels of the path cover whole rows, so a non-zero [0] (which they would
-    otherwise ignore silently) is PLR_ERR_UNSUPPORTED for every pass but histogramCombineTiles, whose x axis is the tile index"""
+def test_gpu_a_first_workgroup_column_is_honoured_or_refused_never_ignored(backend):
+    """plr_compute_pass_execution::dispatch_base has vkCmdDispatchBase semantics. The passes of the per-pixel frame path honour a first workgroup COLUMN (tile
+    rendering, round 5): the dispatch covers exactly the workgroups (base, count) names, in both kernel sets. Every other pass covers whole rows, so a non-zero
+    [0] (which its kernel would ignore silently) is PLR_ERR_UNSUPPORTED"""
     from plainrenderer_amd.backend import ComputePassExecution, ImageResource, RenderPassResources, PlrError
     from util import F, image_desc_2d
-    src = backend.createImage(image_desc_2d(64, 32, F.R11G11B10_uFloat), np.zeros(64 * 32, np.uint32))
+    rng = np.random.default_rng(11)
+    src_data = rng.integers(0, 2 ** 32, 64 * 32, dtype=np.uint32) & np.uint32(0x3bef7bdf)  # finite, modest R11G11B10 values
+    src = backend.createImage(image_desc_2d(64, 32, F.R11G11B10_uFloat), src_data)
     dst = backend.createImage(image_desc_2d(64, 32, F.RGBA8))
+    whole = backend.createImage(image_desc_2d(64, 32, F.RGBA8))
     p = backend.createComputePass("tonemapping.comp", [], "Tonemap")
+    for fast in (False, True):
+        backend.setMathMode(fast)
+        backend.uploadImage(dst, np.full(64 * 32, 0xEEEEEEEE, np.uint32))
+        backend.newFrame()
+        exe = ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(dst, 0, 0)], sampledImages=[ImageResource(src, 0, 1)]), b"", (3, 2, 1))
+        exe.dispatchBase = (4, 1, 0)  # workgroup columns 4..6 = pixel columns 32..55, workgroup rows 1..2 = pixel rows 8..23
+        backend.setComputePassExecution(exe)
+        ref = ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(whole, 0, 0)], sampledImages=[ImageResource(src, 0, 1)]), b"", (8, 4, 1))
+        backend.setComputePassExecution(ref)
+        backend.renderFrame()
+        got = backend.downloadImage(dst, 0, np.uint32).reshape(32, 64)
+        full = backend.downloadImage(whole, 0, np.uint32).reshape(32, 64)
+        expect = np.full((32, 64), 0xEEEEEEEE, np.uint32)
+        expect[8:24, 32:56] = full[8:24, 32:56]
+        assert np.array_equal(got, expect), "tonemapping, %s kernel set: the dispatch's rectangle and nothing else" % ("fast" if fast else "exact")
+    backend.setMathMode(False)
+    lut = backend.createImage(image_desc_2d(64, 64, F.RGBA16_sFloat))
+    q = backend.createComputePass("brdfLut.comp", [], "BRDF Lut creation")
     backend.newFrame()
-    exe = ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(dst, 0, 0)], sampledImages=[ImageResource(src, 0, 1)]), b"", (4, 4, 1))
+    exe = ComputePassExecution(q, RenderPassResources(storageImages=[ImageResource(lut, 0, 0)]), b"", (4, 4, 1))
     exe.dispatchBase = (4, 0, 0)
     with pytest.raises(PlrError, match="dispatch_base"):
         backend.setComputePassExecution(exe)
-    exe.dispatchBase = (0, 2, 0)  # a first workgroup ROW is the band renderer's bread and butter
-    backend.setComputePassExecution(exe)
     backend.newFrame()  # drop the recording (nothing is rendered: the test is about what the recorder accepts)

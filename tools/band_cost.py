@@ -33,10 +33,13 @@ def measure(rects, index):
         if x0 != 0 or x1 != w:
             kw.update(band_col_begin=x0, band_col_end=x1)
         band = (y0, y1)
+    if index is not None and "PLR_BAND_COST_GI_HALO" in os.environ:  # experiment hook: trace texels of GI exchanged with each neighbour (tools/config5_series.sh: the exact mode)
+        kw.update(band_gi_halo=int(os.environ["PLR_BAND_COST_GI_HALO"]))
     fp = FramePipeline(be, w, h, shadow_map_res=2048, **kw)
     if index is not None:
         fp.attach_rccl_rects(None, index, len(rects), w, h, rects)  # loopback: the recording is the multi-GPU one, the local work of the exchange runs
-    scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, band)
+    # (a halo beyond the default needs the inputs of rows beyond bench.input_halo: the whole frame's then)
+    scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, None if "PLR_BAND_COST_GI_HALO" in os.environ else band)
     inputs.upload(fp)
     be.waitForGPUIdle()
     for i in range(args.warmup):
@@ -47,6 +50,9 @@ def measure(rects, index):
         fp.frame(cams[i + 6], 1 / 60, 0.5)
     be.waitForGPUIdle()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    if index is not None:
+        sent, received, groups = fp.rccl_stats()
+        print("    partition %d: %.1f MB sent, %.1f MB received per frame in %d point-to-point groups" % (index, sent / 1e6, received / 1e6, groups))
     be.setPassTiming(True)
     acc = {}
     for i in range(8):
