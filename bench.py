@@ -94,7 +94,7 @@ def kernel_source_digest():
     h = hashlib.sha1()
     base = os.path.join(ROOT, "plainrenderer_amd", "csrc")
     for d, _, files in sorted(os.walk(base)):
-        if os.path.basename(d) == "_obj":
+        if os.path.basename(d).startswith("_obj"):
             continue
         for f in sorted(files):
             if f.endswith((".hip", ".h", ".cpp")):

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplr.so")
+LIB_PATH = os.environ.get("PLR_LIB") or os.path.join(_HERE, "libplr.so")  # PLR_LIB: an experiment's build (plainrenderer_amd/build.py PLR_BUILD_TAG)
 
 
 class PlrError(RuntimeError):

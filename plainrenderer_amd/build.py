@@ -11,8 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ_DIR = os.path.join(CSRC, "_obj")
-LIB_PATH = os.path.join(HERE, "libplr.so")
+# PLR_BUILD_TAG=<tag> (experiments: an A/B pair of libraries in one tree): objects under csrc/_obj_<tag>, the library as libplr_<tag>.so; pick it at run time with
+# PLR_LIB=<path> (plainrenderer_amd/backend.py). The default build has no tag.
+_TAG = os.environ.get("PLR_BUILD_TAG", "")
+OBJ_DIR = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
+LIB_PATH = os.path.join(HERE, "libplr" + ("_" + _TAG if _TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, e.g. -DPLR_SHADE_WAVES=5
 
@@ -54,7 +57,7 @@ def _headers_digest():
     h = hashlib.sha1()
     for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
         for dp, _, files in os.walk(root):
-            if "_obj" in dp:
+            if "_obj" in os.path.basename(dp):
                 continue
             for f in sorted(files):
                 if f.endswith((".h", ".hpp")):

@@ -237,7 +237,10 @@ struct Column { float r, g, b, l, d; }; // (tonemapped) colour, its luminance, r
 PLR_DI Column shiftFromLeft(const Column& c) { return {fromLeft(c.r), fromLeft(c.g), fromLeft(c.b), fromLeft(c.l), 0.f}; }
 PLR_DI Column shiftFromRight(const Column& c) { return {fromRight(c.r), fromRight(c.g), fromRight(c.b), fromRight(c.l), 0.f}; }
 
-constexpr int kStripW = 62, kStripRows = 4;
+#ifndef PLR_TAA_STRIP_ROWS
+#define PLR_TAA_STRIP_ROWS 4 // experiment hook (PLR_EXTRA_FLAGS=-DPLR_TAA_STRIP_ROWS=2): rows per wave; fewer rows = fewer registers, more loads per output row
+#endif
+constexpr int kStripW = 62, kStripRows = PLR_TAA_STRIP_ROWS;
 // History texels a wave stages in LDS (round 3; north star: framebuffer tiles through LDS): {luminance, packed texel} of the bounding box of its
 // 62 x 4 pixels' 4x4 reprojection footprints. With a static or slowly moving camera that box is ~66 x 7 texels: a lane decodes ~8 texels per strip
 // instead of 16 per pixel = 64 (the sixteen R11G11B10 decodes + luminances per pixel were 40 % of this kernel's instructions). A wave whose
@@ -262,7 +265,10 @@ PLR_DI int waveMinI(int v) {
 // BANDED: the launch may cover two row ranges or run its edge rows first (band rendering, backend.h TwoRanges); a whole-frame launch carries none of that code
 // (it cost the 128-register kernel four more spilled dwords)
 template <bool CLIP, bool DILATE, int TECH, bool TONEMAP, bool BANDED>
-__global__ __launch_bounds__(256, 4) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
+#ifndef PLR_TAA_WAVES
+#define PLR_TAA_WAVES 4
+#endif
+__global__ __launch_bounds__(256, PLR_TAA_WAVES) void temporalFilterStripKernel(ImgView current, ImgView output, ImgView historyDst, ImgView historySrc, ImgView motionBuffer,
                                                                  ImgView depthBuffer, const ResolveWeights* __restrict__ rwp, const GlobalUbo* __restrict__ g,
                                                                  int coverW, int coverH, int yBase, int xBase, TwoRanges ranges) {
     static_assert(TECH == 0 || TECH == 4, "strip kernel: Bilinear and Bicubic1Tap history sampling");

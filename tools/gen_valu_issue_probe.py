@@ -136,7 +136,26 @@ variant("mix_cmp_cndmask_fma_fma", "v_cmp, v_cndmask (vcc), v_fma, v_fma: the se
 variant("mix_half_four_kinds", "max, cvt, lshl, perm round robin: half-rate classes only", pattern([MAXF, CVT, LSHL, PERM]))
 variant("mix_realistic", "fma fma max fma cvt fma fma cndmask64: a big kernel's class mix (5 full : 3 half)", pattern([FMA, FMA, MAXF, FMA, CVT, FMA, FMA, CND64]))
 
-CLOBBERS = ", ".join('"v%d"' % r for r in range(ACC0, 128)) + ', "vcc", "s6", "s7", "s10", "s11"'
+# ---- transcendentals among other work: v_rcp_f32 alone streams at 8.1 cycles, one per three v_fma_f32 cost the group 21 cycles. Grouping? Spacing?
+variant("mix_fma12_rcp4_grouped", "twelve v_fma_f32 then four v_rcp_f32 back to back (the 3 : 1 ratio, grouped)", lambda i: (RCP if i % 16 >= 12 else FMA)(i))
+variant("mix_fma24_rcp8_grouped", "twenty-four v_fma_f32 then eight v_rcp_f32", lambda i: (RCP if i % 32 >= 24 else FMA)(i))
+variant("mix_fma7_rcp1", "seven v_fma_f32 per v_rcp_f32", pattern([FMA] * 7 + [RCP]))
+variant("mix_fma15_rcp1", "fifteen v_fma_f32 per v_rcp_f32", pattern([FMA] * 15 + [RCP]))
+variant("mix_mul3_rcp1", "three v_mul_f32 (VOP2) per v_rcp_f32", pattern([lambda i: "v_mul_f32 v%d, v%d, v%d" % (acc(i), acc(i), S)] * 3 + [RCP]))
+variant("mix_fma3_rsq1", "three v_fma_f32 per v_rsq_f32", pattern([FMA, FMA, FMA, lambda i: "v_rsq_f32 v%d, v%d" % (acc(i), acc(i))]))
+variant("mix_fma3_exp1", "three v_fma_f32 per v_exp_f32", pattern([FMA, FMA, FMA, lambda i: "v_exp_f32 v%d, v%d" % (acc(i), acc(i))]))
+variant("mix_max15_rcp1", "fifteen v_max_f32 per v_rcp_f32", pattern([MAXF] * 15 + [RCP]))
+
+# ---- other instruction kinds between VALU work: do they take the wave's VALU issue time?
+MULV = lambda i: "v_mul_f32 v%d, v%d, v%d" % (acc(i), acc(i), S)
+variant("mix_mul_salu", "v_mul_f32 / s_add_u32 s12, s12, s13 alternating", pattern([MULV, lambda i: "s_add_u32 s12, s12, s13"]))
+variant("mix_mul_salu3", "v_mul_f32 / three SALU (s_add_u32, s_and_b32, s_lshl_b32)", pattern([MULV, lambda i: "s_add_u32 s12, s12, s13", lambda i: "s_and_b32 s14, s12, s13", lambda i: "s_lshl_b32 s15, s13, 2"]))
+variant("mix_mul_waitcnt", "v_mul_f32 / s_waitcnt vmcnt(0) lgkmcnt(0) alternating (nothing outstanding)", pattern([MULV, lambda i: "s_waitcnt vmcnt(0) lgkmcnt(0)"]))
+variant("mix_mul_snop", "v_mul_f32 / s_nop 0 alternating", pattern([MULV, lambda i: "s_nop 0"]))
+variant("mix_mul_readfirstlane", "v_mul_f32 / v_readfirstlane_b32 s12, acc alternating", pattern([MULV, lambda i: "v_readfirstlane_b32 s12, v%d" % acc(i)]))
+variant("mix_mul_saveexec", "v_mul_f32 x 3 / s_and_saveexec_b64 + s_mov exec restore (a branch's mask dance)", pattern([MULV, lambda i: "s_or_saveexec_b64 s[16:17], vcc", MULV, lambda i: "s_mov_b64 exec, s[16:17]"]))
+
+CLOBBERS = ", ".join('"v%d"' % r for r in range(ACC0, 128)) + ', "vcc", "s6", "s7", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "memory"'
 
 HEADER = r'''// GENERATED by tools/gen_valu_issue_probe.py - do not edit. VALU issue rates on gfx950 in SHADER cycles (s_memtime), with explicit registers (VGPR banks),
 // 64-instruction loop bodies, one-workgroup and whole-chip runs. See the generator's docstring.
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_%(name)s(Stamp* stamps, float seed, in
     unsigned long long t0, t1;
     unsigned hwid;
     asm volatile(INIT_REGS :: "v"(x) : %(clob)s);
-    asm volatile("s_mov_b32 s6, 0x3f800100\ns_mov_b32 s10, 0x55555555\ns_mov_b32 s11, 0x0f0f0f0f\ns_mov_b64 vcc, s[10:11]\ns_getreg_b32 %%0, hwreg(HW_REG_HW_ID)" : "=s"(hwid) :: "s6", "s10", "s11", "vcc");
+    asm volatile("s_mov_b32 s6, 0x3f800100\ns_mov_b32 s10, 0x55555555\ns_mov_b32 s11, 0x0f0f0f0f\ns_mov_b64 vcc, s[10:11]\ns_mov_b32 s12, 0\ns_mov_b32 s13, 4\ns_getreg_b32 %%0, hwreg(HW_REG_HW_ID)" : "=s"(hwid) :: "s6", "s10", "s11", "vcc");
     __syncthreads();
     asm volatile("s_memtime %%0\ns_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int i = 0; i < iters; i++) asm volatile("%(body)s" ::: %(clob)s);
