@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal partition instead of balancing the rectangles' sizes from measured times")
     ap.add_argument("--partition", choices=["auto", "tiles", "bands"], default="auto", help="N > 1: screen tiles (2 x N/2 grid; N = 4: BASELINE config 5's 2 x 2) or row bands; "
                     "auto = tiles for even N, bands otherwise")
+    ap.add_argument("--exact-partition", action="store_true", help="N > 1: exchange every GI texel with every rank (band_gi_halo = PLRF_HALO_WHOLE_IMAGE): the partitioned frame equals the "
+                    "unpartitioned one bit for bit (tests/test_config5_8k.py); default: a halo of 64 trace rows per 2160 frame rows, whose deviation is stated in profiles/r05_config5_series.txt")
     ap.add_argument("--no-strong-scaling", action="store_true", help="N > 1: skip the single-GPU run of the same frame (rank 0) the strong-scaling figure is taken against")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
@@ -300,6 +302,8 @@ def main():
         kw = dict(band_row_begin=rect[1], band_row_end=rect[3])
         if rect[0] != 0 or rect[2] != w_:
             kw.update(band_col_begin=rect[0], band_col_end=rect[2])
+        if args.exact_partition:
+            kw.update(band_gi_halo=0xffffffff)  # PLRF_HALO_WHOLE_IMAGE
         return kw
 
     def calibrate_partition():
@@ -314,7 +318,7 @@ def main():
             be_ = RenderBackend(w_, h_, device=local_rank)
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **rect_settings(rects_[rank], w_))
             fp_.set_exchange_callback(lambda exchange_id, stream: None)
-            _, cams_, inputs_ = build_scene(args, device, w_, h_, (b0, b1))
+            _, cams_, inputs_ = build_scene(args, device, w_, h_, None if args.exact_partition else (b0, b1))
             inputs_.upload(fp_)
             for i in range(4):
                 fp_.frame(cams_[i + 1], 1.0 / 60.0, 0.5)
@@ -352,7 +356,9 @@ def main():
             rects_ = tiling.tile_rects(w_, h_, grid_x, grid_y, cols_, rows_)
             band_ = (rects_[rank][1], rects_[rank][3])
             band_partition["bounds"] = rows_
-            band_partition.update(kind="tiles %dx%d" % (grid_x, grid_y) if grid_x > 1 else "row bands", col_bounds=cols_, row_bounds=rows_, rects=[list(r) for r in rects_])
+            band_partition.update(kind="tiles %dx%d" % (grid_x, grid_y) if grid_x > 1 else "row bands", col_bounds=cols_, row_bounds=rows_, rects=[list(r) for r in rects_],
+                                  gi_halo="whole image: the partitioned frame equals the unpartitioned one bit for bit" if args.exact_partition else
+                                          "default (64 trace rows per 2160 frame rows): deviation from the unpartitioned frame stated in profiles/r05_config5_series.txt")
             tile_rect[0] = rects_[rank]
         be_ = RenderBackend(w_, h_, device=local_rank)
         if band_ is not None:
@@ -371,7 +377,8 @@ def main():
         else:
             extra = dict(run_sky_luts=1, run_volumetrics=1, run_light_matrix=1) if args.producers else {}
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **extra)
-        sc = build_scene(args, device, w_, h_, band_)
+        # (the exact partition's denoiser weighs samples anywhere in the frame: depth and normals of the whole frame are inputs of every rank then)
+        sc = build_scene(args, device, w_, h_, None if args.exact_partition else band_)
         sc[2].upload(fp_)
         be_.waitForGPUIdle()
         return be_, fp_, sc, w_, h_, band_

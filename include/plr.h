@@ -272,7 +272,11 @@ int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions
  * frame whose count is not zero. (Executions covered by a fused launch are not counted: a fused launcher is fast-set code.) */
 int plr_get_general_kernel_executions(uint32_t* out_count, char* out_names, size_t names_capacity);
 /* GPU time of the last plr_render_frame (hipEvents on the launch stream); blocks until that frame finished */
-int plr_get_last_frame_gpu_time(float* out_ms); /* of a frame rendered with plr_set_pass_timing(1): untimed frames are not bracketed by events (6 us each on the launch stream) */
+/* Frames are bracketed by the two events only on demand (an event record is a ~6 us barrier packet on the launch stream): with plr_set_pass_timing(1),
+ * or because this getter was called since the previous plr_render_frame. So a caller that polls it once per frame (a frame-time overlay; the reference has no such getter, its
+ * getRenderpassTimings, RenderBackend.h:107, reports a past frame in the same way) reads the time of the last frame from its second call on; *out_ms = the most recent bracketed frame's time,
+ * 0 before there is one. Never an error for an untimed frame. */
+int plr_get_last_frame_gpu_time(float* out_ms);
 /* replay the recorded frame `count` times back to back; returns total GPU ms between first launch and last completion */
 int plr_replay_frame(uint32_t count, float* out_total_gpu_ms);
 int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* data, size_t size);
@@ -294,6 +298,10 @@ int plr_get_image_device_pointer(plr_image_handle image, uint32_t mip_level, voi
 int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void** out_ptr, size_t* out_size);
 /* the hipStream_t the passes are launched on (async_tail executions: a second stream, joined as described above) */
 int plr_get_stream(void** out_hip_stream);
+/* the same stream WITHOUT the join: for a caller that fetches the stream every frame only to enqueue work that does not touch what async_tail
+ * executions write (plr_get_stream's join makes the launch stream wait for the tail - it serialises what the tail was meant to overlap, ~20-60 us per
+ * frame when called between frames). Ordering against the tail is then the caller's business. */
+int plr_get_launch_stream(void** out_hip_stream);
 /* raw copies ordered on the launch stream of the calling thread's backend: device-to-device (asynchronous), device-to-host and
  * host-to-device (both return when the copy is done). For exchange callbacks that move rows between two backends of one process. */
 int plr_copy_device_memory(void* dst, const void* src, size_t size);

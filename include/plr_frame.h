@@ -32,6 +32,12 @@ typedef struct plrf_settings {
      * instance renders full-resolution rows [band_row_begin, band_row_end) (multiples of 64, or the last row). band_row_end == 0:
      * off. Halos: rows exchanged / recomputed around the band, see BandSettings in csrc/frontend/frame_pipeline.h */
     uint32_t band_row_begin, band_row_end, band_gi_halo, band_gi_history_halo, band_color_halo, band_post_halo;
+    /* band_gi_halo decides what a partitioned frame IS. The GI denoiser's disc is 1.5 m in world space - on near geometry wider than any bounded halo - and a
+     * sample beyond the exchanged halo gets weight 0. The denoised signal is next frame's history (SDFGI.cpp:421-536), so that deviation feeds back and spreads:
+     * with the default (64 trace rows per 2160 frame rows) the share of pixels more than one R11G11B10 code from the unpartitioned frame grows for hundreds of
+     * frames and has no steady state within 256 (profiles/r05_config5_series.txt). band_gi_halo = PLRF_HALO_WHOLE_IMAGE exchanges every GI texel with every
+     * rank: the partitioned frame then EQUALS the unpartitioned one, bit for bit (tests/test_config5_8k.py, 64 frames at 8K), at the price in the same file. */
+#define PLRF_HALO_WHOLE_IMAGE 0xffffffffu
     /* input producers recorded as compute passes instead of uploaded (0 = uploaded): lightMatrix.comp after the depth pyramid */
     uint32_t run_light_matrix; float volumetrics_max_distance;
     uint32_t taa_use_separate_supersampling, taa_supersample_use_tonemapping; /* TAASettings::useSeparateSupersampling (off), supersampleUseTonemapping */
@@ -113,6 +119,10 @@ typedef struct plrf_exchange_op { uint32_t peer, send, row_begin, row_end; } plr
 int plrf_band_rows(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t* out_row_begin, uint32_t* out_row_end);
 int plrf_exchange_plan_rows(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin,
                             uint32_t row_end, plrf_exchange_op* out_ops, uint32_t* out_count);
+/* what the native exchange moves for a band (up to 2 (n_bands - 1) transfers, out_count = how many there are): the plan above, plus - when a halo is taller
+ * than a neighbouring band (band_gi_halo = PLRF_HALO_WHOLE_IMAGE) - the rows of the bands behind the neighbours */
+int plrf_exchange_plan_all_bands(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin,
+                                 uint32_t row_end, plrf_exchange_op* out_ops, uint32_t capacity, uint32_t* out_count);
 int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,
                        plrf_exchange_op* out_ops_4, uint32_t* out_count);
 

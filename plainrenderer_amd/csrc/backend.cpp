@@ -287,6 +287,8 @@ struct Backend {
     size_t timedExecutions = 0;
     hipEvent_t frameStart = nullptr, frameEnd = nullptr;
     bool frameRecorded = false;
+    bool frameTimeAsked = false; // plr_get_last_frame_gpu_time was called since the last plr_render_frame: the next frame is bracketed by events
+    float lastFrameGpuMs = 0.f;  // of the most recent bracketed frame
     float lastCpuMs = 0.f;
     // stream scheduler (launchAll): independent passes of a frame run on side streams
     static constexpr int kSideStreams = 3;
@@ -1684,7 +1686,9 @@ int plr_render_frame(int /*present_to_screen*/) {
     if (rc) return rc;
     // the frame's two timing events only when somebody asked for timings (plr_set_pass_timing): an event record is a barrier packet of ~6 us on the
     // launch stream (profiles/r04_frame_timeline.txt), and there were four of them between two frames
-    const bool frameTimed = g->passTiming;
+    // (a caller that polls the getter every frame, as a frame-time overlay does, gets every frame bracketed from its second frame on)
+    const bool frameTimed = g->passTiming || g->frameTimeAsked;
+    g->frameTimeAsked = false;
     if (frameTimed) HIP_TRY(hipEventRecord(g->frameStart, g->stream));
     rc = launchAll(g->passTiming);
     if (rc) return rc;
@@ -1959,9 +1963,14 @@ int plr_get_last_frame_cpu_time(float* out_ms) { NEED_INIT(); *out_ms = g->lastC
 
 int plr_get_last_frame_gpu_time(float* out_ms) {
     NEED_INIT_JOINED();
-    if (!g->frameRecorded) return setErr(PLR_ERR_INVALID_ARGUMENT, "the last frame was not timed: plr_set_pass_timing(1) before plr_render_frame (frames are not bracketed by events otherwise)");
-    HIP_TRY(hipEventSynchronize(g->frameEnd));
-    HIP_TRY(hipEventElapsedTime(out_ms, g->frameStart, g->frameEnd));
+    // Asking is what turns the bracket on: the next frame is timed, and the value handed out is that of the most recent bracketed frame (0 before there
+    // is one) - like the reference's getRenderpassTimings (RenderBackend.h:107), whose timestamp queries are read back a frame late.
+    g->frameTimeAsked = true;
+    if (g->frameRecorded) {
+        HIP_TRY(hipEventSynchronize(g->frameEnd));
+        HIP_TRY(hipEventElapsedTime(&g->lastFrameGpuMs, g->frameStart, g->frameEnd));
+    }
+    *out_ms = g->lastFrameGpuMs;
     return PLR_OK;
 }
 
@@ -2064,6 +2073,7 @@ int plr_get_storage_buffer_device_pointer(plr_storage_buffer_handle buffer, void
 }
 
 int plr_get_stream(void** out_hip_stream) { NEED_INIT_JOINED(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
+int plr_get_launch_stream(void** out_hip_stream) { NEED_INIT(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
 
 int plr_get_supported_shaders(const char** out_names, uint32_t capacity) {
     const auto& r = registry();

@@ -91,6 +91,27 @@ uint32_t planItem(uint32_t frameHeight, uint32_t nBands, const uint32_t* bounds,
     return n;
 }
 
+// What the exchange itself moves for a band: planItem's transfers, and - when a halo is taller than a neighbouring band (the exact mode's whole-image halo) -
+// the rows of the bands behind it too: with every band p the rows of the own band within haloRows of p's are sent, p's rows within haloRows of the own band
+// are received. For a halo no taller than the neighbours this is planItem, transfer for transfer.
+std::vector<plrf_exchange_op> planBandRows(uint32_t frameHeight, uint32_t nBands, const uint32_t* bounds, uint32_t band, uint32_t imageRows, uint32_t haloRows, uint32_t rowBegin,
+                                           uint32_t rowEnd) {
+    std::vector<plrf_exchange_op> ops;
+    auto add = [&](uint32_t peer, uint32_t send, uint32_t a, uint32_t b) { if (b > a) ops.push_back({peer, send, a, b}); };
+    const uint32_t lo = rowBegin > haloRows ? rowBegin - haloRows : 0u, hi = (uint32_t)std::min<uint64_t>((uint64_t)rowEnd + haloRows, imageRows);
+    for (uint32_t p = 0; p < nBands; p++) {
+        if (p == band) continue;
+        uint32_t tb, te;
+        bandRowsInImage(frameHeight, nBands, bounds, p, imageRows, &tb, &te);
+        if (p < band) te = std::min(te, rowBegin); // (a reduced image's shared boundary row belongs to the band below it, as in planItem)
+        else tb = std::max(tb, rowEnd);
+        const uint32_t plo = tb > haloRows ? tb - haloRows : 0u, phi = (uint32_t)std::min<uint64_t>((uint64_t)te + haloRows, imageRows);
+        add(p, 1, std::max(rowBegin, plo), std::min(rowEnd, phi));
+        add(p, 0, std::max(tb, lo), std::min(te, hi));
+    }
+    return ops;
+}
+
 // ---------------------------------------------------------------- rectangles (tile rendering)
 struct Rect { uint32_t x0, y0, x1, y1; };
 bool emptyRect(const Rect& r) { return r.x1 <= r.x0 || r.y1 <= r.y0; }
@@ -102,9 +123,6 @@ Rect scaleRect(const Rect& r, uint32_t frameW, uint32_t frameH, uint32_t cols, u
     const uint32_t dx = std::max(1u, (frameW + cols / 2) / std::max(cols, 1u)), dy = std::max(1u, (frameH + rows / 2) / std::max(rows, 1u));
     return {r.x0 / dx, r.y0 / dy, std::min((r.x1 + dx - 1) / dx, cols), std::min((r.y1 + dy - 1) / dy, rows)};
 }
-// closures intersect: the rectangles share an edge or a corner
-bool touching(const Rect& a, const Rect& b) { return a.x0 <= b.x1 && b.x0 <= a.x1 && a.y0 <= b.y1 && b.y0 <= a.y1; }
-
 uint32_t planRects(uint32_t frameW, uint32_t frameH, uint32_t world, const Rect* rects, uint32_t rank, uint32_t cols, uint32_t rows, uint32_t halo, plrf_rect_op* ops, uint32_t capacity) {
     uint32_t n = 0;
     const Rect mine = scaleRect(rects[rank], frameW, frameH, cols, rows);
@@ -114,7 +132,7 @@ uint32_t planRects(uint32_t frameW, uint32_t frameH, uint32_t world, const Rect*
         n++;
     };
     for (uint32_t p = 0; p < world; p++) {
-        if (p == rank || !touching(rects[rank], rects[p])) continue;
+        if (p == rank) continue; // every rank within the halo's reach is a peer: the tiles that touch (edge or corner) and, when a halo is wider than a neighbour, the tile behind it
         const Rect theirs = scaleRect(rects[p], frameW, frameH, cols, rows);
         add(p, 1, intersect(mine, grow(theirs, halo, cols, rows)));
         add(p, 0, intersect(theirs, grow(mine, halo, cols, rows)));
@@ -382,9 +400,8 @@ struct RcclExchange {
         }
         if (loopback) { // bands send straight from the images: nothing local to stand in for; the bytes a real exchange would move are still counted
             for (uint32_t i = 0; i < count; i++) {
-                plrf_exchange_op ops[4];
-                const uint32_t n = planItem(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, items[i].image_rows, items[i].halo_rows, items[i].row_begin, items[i].row_end, ops);
-                for (uint32_t k = 0; k < n; k++) (ops[k].send ? bytesSent : bytesReceived) += (uint64_t)(ops[k].row_end - ops[k].row_begin) * items[i].row_bytes;
+                for (const plrf_exchange_op& o : planBandRows(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, items[i].image_rows, items[i].halo_rows, items[i].row_begin, items[i].row_end))
+                    (o.send ? bytesSent : bytesReceived) += (uint64_t)(o.row_end - o.row_begin) * items[i].row_bytes;
             }
             exchanges++;
             return 0;
@@ -393,9 +410,8 @@ struct RcclExchange {
         int rc = 0;
         for (uint32_t i = 0; i < count && !rc; i++) {
             const plrf_exchange_item& it = items[i];
-            plrf_exchange_op ops[4];
-            const uint32_t n = planItem(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, it.image_rows, it.halo_rows, it.row_begin, it.row_end, ops);
-            for (uint32_t k = 0; k < n && !rc; k++) {
+            const std::vector<plrf_exchange_op> ops = planBandRows(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, it.image_rows, it.halo_rows, it.row_begin, it.row_end);
+            for (size_t k = 0; k < ops.size() && !rc; k++) {
                 uint8_t* p = (uint8_t*)it.device_ptr + (size_t)ops[k].row_begin * it.row_bytes;
                 const size_t bytes = (size_t)(ops[k].row_end - ops[k].row_begin) * it.row_bytes;
                 if (ops[k].send) { rc = nccl(ncclSend(p, bytes, ncclUint8, (int)ops[k].peer, comm, stream), "ncclSend"); bytesSent += bytes; }
@@ -530,6 +546,15 @@ int plrf_exchange_plan_rows(uint32_t frame_height, uint32_t n_bands, const uint3
     if (!out_ops || !out_count || n_bands == 0 || band >= n_bands || image_rows == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_exchange_plan: invalid argument");
     if (int rc = checkBounds(frame_height, n_bands, row_bounds, "plrf_exchange_plan_rows")) return rc;
     *out_count = planItem(frame_height, n_bands, row_bounds, band, image_rows, halo_rows, row_begin, row_end, out_ops);
+    return PLR_OK;
+}
+int plrf_exchange_plan_all_bands(uint32_t frame_height, uint32_t n_bands, const uint32_t* row_bounds, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin,
+                                 uint32_t row_end, plrf_exchange_op* out_ops, uint32_t capacity, uint32_t* out_count) {
+    if (!out_ops || !out_count || n_bands == 0 || band >= n_bands || image_rows == 0) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_exchange_plan_all_bands: invalid argument");
+    if (int rc = checkBounds(frame_height, n_bands, row_bounds, "plrf_exchange_plan_all_bands")) return rc;
+    const std::vector<plrf_exchange_op> ops = planBandRows(frame_height, n_bands, row_bounds, band, image_rows, halo_rows, row_begin, row_end);
+    for (size_t i = 0; i < ops.size() && i < capacity; i++) out_ops[i] = ops[i];
+    *out_count = (uint32_t)ops.size();
     return PLR_OK;
 }
 int plrf_exchange_plan(uint32_t frame_height, uint32_t n_bands, uint32_t band, uint32_t image_rows, uint32_t halo_rows, uint32_t row_begin, uint32_t row_end,

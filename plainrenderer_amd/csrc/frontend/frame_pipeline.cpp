@@ -634,6 +634,10 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
         if (b.tiled() && (b.colEnd > W || b.colBegin % bandAlignment != 0 || (b.colEnd % bandAlignment != 0 && b.colEnd != W)))
             throw std::runtime_error("tile columns must lie inside the frame and start/end on multiples of 64 (or at the last column)");
     } else if (s.band.tiled()) throw std::runtime_error("tile columns without band rows: set rowBegin / rowEnd too");
+    // a halo never needs to be larger than the image (PLRF_HALO_WHOLE_IMAGE: the exact mode of a partitioned frame, every GI texel a denoiser sample can
+    // reach is exchanged); clamping here keeps the row arithmetic below in 32 bits
+    settings.band.giHalo = std::min(settings.band.giHalo, std::max(W, H));
+    settings.band.giHistoryHalo = std::min(settings.band.giHistoryHalo, std::max(W, H));
     for (int i = 0; i < ExchangeCount; i++) {
         m_exchangeCtx[i] = {this, i};
         m_exchangeCtx[ExchangeCount + i] = {this, i | ExchangeBegin};

@@ -562,7 +562,6 @@ __global__ __launch_bounds__(256) void froxelFrontFusedKernel(ImgView material, 
     const float gg = s.phaseFunctionG;
     const float phase = (1.f - gg * gg) / (4.f * kPi * det_powf(1.f + gg * gg - 2.f * gg * VoL, 1.5f));
     const int zn = valid ? min(kFroxelSegment, cz - z0) : 0;
-    float segR = 0.f, segG = 0.f, segB = 0.f, segT = 1.f;
     for (int k = 0; k < zn; k++) {
         const int z = z0 + k;
         const size_t texel = idx3(target, x, y, z); // the launcher checked: all three volumes have the target's size

@@ -461,8 +461,8 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         // minus what the producer of the input packed itself (fused_gi.h). Tile rendering: the same for the columns.
         // (the margin follows the declared valid rows: a band's GI halo grows with the frame height, 64 trace rows per 2160 - ADVICE r03: with a fixed 128
         //  a frame taller than 4320 rows read stale packed texels on valid halo rows beyond it)
-        const bool banded = validLo > 0 || validHi < (int)c.sampled[2].h;
-        const int margin = banded ? std::max({128, y0 - validLo, validHi - h}) : 128;
+        // (and the declared valid rows may be the whole image while the dispatch is a band: a GI halo as large as the image, the exact mode of tools/config5_series.sh)
+        const int margin = std::max({128, y0 - validLo, validHi - h});
         const int p0 = std::max({y0 - margin, 0, validLo}), p1 = std::min({h + margin, (int)c.sampled[2].h, validHi});
         const bool tiled = validLoX > 0 || validHiX < (int)c.sampled[2].w || x0 > 0 || w < (int)c.sampled[2].w;
         const int marginX = std::max({128, x0 - validLoX, validHiX - w});

@@ -144,18 +144,14 @@ def _intersect(a, b):
     return max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
 
 
-def _touching(a, b):
-    return a[0] <= b[2] and b[0] <= a[2] and a[1] <= b[3] and b[1] <= a[3]
-
-
 def rect_plan(rects, rank, frame_w, frame_h, image_cols, image_rows, halo):
     """[(peer, 'send'|'recv', x0, y0, x1, y1)] in texels of an image of image_cols x image_rows showing the frame at frame_w / image_cols scale: with every
-    rank whose rectangle touches this rank's (edge or corner), the part of the own rectangle within `halo` texels of the peer's is sent, the part of the
+    rank whose rectangle lies within `halo` of this rank's (the ones that touch it, edge or corner - and the one behind a neighbour narrower than the halo), the part of the own rectangle within `halo` texels of the peer's is sent, the part of the
     peer's within `halo` of the own is received (the mirror of plrf_exchange_plan_rects; for whole-row rectangles it equals neighbour_plan)"""
     ops = []
     mine = _scale_rect(rects[rank], frame_w, frame_h, image_cols, image_rows)
     for p, r in enumerate(rects):
-        if p == rank or not _touching(rects[rank], r):
+        if p == rank:
             continue
         theirs = _scale_rect(r, frame_w, frame_h, image_cols, image_rows)
         for kind, q in (("send", _intersect(mine, _grow(theirs, halo, image_cols, image_rows))), ("recv", _intersect(theirs, _grow(mine, halo, image_cols, image_rows)))):

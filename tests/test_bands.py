@@ -542,6 +542,18 @@ def test_rect_plan_of_bands_equals_the_band_plan_and_the_cpp_plan():
                                             C.byref(cnt)) == 0
         return [(int(o.peer), "send" if o.send else "recv", int(o.x0), int(o.y0), int(o.x1), int(o.y1)) for o in ops[:cnt.value]]
 
+    class RowOp(C.Structure):
+        _fields_ = [(n, C.c_uint32) for n in ("peer", "send", "row_begin", "row_end")]
+
+    def cpp_band_plan(h, rects, rank, rows, halo, own):
+        # what the native exchange moves for a band (planBandRows): every band within the halo's reach
+        n = len(rects)
+        ops, cnt = (RowOp * (2 * n))(), C.c_uint32()
+        bounds = (C.c_uint32 * (n + 1))(*([r[1] for r in rects] + [h]))
+        assert lib.plrf_exchange_plan_all_bands(C.c_uint32(h), C.c_uint32(n), bounds, C.c_uint32(rank), C.c_uint32(rows), C.c_uint32(halo), C.c_uint32(own[0]), C.c_uint32(own[1]), ops,
+                                                C.c_uint32(2 * n), C.byref(cnt)) == 0, lib.plrf_rccl_last_error()
+        return [(int(o.peer), "send" if o.send else "recv", int(o.row_begin), int(o.row_end)) for o in ops[:cnt.value]]
+
     # bands as rectangles
     w = 7680
     for height, n in ((4320, 4), (2160, 2), (1088, 3), (8640, 8)):
@@ -551,9 +563,16 @@ def test_rect_plan_of_bands_equals_the_band_plan_and_the_cpp_plan():
             for halo in (0, 16, 64, 224, 5000):
                 bands = [tiling.Rows(0, r[1] // div, min((r[3] + div - 1) // div, rows), halo, 16 * cols, rows) for r in rects]
                 for b in range(n):
-                    expect = [(peer, kind, 0, a, cols, e) for peer, kind, a, e in tiling.neighbour_plan(bands, b, n)]
-                    assert tiling.rect_plan(rects, b, w, height, cols, rows, halo) == expect, (height, n, b, div, halo)
-                    assert cpp_plan(w, height, rects, b, cols, rows, halo) == expect
+                    got = tiling.rect_plan(rects, b, w, height, cols, rows, halo)
+                    assert cpp_plan(w, height, rects, b, cols, rows, halo) == got
+                    assert [(p, k, 0, a, cols, e) for p, k, a, e in cpp_band_plan(height, rects, b, rows, halo, (bands[b].row_begin, bands[b].row_end))] == got
+                    if halo <= min(e.row_end - e.row_begin for e in bands):
+                        assert got == [(peer, kind, 0, a, cols, e) for peer, kind, a, e in tiling.neighbour_plan(bands, b, n)], (height, n, b, div, halo)
+                    else:  # a halo wider than a neighbour reaches the band behind it (the band plan stops at the neighbour)
+                        if halo >= rows:
+                            assert sorted((p, k) for p, k, *_ in got) == sorted((p, k) for p in range(n) if p != b for k in ("send", "recv"))
+                        lo, hi = max(bands[b].row_begin - halo, 0), min(bands[b].row_end + halo, rows)
+                        assert sum((y1 - y0) for p, k, x0, y0, x1, y1 in got if k == "recv") == (hi - lo) - (bands[b].row_end - bands[b].row_begin)
     # tile grids
     for (fw, fh, gx, gy) in ((7680, 4320, 2, 2), (7680, 8640, 2, 4), (3840, 2160, 4, 2), (256, 192, 2, 2), (7680, 2160, 2, 1)):
         rects = tiling.tile_rects(fw, fh, gx, gy)

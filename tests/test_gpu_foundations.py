@@ -132,6 +132,8 @@ def test_gpu_a_first_workgroup_column_is_honoured_or_refused_never_ignored(backe
     [0] (which its kernel would ignore silently) is PLR_ERR_UNSUPPORTED"""
     from plainrenderer_amd.backend import ComputePassExecution, ImageResource, RenderPassResources, PlrError
     from util import F, image_desc_2d
+    import passes
+    passes.global_binding(backend).set(np.zeros(340, np.uint8))  # (tonemapping.comp declares the global set; this test does not depend on its contents)
     rng = np.random.default_rng(11)
     src_data = rng.integers(0, 2 ** 32, 64 * 32, dtype=np.uint32) & np.uint32(0x3bef7bdf)  # finite, modest R11G11B10 values
     src = backend.createImage(image_desc_2d(64, 32, F.R11G11B10_uFloat), src_data)
@@ -162,3 +164,37 @@ def test_gpu_a_first_workgroup_column_is_honoured_or_refused_never_ignored(backe
     with pytest.raises(PlrError, match="dispatch_base"):
         backend.setComputePassExecution(exe)
     backend.newFrame()  # drop the recording (nothing is rendered: the test is about what the recorder accepts)
+
+
+@pytest.mark.gpu
+def test_gpu_frame_time_getter_turns_the_bracket_on_and_never_fails_for_an_untimed_frame(backend):
+    """plr_get_last_frame_gpu_time: untimed frames carry no events (6 us each); the getter asks for the NEXT frame to be bracketed and hands out the most
+    recent bracketed frame's time - a caller polling once per frame reads a time from its second call on, and stops paying when it stops asking.
+    plr_get_launch_stream: the launch stream without joining the tail."""
+    import ctypes as C
+    from plainrenderer_amd.backend import ComputePassExecution, ImageResource, RenderPassResources
+    from util import F, image_desc_2d
+    src = backend.createImage(image_desc_2d(64, 32, F.R11G11B10_uFloat), np.zeros(64 * 32, np.uint32))
+    dst = backend.createImage(image_desc_2d(64, 32, F.RGBA8))
+    p = backend.createComputePass("tonemapping.comp", [], "Tonemap")
+    import passes
+    passes.global_binding(backend).set(np.zeros(340, np.uint8))
+
+    def frame():
+        backend.newFrame()
+        backend.setComputePassExecution(ComputePassExecution(p, RenderPassResources(storageImages=[ImageResource(dst, 0, 0)], sampledImages=[ImageResource(src, 0, 1)]), b"", (8, 4, 1)))
+        backend.renderFrame()
+
+    backend.setPassTiming(False)
+    frame()
+    first = backend.getLastFrameGpuTime()  # the frame above was not bracketed: the previous bracketed value (whatever an earlier test left), no error
+    frame()
+    second = backend.getLastFrameGpuTime()
+    assert second > 0.0 and second != first, "the frame after the first call is bracketed"
+    frame()
+    third = backend.getLastFrameGpuTime()
+    assert third > 0.0
+    a, b = C.c_void_p(), C.c_void_p()
+    backend._check(backend.lib.plr_get_launch_stream(C.byref(a)))
+    backend._check(backend.lib.plr_get_stream(C.byref(b)))
+    assert a.value == b.value
