@@ -1,4 +1,6 @@
-"""Builds the HIP backend (libplr.so) for gfx950 with hipcc, in-tree.
+"""Builds the HIP backend for gfx950 with hipcc, in-tree: libplr.so (the C ABI, the C++ frame host, the benchmarked PLR_MATH_FAST kernel set and the kernels that
+serve both math modes) and libplr_exact.so (csrc/kernels_exact/: the PLR_MATH_EXACT launch paths of the GI trace, the GI filters, the deferred shade, TAA and bloom -
+the reference's operation order, bit-exact against the oracle; loaded by libplr.so on demand: plr_set_math_mode(PLR_MATH_EXACT), or an execution the fast set declines).
 
 Every translation unit is compiled with -ffp-contract=off: the kernels' arithmetic is specified operation
 by operation (no FMA contraction) so results are reproducible against an IEEE scalar evaluation.
@@ -16,6 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 _TAG = os.environ.get("PLR_BUILD_TAG", "")
 OBJ_DIR = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
 LIB_PATH = os.path.join(HERE, "libplr" + ("_" + _TAG if _TAG else "") + ".so")
+EXACT_LIB_PATH = os.path.join(HERE, "libplr_exact" + ("_" + _TAG if _TAG else "") + ".so")  # found by libplr.so next to itself (same tag)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA_FLAGS = os.environ.get("PLR_EXTRA_FLAGS", "").split()  # experiment hook, e.g. -DPLR_SHADE_WAVES=5
 
@@ -42,9 +45,9 @@ def _rocm_lib_dir():
     return "/opt/rocm/lib"
 
 
-def _sources():
-    out = [os.path.join(CSRC, "backend.cpp")]
-    for sub in ("kernels", "kernels_fast", "frontend"):
+def _sources(subdirs=("kernels", "kernels_fast", "frontend")):
+    out = [os.path.join(CSRC, "backend.cpp")] if "frontend" in subdirs else []
+    for sub in subdirs:
         d = os.path.join(CSRC, sub)
         if os.path.isdir(d):
             for f in sorted(os.listdir(d)):
@@ -99,20 +102,27 @@ def build(verbose=False, jobs=None):
     """Compile every HIP source for gfx950 and link libplr.so. Cross-compiles without a GPU."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     digest = _headers_digest()
-    srcs = _sources()
+    srcs, exact_srcs = _sources(), _sources(("kernels_exact",))
     jobs = jobs or min(6, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        results = list(ex.map(lambda s: _compile(s, digest, verbose), srcs))
-    objs = [o for o, _ in results]
-    changed = any(c for _, c in results)
-    if changed or not os.path.exists(LIB_PATH):
-        # librccl: the band exchange of the C++ host (csrc/frontend/band_exchange.cpp) calls ncclSend / ncclRecv / ncclAllReduce directly
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-L" + _rocm_lib_dir(), "-lrccl"]
+        results = list(ex.map(lambda s: _compile(s, digest, verbose), srcs + exact_srcs))
+    objs = [o for o, _ in results[:len(srcs)]]
+    exact_objs = [o for o, _ in results[len(srcs):]]
+
+    def link(path, objects, extra, relink):
+        if not relink and os.path.exists(path):
+            return
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", path] + objects + extra
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # librccl: the band exchange of the C++ host (csrc/frontend/band_exchange.cpp) calls ncclSend / ncclRecv / ncclAllReduce directly
+    link(LIB_PATH, objs, ["-Wl,-soname," + os.path.basename(LIB_PATH), "-L" + _rocm_lib_dir(), "-lrccl"], any(c for _, c in results[:len(srcs)]))
+    # the exact set resolves the backend's symbols (PassCtx, the shader registry) against the libplr.so that loads it: linked against it, found through $ORIGIN
+    link(EXACT_LIB_PATH, exact_objs, ["-Wl,-soname," + os.path.basename(EXACT_LIB_PATH), "-Wl,-rpath,$ORIGIN", "-L" + HERE, "-l:" + os.path.basename(LIB_PATH),
+                                      "-Wl,--no-undefined"], any(c for _, c in results))
     return LIB_PATH
 
 

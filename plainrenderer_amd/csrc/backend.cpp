@@ -8,8 +8,10 @@
 #include "backend.h"
 #include "kernels_fast/pcf_taps.h"
 
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdlib>
 #include <atomic>
 #include <set>
@@ -87,15 +89,6 @@ static std::vector<ConsumerLink>& consumerLinks() {
     return r;
 }
 ConsumerLinkRegistrar::ConsumerLinkRegistrar(const char* producerShader, const char* consumerShader) { consumerLinks().push_back({producerShader, consumerShader}); }
-
-static const ShaderEntry* findShader(const std::string& path) {
-    std::string base = path;
-    const size_t slash = base.find_last_of("/\\");
-    if (slash != std::string::npos) base = base.substr(slash + 1);
-    for (const auto& e : registry())
-        if (e.name == base && e.fn) return &e;
-    return nullptr;
-}
 
 // ---------------------------------------------------------------- PassCtx helpers
 const SpecConstant* PassCtx::findSpec(uint32_t location) const {
@@ -337,6 +330,62 @@ struct Backend {
 // again instead of silently operating on another thread's backend.
 static thread_local Backend* g = nullptr;
 static thread_local std::string g_err;
+
+// ---- The PLR_MATH_EXACT launch paths of the hot path's big passes (GI trace, GI filters, deferred shade, TAA, bloom: csrc/kernels_exact/) are a library of their
+// own, libplr_exact.so next to this one (plainrenderer_amd/build.py): the shipped path is the fast set, the exact set is the parity instrument. It is loaded the first
+// time it is needed - plr_set_math_mode(PLR_MATH_EXACT), or an execution whose fast launcher declines its bindings - and registers its launchers like any other
+// translation unit (ShaderRegistrar). Fails loudly when the file is missing.
+static std::mutex g_exactSetMutex;
+static bool g_exactSetTried = false;
+static void* g_exactSetHandle = nullptr;
+static std::string g_exactSetError;
+static int ensureExactSet() {
+    std::lock_guard<std::mutex> lock(g_exactSetMutex);
+    if (!g_exactSetTried) {
+        g_exactSetTried = true;
+        Dl_info info{};
+        std::string path;
+        if (dladdr((const void*)&ensureExactSet, &info) && info.dli_fname) {
+            path = info.dli_fname; // .../libplr.so or .../libplr_<tag>.so
+            const size_t slash = path.find_last_of('/');
+            const size_t name = slash == std::string::npos ? 0 : slash + 1;
+            if (path.compare(name, 6, "libplr") == 0) path.insert(name + 6, "_exact");
+            else path.clear();
+        }
+        if (path.empty()) g_exactSetError = "cannot locate libplr.so to find libplr_exact.so next to it";
+        else {
+            g_exactSetHandle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!g_exactSetHandle) g_exactSetError = "the PLR_MATH_EXACT kernel set is a separate library and it did not load (" + path + "): " + (dlerror() ? dlerror() : "?") +
+                                                     " - build it with plainrenderer_amd/build.py";
+        }
+    }
+    if (!g_exactSetHandle) { g_err = g_exactSetError; return PLR_ERR_UNSUPPORTED; }
+    return PLR_OK;
+}
+
+static std::string shaderBaseName(const std::string& path) {
+    const size_t slash = path.find_last_of("/\\");
+    return slash == std::string::npos ? path : path.substr(slash + 1);
+}
+static const ShaderEntry* findShader(const std::string& path) {
+    const std::string base = shaderBaseName(path);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (const auto& e : registry())
+            if (e.name == base && (e.fn || e.fast)) return &e;
+        if (attempt == 0 && ensureExactSet() != PLR_OK) break; // a shader only the exact set has
+    }
+    return nullptr;
+}
+// the general launcher of a pass whose shader's exact launch path lives in libplr_exact.so
+static int resolveExactLauncher(LaunchFn* fn, const std::string& shader) {
+    if (int rc = ensureExactSet()) return rc;
+    const std::string base = shaderBaseName(shader);
+    for (const auto& e : registry())
+        if (e.name == base && e.fn) { *fn = e.fn; return PLR_OK; }
+    g_err = "no PLR_MATH_EXACT kernel for shader '" + shader + "'";
+    return PLR_ERR_UNKNOWN_SHADER;
+}
+
 static thread_local bool g_adopted = false;
 static thread_local bool g_ownedOnce = false; // this thread has set up (and possibly shut down) a backend of its own: it never adopts another thread's
 static thread_local uint64_t g_adoptedEpoch = 0;
@@ -1333,6 +1382,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
             g->lastGeneral++;
             if (g->lastGeneralNames.size() < 2048) g->lastGeneralNames += (g->lastGeneralNames.empty() ? "" : ", ") + p.name + " [" + p.shader + "]";
         }
+        if (!p.fn) if (int lrc = resolveExactLauncher(&p.fn, p.shader)) return lrc;
         rc = p.fn(x.ctx);
     }
     if (rc) { g_err = "pass '" + p.name + "' (" + p.shader + "): " + g_err; return rc; }
@@ -1934,6 +1984,7 @@ int plr_debug_sampler_eval(plr_image_handle image, uint32_t mip_level, int filte
 int plr_set_math_mode(int mode) {
     NEED_INIT_JOINED();
     if (mode != PLR_MATH_EXACT && mode != PLR_MATH_FAST) return setErr(PLR_ERR_INVALID_ARGUMENT, "math mode must be PLR_MATH_EXACT or PLR_MATH_FAST");
+    if (mode == PLR_MATH_EXACT) if (int rc = ensureExactSet()) return rc; // (loudly, here - not at the first launch)
     g->mathMode = mode;
     return PLR_OK;
 }

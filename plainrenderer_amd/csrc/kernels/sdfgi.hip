@@ -1,5 +1,5 @@
-// SDF diffuse GI for gfx950, part 1: depthDownscale.comp, sdfCameraFrustumCulling.comp, sdfCameraTileCulling.comp,
-// sdfDiffuseTrace.comp (+ SDF.inc, sdfCulling.inc, sampling.inc, sunShadowCascades.inc, sky.inc, SphericalHarmonics.inc);
+// SDF diffuse GI for gfx950, part 1: depthDownscale.comp, sdfCameraFrustumCulling.comp, sdfCameraTileCulling.comp, sdfDebugVisualisation.comp
+// (+ SDF.inc, sdfCulling.inc, sampling.inc, sunShadowCascades.inc, sky.inc, SphericalHarmonics.inc);
 // host side Techniques/SDFGI.cpp:380-419,538-630 and RenderFrontend.cpp:873-892.
 //
 // Mapping to CDNA4: one wave64 is one 8x8 reference workgroup (the shared-memory ray exchange of resolveColor becomes a
@@ -12,6 +12,7 @@
 #include "../device/shading_common.h"
 #include "../device/culling_device.h"
 #include "../device/hiz_fast_device.h"
+#include "../device/sdf_march_device.h"
 
 namespace plr {
 
@@ -94,6 +95,7 @@ static int launchFrustumCulling(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("sdfCameraFrustumCulling.comp", launchFrustumCulling);
+PLR_REGISTER_SHADER_FAST("sdfCameraFrustumCulling.comp", launchFrustumCulling); // one kernel serves both math modes (the fused launches below use the same device code)
 
 template <bool USE_HIZ>
 __global__ __launch_bounds__(256) void tileCullingKernel(const uint32_t* __restrict__ culled, const BoundingBox* __restrict__ bbs, CulledInstancesPerTile* __restrict__ tiles,
@@ -143,6 +145,7 @@ static int launchTileCulling(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER("sdfCameraTileCulling.comp", launchTileCulling);
+PLR_REGISTER_SHADER_FAST("sdfCameraTileCulling.comp", launchTileCulling);
 
 int prepareFusedCulling(const PassCtx& fc, const PassCtx& tc, FusedCullParams* out, bool* useHiZOut, ImgView* hizOut) {
     if (!fc.hasSbuf(0) || !fc.hasUbuf(1) || !fc.hasSbuf(2) || !fc.hasSbuf(3) || !fc.hasUbuf(4) || fc.ubuf[1].size < sizeof(FrustumUbo) || fc.sbuf[2].size < 8) return kUseGeneralKernel;
@@ -224,287 +227,7 @@ PLR_REGISTER_FUSION("depthHiZPyramid + depthDownscale + sdfCameraFrustumCulling 
                     "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 PLR_REGISTER_FUSION("sdfCameraFrustumCulling + sdfCameraTileCulling", launchFusedCulling, "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 
-// ------------------------------------------------------------------------------------------------ trace
-// trilinear, clamp-to-edge sample of an R16F volume (sampler contract: 8-bit sub-texel weights)
-PLR_DI float sampleSDF(const ImgView& v, vec3 uvw) {
-    int i0, j0, k0; float a, b, c;
-    linearCoord(uvw.x * (float)v.w, &i0, &a);
-    linearCoord(uvw.y * (float)v.h, &j0, &b);
-    linearCoord(uvw.z * (float)v.d, &k0, &c);
-    const int x0 = clampi(i0, v.w), x1 = clampi(i0 + 1, v.w);
-    const int y0 = clampi(j0, v.h) * v.w, y1 = clampi(j0 + 1, v.h) * v.w;
-    const int sl = v.w * v.h;
-    const int z0 = clampi(k0, v.d) * sl, z1 = clampi(k0 + 1, v.d) * sl;
-    const uint16_t* p = (const uint16_t*)v.ptr;
-    const float t000 = halfBitsToFloat(p[z0 + y0 + x0]), t100 = halfBitsToFloat(p[z0 + y0 + x1]);
-    const float t010 = halfBitsToFloat(p[z0 + y1 + x0]), t110 = halfBitsToFloat(p[z0 + y1 + x1]);
-    const float t001 = halfBitsToFloat(p[z1 + y0 + x0]), t101 = halfBitsToFloat(p[z1 + y0 + x1]);
-    const float t011 = halfBitsToFloat(p[z1 + y1 + x0]), t111 = halfBitsToFloat(p[z1 + y1 + x1]);
-    const float a0 = 1.f - a, b0 = 1.f - b, c0 = 1.f - c;
-    float r = t000 * ((a0 * b0) * c0);
-    r = r + t100 * ((a * b0) * c0);
-    r = r + t010 * ((a0 * b) * c0);
-    r = r + t110 * ((a * b) * c0);
-    r = r + t001 * ((a0 * b0) * c);
-    r = r + t101 * ((a * b0) * c);
-    r = r + t011 * ((a0 * b) * c);
-    r = r + t111 * ((a * b) * c);
-    return r;
-}
-
-// SDF.inc:16-25
-PLR_DI vec3 normalFromSDF(vec3 uv, vec3 extends, const ImgView& sdf) {
-    const float extendsMax = gmax(extends.x, gmax(extends.y, extends.z));
-    const vec3 extendsNormalized = extends / extendsMax;
-    const vec3 epsilon = vec3(0.15f) / vec3((float)sdf.w, (float)sdf.h, (float)sdf.d) / extendsNormalized;
-    return normalize(vec3(sampleSDF(sdf, uv + vec3(epsilon.x, 0.f, 0.f)) - sampleSDF(sdf, uv - vec3(epsilon.x, 0.f, 0.f)),
-                          sampleSDF(sdf, uv + vec3(0.f, epsilon.y, 0.f)) - sampleSDF(sdf, uv - vec3(0.f, epsilon.y, 0.f)),
-                          sampleSDF(sdf, uv + vec3(0.f, 0.f, epsilon.z)) - sampleSDF(sdf, uv - vec3(0.f, 0.f, epsilon.z))));
-}
-
-struct TraceResult {
-    bool hit;
-    float closestHitDistance;
-    vec3 hitPos;
-    vec3 albedo;
-    vec3 N;       // only written by the WITH_NORMAL instantiation (sdfDebugVisualisation.comp)
-    int hitCount; // "
-};
-
-// SDF.inc:42-86
-PLR_DI bool rayAABBIntersection(vec3 o, vec3 dir, vec3 mn, vec3 mx, float* tOut) {
-    bool hit = false;
-    float t = 100000.f;
-    float intersection = o.x < 0.f ? mn.x : mx.x;
-    const float tx = (intersection - o.x) / dir.x;
-    vec3 p = o + tx * dir;
-    if (tx > 0.f && p.y >= mn.y && p.y <= mx.y && p.z >= mn.z && p.z <= mx.z) { t = gmin(t, tx); hit = true; }
-    intersection = o.y < 0.f ? mn.y : mx.y;
-    const float ty = (intersection - o.y) / dir.y;
-    p = o + ty * dir;
-    if (ty > 0.f && p.x >= mn.x && p.x <= mx.x && p.z >= mn.z && p.z <= mx.z) { t = gmin(t, ty); hit = true; }
-    intersection = o.z < 0.f ? mn.z : mx.z;
-    const float tz = (intersection - o.z) / dir.z;
-    p = o + tz * dir;
-    if (tz > 0.f && p.x >= mn.x && p.x <= mx.x && p.y >= mn.y && p.y <= mx.y) { t = gmin(t, tz); hit = true; }
-    *tOut = t;
-    return hit;
-}
-
-// SDF.inc:101-184. `inst` and `sdf` are wave uniform (diffuse trace) or per lane (debug visualisation).
-template <bool WITH_NORMAL = false>
-PLR_DI void traceRayTroughSDFInstance(const SDFInstance& inst, vec3 rayStartWorld, const ImgView& sdf, vec3 rayDirectionWorld, TraceResult& tr) {
-    const float* m = inst.worldToLocal;
-    const vec3 localExtends = ld3(inst.localExtends);
-    vec3 rayStartLocal = mulMat4(m, vec4(rayStartWorld, 1.f)).xyz();
-    const vec3 rayEndLocal = mulMat4(m, vec4(rayStartWorld + rayDirectionWorld, 1.f)).xyz();
-    vec3 rayDirection = rayEndLocal - rayStartLocal;
-    rayDirection /= length(rayDirection);
-    const vec3 sdfMaxLocal = localExtends * 0.5f;
-    const vec3 sdfMinLocal = -sdfMaxLocal;
-    float hitDistanceLocal = 0.f;
-    const bool inside = rayStartLocal.x >= sdfMinLocal.x && rayStartLocal.y >= sdfMinLocal.y && rayStartLocal.z >= sdfMinLocal.z &&
-                        rayStartLocal.x <= sdfMaxLocal.x && rayStartLocal.y <= sdfMaxLocal.y && rayStartLocal.z <= sdfMaxLocal.z;
-    if (!inside) {
-        float t;
-        if (rayAABBIntersection(rayStartLocal, rayDirection, sdfMinLocal, sdfMaxLocal, &t)) {
-            rayStartLocal += t * rayDirection;
-            hitDistanceLocal = t;
-        } else return;
-    }
-    vec3 localSamplePos = rayStartLocal;
-    const float distanceThreshold = length(localExtends / vec3((float)sdf.w, (float)sdf.h, (float)sdf.d)) * 0.25f;
-    float dLast = 0.f, d = 0.f;
-    const float localToGlobalScale = 1.f / length(vec3(m[0], m[1], m[2]));
-    if (localToGlobalScale * hitDistanceLocal > tr.closestHitDistance) return;
-    vec3 localExtendsHalf = localExtends * 0.5f;
-    localExtendsHalf = localExtendsHalf + 0.01f;
-    for (int i = 0; i < 128; i++) {
-        if (localSamplePos.x > localExtendsHalf.x || localSamplePos.y > localExtendsHalf.y || localSamplePos.z > localExtendsHalf.z ||
-            localSamplePos.x < -localExtendsHalf.x || localSamplePos.y < -localExtendsHalf.y || localSamplePos.z < -localExtendsHalf.z)
-            break;
-        vec3 sampleUV = localSamplePos / localExtends + 0.5f;
-        dLast = d;
-        d = sampleSDF(sdf, sampleUV);
-        if (d < distanceThreshold) {
-            tr.hit = true;
-            const float distanceGlobal = hitDistanceLocal * localToGlobalScale;
-            if (distanceGlobal < tr.closestHitDistance) {
-                tr.closestHitDistance = distanceGlobal;
-                const float lastStepSizeLocal = d / (1.f - (d - dLast));
-                localSamplePos += rayDirection * lastStepSizeLocal;
-                // the reference also evaluates normalFromSDF and the transformed normal here; neither reaches an output of
-                // sdfDiffuseTrace.comp (only the debug visualisation reads traceResult.N and hitCount), so they are computed on request
-                if (WITH_NORMAL) {
-                    tr.hitCount = i;
-                    const vec3 nUV = localSamplePos / localExtends + 0.5f;
-                    const vec3 nl = normalFromSDF(nUV, localExtends, sdf);
-                    // transpose(mat3(worldToLocal)) * N
-                    tr.N = vec3(m[0] * nl.x + m[1] * nl.y + m[2] * nl.z, m[4] * nl.x + m[5] * nl.y + m[6] * nl.z, m[8] * nl.x + m[9] * nl.y + m[10] * nl.z);
-                }
-                tr.albedo = vpow(ld3(inst.meanAlbedo), 2.2f);
-                const float lastStepSizeGlobal = lastStepSizeLocal * localToGlobalScale;
-                tr.hitPos = rayStartWorld + rayDirectionWorld * (distanceGlobal + lastStepSizeGlobal);
-            }
-            break;
-        }
-        localSamplePos += rayDirection * fabsf(d);
-        hitDistanceLocal += fabsf(d);
-    }
-}
-
-// sunShadowCascades.inc:13-20 with the nearest / white-border sampler and a D16 map
-PLR_DI float simpleShadow(vec3 posWorld, const float* lightMatrix, const ImgView& shadowMap) {
-    vec4 p = mulMat4(lightMatrix, vec4(posWorld, 1.f));
-    p = p / p.w;
-    const vec2 xy(p.x * 0.5f + 0.5f, p.y * 0.5f + 0.5f);
-    const float actualDepth = gclamp(p.z, 0.f, 1.f);
-    const float shadowMapDepth = sampleNearest2D<F_D16, BORDER_WHITE>(shadowMap, xy).x;
-    return actualDepth > shadowMapDepth ? 1.f : 0.f;
-}
-
-struct SdfInstanceBuffer { uint32_t instanceCount, pad1, pad2, pad3; SDFInstance instances[1]; };
-struct RayInfo { float nx, ny, nz, depth, cr, cg, cb; };
-
-template <bool STRICT_CUTOFF>
-__global__ __launch_bounds__(256) void sdfDiffuseTraceKernel(ImgView outYSH, ImgView outCoCg, ImgView depthTexture, ImgView normalTexture, ImgView skyLut,
-                                                             const LightBuffer* __restrict__ light, const SdfInstanceBuffer* __restrict__ instanceBuffer,
-                                                             const CulledInstancesPerTile* __restrict__ tiles, const float* __restrict__ influenceRangeP,
-                                                             const ShadowCascadeInfo* __restrict__ shadowInfo, ImgView shadowMap, const ImgView* __restrict__ bindless,
-                                                             uint32_t bindlessCount, const GlobalUbo* __restrict__ g, int shadowCascadeIndex, int groupsX, int groupsY, int groupY0, int groupX0,
-                                                             uint32_t tileCapacity, uint32_t instanceCapacity) {
-    __shared__ RayInfo sharedRays[4][64];
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    // one wave = one 8x8 reference workgroup; the four waves of a block are a 2x2 arrangement inside one culling tile
-    const int gx = groupX0 + (int)blockIdx.x * 2 + (wave & 1), gy = groupY0 + (int)blockIdx.y * 2 + (wave >> 1); // workgroups [groupX0, groupsX) x [groupY0, groupsY)
-    const bool active = gx < groupsX && gy < groupsY;
-    const int lx = lane & 7, ly = lane >> 3;
-    const int px = gx * 8 + lx, py = gy * 8 + ly;
-    vec3 L(0.f, 0.f, 1.f);
-    RayInfo mine{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        const vec2 uv((float)px / (float)outYSH.w, (float)py / (float)outYSH.h);
-        const float depth = sampleNearest2D<F_D32, CLAMP>(depthTexture, uv).x;
-        const float depthLinear = linearizeDepth(depth, g->nearPlane, g->farPlane);
-        const vec2 pixelNDC(uv.x * 2.f - 1.f, uv.y * 2.f - 1.f);
-        const vec3 camFwd = ld3(g->cameraForward);
-        const vec3 V = -calculateViewDirectionFromPixel(pixelNDC, camFwd, ld3(g->cameraUp), ld3(g->cameraRight), g->cameraTanFovHalf, g->cameraAspectRatio);
-        const vec3 pWorld = ld3(g->cameraPosition) + V / dot(V, camFwd) * depthLinear;
-
-        const uint32_t noiseSlot = (uint32_t)g->noiseTextureIndices[g->frameIndexMod4 & 3u];
-        const ImgView noiseTex = bindless[min(noiseSlot, bindlessCount - 1u)];
-        const vec2 noiseUV((float)px / (float)noiseTex.w, (float)py / (float)noiseTex.h);
-        const vec4 nz = sampleNearest2D<F_RG8, REPEAT>(noiseTex, noiseUV);
-        const vec2 xi(nz.x, nz.y);
-        const vec3 normalTexel = sampleNearest2D<F_RGBA8, CLAMP>(normalTexture, uv).xyz();
-        const vec3 N = normalTexel * 2.f - 1.f;
-        mine.nx = N.x; mine.ny = N.y; mine.nz = N.z; mine.depth = depthLinear;
-        const vec3 rayOrigin = pWorld + N * 0.2f;
-        L = importanceSampleCosine(xi, N);
-
-        TraceResult tr;
-        tr.hit = false;
-        tr.closestHitDistance = 10000.f;
-        tr.hitPos = vec3(0.f);
-        tr.albedo = vec3(0.f);
-        // tileUV = gl_WorkGroupID.xy / (cullingTileSize / 8); wave uniform
-        const uint32_t tileIndex = min(tileIndexFromTileUV(gx / (int)(kCullingTileSize / 8u), gy / (int)(kCullingTileSize / 8u), g), tileCapacity - 1u);
-        const CulledInstancesPerTile* tile = tiles + tileIndex;
-        const int objectCount = (int)min(tile->objectCount, kMaxObjectsPerTile);
-        for (int i = 0; i < objectCount; i++) {
-            const uint32_t instIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)tile->indices[i]), instanceCapacity - 1u);
-            const SDFInstance& inst = instanceBuffer->instances[instIndex];
-            const uint32_t texIndex = min((uint32_t)__builtin_amdgcn_readfirstlane((int)inst.sdfTextureIndex), bindlessCount - 1u);
-            const ImgView sdf = bindless[texIndex];
-            traceRayTroughSDFInstance(inst, rayOrigin, sdf, L, tr);
-        }
-        vec3 hitColor;
-        if (tr.hit) {
-            const float shadow = simpleShadow(tr.hitPos, shadowInfo->lightMatrices[shadowCascadeIndex], shadowMap);
-            const vec3 sunLight = shadow * light->sunStrengthExposed * ld3(light->sunColor);
-            hitColor = tr.albedo * sunLight;
-            bool hitInRange = tr.closestHitDistance < *influenceRangeP;
-            hitInRange = hitInRange || !STRICT_CUTOFF;
-            const bool selfIntersection = tr.closestHitDistance < 0.0001f;
-            if (!hitInRange || selfIntersection) hitColor = vec3(0.f);
-        } else {
-            hitColor = sampleSkyLut(L, skyLut);
-        }
-        mine.cr = hitColor.x; mine.cg = hitColor.y; mine.cb = hitColor.z;
-    }
-    sharedRays[wave][lane] = mine;
-    __syncthreads();
-    if (!active) return;
-
-    // resolveColor (:70-116); sharedRays[x][y] of the reference = slab[y * 8 + x]
-    float weightTotal = 1.f;
-    vec3 color(mine.cr, mine.cg, mine.cb);
-    const vec3 myN(mine.nx, mine.ny, mine.nz);
-    for (int x = -1; x <= 1; x++)
-        for (int y = -1; y <= 1; y++) {
-            if (x == 0 && y == 0) continue;
-            const int rx = lx + x, ry = ly + y;
-            const bool isValidIndex = (rx > 0 && ry > 0) && (rx < 8 && ry < 8); // sic: > 0 (:88)
-            if (!isValidIndex) continue;
-            const RayInfo nb = sharedRays[wave][ry * 8 + rx];
-            const float NoN = gclamp(dot(myN, vec3(nb.nx, nb.ny, nb.nz)), 0.f, 1.f);
-            const bool normalsMatch = NoN > 0.9f;
-            const bool depthMatch = fabsf(mine.depth - nb.depth) < 0.5f;
-            if (normalsMatch && depthMatch) {
-                const float weight = (x == 0 ? 1.f : 0.5f) * (y == 0 ? 1.f : 0.5f);
-                color += weight * vec3(nb.cr, nb.cg, nb.cb);
-                weightTotal += weight;
-            }
-        }
-    color /= weightTotal;
-    const vec3 YCoCg = linearToYCoCg(color);
-    if (px < outYSH.w && py < outYSH.h) {
-        const vec4 sh = directionToSH_L1(L);
-        // result_Y_SH = vec4(0) + YCoCg.x * SH
-        const vec4 ysh = vec4(0.f) + YCoCg.x * sh;
-        const size_t idx = (size_t)py * (size_t)outYSH.w + px;
-        Texel<F_RGBA16F>::store(outYSH.ptr, idx, ysh);
-        Texel<F_RG16F>::store(outCoCg.ptr, idx, vec4(0.f + YCoCg.y, 0.f + YCoCg.z, 0.f, 0.f));
-    }
-}
-
-static int launchSdfDiffuseTrace(const PassCtx& c) {
-    if (int rc = c.needGlobal()) return rc;
-    if (int rc = c.needStorage(0, F_RGBA16F, "sdfDiffuseTrace imageOut_Y_SH")) return rc;
-    if (int rc = c.needStorage(1, F_RG16F, "sdfDiffuseTrace imageOut_CoCg")) return rc;
-    if (int rc = c.needSampled(2, F_D32, "sdfDiffuseTrace depthTexture")) return rc;
-    if (int rc = c.needSampled(3, F_RGBA8, "sdfDiffuseTrace normalTexture")) return rc;
-    if (int rc = c.needSampled(4, F_R11G11B10, "sdfDiffuseTrace skyLut")) return rc;
-    if (int rc = c.needSbuf(5, sizeof(LightBuffer), "sdfDiffuseTrace lightBuffer")) return rc;
-    if (int rc = c.needSbuf(6, 16 + sizeof(SDFInstance), "sdfDiffuseTrace sdfInstanceBuffer")) return rc;
-    if (int rc = c.needSbuf(7, sizeof(CulledInstancesPerTile), "sdfDiffuseTrace cameraCulledTileBuffer")) return rc;
-    if (int rc = c.needUbuf(8, 4, "sdfDiffuseTrace influenceRangeBuffer")) return rc;
-    if (int rc = c.needSbuf(9, sizeof(ShadowCascadeInfo), "sdfDiffuseTrace sunShadowInfo")) return rc;
-    if (int rc = c.needSampled(10, F_D16, "sdfDiffuseTrace shadowMap")) return rc;
-    if (!c.bindless || c.bindlessCount == 0) return c.fail(-4, "sdfDiffuseTrace: global texture array (set 2) is empty");
-    const bool strict = c.specBool(0, false);
-    const int cascade = c.specInt(1, 3);
-    if (cascade < 0 || cascade > 3) return c.fail(-1, "sdfDiffuseTrace: shadowCascadeIndex must be 0..3");
-    const ImgView& out = c.storage[0];
-    if (c.storage[1].w != out.w || c.storage[1].h != out.h) return c.fail(-4, "sdfDiffuseTrace: Y_SH and CoCg targets differ in size");
-    // workgroup rows [groupY0, groupsY) of the recorded dispatch; a block is 2x2 workgroups inside one culling tile
-    const int groupX0 = (int)c.base[0], groupsX = groupX0 + (int)c.dispatch[0], groupY0 = (int)c.base[1], groupsY = groupY0 + (int)c.dispatch[1];
-    if (groupsX <= groupX0 || groupsY <= groupY0) return 0;
-    if ((groupY0 & 1) || (groupX0 & 1)) return c.fail(-1, "sdfDiffuseTrace: dispatch base must be a multiple of 2 workgroups");
-    const uint32_t tileCapacity = (uint32_t)(c.sbuf[7].size / sizeof(CulledInstancesPerTile));
-    const uint32_t instanceCapacity = (uint32_t)((c.sbuf[6].size - 16u) / sizeof(SDFInstance));
-    const dim3 grid(divUp((unsigned)(groupsX - groupX0), 2u), divUp((unsigned)(groupsY - groupY0), 2u));
-#define PLR_TRACE_ARGS c.storage[0], c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], (const LightBuffer*)c.sbuf[5].ptr,                       \
-                       (const SdfInstanceBuffer*)c.sbuf[6].ptr, (const CulledInstancesPerTile*)c.sbuf[7].ptr, (const float*)c.ubuf[8].ptr,            \
-                       (const ShadowCascadeInfo*)c.sbuf[9].ptr, c.sampled[10], c.bindless, c.bindlessCount, c.global, cascade, groupsX, groupsY, groupY0, groupX0, \
-                       tileCapacity, instanceCapacity
-    if (strict) sdfDiffuseTraceKernel<true><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-    else sdfDiffuseTraceKernel<false><<<grid, 256, 0, c.stream>>>(PLR_TRACE_ARGS);
-#undef PLR_TRACE_ARGS
-    PLR_CHECK_LAUNCH(c);
-    return 0;
-}
-PLR_REGISTER_SHADER("sdfDiffuseTrace.comp", launchSdfDiffuseTrace);
+// (the ray march's device functions: device/sdf_march_device.h; the exact-set sdfDiffuseTrace.comp: kernels_exact/sdf_trace_exact.hip)
 
 
 // ------------------------------------------------------------------------------------------------

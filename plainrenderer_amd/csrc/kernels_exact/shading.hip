@@ -185,26 +185,6 @@ PLR_DI float calcShadow(vec3 pos, const ImgView& shadowMap, const float* lightMa
     return shadow / sampleCount;
 }
 
-// ---- the tap table of the fast shade (kernels_fast/pcf_taps.h): the statements of the loop above that depend on (noise, i) only, for the 256 values a
-// UNORM8 noise texel decodes to. Lives here because this file is compiled with the exact set's flags (no contraction, IEEE divide / sqrt).
-__global__ void pcfTapTableKernel(float2* __restrict__ table) {
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= kPcfNoiseValues * kPcfTaps) return;
-    const int i = e % kPcfTaps;
-    const float noise = decodeUnorm8((uint32_t)(e / kPcfTaps));
-    const float sampleCount = 12.f;
-    float d = ((float)i + 0.5f * noise) / sampleCount;
-    d = sqrtf(d);
-    const float angle = noise * 2.f * PLR_GLSL_PI + 2.f * PLR_GLSL_PI * (float)i / sampleCount;
-    float sa, ca;
-    det_sincosf(angle, &sa, &ca);
-    table[e] = make_float2(ca * d, sa * d);
-}
-hipError_t buildPcfTapTable(float2* table, hipStream_t stream) {
-    pcfTapTableKernel<<<(kPcfNoiseValues * kPcfTaps + 255) / 256, 256, 0, stream>>>(table);
-    return hipGetLastError();
-}
-
 PLR_DI float ReflectedEnergyAverage(float roughness) {
     const float smoothness = 1.f - sqrtf(roughness);
     float r = -0.0761947f - 0.383026f * smoothness;

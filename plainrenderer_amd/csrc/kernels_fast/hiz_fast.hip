@@ -11,10 +11,13 @@
 //   hizTailKernel: one 1024-thread block finishes levels 4.. out of LDS (level 4 of the 4K frame is 120 x 67 texels = 63 KB).
 //   hizTileTailKernel: six-level per-tile pyramids (band rendering, 8K): levels 4 and 5 of the launch's tile rows straight from level 3 (device/hiz_fast_device.h).
 // 55 MB of compulsory traffic in two launches.
+// Every other size (odd sides, sides that are no multiple of 8: 322 x 182 after a window resize) takes the any-size block bodies of device/hiz_any_size.h, launched
+// from here: the fast set covers every size itself, the exact set's launch path (kernels/hiz.hip) is reached through PLR_MATH_EXACT only.
 #include "../backend.h"
 #include "../device/shading_common.h"
 #include "../device/hiz_common.h"
 #include "../device/hiz_fast_device.h"
+#include "../device/hiz_any_size.h"
 
 namespace plr {
 namespace fasthiz {
@@ -27,6 +30,22 @@ __global__ __launch_bounds__(256) void hizTileTailKernel(TileTailParams p) { hiz
 __global__ __launch_bounds__(1024) void hizTailKernel(HizParams p, int first, int texelsA) {
     extern __shared__ float2 hizTailLds[];
     hizTailBlock<1024>(p, first, texelsA, hizTailLds);
+}
+
+__global__ __launch_bounds__(256) void hizAnySizeBaseKernel(HizParams p) {
+    extern __shared__ float2 hizAnySizeLds[];
+    hizBaseBlock(p, hizAnySizeLds);
+}
+
+__global__ __launch_bounds__(1024) void hizAnySizeTailKernel(HizParams p) {
+    __shared__ float2 bufA[32 * 32];
+    __shared__ float2 bufB[32 * 32];
+    hizTailAnyBlock(p, bufA, bufB);
+}
+
+static int launchAnySize(const PassCtx& c) {
+    return hizLaunchAnySize(c, [&](dim3 grid, size_t ldsBytes, const HizParams& p) { hizAnySizeBaseKernel<<<grid, 256, ldsBytes, c.stream>>>(p); },
+                            [&](const HizParams& p) { hizAnySizeTailKernel<<<1, 1024, 0, c.stream>>>(p); });
 }
 
 int prepare(const PassCtx& c, const PassCtx* down, Plan* out) {
@@ -117,7 +136,11 @@ int launchQuadBlocks(const PassCtx& c, const Plan& plan) {
 
 static int launchImpl(const PassCtx& c, const PassCtx* down) {
     Plan plan;
-    if (int rc = prepare(c, down, &plan)) return rc;
+    if (int rc = prepare(c, down, &plan)) {
+        // not a size / configuration of the register-quad kernels: the any-size path (alone - a fused downscale member is launched by its own fast kernel then)
+        if (rc == kUseGeneralKernel && !down) return launchAnySize(c);
+        return rc;
+    }
     // per device and per host thread's backend: set every time (a host call of a microsecond), not cached in a process-wide flag
     if (!plan.perTile && hipFuncSetAttribute((const void*)hizTailKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) return kUseGeneralKernel;
     if (int rc = launchQuadBlocks(c, plan)) return rc;

@@ -145,3 +145,34 @@ def test_reference_frontend_setup_compiles_against_the_shim():
         assert p.returncode == 0, p.stderr[-3000:]
     hdr = open(os.path.join(ROOT, "include", "plr_render_backend.hpp")).read()
     assert "void setGlobalDescriptorSetLayout(const ShaderLayout& layout)" in hdr and "struct ShaderLayout" in hdr
+
+
+def test_the_exact_kernel_set_is_a_library_of_its_own():
+    """the shipped library holds the benchmarked kernel set; the reference-order (PLR_MATH_EXACT) launch paths of the GI trace, the GI filters, the
+    deferred shade, TAA and bloom live in libplr_exact.so, which libplr.so loads on demand. No kernel of csrc/kernels_exact/ is defined in libplr.so, every one of
+    them is in libplr_exact.so, and that library resolves the backend's symbols against libplr.so (it carries no copy of the backend)."""
+    import glob
+    import subprocess
+    from plainrenderer_amd import backend, build
+    if not (os.path.exists(backend.LIB_PATH) and os.path.exists(build.EXACT_LIB_PATH)):
+        import __graft_entry__
+        __graft_entry__.build()
+    kernels = set()
+    for path in glob.glob(os.path.join(ROOT, "plainrenderer_amd", "csrc", "kernels_exact", "*.hip")):
+        kernels |= set(re.findall(r"__global__[^;{]*?\bvoid\s+([A-Za-z0-9_]+)\s*\(", open(path).read()))
+    assert len(kernels) >= 10, kernels
+
+    def defined(lib):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+        return out
+
+    main, exact = defined(backend.LIB_PATH), defined(build.EXACT_LIB_PATH)
+    for k in sorted(kernels):
+        assert k in exact, "%s is not in libplr_exact.so" % k
+        assert k not in main, "%s (an exact-set kernel) is defined in libplr.so" % k
+    assert "plr_setup" in main and "plr_setup" not in exact
+    needed = subprocess.run(["readelf", "-d", build.EXACT_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "libplr.so" in needed and "$ORIGIN" in needed
+    # it loads beside libplr.so without a GPU (its launchers register themselves with the backend's shader registry at load time)
+    C.CDLL(backend.LIB_PATH, mode=C.RTLD_GLOBAL)
+    C.CDLL(build.EXACT_LIB_PATH)

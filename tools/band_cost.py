@@ -35,6 +35,8 @@ def measure(rects, index):
         band = (y0, y1)
     if index is not None and "PLR_BAND_COST_GI_HALO" in os.environ:  # experiment hook: trace texels of GI exchanged with each neighbour (tools/config5_series.sh: the exact mode)
         kw.update(band_gi_halo=int(os.environ["PLR_BAND_COST_GI_HALO"]))
+    if index is not None and "PLR_BAND_COST_OVERLAP" in os.environ:  # experiment hook: band_overlap_exchange (plr_frame.h; 2 = edges first in one launch, the default)
+        kw.update(band_overlap_exchange=int(os.environ["PLR_BAND_COST_OVERLAP"]))
     fp = FramePipeline(be, w, h, shadow_map_res=2048, **kw)
     if index is not None:
         fp.attach_rccl_rects(None, index, len(rects), w, h, rects)  # loopback: the recording is the multi-GPU one, the local work of the exchange runs
