@@ -30,13 +30,13 @@ PLR_DI Tap tap1D(float u, int n, float h) {
 }
 
 template <bool LOWEST>
-__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase, int xBase) {
+PLR_DI void bloomUpsampleFastBlock(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase, int xBase, unsigned bx, unsigned by) {
     __shared__ float HA[ROWS_A][3][TW];
     __shared__ float HB[ROWS_B][3][TW];
     const int t = (int)threadIdx.x;
     const int lx = t & 63, lyBase = t >> 6;
-    const int x = xBase + (int)blockIdx.x * TW + lx; // columns [xBase, coverW) (tile rendering: PassCtx::colSpan; a multiple of 8)
-    const int y0 = yBase + (int)blockIdx.y * TH;
+    const int x = xBase + (int)bx * TW + lx; // columns [xBase, coverW) (tile rendering: PassCtx::colSpan; a multiple of 8)
+    const int y0 = yBase + (int)by * TH;
     const float tsx = 1.f / (float)source.w, tsy = 1.f / (float)source.h;
     const float sx = blurRadius * tsx, sy = blurRadius * tsy;
     const float invTW = 1.f / (float)target.w, invTH = 1.f / (float)target.h;
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, I
         ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
     }
 }
+template <bool LOWEST>
+__global__ __launch_bounds__(256) void bloomUpsampleFastKernel(ImgView source, ImgView previous, ImgView target, float blurRadius, int coverW, int coverH, int yBase, int xBase) { bloomUpsampleFastBlock<LOWEST>(source, previous, target, blurRadius, coverW, coverH, yBase, xBase, blockIdx.x, blockIdx.y); }
 
 // ---- 2x2 outputs per thread for the regular case (target = exactly twice the source and the previous mip; footprint within +-2)
 // An output pixel X = 2k + p samples the half-resolution images at k + 0.25 + 0.5 p (texel units), so the three tent taps and the
@@ -118,11 +120,11 @@ struct ParityWeights { float tent[2][5]; float box[2][3]; };
 // so the decode and the horizontal filter of a source row are done once for both. Every output accumulates its rows in the same order
 // whatever QY is: the result does not depend on it.
 template <int QY>
-__global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
-                                                               int yBase, int xBase) {
+PLR_DI void bloomUpsampleQuadBlock(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
+                                                               int yBase, int xBase, unsigned bx, unsigned by) {
     // thread -> QY vertically adjacent 2x2 output quads; a wave covers 128 x 2 QY outputs
-    const int k = (xBase >> 1) + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6)) * QY;
+    const int k = (xBase >> 1) + (int)(bx * 64u + (threadIdx.x & 63u));
+    const int m = (yBase >> 1) + (int)(by * 4u + (threadIdx.x >> 6)) * QY;
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
     float wt[2][5], wb[2][3]; // in vector registers: see the strip kernel below
@@ -202,6 +204,9 @@ __global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, I
             else orow[0] = p0;
         }
 }
+template <int QY>
+__global__ __launch_bounds__(256) void bloomUpsampleQuadKernel(ImgView source, ImgView previous, ImgView target, ParityWeights pw, bool lowest, int coverW, int coverH,
+                                                               int yBase, int xBase) { bloomUpsampleQuadBlock<QY>(source, previous, target, pw, lowest, coverW, coverH, yBase, xBase, blockIdx.x, blockIdx.y); }
 
 // ---- the same filter with the lanes of a wave holding neighbouring source columns (the quad kernel's 175 instructions per output are
 // mostly texel decodes: each lane decodes the 5 x 6 + 3 x 4 texels of its own footprint although its neighbours decode four fifths of the
@@ -323,7 +328,18 @@ static bool makeParityWeights(float blurRadius, ParityWeights* pw) {
     return true;
 }
 
-static int launch(const PassCtx& c) {
+// what one bloomUpsample execution launches: the kernel kind, its grid and its arguments (shared by the single launch and the chain launch below)
+enum UpKind { UP_NOTHING = 0, UP_STRIP, UP_QUAD, UP_GENERIC };
+constexpr int kQuadQY = 2; // 4: mip 0 35.0 vs 36.6 us, but the small mips lose more (fewer, longer waves)
+struct UpPlan {
+    ImgView source, previous, target;
+    ParityWeights pw;
+    float blurRadius;
+    int lowest, w, h, yBase, x0; // columns [x0, w), rows [yBase, h)
+    int kind;
+    unsigned gridX, gridY;
+};
+static int planUp(const PassCtx& c, UpPlan* out) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomUpsample target")) return rc;
     if (int rc = c.needSampled(2, F_R11G11B10, "bloomUpsample source")) return rc;
     const bool lowest = c.specBool(0, false);
@@ -335,42 +351,55 @@ static int launch(const PassCtx& c) {
     const ImgView& source = c.sampled[2];
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
     const PassCtx::ColSpan cs = c.colSpan(target.w);
-    const int w = cs.x1, x0 = cs.x0, h = rs.y1, yBase = rs.y0; // columns [x0, w), rows [yBase, h)
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, yBase = rs.y0;
+    UpPlan& p = *out;
+    p.source = source; p.previous = lowest ? source : c.sampled[1]; p.target = target;
+    p.blurRadius = blurRadius; p.lowest = lowest; p.w = w; p.h = h; p.yBase = yBase; p.x0 = x0;
+    p.kind = UP_NOTHING; p.gridX = p.gridY = 0;
     if (w <= x0 || h <= yBase) return 0;
     // the LDS row budget assumes the reference's configuration: source = next smaller mip (>= half the target height) and a
     // blur radius of at most 3 source texels; anything else takes the general (exact-order) kernel
     const bool fits = blurRadius >= 0.f && blurRadius <= 3.f && source.h * 2 + 1 >= target.h && (lowest || c.sampled[1].h * 2 + 1 >= target.h);
     if (!fits) return kUseGeneralKernel;
-    {
-        // regular case: one thread per 2x2 outputs with per-parity weight vectors (needs even row base so quads do not straddle the dispatch)
-        ParityWeights pw;
-        const bool regular = target.w == 2 * source.w && target.h == 2 * source.h && (lowest || (c.sampled[1].w == source.w && c.sampled[1].h == source.h)) &&
-                             source.w >= 5 && (yBase & 1) == 0 && (target.w & 1) == 0 && makeParityWeights(blurRadius, &pw);
-        if (regular) {
-            // the strip kernel needs enough waves to fill the SIMDs (a wave is 60 x 8 quads): mip 0 of a 4K frame has 4320, mip 1 1088
-            static const int stripMinWaves = std::getenv("PLR_BLOOM_STRIP_MIN_WAVES") ? atoi(std::getenv("PLR_BLOOM_STRIP_MIN_WAVES")) : 2048;
-            const unsigned stripWaves = divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols) * divUp((unsigned)divUp((unsigned)(h - yBase), 2u), (unsigned)kStripRows);
-            if ((int)stripWaves >= stripMinWaves) {
-                const dim3 sgrid(divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kStripRows));
-                if (lowest) bloomUpsampleStripKernel<true><<<sgrid, 256, 0, c.stream>>>(source, source, target, pw, w, h, yBase, x0);
-                else bloomUpsampleStripKernel<false><<<sgrid, 256, 0, c.stream>>>(source, c.sampled[1], target, pw, w, h, yBase, x0);
-                PLR_CHECK_LAUNCH(c);
-                return 0;
-            }
-            constexpr int QY = 2; // 4: mip 0 35.0 vs 36.6 us, but the small mips lose more (fewer, longer waves)
-            const dim3 qgrid(divUp((unsigned)divUp((unsigned)(w - x0), 2u), 64u), divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * QY));
-            bloomUpsampleQuadKernel<QY><<<qgrid, 256, 0, c.stream>>>(source, lowest ? source : c.sampled[1], target, pw, lowest, w, h, yBase, x0);
-            PLR_CHECK_LAUNCH(c);
+    // regular case: one thread per 2x2 outputs with per-parity weight vectors (needs even row base so quads do not straddle the dispatch)
+    const bool regular = target.w == 2 * source.w && target.h == 2 * source.h && (lowest || (c.sampled[1].w == source.w && c.sampled[1].h == source.h)) &&
+                         source.w >= 5 && (yBase & 1) == 0 && (target.w & 1) == 0 && makeParityWeights(blurRadius, &p.pw);
+    if (regular) {
+        // the strip kernel needs enough waves to fill the SIMDs (a wave is 60 x 8 quads): mip 0 of a 4K frame has 4320, mip 1 1088
+        static const int stripMinWaves = std::getenv("PLR_BLOOM_STRIP_MIN_WAVES") ? atoi(std::getenv("PLR_BLOOM_STRIP_MIN_WAVES")) : 2048;
+        const unsigned stripWaves = divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols) * divUp((unsigned)divUp((unsigned)(h - yBase), 2u), (unsigned)kStripRows);
+        if ((int)stripWaves >= stripMinWaves) {
+            p.kind = UP_STRIP;
+            p.gridX = divUp((unsigned)divUp((unsigned)(w - x0), 2u), (unsigned)kStripCols); p.gridY = divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kStripRows);
             return 0;
         }
+        p.kind = UP_QUAD;
+        p.gridX = divUp((unsigned)divUp((unsigned)(w - x0), 2u), 64u); p.gridY = divUp((unsigned)divUp((unsigned)(h - yBase), 2u), 4u * kQuadQY);
+        return 0;
     }
-    const dim3 grid(divUp((unsigned)(w - x0), (unsigned)TW), divUp((unsigned)(h - yBase), (unsigned)TH));
-    if (lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(source, source, target, blurRadius, w, h, yBase, x0);
-    else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(source, c.sampled[1], target, blurRadius, w, h, yBase, x0);
-    PLR_CHECK_LAUNCH(c);
+    p.kind = UP_GENERIC;
+    p.gridX = divUp((unsigned)(w - x0), (unsigned)TW); p.gridY = divUp((unsigned)(h - yBase), (unsigned)TH);
     return 0;
 }
 
+static int launch(const PassCtx& c) {
+    UpPlan p;
+    if (int rc = planUp(c, &p)) return rc;
+    const dim3 grid(p.gridX, p.gridY);
+    switch (p.kind) {
+        case UP_NOTHING: return 0;
+        case UP_STRIP:
+            if (p.lowest) bloomUpsampleStripKernel<true><<<grid, 256, 0, c.stream>>>(p.source, p.source, p.target, p.pw, p.w, p.h, p.yBase, p.x0);
+            else bloomUpsampleStripKernel<false><<<grid, 256, 0, c.stream>>>(p.source, p.previous, p.target, p.pw, p.w, p.h, p.yBase, p.x0);
+            break;
+        case UP_QUAD: bloomUpsampleQuadKernel<kQuadQY><<<grid, 256, 0, c.stream>>>(p.source, p.previous, p.target, p.pw, p.lowest != 0, p.w, p.h, p.yBase, p.x0); break;
+        default:
+            if (p.lowest) bloomUpsampleFastKernel<true><<<grid, 256, 0, c.stream>>>(p.source, p.source, p.target, p.blurRadius, p.w, p.h, p.yBase, p.x0);
+            else bloomUpsampleFastKernel<false><<<grid, 256, 0, c.stream>>>(p.source, p.previous, p.target, p.blurRadius, p.w, p.h, p.yBase, p.x0);
+    }
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------ bloomDownsample.comp:12-49
 // When the source is exactly twice the target in both dimensions, every one of the 13 bilinear taps lands on a texel centre or
@@ -381,9 +410,9 @@ static int launch(const PassCtx& c) {
 // One thread makes a 2x2 block of outputs from a 6x6 block of source texels (rows 4m-1 .. 4m+4, columns 4k-1 .. 4k+4): 9 texel decodes per
 // output instead of 16 - the pass is bound by VALU issue. Per source row and output column A = the two inner texels, B = the two outer
 // ones; a row is an inner row (centre += A, border += B) for one output row and an outer row (border += A + B) for the other.
-__global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) {
-    const int k = (xBase >> 1) + (int)(blockIdx.x * 64u + (threadIdx.x & 63u)); // xBase: a multiple of 8 (PassCtx::colSpan)
-    const int m = (yBase >> 1) + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+PLR_DI void bloomDownsampleFastBlock(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase, unsigned bx, unsigned by) {
+    const int k = (xBase >> 1) + (int)(bx * 64u + (threadIdx.x & 63u)); // xBase: a multiple of 8 (PassCtx::colSpan)
+    const int m = (yBase >> 1) + (int)(by * 4u + (threadIdx.x >> 6));
     const int X = 2 * k, Y = 2 * m;
     if (X >= coverW || Y >= coverH) return;
     const uint32_t* src = (const uint32_t*)source.ptr;
@@ -428,6 +457,7 @@ __global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source,
         else { orow[0] = p0; if (X + 1 < coverW) orow[1] = p1; }
     }
 }
+__global__ __launch_bounds__(256) void bloomDownsampleFastKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) { bloomDownsampleFastBlock(source, target, coverW, coverH, yBase, xBase, blockIdx.x, blockIdx.y); }
 
 // ---- any source / target size (the one odd level of a 4K chain, 135 -> 68 rows: 8 k outputs, a fraction of a wave per CU, so the launch is one
 // wave's latency). The exact kernel fetches a tap's texels only where the weight is not zero - thirteen taps of up to four dependent, branch-guarded
@@ -455,9 +485,9 @@ PLR_DI vec3 bloomTapValue(const TapFetch& f) {
     r = f.w11 != 0.f ? r + c11 : r;
     return r;
 }
-__global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) {
-    const int x = xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+PLR_DI void bloomDownsampleAnySizeBlock(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase, unsigned bx, unsigned by) {
+    const int x = xBase + (int)(bx * 64u + (threadIdx.x & 63u));
+    const int y = yBase + (int)(by * 4u + (threadIdx.x >> 6));
     if (x >= coverW || y >= coverH) return;
     // correctly rounded quotients / reciprocals (Newton step on v_rcp_f32), as the shader's divisions: the taps sit on 1/256 sub-texel weight steps
     auto quot = [](float a, float b) { const float r = __builtin_amdgcn_rcpf(b), q = a * r; return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q); };
@@ -475,29 +505,169 @@ __global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView sour
     for (int i = 0; i < 13; i++) color = color + bloomTapValue(f[i]) * wt[i];
     ((uint32_t*)target.ptr)[(size_t)y * (size_t)target.w + x] = packR11G11B10(color);
 }
-static int launchDownAnySize(const PassCtx& c, const ImgView& source, const ImgView& target) {
-    const PassCtx::RowSpan rs = c.rowSpan(target.h);
-    const PassCtx::ColSpan cs = c.colSpan(target.w);
-    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
-    if (w <= x0 || h <= y0) return 0;
-    if (source.w < 1 || source.h < 1 || source.w >= (1 << 12) || source.h >= (1 << 12)) return kUseGeneralKernel; // 24-bit texel index arithmetic
-    bloomDownsampleAnySizeKernel<<<dim3(divUp((unsigned)(w - x0), 64u), divUp((unsigned)(h - y0), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0, x0);
-    PLR_CHECK_LAUNCH(c);
-    return 0;
-}
-
-static int launchDown(const PassCtx& c) {
+__global__ __launch_bounds__(256) void bloomDownsampleAnySizeKernel(ImgView source, ImgView target, int coverW, int coverH, int yBase, int xBase) { bloomDownsampleAnySizeBlock(source, target, coverW, coverH, yBase, xBase, blockIdx.x, blockIdx.y); }
+enum DownKind { DOWN_NOTHING = 0, DOWN_REGULAR, DOWN_ANY_SIZE };
+struct DownPlan { ImgView source, target; int w, h, y0, x0, kind; unsigned gridX, gridY; };
+static int planDown(const PassCtx& c, DownPlan* out) {
     if (int rc = c.needStorage(0, F_R11G11B10, "bloomDownsample target")) return rc;
     if (int rc = c.needSampled(1, F_R11G11B10, "bloomDownsample source")) return rc;
     const ImgView& target = c.storage[0];
     const ImgView& source = c.sampled[1];
-    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) return launchDownAnySize(c, source, target); // odd sizes: taps are not on texel centres
     const PassCtx::RowSpan rs = c.rowSpan(target.h);
     const PassCtx::ColSpan cs = c.colSpan(target.w);
-    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
-    if (w <= x0 || h <= y0) return 0;
-    if (y0 & 1) return kUseGeneralKernel; // 2x2 output blocks start on even rows
-    bloomDownsampleFastKernel<<<dim3(divUp(divUp((unsigned)(w - x0), 2u), 64u), divUp(divUp((unsigned)(h - y0), 2u), 4u)), 256, 0, c.stream>>>(source, target, w, h, y0, x0);
+    DownPlan& p = *out;
+    p.source = source; p.target = target; p.w = cs.x1; p.x0 = cs.x0; p.h = rs.y1; p.y0 = rs.y0;
+    p.kind = DOWN_NOTHING; p.gridX = p.gridY = 0;
+    if (p.w <= p.x0 || p.h <= p.y0) return 0;
+    if (source.w != 2 * target.w || source.h != 2 * target.h || source.w < 6) { // odd sizes: taps are not on texel centres
+        if (source.w < 1 || source.h < 1 || source.w >= (1 << 12) || source.h >= (1 << 12)) return kUseGeneralKernel; // 24-bit texel index arithmetic
+        p.kind = DOWN_ANY_SIZE;
+        p.gridX = divUp((unsigned)(p.w - p.x0), 64u); p.gridY = divUp((unsigned)(p.h - p.y0), 4u);
+        return 0;
+    }
+    if (p.y0 & 1) return kUseGeneralKernel; // 2x2 output blocks start on even rows
+    p.kind = DOWN_REGULAR;
+    p.gridX = divUp(divUp((unsigned)(p.w - p.x0), 2u), 64u); p.gridY = divUp(divUp((unsigned)(p.h - p.y0), 2u), 4u);
+    return 0;
+}
+
+static int launchDown(const PassCtx& c) {
+    DownPlan p;
+    if (int rc = planDown(c, &p)) return rc;
+    if (p.kind == DOWN_NOTHING) return 0;
+    const dim3 grid(p.gridX, p.gridY);
+    if (p.kind == DOWN_ANY_SIZE) bloomDownsampleAnySizeKernel<<<grid, 256, 0, c.stream>>>(p.source, p.target, p.w, p.h, p.y0, p.x0);
+    else bloomDownsampleFastKernel<<<grid, 256, 0, c.stream>>>(p.source, p.target, p.w, p.h, p.y0, p.x0);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the small levels of the chain as ONE launch per direction
+// Bloom.cpp:56-143 records five downsamples and five upsamples. From the third level on a launch is a few hundred blocks or less and costs its launch boundary,
+// not its work (profiles/r04_tail_cost.txt: ten launches at the launch floor). With pass fusion a run of such executions is one PERSISTENT launch: its blocks draw
+// tickets - the tiles of level 0, then of level 1, ... - from one counter and run them with the very block bodies of the single launches above (same bits). A finished
+// tile is counted on its level's arrival word (release, agent scope); a block holding a tile of level l first waits until level l - 1 is complete (acquire).
+// Only blocks that are running hold tickets, so the waits end whatever else occupies the chip (this is the asynchronous tail: the next frame's front runs beside
+// it) and however many of the launch's blocks are resident; the last block out zeroes the words for the next launch.
+constexpr int kChainMaxLevels = 4;
+struct ChainLevel {
+    ImgView source, previous, target;
+    ParityWeights pw;
+    float blurRadius;
+    int lowest, w, h, yBase, x0, kind;
+    unsigned gridX, tiles;
+};
+struct ChainParams { ChainLevel level[kChainMaxLevels]; int n; uint32_t* counters; }; // counters: kChainMaxLevels arrival words, the ticket word, the exit word; zero between launches
+
+template <bool UP>
+__global__ __launch_bounds__(256) void bloomChainKernel(ChainParams p) {
+    __shared__ uint32_t ticketLds;
+    uint32_t* const next = p.counters + kChainMaxLevels;     // work tickets handed out
+    uint32_t* const exited = p.counters + kChainMaxLevels + 1; // blocks that found no ticket left
+    uint32_t total = 0;
+    for (int l = 0; l < p.n; l++) total += p.level[l].tiles;
+    for (;;) {
+        __syncthreads(); // (ticketLds of the previous round has been read by everybody)
+        if (threadIdx.x == 0) ticketLds = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        uint32_t t = ticketLds;
+        if (t >= total) break;
+        int l = 0;
+        while (t >= p.level[l].tiles) { t -= p.level[l].tiles; l++; }
+        const ChainLevel& L = p.level[l];
+        if (l > 0) {
+            // Tickets are handed out in order: every tile of level l - 1 is in the hands of a block that is RUNNING (it fetched the ticket), so this wait ends
+            // whatever else occupies the chip - a block that has not started yet holds no work.
+            if (threadIdx.x == 0) {
+                const uint32_t need = p.level[l - 1].tiles;
+                while (__hip_atomic_load(&p.counters[l - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the XCDs' L2s are not coherent with each other: see the level's texels, not stale lines
+        }
+        const unsigned bx = t % L.gridX, by = t / L.gridX;
+        if (UP) {
+            if (L.kind == UP_QUAD) bloomUpsampleQuadBlock<kQuadQY>(L.source, L.previous, L.target, L.pw, L.lowest != 0, L.w, L.h, L.yBase, L.x0, bx, by);
+            else if (L.lowest) bloomUpsampleFastBlock<true>(L.source, L.source, L.target, L.blurRadius, L.w, L.h, L.yBase, L.x0, bx, by);
+            else bloomUpsampleFastBlock<false>(L.source, L.previous, L.target, L.blurRadius, L.w, L.h, L.yBase, L.x0, bx, by);
+        } else {
+            if (L.kind == DOWN_ANY_SIZE) bloomDownsampleAnySizeBlock(L.source, L.target, L.w, L.h, L.yBase, L.x0, bx, by);
+            else bloomDownsampleFastBlock(L.source, L.target, L.w, L.h, L.yBase, L.x0, bx, by);
+        }
+        if (l + 1 < p.n) { // (nobody waits for the last level)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&p.counters[l], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t gone = __hip_atomic_fetch_add(exited, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1) // the last block out: every ticket is done and nobody will ask again - zero the words for the next launch
+            for (int i = 0; i < kChainMaxLevels + 2; i++) __hip_atomic_store(&p.counters[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// MEASURED AND NOT KEPT (profiles/r05_not_kept.txt (5)): OFF unless PLR_BLOOM_CHAIN=1. The 4K frame takes 0.857 ms with the two chain launches against 0.707 ms
+// with the ten single ones: the agent-scope release / acquire between levels is a write-back and an invalidate of a whole XCD's L2 (buffer_wbl2 / buffer_inv sc1) per
+// tile - that is what makes one XCD's texels visible to another inside a launch - and the L2 it flushes is the one the next frame's front is working in.
+// The largest level a chain takes (PLR_BLOOM_CHAIN_MAX_TILES): above this a level has enough blocks to be worth a launch of its own.
+static int chainMaxTiles() {
+    static const int v = std::getenv("PLR_BLOOM_CHAIN_MAX_TILES") ? atoi(std::getenv("PLR_BLOOM_CHAIN_MAX_TILES")) : 640;
+    static const bool on = std::getenv("PLR_BLOOM_CHAIN") && atoi(std::getenv("PLR_BLOOM_CHAIN")) != 0;
+    return on ? v : 0;
+}
+template <bool UP>
+static int chainGrid(const PassCtx& c, unsigned maxTiles, unsigned* grid) {
+    // blocks resident at once on an empty chip, from the runtime's occupancy calculator (the kernel's registers and LDS), halved for margin
+    // (asked once per host thread and device: a thread renders on one device, plr.h)
+    static thread_local int cachedDev = -1;
+    static thread_local unsigned cachedResident = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return kUseGeneralKernel;
+    if (dev != cachedDev) {
+        int perCu = 0, cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1 ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void*)bloomChainKernel<UP>, 256, 0) != hipSuccess || perCu < 1)
+            return kUseGeneralKernel;
+        cachedResident = (unsigned)cus * (unsigned)std::min(perCu, 2);
+        cachedDev = dev;
+    }
+    (void)c;
+    *grid = std::max(1u, std::min(maxTiles, cachedResident));
+    return 0;
+}
+template <bool UP>
+static int launchChain(const PassCtx* const* ctxs, size_t count) {
+    if (count < 2 || count > (size_t)kChainMaxLevels || chainMaxTiles() <= 0) return kUseGeneralKernel;
+    ChainParams cp{};
+    cp.n = (int)count;
+    unsigned maxTiles = 0;
+    for (size_t i = 0; i < count; i++) {
+        ChainLevel& L = cp.level[i];
+        if (UP) {
+            UpPlan u;
+            if (int rc = planUp(*ctxs[i], &u)) return rc < 0 ? kUseGeneralKernel : rc; // (a broken execution reports its error from its own launch)
+            if (u.kind != UP_QUAD && u.kind != UP_GENERIC) return kUseGeneralKernel;
+            L.source = u.source; L.previous = u.previous; L.target = u.target; L.pw = u.pw; L.blurRadius = u.blurRadius; L.lowest = u.lowest;
+            L.w = u.w; L.h = u.h; L.yBase = u.yBase; L.x0 = u.x0; L.kind = u.kind; L.gridX = u.gridX; L.tiles = u.gridX * u.gridY;
+        } else {
+            DownPlan d;
+            if (int rc = planDown(*ctxs[i], &d)) return rc < 0 ? kUseGeneralKernel : rc;
+            if (d.kind == DOWN_NOTHING) return kUseGeneralKernel;
+            L.source = d.source; L.previous = d.source; L.target = d.target; L.blurRadius = 0.f; L.lowest = 0;
+            L.w = d.w; L.h = d.h; L.yBase = d.y0; L.x0 = d.x0; L.kind = d.kind; L.gridX = d.gridX; L.tiles = d.gridX * d.gridY;
+        }
+        if (L.tiles == 0 || (int)L.tiles > chainMaxTiles()) return kUseGeneralKernel;
+        // a chain: every level reads what the level before it wrote (anything else has no order to keep and is launched pass by pass)
+        if (i > 0 && L.source.ptr != cp.level[i - 1].target.ptr) return kUseGeneralKernel;
+        maxTiles = std::max(maxTiles, L.tiles);
+    }
+    const PassCtx& c = *ctxs[0];
+    cp.counters = (uint32_t*)c.scratch(64); // zeroed when allocated, zeroed again by the last block of every launch
+    if (!cp.counters) return kUseGeneralKernel;
+    unsigned grid = 0;
+    if (int rc = chainGrid<UP>(c, maxTiles, &grid)) return rc;
+    bloomChainKernel<UP><<<grid, 256, 0, c.stream>>>(cp);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -508,4 +678,19 @@ static int fastbloom_up_launch(const PassCtx& c) { return fastbloom::launch(c); 
 PLR_REGISTER_SHADER_FAST("bloomUpsample.comp", fastbloom_up_launch);
 static int fastbloom_down_launch(const PassCtx& c) { return fastbloom::launchDown(c); }
 PLR_REGISTER_SHADER_FAST("bloomDownsample.comp", fastbloom_down_launch);
+// runs of small levels as one persistent launch (the longest run first; a run that starts on a level too large declines and the next execution starts one)
+static int fastbloom_down_chain(const PassCtx* const* ctxs, size_t count) { return fastbloom::launchChain<false>(ctxs, count); }
+static int fastbloom_up_chain(const PassCtx* const* ctxs, size_t count) { return fastbloom::launchChain<true>(ctxs, count); }
+static int fastbloom_down_chain4(const PassCtx* const* ctxs, size_t count) { return fastbloom_down_chain(ctxs, count); }
+static int fastbloom_down_chain3(const PassCtx* const* ctxs, size_t count) { return fastbloom_down_chain(ctxs, count); }
+static int fastbloom_down_chain2(const PassCtx* const* ctxs, size_t count) { return fastbloom_down_chain(ctxs, count); }
+static int fastbloom_up_chain4(const PassCtx* const* ctxs, size_t count) { return fastbloom_up_chain(ctxs, count); }
+static int fastbloom_up_chain3(const PassCtx* const* ctxs, size_t count) { return fastbloom_up_chain(ctxs, count); }
+static int fastbloom_up_chain2(const PassCtx* const* ctxs, size_t count) { return fastbloom_up_chain(ctxs, count); }
+PLR_REGISTER_FUSION("bloomDownsample x4 (persistent chain)", fastbloom_down_chain4, "bloomDownsample.comp", "bloomDownsample.comp", "bloomDownsample.comp", "bloomDownsample.comp");
+PLR_REGISTER_FUSION("bloomDownsample x3 (persistent chain)", fastbloom_down_chain3, "bloomDownsample.comp", "bloomDownsample.comp", "bloomDownsample.comp");
+PLR_REGISTER_FUSION("bloomDownsample x2 (persistent chain)", fastbloom_down_chain2, "bloomDownsample.comp", "bloomDownsample.comp");
+PLR_REGISTER_FUSION("bloomUpsample x4 (persistent chain)", fastbloom_up_chain4, "bloomUpsample.comp", "bloomUpsample.comp", "bloomUpsample.comp", "bloomUpsample.comp");
+PLR_REGISTER_FUSION("bloomUpsample x3 (persistent chain)", fastbloom_up_chain3, "bloomUpsample.comp", "bloomUpsample.comp", "bloomUpsample.comp");
+PLR_REGISTER_FUSION("bloomUpsample x2 (persistent chain)", fastbloom_up_chain2, "bloomUpsample.comp", "bloomUpsample.comp");
 } // namespace plr

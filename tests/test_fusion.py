@@ -3,6 +3,8 @@ launches. The boundary and the results are unchanged: every frame of a fused run
 the fused upscale + deferred shade keeps the upscaled GI texels in registers when no other pass reads them, and the temporal GI filter writes only the
 packed texels the spatial filter behind it gathers: those images are then not written, a download of them fails loudly, and everything else still equals
 the unfused run."""
+import os
+
 import numpy as np
 import pytest
 
@@ -246,3 +248,15 @@ def test_gpu_a_frame_recorded_differently_cannot_read_an_image_the_last_frame_le
         fp.destroy()
         backend.setPassFusion(2)
         backend.setMathMode(False)
+
+
+@pytest.mark.gpu
+def test_gpu_the_persistent_bloom_chain_changes_no_bit():
+    """kernels_fast/bloom_fast.hip bloomChainKernel (measured and not kept: off unless PLR_BLOOM_CHAIN=1): runs of small bloom levels as one persistent launch per
+    direction, the levels ordered by arrival counters. The fused-vs-unfused byte comparisons of this file, run in a process that turns it on."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PLR_BLOOM_CHAIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not persistent_bloom_chain"], env=env, capture_output=True, text=True,
+                       timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
