@@ -8,8 +8,8 @@ bloom x11, tonemap) on synthetic inputs that are resident in HBM before the time
   python bench.py --gpus N --steps K --warmup W
 
 N > 1: ONE frame of N x the 4K pixel count (7680 x 1080*N; N = 4 is the 7680x4320 frame of BASELINE config 5), partitioned into N
-rectangles, one rank per GPU - 2 x N/2 SCREEN TILES (N = 4: config 5's 2 x 2; --partition tiles, the default for even N) or N row bands
-(--partition bands) - halos exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
+rectangles, one rank per GPU - N row bands (the default: the faster partition in the single-GPU replay of both, profiles/r05_tile_vs_band.txt) or 2 x N/2 SCREEN
+TILES (--partition tiles; N = 4: config 5's 2 x 2) - halos exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
 histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels), and the JSON line also carries the STRONG-scaling figure the
 target is written in: the time of the same frame unpartitioned on one GPU (measured on rank 0 in the same run) over the N-GPU time. The rectangles'
 sizes are balanced before the timed region from measured render times (two calibration rounds, `band_partition` in the JSON line; --no-balance keeps equal sizes). When WORLD_SIZE is not set, `--gpus N` spawns the N
@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal partition instead of balancing the rectangles' sizes from measured times")
     ap.add_argument("--partition", choices=["auto", "tiles", "bands"], default="auto", help="N > 1: screen tiles (2 x N/2 grid; N = 4: BASELINE config 5's 2 x 2) or row bands; "
-                    "auto = tiles for even N, bands otherwise")
+                    "auto = row bands, the faster of the two in the single-GPU replay (profiles/r05_tile_vs_band.txt)")
     ap.add_argument("--exact-partition", action="store_true", help="N > 1: exchange every GI texel with every rank (band_gi_halo = PLRF_HALO_WHOLE_IMAGE): the partitioned frame equals the "
                     "unpartitioned one bit for bit (tests/test_config5_8k.py); default: a halo of 64 trace rows per 2160 frame rows, whose deviation is stated in profiles/r05_config5_series.txt")
     ap.add_argument("--no-strong-scaling", action="store_true", help="N > 1: skip the single-GPU run of the same frame (rank 0) the strong-scaling figure is taken against")
@@ -287,7 +287,9 @@ def main():
     from plainrenderer_amd.frame import FramePipeline
 
     band_partition = {"bounds": None, "calibration": []}
-    use_tiles = world > 1 and world % 2 == 0 and args.partition in ("auto", "tiles")
+    # auto = the measured winner of the single-GPU replay of both partitions from one build (profiles/r05_tile_vs_band.txt: slowest of four row bands 0.88 ms, slowest of
+    # 2 x 2 tiles 0.91 ms of the 2.72 ms 8K frame): row bands. Config 5's own 2 x 2 tiles: --partition tiles. Neither has been measured on more than one GPU.
+    use_tiles = world > 1 and world % 2 == 0 and args.partition == "tiles"
     if args.partition == "tiles" and world > 1 and world % 2:
         raise SystemExit("bench.py: --partition tiles needs an even number of GPUs (2 x N/2 grid)")
     grid_x, grid_y = (2, world // 2) if use_tiles else (1, world)

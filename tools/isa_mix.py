@@ -1,27 +1,29 @@
-"""Instruction mix of the big kernels of the current build, by issue class, priced with the measured rate table and set beside the
-hardware's instruction counters.
+"""Instruction mix of the big kernels of the current build, priced with the round-5 issue model and set beside the hardware's counters.
 
     python tools/isa_mix.py [profiles/<tag>_sq_counters.csv] > profiles/<tag>_isa_mix.txt
 
-Static: the gfx950 code objects inside plainrenderer_amd/csrc/_obj/*.o (after plainrenderer_amd.build.build()) are disassembled and every
-VALU instruction of a kernel is put into one class of the rate table tools/valu_rates.hip measured on MI355X (profiles/r04_valu_rates.txt,
-cycles per wave64 instruction per SIMD, nominal 2.4 GHz):
-    full      2.4 - 3.0   v_fma / fmac / mul / add / sub _f32 (also with neg / abs modifiers, inline constants, literals), v_add / sub _u32,
-                          v_and / or / xor / not _b32, v_mov_b32, v_lshrrev_b32, v_ashrrev_i32, v_mul_f16
-    half      4.1 - 4.7   min / max / med3, every conversion, floor / fract / trunc / rndne, compares, v_cndmask, integer multiplies, three-operand
-                          integer ops, bit-field ops, left shifts, v_lshl_add_u64, v_fma_mix_f32, packed ops, v_readfirstlane
-    sgpr      4.1         a full-rate opcode with an SGPR / VCC source operand
-    dpp       4.2 - 4.4   any DPP-modified instruction
-    quarter   8.1 - 8.6   v_rcp / rsq / sqrt / exp / log / sin / cos _f32, v_fma_f16, v_fma_mixlo_f16, v_permlane32_swap
-Dynamic: SQ_INSTS_VALU / SQ_WAVES of the same build (rocprofv3 --pmc, tools/profile_round.sh) = VALU instructions a wave really issues; the
-static mix is scaled to it (a kernel's rare paths - sky pixels, off-screen discs, out-of-range encoder - are in the static count only).
+Static: the gfx950 code objects inside plainrenderer_amd/csrc/_obj/*.o (after plainrenderer_amd.build.build()) are disassembled and classified.
+The model (profiles/r05_valu_rates.txt, measured with tools/valu_issue_probe.hip in SHADER cycles - no clock assumption):
+    every VALU instruction            2.2 cycles of its wave's SIMD issue (the "half-rate" class - min / max / med3, conversions, compares, v_cndmask, shifts, bit-field
+                                      ops - is a second issue resource that overlaps with full-rate work: it only bounds a stream through 4.4 x its own count)
+    surcharges beyond the 2.2         transcendental (v_rcp / rsq / sqrt / exp / log / sin / cos) + 9.8 (10 - 14 cycles each among other work), v_fma_mix* / v_dot2* / v_pk_* + 2.1,
+                                      DPP + 2.9, v_mul_lo / hi / mad_u64 + 1.8, an SGPR / VCC source on a full-rate opcode + 0.9, v_readfirstlane + 4.4
+    every scalar instruction          3.0 cycles (s_waitcnt / s_nop: 0) - the CU's scalar unit serves four SIMDs
+Dynamic: SQ_INSTS_VALU, SQ_INSTS_SALU / SQ_WAVES of the same build (rocprofv3 --pmc, tools/profile_round.sh) = what a wave really issues; the static shares are
+scaled to them. Measured = GRBM_GUI_ACTIVE / 8 XCDs: cycles the kernel occupies the chip. estimate / measured says how much of the kernel's time its own instruction
+stream explains; the rest is waiting (memory, barriers, launch ramp).
 """
 import glob, os, re, subprocess, sys, tempfile
 from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-RATE = {"full": 2.8, "half": 4.3, "sgpr": 4.1, "dpp": 4.3, "quarter": 8.3}
+BASE = 2.2  # cycles per VALU instruction of any class
+SURCHARGE = {"full": 0.0, "half": 0.0, "sgpr": 0.9, "dpp": 2.9, "mix": 2.1, "mul": 1.8, "lane": 4.4, "quarter": 9.8}
+HALF_BOUND = 4.4  # a stream cannot issue its half-rate class faster than this
+SALU_COST = 3.0
+MIX = re.compile(r"v_fma_mix|v_dot2|v_pk_")
+MUL = re.compile(r"v_mul_lo_|v_mul_hi_|v_mad_u64|v_mad_i64")
 FULL = re.compile(r"v_(fma|fmac|mul|add|sub|subrev|mac|mad|fmaak|fmamk|mul_legacy)_f32|v_(add|sub|subrev)_u32|v_(and|or|xor|not)_b32|v_mov_b32|v_lshrrev_b32|v_ashrrev_i32|v_mul_f16")
 QUARTER = re.compile(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)_|v_rcp_iflag|v_fma_f16|v_fma_mixlo|v_fma_mixhi|v_permlane32_swap")
 SGPR = re.compile(r"[ ,]s\d+\b|[ ,]s\[|[ ,]vcc|[ ,]exec")
@@ -44,6 +46,12 @@ def classify(line):
     args = args.split("//")[0]
     if QUARTER.match(op):
         return "quarter"
+    if MIX.match(op):
+        return "mix"
+    if MUL.match(op):
+        return "mul"
+    if op.startswith("v_readfirstlane") or op.startswith("v_readlane"):
+        return "lane"
     if "dpp" in op or "quad_perm" in args or "row_" in args or "wave_" in args:
         return "dpp"
     if FULL.match(op) and not op.startswith(("v_cmp", "v_cndmask")):
@@ -106,8 +114,10 @@ def main():
     import bench
     print("# instruction mix by issue class of the build with kernel source digest %s (tools/isa_mix.py)" % bench.kernel_source_digest())
     print("# counters: %s (digest %s)" % (os.path.basename(counters_path) if counters_path else "none", digest))
-    print("# rates (cycles per wave64 instruction per SIMD, profiles/r04_valu_rates.txt): " + ", ".join("%s %.1f" % kv for kv in RATE.items()))
+    print("# model (profiles/r05_valu_rates.txt, shader cycles): %.1f per VALU instruction + surcharges %s; half-rate class bound %.1f x its count; %.1f per scalar instruction "
+          "(s_waitcnt / s_nop free)" % (BASE, ", ".join("%s +%.1f" % kv for kv in SURCHARGE.items() if kv[1]), HALF_BOUND, SALU_COST))
     cache = {}
+    order = ("full", "half", "sgpr", "dpp", "mix", "mul", "lane", "quarter")
     for obj_sub, want, label in KERNELS:
         if obj_sub not in cache:
             cache[obj_sub] = disassemble(obj_sub)
@@ -117,16 +127,17 @@ def main():
             continue
         c = Counter(filter(None, (classify(l) for l in ins)))
         static_valu = sum(c.values())
-        static_cycles = sum(RATE[k] * v for k, v in c.items())
         vmem = sum(1 for l in ins if l.startswith(("global_", "buffer_", "flat_", "scratch_")))
         lds = sum(1 for l in ins if l.startswith("ds_"))
         salu = sum(1 for l in ins if l.startswith("s_"))
+        salu_priced = sum(1 for l in ins if l.startswith("s_") and not l.startswith(("s_waitcnt", "s_nop", "s_endpgm", "s_code_end")))
+        static_valu_cycles = BASE * static_valu + sum(SURCHARGE[k] * v for k, v in c.items())
         print("\n%s\n  %s" % (label, want))
         print("  registers: vgpr %(vgpr_count)d sgpr %(sgpr_count)d scratch %(private_segment_fixed_size)d B lds %(group_segment_fixed_size)d B" % regs)
-        print("  static: %d instructions: VALU %d = full %d + half %d + sgpr-sourced %d + dpp %d + quarter %d; VMEM %d, LDS %d, SALU %d" % (
-            len(ins), static_valu, c["full"], c["half"], c["sgpr"], c["dpp"], c["quarter"], vmem, lds, salu))
-        print("  static class shares: " + ", ".join("%s %.1f %%" % (k, 100.0 * c[k] / static_valu) for k in ("full", "half", "sgpr", "dpp", "quarter")) +
-              "; priced: %.0f cycles = %.2f cycles per VALU instruction" % (static_cycles, static_cycles / static_valu))
+        print("  static: %d instructions: VALU %d (%s); VMEM %d, LDS %d, SALU %d of which %d priced" % (
+            len(ins), static_valu, ", ".join("%s %d" % (k, c[k]) for k in order if c[k]), vmem, lds, salu, salu_priced))
+        print("  static: VALU stream %.0f cycles = %.2f per VALU instruction; half-rate class %.1f %% of the VALU instructions (bounds the stream only above 50 %%); scalar %.0f cycles" % (
+            static_valu_cycles, static_valu_cycles / static_valu, 100.0 * c["half"] / static_valu, SALU_COST * salu_priced))
         key = [k for k in counters if want.replace(", ", "; ") in k]
         if key:
             d = counters[key[0]]
@@ -134,24 +145,24 @@ def main():
             if waves and valu:
                 per_wave = valu / waves
                 scale = per_wave / static_valu
-                est_cycles = static_cycles * scale  # per wave
+                salu_dyn = d.get("SQ_INSTS_SALU", 0.0) / waves
+                salu_dyn_priced = salu_dyn * (salu_priced / max(salu, 1))
+                valu_cycles = max(static_valu_cycles * scale, HALF_BOUND * c["half"] * scale)
+                est_cycles = valu_cycles + SALU_COST * salu_dyn_priced  # per wave
                 waves_per_simd = waves / 1024.0
-                t_est = est_cycles * waves_per_simd / 2.4e9 * 1e6
-                t_floor = per_wave * 2.0 * waves_per_simd / 2.4e9 * 1e6
-                line = "  dynamic: SQ_INSTS_VALU %.0f / SQ_WAVES %.0f = %.1f VALU per wave (%.0f %% of the static count)" % (valu, waves, per_wave, 100 * scale)
-                print(line)
-                print("  per wave by class (static shares x dynamic count): " + ", ".join("%s %.0f" % (k, c[k] * scale) for k in ("full", "half", "sgpr", "dpp", "quarter")))
-                print("  issue estimate: %.0f cycles per wave x %.1f waves per SIMD / 2.4 GHz = %.1f us; at the 2-cycle peak rate the same instructions take %.1f us" % (
-                    est_cycles, waves_per_simd, t_est, t_floor))
+                print("  dynamic: SQ_INSTS_VALU / SQ_WAVES = %.1f VALU per wave (%.0f %% of the static count), SQ_INSTS_SALU / SQ_WAVES = %.1f (%.0f priced)" % (per_wave, 100 * scale, salu_dyn, salu_dyn_priced))
+                print("  per wave by class (static shares x dynamic count): " + ", ".join("%s %.0f" % (k, c[k] * scale) for k in order if c[k]))
+                print("  issue estimate: %.0f (VALU) + %.0f (scalar) = %.0f cycles per wave x %.1f waves per SIMD = %.0f cycles; at 2 cycles per VALU instruction and nothing else: %.0f" % (
+                    valu_cycles, SALU_COST * salu_dyn_priced, est_cycles, waves_per_simd, est_cycles * waves_per_simd, per_wave * 2.0 * waves_per_simd))
                 if d.get("GRBM_GUI_ACTIVE"):
-                    t_meas = d["GRBM_GUI_ACTIVE"] / 8.0 / 2.4e9 * 1e6
-                    print("  measured (GRBM_GUI_ACTIVE / 8 XCDs at 2.4 GHz, kernels serialised by the profiler): %.1f us -> issue estimate / measured = %.2f, VALU roofline fraction %.2f" % (
-                        t_meas, t_est / t_meas, t_floor / t_meas))
+                    meas = d["GRBM_GUI_ACTIVE"] / 8.0
+                    print("  measured: GRBM_GUI_ACTIVE / 8 XCDs = %.0f cycles (kernels serialised by the profiler; %.1f us at 2.4 GHz) -> issue estimate / measured = %.2f (VALU stream alone %.2f), "
+                          "VALU roofline fraction (2 cycles per instruction) %.2f" % (meas, meas / 2400.0, est_cycles * waves_per_simd / meas, valu_cycles * waves_per_simd / meas, per_wave * 2.0 * waves_per_simd / meas))
                 if d.get("TCP_TOTAL_CACHE_ACCESSES_sum") and d.get("GRBM_GUI_ACTIVE"):
                     acc = d["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256.0
                     print("  L1: %.0f cache-line accesses per CU = %.2f per cycle; VMEM reads per wave %.1f" % (acc, acc / (d["GRBM_GUI_ACTIVE"] / 8.0), d.get("SQ_INSTS_VMEM_RD", 0) / waves))
-        top = Counter(l.split()[0] for l in ins if classify(l) in ("half", "sgpr", "dpp", "quarter")).most_common(12)
-        print("  slow-class opcodes: " + ", ".join("%s %d" % kv for kv in top))
+        top = Counter(l.split()[0] for l in ins if classify(l) in ("sgpr", "dpp", "mix", "mul", "lane", "quarter")).most_common(12)
+        print("  opcodes that carry a surcharge: " + ", ".join("%s %d" % kv for kv in top))
 
 
 if __name__ == "__main__":

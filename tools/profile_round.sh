@@ -33,12 +33,6 @@ python $REPO/bench.py --width 7680 --height 4320 --steps 150 --no-cpu-baseline >
 # the input producers recorded as compute passes (not the headline workload): fast set and exact set, per-pass times
 python $REPO/bench.py --producers --steps 100 --warmup 10 --no-cpu-baseline --pass-table 2> $OUT/pass_table_producers.txt > $OUT/bench_producers.json
 python $REPO/bench.py --producers --exact --steps 30 --warmup 5 --no-cpu-baseline --pass-table 2> $OUT/pass_table_producers_exact.txt > /dev/null
-# 2x2 tiles against row bands at 8K on four GPUs, by proxy (the pipeline partitions by rows only): a stand-alone frame of the size of one
-# partition plus a 256-pixel GI halo on every side that has a neighbour - interior row band 7680 x (1080 + 512) -> 1600 rows (the fast pyramid of a frame
-# beyond 11 levels wants a height that is a multiple of 16; 1592 runs the general pyramid kernel and bench.py refuses the line), corner tile (3840 + 256) x (2160 + 256)
-{ echo "# stand-alone frames of the partition's size + halo (proxy, see DESIGN section 6): ms per frame";
-  for WH in "7680 1600" "4096 2416" "7680 1088" "3840 2160"; do set -- $WH;
-    python $REPO/bench.py --width $1 --height $2 --steps 150 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; t=sys.stdin.read(); print('$1 x $2', json.loads(t)['ms_per_step'] if t.strip() else 'no bench line (see bench.py: general-kernel fallback or error)')"; done; } > $OUT/tile_vs_band_proxy.txt
 rm -rf $OUT/kt
 # ---- parity evidence FROM THIS BUILD: the full-size suite at the benchmarked size, config 5 at 8K, the band cost table; every
 # report carries the kernel source digest the PMC summary was stamped with, and the run fails if the sources changed in between
@@ -46,10 +40,16 @@ DIGEST=$(cat $OUT/source_digest.txt)
 cd $REPO
 { echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_parity_fullsize.py -m gpu -s   (3840x2160, 256 x 64^3: bench.py's scene)";
   python -m pytest tests/test_parity_fullsize.py -m gpu -q -s 2>&1 | grep -E "^\.?PARITY|passed|failed" | sed 's/^\.//'; } > $OUT/parity_4k.txt
-{ echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_config5_8k.py -m gpu -s   (7680x4320 in 4 bands on one GPU vs the unpartitioned frame and the oracle)";
-  python -m pytest tests/test_config5_8k.py -m gpu -q -s 2>&1 | grep -E "CONFIG5|passed|failed"; } > $OUT/config5_8k.txt
-{ echo "# kernel source digest: $DIGEST"; python tools/band_cost.py 4 --passes --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/band_cost.txt
+{ echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_config5_8k.py -m gpu -s   (7680x4320 as 2 x 2 tiles and as 4 row bands on one GPU, exact mode and default halos, 64 frames, vs the unpartitioned frame and the oracle)";
+  python -m pytest tests/test_config5_8k.py -m gpu -q -s 2>&1 | grep -E "CONFIG5 .*(summary|partition:|oracle|halos)|passed|failed" | sed 's/^\.*//'; } > $OUT/config5_8k.txt
+# tiles against bands, measured: the single-GPU replay of both partitions of the 8K frame from this build (loopback exchange, edges-first producers, balanced), then
+# the bands without the edges-first machinery (what the overlap costs when there is no link time to hide)
+{ echo "# kernel source digest: $DIGEST"; echo "# ---- python tools/band_cost.py 4 --tiles 2x2 --passes --balance"; python tools/band_cost.py 4 --tiles 2x2 --passes --balance 2>&1 | grep -v amdgpu.ids;
+  echo "# ---- python tools/band_cost.py 4 --passes --balance"; python tools/band_cost.py 4 --passes --balance 2>&1 | grep -v amdgpu.ids;
+  echo "# ---- PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance   (band_overlap_exchange 0: producers not split, exchanges whole)"; PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/tile_vs_band.txt
+bash tools/config5_series.sh 256 > $OUT/config5_series.txt 2>&1
+{ echo "# kernel source digest: $DIGEST"; python tools/tail_cost.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tail_cost.txt
 NOW=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())")
 if [ "$NOW" != "$DIGEST" ]; then echo "kernel sources changed during the profile run ($DIGEST -> $NOW): evidence is inconsistent" >&2; exit 1; fi
-grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt && { echo "parity suite failed" >&2; exit 1; }
+grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt $OUT/config5_series.txt && { echo "parity suite failed" >&2; exit 1; }
 ls -la $OUT
