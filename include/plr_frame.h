@@ -160,7 +160,8 @@ int plrf_rccl_self_test_rect(void* exchange, void* device_ptr, uint32_t pitch_by
  * hangs and says nothing. Every BEGIN arms an entry {rank, exchange id, phase, completion query, time}; entries are checked at every later exchange
  * callback (the frame then fails with the message) and by a background thread every 50 ms, which prints the message to stderr and - unless
  * PLRF_EXCHANGE_WATCHDOG_ABORT=0 - aborts the process: a hung collective cannot be cancelled, only reported. Deadline: PLRF_EXCHANGE_WATCHDOG_MS (default 2000,
- * 0 = off). The functions below expose the mechanism with a caller-supplied completion query, so it can be tested without a GPU. */
+ * 0 = off); the first 64 exchanges of a communicator (about ten frames: RCCL sets up its point-to-point connections inside the first group with each peer, and ranks
+ * leave their set-up at different times) get PLRF_EXCHANGE_WATCHDOG_FIRST_MS (default 60000) instead. The functions below expose the mechanism with a caller-supplied completion query, so it can be tested without a GPU. */
 typedef int (*plrf_watchdog_query)(void* user); /* 0 = still running, 1 = complete */
 int plrf_watchdog_create(uint32_t deadline_ms, void** out_watchdog);
 int plrf_watchdog_destroy(void* watchdog);

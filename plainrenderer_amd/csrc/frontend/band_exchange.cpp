@@ -182,10 +182,13 @@ __global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
 
 // ---------------------------------------------------------------- watchdog
 struct Watchdog {
-    struct Entry { int rank, id, phase; plrf_watchdog_query query; void* user; std::chrono::steady_clock::time_point armed; };
+    struct Entry { int rank, id, phase; plrf_watchdog_query query; void* user; std::chrono::steady_clock::time_point armed; uint32_t deadlineMs; };
     std::mutex m;
     std::vector<Entry> entries;
     uint32_t deadlineMs = 2000;
+    // the first exchanges of a communicator are not steady state: RCCL sets up its point-to-point connections inside the first group with each peer (hundreds of
+    // milliseconds to seconds on a node), and ranks leave their set-up at different times. The first graceArms arms (~ the first ten frames) get graceMs instead.
+    uint32_t graceMs = 60000, graceArms = 64, arms = 0;
     static const char* phaseName(int phase) { return phase == PLRF_EXCHANGE_BEGIN ? "BEGIN (transfers posted, completion pending)" : (phase == PLRF_EXCHANGE_END ? "END" : "in line on the launch stream"); }
     static const char* idName(int id) {
         static const char* names[PLRF_EXCHANGE_COUNT] = {"histogram all-reduce", "traced GI halo", "temporally filtered GI halo", "GI history halo", "resolved colour + TAA history halo", "depth range all-reduce"};
@@ -194,8 +197,10 @@ struct Watchdog {
     void arm(int rank, int id, int phase, plrf_watchdog_query query, void* user) {
         if (!deadlineMs) return;
         std::lock_guard<std::mutex> lock(m);
-        for (Entry& e : entries) if (e.id == id && e.query == query && e.user == user) { e.phase = phase; e.armed = std::chrono::steady_clock::now(); return; } // re-armed every frame
-        entries.push_back({rank, id, phase, query, user, std::chrono::steady_clock::now()});
+        const uint32_t limit = arms < graceArms ? std::max(deadlineMs, graceMs) : deadlineMs;
+        arms++;
+        for (Entry& e : entries) if (e.id == id && e.query == query && e.user == user) { e.phase = phase; e.armed = std::chrono::steady_clock::now(); e.deadlineMs = limit; return; } // re-armed every frame
+        entries.push_back({rank, id, phase, query, user, std::chrono::steady_clock::now(), limit});
     }
     // drops completed entries; true + message if one is overdue
     bool poll(std::string* msg) {
@@ -206,9 +211,9 @@ struct Watchdog {
             const Entry& e = entries[i];
             if (e.query(e.user)) { entries.erase(entries.begin() + (long)i); continue; }
             const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - e.armed).count();
-            if (ms > (long long)deadlineMs) {
+            if (ms > (long long)e.deadlineMs) {
                 if (msg) *msg = "exchange watchdog: rank " + std::to_string(e.rank) + ", exchange " + std::to_string(e.id) + " (" + idName(e.id) + "), phase " + phaseName(e.phase) +
-                                ": not complete after " + std::to_string(ms) + " ms (deadline " + std::to_string(deadlineMs) +
+                                ": not complete after " + std::to_string(ms) + " ms (deadline " + std::to_string(e.deadlineMs) +
                                 " ms) - a peer has not posted its side of the group, or the producer's edge signal was never raised (the launch stream may be parked in an earlier in-line exchange: "
                                 "the histogram / depth-range all-reduce or the GI history exchange)";
                 return true;
@@ -232,6 +237,11 @@ struct RcclExchange {
     hipStream_t commStream = nullptr;
     uint32_t lastSignalValue = 0; // the edge signal value the previous BEGIN waited for: a BEGIN whose producer raised no new one orders behind the launch stream
     hipEvent_t ready[PLRF_EXCHANGE_COUNT] = {}, done[PLRF_EXCHANGE_COUNT] = {};
+    // END without an event wait: the communication stream stores the exchange's serial into a word of signal memory behind its transfers (hipStreamWriteValue32)
+    // and the launch stream waits for that value (hipStreamWaitValue32) - a cross-stream event dependency costs the launch stream ~10 us even when the event fired
+    // long ago (profiles/r05_tile_vs_band.txt), a satisfied value wait a fraction of that. One 8-byte signal allocation per exchange point; nullptr: events.
+    uint32_t* doneFlag[PLRF_EXCHANGE_COUNT] = {};
+    uint32_t doneSerial[PLRF_EXCHANGE_COUNT] = {};
     StageArena sendArena[PLRF_EXCHANGE_COUNT], recvArena[PLRF_EXCHANGE_COUNT];
     uint64_t bytesSent = 0, bytesReceived = 0, exchanges = 0; // of the last frame (reset by the histogram exchange, the first of a frame)
     int lastOverlapMode = 0;
@@ -257,6 +267,7 @@ struct RcclExchange {
         if (comm) ncclCommDestroy(comm);
         for (auto e : ready) if (e) hipEventDestroy(e);
         for (auto e : done) if (e) hipEventDestroy(e);
+        for (auto f : doneFlag) if (f) hipFree(f);
         for (auto& a : sendArena) if (a.ptr) hipFree(a.ptr);
         for (auto& a : recvArena) if (a.ptr) hipFree(a.ptr);
         if (commStream) hipStreamDestroy(commStream);
@@ -271,6 +282,7 @@ struct RcclExchange {
     }
     void startWatchdog() {
         if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_MS")) dog.deadlineMs = (uint32_t)std::max(0, std::atoi(ms));
+        if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_FIRST_MS")) dog.graceMs = (uint32_t)std::max(0, std::atoi(ms));
         if (const char* ab = std::getenv("PLRF_EXCHANGE_WATCHDOG_ABORT")) dogAbort = std::atoi(ab) != 0;
         for (int i = 0; i < PLRF_EXCHANGE_COUNT; i++) dogArgs[i] = {this, i};
         if (!dog.deadlineMs) return;
@@ -468,11 +480,16 @@ struct RcclExchange {
                 if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
             }
             if (int rc = post(id, commStream)) return rc;
-            if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc;
+            if (doneFlag[id]) if (int rc = hip(hipStreamWriteValue32(commStream, doneFlag[id], ++doneSerial[id], 0), "hipStreamWriteValue32")) return rc;
+            // (the event stays: it is what the watchdog queries, and the END's order when there are no stream memory operations)
+            if (!doneFlag[id] || dog.deadlineMs) if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc;
             dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]);
             return 0;
         }
-        if (phase == PLRF_EXCHANGE_END) return hip(hipStreamWaitEvent(launchStream, done[id], 0), "hipStreamWaitEvent");
+        if (phase == PLRF_EXCHANGE_END) {
+            if (doneFlag[id]) return hip(hipStreamWaitValue32(launchStream, doneFlag[id], doneSerial[id], hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32(END)");
+            return hip(hipStreamWaitEvent(launchStream, done[id], 0), "hipStreamWaitEvent");
+        }
         if (int rc = post(id, launchStream)) return rc;
         return watch(id, 0, launchStream);
     }
@@ -510,6 +527,11 @@ int attachCommon(void* pipeline, const void* unique_id_128_bytes, int rank, int 
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, x->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
         x->streamWaitValueSupported = can;
+        static const bool endByValue = !std::getenv("PLRF_EXCHANGE_END_BY_VALUE") || std::atoi(std::getenv("PLRF_EXCHANGE_END_BY_VALUE")) != 0; // experiment hook: 0 = events
+        for (int i = 0; can && endByValue && i < PLRF_EXCHANGE_COUNT; i++) {
+            if (hipExtMallocWithFlags((void**)&x->doneFlag[i], 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); x->doneFlag[i] = nullptr; continue; }
+            if (hipMemset(x->doneFlag[i], 0, 8) != hipSuccess) { (void)hipGetLastError(); hipFree(x->doneFlag[i]); x->doneFlag[i] = nullptr; }
+        }
     }
     if (rc) { delete x; return rc; }
     if (plrf_set_exchange_callback(pipeline, &RcclExchange::callback, x) != PLR_OK) { delete x; return xfail(PLR_ERR_INVALID_ARGUMENT, plrf_last_error()); }
@@ -714,6 +736,7 @@ int plrf_watchdog_create(uint32_t deadline_ms, void** out_watchdog) {
     if (!out_watchdog) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_watchdog_create: null argument");
     Watchdog* w = new Watchdog();
     w->deadlineMs = deadline_ms;
+    w->graceArms = 0; // the bare mechanism: every arm has the stated deadline (the native exchange gives its first arms PLRF_EXCHANGE_WATCHDOG_FIRST_MS)
     *out_watchdog = w;
     return PLR_OK;
 }
