@@ -1,7 +1,10 @@
+#!/bin/bash
+# The round's evidence from ONE build, on the GPU box:  bash tools/final_round.sh r05c
+# -> gpurun_out/prof_<tag>/ (tools/profile_round.sh), gpurun_out/final/pytest_gpu.txt (the whole -m gpu suite), then tools/adopt_evidence.py <tag> <previous tag> here.
 set -u
-O=gpurun_out/r03z; mkdir -p $O
+TAG=${1:-r00}
 export TMPDIR=/tmp
-bash tools/profile_round.sh r03d > $O/profile_round.log 2>&1; echo "rc=$?" >> $O/profile_round.log
-timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "rc=$?" >> $O/pytest_all.log
-python bench.py > $O/bench_with_cpu.json 2> $O/bench_with_cpu.err
-tail -n 4 $O/pytest_all.log; tail -n 3 $O/profile_round.log; head -c 300 gpurun_out/prof_r03d/bench.json
+mkdir -p gpurun_out/final
+bash tools/profile_round.sh $TAG > gpurun_out/final/profile_round.log 2>&1; echo "rc=$?" >> gpurun_out/final/profile_round.log
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final/pytest_gpu.txt
+tail -n 3 gpurun_out/final/profile_round.log; cat gpurun_out/final/pytest_gpu.txt
