@@ -28,10 +28,11 @@ for line in open("profiles/%s_big_kernel_counters.txt" % prev).read().splitlines
 open("profiles/%s_big_kernel_counters.txt" % tag, "w").write("\n".join(out) + "\n")
 with open("profiles/%s_pytest_gpu.txt" % tag, "w") as fh:
     fh.write("# python -m pytest tests -m gpu -q   (kernel source digest %s, MI355X box)\n" % digest + open("gpurun_out/final/pytest_gpu.txt").read())
-for f in glob.glob("profiles/%s_*" % prev):
+same_round = tag[:3] == prev[:3]  # a previous ROUND's final set stays (the documents' history cites it); an earlier build of this round is replaced
+for f in glob.glob("profiles/%s_*" % prev) if same_round else []:
     subprocess.check_call(["git", "rm", "-q", "-f", f])
-docs = ["DESIGN.md", "BASELINE.md", "README.md", "INTEGRATION.md", "profiles/README.md"] + glob.glob("profiles/r04_*.txt")
-for p in docs:
+docs = ["DESIGN.md", "BASELINE.md", "README.md", "INTEGRATION.md", "profiles/README.md"] + glob.glob("profiles/r04_*.txt") + glob.glob("profiles/r05_*.txt")
+for p in docs if same_round else []:
     s = open(p).read()
     if prev in s: open(p, "w").write(s.replace(prev, tag))
 print("adopted %s (digest %s); %d files" % (tag, digest, len(glob.glob("profiles/%s_*" % tag))))

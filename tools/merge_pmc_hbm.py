@@ -22,7 +22,7 @@ with open(out, "w") as fh:
         fh.write("# kernel source digest: %s\n" % open(dig).read().strip())
     fh.write("kernel,dispatches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,traffic_bytes\n")
     for r in rows: fh.write("%s,%d,%.1f,%.1f,%d\n" % r)
-for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pass_table.txt", "bench_1080p.json", "bench_8k.json", "parity_4k.txt", "config5_8k.txt", "valu_rates.txt", "band_cost.txt", "pass_table_producers.txt", "pass_table_producers_exact.txt", "bench_producers.json", "tile_vs_band_proxy.txt"):
+for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pass_table.txt", "bench_1080p.json", "bench_8k.json", "parity_4k.txt", "config5_8k.txt", "valu_rates.txt", "band_cost.txt", "pass_table_producers.txt", "pass_table_producers_exact.txt", "bench_producers.json", "tile_vs_band.txt", "config5_series.txt", "tail_cost.txt"):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(ROOT, "profiles", tag + "_" + a))
 print(open(out).read()[:1500])
