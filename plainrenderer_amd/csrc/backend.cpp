@@ -9,6 +9,7 @@
 #include "kernels_fast/pcf_taps.h"
 
 #include <dlfcn.h>
+#include <deque>
 #include <algorithm>
 #include <chrono>
 #include <mutex>
@@ -45,11 +46,18 @@ static bool shaderTakesColumns(const std::string& shader) {
     return false;
 }
 static bool storageBindingIsReadOnly(const std::string& shader, uint32_t binding) { return shader == "lightMatrix.comp" && binding == 1; }
-static std::vector<ShaderEntry>& registry() {
-    static std::vector<ShaderEntry> r;
+// The registry is written by static initialisers: libplr.so's own before anything runs, libplr_exact.so's when a thread loads it - possibly while another thread
+// (one backend per host thread) looks a shader up. A deque keeps entries in place; every access takes the lock.
+static std::deque<ShaderEntry>& registry() {
+    static std::deque<ShaderEntry> r;
     return r;
 }
+static std::mutex& registryMutex() {
+    static std::mutex m;
+    return m;
+}
 ShaderRegistrar::ShaderRegistrar(const char* name, LaunchFn fn, bool fast) {
+    std::lock_guard<std::mutex> lock(registryMutex());
     for (auto& e : registry())
         if (e.name == name) { (fast ? e.fast : e.fn) = fn; return; }
     ShaderEntry e;
@@ -367,21 +375,27 @@ static std::string shaderBaseName(const std::string& path) {
     const size_t slash = path.find_last_of("/\\");
     return slash == std::string::npos ? path : path.substr(slash + 1);
 }
-static const ShaderEntry* findShader(const std::string& path) {
+static bool findShader(const std::string& path, ShaderEntry* out) {
     const std::string base = shaderBaseName(path);
     for (int attempt = 0; attempt < 2; attempt++) {
-        for (const auto& e : registry())
-            if (e.name == base && (e.fn || e.fast)) return &e;
+        {
+            std::lock_guard<std::mutex> lock(registryMutex());
+            for (const auto& e : registry())
+                if (e.name == base && (e.fn || e.fast)) { *out = e; return true; }
+        }
         if (attempt == 0 && ensureExactSet() != PLR_OK) break; // a shader only the exact set has
     }
-    return nullptr;
+    return false;
 }
 // the general launcher of a pass whose shader's exact launch path lives in libplr_exact.so
 static int resolveExactLauncher(LaunchFn* fn, const std::string& shader) {
     if (int rc = ensureExactSet()) return rc;
     const std::string base = shaderBaseName(shader);
-    for (const auto& e : registry())
-        if (e.name == base && e.fn) { *fn = e.fn; return PLR_OK; }
+    {
+        std::lock_guard<std::mutex> lock(registryMutex());
+        for (const auto& e : registry())
+            if (e.name == base && e.fn) { *fn = e.fn; return PLR_OK; }
+    }
     g_err = "no PLR_MATH_EXACT kernel for shader '" + shader + "'";
     return PLR_ERR_UNKNOWN_SHADER;
 }
@@ -966,7 +980,8 @@ int plr_set_global_descriptor_set_resources(const plr_pass_resources* r) {
 
 static int fillPass(PassRes& p, const plr_compute_pass_desc* desc) {
     if (!desc || !desc->src_path_relative) return setErr(PLR_ERR_INVALID_ARGUMENT, "pass description / shader path is null");
-    const ShaderEntry* entry = findShader(desc->src_path_relative);
+    ShaderEntry found;
+    const ShaderEntry* entry = findShader(desc->src_path_relative, &found) ? &found : nullptr;
     if (!entry) return setErr(PLR_ERR_UNKNOWN_SHADER, std::string("no HIP kernel for shader '") + desc->src_path_relative + "'");
     p.shader = desc->src_path_relative;
     if (desc->name) p.name = desc->name;
@@ -2127,6 +2142,7 @@ int plr_get_stream(void** out_hip_stream) { NEED_INIT_JOINED(); *out_hip_stream 
 int plr_get_launch_stream(void** out_hip_stream) { NEED_INIT(); *out_hip_stream = (void*)g->stream; return PLR_OK; }
 
 int plr_get_supported_shaders(const char** out_names, uint32_t capacity) {
+    std::lock_guard<std::mutex> lock(registryMutex());
     const auto& r = registry();
     for (uint32_t i = 0; i < capacity && i < r.size(); i++) out_names[i] = r[i].name.c_str();
     return (int)r.size();

@@ -180,6 +180,17 @@ __global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
     }
 }
 
+// ---------------------------------------------------------------- waiting for the producer's edge signal on the communication stream
+// hipStreamWaitValue32 does it in the command processor - and a PENDING value wait on one stream slows every kernel the chip runs meanwhile: with the host a frame
+// ahead the communication stream's head is such a wait nearly all the time, and the kernels of a band measured 5 - 20 % longer (trace 116 -> 141 us, shade 215 -> 227,
+// spatial filter 111 -> 125: profiles/r05_tile_vs_band.txt "value wait"). A pending EVENT wait costs nothing, and neither does one sleeping wave: the wait is a
+// one-wave kernel on the communication stream that sleeps until the word has reached the value; stream order then holds the transfers back behind it.
+__global__ __launch_bounds__(64) void waitForValueKernel(const uint32_t* __restrict__ word, uint32_t value) {
+    if (threadIdx.x == 0)
+        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // ---------------------------------------------------------------- watchdog
 struct Watchdog {
     struct Entry { int rank, id, phase; plrf_watchdog_query query; void* user; std::chrono::steady_clock::time_point armed; uint32_t deadlineMs; };
@@ -473,7 +484,11 @@ struct RcclExchange {
             if (rowsFirst) {
                 lastSignalValue = value;
                 lastOverlapMode = 2;
-                if (int rc = hip(hipStreamWaitValue32(commStream, signal, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32")) return rc;
+                static const bool waitInKernel = !std::getenv("PLRF_EXCHANGE_BEGIN_WAIT") || std::string(std::getenv("PLRF_EXCHANGE_BEGIN_WAIT")) != "value"; // experiment hook
+                if (waitInKernel) {
+                    waitForValueKernel<<<1, 64, 0, commStream>>>((const uint32_t*)signal, value);
+                    if (int rc = hip(hipGetLastError(), "waitForValueKernel")) return rc;
+                } else if (int rc = hip(hipStreamWaitValue32(commStream, signal, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32")) return rc;
             } else {
                 lastOverlapMode = 1;
                 if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;

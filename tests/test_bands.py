@@ -604,7 +604,7 @@ def test_rect_plan_of_bands_equals_the_band_plan_and_the_cpp_plan():
                                         C.byref(C.c_uint32())) != 0
 
 
-def _gloo_tile_worker(rank, world, port, fw, fh, gx, gy, out):
+def _gloo_tile_worker(rank, world, port, fw, fh, gx, gy, out, images=((1, 4, 16), (2, 8, 8))):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -613,7 +613,7 @@ def _gloo_tile_worker(rank, world, port, fw, fh, gx, gy, out):
         t = tiling.DistTransport(rank, world, device=None)
         rects = tiling.tile_rects(fw, fh, gx, gy)
         items, arrays, plans = [], [], []
-        for div, texel_bytes, halo in ((1, 4, 16), (2, 8, 8)):
+        for div, texel_bytes, halo in images:
             cols, rows = fw // div, fh // div
             x0, y0, x1, y1 = tiling._scale_rect(rects[rank], fw, fh, cols, rows)
             img = np.full((rows, cols * texel_bytes), 0xEE, np.uint8)
@@ -629,15 +629,18 @@ def _gloo_tile_worker(rank, world, port, fw, fh, gx, gy, out):
         dist.destroy_process_group()
 
 
-def test_dist_transport_gloo_world4_tiles():
-    """the torch.distributed transport over a 2 x 2 tile partition, world size 4 over gloo: every tile ends up with its own texels, the halo frame of its
-    three neighbours' texels (corners from the diagonal tile) and nothing else"""
+@pytest.mark.parametrize("gx,gy,images", [(2, 2, ((1, 4, 16), (2, 8, 8))), (1, 4, ((1, 4, 4096), (2, 8, 4096))), (2, 2, ((1, 4, 4096), (2, 8, 40)))],
+                         ids=["tiles2x2", "bands4-whole-image-halo", "tiles2x2-whole-image-halo"])
+def test_dist_transport_gloo_world4_tiles(gx, gy, images):
+    """the torch.distributed transport over a partition into four rectangles, world size 4 over gloo: every rank ends up with its own texels, the halo frame of the
+    other ranks' texels (corners from the diagonal tile) and nothing else. With a halo as large as the image (the exact mode of a partitioned frame) every rank is
+    a peer - a band receives the rows of the band BEHIND its neighbour too - and every rank ends up with the whole image."""
     import torch.multiprocessing as mp
-    fw, fh, gx, gy, world = 256, 128, 2, 2, 4
+    fw, fh, world = 256, 256 if gy == 4 else 128, 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_tile_worker, args=(r, world, port, fw, fh, gx, gy, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gloo_tile_worker, args=(r, world, port, fw, fh, gx, gy, q, images)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -649,7 +652,7 @@ def test_dist_transport_gloo_world4_tiles():
         assert p.exitcode == 0
     rects = tiling.tile_rects(fw, fh, gx, gy)
     for rank in range(world):
-        for (div, texel_bytes, halo), img in zip(((1, 4, 16), (2, 8, 8)), got[rank]):
+        for (div, texel_bytes, halo), img in zip(images, got[rank]):
             cols, rows = fw // div, fh // div
             x0, y0, x1, y1 = tiling._scale_rect(rects[rank], fw, fh, cols, rows)
             stamp = ((np.arange(rows)[:, None] * 7 + np.arange(cols * texel_bytes)[None, :] * 3) % 251).astype(np.uint8)
