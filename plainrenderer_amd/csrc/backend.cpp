@@ -613,6 +613,9 @@ bool TwoRanges::setEdgeFirst(const PassCtx& c, int y0, int y1, int blockRowsPx, 
     edgeBlocks = (uint32_t)(top + bottom) * blocksX + (uint32_t)(left + right) * (uint32_t)(totalRows - top - bottom);
     edgeCounter = c.edgeCounter; edgeSignal = c.edgeSignal; edgeValue = c.edgeValue;
     if (edgeBlocks == 0) { edgeTop = edgeBottom = edgeLeft = edgeRight = 0; total = 0; return false; }
+    // experiment hook (profiles/r05_not_kept.txt (6)): the edges-first block ORDER alone - no write-through, no arrivals, the backend raises the signal behind the launch
+    static const bool orderOnly = std::getenv("PLR_EDGE_ORDER_ONLY") && std::atoi(std::getenv("PLR_EDGE_ORDER_ONLY")) != 0;
+    if (orderOnly) { edgeBlocks = 0; return false; }
     c.edgeSignalHonoured = true;
     return true;
 }

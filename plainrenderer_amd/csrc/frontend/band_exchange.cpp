@@ -248,9 +248,9 @@ struct RcclExchange {
     hipStream_t commStream = nullptr;
     uint32_t lastSignalValue = 0; // the edge signal value the previous BEGIN waited for: a BEGIN whose producer raised no new one orders behind the launch stream
     hipEvent_t ready[PLRF_EXCHANGE_COUNT] = {}, done[PLRF_EXCHANGE_COUNT] = {};
-    // END without an event wait: the communication stream stores the exchange's serial into a word of signal memory behind its transfers (hipStreamWriteValue32)
-    // and the launch stream waits for that value (hipStreamWaitValue32) - a cross-stream event dependency costs the launch stream ~10 us even when the event fired
-    // long ago (profiles/r05_tile_vs_band.txt), a satisfied value wait a fraction of that. One 8-byte signal allocation per exchange point; nullptr: events.
+    // END without an event wait (PLRF_EXCHANGE_END_BY_VALUE=1; measured, not the default): the communication stream stores the exchange's serial into a word of signal
+    // memory behind its transfers (hipStreamWriteValue32) and the launch stream waits for that value (hipStreamWaitValue32) - a satisfied value wait is cheaper than a
+    // cross-stream event dependency (~3 against ~10 us), a PENDING one slows every kernel on the chip. One 8-byte signal allocation per exchange point; nullptr: events.
     uint32_t* doneFlag[PLRF_EXCHANGE_COUNT] = {};
     uint32_t doneSerial[PLRF_EXCHANGE_COUNT] = {};
     StageArena sendArena[PLRF_EXCHANGE_COUNT], recvArena[PLRF_EXCHANGE_COUNT];
@@ -542,7 +542,9 @@ int attachCommon(void* pipeline, const void* unique_id_128_bytes, int rank, int 
         int can = 0;
         if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, x->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
         x->streamWaitValueSupported = can;
-        static const bool endByValue = !std::getenv("PLRF_EXCHANGE_END_BY_VALUE") || std::atoi(std::getenv("PLRF_EXCHANGE_END_BY_VALUE")) != 0; // experiment hook: 0 = events
+        // OFF by default: with the BEGIN's wait in a kernel the two forms of the END measure the same in the replay (slowest band 0.841 / 0.838 ms), and a value wait that
+        // stays pending - an END on a real link - slows whatever runs beside it (the transfers' kernels, the asynchronous tail): profiles/r05_not_kept.txt (6)
+        static const bool endByValue = std::getenv("PLRF_EXCHANGE_END_BY_VALUE") && std::atoi(std::getenv("PLRF_EXCHANGE_END_BY_VALUE")) != 0; // experiment hook: 1 = stream value wait
         for (int i = 0; can && endByValue && i < PLRF_EXCHANGE_COUNT; i++) {
             if (hipExtMallocWithFlags((void**)&x->doneFlag[i], 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); x->doneFlag[i] = nullptr; continue; }
             if (hipMemset(x->doneFlag[i], 0, 8) != hipSuccess) { (void)hipGetLastError(); hipFree(x->doneFlag[i]); x->doneFlag[i] = nullptr; }

@@ -47,7 +47,8 @@ cd $REPO
 { echo "# kernel source digest: $DIGEST"; echo "# ---- python tools/band_cost.py 4 --tiles 2x2 --passes --balance"; python tools/band_cost.py 4 --tiles 2x2 --passes --balance 2>&1 | grep -v amdgpu.ids;
   echo "# ---- python tools/band_cost.py 4 --passes --balance"; python tools/band_cost.py 4 --passes --balance 2>&1 | grep -v amdgpu.ids;
   echo "# ---- PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance   (band_overlap_exchange 0: producers not split, exchanges whole)"; PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids;
-  echo "# ---- PLRF_EXCHANGE_END_BY_VALUE=0 python tools/band_cost.py 4 --balance   (the END of an exchange as an event wait, as until round 4, instead of a stream value wait)"; PLRF_EXCHANGE_END_BY_VALUE=0 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/tile_vs_band.txt
+  echo "# ---- PLRF_EXCHANGE_END_BY_VALUE=1 python tools/band_cost.py 4 --balance   (the END of an exchange as a stream value wait instead of an event wait)"; PLRF_EXCHANGE_END_BY_VALUE=1 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids;
+  echo "# ---- PLRF_EXCHANGE_BEGIN_WAIT=value python tools/band_cost.py 4 --balance   (the BEGIN's wait for the edge signal as hipStreamWaitValue32, as until the middle of round 5, instead of a sleeping one-wave kernel)"; PLRF_EXCHANGE_BEGIN_WAIT=value python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/tile_vs_band.txt
 bash tools/config5_series.sh 256 > $OUT/config5_series.txt 2>&1
 { echo "# kernel source digest: $DIGEST"; python tools/tail_cost.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tail_cost.txt
 NOW=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())")
