@@ -12,7 +12,7 @@ rectangles, one rank per GPU - N row bands (the default: the faster partition in
 TILES (--partition tiles; N = 4: config 5's 2 x 2) - halos exchanged over RCCL point-to-point (C++ host, csrc/frontend/band_exchange.cpp) plus one 512-byte
 histogram all-reduce; weak scaling (every GPU keeps one 4K frame's worth of pixels), and the JSON line also carries the STRONG-scaling figure the
 target is written in: the time of the same frame unpartitioned on one GPU (measured on rank 0 in the same run) over the N-GPU time. The rectangles'
-sizes are balanced before the timed region from measured render times (two calibration rounds, `band_partition` in the JSON line; --no-balance keeps equal sizes). When WORLD_SIZE is not set, `--gpus N` spawns the N
+sizes are balanced before the timed region from measured render times (up to four calibration rounds, the best measured partition is kept; `band_partition` in the JSON line; --no-balance keeps equal sizes). When WORLD_SIZE is not set, `--gpus N` spawns the N
 ranks itself (python -m torch.distributed.run, rendezvous on 127.0.0.1); under torchrun WORLD_SIZE must equal --gpus. A band frame that
 cannot run fails the benchmark (non-zero exit) unless --allow-replicas is given.
 """
@@ -314,7 +314,9 @@ def main():
         (tiling.balanced_tile_bounds). Two rounds; the same partition on every rank."""
         w_, h_ = band_frame_size()
         cols, rows = tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)
-        for _ in range(2):
+        best = None  # (slowest time, cols, rows) of the partitions MEASURED so far: the cost density inside a rectangle is not flat (sky above ground), so a re-cut
+        # overshoots or undershoots; up to four rounds, and the partition returned is the best one that was actually timed, not the last proposal
+        for _ in range(4):
             rects_ = tiling.tile_rects(w_, h_, grid_x, grid_y, cols, rows)
             b0, b1 = rects_[rank][1], rects_[rank][3]
             be_ = RenderBackend(w_, h_, device=local_rank)
@@ -340,11 +342,13 @@ def main():
                 dist.all_reduce(times, op=dist.ReduceOp.SUM)
             times = [float(v) for v in times.cpu().tolist()]
             band_partition["calibration"].append({"col_bounds": list(cols), "row_bounds": list(rows), "partition_ms": [round(t * 1e3, 4) for t in times]})
+            if best is None or max(times) < best[0]:
+                best = (max(times), list(cols), list(rows))
             new = tiling.balanced_tile_bounds(w_, h_, grid_x, grid_y, cols, rows, times, min_size=512)  # every rectangle stays larger than the widest halo (224)
-            if new == (cols, rows):
+            if new == (cols, rows) or any(new == (c["col_bounds"], c["row_bounds"]) for c in band_partition["calibration"]):
                 break
             cols, rows = new
-        return cols, rows
+        return best[1], best[2]
 
     def make(mode):
         """mode 'single': the 4K frame on this GPU; 'bands': one band of the N x larger frame; -> (be, fp, scene-tuple, w, h, band)"""
