@@ -700,10 +700,11 @@ def _tile_rects(gx, gy):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,half_res", [((2, 2), 1), ((2, 1), 1), ((2, 2), 0)])
+@pytest.mark.parametrize("grid,half_res", [((2, 2), 1), ((2, 1), 1), ((2, 2), 0), ((4, 3), 1), ((1, 3), 1)])
 def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res):
-    """BASELINE config 5's partition: the frame as 2 x 2 screen tiles (and 2 x 1), one backend per tile on this GPU, rectangles moved by the in-process transport.
-    Every tile touches every other one, so halos as large as the image make every pass's inputs complete: the tiled frame must equal the unpartitioned one in
+    """BASELINE config 5's partition: the frame as 2 x 2 screen tiles (and 2 x 1; 4 x 3 tiles of 64 x 64 pixels and three whole-row rectangles, where tiles that do NOT
+    touch exchange too: a plan reaches every rank within the halo), one backend per tile on this GPU, rectangles moved by the in-process transport.
+    Halos as large as the image make every pass's inputs complete: the tiled frame must equal the unpartitioned one in
     every bit (exact kernel set), over three frames of temporal feedback - every column span, every valid-column range, every exchange rectangle, the per-tile
     pyramid and culling by tile columns, the histogram all-reduce of tile rectangles"""
     inputs = _make_inputs()
