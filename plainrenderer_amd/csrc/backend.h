@@ -1,4 +1,4 @@
-// Internal interface between the backend runtime (backend.cpp) and the pass kernels (kernels/*.hip).
+// Internal interface between the backend runtime (backend.cpp) and the pass kernels (kernels/*.hip, kernels_fast/*.hip, kernels_exact/*.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

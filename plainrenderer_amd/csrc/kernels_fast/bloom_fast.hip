@@ -1,4 +1,4 @@
-// PLR_MATH_FAST variant of bloomUpsample.comp:19-57 (exact variant: kernels/bloom.hip).
+// PLR_MATH_FAST variant of bloomUpsample.comp:19-57 (exact variant: kernels_exact/bloom.hip).
 //
 // The 9-tap tent (weights .25/.125/.0625 at 0, +-blurRadius texels) is the outer product of the 1D tent (.5, .25, .25), the
 // 4-tap box of the previous mip (4 x .25 at +-0.5 texel) is the outer product of (.5, .5), and bilinear filtering is itself

@@ -1,4 +1,4 @@
-// PLR_MATH_FAST variant of filterIndirectDiffuseSpatial.comp:30-135 (exact variant: kernels/gi_filters.hip).
+// PLR_MATH_FAST variant of filterIndirectDiffuseSpatial.comp:30-135 (exact variant: kernels_exact/gi_filters.hip).
 //
 // Same samples, same weights, same accumulation order; what changes is how each quantity is computed:
 //  * pixelToWorld(uv) = camPos + cameraToPixel / dot(cameraToPixel, forward) * depthLinear. cameraToPixel is the normalised
@@ -495,7 +495,7 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     fc.tsx = 1.f / (float)out.w; fc.tsy = 1.f / (float)out.h; // IEEE single-precision quotients (this file's host code is built without fast-math)
     fc.dW = (float)c.sampled[4].w; fc.dH = (float)c.sampled[4].h; fc.nW = (float)c.sampled[5].w; fc.nH = (float)c.sampled[5].h;
     fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
-    static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels/gi_filters.hip)
+    static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels_exact/gi_filters.hip)
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, sig, \
                          (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), rowMissShrinks, fc
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \

@@ -1,4 +1,4 @@
-// PLR_MATH_FAST variant of sdfDiffuseTrace.comp (exact variant and the wave / tile mapping: kernels/sdfgi.hip).
+// PLR_MATH_FAST variant of sdfDiffuseTrace.comp (exact variant and the wave / tile mapping: kernels_exact/sdf_trace_exact.hip).
 //
 // Same sphere trace, same culling tiles, same LDS ray exchange. Arithmetic changes:
 //  * the per-step uv = localPos / localExtends + 0.5 is a multiply-add with the precomputed reciprocal extents (three IEEE

@@ -1,4 +1,4 @@
-// PLR_MATH_FAST variant of the deferred shade (exact variant and the description of the re-expression: kernels/shading.hip).
+// PLR_MATH_FAST variant of the deferred shade (exact variant and the description of the re-expression: kernels_exact/shading.hip).
 //
 // Same lighting model term by term; the arithmetic is restructured for the VALU:
 //  * (1-x)^5 Fresnel / CoD terms are x2*x2*x instead of exp2(5*log2(x)); the remaining pow/log/exp use v_log_f32 / v_exp_f32

@@ -1,5 +1,5 @@
 // PLR_MATH_FAST variants of the streaming passes: applyBloom.comp, tonemapping.comp, indirectLightUpscale.comp,
-// filterIndirectDiffuseTemporal.comp (exact variants: kernels/bloom.hip, exposure_tonemap.hip, gi_filters.hip).
+// filterIndirectDiffuseTemporal.comp (exact variants: kernels_exact/bloom.hip, kernels/exposure_tonemap.hip, kernels_exact/gi_filters.hip).
 //
 // Every pass of this pipeline is bound by VALU issue on gfx950 (a wave64 FP32 instruction occupies a SIMD for 4 cycles; PMC:
 // SQ_INSTS_VALU x 4 cycles / 4 SIMDs accounts for each kernel's time), not by HBM. These variants keep the algorithms and cut the

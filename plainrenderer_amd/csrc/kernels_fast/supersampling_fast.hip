@@ -1,5 +1,5 @@
 // PLR_MATH_FAST kernels of the optional TAA stage (TAASettings::useSeparateSupersampling, Techniques/TAA.cpp:85-137):
-// colorToLuminance.comp:14-21 and temporalSupersampling.comp:23-110 (exact set: kernels/taa.hip).
+// colorToLuminance.comp:14-21 and temporalSupersampling.comp:23-110 (exact set: kernels_exact/taa.hip).
 //
 // What a pixel of the supersampling pass DECIDES - which 3x3 neighbour's motion vector it takes, where that reprojects to, the 8-bit sub-texel weights of the
 // history tap, the four luminance texels of each gather, the closest depth of both neighbourhoods, the contrast and depth rejection tests - is computed with the

@@ -1,4 +1,4 @@
-// PLR_MATH_FAST variant of temporalFilter.comp (exact variant: kernels/taa.hip).
+// PLR_MATH_FAST variant of temporalFilter.comp (exact variant: kernels_exact/taa.hip).
 //
 // Same algorithm; restructured where the shader repeats work:
 //  * tonemap(c) = c / (1 + lum(c)) is one v_rcp_f32 and three multiplies instead of three IEEE divisions
