@@ -410,14 +410,25 @@ class Exchange:
             return b0 // div, min((b1 + div - 1) // div, items[i].image_rows)
 
         # the row-band plan stops at the two neighbours (neighbour_plan): a halo taller than a neighbour would leave rows the pipeline declares valid unsent
-        # (the exact mode's whole-image halo) - such a partition is exchanged as rectangles (rects=..., rect_plan reaches every band within the halo)
-        for i, r in enumerate(items):
-            for b in (self.index - 1, self.index + 1):
-                if 0 <= b < self.n:
-                    lo, hi = band_meta(i, b)
-                    if r.halo_rows > hi - lo and ((b < self.index and lo > 0) or (b > self.index and hi < r.image_rows)):
-                        raise ValueError("exchange %d: a halo of %d rows is taller than the neighbouring band (%d rows): pass the partition as rects" % (exchange_id, r.halo_rows, hi - lo))
-
+        # (the exact mode's whole-image halo). Such an exchange goes through the rectangle plan, which reaches every band within the halo (whole-row rectangles).
+        def reaches_past_a_neighbour():
+            for i, r in enumerate(items):
+                for b in (self.index - 1, self.index + 1):
+                    if 0 <= b < self.n:
+                        lo, hi = band_meta(i, b)
+                        if r.halo_rows > hi - lo and ((b < self.index and lo > 0) or (b > self.index and hi < r.image_rows)):
+                            return True
+            return False
+        if items and reaches_past_a_neighbour():
+            div = max(1, round(self.height / items[0].image_rows))
+            width = items[0].image_cols * div
+            rects = [(0,) + (band_rows(self.height, self.n, b, self.bounds)[0],) + (width,) + (band_rows(self.height, self.n, b, self.bounds)[1],) for b in range(self.n)]
+            plans = [rect_plan(rects, self.index, width, self.height, r.image_cols, r.image_rows, r.halo_rows) for r in items]
+            if phase == EXCHANGE_BEGIN:
+                self._pending[exchange_id] = self.t.begin_exchange_rects(items, plans, stream_ptr)
+            else:
+                self.t.exchange_rects(items, plans, stream_ptr)
+            return
         if phase == EXCHANGE_BEGIN:
             self._pending[exchange_id] = self.t.begin_exchange(items, stream_ptr, band_meta)
         else:
