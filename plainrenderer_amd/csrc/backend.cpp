@@ -1506,8 +1506,9 @@ static size_t fusionWindow(size_t i, size_t last) {
 // (histogram chain, pyramid, culling), which then ran as six launches instead of two. The executions in between are moved out of the way when the
 // recorded resources say that nothing changes: an execution is hoisted in front of the group if it shares no resource (with a write on either side) with
 // the members recorded before it, or sunk behind the group if it shares none with the members recorded after it; executions moved to the same side keep
-// their order, and one that moves in front of an earlier one that moves behind must not share a resource with it either. Host callbacks and rows-first
-// executions end the search.
+// their order, and one that moves in front of an earlier one that moves behind must not share a resource with it either. Rows-first executions and host
+// callbacks end the search - except a callback recorded with its resource list, which may be sunk behind the group like an execution (round 5: band
+// rendering's histogram all-reduce sits between the histogram chain and the pyramid; behind the group, the band's front is two launches).
 // The order is changed in place (a replayed frame keeps it); what is launched is the same set of executions on the same resources.
 static bool executionsConflict(const Execution& a, const Execution& b) {
     for (const Access& x : a.access)
@@ -1532,7 +1533,10 @@ static void gatherFusionGroups() {
             for (size_t j = i + 1; j < ex.size() && members.size() < m && moved.size() <= kMaxMoved; j++) {
                 const Execution& y = ex[j];
                 // a rows-first execution belongs to the callback recorded behind it (edge signal): it is neither fused nor moved
-                if (y.callback || y.asyncTail != ex[i].asyncTail || y.edgesFirst()) break;
+                if ((y.callback && !y.callbackAccessKnown) || y.asyncTail != ex[i].asyncTail || y.edgesFirst()) break;
+                // a host callback recorded WITH its resource list (plr_set_host_callback_execution_on: band rendering's histogram all-reduce names the histogram
+                // buffer) is an execution like any other for this purpose, except that it is only ever sunk behind the group, never hoisted in front of it
+                if (y.callback) { moved.push_back(j); continue; }
                 if (g->passes[y.pass]->shader == f.shaders[members.size()]) members.push_back(j);
                 else moved.push_back(j);
             }
@@ -1541,7 +1545,7 @@ static void gatherFusionGroups() {
             std::vector<size_t> front, back;
             bool legal = true;
             for (size_t s : moved) {
-                bool hoist = true, sink = true;
+                bool hoist = !ex[s].callback, sink = true;
                 for (size_t k : members) {
                     if (!executionsConflict(ex[s], ex[k])) continue;
                     if (k < s) hoist = false; else sink = false;

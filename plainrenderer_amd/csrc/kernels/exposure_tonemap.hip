@@ -456,8 +456,7 @@ int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz:
 }
 PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles + preExposeLights", launchFusedExposureChain, "histogramReset.comp", "histogramCombineTiles.comp", "preExposeLights.comp");
 // band rendering: reset + combine of the band's tiles (any first tile), one launch; the all-reduce callback and the exposure pass follow
-static int launchFusedResetCombine(const PassCtx* const* ctxs, size_t count) {
-    if (count != 2) return kUseGeneralKernel;
+int prepareResetCombine(const PassCtx* const* ctxs, ResetCombinePlan* out) {
     const PassCtx &reset = *ctxs[0], &comb = *ctxs[1];
     const uint32_t nBins = comb.specUint(0, 64u);
     if (nBins == 0 || nBins > (uint32_t)kFusedExposureMaxBins || reset.specUint(0, 64u) != nBins) return kUseGeneralKernel;
@@ -467,10 +466,64 @@ static int launchFusedResetCombine(const PassCtx* const* ctxs, size_t count) {
     if (comb.sbuf[0].size < (size_t)(tile0 + nTiles) * nBins * 4u) return kUseGeneralKernel;
     ExposureScratch* scratch = (ExposureScratch*)comb.scratch(sizeof(ExposureScratch)); // zero-initialised by the backend, kept zero by the kernel
     if (!scratch) return comb.fail(-2, "histogramCombineTiles: cannot allocate scratch memory");
-    histogramResetCombineKernel<<<divUp(nTiles, kCombineTilesPerBlock), 128, 0, comb.stream>>>((const uint32_t*)comb.sbuf[0].ptr + (size_t)tile0 * nBins, (uint32_t*)comb.sbuf[1].ptr, nBins,
-                                                                                              nTiles, scratch);
-    PLR_CHECK_LAUNCH(comb);
+    out->perTileBase = (const uint32_t*)comb.sbuf[0].ptr; out->perTile = out->perTileBase + (size_t)tile0 * nBins; out->histogram = (uint32_t*)comb.sbuf[1].ptr;
+    out->nBins = nBins; out->nTiles = nTiles; out->blocks = divUp(nTiles, kCombineTilesPerBlock); out->scratch = scratch;
     return 0;
+}
+static int launchFusedResetCombine(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    ResetCombinePlan r;
+    if (int rc = prepareResetCombine(ctxs, &r)) return rc;
+    histogramResetCombineKernel<<<r.blocks, 128, 0, ctxs[1]->stream>>>(r.perTile, r.histogram, r.nBins, r.nTiles, (ExposureScratch*)r.scratch);
+    PLR_CHECK_LAUNCH(*ctxs[1]);
+    return 0;
+}
+// launch 2 of a BAND's front (kernels_fast/fused_front.h, round 5): the blocks that finish the tiles' pyramid levels 4 and 5, the camera culling's blocks (a culling
+// tile evaluates its one texel of level 4 from level 3, as in tileTailAndCullingKernel, kernels/sdfgi.hip) and the blocks of histogramReset + histogramCombineTiles over
+// the band's tiles - three kinds of work that depend on launch 1 only, each block running the code of its own kernel.
+// EXPOSE: a frame with a per-tile pyramid that is NOT partitioned (8K on one GPU: twelve levels, one more than the shader binds) - no all-reduce, the block that
+// takes the last combine ticket runs the exposure as in the whole frame's launch 2.
+template <bool EXPOSE>
+__global__ __launch_bounds__(256) void bandFrontSecondKernel(fasthiz::TileTailParams t, uint32_t tailBlocks, FusedCullParams cull, uint32_t cullBlocks, const uint32_t* __restrict__ perTile,
+                                                             uint32_t* __restrict__ histogram, uint32_t nBins, uint32_t nTiles, ExposureScratch* __restrict__ scratch, uint32_t combineBlocks,
+                                                             LightBuffer* __restrict__ light, ImgView transmissionLut, const GlobalUbo* __restrict__ g, float minLuminanceLog, float maxLuminanceLog) {
+    __shared__ uint32_t list[kFusedCullMaxInstances];
+    __shared__ uint32_t waveTotals[4];
+    __shared__ uint32_t base;
+    __shared__ uint32_t totals[kFusedExposureMaxBins];
+    __shared__ uint32_t isLast;
+    __shared__ float term[EXPOSE ? kMaxExposureBins : 1];
+    __shared__ uint32_t counted[EXPOSE ? kMaxExposureBins : 1];
+    if (blockIdx.x < tailBlocks) { fasthiz::hizTileTailThread(t, (int)(blockIdx.x * 256u + threadIdx.x)); return; }
+    if (blockIdx.x < tailBlocks + cullBlocks) {
+        frustumAndTileCullingBlock<true, 256>(cull, blockIdx.x - tailBlocks, cullBlocks, list, waveTotals, &base, [&](vec2 uv) {
+            const int x = clampi((int)floorf(saneCoord(uv.x * (float)t.w4)), t.w4), y = clampi((int)floorf(saneCoord(uv.y * (float)t.h4)), t.h4);
+            const MinMax m = footprint<false>(2 * x, 2 * y, t.w3, t.h3, t.h3 & 1, t.w3 & 1, [&](int sx, int sy) { return t.level3[(size_t)sy * (size_t)t.w3 + (size_t)sx]; });
+            return make_float2(m.mn, m.mx);
+        });
+        return;
+    }
+    histogramCombineExposeBlock<EXPOSE>(blockIdx.x - tailBlocks - cullBlocks, combineBlocks, perTile, histogram, nBins, nTiles, scratch, light, transmissionLut, g, minLuminanceLog,
+                                        maxLuminanceLog, term, counted, totals, &isLast);
+}
+static int launchTileFrontSecond(const fasthiz::Plan& h, const FusedCullParams& cull, const uint32_t* perTile, uint32_t* histogram, uint32_t nBins, uint32_t nTiles, void* scratch,
+                                 uint32_t combineBlocks, const ExposureChainPlan* expose, hipStream_t stream) {
+    const fasthiz::TileTailParams& t = h.tileTail;
+    const int n = (t.col4End - t.col4Begin) * (t.row4End - t.row4Begin) + (t.col5End - t.col5Begin) * (t.row5End - t.row5Begin);
+    const uint32_t tailBlocks = n > 0 ? divUp((unsigned)n, 256u) : 0u, cullBlocks = divUp(cull.domainX * cull.domainY, 4u);
+    const uint32_t grid = tailBlocks + cullBlocks + combineBlocks;
+    if (expose) bandFrontSecondKernel<true><<<grid, 256, 0, stream>>>(t, tailBlocks, cull, cullBlocks, perTile, histogram, nBins, nTiles, (ExposureScratch*)scratch, combineBlocks,
+                                                                       (LightBuffer*)expose->light, expose->transmissionLut, expose->global, expose->minLuminanceLog, expose->maxLuminanceLog);
+    else bandFrontSecondKernel<false><<<grid, 256, 0, stream>>>(t, tailBlocks, cull, cullBlocks, perTile, histogram, nBins, nTiles, (ExposureScratch*)scratch, combineBlocks, nullptr, ImgView{},
+                                                                 nullptr, 0.f, 0.f);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? 0 : setLastError(-2, std::string("per-tile front, launch 2 failed: ") + hipGetErrorString(err));
+}
+int launchBandFrontSecond(const fasthiz::Plan& h, const FusedCullParams& cull, const ResetCombinePlan& r, hipStream_t stream) {
+    return launchTileFrontSecond(h, cull, r.perTile, r.histogram, r.nBins, r.nTiles, r.scratch, r.blocks, nullptr, stream);
+}
+int launchTileFrontSecondWithExposure(const fasthiz::Plan& h, const FusedCullParams& cull, const ExposureChainPlan& e, hipStream_t stream) {
+    return launchTileFrontSecond(h, cull, e.perTile, e.histogram, e.nBins, e.nTiles, e.scratch, e.blocks, &e, stream);
 }
 PLR_REGISTER_FUSION("histogramReset + histogramCombineTiles", launchFusedResetCombine, "histogramReset.comp", "histogramCombineTiles.comp");
 

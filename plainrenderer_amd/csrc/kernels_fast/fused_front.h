@@ -30,4 +30,22 @@ int prepareExposureChain(const PassCtx* const* ctxs3, ExposureChainPlan* out);  
 // h.tailFirst or h.tailFirst + 1
 int launchExposureChainAndPyramidTail(const ExposureChainPlan& e, const fasthiz::Plan& h, hipStream_t stream, const FusedCullParams* cull = nullptr, int cullLevel = 0); // 0 / < 0
 
+// ---- a BAND's (or tile's) front, round 5. Recorded: histogramPerTile, histogramReset, histogramCombineTiles, [all-reduce callback], preExposeLights, depthHiZPyramid,
+// depthDownscale, sdfCameraFrustumCulling, sdfCameraTileCulling. The callback names the histogram buffer, so the backend may sink it (and the exposure pass, which
+// reads that buffer) behind the pyramid and the culling, which touch neither (backend.cpp gatherFusionGroups); the seven passes in front of it then run as two launches:
+//   launch 1: the per-tile histogram's blocks beside the pyramid's quad blocks (histogramAndPyramidKernel, as for the whole frame)           [histogram_fast.hip]
+//   launch 2: the tiles' levels 4 and 5, the culling's blocks, the reset + combine blocks (bandFrontSecondKernel)                             [exposure_tonemap.hip]
+// instead of four (per-tile histogram | reset + combine | quad blocks | tile tail + culling): the two histogram launches sat at their launch floors.
+struct ResetCombinePlan {
+    const uint32_t* perTileBase = nullptr; // the per-tile histogram buffer
+    const uint32_t* perTile = nullptr;     // the first tile of the dispatch in it
+    uint32_t* histogram = nullptr;
+    uint32_t nBins = 0, nTiles = 0, blocks = 0;
+    void* scratch = nullptr;
+};
+int prepareResetCombine(const PassCtx* const* ctxs2, ResetCombinePlan* out); // histogramReset + histogramCombineTiles: 0 / kUseGeneralKernel / < 0 (kernels/exposure_tonemap.hip)
+int launchBandFrontSecond(const fasthiz::Plan& h, const FusedCullParams& cull, const ResetCombinePlan& r, hipStream_t stream); // 0 / < 0
+// the same launch for a frame with a per-tile pyramid that is not partitioned (8K on one GPU): the exposure runs in the block that takes the last combine ticket
+int launchTileFrontSecondWithExposure(const fasthiz::Plan& h, const FusedCullParams& cull, const ExposureChainPlan& e, hipStream_t stream);
+
 } // namespace plr

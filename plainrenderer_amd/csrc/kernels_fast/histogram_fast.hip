@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void histogramAndPyramidKernel(HistParams p, f
     uint32_t index;
     if (b < 5u * paired) { const uint32_t g = b / 5u, r = b % 5u; isHiz = r == 4u; index = isHiz ? g : 4u * g + r; }
     else { const uint32_t rem = b - 5u * paired; isHiz = rem >= remHist; index = isHiz ? paired + (rem - remHist) : 4u * paired + rem; }
-    if (isHiz) fasthiz::hizQuadBlock<4, DOWNSCALE>(q, (int)(index % hizGridX), (int)(index / hizGridX));
+    if (isHiz) fasthiz::hizQuadBlock<4, DOWNSCALE>(q, (int)(index % hizGridX) + q.tileX0, (int)(index / hizGridX) + q.tileY0); // (the whole frame's launch starts at tile 0, 0)
     else histogramTileBlock(p, index % p.gridX, index / p.gridX, localHistogram, thr);
 }
 
@@ -183,9 +183,23 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (ep.perTile != hp.perTile) return kUseGeneralKernel; // the combine must read what the per-tile pass writes
     fasthiz::Plan zp;
     if (int rc = fasthiz::prepare(*ctxs[4], ctxs[5], &zp)) return rc;
-    if (zp.perTile) return kUseGeneralKernel; // a per-tile pyramid has no chain tail for launch 2 to host: its passes fuse on their own (hiz_fast.hip)
     FusedCullParams cull;
     int cullLevel = -1;
+    if (zp.perTile) {
+        // a per-tile pyramid (a frame beyond the shader's 11 levels: 8K on one GPU) has no chain tail; with the culling behind it launch 2 is the band front's
+        // (tile levels 4 and 5, culling, combine) with the exposure in its last combine block - fused_front.h
+        if (count != 8) return kUseGeneralKernel;
+        bool useHiZ = false;
+        ImgView hiz;
+        if (int rc = prepareFusedCulling(*ctxs[6], *ctxs[7], &cull, &useHiZ, &hiz)) return rc;
+        const fasthiz::TileTailParams& t = zp.tileTail;
+        if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel;
+        if (ctxs[0]->pendingFillSlot) if (int rc = ctxs[0]->applyPendingFillsNow()) return rc;
+        const uint32_t histBlocksT = hp.gridX * hp.gridY, hizBlocksT = (uint32_t)(zp.gridX * zp.gridY);
+        histogramAndPyramidKernel<true><<<histBlocksT + hizBlocksT, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocksT, hizBlocksT, (uint32_t)zp.gridX, nullptr);
+        PLR_CHECK_LAUNCH(*ctxs[0]);
+        return launchTileFrontSecondWithExposure(zp, cull, ep, ctxs[0]->stream);
+    }
     if (count == 8) {
         // launch 2 hosts the culling when its tiles sample the pyramid level launch 2 starts with or the one above it (not a level the quad blocks make)
         bool useHiZ = false;
@@ -220,6 +234,32 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr, cullLevel);
 }
 
+// the seven passes in front of a band's histogram all-reduce - per-tile histogram, reset, combine, pyramid, depth downscale, the two culling passes - as two launches
+// (fused_front.h; the backend has sunk the all-reduce callback and the exposure pass behind them)
+static int launchBandFront(const PassCtx* const* ctxs, size_t count) {
+    if (count != 7) return kUseGeneralKernel;
+    HistParams hp;
+    if (int rc = prepare(*ctxs[0], &hp)) return rc;
+    if (hp.gridX == 0 || hp.gridY == 0) return kUseGeneralKernel;
+    ResetCombinePlan rp;
+    if (int rc = prepareResetCombine(ctxs + 1, &rp)) return rc;
+    if (rp.perTileBase != hp.perTile) return kUseGeneralKernel; // the combine must read what the per-tile pass writes
+    fasthiz::Plan zp;
+    if (int rc = fasthiz::prepare(*ctxs[3], ctxs[4], &zp)) return rc;
+    if (!zp.perTile) return kUseGeneralKernel; // the whole frame's chain has its own front (launchFusedFront)
+    FusedCullParams cull;
+    bool useHiZ = false;
+    ImgView hiz;
+    if (int rc = prepareFusedCulling(*ctxs[5], *ctxs[6], &cull, &useHiZ, &hiz)) return rc;
+    const fasthiz::TileTailParams& t = zp.tileTail;
+    if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel; // the tiles must sample the level launch 2 finishes
+    if (ctxs[0]->pendingFillSlot) if (int rc = ctxs[0]->applyPendingFillsNow()) return rc; // (not registered for the frame's fills: the backend applies them first)
+    const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
+    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX, nullptr);
+    PLR_CHECK_LAUNCH(*ctxs[0]);
+    return launchBandFrontSecond(zp, cull, rp, ctxs[0]->stream);
+}
+
 // ---- exhaustive verification (plr_debug_verify_histogram_thresholds)
 __global__ void verifyKernel(const uint32_t* __restrict__ thresholds, const uint8_t* __restrict__ exact, uint32_t first, uint32_t count, float guessScale, float guessBias,
                              unsigned long long* __restrict__ mismatches) {
@@ -236,6 +276,9 @@ __global__ void verifyKernel(const uint32_t* __restrict__ thresholds, const uint
 static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
 PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
 static int fused_frame_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
+static int fused_band_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchBandFront(ctxs, count); }
+PLR_REGISTER_FUSION("band front: histogram + reset + combine || per-tile depth pyramid || camera culling", fused_band_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+                    "depthHiZPyramid.comp", "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 static int fused_frame_front_and_culling(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
 PLR_REGISTER_FUSION_TAKES_FILLS("frame front: histogram + exposure chain || depth pyramid || camera culling", fused_frame_front_and_culling, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
                     "preExposeLights.comp", "depthHiZPyramid.comp", "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
