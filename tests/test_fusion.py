@@ -69,6 +69,61 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", [(0, 720), (128, 576)])
+def test_gpu_the_front_of_a_band_as_two_launches_changes_no_byte(backend, rows):
+    """Band rendering records histogramPerTile, reset, combine, [histogram all-reduce callback], preExposeLights, per-tile pyramid, depth downscale, the two culling passes.
+    The callback names the histogram buffer: the backend sinks it and the exposure pass behind the pyramid and the culling (plr_set_pass_fusion_reorder), and the seven
+    passes in front of it run as two launches (kernels_fast/fused_front.h "a BAND's front"). Every image and buffer equals the unfused frame's, over frames of
+    feedback, for a band that is the whole frame and for one in its middle (1280 x 720; compared on the band's rows)."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    w, h, n_frames = 1280, 720, 3
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=512)
+    inputs = None
+    results, fused_counts = {}, {}
+    names = ["swapchain", "post1", "pyramid", "depthHalfRes", "giHistoryYSH0", "giHistoryCoCg0", "taaHistory0", "taaHistory1"]
+    try:
+        backend.setMathMode(True)
+        for mode, (fusion, reorder) in {"two launches": (2, True), "recorded order": (2, False), "unfused": (0, False)}.items():
+            backend.setPassFusion(fusion)
+            backend.setPassFusionReorder(reorder)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64, band_row_begin=rows[0], band_row_end=rows[1])
+            fp.set_exchange_callback(lambda exchange_id, stream: None)  # a band with no neighbour to exchange with: the recording is what matters here
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                fused_counts[mode] = backend.getPassFusion()[1]
+                if fusion:
+                    general, which = backend.getGeneralKernelExecutions()
+                    assert general == 0, which
+                def band_rows_of(name):  # the band's own rows of an image (outside them a launch may or may not write its halo tiles: whole 64-row tiles in the fused front)
+                    wi, hi, _, bpp = backend.mipSize(fp.image(name), 0)
+                    a = backend.downloadImage(fp.image(name), 0, np.uint8).reshape(hi, wi * bpp)
+                    return a[rows[0] * hi // h:rows[1] * hi // h].copy()
+                out.append([band_rows_of(name) for name in names] +
+                           [backend.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint8).copy(),
+                            backend.downloadStorageBuffer(fp.storage_buffer("sdfCulledTiles"), 4096, dtype=np.uint8).copy()])
+            results[mode] = out
+            fp.destroy()
+    finally:
+        backend.setPassFusion(2)
+        backend.setPassFusionReorder(True)
+        backend.setMathMode(False)
+    print("FUSION band front rows %s: executions inside fused launches %s" % (rows, fused_counts), flush=True)
+    assert fused_counts["unfused"] == 0
+    assert fused_counts["two launches"] >= fused_counts["recorded order"] + 1, fused_counts  # seven executions in one group instead of a pair (reset + combine) and a four
+    what = names + ["light buffer", "histogram", "culled tiles"]
+    for mode in ("two launches", "recorded order"):
+        for f in range(n_frames):
+            for a, b, name in zip(results[mode][f], results["unfused"][f], what):
+                assert np.array_equal(a, b), "%s differs (%s), frame %d, band rows %s" % (name, mode, f, rows)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w,h", [(1280, 720), (648, 360)])
 def test_gpu_fusion_across_the_callers_pass_order_changes_no_byte(backend, w, h):
     """With the input producers recorded as compute passes (RenderFrontend.cpp:342-405 order) the transmission / multiscatter / sky LUT passes and the
