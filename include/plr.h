@@ -242,6 +242,21 @@ int plr_set_stream_overlap(int enabled);
  * the last plr_render_frame launched on the tail stream. plr_get_last_frame_gpu_time covers the launch stream only. */
 int plr_set_async_tail(int enabled);
 int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions);
+/* Early parts (round 6; default OFF - measured slower on MI355X, see the end of this comment; PLR_EARLY_PARTS=1 turns it on; PLR_MATH_FAST with pass fusion only). A fused launch may have a part that depends on none of
+ * the frame's intermediate results: the deferred shade's DIRECT lighting (triangle.frag:146-290 - material, cascade select, twelve-tap PCF, diffuse + GGX +
+ * multiscattering response to the sun, the froxel lookup) needs the G-buffer, the shadow cascades and the LUTs, not the GI chain recorded in front of it
+ * (RenderFrontend.cpp:342-405: the shade is recorded behind trace, denoise and upscale). The backend issues such a part as a launch of its own on a third stream
+ * as soon as the resources recorded with the executions allow - behind the last execution or buffer fill of the frame that writes anything it reads, at the
+ * frame's start if there is none - beside the executions recorded in between, and the sequence itself then runs what is left (upscale + indirect + fog + pack).
+ * The recorded executions, their order and their outputs' meaning are unchanged; the colour target is within one R11G11B10 code of the single launch
+ * (tests/test_fusion.py), every other image byte-identical. out_early_launches: early parts launched by the last plr_render_frame (0: nothing to run beside,
+ * a decision-signature buffer is set, the launcher declined the bindings). enabled = 2: the early part is split off even when nothing is recorded that it could run
+ * beside (the parity tests hold the two-launch form to the oracle on a frame that records the pair alone).
+ * Measured (profiles/r06_overlap.txt, 4K frame): one launch 0.705 ms; two launches back to back 0.814 (direct 168 us + combine 92 us against 176 us fused: the 36-byte
+ * record per pixel makes both halves HBM-heavy); direct lighting beside trace .. second spatial filter 0.770, from the frame's start 0.79 - the kernels it runs beside
+ * lose what it gains (trace 104 -> 191 us, spatial filter 104 -> 122): a latency-bound kernel's waves hold the register file, there is no idle capacity to fill. */
+int plr_set_early_parts(int enabled);
+int plr_get_early_parts(int* out_enabled, uint32_t* out_early_launches);
 /* Pass fusion (default level 2, PLR_MATH_FAST only): where the recorded frame contains certain shaders back to back - histogramReset +
  * histogramCombineTiles + preExposeLights; depthHiZPyramid + depthDownscale; sdfCameraFrustumCulling + sdfCameraTileCulling; applyBloom +
  * tonemapping; a GI pass followed by the spatial filter that reads its output - the backend covers them with fewer kernel launches. The

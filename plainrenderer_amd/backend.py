@@ -225,7 +225,7 @@ EXPORTED_SYMBOLS = [
     "plr_get_last_frame_cpu_time", "plr_get_image_description", "plr_set_pass_timing", "plr_get_last_frame_gpu_time",
     "plr_replay_frame", "plr_upload_image", "plr_download_image", "plr_download_storage_buffer", "plr_download_uniform_buffer",
     "plr_get_image_device_pointer", "plr_get_storage_buffer_device_pointer", "plr_get_stream", "plr_get_launch_stream", "plr_copy_device_memory", "plr_read_device_memory", "plr_write_device_memory", "plr_get_supported_shaders",
-    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_verify_r11g11b10_fast", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_pass_fusion_reorder", "plr_get_general_kernel_executions", "plr_get_edge_signal", "plr_set_async_tail", "plr_get_async_tail", "plr_set_host_callback_execution", "plr_set_host_callback_execution_on", "plr_upload_image_rows",
+    "plr_debug_math_eval", "plr_debug_codec_eval", "plr_debug_sampler_eval", "plr_debug_sky_lut_eval", "plr_debug_verify_histogram_thresholds", "plr_debug_verify_r11g11b10_fast", "plr_debug_set_decision_signature", "plr_debug_read_decision_signature", "plr_set_math_mode", "plr_get_math_mode", "plr_set_stream_overlap", "plr_get_stream_overlap", "plr_set_pass_fusion", "plr_get_pass_fusion", "plr_set_pass_fusion_reorder", "plr_get_general_kernel_executions", "plr_get_edge_signal", "plr_set_async_tail", "plr_get_async_tail", "plr_set_early_parts", "plr_get_early_parts", "plr_set_host_callback_execution", "plr_set_host_callback_execution_on", "plr_upload_image_rows",
     "plr_copy_device_memory_2d", "plr_set_global_descriptor_set_layout",
 ]
 
@@ -572,6 +572,16 @@ class RenderBackend:
         e, n = C.c_int(), C.c_uint32()
         self._check(self.lib.plr_get_async_tail(C.byref(e), C.byref(n)))
         return bool(e.value), n.value
+
+    def setEarlyParts(self, enabled):
+        """early parts of fused launches (the deferred shade's direct lighting as a launch of its own beside the GI chain; include/plr.h)"""
+        self._check(self.lib.plr_set_early_parts(C.c_int(int(enabled))))
+
+    def getEarlyParts(self):
+        """-> (level: 0 off, 1 on, 2 forced; early parts launched by the last frame)"""
+        e, n = C.c_int(), C.c_uint32()
+        self._check(self.lib.plr_get_early_parts(C.byref(e), C.byref(n)))
+        return e.value, n.value
 
     def setDecisionSignature(self, words):
         """decision-signature buffer for the next single-pass frame (include/plr.h); 0 frees it"""

@@ -72,6 +72,8 @@ struct FusionEntry {
     FusedLaunchFn fn;
     bool writesSignatures = false;
     bool takesFills = false; // handles PassCtx::pendingFillSlot of its first execution itself (backend.h)
+    EarlyLaunchFn early = nullptr; // the sequence's early part (backend.h EarlyPart), or null
+    std::string earlyLabel;
 };
 static std::vector<FusionEntry>& fusions() {
     static std::vector<FusionEntry> r;
@@ -89,6 +91,10 @@ FusionRegistrar::FusionRegistrar(const char* label, std::initializer_list<const 
     auto pos = list.begin();
     while (pos != list.end() && pos->shaders.size() >= e.shaders.size()) ++pos;
     list.insert(pos, std::move(e));
+}
+
+EarlyPartRegistrar::EarlyPartRegistrar(FusedLaunchFn fused, EarlyLaunchFn early, const char* label) {
+    for (FusionEntry& e : fusions()) if (e.fn == fused) { e.early = early; e.earlyLabel = label ? label : "early part"; }
 }
 
 struct ConsumerLink { std::string producer, consumer; };
@@ -317,6 +323,17 @@ struct Backend {
     hipEvent_t tailDone = nullptr, tailStart = nullptr;
     uint8_t* pendingFillSlot = nullptr;     // this frame's fill table, not applied yet (applyPendingFillsNow)
     hipEvent_t pendingFillEvent = nullptr;  // its slot's completion event, recorded behind the launch that applies it
+
+    // early parts of fused sequences (backend.h EarlyPart; plr_set_early_parts): their stream, the event the launch stream records for it when the early part has to
+    // start behind executions of this frame, the event behind the early part. mainOps counts what has been put on the launch stream (launches, callbacks, copies):
+    // the tail's start event of the previous frame (tailStartOps = the count when it was recorded, tailStartCoversLate = it was recorded behind that frame's late
+    // part) orders the early stream behind the previous frame's late part for free when nothing has gone onto the launch stream since
+    hipStream_t earlyStream = nullptr;
+    int earlyParts = 0;                  // plr_set_early_parts: 0 off (default: measured slower, profiles/r06_overlap.txt), 1 on, 2 on even with nothing to run beside (tests)
+    uint32_t lastEarly = 0;              // early parts launched in the last frame
+    uint64_t mainOps = 0, tailStartOps = ~0ull;
+    bool tailStartCoversLate = false, lateLaunchedThisFrame = false;
+    std::vector<const void*> lastFillDsts; // destinations of the buffer fills flushed for the frame being launched
 
     std::vector<Access> tailPending;
     bool asyncTail = true;               // plr_set_async_tail
@@ -646,7 +663,12 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
         g_first.compare_exchange_strong(none, g); // the process's first backend: what threads without a backend of their own use
     }
     g->device = device_ordinal;
-    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    int leastPriority = 0, greatestPriority = 0; // (numerically: greatest <= least)
+    if (hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority) != hipSuccess) { (void)hipGetLastError(); leastPriority = greatestPriority = 0; }
+    static const int mainPriority = std::getenv("PLR_MAIN_PRIORITY") ? std::atoi(std::getenv("PLR_MAIN_PRIORITY")) : 0;   // experiment hooks: 1 = the launch stream at the greatest priority
+    static const int earlyPriority = std::getenv("PLR_EARLY_PRIORITY") ? std::atoi(std::getenv("PLR_EARLY_PRIORITY")) : 0; // 1 = the early stream at the least priority
+    if (mainPriority) HIP_TRY(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, greatestPriority));
+    else HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&g->frameStart));
     HIP_TRY(hipEventCreate(&g->frameEnd));
     for (auto& slot : g->pinnedSlots) HIP_TRY(hipEventCreateWithFlags(&slot.free, hipEventDisableTiming));
@@ -654,6 +676,10 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipStreamCreateWithFlags(&g->tailStream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g->tailDone, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&g->tailStart, hipEventDisableTiming));
+    if (earlyPriority) HIP_TRY(hipStreamCreateWithPriority(&g->earlyStream, hipStreamNonBlocking, leastPriority));
+    else HIP_TRY(hipStreamCreateWithFlags(&g->earlyStream, hipStreamNonBlocking));
+    if (std::getenv("PLR_STREAM_DEBUG")) fprintf(stderr, "[plr streams] priority range least %d greatest %d; main %s, early %s\n", leastPriority, greatestPriority, mainPriority ? "greatest" : "default", earlyPriority ? "least" : "default");
+    if (const char* ep = std::getenv("PLR_EARLY_PARTS")) g->earlyParts = std::min(std::max(std::atoi(ep), 0), 2);
     // the edge signal is waited for with hipStreamWaitValue32: asked of the device, not assumed (without it plr_get_edge_signal reports no signal and a caller orders
     // behind the launch stream - VERDICT r04 item 5)
     int canWaitValue = 0;
@@ -683,6 +709,7 @@ int plr_shutdown(void) {
     if (g->tailStream) hipStreamDestroy(g->tailStream);
     if (g->tailDone) hipEventDestroy(g->tailDone);
     if (g->tailStart) hipEventDestroy(g->tailStart);
+    if (g->earlyStream) hipStreamDestroy(g->earlyStream);
     for (void* c : g->globalCopies) if (c) hipFree(c);
     if (g->edgeSignal) hipFree(g->edgeSignal);
     if (g->edgeCounter) hipFree(g->edgeCounter);
@@ -734,6 +761,7 @@ int plr_copy_device_memory(void* dst, const void* src, size_t size) {
     if (size == 0) return PLR_OK;
     if (!dst || !src) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory: null pointer");
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToDevice, g->stream));
+    g->mainOps++;
     touchAddress(dst);
     return PLR_OK;
 }
@@ -742,6 +770,7 @@ int plr_copy_device_memory_2d(void* dst, size_t dst_pitch, const void* src, size
     if (width_bytes == 0 || rows == 0) return PLR_OK;
     if (!dst || !src || dst_pitch < width_bytes || src_pitch < width_bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "plr_copy_device_memory_2d: null pointer or a pitch smaller than the width");
     HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, g->stream));
+    g->mainOps++;
     touchAddress(dst);
     return PLR_OK;
 }
@@ -1038,6 +1067,7 @@ static int applyPendingFillsNow() {
     if (!g->pendingFillSlot) return PLR_OK;
     applyFillsKernel<<<1, 256, 0, g->stream>>>(g->pendingFillSlot, 0);
     HIP_TRY(hipGetLastError());
+    g->mainOps++;
     g->pendingFillSlot = nullptr;
     if (g->pendingFillEvent) { HIP_TRY(hipEventRecord(g->pendingFillEvent, g->stream)); g->pendingFillEvent = nullptr; }
     return PLR_OK;
@@ -1096,6 +1126,7 @@ static int flushFills() {
                 count = 0;
             }
             HIP_TRY(hipMemcpyAsync(f.dst, host + payloadBase + f.stagingOffset, f.size, hipMemcpyHostToDevice, g->stream));
+            g->mainOps++;
             usedCopyEngine = true;
         } else {
             entries[count++] = FillEntry{(uint64_t)(uintptr_t)f.dst, (uint32_t)(payloadBase + f.stagingOffset), (uint32_t)f.size};
@@ -1117,6 +1148,7 @@ static int flushFills() {
             // a partial fill of the global buffer: the copy must be the whole buffer as it is after the fills
             if (count) { *(uint32_t*)host = count; applyFillsKernel<<<1, 256, 0, g->stream>>>(host, 0); HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(g->stream)); count = 0; }
             HIP_TRY(hipMemcpyAsync(g->globalCopies[next], globalDev, sizeof(GlobalUbo), hipMemcpyDeviceToDevice, g->stream));
+            g->mainOps++;
         }
         g->globalCopyIndex = next;
     }
@@ -1128,15 +1160,18 @@ static int flushFills() {
         *(volatile uint64_t*)(host + 8) = 0;
         applyFillsKernel<<<1, 256, 0, g->stream>>>(host, slot.serial);
         HIP_TRY(hipGetLastError());
+        g->mainOps++;
     } else {
         slot.eventPending = true; // its event is recorded behind whatever reads the slot last
         if (count && !usedCopyEngine) { *(uint32_t*)host = count; g->pendingFillSlot = host; g->pendingFillEvent = slot.free; } // applied by the frame's first launch
         else {
             if (count) { *(uint32_t*)host = count; applyFillsKernel<<<1, 256, 0, g->stream>>>(host, 0); HIP_TRY(hipGetLastError()); }
+            g->mainOps++;
             HIP_TRY(hipEventRecord(slot.free, g->stream)); // a copy-engine transfer read the slot too (set-up frames): an event covers both
         }
     }
     slot.busy = true;
+    for (const auto& f : g->fills) g->lastFillDsts.push_back(f.dst);
     g->fills.clear();
     g->fillData.clear();
     return PLR_OK;
@@ -1296,6 +1331,7 @@ static void prepareCtx(Execution& x, hipStream_t stream, const GlobalUbo* global
     x.ctx.globalHost = globalPtr && g->globalShadowValid ? &g->globalShadow : nullptr;
     x.ctx.elidableStorage = 0;
     x.ctx.elidedStorage = 0;
+    x.ctx.earlyPartDone = false;
     x.ctx.firstRows[0] = x.firstRows[0]; x.ctx.firstRows[1] = x.firstRows[1];
     x.ctx.firstCols[0] = x.firstCols[0]; x.ctx.firstCols[1] = x.firstCols[1];
     x.ctx.edgeSignal = nullptr; x.ctx.edgeCounter = nullptr; x.ctx.edgeValue = 0; x.ctx.edgeSignalHonoured = false;
@@ -1393,6 +1429,7 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     touchAccesses(x.access); // the images it writes have new contents from here on (contentVersionOf)
     const bool signalled = x.edgesFirst() && g->edgeSignal;
     if (signalled) { x.ctx.edgeSignal = g->edgeSignal; x.ctx.edgeCounter = g->edgeCounter; x.ctx.edgeValue = ++g->edgeSerial; }
+    if (stream == g->stream) g->mainOps++;
     int rc = (g->mathMode == PLR_MATH_FAST && p.fast) ? p.fast(x.ctx) : kUseGeneralKernel;
     if (rc == kUseGeneralKernel) {
         x.ctx.edgeSignalHonoured = false; // (a fast launcher that ordered its blocks and then declined: the general kernel raises nothing - ADVICE r04)
@@ -1408,6 +1445,116 @@ static int launchExecution(Execution& x, hipStream_t stream, const GlobalUbo* gl
     if (signalled && !x.ctx.edgeSignalHonoured) HIP_TRY(hipStreamWriteValue32(stream, g->edgeSignal, x.ctx.edgeValue, 0));
     if (timed) if (int trc = endSegment()) return trc;
     noteElidedImages(x);
+    return PLR_OK;
+}
+
+// ---- early parts of fused sequences (backend.h EarlyPart). planEarlyParts runs once per launchAll, after the executions have their final order: for every
+// sequence whose fused launcher has an early part and accepts the bindings it finds the earliest position `at` of the recorded list where that part may start -
+// behind the last execution that writes (or the last host callback that may write) anything the early kernels read - and keeps the plan only if at least one
+// compute execution lies between that position and the sequence: something to run beside. launchEarlyPartsAt(i) issues the plans of position i on the early
+// stream before execution i is launched; tryFusedLaunch makes the launch stream wait for the part's event and tells the launcher (PassCtx::earlyPartDone).
+struct EarlyPlan { size_t at = 0, group = 0, count = 0; const FusionEntry* f = nullptr; hipEvent_t done = nullptr; bool launched = false; };
+static thread_local std::vector<EarlyPlan> g_earlyPlans;
+static bool fusionNamesMatch(const FusionEntry& f, size_t i, size_t n) {
+    const size_t m = f.shaders.size();
+    if (i + m > n || m > 8) return false;
+    for (size_t k = 0; k < m; k++) {
+        const Execution& y = g->executions[i + k];
+        if (y.callback || y.edgesFirst() || g->passes[y.pass]->shader != f.shaders[k]) return false;
+    }
+    return true;
+}
+static void planEarlyParts(const GlobalUbo* globalPtr) {
+    g_earlyPlans.clear();
+    if (!g->earlyParts || !g->fusion || g->mathMode != PLR_MATH_FAST || g->debugSig || g->overlap || !g->earlyStream) return;
+    const size_t n = g->executions.size();
+    std::vector<const void*> reads;
+    for (size_t i = 0; i < n; i++) {
+        if (g->executions[i].callback) continue;
+        const FusionEntry* f = nullptr;
+        for (const FusionEntry& e : fusions()) if (fusionNamesMatch(e, i, n)) { f = &e; break; } // the entry tryFusedLaunch tries first
+        if (!f || !f->early) continue;
+        const size_t m = f->shaders.size();
+        bool plain = true;
+        for (size_t k = 0; k < m; k++) plain = plain && !g->executions[i + k].asyncTail;
+        if (!plain) continue;
+        const PassCtx* ctxs[8];
+        for (size_t k = 0; k < m; k++) { prepareCtx(g->executions[i + k], g->earlyStream, globalPtr); ctxs[k] = &g->executions[i + k].ctx; }
+        reads.clear();
+        EarlyPart query;
+        query.mode = EarlyPart::Query;
+        query.reads = &reads;
+        if (f->early(ctxs, m, query) != 0) { g_err.clear(); continue; } // no early part for these bindings (an error is reported by the fused launch itself)
+        auto isRead = [&](const void* key) { return key && std::find(reads.begin(), reads.end(), key) != reads.end(); };
+        size_t at = i;
+        while (at > 0) {
+            const Execution& y = g->executions[at - 1];
+            if (y.callback && !y.callbackAccessKnown) break; // may write anything
+            bool writes = false;
+            for (const Access& a : y.access) writes = writes || (a.write && a.key != kBindlessKey && isRead(a.key));
+            if (writes) break;
+            at--;
+        }
+        // a pending buffer fill of something the part reads is applied by (or in front of) the frame's first launch: the part starts behind that
+        bool filled = false;
+        for (const void* dst : g->lastFillDsts) filled = filled || isRead(dst);
+        if (filled && at == 0) at = 1;
+        // what the asynchronous tail of the previous frame still writes: not worth a join
+        bool tailHazard = false;
+        for (const void* key : reads) tailHazard = tailHazard || (key && hazardWithTail({Access{key, false}}));
+        size_t beside = 0;
+        for (size_t j = at; j < i; j++) beside += g->executions[j].callback ? 0 : 1;
+        // experiment hook (tools/early_overlap.sh): PLR_EARLY_AT=<substring of a pass name> starts the part in front of the first execution at or behind the legal
+        // position whose pass name contains it ("self": in front of the sequence itself = the two launches back to back)
+        static const char* forcedAt = std::getenv("PLR_EARLY_AT");
+        if (forcedAt && *forcedAt) {
+            size_t j = at;
+            while (j < i && (g->executions[j].callback || g->passes[g->executions[j].pass]->name.find(forcedAt) == std::string::npos)) j++;
+            at = j;
+        }
+        beside = 0;
+        for (size_t j = at; j < i; j++) beside += g->executions[j].callback ? 0 : 1;
+        if (tailHazard || (g->earlyParts < 2 && (at >= i || beside == 0))) continue;
+        EarlyPlan plan;
+        plan.at = at; plan.group = i; plan.count = m; plan.f = f;
+        g_earlyPlans.push_back(plan);
+        i += m - 1;
+    }
+}
+static int launchEarlyPartsAt(size_t index, const GlobalUbo* globalPtr, bool timed) {
+    for (EarlyPlan& plan : g_earlyPlans) {
+        if (plan.at != index || plan.launched) continue;
+        // order the early stream behind what the part depends on: everything launched so far in this frame - or, at the frame's start, the previous frame's late
+        // part, which read the scratch memory this part overwrites: the tail's start event of that frame covers it for free (an event record is a barrier packet
+        // of several microseconds on the launch stream) when nothing has gone onto the launch stream since
+        if (index == 0 && g->tailStartCoversLate && g->tailStartOps == g->mainOps) HIP_TRY(hipStreamWaitEvent(g->earlyStream, g->tailStart, 0));
+        else {
+            hipEvent_t start;
+            if (int rc = orderEvent(&start)) return rc;
+            HIP_TRY(hipEventRecord(start, g->stream));
+            HIP_TRY(hipStreamWaitEvent(g->earlyStream, start, 0));
+        }
+        const PassCtx* ctxs[8];
+        for (size_t k = 0; k < plan.count; k++) { prepareCtx(g->executions[plan.group + k], g->earlyStream, globalPtr); ctxs[k] = &g->executions[plan.group + k].ctx; }
+        hipStream_t previous = g->curStream;
+        g->curStream = g->earlyStream;
+        if (timed) {
+            std::string name;
+            for (size_t k = 0; k < plan.count; k++) name += (k ? " + " : "") + g->passes[g->executions[plan.group + k].pass]->name;
+            name += " (" + plan.f->earlyLabel + ", early stream)";
+            if (int trc = beginSegment(g->fusedNames.insert(name).first->c_str())) return trc;
+        }
+        EarlyPart part;
+        part.mode = EarlyPart::Launch;
+        const int rc = plan.f->early(ctxs, plan.count, part);
+        if (rc) { g_err = "early part of fused launch '" + plan.f->label + "': " + g_err; return rc < 0 ? rc : PLR_ERR_HIP; }
+        if (timed) if (int trc = endSegment()) return trc;
+        g->curStream = previous;
+        if (int erc = orderEvent(&plan.done)) return erc;
+        HIP_TRY(hipEventRecord(plan.done, g->earlyStream));
+        plan.launched = true;
+        g->lastEarly++;
+    }
     return PLR_OK;
 }
 
@@ -1427,6 +1574,12 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         const PassCtx* ctxs[8];
         if (n > 8) continue;
         for (size_t k = 0; k < n; k++) { prepareCtx(g->executions[i + k], stream, globalPtr); ctxs[k] = &g->executions[i + k].ctx; }
+        EarlyPlan* early = nullptr;
+        for (EarlyPlan& plan : g_earlyPlans) if (plan.launched && plan.group == i && plan.f == &f) early = &plan;
+        if (early) {
+            HIP_TRY(hipStreamWaitEvent(stream, early->done, 0));
+            for (size_t k = 0; k < n; k++) g->executions[i + k].ctx.earlyPartDone = true;
+        }
         if (g->fusion >= 2) {
             // which storage images of the sequence does nothing else in this frame touch? (keys are allocation bases: an image with all its mips)
             for (size_t k = 0; k < n; k++) {
@@ -1473,6 +1626,7 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
             first.ctx.pendingFillSlot = nullptr; first.ctx.applyPendingFillsNow = nullptr;
         }
         if (rc == kUseGeneralKernel) {
+            if (early) { g_err = "fused launch '" + f.label + "' declined the bindings its early part accepted"; return PLR_ERR_HIP; }
             if (timed) { g->segments.pop_back(); g->eventsUsed -= 1; } // the opening event stays recorded on the stream; its slot is reused
             continue;
         }
@@ -1481,6 +1635,8 @@ static int tryFusedLaunch(size_t i, size_t last, hipStream_t stream, const Globa
         for (size_t k = 0; k < n; k++) noteElidedImages(g->executions[i + k]);
         *covered = n;
         g->lastFused += (uint32_t)n;
+        if (stream == g->stream) g->mainOps++;
+        if (early) g->lateLaunchedThisFrame = true;
         return PLR_OK;
     }
     return PLR_OK;
@@ -1620,12 +1776,16 @@ static int launchAll(bool timed) {
     auto closeTail = [&]() -> int { if (tailDirty) { HIP_TRY(hipEventRecord(g->tailDone, g->tailStream)); tailDirty = false; } return PLR_OK; };
     gatherFusionGroups();
     linkConsumers(globalPtr);
+    g->lastEarly = 0;
+    g->lateLaunchedThisFrame = false;
+    planEarlyParts(globalPtr);
     std::vector<PlanNode> plan(n);
     std::vector<hipEvent_t> done(n, nullptr);
     size_t i = 0;
     while (i < n) {
         Execution& x = g->executions[i];
         if (x.callback) {
+            if (int erc = launchEarlyPartsAt(i, globalPtr, timed)) return erc;
             // everything before a callback has joined the main stream (end of the previous run)
             // a host callback may touch anything (halo exchange on raw pointers): the asynchronous tail joins first - unless the callback was
             // recorded with the resources it touches and shares none with the tail
@@ -1640,6 +1800,7 @@ static int launchAll(bool timed) {
             if (x.callbackAccessKnown) { if (int rc = refuseStaleReads(x, nullptr, 0)) return rc; }
             if (x.callbackAccessKnown) touchAccesses(x.access);
             else g->contentVersion.clear(); // may have written anything: every image gets a new version at its next query
+            g->mainOps++;
             const int crc = x.callback(x.callbackUser, (void*)g->stream);
             if (crc) return setErr(crc, "host callback '" + std::string(x.callbackName) + "' failed with code " + std::to_string(crc));
             if (timed) if (int rc = endSegment()) return rc;
@@ -1650,6 +1811,7 @@ static int launchAll(bool timed) {
         while (last < n && !g->executions[last].callback) last++;
         if (!g->overlap) {
             while (i < last) {
+                if (int erc = launchEarlyPartsAt(i, globalPtr, timed)) return erc;
                 // executions flagged async_tail (plr.h) go to the tail stream: behind everything launched before them, beside everything launched
                 // after them that shares no resource with them - the next frame's passes included
                 const bool async = tailAllowed && g->executions[i].asyncTail;
@@ -1661,6 +1823,8 @@ static int launchAll(bool timed) {
                     if (!tailOpen) {
                         HIP_TRY(hipEventRecord(g->tailStart, g->stream));
                         HIP_TRY(hipStreamWaitEvent(g->tailStream, g->tailStart, 0));
+                        g->tailStartOps = g->mainOps; // (launchEarlyPartsAt: may the next frame's early part order itself behind this event?)
+                        g->tailStartCoversLate = g->lateLaunchedThisFrame;
                         tailOpen = true;
                     }
                     stream = g->tailStream;
@@ -1689,6 +1853,7 @@ static int launchAll(bool timed) {
                     g->lastAsync += (uint32_t)count;
                 } else tailOpen = false; // the main stream moves on: a later tail execution must be ordered behind this one
                 if (!covered) if (int rc = launchExecution(g->executions[i], stream, globalPtr, timed)) return rc;
+                for (size_t k = i + 1; k < i + count; k++) if (int erc = launchEarlyPartsAt(k, globalPtr, timed)) return erc; // positions inside a fused launch: right behind it
                 i += count;
             }
             continue;
@@ -1752,6 +1917,7 @@ static int launchAll(bool timed) {
 int plr_render_frame(int /*present_to_screen*/) {
     NEED_INIT();
     const auto t0 = std::chrono::steady_clock::now();
+    g->lastFillDsts.clear();
     int rc = flushFills();
     if (rc) return rc;
     rc = flushBindless();
@@ -1827,6 +1993,18 @@ int plr_get_async_tail(int* out_enabled, uint32_t* out_async_executions) {
     return PLR_OK;
 }
 
+int plr_set_early_parts(int enabled) {
+    NEED_INIT();
+    g->earlyParts = std::min(std::max(enabled, 0), 2);
+    return PLR_OK;
+}
+int plr_get_early_parts(int* out_enabled, uint32_t* out_early_launches) {
+    NEED_INIT();
+    if (out_enabled) *out_enabled = g->earlyParts;
+    if (out_early_launches) *out_early_launches = g->lastEarly;
+    return PLR_OK;
+}
+
 int plr_set_stream_overlap(int enabled) {
     NEED_INIT_JOINED();
     g->overlap = enabled != 0;
@@ -1841,6 +2019,7 @@ int plr_get_stream_overlap(int* out_enabled, uint32_t* out_overlapped_executions
 
 int plr_replay_frame(uint32_t count, float* out_total_gpu_ms) {
     NEED_INIT_JOINED();
+    g->lastFillDsts.clear();
     int rc = flushFills();
     if (rc) return rc;
     rc = flushBindless();

@@ -85,6 +85,8 @@ struct PassCtx {
     // image this execution writes, possibly with host callbacks (halo exchanges) and further executions of this same pass in between; null if
     // there is none, if another pass writes the image first, in PLR_MATH_EXACT, with pass fusion off or a signature buffer set
     const PassCtx* consumer = nullptr;
+    // set by the backend on the contexts of a fused sequence whose EARLY PART (EarlyPart below) it has launched in this frame: the fused launcher issues the rest only
+    mutable bool earlyPartDone = false;
     uint64_t frameSerial = 0;             // serial of this plr_render_frame call, unique in the process: lets a pass's host-side bookkeeping tell this frame's entries from stale ones
     const std::vector<SpecConstant>* spec = nullptr;
     std::string* err = nullptr;
@@ -298,6 +300,27 @@ struct FusionRegistrar {
 #define PLR_REGISTER_FUSION_WITH_SIGNATURES(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn, true)
 // the launcher handles PassCtx::pendingFillSlot of its first execution (see there)
 #define PLR_REGISTER_FUSION_TAKES_FILLS(label, fn, ...) static ::plr::FusionRegistrar plr_fusion_##fn(label, {__VA_ARGS__}, fn, false, true)
+
+// EARLY PART of a fused sequence (round 6; plr_set_early_parts). A fused launcher may split off the work of its passes that depends on none of the frame's
+// intermediate results - the deferred shade's direct lighting needs the G-buffer, the shadow cascades and the LUTs, but nothing of the GI chain recorded in front
+// of it - as a launch of its own that the backend issues on the EARLY STREAM as soon as the recorded resources allow: behind the last execution of the frame (or
+// pending buffer fill) that writes anything the early kernels read, beside everything recorded between that point and the sequence itself. The boundary does not
+// change: the caller records the same executions in the same order; what changes is when a part of one of them starts.
+//   Query:  the launcher validates the bindings (no launch, no allocation) and lists the allocations its early kernels READ (image mip-0 addresses, buffer
+//           addresses; the global uniform block must be taken from PassCtx::globalHost, by value - the device copy is filled by the frame's first launch).
+//           Returns 0, or kUseGeneralKernel: no early part for these bindings (the sequence runs as one fused launch, as without this feature).
+//   Launch: PassCtx::stream of the contexts is the early stream. The early kernels write nothing but the pass's scratch memory.
+// When the sequence's turn comes, the launch stream waits for the early part and the fused launcher is called with PassCtx::earlyPartDone set on its contexts.
+struct EarlyPart {
+    enum Mode { Query, Launch } mode = Query;
+    std::vector<const void*>* reads = nullptr;
+};
+typedef int (*EarlyLaunchFn)(const PassCtx* const* ctxs, size_t count, EarlyPart& part);
+struct EarlyPartRegistrar {
+    EarlyPartRegistrar(FusedLaunchFn fused, EarlyLaunchFn early, const char* label);
+};
+// after the PLR_REGISTER_FUSION* of `fusedFn`, in the same translation unit
+#define PLR_REGISTER_EARLY_PART(fusedFn, earlyFn, label) static ::plr::EarlyPartRegistrar plr_early_part_##earlyFn(fusedFn, earlyFn, label)
 
 // Fusion ACROSS the recorded order: when an execution of `producer` is launched, PassCtx::consumer points at the first later execution of
 // `consumer` that samples one of its storage images. The producer's fast launcher may then do part of the consumer's work on the rows it

@@ -320,11 +320,20 @@ PLR_DI vec3 decodeNormal(uint32_t texel) {
     return raw * rsqf(fmax1(dot(raw, raw), 1e-30f));
 }
 
-// one geometry pixel (depth != 0) of the deferred shade: returns the R11G11B10 colour; *sigWord = decision signature (oracle/oracle.h)
-template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
-PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const ViewRay& vr, const PixelInputs& in, uint32_t* sigWord) {
+// ---- one geometry pixel (depth != 0) of the deferred shade, in three parts (round 6: the direct lighting can run as a launch of its own, see shadeDirectKernel):
+//  shadeDirect   triangle.frag:146-290 - material, view / half vectors, cascade select + PCF, diffuse + GGX + multiscattering lobe of the sun. Needs no GI.
+//  shadeIndirect triangle.frag:294-334 - irradiance from the L1 SH, its diffuse and specular response
+//  froxelLookup  volumetricLighting.inc applyVolumetricLighting - the froxel LUT's in-scattering and transmittance at the pixel
+// what the indirect half needs to know about the surface
+struct SurfaceTerms {
+    vec3 N, V, f0, diffuseColor, diffuseBRDFIntegral;
+    float r, NoV, energyOutgoing; // r: after geometric AA; energyOutgoing = brdfLut.y at (r, NoV)
+    vec3 brdfLut;                 // the LUT texel (INDIRECT_TECH 1 reads .x)
+};
+struct DirectOut { vec3 direct; float pixelDepth; vec2 noiseTexel; }; // direct = diffuseDirect + specularDirect for a sun of colour `lightColor`
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA>
+PLR_DI DirectOut shadeDirect(const ShadeParams& P, int px, int py, const ViewRay& vr, const PixelInputs& in, vec3 lightColor, SurfaceTerms* st, uint32_t* sigWord) {
     const GlobalUbo* g = P.g;
-    const float su = vr.su, sv = vr.sv;
     const Surface surf = exactSurface(g, vr.Vn, in.depth);
     const vec3 passPos = surf.passPos;
     const float pixelDepth = surf.pixelDepth;
@@ -402,7 +411,7 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
         }
     }
     *sigWord = (uint32_t)cascadeIndex | ((uint32_t)(sunShadow * 12.f + 0.5f) << 2) | 64u; // cascade, lit PCF taps, geometry (oracle/oracle.h)
-    const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * ld3(P.light->sunColor);
+    const vec3 directLighting = (fmax1(NdotL, 0.f) * sunShadow) * lightColor;
     const vec3 brdfLut = bilinearLut(P.brdfLut, r, NoV).xyz();
 
     vec3 diffuseDirect;
@@ -424,65 +433,89 @@ PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const V
     const vec3 multiScatteringLobe = specularMultiscatteringLobe<MULTISCATTER>(P, r, NoL, f0, singleScatteringLobe, brdfLut);
     const vec3 specularDirect = directLighting * (singleScatteringLobe + multiScatteringLobe);
 
+    st->N = N; st->V = V; st->f0 = f0; st->diffuseColor = diffuseColor; st->diffuseBRDFIntegral = diffuseBRDFIntegral;
+    st->r = r; st->NoV = NoV; st->energyOutgoing = brdfLut.y; st->brdfLut = brdfLut;
+    DirectOut o;
+    o.direct = diffuseDirect + specularDirect;
+    o.pixelDepth = pixelDepth;
+    o.noiseTexel = noiseTexel;
+    return o;
+}
+
+// the response to the traced irradiance (triangle.frag:294-334); ysh / cocg: the (upscaled) indirectDiffuse_Y_SH / _CoCg texels
+template <int MULTISCATTER>
+PLR_DI vec3 shadeIndirect(const ShadeParams& P, const SurfaceTerms& st, uint2 ysh, uint32_t cocg) {
+    const vec3 N = st.N, V = st.V, f0 = st.f0;
+    const float r = st.r, NoV = st.NoV;
+    const vec4 irradiance_Y_SH(halfBitsToFloat(ysh.x & 0xffffu), halfBitsToFloat(ysh.x >> 16), halfBitsToFloat(ysh.y & 0xffffu), halfBitsToFloat(ysh.y >> 16));
+    const vec2 cc(halfBitsToFloat(cocg & 0xffffu), halfBitsToFloat(cocg >> 16));
+    // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
+    const vec4 shN(0.5f, -0.8660254f * N.y, 0.8660254f * N.z, -0.8660254f * N.x);
+    const float irradiance_Y = dot(irradiance_Y_SH, shN);
+    const vec3 irradiance = YCoCgToLinear(vec3(irradiance_Y, cc.x, cc.y));
+    const vec3 diffuseIndirect = irradiance * st.diffuseColor * st.diffuseBRDFIntegral;
+    const vec3 dominantDirection = dominantDirectionFromSH_L1(irradiance_Y_SH);
+    const float dominantDirectionLength = fclamp(sqrtv(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
+    const float r_indirect = fmix(1.f, r, sqrtv(dominantDirectionLength));
+    const vec3 L_indirect = dominantDirection * rcpf(dominantDirectionLength);
+    const vec3 H_indirect = nrm(L_indirect + V);
+    const float NoH_indirect = fmax1(dot(N, H_indirect), 0.f);
+    const float NoL_indirect = fmax1(dot(N, L_indirect), 0.f);
+    const float VoH_indirect = fmax1(dot(V, H_indirect), 0.f);
+    const vec3 single_i = GGXSingleScattering(r_indirect, f0, NoH_indirect, NoV, VoH_indirect, NoL_indirect);
+    const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P, r_indirect, NoL_indirect, f0, single_i, vec3(0.f, st.energyOutgoing, 0.f));
+    const vec3 specularIndirect = (single_i + multi_i) * YCoCgToLinear(vec3(irradiance_Y_SH.x, cc.x, cc.y));
+    return diffuseIndirect + specularIndirect;
+}
+
+// applyVolumetricLighting's LUT sample: .xyz in-scattering, .w transmittance (froxel z = log(linear * (e^3 - 1) + 1) / 3)
+PLR_DI vec4 froxelLookup(const ShadeParams& P, float su, float sv, vec2 noiseTexel, float pixelDepth) {
+    const float nu = su + (noiseTexel.x - 0.5f) * 0.013f, nv = sv + (noiseTexel.y - 0.5f) * 0.013f;
+    const float linear = pixelDepth * rcpf(P.vol->maxDistance);
+    const float z = log2h(linear * 19.0855369f + 1.f) * (0.693147181f / 3.f);
+    const ImgView& vol = P.volumetricLut;
+    int i0, j0, k0; float a, b, c;
+    linearCoord(nu * (float)vol.w, &i0, &a);
+    linearCoord(nv * (float)vol.h, &j0, &b);
+    linearCoord(z * (float)vol.d, &k0, &c);
+    int xb; float a2;
+    edgePair(i0, a, vol.w, &xb, &a2); // the texel pair of every row in one 16-byte load, the x edge in the weight (bilinearLut above)
+    const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
+    const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
+    const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
+    const BufferDesc texels = texelBuffer(vol.ptr, 8u);
+    const uint32_t x0 = (uint32_t)xb;
+    const uint4 q00 = fetch128(texels, z0 + y0 + x0), q01 = fetch128(texels, z0 + y1 + x0), q10 = fetch128(texels, z1 + y0 + x0), q11 = fetch128(texels, z1 + y1 + x0); // [z][y]
+    // the sampler contract's weights and summation order (image.h sampleLinear3D): eight texels x four channels = 32 v_fma_mix_f32 on the fp16 words
+    const float a0 = 1.f - a2, b0 = 1.f - b, c0 = 1.f - c;
+    const float wab00 = a0 * b0, wab10 = a2 * b0, wab01 = a0 * b, wab11 = a2 * b;
+    vec4 it(0.f);
+    it = accumulateTexel(it, q00.x, q00.y, wab00 * c0);
+    it = accumulateTexel(it, q00.z, q00.w, wab10 * c0);
+    it = accumulateTexel(it, q01.x, q01.y, wab01 * c0);
+    it = accumulateTexel(it, q01.z, q01.w, wab11 * c0);
+    it = accumulateTexel(it, q10.x, q10.y, wab00 * c);
+    it = accumulateTexel(it, q10.z, q10.w, wab10 * c);
+    it = accumulateTexel(it, q11.x, q11.y, wab01 * c);
+    it = accumulateTexel(it, q11.z, q11.w, wab11 * c);
+    return it;
+}
+
+// one geometry pixel (depth != 0) of the deferred shade: returns the R11G11B10 colour; *sigWord = decision signature (oracle/oracle.h)
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA, int INDIRECT_TECH>
+PLR_DI uint32_t shadeGeometryPixel(const ShadeParams& P, int px, int py, const ViewRay& vr, const PixelInputs& in, uint32_t* sigWord) {
+    SurfaceTerms st;
+    const DirectOut d = shadeDirect<DIFFUSE_BRDF, MULTISCATTER, GEOMETRIC_AA>(P, px, py, vr, in, ld3(P.light->sunColor), &st, sigWord);
     vec3 lightingIndirect;
-    if (INDIRECT_TECH == 0) {
-        const vec4 irradiance_Y_SH(halfBitsToFloat(in.ysh.x & 0xffffu), halfBitsToFloat(in.ysh.x >> 16), halfBitsToFloat(in.ysh.y & 0xffffu), halfBitsToFloat(in.ysh.y >> 16));
-        const vec2 cc(halfBitsToFloat(in.cocg & 0xffffu), halfBitsToFloat(in.cocg >> 16));
-        // directionToSH_L1(N) for unit N: normalize((0.28209, -0.48860 N.y, 0.48860 N.z, -0.48860 N.x)) = (0.5, -0.86603 N.y, ...)
-        const vec4 shN(0.5f, -0.8660254f * N.y, 0.8660254f * N.z, -0.8660254f * N.x);
-        const float irradiance_Y = dot(irradiance_Y_SH, shN);
-        const vec3 irradiance = YCoCgToLinear(vec3(irradiance_Y, cc.x, cc.y));
-        const vec3 diffuseIndirect = irradiance * diffuseColor * diffuseBRDFIntegral;
-        const vec3 dominantDirection = dominantDirectionFromSH_L1(irradiance_Y_SH);
-        const float dominantDirectionLength = fclamp(sqrtv(dot(dominantDirection, dominantDirection)), 0.01f, 1.f);
-        const float r_indirect = fmix(1.f, r, sqrtv(dominantDirectionLength));
-        const vec3 L_indirect = dominantDirection * rcpf(dominantDirectionLength);
-        const vec3 H_indirect = nrm(L_indirect + V);
-        const float NoH_indirect = fmax1(dot(N, H_indirect), 0.f);
-        const float NoL_indirect = fmax1(dot(N, L_indirect), 0.f);
-        const float VoH_indirect = fmax1(dot(V, H_indirect), 0.f);
-        const vec3 single_i = GGXSingleScattering(r_indirect, f0, NoH_indirect, NoV, VoH_indirect, NoL_indirect);
-        const vec3 multi_i = specularMultiscatteringLobe<MULTISCATTER>(P, r_indirect, NoL_indirect, f0, single_i, brdfLut);
-        const vec3 specularIndirect = (single_i + multi_i) * YCoCgToLinear(vec3(irradiance_Y_SH.x, cc.x, cc.y));
-        lightingIndirect = diffuseIndirect + specularIndirect;
-    } else {
+    if (INDIRECT_TECH == 0) lightingIndirect = shadeIndirect<MULTISCATTER>(P, st, in.ysh, in.cocg);
+    else {
         const float amb = 0.003f * P.light->sunStrengthExposed;
-        const vec3 singleScattering = vmix(vec3(brdfLut.x), vec3(brdfLut.y), f0);
-        lightingIndirect = (amb * diffuseColor) * diffuseBRDFIntegral + singleScattering * amb;
+        const vec3 singleScattering = vmix(vec3(st.brdfLut.x), vec3(st.brdfLut.y), st.f0);
+        lightingIndirect = (amb * st.diffuseColor) * st.diffuseBRDFIntegral + singleScattering * amb;
     }
-    vec3 outColor = (diffuseDirect + specularDirect) * P.light->sunStrengthExposed + lightingIndirect;
-    {
-        // applyVolumetricLighting: froxel z = log(linear * (e^3 - 1) + 1) / 3
-        const float nu = su + (noiseTexel.x - 0.5f) * 0.013f, nv = sv + (noiseTexel.y - 0.5f) * 0.013f;
-        const float linear = pixelDepth * rcpf(P.vol->maxDistance);
-        const float z = log2h(linear * 19.0855369f + 1.f) * (0.693147181f / 3.f);
-        const ImgView& vol = P.volumetricLut;
-        int i0, j0, k0; float a, b, c;
-        linearCoord(nu * (float)vol.w, &i0, &a);
-        linearCoord(nv * (float)vol.h, &j0, &b);
-        linearCoord(z * (float)vol.d, &k0, &c);
-        int xb; float a2;
-        edgePair(i0, a, vol.w, &xb, &a2); // the texel pair of every row in one 16-byte load, the x edge in the weight (bilinearLut above)
-        const uint32_t y0 = __umul24((uint32_t)clampi(j0, vol.h), (uint32_t)vol.w), y1 = __umul24((uint32_t)clampi(j0 + 1, vol.h), (uint32_t)vol.w);
-        const uint32_t sl = (uint32_t)vol.w * (uint32_t)vol.h; // uniform
-        const uint32_t z0 = __umul24((uint32_t)clampi(k0, vol.d), sl), z1 = __umul24((uint32_t)clampi(k0 + 1, vol.d), sl); // slices below 2^24 texels
-        const BufferDesc texels = texelBuffer(vol.ptr, 8u);
-        const uint32_t x0 = (uint32_t)xb;
-        const uint4 q00 = fetch128(texels, z0 + y0 + x0), q01 = fetch128(texels, z0 + y1 + x0), q10 = fetch128(texels, z1 + y0 + x0), q11 = fetch128(texels, z1 + y1 + x0); // [z][y]
-        // the sampler contract's weights and summation order (image.h sampleLinear3D): eight texels x four channels = 32 v_fma_mix_f32 on the fp16 words
-        const float a0 = 1.f - a2, b0 = 1.f - b, c0 = 1.f - c;
-        const float wab00 = a0 * b0, wab10 = a2 * b0, wab01 = a0 * b, wab11 = a2 * b;
-        vec4 it(0.f);
-        it = accumulateTexel(it, q00.x, q00.y, wab00 * c0);
-        it = accumulateTexel(it, q00.z, q00.w, wab10 * c0);
-        it = accumulateTexel(it, q01.x, q01.y, wab01 * c0);
-        it = accumulateTexel(it, q01.z, q01.w, wab11 * c0);
-        it = accumulateTexel(it, q10.x, q10.y, wab00 * c);
-        it = accumulateTexel(it, q10.z, q10.w, wab10 * c);
-        it = accumulateTexel(it, q11.x, q11.y, wab01 * c);
-        it = accumulateTexel(it, q11.z, q11.w, wab11 * c);
-        outColor = outColor * it.w + it.xyz();
-    }
+    vec3 outColor = d.direct * P.light->sunStrengthExposed + lightingIndirect;
+    const vec4 it = froxelLookup(P, vr.su, vr.sv, d.noiseTexel, d.pixelDepth);
+    outColor = outColor * it.w + it.xyz();
     return packR11G11B10(outColor);
 }
 
@@ -637,6 +670,164 @@ __global__ __launch_bounds__(256, PLR_SHADE_WAVES) void upscaleAndShadeKernel(Sh
     if (P.sig) P.sig[idx] = sigWord | (upSig << 8); // decision signature of the fused launch: the shade's word | the upscale's word << 8
 }
 
+// ---- Round 6: the fused upscale + shade as TWO launches, so that the half of the shade that needs no GI can run BESIDE the GI chain.
+//  (A) shadeDirectKernel - per pixel, everything of triangle.frag:146-290 that depends on the G-buffer, the shadow cascades and the LUTs only: material, view /
+//      half vectors, cascade select + twelve-tap PCF, diffuse + GGX + multiscattering response to a sun of UNIT colour, the froxel lookup. It reads no GI image,
+//      not the light buffer (sun colour x exposure: the frame front writes it) and takes the global uniform block BY VALUE (the host copy, PassCtx::globalHost:
+//      the device buffer is filled by the frame's first launch on the main stream), so the backend may start it on the early stream before the frame front
+//      (backend.h EarlyPart). Its result is a 36-byte record per pixel in the pass's scratch memory, three planes:
+//        a (16 B)  X.rgb fp32 = (diffuseDirect + specularDirect) / lightColor * transmittance        | half transmittance, half r (after geometric AA)
+//        b (16 B)  half in-scattering rgb, half energyOutgoing (brdfLut.y) | half diffuseColor * diffuseBRDFIntegral rgb, half f0.r
+//        c ( 4 B)  half f0.g, half f0.b
+//      a sky pixel (depth 0): a.x = the packed sky colour, nothing else is read.
+//      The direct term stays fp32 (it is most of the pixel and un-exposed: a mirror-like highlight can exceed the fp16 range); the rest only enters the
+//      indirect term or the additive fog and is rounded towards zero to fp16: 2^-10 relative on a part of a sum that is stored with 6 / 5 mantissa bits.
+//  (B) upscaleAndCombineKernel - the block's GI tile in LDS and the per-pixel upscale exactly as upscaleAndShadeKernel, then shadeIndirect from the record and
+//      colour = X * (sunColor * sunStrengthExposed) + (indirect * transmittance + in-scattering)
+//      (fused: ((direct * exposure) + indirect) * transmittance + in-scattering; the same sum up to fp32 re-association).
+// The pair is chosen by the backend when the early part has something to run beside (launchUpscaleAndShade below); tests/test_fusion.py holds its output to
+// within one R11G11B10 code of the single launch, tests/test_parity_fullsize.py to the same caps against the oracle.
+struct DirectRecords { uint4* a; uint4* b; uint32_t* c; };
+PLR_DI uint32_t packHalves(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+
+template <int DIFFUSE_BRDF, int MULTISCATTER, bool GEOMETRIC_AA>
+__global__ __launch_bounds__(256, PLR_SHADE_WAVES) void shadeDirectKernel(ShadeParams P, DirectRecords R, const GlobalUbo G, const ShadowCascadeInfo* __restrict__ shadowUniform,
+                                                                          const VolumetricLightingSettings* __restrict__ volUniform) {
+    P.g = &G; P.shadowInfo = shadowUniform; P.vol = volUniform; P.light = nullptr;
+    const int px = P.xBase + (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+    const int py = P.yBase + (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+    if (px >= P.coverW || py >= P.coverH) return;
+    const ViewRay vr = exactViewRay(P.g, px, py);
+    const uint32_t idx = fastm::texelIndex((uint32_t)px, (uint32_t)py, (uint32_t)P.color.w);
+    PixelInputs in;
+    in.depth = u2f(fetch32(texelBuffer(P.depth.ptr, 4u), idx));
+    if (in.depth == 0.f) {
+        R.a[idx] = make_uint4(packR11G11B10(fastm::sampleSkyLut(-vr.Vn, P.skyLut)), 0u, 0u, 0u);
+        return;
+    }
+    in.albedo = fetch32(texelBuffer(P.albedo.ptr, 4u), idx);
+    in.specular = fetch32(texelBuffer(P.specular.ptr, 4u), idx);
+    in.normal = fetch32(texelBuffer(P.normal.ptr, 4u), idx); // the launcher guarantees the normal image has the colour target's size
+    in.normalH = in.normalV = in.normal;
+    if (GEOMETRIC_AA) {
+        in.normalH = fetch32(texelBuffer(P.normal.ptr, 4u), fastm::texelIndex((uint32_t)clampi(px ^ 1, P.normal.w), (uint32_t)py, (uint32_t)P.normal.w));
+        in.normalV = fetch32(texelBuffer(P.normal.ptr, 4u), fastm::texelIndex((uint32_t)px, (uint32_t)clampi(py ^ 1, P.normal.h), (uint32_t)P.normal.w));
+    }
+    in.ysh = make_uint2(0u, 0u);
+    in.cocg = 0u;
+    SurfaceTerms st;
+    uint32_t sigWord;
+    const DirectOut d = shadeDirect<DIFFUSE_BRDF, MULTISCATTER, GEOMETRIC_AA>(P, px, py, vr, in, vec3(1.f), &st, &sigWord);
+    const vec4 it = froxelLookup(P, vr.su, vr.sv, d.noiseTexel, d.pixelDepth);
+    const vec3 X = d.direct * it.w;
+    const vec3 dci = st.diffuseColor * st.diffuseBRDFIntegral;
+    R.a[idx] = make_uint4(f2u(X.x), f2u(X.y), f2u(X.z), packHalves(it.w, st.r));
+    R.b[idx] = make_uint4(packHalves(it.x, it.y), packHalves(it.z, st.energyOutgoing), packHalves(dci.x, dci.y), packHalves(dci.z, st.f0.x));
+    R.c[idx] = packHalves(st.f0.y, st.f0.z);
+}
+
+template <int MULTISCATTER>
+__global__ __launch_bounds__(256) void upscaleAndCombineKernel(ShadeParams P, FusedUpscale U, DirectRecords R, const GlobalUbo* __restrict__ gUniform, const LightBuffer* __restrict__ lightUniform) {
+    P.g = gUniform; P.light = lightUniform;
+    __shared__ GiTexel tile[kGiTileH][kGiTileW];
+    const int t = (int)threadIdx.x;
+    const int X0 = P.xBase + (int)(blockIdx.x * 64u), Y0 = P.yBase + (int)(blockIdx.y * 4u); // both even
+    const int k0 = (X0 >> 1) - 1, m0 = (Y0 >> 1) - 1;                               // half-res texel of tile[0][0]
+    const GlobalUbo* g = P.g;
+    const float nearP = g->nearPlane, farP = g->farPlane, nf = nearP * farP, nmf = nearP - farP;
+    if (t < kGiTileW * kGiTileH) {
+        const int r = t / kGiTileW, c = t - r * kGiTileW;
+        const int hw = U.srcYSH.w, hh = U.srcYSH.h;
+        const uint32_t i = fastm::texelIndex((uint32_t)clampi(k0 + c, hw), (uint32_t)clampi(m0 + r, hh), (uint32_t)hw); // clamp-to-edge, as the sampler
+        const uint2 ys = fetch64(texelBuffer(U.srcYSH.ptr, 8u), i);
+        const uint32_t cc = fetch32(texelBuffer(U.srcCoCg.ptr, 4u), i);
+        GiTexel e;
+        e.depthLinear = fastquad::linearDepthRounded(halfBitsToFloat(fetch16(texelBuffer(U.halfResDepth.ptr, 2u), i)), nf, nmf, farP);
+        e.y0 = halfBitsToFloat(ys.x & 0xffffu); e.y1 = halfBitsToFloat(ys.x >> 16); e.y2 = halfBitsToFloat(ys.y & 0xffffu); e.y3 = halfBitsToFloat(ys.y >> 16);
+        e.co = halfBitsToFloat(cc & 0xffffu); e.cg = halfBitsToFloat(cc >> 16); e.pad = 0.f;
+        tile[r][c] = e;
+    }
+    // the pixel's depth, normal and record do not depend on the tile: their loads are in flight while the tile is being staged
+    const int px = X0 + (t & 63), py = Y0 + (t >> 6);
+    const bool covered = px < P.coverW && py < P.coverH;
+    const int cpx = covered ? px : 0, cpy = covered ? py : 0;
+    const uint32_t idx = fastm::texelIndex((uint32_t)cpx, (uint32_t)cpy, (uint32_t)P.color.w);
+    const float depth = u2f(fetch32(texelBuffer(P.depth.ptr, 4u), idx));
+    const uint32_t normalTexel = fetch32(texelBuffer(P.normal.ptr, 4u), idx);
+    const uint4 ra = fetch128(texelBuffer(R.a, 16u), idx), rb = fetch128(texelBuffer(R.b, 16u), idx);
+    const uint32_t rc = fetch32(texelBuffer(R.c, 4u), idx);
+    __syncthreads();
+    if (!covered) return;
+    // ---- the pixel's upscaled GI texel: upscaleQuad's statements for pixel (parity p, q) of quad (k, m) (upscale_quad.h), as in upscaleAndShadeKernel
+    uint2 ysh;
+    uint32_t cocg;
+    {
+#pragma clang fp contract(off)
+        const int p = px & 1, q = py & 1;
+        const int kc = (px >> 1) - k0, mr = (py >> 1) - m0;
+        const int c0 = kc - 1 + p, r0 = mr - 1 + q;
+        const GiTexel f00 = tile[r0][c0], f10 = tile[r0][c0 + 1], f01 = tile[r0 + 1][c0], f11 = tile[r0 + 1][c0 + 1];
+        const float full = fastquad::linearDepthRounded(depth, nf, nmf, farP);
+        const float ds[4] = {f01.depthLinear, f11.depthLinear, f10.depthLinear, f00.depthLinear};
+        const int offx[4] = {0, 1, 1, 0}, offy[4] = {1, 1, 0, 0};
+        float minDiff = 1000.f;
+        int cx = 0, cy = 0;
+        bool isEdge = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float diff = fabsf(ds[i] - full);
+            isEdge = isEdge || diff > 0.5f;
+            if (diff < minDiff) { minDiff = diff; cx = offx[i]; cy = offy[i]; }
+        }
+        float y0, y1, y2, y3, co, cg;
+        if (isEdge) {
+            const int hw = U.srcYSH.w, hh = U.srcYSH.h;
+            const GiTexel n = tile[min((py >> 1) + cy, hh - 1) - m0][min((px >> 1) + cx, hw - 1) - k0];
+            y0 = n.y0; y1 = n.y1; y2 = n.y2; y3 = n.y3; co = n.co; cg = n.cg;
+        } else {
+            const float a = p ? 0.25f : 0.75f, b = q ? 0.25f : 0.75f;
+            const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+            auto bl = [&](float t00, float t10, float t01, float t11) { return __builtin_fmaf(t11, w11, __builtin_fmaf(t01, w01, __builtin_fmaf(t10, w10, t00 * w00))); };
+            y0 = bl(f00.y0, f10.y0, f01.y0, f11.y0); y1 = bl(f00.y1, f10.y1, f01.y1, f11.y1); y2 = bl(f00.y2, f10.y2, f01.y2, f11.y2); y3 = bl(f00.y3, f10.y3, f01.y3, f11.y3);
+            co = bl(f00.co, f10.co, f01.co, f11.co); cg = bl(f00.cg, f10.cg, f01.cg, f11.cg);
+        }
+        // the fused kernel shades with the texel ROUNDED to the images' fp16 (it is what a stand-alone upscale would have stored): the same here
+        ysh = make_uint2(floatToHalfBits(y0) | (floatToHalfBits(y1) << 16), floatToHalfBits(y2) | (floatToHalfBits(y3) << 16));
+        cocg = floatToHalfBits(co) | (floatToHalfBits(cg) << 16);
+    }
+    if (U.storeUpscaled) {
+        ((uint2*)U.dstYSH.ptr)[idx] = ysh;
+        ((uint32_t*)U.dstCoCg.ptr)[idx] = cocg;
+    }
+    if (depth == 0.f) {
+        ((uint32_t*)P.color.ptr)[idx] = ra.x; // the sky colour, packed by the direct launch
+        return;
+    }
+    SurfaceTerms st;
+    st.N = decodeNormal(normalTexel);
+    {
+        // the view ray for SHADING only (no discrete decision hangs on it): one v_rsq instead of the correctly rounded chain of exactViewRay
+        const float su = ((float)px + 0.5f) * rcpf((float)g->screenResolution[0]), sv = ((float)py + 0.5f) * rcpf((float)g->screenResolution[1]);
+        const float ndx = su * 2.f - 1.f, ndy = sv * 2.f - 1.f;
+        const float ty = g->cameraTanFovHalf * ndy, tx = (g->cameraTanFovHalf * g->cameraAspectRatio) * ndx;
+        st.V = nrm(vec3((-g->cameraForward[0] + ty * g->cameraUp[0]) - tx * g->cameraRight[0], (-g->cameraForward[1] + ty * g->cameraUp[1]) - tx * g->cameraRight[1],
+                        (-g->cameraForward[2] + ty * g->cameraUp[2]) - tx * g->cameraRight[2]));
+    }
+    st.NoV = fmax1(fabsf(dot(st.N, st.V)), 0.0001f);
+    const float transmittance = (float)halfLo(ra.w);
+    st.r = (float)halfHi(ra.w);
+    st.energyOutgoing = (float)halfHi(rb.y);
+    st.diffuseColor = vec3((float)halfLo(rb.z), (float)halfHi(rb.z), (float)halfLo(rb.w)); // diffuseColor * diffuseBRDFIntegral
+    st.diffuseBRDFIntegral = vec3(1.f);
+    st.f0 = vec3((float)halfHi(rb.w), (float)halfLo(rc), (float)halfHi(rc));
+    st.brdfLut = vec3(0.f);
+    const vec3 lightingIndirect = shadeIndirect<MULTISCATTER>(P, st, ysh, cocg);
+    const vec3 inScattering((float)halfLo(rb.x), (float)halfHi(rb.x), (float)halfLo(rb.y));
+    const vec3 light = ld3(P.light->sunColor) * P.light->sunStrengthExposed;
+    const vec3 outColor = vec3(u2f(ra.x), u2f(ra.y), u2f(ra.z)) * light + (lightingIndirect * transmittance + inScattering);
+    ((uint32_t*)P.color.ptr)[idx] = packR11G11B10(outColor);
+}
+
 typedef void (*ShadeKernel)(ShadeParams, const GlobalUbo*, const LightBuffer*, const ShadowCascadeInfo*, const VolumetricLightingSettings*);
 template <int D, int M, bool G> static ShadeKernel pickIndirect(int tech) {
     return tech == 0 ? (ShadeKernel)deferredShadingFastKernel<D, M, G, 0> : (ShadeKernel)deferredShadingFastKernel<D, M, G, 1>;
@@ -697,14 +888,18 @@ struct ShadeDerived {
     const void* lut = nullptr; int lutW = 0, lutH = 0; uint64_t lutVersion = 0; // what the energy footprint was derived from
 };
 static thread_local std::map<const void*, ShadeDerived> g_shadeDerived; // key = the pass's scratch slot (one backend per host thread)
-static int shadeDerivedTables(const PassCtx& c, ShadeParams* P) {
-    // [tap table by value | noise slots | BRDF LUT energy footprint (size follows the LUT: a larger LUT re-allocates the scratch and everything is rebuilt)]
+static int shadeDerivedTables(const PassCtx& c, ShadeParams* P, DirectRecords* records = nullptr) {
+    // [tap table by value | noise slots | BRDF LUT energy footprint (size follows the LUT: a larger LUT re-allocates the scratch and everything is rebuilt)
+    //  | the direct launch's records: planes a, b, c over the colour target (only when the shade runs as two launches)]
     const ImgView& lut = P->brdfLut;
     const size_t footprintOffset = kPcfTapTableBytes + kNoiseSlots * kNoiseSlotBytes;
     const size_t footprintBytes = (size_t)(lut.w - 1) * (size_t)std::max(lut.h - 1, 1) * sizeof(uint2); // (the launcher sends LUTs narrower than two texels to the general kernel)
-    const size_t total = footprintOffset + footprintBytes;
+    const size_t recordsOffset = (footprintOffset + footprintBytes + 255) & ~(size_t)255;
+    const size_t pixels = (size_t)P->color.w * (size_t)P->color.h;
+    const size_t total = records ? recordsOffset + pixels * 36 : footprintOffset + footprintBytes;
     uint8_t* scratch = (uint8_t*)c.scratch(total);
     if (!scratch) return c.fail(-2, "deferredShading: cannot allocate scratch memory");
+    if (records) { records->a = (uint4*)(scratch + recordsOffset); records->b = records->a + pixels; records->c = (uint32_t*)(records->b + pixels); }
     ShadeDerived& d = g_shadeDerived[(const void*)c.scratchSlot];
     if (d.scratchBase != scratch) {
         d = ShadeDerived{};
@@ -746,7 +941,7 @@ static int shadeDerivedTables(const PassCtx& c, ShadeParams* P) {
 }
 
 // validates the bindings of a deferred shade execution and fills the kernel parameters; 0, kUseGeneralKernel or an error
-static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, int* multi, bool* aa, int* tech) {
+static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, int* multi, bool* aa, int* tech, bool deriveTables = true, DirectRecords* records = nullptr) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needStorage(0, F_R11G11B10, "deferredShading colour target")) return rc;
     if (int rc = c.needSampled(3, F_RGBA16F, "deferredShading brdfLutTexture")) return rc;
@@ -783,7 +978,7 @@ static int shadeParamsFor(const PassCtx& c, ShadeParams* out, int* diffuseBRDF, 
     // frame index -> texture index -> view are three dependent round trips in front of every pixel's shadow taps when a kernel chases them itself; this
     // kernel takes the view from the host, and a host that does not know the global buffer's contents (PassCtx::hostNoiseView) gets the general kernel
     if (!c.hostNoiseView(&P.noiseTex)) return kUseGeneralKernel;
-    if (int rc = shadeDerivedTables(c, &P)) return rc;
+    if (deriveTables) if (int rc = shadeDerivedTables(c, &P, records)) return rc;
     const PassCtx::RowSpan rs = c.rowSpan(P.color.h);
     const PassCtx::ColSpan cs = c.colSpan(P.color.w);
     P.coverW = cs.x1; P.xBase = cs.x0; P.coverH = rs.y1; P.yBase = rs.y0; // columns [xBase, coverW), rows [yBase, coverH)
@@ -810,8 +1005,11 @@ static int launchDeferredShadingFast(const PassCtx& c) {
     return 0;
 }
 
-// fused: indirectLightUpscale.comp, then the deferred shade that samples the images it wrote, over the same rows
-static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
+// fused: indirectLightUpscale.comp, then the deferred shade that samples the images it wrote, over the same rows.
+// fusedShadeSetup validates the pair and fills the kernel parameters (0, kUseGeneralKernel or an error); deriveTables = false: no launch, no allocation (the early
+// part's query); records: the shade runs as two launches and these are the planes between them
+struct FusedShade { ShadeParams P; FusedUpscale U; int diffuseBRDF, multi; bool aa; };
+static int fusedShadeSetup(const PassCtx* const* ctxs, size_t count, FusedShade* f, bool deriveTables, DirectRecords* records) {
     if (count != 2) return kUseGeneralKernel;
     const PassCtx &u = *ctxs[0], &c = *ctxs[1];
     // the upscale's bindings (launchUpscale, stream_fast.hip) in its "regular" 2x case
@@ -825,10 +1023,9 @@ static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
                          u.sampled[5].w == u.sampled[2].w && u.sampled[5].h == u.sampled[2].h && u.sampled[4].w == out.w && u.sampled[4].h == out.h &&
                          u.storage[1].w == out.w && u.storage[1].h == out.h && (ur.y0 & 1) == 0 && u.sampled[2].w >= 4;
     if (!regular) return kUseGeneralKernel;
-    ShadeParams P;
-    int diffuseBRDF, multi, tech;
-    bool aa;
-    if (int rc = shadeParamsFor(c, &P, &diffuseBRDF, &multi, &aa, &tech)) return rc;
+    ShadeParams& P = f->P;
+    int tech;
+    if (int rc = shadeParamsFor(c, &P, &f->diffuseBRDF, &f->multi, &f->aa, &tech, deriveTables, records)) return rc;
     if (tech != 0) return kUseGeneralKernel; // the shade does not read the upscaled images
     // the shade must read exactly what the upscale writes, on the same pixel grid, the same depth buffer, over the same rows and whole rows
     if (c.sampled[15].ptr != out.ptr || c.sampled[16].ptr != u.storage[1].ptr || c.sampled[15].w != out.w || c.sampled[15].h != out.h || P.color.w != out.w ||
@@ -838,19 +1035,84 @@ static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
     if (uc.x0 != P.xBase || uc.x1 != P.coverW || ur.y0 != P.yBase || ur.y1 != P.coverH) return kUseGeneralKernel; // the same rows and the same columns
     // uv is defined by the UBO's screen resolution (indirectLightUpscale.comp:19): the quad reasoning needs it to be the target size
     if (c.global != u.global || !u.globalHost || u.globalHost->screenResolution[0] != out.w || u.globalHost->screenResolution[1] != out.h) return kUseGeneralKernel;
-    if (P.coverH <= P.yBase || P.coverW <= P.xBase) return 0;
-    FusedUpscale U;
+    FusedUpscale& U = f->U;
     U.srcYSH = u.sampled[2]; U.srcCoCg = u.sampled[3]; U.halfResDepth = u.sampled[5]; U.dstYSH = u.storage[0]; U.dstCoCg = u.storage[1];
+    U.storeUpscaled = 1;
+    return 0;
+}
+
+typedef void (*DirectKernel)(ShadeParams, DirectRecords, const GlobalUbo, const ShadowCascadeInfo*, const VolumetricLightingSettings*);
+template <int D, int M> static DirectKernel pickDirectAA(bool aa) { return aa ? (DirectKernel)shadeDirectKernel<D, M, true> : (DirectKernel)shadeDirectKernel<D, M, false>; }
+template <int D> static DirectKernel pickDirectMulti(int m, bool aa) {
+    switch (m) {
+        case 0: return pickDirectAA<D, 0>(aa);
+        case 1: return pickDirectAA<D, 1>(aa);
+        case 2: return pickDirectAA<D, 2>(aa);
+        default: return pickDirectAA<D, 3>(aa);
+    }
+}
+
+// the EARLY PART of the pair (backend.h EarlyPart): the direct lighting, as a launch of its own on the early stream
+static int earlyShadeDirect(const PassCtx* const* ctxs, size_t count, EarlyPart& part) {
+    FusedShade f;
+    DirectRecords R{};
+    const bool launch = part.mode == EarlyPart::Launch;
+    if (int rc = fusedShadeSetup(ctxs, count, &f, launch, launch ? &R : nullptr)) return rc;
+    const PassCtx& c = *ctxs[1];
+    if (!c.globalHost || c.sigFor(1)) return kUseGeneralKernel; // the kernel takes the uniform block by value; decision signatures are written by the single launch
+    if (!launch) {
+        // everything the direct launch reads (allocation bases): G-buffer, LUTs, shadow cascades, the two small blocks, the frame's noise texture
+        const ShadeParams& P = f.P;
+        for (const void* k : {(const void*)P.depth.ptr, (const void*)P.normal.ptr, (const void*)P.albedo.ptr, (const void*)P.specular.ptr, (const void*)P.brdfLut.ptr,
+                              (const void*)P.shadowMaps[0].ptr, (const void*)P.shadowMaps[1].ptr, (const void*)P.shadowMaps[2].ptr, (const void*)P.shadowMaps[3].ptr,
+                              (const void*)P.volumetricLut.ptr, (const void*)P.skyLut.ptr, (const void*)P.shadowInfo, (const void*)P.vol, (const void*)P.noiseTex.ptr})
+            part.reads->push_back(k);
+        return 0;
+    }
+    const ShadeParams& P = f.P;
+    if (P.coverH <= P.yBase || P.coverW <= P.xBase) return 0;
+    DirectKernel k = nullptr;
+    switch (f.diffuseBRDF) {
+        case 0: k = pickDirectMulti<0>(f.multi, f.aa); break;
+        case 1: k = pickDirectMulti<1>(f.multi, f.aa); break;
+        case 2: k = pickDirectMulti<2>(f.multi, f.aa); break;
+        default: k = pickDirectMulti<3>(f.multi, f.aa); break;
+    }
+    k<<<dim3(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, R, *c.globalHost, P.shadowInfo, P.vol);
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+
+static int launchUpscaleAndShade(const PassCtx* const* ctxs, size_t count) {
+    FusedShade f;
+    DirectRecords R{};
+    const bool late = count == 2 && ctxs[0]->earlyPartDone; // the backend launched earlyShadeDirect for this pair in this frame: the combine is what is left
+    if (int rc = fusedShadeSetup(ctxs, count, &f, true, late ? &R : nullptr)) return rc;
+    const PassCtx &u = *ctxs[0], &c = *ctxs[1];
+    const ShadeParams& P = f.P;
+    FusedUpscale& U = f.U;
+    if (P.coverH <= P.yBase || P.coverW <= P.xBase) return 0;
     U.storeUpscaled = (u.elidableStorage & 3u) == 3u ? 0 : 1;
     if (!U.storeUpscaled) u.elidedStorage = 3u;
-    FusedKernel k = nullptr;
-    switch (diffuseBRDF) {
-        case 0: k = pickFusedMulti<0>(multi, aa); break;
-        case 1: k = pickFusedMulti<1>(multi, aa); break;
-        case 2: k = pickFusedMulti<2>(multi, aa); break;
-        default: k = pickFusedMulti<3>(multi, aa); break;
+    const dim3 grid(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u));
+    if (late) {
+        switch (f.multi) {
+            case 0: upscaleAndCombineKernel<0><<<grid, 256, 0, c.stream>>>(P, U, R, P.g, P.light); break;
+            case 1: upscaleAndCombineKernel<1><<<grid, 256, 0, c.stream>>>(P, U, R, P.g, P.light); break;
+            case 2: upscaleAndCombineKernel<2><<<grid, 256, 0, c.stream>>>(P, U, R, P.g, P.light); break;
+            default: upscaleAndCombineKernel<3><<<grid, 256, 0, c.stream>>>(P, U, R, P.g, P.light); break;
+        }
+        PLR_CHECK_LAUNCH(c);
+        return 0;
     }
-    k<<<dim3(divUp((unsigned)(P.coverW - P.xBase), 64u), divUp((unsigned)(P.coverH - P.yBase), 4u)), 256, 0, c.stream>>>(P, U, PLR_SHADE_UNIFORM_ARGS(P));
+    FusedKernel k = nullptr;
+    switch (f.diffuseBRDF) {
+        case 0: k = pickFusedMulti<0>(f.multi, f.aa); break;
+        case 1: k = pickFusedMulti<1>(f.multi, f.aa); break;
+        case 2: k = pickFusedMulti<2>(f.multi, f.aa); break;
+        default: k = pickFusedMulti<3>(f.multi, f.aa); break;
+    }
+    k<<<grid, 256, 0, c.stream>>>(P, U, PLR_SHADE_UNIFORM_ARGS(P));
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
@@ -961,6 +1223,8 @@ static int fastshade_launch(const PassCtx& c) { return fastshade::launchDeferred
 PLR_REGISTER_SHADER_FAST("deferredShading.comp", fastshade_launch);
 static int fastshade_upscale_and_shade(const PassCtx* const* ctxs, size_t count) { return fastshade::launchUpscaleAndShade(ctxs, count); }
 PLR_REGISTER_FUSION_WITH_SIGNATURES("indirectLightUpscale + deferredShading", fastshade_upscale_and_shade, "indirectLightUpscale.comp", "deferredShading.comp");
+static int fastshade_early_direct(const PassCtx* const* ctxs, size_t count, EarlyPart& part) { return fastshade::earlyShadeDirect(ctxs, count, part); }
+PLR_REGISTER_EARLY_PART(fastshade_upscale_and_shade, fastshade_early_direct, "direct lighting");
 static int fastshade_brdf_lut(const PassCtx& c) { return fastshade::launchBrdfLutFast(c); }
 PLR_REGISTER_SHADER_FAST("brdfLut.comp", fastshade_brdf_lut);
 } // namespace plr

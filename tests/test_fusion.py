@@ -25,6 +25,7 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
     results, fused_counts = {}, {}
     try:
         backend.setMathMode(True)
+        backend.setEarlyParts(0)  # (the shade as two launches is within one code of the single launch, not byte-identical: test_gpu_the_shade_as_two_launches_... below)
         for fusion in (2, 1, 0):
             backend.setPassFusion(fusion)
             fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64, sdf_half_res_trace=half_res)
@@ -56,6 +57,7 @@ def test_gpu_fused_frames_equal_unfused_frames_byte_for_byte(backend, w, h, half
             fp.destroy()
     finally:
         backend.setPassFusion(2)
+        backend.setEarlyParts(0)
         backend.setMathMode(False)
     assert fused_counts[0] == 0
     assert fused_counts[1] >= 6, "executions inside fused launches: %d" % fused_counts[1]
@@ -315,3 +317,52 @@ def test_gpu_the_persistent_bloom_chain_changes_no_bit():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not persistent_bloom_chain"], env=env, capture_output=True, text=True,
                        timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1280, 720), (648, 360)])
+def test_gpu_the_shade_as_two_launches_beside_the_gi_chain_stays_within_one_code(backend, w, h):
+    """Early parts (include/plr.h plr_set_early_parts, backend.h EarlyPart): in a full frame the deferred shade's direct lighting is launched on the early stream
+    at the frame's start - nothing recorded in front of the shade writes what it reads - and runs beside the frame front and the GI chain; the fused upscale + shade
+    launch then only upscales, adds the indirect response and the fog, and packs. Frame 0 (no feedback yet): the colour target is within ONE R11G11B10 code of the
+    single launch's on every pixel and every image that does not depend on it is byte-identical. Later frames feed the colour back (histogram -> exposure, TAA
+    history): the resolved image stays within one code on all but a handful of pixels."""
+    from plainrenderer_amd.frame import FramePipeline, SyntheticInputs
+    import parity
+    n_frames = 4
+    cams = [Camera.look((15.0 + 0.03 * i, -7.0, -6.0 + 0.05 * i), (0.0, 0.16, 1.0), aspect=w / h) for i in range(n_frames + 1)]
+    scene = synth.SynthScene(grid=4, cell=8.0, seed_id=510)
+    inputs = None
+    results = {}
+    try:
+        backend.setMathMode(True)
+        for early in (0, 1):
+            backend.setEarlyParts(early)
+            fp = FramePipeline(backend, w, h, shadow_map_res=256, brdf_lut_res=LUT_RES, froxel_depth=16, max_sdf_instances=64)
+            if inputs is None:
+                inputs = SyntheticInputs(scene, cams[1], cams[0], w, h, sdf_res=16, shadow_res=256, froxel_depth=16, sun_direction=(0.35, -0.8, 0.45))
+            inputs.upload(fp)
+            out = []
+            for f in range(n_frames):
+                fp.frame(cams[f + 1], 1.0 / 60.0, 0.5 + f / 60.0)
+                level, launched = backend.getEarlyParts()
+                assert (level, launched) == (early, early), "one early part per frame: the shade's direct lighting"
+                assert backend.getGeneralKernelExecutions()[0] == 0
+                color = backend.downloadImage(fp.image("color%d" % ((f + 1) % 2)), 0, np.uint32).copy()
+                same = {n: backend.downloadImage(fp.image(n), 0, np.uint8).copy() for n in ("giHistoryYSH0", "giHistoryCoCg0", "pyramid", "depthHalfRes")}
+                out.append((color, backend.downloadImage(fp.image("post1"), 0, np.uint32).copy(), same))
+            results[early] = out
+            fp.destroy()
+    finally:
+        backend.setEarlyParts(0)
+        backend.setMathMode(False)
+    c0, c1 = results[0][0][0], results[1][0][0]
+    assert not np.array_equal(c0, np.zeros_like(c0))
+    d = parity.r11g11b10_code_diff(c1, c0)
+    assert d.max() <= 1, "frame 0: two launches against one, colour target"
+    for f in range(n_frames):
+        for name in results[0][f][2]:
+            if f == 0 or name in ("pyramid", "depthHalfRes"):
+                assert np.array_equal(results[0][f][2][name], results[1][f][2][name]), "%s differs in frame %d" % (name, f)
+        dp = parity.r11g11b10_code_diff(results[1][f][1], results[0][f][1])
+        assert (dp > 1).any(axis=1).mean() <= 1e-3 and dp.max() <= 4, "frame %d: resolved colour, %.2e of the pixels beyond one code, max %d" % (f, (dp > 1).any(axis=1).mean(), dp.max())

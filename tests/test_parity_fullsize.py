@@ -230,6 +230,24 @@ def test_gpu_fullsize_fused_upscale_and_shade(backend, fs):
         backend.setPassFusion(2)
     assert np.array_equal(sep, got) and np.array_equal(one, got)
     assert np.array_equal(ys, y1) and np.array_equal(cs, c1)
+    # round 6 - the pair as TWO launches: the shade's direct lighting as the early part (beside the GI chain in a full frame; forced here, where the pair is all that is
+    # recorded), then upscale + indirect + fog + pack. Its discrete decisions are the single launch's (the same statements), so the single launch's signatures say which
+    # pixels are clean; held to the oracle with the same caps, and to the single launch within one code on EVERY pixel
+    level = backend.getEarlyParts()[0]
+    backend.setEarlyParts(2)
+    try:
+        split = passes.gpu_upscale_and_shade(backend, cu["inp"][0], cu["inp"][1], TW, TH, cu["half_depth"], *common, *tail, *var)
+        assert backend.getEarlyParts() == (2, 1) and backend.getPassFusion() == (2, 2), "direct lighting launched as the early part, the rest as the fused launch"
+    finally:
+        backend.setEarlyParts(level)
+    ds = parity.r11g11b10_code_diff(split, ref)
+    dd = parity.r11g11b10_code_diff(split, got)
+    report("split_upscale_shade", clean_max_code_diff=int(ds[clean & ~sky].max()), sky_max_code_diff=int(ds[clean & sky].max(initial=0)),
+           against_single_launch_max_code_diff=int(dd.max()), against_single_launch_differing=float((dd != 0).any(axis=1).mean()),
+           clean_differing_from_oracle=float((ds[clean] != 0).any(axis=1).mean()), single_launch_clean_differing_from_oracle=float((d[clean] != 0).any(axis=1).mean()))
+    assert ds[clean & ~sky].max() <= 1 and ds[clean & sky].max(initial=0) <= 2
+    assert dd.max() <= 1, "two launches against one: the direct term travels in fp32, the indirect operands in fp16 - never more than one code"
+    assert np.array_equal(split.reshape(-1)[sky.reshape(-1)], got.reshape(-1)[sky.reshape(-1)]), "sky pixels are packed by the direct launch from the same value"
 
 
 # ------------------------------------------------------------------ config 3: TAA + bloom (+ HiZ: bit exact in tests/test_hiz_bloom_taa.py at 3840x2160)

@@ -6,7 +6,7 @@ import csv, sys
 from collections import defaultdict
 
 FAMILIES = [("histogramAndPyramid", "front 1 (histogram + pyramid)"), ("exposureChainAndPyramidTail", "front 2 (exposure + pyramid tail)"), ("frustumAndTileCulling", "culling"),
-            ("sdfDiffuseTrace", "trace"), ("spatialFilter", "spatial filter"), ("temporalGiFilter", "temporal GI"), ("upscaleAndShade", "upscale + shade"),
+            ("sdfDiffuseTrace", "trace"), ("spatialFilter", "spatial filter"), ("temporalGiFilter", "temporal GI"), ("upscaleAndShade", "upscale + shade"), ("shadeDirect", "shade: direct (early)"), ("upscaleAndCombine", "shade: upscale + combine"),
             ("temporalFilterStrip", "TAA"), ("bloom", "bloom chain"), ("applyBloomTonemap", "apply + tonemap")]
 
 
