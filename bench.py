@@ -150,7 +150,78 @@ def pmc_counters(pass_name):
     return (acc, src) if acc else (None, None)
 
 
-SIMDS, CUS, SHADER_CLOCK_GHZ = 1024, 256, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz
+SIMDS, CUS, SHADER_CLOCK_GHZ = 1024, 256, 2.4  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz nominal
+DENSE_VALU_CLOCK_GHZ = 2.0  # profiles/r05_valu_rates.txt, column "clock GHz": a chip-wide dense full-rate VALU stream sustains 1.85 - 2.0 GHz (DVFS)
+
+
+def _newest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
+    return files[-1] if files else None
+
+
+def _norm_kernel(name):
+    """kernel names differ between the rocprofv3 summaries (template arguments separated by ', ' or '; '): one spelling"""
+    return name.replace("; ", ", ").strip().strip('"')
+
+
+def frame_valu_floor():
+    """The whole frame's VALU issue floor from the newest committed counter set (profiles/*_sq_counters.csv + *_kernel_stats.csv of the same round):
+    sum over the frame's launches of SQ_INSTS_VALU x 2 cycles / 1024 SIMDs / clock - what the frame would take if every SIMD issued one VALU instruction every
+    2 cycles and nothing else ever waited. The clock is MEASURED per kernel, GRBM_GUI_ACTIVE / 8 XCDs over the kernel's traced duration, capped at the nominal
+    2.4 GHz (the counter also ticks a little before and after the traced interval); the same floor at the 2.0 GHz a dense VALU stream sustains is given beside it.
+    -> dict or None"""
+    cfile, kfile = _newest_profile("_sq_counters.csv"), _newest_profile("_kernel_stats.csv")
+    if not cfile or not kfile or os.path.basename(cfile).split("_")[0] != os.path.basename(kfile).split("_")[0]:
+        return None
+    dur = {}
+    for line in open(kfile):
+        if line.startswith("kernel,") or line.startswith("#"):
+            continue
+        # the kernel name contains commas: the last six fields are the numbers
+        parts = line.rstrip("\n").rsplit(",", 6)
+        if len(parts) == 7:
+            dur[_norm_kernel(parts[0])] = float(parts[2])
+    header, rows, digest = None, [], None
+    for line in open(cfile):
+        line = line.strip()
+        if line.startswith("# kernel source digest:"):
+            digest = line.split(":", 1)[1].strip()
+        elif line.startswith("kernel,"):
+            header = line.split(",")
+        elif header and line and not line.startswith("#"):
+            cols = line.split(",")
+            rows.append(dict(zip(header, cols)))
+    if not rows:
+        return None
+    per_frame = None
+    for r in rows:
+        if "histogramAndPyramid" in r["kernel"]:
+            per_frame = float(r["dispatches"])
+    if not per_frame:
+        return None
+    floor_measured = floor_nominal = 0.0
+    clocks, kernels = [], []
+    for r in rows:
+        launches = float(r["dispatches"]) / per_frame
+        if launches < 0.5:  # set-up kernels (LUT bake, tables): not part of a frame
+            continue
+        valu = float(r.get("SQ_INSTS_VALU", 0) or 0)
+        d_us = dur.get(_norm_kernel(r["kernel"]))
+        grbm = float(r.get("GRBM_GUI_ACTIVE", 0) or 0) / 8.0
+        clock = min(grbm / (d_us * 1e3), SHADER_CLOCK_GHZ) if (d_us and grbm) else SHADER_CLOCK_GHZ
+        floor_measured += launches * valu * 2.0 / SIMDS / (clock * 1e9) * 1e3
+        floor_nominal += launches * valu * 2.0 / SIMDS / (SHADER_CLOCK_GHZ * 1e9) * 1e3
+        if d_us and grbm:
+            clocks.append((launches * valu, clock))
+        kernels.append(_norm_kernel(r["kernel"]).split("<")[0].split("::")[-1])
+    wsum = sum(w for w, _ in clocks)
+    clock_mean = sum(w * c for w, c in clocks) / wsum if wsum else SHADER_CLOCK_GHZ
+    src = os.path.basename(cfile) + " + " + os.path.basename(kfile) + (" (kernel sources unchanged since)" if digest == kernel_source_digest() else " (kernel sources CHANGED since: stale)" if digest else "")
+    return {"frame_valu_floor_ms": round(floor_measured, 4), "clock_GHz_measured": round(clock_mean, 3),
+            "clock_source": "GRBM_GUI_ACTIVE / 8 XCDs over the traced kernel duration, VALU-weighted mean over the frame's kernels, capped at the nominal 2.4 GHz",
+            "frame_valu_floor_ms_at_2.0GHz_dense_valu_clock": round(floor_nominal * SHADER_CLOCK_GHZ / DENSE_VALU_CLOCK_GHZ, 4),
+            "cycles_per_valu_instruction_at_peak": 2, "simds": SIMDS, "kernels": len(kernels), "source": src}
 
 
 def build_scene(args, device, w, h, band=None):
@@ -534,12 +605,19 @@ def main():
         # cycle and CU (the rate the shade ablation of round 4 ran into, profiles/r04_shade_ablation.txt) - each as a fraction of the measured launch time
         counters, counters_src = pmc_counters(name) if default_workload else (None, None)
         valu_roofline = l1_roofline = None
+        clock = SHADER_CLOCK_GHZ
         if counters and counters.get("SQ_INSTS_VALU"):
-            t_valu_ms = counters["SQ_INSTS_VALU"] * 2.0 / SIMDS / (SHADER_CLOCK_GHZ * 1e9) * 1e3
+            # the clock the kernel actually ran at: GRBM_GUI_ACTIVE / 8 XCDs cycles of the counter pass over this run's measured launch time,
+            # capped at the nominal 2.4 GHz; the floor at the 2.0 GHz of a dense VALU stream beside it
+            if counters.get("GRBM_GUI_ACTIVE"):
+                clock = min(counters["GRBM_GUI_ACTIVE"] / 8.0 / (avg_ms * 1e6), SHADER_CLOCK_GHZ)
+            t_valu_ms = counters["SQ_INSTS_VALU"] * 2.0 / SIMDS / (clock * 1e9) * 1e3
             valu_roofline = {"bound": "valu issue", "valu_instructions_per_launch": int(counters["SQ_INSTS_VALU"]), "cycles_per_instruction_at_peak": 2, "simds": SIMDS,
-                             "clock_GHz": SHADER_CLOCK_GHZ, "floor_ms": round(t_valu_ms, 4), "frac": round(t_valu_ms / avg_ms, 4), "source": counters_src}
+                             "clock_GHz": round(clock, 3), "clock_source": "GRBM_GUI_ACTIVE / 8 XCDs (counter pass) / this run's launch time, capped at 2.4",
+                             "floor_ms": round(t_valu_ms, 4), "frac": round(t_valu_ms / avg_ms, 4),
+                             "frac_at_2.0GHz_dense_valu_clock": round(t_valu_ms * clock / DENSE_VALU_CLOCK_GHZ / avg_ms, 4), "source": counters_src}
         if counters and counters.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-            t_l1_ms = counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / CUS / (SHADER_CLOCK_GHZ * 1e9) * 1e3
+            t_l1_ms = counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / CUS / (clock * 1e9) * 1e3
             l1_roofline = {"bound": "L1 (TCP) cache-line accesses", "accesses_per_launch": int(counters["TCP_TOTAL_CACHE_ACCESSES_sum"]), "accesses_per_cycle_per_cu_at_peak": 1,
                            "cus": CUS, "floor_ms": round(t_l1_ms, 4), "frac": round(t_l1_ms / avg_ms, 4), "source": counters_src}
         roofline = {"bound": "hbm", "kernel": name, "hip_kernel": (PASS_KERNEL.get(name) or PASS_KERNEL.get(name.split(" + ")[-1]) or [None])[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -587,8 +665,12 @@ def main():
                                                                                         ("%d row bands of ~%d rows" % (world, h // world)),
                                                                                         "torch.distributed from Python" if args.python_exchange else "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
-            "frame_roofline": {"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                               "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            # the frame against its two bounds: the HBM roofline (algorithmic bytes / 8 TB/s) and the VALU issue floor of its instruction streams - the 60 % target
+            # of the HBM roofline is ms_at_60pct_of_8TBs; a frame_valu_floor_ms above it says the target is out of reach of these kernels at any issue efficiency
+            "frame_roofline": dict({"algorithmic_bytes": int(frame_bytes), "achieved_GBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                    "frac_of_8TBs": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "ms_at_60pct_of_8TBs": round(frame_bytes / (0.6 * HBM_PEAK_GBS * 1e9) * 1e3, 4)},
+                                   **((frame_valu_floor() or {}) if (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None else {})),
             "band_partition": band_partition if band is not None else None,
             # strong scaling against the SAME frame on one GPU (rank 0, same run): the figure BASELINE's ">= 3.5x at 4 GPUs on 8K" is written in. Measured on
             # one node only when the driver's scaling run has N GPUs; null at N = 1

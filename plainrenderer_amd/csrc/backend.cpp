@@ -487,10 +487,16 @@ uint64_t contentVersionOf(const void* base) {
 }
 
 // a raw device address was written (plr_write / copy_device_memory): the image allocation it lies in, if any, has new contents
+// a HOST write into an image (upload, raw copy / write into its allocation): new contents, and the texels are the host's now - an image a fused launch had left
+// unwritten (ImageRes::elided) is readable again (a host that re-initialised such an image got the "not written" error on its next read)
+static void hostWroteImage(ImageRes& im) {
+    touchAllocation(im.dev);
+    im.elided = false; im.elidedReader = nullptr; im.elidedSerial = 0;
+}
 static void touchAddress(const void* p) {
     auto inside = [&](const ImageRes& im) { return im.dev && (const uint8_t*)p >= (const uint8_t*)im.dev && (const uint8_t*)p < (const uint8_t*)im.dev + im.bytes; };
-    for (const ImageRes& im : g->images) if (inside(im)) { touchAllocation(im.dev); return; }
-    for (const ImageRes& im : g->transient) if (inside(im)) { touchAllocation(im.dev); return; }
+    for (ImageRes& im : g->images) if (inside(im)) { hostWroteImage(im); return; }
+    for (ImageRes& im : g->transient) if (inside(im)) { hostWroteImage(im); return; }
 }
 
 static uint32_t mipCountFromResolution(uint32_t w, uint32_t h, uint32_t d) {
@@ -2250,7 +2256,7 @@ int plr_upload_image(plr_image_handle image, uint32_t mip_level, const void* dat
     if (size != mi->bytes) return setErr(PLR_ERR_INVALID_ARGUMENT, "upload size " + std::to_string(size) + " != mip size " + std::to_string(mi->bytes));
     HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset, data, size, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    touchAllocation(im->dev);
+    hostWroteImage(*im);
     return PLR_OK;
 }
 
@@ -2266,7 +2272,7 @@ int plr_upload_image_rows(plr_image_handle image, uint32_t mip_level, uint32_t r
     if (size == 0) return PLR_OK;
     HIP_TRY(hipMemcpyAsync((uint8_t*)im->dev + mi->offset + rowBytes * row_begin, data, size, hipMemcpyHostToDevice, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
-    touchAllocation(im->dev);
+    hostWroteImage(*im);
     return PLR_OK;
 }
 
