@@ -146,6 +146,19 @@ int plrf_tile_rects(uint32_t frame_width, uint32_t frame_height, uint32_t gx, ui
  * single-GPU replay of a partition's frame costs, tools/band_cost.py; the received texels are meaningless). */
 int plrf_rccl_attach_rects(void* pipeline, const void* unique_id_128_bytes, int rank, int world, uint32_t frame_width, uint32_t frame_height, const uint32_t* rects,
                            void** out_exchange);
+/* ---- the IN-PROCESS transport (round 6): every rank of the partition in ONE process on one GPU - one host thread, backend, pipeline and exchange each, as the
+ * partition tests run them. The exchange is the communicator path's code (plans, pack / unpack kernels, communication stream, BEGIN behind the producers' edge
+ * signal, END, watchdog); where ncclSend / ncclRecv go, a rank publishes its transfers with an event behind its pack, waits on the host until its peers have posted
+ * the same exchange, copies their send ranges into its receive ranges on its own stream (the k-th send of a to b pairs with b's k-th receive from a, RCCL's rule
+ * inside a group) and orders its stream behind the peers' reads of what it sent. The all-reduces go through slots of group memory. One group per partition; it
+ * must outlive its exchanges (plrf_rccl_detach). plrf_local_group_abort: wake ranks waiting for a peer that failed. plrf_local_group_freeze(1): a rank no longer
+ * waits for its peers and copies from what they posted LAST (their buffers keep their last frame's texels): tools/band_cost.py times ONE partition alone with real
+ * neighbour data in its halos. */
+int plrf_local_group_create(int world, void** out_group);
+int plrf_local_group_destroy(void* group);
+int plrf_local_group_abort(void* group);
+int plrf_local_group_freeze(void* group, int frozen);
+int plrf_local_attach_rects(void* pipeline, void* group, int rank, int world, uint32_t frame_width, uint32_t frame_height, const uint32_t* rects, void** out_exchange);
 /* what the exchange runs on: ranks of the communicator (ncclCommCount; 0 in loopback), the RCCL version code (ncclGetVersion), the ordering mode of the overlapped
  * exchanges (2 = the producer's edge signal + hipStreamWaitValue32, 1 = an event behind the producer - also what mode 2 falls back to on a device without
  * stream memory operations, 0 = not overlapped), whether the regions go through pack / unpack kernels (a tile partition) or straight from the images (bands) */
@@ -158,9 +171,10 @@ int plrf_rccl_self_test_rect(void* exchange, void* device_ptr, uint32_t pitch_by
 
 /* ---- exchange watchdog (round 5): an overlapped exchange is a wait the launch stream parks on; if a peer never posts its side the frame
  * hangs and says nothing. Every BEGIN arms an entry {rank, exchange id, phase, completion query, time}; entries are checked at every later exchange
- * callback (the frame then fails with the message) and by a background thread every 50 ms, which prints the message to stderr and - unless
- * PLRF_EXCHANGE_WATCHDOG_ABORT=0 - aborts the process: a hung collective cannot be cancelled, only reported. Deadline: PLRF_EXCHANGE_WATCHDOG_MS (default 2000,
- * 0 = off); the first 64 exchanges of a communicator (about ten frames: RCCL sets up its point-to-point connections inside the first group with each peer, and ranks
+ * callback (the frame then fails with the message) and by a background thread every 50 ms, which prints the message to stderr when an entry goes overdue - a REPORT:
+ * a peer paused in a debugger or an oversubscribed host recovers, and the thread says so and frames go on (round 6) - and aborts the process only when
+ * the entry is still incomplete PLRF_EXCHANGE_WATCHDOG_ABORT_MS later (default 30000; PLRF_EXCHANGE_WATCHDOG_ABORT=0: never): a hung collective cannot be
+ * cancelled, only reported. Deadline: PLRF_EXCHANGE_WATCHDOG_MS (default 2000, 0 = off); the first 64 exchanges of a communicator (about ten frames: RCCL sets up its point-to-point connections inside the first group with each peer, and ranks
  * leave their set-up at different times) get PLRF_EXCHANGE_WATCHDOG_FIRST_MS (default 60000) instead. The functions below expose the mechanism with a caller-supplied completion query, so it can be tested without a GPU. */
 typedef int (*plrf_watchdog_query)(void* user); /* 0 = still running, 1 = complete */
 int plrf_watchdog_create(uint32_t deadline_ms, void** out_watchdog);

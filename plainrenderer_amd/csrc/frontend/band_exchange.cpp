@@ -42,6 +42,8 @@ using namespace plrhost;
 namespace {
 
 thread_local std::string g_xerr;
+struct LocalGroup;
+thread_local LocalGroup* g_pendingLocalGroup = nullptr;
 int xfail(int code, const std::string& msg) { g_xerr = msg; return code; }
 
 constexpr uint32_t kBandAlignment = 64; // rows / columns; edges never split a HiZ / culling / histogram tile or the coarsest bloom texel
@@ -116,7 +118,10 @@ std::vector<plrf_exchange_op> planBandRows(uint32_t frameHeight, uint32_t nBands
 struct Rect { uint32_t x0, y0, x1, y1; };
 bool emptyRect(const Rect& r) { return r.x1 <= r.x0 || r.y1 <= r.y0; }
 Rect intersect(const Rect& a, const Rect& b) { return {std::max(a.x0, b.x0), std::max(a.y0, b.y0), std::min(a.x1, b.x1), std::min(a.y1, b.y1)}; }
-Rect grow(const Rect& r, uint32_t k, uint32_t w, uint32_t h) { return {r.x0 > k ? r.x0 - k : 0u, r.y0 > k ? r.y0 - k : 0u, std::min(r.x1 + k, w), std::min(r.y1 + k, h)}; }
+// (the sums in 64 bits: PLRF_HALO_WHOLE_IMAGE = 0xffffffff must saturate, not wrap - plrf_exchange_plan_rects is public and does not clamp its halo)
+Rect grow(const Rect& r, uint32_t k, uint32_t w, uint32_t h) {
+    return {r.x0 > k ? r.x0 - k : 0u, r.y0 > k ? r.y0 - k : 0u, (uint32_t)std::min<uint64_t>((uint64_t)r.x1 + k, w), (uint32_t)std::min<uint64_t>((uint64_t)r.y1 + k, h)};
+}
 // the rectangle of a full-resolution rectangle in an image of cols x rows texels showing the frame at 1 / divisor resolution (begin rounds down, end up:
 // the same rule as bandRowsInImage)
 Rect scaleRect(const Rect& r, uint32_t frameW, uint32_t frameH, uint32_t cols, uint32_t rows) {
@@ -185,9 +190,14 @@ __global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
 // ahead the communication stream's head is such a wait nearly all the time, and the kernels of a band measured 5 - 20 % longer (trace 116 -> 141 us, shade 215 -> 227,
 // spatial filter 111 -> 125: profiles/r05_tile_vs_band.txt "value wait"). A pending EVENT wait costs nothing, and neither does one sleeping wave: the wait is a
 // one-wave kernel on the communication stream that sleeps until the word has reached the value; stream order then holds the transfers back behind it.
-__global__ __launch_bounds__(64) void waitForValueKernel(const uint32_t* __restrict__ word, uint32_t value) {
+// `cancel`: a word of pinned host memory the exchange's destructor sets - a frame that failed between the producer's launch and its edge signal would otherwise
+// leave this wave asleep for ever and hipStreamDestroy / hipFree waiting for it
+__global__ __launch_bounds__(64) void waitForValueKernel(const uint32_t* __restrict__ word, uint32_t value, const uint32_t* __restrict__ cancel) {
     if (threadIdx.x == 0)
-        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) __builtin_amdgcn_s_sleep(16);
+        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+            if (cancel && __hip_atomic_load(cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
@@ -237,9 +247,66 @@ struct Watchdog {
 
 struct StageArena { uint8_t* ptr = nullptr; size_t size = 0; };
 
+// ---------------------------------------------------------------- the IN-PROCESS transport (round 6)
+// All ranks of a partition in ONE process on one GPU (one host thread + backend + pipeline + exchange each, as tests/test_config5_8k.py runs them): where a
+// communicator's ncclSend / ncclRecv go, a rank publishes what it posted - per transfer {peer, direction, address, bytes}, in posting order: the k-th send of rank a
+// to rank b pairs with b's k-th receive from a, RCCL's matching rule inside a group - with an event behind its pack kernel, waits (on the host) until the peers it
+// receives from have published the same exchange of the same frame, and copies their send ranges into its receive ranges on ITS stream behind their events
+// (hipMemcpyAsync device to device). Then it waits until the peers it sends to have enqueued their copies and orders its stream behind them: a send buffer - a
+// staging arena, or for bands the image rows themselves - is not overwritten while a peer still reads it, which is what a completed ncclSend guarantees.
+// Everything else of an exchange is the code the communicator path runs: plans, pack / unpack kernels, the communication stream, BEGIN behind the producers' edge
+// signal (the sleeping-wave wait), END, the watchdog. The all-reduces (histogram sum, depth range min / max) go through per-rank slots of group memory and a
+// one-block kernel per rank.
+// FROZEN (plrf_local_group_freeze): a rank no longer waits for its peers; it copies from what they published LAST - their buffers keep the texels of their last
+// frame. tools/band_cost.py times one partition alone that way, with real neighbour data (one frame old) in its halos instead of its own texels.
+struct LocalGroup {
+    struct Op { int peer; bool send; uint8_t* ptr; size_t bytes; };
+    struct Post { uint64_t generation = 0, received = 0; std::vector<Op> ops; hipEvent_t posted = nullptr, copied = nullptr; };
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, device = -1;
+    bool aborted = false, frozen = false;
+    uint32_t timeoutMs = 120000;
+    std::vector<std::vector<Post>> posts; // [rank][exchange id]
+    // all-reduce slots: [parity][rank] x 512 bytes of device memory, the event behind each rank's copy into its slot
+    uint8_t* slots = nullptr;
+    static constexpr size_t kSlotBytes = 512;
+    struct Reduce { uint64_t generation = 0; hipEvent_t filled = nullptr; };
+    std::vector<std::vector<Reduce>> reduces; // [rank][exchange id]
+    std::string error;
+
+    ~LocalGroup() {
+        for (auto& r : posts) for (Post& p : r) { if (p.posted) hipEventDestroy(p.posted); if (p.copied) hipEventDestroy(p.copied); }
+        for (auto& r : reduces) for (Reduce& q : r) if (q.filled) hipEventDestroy(q.filled);
+        if (slots) hipFree(slots);
+    }
+    // waits until pred() holds; false (with `error` set) on abort or timeout
+    template <class Pred> bool waitFor(std::unique_lock<std::mutex>& lock, const char* what, Pred pred) {
+        const bool ok = cv.wait_for(lock, std::chrono::milliseconds(timeoutMs), [&] { return aborted || pred(); });
+        if (!ok) { aborted = true; error = std::string("in-process exchange: timed out waiting for ") + what; cv.notify_all(); return false; }
+        if (aborted && !pred()) { if (error.empty()) error = "in-process exchange: another rank failed"; return false; }
+        return true;
+    }
+};
+// dst[i] = reduction over the ranks' slots; op 0: uint32 sum (histogram bins), 1: {min, max} of two floats (depth range)
+__global__ __launch_bounds__(128) void localAllReduceKernel(const uint8_t* __restrict__ slots, int world, int op, uint32_t words, uint32_t* __restrict__ dst) {
+    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= words) return;
+    if (op == 0) {
+        uint32_t sum = 0;
+        for (int r = 0; r < world; r++) sum += ((const uint32_t*)(slots + (size_t)r * LocalGroup::kSlotBytes))[i];
+        dst[i] = sum;
+    } else {
+        float v = ((const float*)slots)[i];
+        for (int r = 1; r < world; r++) { const float o = ((const float*)(slots + (size_t)r * LocalGroup::kSlotBytes))[i]; v = i == 0 ? fminf(v, o) : fmaxf(v, o); }
+        ((float*)dst)[i] = v;
+    }
+}
+
 struct RcclExchange {
     FramePipeline* fp = nullptr;
     ncclComm_t comm = nullptr;
+    LocalGroup* local = nullptr;  // the in-process transport (plrf_local_attach_rects): ranks of one process exchange through device copies
     bool loopback = false;
     int rank = 0, world = 1, device = 0;
     uint32_t frameWidth = 0, frameHeight = 0;
@@ -265,6 +332,11 @@ struct RcclExchange {
     std::mutex dogMutex;
     std::condition_variable dogWake;
     bool dogStop = false, dogAbort = true;
+    // the watchdog REPORTS an overdue exchange after dog.deadlineMs (stderr, and the next exchange callback fails); it ABORTS the process only when the exchange is
+    // still incomplete dogAbortAfterMs later (PLRF_EXCHANGE_WATCHDOG_ABORT_MS; a peer paused in a debugger or an oversubscribed host recovers before that - ADVICE r05)
+    uint32_t dogAbortAfterMs = 30000;
+    std::chrono::steady_clock::time_point dogFiredAt;
+    uint32_t* cancelWord = nullptr; // pinned host word waitForValueKernel polls (set by the destructor)
     std::atomic<bool> dogFired{false};
     std::string dogMessage;
 
@@ -275,6 +347,7 @@ struct RcclExchange {
         }
         dogWake.notify_all();
         if (dogThread.joinable()) dogThread.join();
+        if (cancelWord) *(volatile uint32_t*)cancelWord = 1u; // a wave still asleep on an edge signal that will never come lets go
         if (comm) ncclCommDestroy(comm);
         for (auto e : ready) if (e) hipEventDestroy(e);
         for (auto e : done) if (e) hipEventDestroy(e);
@@ -282,6 +355,7 @@ struct RcclExchange {
         for (auto& a : sendArena) if (a.ptr) hipFree(a.ptr);
         for (auto& a : recvArena) if (a.ptr) hipFree(a.ptr);
         if (commStream) hipStreamDestroy(commStream);
+        if (cancelWord) hipHostFree(cancelWord);
     }
 
     int nccl(ncclResult_t r, const char* what) { return r == ncclSuccess ? 0 : xfail(PLR_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r)); }
@@ -295,6 +369,7 @@ struct RcclExchange {
         if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_MS")) dog.deadlineMs = (uint32_t)std::max(0, std::atoi(ms));
         if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_FIRST_MS")) dog.graceMs = (uint32_t)std::max(0, std::atoi(ms));
         if (const char* ab = std::getenv("PLRF_EXCHANGE_WATCHDOG_ABORT")) dogAbort = std::atoi(ab) != 0;
+        if (const char* ms = std::getenv("PLRF_EXCHANGE_WATCHDOG_ABORT_MS")) dogAbortAfterMs = (uint32_t)std::max(0, std::atoi(ms));
         for (int i = 0; i < PLRF_EXCHANGE_COUNT; i++) dogArgs[i] = {this, i};
         if (!dog.deadlineMs) return;
         dogThread = std::thread([this] {
@@ -304,12 +379,20 @@ struct RcclExchange {
                 dogWake.wait_for(lock, std::chrono::milliseconds(50));
                 if (dogStop) break;
                 std::string msg;
-                if (!dogFired.load() && dog.poll(&msg)) {
+                const bool overdue = dog.poll(&msg);
+                if (!dogFired.load() && overdue) {
                     dogMessage = msg;
                     dogFired.store(true);
+                    dogFiredAt = std::chrono::steady_clock::now();
                     std::fprintf(stderr, "[plr] %s\n", msg.c_str());
                     std::fflush(stderr);
-                    if (dogAbort) std::abort();
+                } else if (dogFired.load() && !overdue) {
+                    dogFired.store(false); // it completed after all (a benign stall): frames go on
+                    std::fprintf(stderr, "[plr] exchange watchdog: the overdue exchange of rank %d has completed\n", rank);
+                } else if (dogFired.load() && dogAbort && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - dogFiredAt).count() > (long long)dogAbortAfterMs) {
+                    std::fprintf(stderr, "[plr] exchange watchdog: still incomplete %u ms after the report: aborting (a posted collective cannot be cancelled)\n", dogAbortAfterMs);
+                    std::fflush(stderr);
+                    std::abort();
                 }
             }
         });
@@ -352,6 +435,79 @@ struct RcclExchange {
         return 0;
     }
 
+    // ---- the in-process transport: `ops` = this rank's transfers of exchange `id` in posting order; the send data is final on `stream` when this is called
+    // (behind the pack kernel / the producer); returns with the copies of every receive enqueued on `stream` and `stream` ordered behind the peers' reads of the sends
+    int localTransfer(int id, const std::vector<LocalGroup::Op>& ops, hipStream_t stream) {
+        LocalGroup& g = *local;
+        LocalGroup::Post& mine = g.posts[(size_t)rank][(size_t)id];
+        if (!mine.posted) {
+            if (int rc = hip(hipEventCreateWithFlags(&mine.posted, hipEventDisableTiming), "hipEventCreateWithFlags")) return rc;
+            if (int rc = hip(hipEventCreateWithFlags(&mine.copied, hipEventDisableTiming), "hipEventCreateWithFlags")) return rc;
+        }
+        if (int rc = hip(hipEventRecord(mine.posted, stream), "hipEventRecord(posted)")) return rc;
+        std::unique_lock<std::mutex> lock(g.m);
+        mine.ops = ops;
+        const uint64_t gen = ++mine.generation;
+        g.cv.notify_all();
+        std::vector<int> from, to;
+        for (const LocalGroup::Op& o : ops) { std::vector<int>& v = o.send ? to : from; if (std::find(v.begin(), v.end(), o.peer) == v.end()) v.push_back(o.peer); }
+        if (!g.frozen) {
+            if (!g.waitFor(lock, "a peer to post its side of the exchange", [&] { for (int p : from) if (g.posts[(size_t)p][(size_t)id].generation < gen) return false; return true; }))
+                return xfail(PLR_ERR_HIP, g.error);
+        }
+        // my k-th receive from p <- p's k-th send to me
+        for (int p : from) {
+            const LocalGroup::Post& theirs = g.posts[(size_t)p][(size_t)id];
+            if (!theirs.posted || theirs.generation == 0) return xfail(PLR_ERR_HIP, "in-process exchange: peer " + std::to_string(p) + " has never posted exchange " + std::to_string(id));
+            std::vector<const LocalGroup::Op*> sends;
+            for (const LocalGroup::Op& o : theirs.ops) if (o.send && o.peer == rank) sends.push_back(&o);
+            size_t k = 0;
+            if (int rc = hip(hipStreamWaitEvent(stream, theirs.posted, 0), "hipStreamWaitEvent(peer posted)")) return rc;
+            for (const LocalGroup::Op& o : ops) {
+                if (o.send || o.peer != p) continue;
+                if (k >= sends.size() || sends[k]->bytes != o.bytes)
+                    return xfail(PLR_ERR_HIP, "in-process exchange " + std::to_string(id) + ": rank " + std::to_string(rank) + " expects " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(p) +
+                                                  ", which posted " + (k < sends.size() ? std::to_string(sends[k]->bytes) + " bytes" : std::string("fewer sends")) + " (the plans of the two ranks disagree)");
+                if (int rc = hip(hipMemcpyAsync(o.ptr, sends[k]->ptr, o.bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(in-process transfer)")) return rc;
+                k++;
+            }
+            if (k != sends.size()) return xfail(PLR_ERR_HIP, "in-process exchange " + std::to_string(id) + ": rank " + std::to_string(p) + " posted more sends to rank " + std::to_string(rank) + " than it receives");
+        }
+        if (int rc = hip(hipEventRecord(mine.copied, stream), "hipEventRecord(copied)")) return rc;
+        mine.received = gen;
+        g.cv.notify_all();
+        if (!g.frozen) {
+            if (!g.waitFor(lock, "a peer to take what was sent to it", [&] { for (int p : to) if (g.posts[(size_t)p][(size_t)id].received < gen) return false; return true; }))
+                return xfail(PLR_ERR_HIP, g.error);
+            for (int p : to) if (int rc = hip(hipStreamWaitEvent(stream, g.posts[(size_t)p][(size_t)id].copied, 0), "hipStreamWaitEvent(peer copied)")) return rc;
+        }
+        return 0;
+    }
+    // in-process all-reduce of `bytes` (<= 512) at ptr, in place: op 0 = uint32 sum, 1 = {min, max} of two floats
+    int localAllReduce(int id, void* ptr, size_t bytes, int op, hipStream_t stream) {
+        LocalGroup& g = *local;
+        if (bytes > LocalGroup::kSlotBytes) return xfail(PLR_ERR_UNSUPPORTED, "in-process all-reduce: more than 512 bytes");
+        LocalGroup::Reduce& mine = g.reduces[(size_t)rank][(size_t)id];
+        if (!mine.filled) if (int rc = hip(hipEventCreateWithFlags(&mine.filled, hipEventDisableTiming), "hipEventCreateWithFlags")) return rc;
+        std::unique_lock<std::mutex> lock(g.m);
+        const uint64_t gen = mine.generation + 1;
+        uint8_t* base = g.slots + (size_t)(gen & 1u) * (size_t)g.world * LocalGroup::kSlotBytes; // two sets of slots: a rank one exchange ahead does not overwrite what a peer still reads
+        lock.unlock();
+        if (int rc = hip(hipMemcpyAsync(base + (size_t)rank * LocalGroup::kSlotBytes, ptr, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(all-reduce slot)")) return rc;
+        if (int rc = hip(hipEventRecord(mine.filled, stream), "hipEventRecord(filled)")) return rc;
+        lock.lock();
+        mine.generation = gen;
+        g.cv.notify_all();
+        if (g.frozen) return 0; // a rank on its own: its value is the "sum" (timing replay only)
+        if (!g.waitFor(lock, "every rank to reach the all-reduce", [&] { for (int p = 0; p < g.world; p++) if (g.reduces[(size_t)p][(size_t)id].generation < gen) return false; return true; }))
+            return xfail(PLR_ERR_HIP, g.error);
+        for (int p = 0; p < g.world; p++) if (p != rank) if (int rc = hip(hipStreamWaitEvent(stream, g.reduces[(size_t)p][(size_t)id].filled, 0), "hipStreamWaitEvent(filled)")) return rc;
+        lock.unlock();
+        const uint32_t words = (uint32_t)(bytes / 4);
+        localAllReduceKernel<<<(words + 127u) / 128u, 128, 0, stream>>>(base, g.world, op, words, (uint32_t*)ptr);
+        return hip(hipGetLastError(), "localAllReduceKernel");
+    }
+
     // tile rendering: pack -> one send / receive per peer -> unpack, on `stream`
     int postPacked(int id, const plrf_exchange_item* items, uint32_t count, hipStream_t stream) {
         struct PeerPlan { size_t sendBytes = 0, recvBytes = 0, sendOffset = 0, recvOffset = 0; };
@@ -390,7 +546,15 @@ struct RcclExchange {
             (o.send ? packs : unpacks).push_back(r);
         }
         if (int rc = launchCopies<true>(packs, stream)) return rc;
-        if (loopback) {
+        if (local) {
+            std::vector<LocalGroup::Op> lops;
+            for (int p = 0; p < world; p++) { // the order of the communicator path's group: per peer, the send, then the receive
+                const PeerPlan& pp = peers[(size_t)p];
+                if (pp.sendBytes) lops.push_back({p, true, sendArena[id].ptr + pp.sendOffset, pp.sendBytes});
+                if (pp.recvBytes) lops.push_back({p, false, recvArena[id].ptr + pp.recvOffset, pp.recvBytes});
+            }
+            if (int rc = localTransfer(id, lops, stream)) return rc;
+        } else if (loopback) {
             // stand-in for the links: the arena's bytes make one trip through the copy path (the texels that "arrive" are this rank's own: timing only)
             const size_t n = std::min(sendTotal, recvTotal);
             if (n) if (int rc = hip(hipMemcpyAsync(recvArena[id].ptr, sendArena[id].ptr, n, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(loopback)")) return rc;
@@ -420,6 +584,19 @@ struct RcclExchange {
         if (packedRegions) {
             if (rects.empty()) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: the pipeline renders a tile but the exchange was attached with rows only (plrf_rccl_attach_rects)");
             return postPacked(id, items, count, stream);
+        }
+        if (local) { // the transfers of the communicator path below, through the in-process transport: straight from / into the images
+            std::vector<LocalGroup::Op> lops;
+            for (uint32_t i = 0; i < count; i++) {
+                const plrf_exchange_item& it = items[i];
+                for (const plrf_exchange_op& o : planBandRows(frameHeight, (uint32_t)world, bounds.empty() ? nullptr : bounds.data(), (uint32_t)rank, it.image_rows, it.halo_rows, it.row_begin, it.row_end)) {
+                    const size_t bytes = (size_t)(o.row_end - o.row_begin) * it.row_bytes;
+                    lops.push_back({(int)o.peer, o.send != 0, (uint8_t*)it.device_ptr + (size_t)o.row_begin * it.row_bytes, bytes});
+                    (o.send ? bytesSent : bytesReceived) += bytes;
+                }
+            }
+            exchanges++;
+            return localTransfer(id, lops, stream);
         }
         if (loopback) { // bands send straight from the images: nothing local to stand in for; the bytes a real exchange would move are still counted
             for (uint32_t i = 0; i < count; i++) {
@@ -455,6 +632,7 @@ struct RcclExchange {
             void* ptr = nullptr;
             size_t bytes = 0;
             if (int rc = plrf_get_histogram_exchange(fp, &ptr, &bytes)) return xfail(rc, plrf_last_error());
+            if (local) return localAllReduce(id, ptr, bytes, 0, launchStream);
             if (loopback) return 0;
             // 128 bin counts, each < 2^32 pixels in total: the unsigned sum is exact, so every band derives the same exposure
             if (int rc = nccl(ncclAllReduce(ptr, ptr, bytes / 4, ncclUint32, ncclSum, comm, launchStream), "ncclAllReduce(histogram)")) return rc;
@@ -465,6 +643,7 @@ struct RcclExchange {
             void* ptr = nullptr;
             size_t bytes = 0;
             if (int rc = plrf_get_depth_apex_exchange(fp, &ptr, &bytes)) return xfail(rc, plrf_last_error());
+            if (local) return localAllReduce(id, ptr, 8, 1, launchStream);
             if (loopback) return 0;
             float* f = (float*)ptr;
             if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
@@ -486,7 +665,7 @@ struct RcclExchange {
                 lastOverlapMode = 2;
                 static const bool waitInKernel = !std::getenv("PLRF_EXCHANGE_BEGIN_WAIT") || std::string(std::getenv("PLRF_EXCHANGE_BEGIN_WAIT")) != "value"; // experiment hook
                 if (waitInKernel) {
-                    waitForValueKernel<<<1, 64, 0, commStream>>>((const uint32_t*)signal, value);
+                    waitForValueKernel<<<1, 64, 0, commStream>>>((const uint32_t*)signal, value, cancelWord);
                     if (int rc = hip(hipGetLastError(), "waitForValueKernel")) return rc;
                 } else if (int rc = hip(hipStreamWaitValue32(commStream, signal, value, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32")) return rc;
             } else {
@@ -525,14 +704,15 @@ struct RcclExchange {
 int attachCommon(void* pipeline, const void* unique_id_128_bytes, int rank, int world, RcclExchange* x, void** out_exchange) {
     x->fp = (FramePipeline*)pipeline;
     x->rank = rank; x->world = world;
-    x->loopback = unique_id_128_bytes == nullptr;
+    x->loopback = unique_id_128_bytes == nullptr && !x->local;
     int rc = x->hip(hipGetDevice(&x->device), "hipGetDevice");
-    if (!rc && !x->loopback) {
+    if (!rc && !x->loopback && !x->local) {
         ncclUniqueId id;
         std::memcpy(&id, unique_id_128_bytes, sizeof(id));
         rc = x->nccl(ncclCommInitRank(&x->comm, world, id, rank), "ncclCommInitRank");
     }
     if (!rc) rc = x->hip(hipStreamCreateWithFlags(&x->commStream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    if (!rc) { rc = x->hip(hipHostMalloc((void**)&x->cancelWord, 64, hipHostMallocMapped), "hipHostMalloc(cancel word)"); if (!rc) *x->cancelWord = 0u; }
     for (int i = 0; i < PLRF_EXCHANGE_COUNT && !rc; i++) {
         rc = x->hip(hipEventCreateWithFlags(&x->ready[i], hipEventDisableTiming), "hipEventCreateWithFlags");
         if (!rc) rc = x->hip(hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming), "hipEventCreateWithFlags");
@@ -658,6 +838,7 @@ int plrf_rccl_attach_rects(void* pipeline, const void* unique_id_128_bytes, int 
     if (!b.enabled() || mine[0] != c0 || mine[2] != c1 || mine[1] != b.rowBegin || mine[3] != b.rowEnd || fp->settings.width != frame_width || fp->settings.height != frame_height)
         return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_rccl_attach_rects: the pipeline was not created with this rank's rectangle");
     RcclExchange* x = new RcclExchange();
+    x->local = g_pendingLocalGroup; // plrf_local_attach_rects: the in-process transport takes the communicator's place
     x->frameWidth = frame_width; x->frameHeight = frame_height;
     x->rects.assign((const Rect*)rects, (const Rect*)rects + world);
     // (whole-row rectangles: the band path needs the row boundaries, which the rectangles carry when they are listed top to bottom)
@@ -669,6 +850,59 @@ int plrf_rccl_attach_rects(void* pipeline, const void* unique_id_128_bytes, int 
         for (const Rect& r : x->rects) x->bounds.push_back(r.y1);
     }
     return attachCommon(pipeline, unique_id_128_bytes, rank, world, x, out_exchange);
+}
+
+// ---- the in-process transport (see LocalGroup above)
+int plrf_local_group_create(int world, void** out_group) {
+    if (!out_group || world < 1 || world > 64) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_local_group_create: invalid argument");
+    LocalGroup* g = new LocalGroup();
+    g->world = world;
+    g->posts.assign((size_t)world, std::vector<LocalGroup::Post>(PLRF_EXCHANGE_COUNT));
+    g->reduces.assign((size_t)world, std::vector<LocalGroup::Reduce>(PLRF_EXCHANGE_COUNT));
+    if (const char* ms = std::getenv("PLRF_LOCAL_EXCHANGE_TIMEOUT_MS")) g->timeoutMs = (uint32_t)std::max(1, std::atoi(ms));
+    *out_group = g;
+    return PLR_OK;
+}
+int plrf_local_group_destroy(void* group) { delete (LocalGroup*)group; return PLR_OK; }
+int plrf_local_group_abort(void* group) {
+    if (!group) return PLR_OK;
+    LocalGroup* g = (LocalGroup*)group;
+    std::lock_guard<std::mutex> lock(g->m);
+    g->aborted = true;
+    g->cv.notify_all();
+    return PLR_OK;
+}
+int plrf_local_group_freeze(void* group, int frozen) {
+    if (!group) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_local_group_freeze: null group");
+    LocalGroup* g = (LocalGroup*)group;
+    std::lock_guard<std::mutex> lock(g->m);
+    g->frozen = frozen != 0;
+    g->cv.notify_all();
+    return PLR_OK;
+}
+int plrf_local_attach_rects(void* pipeline, void* group, int rank, int world, uint32_t frame_width, uint32_t frame_height, const uint32_t* rects, void** out_exchange) {
+    if (!group) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_local_attach_rects: null group");
+    LocalGroup* g = (LocalGroup*)group;
+    if (world != g->world) return xfail(PLR_ERR_INVALID_ARGUMENT, "plrf_local_attach_rects: the group was created for another number of ranks");
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return xfail(PLR_ERR_HIP, "hipGetDevice");
+    {
+        std::lock_guard<std::mutex> lock(g->m);
+        if (g->device < 0) g->device = device;
+        if (g->device != device) return xfail(PLR_ERR_UNSUPPORTED, "plrf_local_attach_rects: the in-process transport copies device to device on ONE GPU; ranks on several GPUs use the communicator (plrf_rccl_attach_rects)");
+        if (!g->slots) {
+            if (hipMalloc((void**)&g->slots, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMalloc(all-reduce slots)");
+            if (hipMemset(g->slots, 0, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMemset(all-reduce slots)");
+        }
+    }
+    void* exchange = nullptr;
+    // the rectangle checks and the band bookkeeping of the communicator path; the group takes the communicator's place
+    g_pendingLocalGroup = g;
+    const int rc = plrf_rccl_attach_rects(pipeline, nullptr, rank, world, frame_width, frame_height, rects, &exchange);
+    g_pendingLocalGroup = nullptr;
+    if (rc) return rc;
+    *out_exchange = exchange;
+    return PLR_OK;
 }
 
 int plrf_rccl_detach(void* pipeline, void* exchange) {

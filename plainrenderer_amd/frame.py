@@ -44,6 +44,35 @@ class PlrfCamera(C.Structure):
     _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3)]
 
 
+class LocalExchangeGroup:
+    """shared state of the in-process transport of the native exchange (include/plr_frame.h plrf_local_group_*): one per partition, created before its ranks'
+    pipelines attach (FramePipeline.attach_local_rects), destroyed after they are gone"""
+
+    def __init__(self, world):
+        from .backend import _load
+        self.lib = _load()
+        self.handle = C.c_void_p()
+        self.lib.plrf_local_group_destroy.argtypes = [C.c_void_p]
+        self.lib.plrf_local_group_abort.argtypes = [C.c_void_p]
+        self.lib.plrf_local_group_freeze.argtypes = [C.c_void_p, C.c_int]
+        if self.lib.plrf_local_group_create(C.c_int(world), C.byref(self.handle)) != 0:
+            raise PlrError("plrf_local_group_create failed")
+
+    def abort(self):
+        """wake ranks that wait for a peer which has failed"""
+        if self.handle:
+            self.lib.plrf_local_group_abort(self.handle)
+
+    def freeze(self, frozen=True):
+        """frozen: a rank copies from what its peers posted last instead of waiting for them (one partition timed alone with real neighbour data)"""
+        self.lib.plrf_local_group_freeze(self.handle, C.c_int(int(bool(frozen))))
+
+    def destroy(self):
+        if self.handle:
+            self.lib.plrf_local_group_destroy(self.handle)
+            self.handle = None
+
+
 class FramePipeline:
     def __init__(self, be: RenderBackend, width, height, **overrides):
         self.be, self.lib = be, be.lib
@@ -99,6 +128,17 @@ class FramePipeline:
         rc = self.lib.plrf_rccl_attach_rects(self.handle, uid, C.c_int(rank), C.c_int(world), C.c_uint32(frame_width), C.c_uint32(frame_height), flat, C.byref(x))
         if rc != 0:
             raise PlrError("plrf_rccl_attach_rects failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
+        self._rccl = x
+
+    def attach_local_rects(self, group, rank, world, frame_width, frame_height, rects):
+        """the native exchange over the IN-PROCESS transport (plrf_local_attach_rects): every rank of the partition lives in this process on one GPU (a thread each);
+        group: a LocalExchangeGroup shared by the ranks"""
+        self.lib.plrf_rccl_last_error.restype = C.c_char_p
+        x = C.c_void_p()
+        flat = (C.c_uint32 * (4 * world))(*[int(v) for r in rects for v in r])
+        rc = self.lib.plrf_local_attach_rects(self.handle, group.handle, C.c_int(rank), C.c_int(world), C.c_uint32(frame_width), C.c_uint32(frame_height), flat, C.byref(x))
+        if rc != 0:
+            raise PlrError("plrf_local_attach_rects failed (%d): %s" % (rc, self.lib.plrf_rccl_last_error().decode()))
         self._rccl = x
 
     def rccl_info(self):

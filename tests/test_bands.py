@@ -147,7 +147,7 @@ def _make_inputs():
     return SyntheticInputs(scene, cams[1], cams[0], W, H, sdf_res=16, shadow_res=128, froxel_depth=8, sun_direction=(0.35, -0.8, 0.45))
 
 
-def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1, extra=None, rects=None):
+def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1, extra=None, rects=None, transport="python"):
     """one backend + pipeline on the calling thread; band = (index, n) or None for the whole frame; extra = more FramePipeline settings;
     rects: the partition as rectangles (tile rendering) - band[0] then indexes it"""
     from plainrenderer_amd import RenderBackend
@@ -165,7 +165,12 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1,
         fp = FramePipeline(be, W, H, **kw)
         inp = copy.copy(inputs)
         inp.upload(fp)
-        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band[0]), H, band[1], band[0], rects=rects, width=W) if band is not None else None
+        ex = None
+        if band is not None and transport == "native":
+            # the native exchange (csrc/frontend/band_exchange.cpp) over its in-process transport: the exchange code of the multi-GPU run, device copies for links
+            fp.attach_local_rects(group, band[0], band[1], W, H, rects if rects is not None else tiling.band_rects(W, H, band[1]))
+        elif band is not None:
+            ex = tiling.Exchange(fp, tiling.LocalTransport(group, band[0]), H, band[1], band[0], rects=rects, width=W)
         cams = _cams()
         frames = []
         for f in range(N_FRAMES):
@@ -184,7 +189,7 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1,
     except BaseException as e:  # surface failures of worker threads (and unblock the others)
         out[band[0] if band is not None else "full"] = e
         if group is not None:
-            group.barrier.abort()
+            group.abort() if transport == "native" else group.barrier.abort()
         raise
 
 
@@ -200,15 +205,18 @@ def _run_full(inputs, exact, half_res=1, extra=None):
     return out["full"]
 
 
-def _run_bands(inputs, n, exact, halos, half_res=1, extra=None, rects=None):
+def _run_bands(inputs, n, exact, halos, half_res=1, extra=None, rects=None, transport="python"):
     from plainrenderer_amd import backend
-    group = tiling.LocalGroup(n, backend._load())
+    from plainrenderer_amd.frame import LocalExchangeGroup
+    group = LocalExchangeGroup(n) if transport == "native" else tiling.LocalGroup(n, backend._load())
     out = {}
-    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res, extra, rects)) for i in range(n)]
+    threads = [threading.Thread(target=_run, args=(inputs, exact, (i, n), group, halos, out, half_res, extra, rects, transport)) for i in range(n)]
     for t in threads:
         t.start()
     for t in threads:
         t.join(timeout=600)
+    if transport == "native":
+        group.destroy()
     for i in range(n):
         assert i in out, "band %d did not finish" % i
         if isinstance(out[i], BaseException):
@@ -234,8 +242,9 @@ def _compare(full, bands, n, what=("post", "color", "swap"), rects=None):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["native", "python"])
 @pytest.mark.parametrize("half_res", [1, 0])
-def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
+def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res, transport):
     # n = 2: the neighbour is the rest of the frame, so halos as tall as the image make every pass's inputs complete and the
     # partitioned frame must equal the unpartitioned one in every bit, over 3 frames of temporal feedback
     inputs = _make_inputs()
@@ -243,13 +252,14 @@ def test_gpu_two_bands_reproduce_the_full_frame_bit_exact(half_res):
     # half_res 1: the default overlapped exchange (producers' edge rows first, begin / end callbacks); half_res 0: one callback per exchange
     overlap = half_res == 1
     halos = dict(band_gi_halo=H, band_gi_history_halo=H, band_post_halo=H, band_taa_history_halo=H, band_overlap_exchange=int(overlap))
-    bands = _run_bands(inputs, 2, True, halos, half_res)
+    bands = _run_bands(inputs, 2, True, halos, half_res, transport=transport)
     mism = _compare(full, bands, 2)
     bad = {k: v for k, v in mism.items() if v != 0.0}
     assert not bad, bad
     B, E = 0x100, 0x200
     expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if overlap else [0, 1, 2, 3, 4]
-    assert bands[0]["calls"][:len(expected)] == expected
+    if transport == "python":  # (the native exchange is the callback itself: no Python-side log of its calls)
+        assert bands[0]["calls"][:len(expected)] == expected
 
 
 @pytest.mark.gpu
@@ -700,8 +710,9 @@ def _tile_rects(gx, gy):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["native", "python"])
 @pytest.mark.parametrize("grid,half_res", [((2, 2), 1), ((2, 1), 1), ((2, 2), 0), ((4, 3), 1), ((1, 3), 1)])
-def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res):
+def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res, transport):
     """BASELINE config 5's partition: the frame as 2 x 2 screen tiles (and 2 x 1; 4 x 3 tiles of 64 x 64 pixels and three whole-row rectangles, where tiles that do NOT
     touch exchange too: a plan reaches every rank within the halo), one backend per tile on this GPU, rectangles moved by the in-process transport.
     Halos as large as the image make every pass's inputs complete: the tiled frame must equal the unpartitioned one in
@@ -713,13 +724,14 @@ def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res):
     n = len(rects)
     big = max(W, H)
     halos = dict(band_gi_halo=big, band_gi_history_halo=big, band_post_halo=big, band_taa_history_halo=big, band_overlap_exchange=2 if half_res else 0)
-    tiles = _run_bands(inputs, n, True, halos, half_res, rects=rects)
+    tiles = _run_bands(inputs, n, True, halos, half_res, rects=rects, transport=transport)
     mism = _compare(full, tiles, n, rects=rects)
     bad = {k: v for k, v in mism.items() if v != 0.0}
     assert not bad, bad
     B, E = 0x100, 0x200
     expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if half_res else [0, 1, 2, 3, 4]
-    assert tiles[0]["calls"][:len(expected)] == expected
+    if transport == "python":
+        assert tiles[0]["calls"][:len(expected)] == expected
 
 
 @pytest.mark.gpu

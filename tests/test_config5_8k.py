@@ -2,8 +2,11 @@
 partition config 5 names - and as FOUR row bands, with the default halos, the benchmarked (PLR_MATH_FAST) kernel set, pass fusion on and a balanced
 partition, over temporal feedback.
 
-All four partitions run in this process on one GPU (one host thread + one backend each, tiling.LocalTransport moves the halo rectangles - the recording,
-the dispatch bases, the exchange points and the kernels are exactly those of the 4-GPU run; only the transport differs). Every partition is held to the
+All four partitions run in this process on one GPU, one host thread + one backend + one pipeline each. The exchange is the NATIVE one (csrc/frontend/band_exchange.cpp:
+plans, pack / unpack kernels, communication stream, BEGIN behind the producers' edge signal, END, watchdog) over its in-process transport (round 6,
+plr_frame.h plrf_local_attach_rects: device copies where a communicator's ncclSend / ncclRecv go) - the recording, the dispatch bases, the exchange points, the kernels
+AND the exchange code are those of the 4-GPU run; only the links differ. transport "python" (the exact mode only) is the older diagnostic path: the same pipelines
+with tiling.LocalTransport moving the rectangles from Python behind host synchronisations. Every partition is held to the
 UNPARTITIONED 8K frame, and a strip that straddles a boundary to the ORACLE frame (the scalar C++ restatement, run on the host cores).
 
 Two modes (plr_frame.h band_gi_halo):
@@ -93,7 +96,7 @@ def _partition(inputs, cams, kind):
     return out
 
 
-def _render(inputs, cams, band, rects, group, out, capture, mode="halo"):
+def _render(inputs, cams, band, rects, group, out, capture, mode="halo", transport="native"):
     """one backend + C++ FramePipeline on the calling thread; band = index or None (the unpartitioned frame)"""
     from plainrenderer_amd import RenderBackend
     from plainrenderer_amd.frame import FramePipeline
@@ -121,7 +124,11 @@ def _render(inputs, cams, band, rects, group, out, capture, mode="halo"):
                                                                                           fp.settings.band_post_halo, fp.settings.band_taa_history_halo), flush=True)
         inp = inputs if band is None else copy.copy(inputs)  # (the unpartitioned run's upload leaves the texture-array indices the oracle frame needs)
         inp.upload(fp)
-        ex = tiling.Exchange(fp, tiling.LocalTransport(group, band), H, N_BANDS, band, rects=rects, width=W) if band is not None else None
+        ex = None
+        if band is not None and transport == "native":
+            fp.attach_local_rects(group, band, N_BANDS, W, H, rects)
+        elif band is not None:
+            ex = tiling.Exchange(fp, tiling.LocalTransport(group, band), H, N_BANDS, band, rects=rects, width=W)
         c0, r0, c1, r1 = (0, 0, W, H) if band is None else rects[band]
         frames = []
         for f in range(N_FRAMES):
@@ -145,14 +152,15 @@ def _render(inputs, cams, band, rects, group, out, capture, mode="halo"):
                 rec["weights"] = fp.resolve_weights()
                 rec["frustum"] = be.downloadUniformBuffer(fp.uniform_buffer("sdfCameraFrustum"), 192).tobytes()
             frames.append(rec)
-        res = dict(frames=frames, fused=be.getPassFusion()[1], settings=fp.settings if band is None else None, calls=list(ex.calls) if ex else [])
+        res = dict(frames=frames, fused=be.getPassFusion()[1], settings=fp.settings if band is None else None, calls=list(ex.calls) if ex else [],
+                   exchange=(fp.rccl_stats(), fp.rccl_info()) if (band is not None and transport == "native") else None)
         fp.destroy()
         be.shutdown()
         out[key] = res
     except BaseException as e:  # surface failures of worker threads (and unblock the others)
         out[key] = e
         if group is not None:
-            group.barrier.abort()
+            group.abort() if transport == "native" else group.barrier.abort()
         raise
 
 
@@ -175,11 +183,12 @@ _FULL = {}  # the unpartitioned 8K frames, rendered once for both partitions
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["exact", "halo"])
+@pytest.mark.parametrize("transport,mode", [("native", "exact"), ("native", "halo"), ("python", "exact")])
 @pytest.mark.parametrize("kind", ["tiles2x2", "bands4"])
-def test_gpu_config5_the_8k_frame_partitioned_against_the_unpartitioned_frame_and_the_oracle(kind, mode):
+def test_gpu_config5_the_8k_frame_partitioned_against_the_unpartitioned_frame_and_the_oracle(kind, mode, transport):
     import bench
     from plainrenderer_amd import backend as backend_mod
+    from plainrenderer_amd.frame import LocalExchangeGroup
     assert H % 256 == 0 or H == 4320
     if "scene" not in _FULL:
         _FULL["scene"] = bench.build_scene(_Args, "cuda:0", W, H)
@@ -191,10 +200,19 @@ def test_gpu_config5_the_8k_frame_partitioned_against_the_unpartitioned_frame_an
         _join([threading.Thread(target=_render, args=(inputs, cams, None, rects, None, out, True))], out, ["full"])
         _FULL["full"] = out["full"]
     full = _FULL["full"]
-    group = tiling.LocalGroup(N_BANDS, backend_mod._load())
-    _join([threading.Thread(target=_render, args=(inputs, cams, i, rects, group, out, None, mode)) for i in range(N_BANDS)], out, list(range(N_BANDS)))
+    group = LocalExchangeGroup(N_BANDS) if transport == "native" else tiling.LocalGroup(N_BANDS, backend_mod._load())
+    try:
+        _join([threading.Thread(target=_render, args=(inputs, cams, i, rects, group, out, None, mode, transport)) for i in range(N_BANDS)], out, list(range(N_BANDS)))
+    finally:
+        if transport == "native":
+            group.destroy()
+    if transport == "native":
+        (sent, received, groups), info = out[1]["exchange"]
+        print("CONFIG5 %s %s native in-process exchange, partition 1: %.1f MB sent, %.1f MB received per frame in %d groups; overlap mode %d, %s" % (
+            kind, mode, sent / 1e6, received / 1e6, groups, info["overlap_mode"], "rectangles through pack / unpack kernels" if info["packed_regions"] else "whole rows straight from the images"), flush=True)
+        assert sent > 0 and received > 0 and groups >= 4
     worst_within1, worst_swap, worst_moved, worst_exposure, worst_early, worst_code = 1.0, 1.0, 0, 0.0, 1.0, 0
-    kind_mode = "%s %s" % (kind, mode)
+    kind_mode = "%s %s" % (kind, mode) + ("" if transport == "native" else " (python transport)")
     lines = []
     for f in range(N_FRAMES):
         if not _kept(f):
@@ -256,7 +274,8 @@ def test_gpu_config5_the_8k_frame_partitioned_against_the_unpartitioned_frame_an
     assert worst_swap >= 0.99
     # the overlapped exchange sequence of a partition: histogram, GI trace (begin / end), temporal GI (begin / end), GI history, resolved colour (begin / end)
     B, E = 0x100, 0x200
-    assert out[1]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E]
+    if transport != "native":
+        assert out[1]["calls"][:8] == [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E]
     # partition mode keeps the fusions that matter: per-tile pyramid + culling, upscale + shade as one launch, packed GI texels from the producers
     assert out[1]["fused"] >= 10, out[1]["fused"]
 
