@@ -38,6 +38,15 @@ typedef struct plrf_settings {
      * frames and has no steady state within 256 (profiles/r05_config5_series.txt). band_gi_halo = PLRF_HALO_WHOLE_IMAGE exchanges every GI texel with every
      * rank: the partitioned frame then EQUALS the unpartitioned one, bit for bit (tests/test_config5_8k.py, 64 frames at 8K), at the price in the same file. */
 #define PLRF_HALO_WHOLE_IMAGE 0xffffffffu
+    /* band_gi_halo = PLRF_HALO_REQUESTED (round 6; half-resolution trace only): REQUEST LISTS instead of a halo in front of the two spatial filter passes. Where a disc
+     * sample lands depends on depth, camera and frame index only (filterIndirectDiffuseSpatial.comp:53-105), so right after the depth downscale a giSampleRequests pass per
+     * filter marks, in a bitmap over the trace image, every texel outside this rectangle a sample of this rectangle's pixels lands on; the exchange callback
+     * PLRF_EXCHANGE_GI_REQUESTS trades the bitmaps (to each peer the part over its rectangle) while the trace runs, and at PLRF_EXCHANGE_GI_TRACE /
+     * PLRF_EXCHANGE_GI_TEMPORAL every owner sends exactly the requested texels - Y_SH, CoCg and the half-resolution depth, 16 bytes each - which the receiver scatters
+     * into its images. Nothing is masked, nothing is approximated: the partitioned frame EQUALS the unpartitioned one bit for bit (tests/test_config5_8k.py), like
+     * PLRF_HALO_WHOLE_IMAGE, for 6 - 27 MB received per rank and frame at 8K instead of 200 MB (profiles/r06_gi_request_count.txt). plrf_get_gi_request_exchange
+     * describes the buffers to an exchange callback; the native exchange (plrf_rccl_attach_rects / plrf_local_attach_rects) implements it. */
+#define PLRF_HALO_REQUESTED 0xfffffffeu
     /* input producers recorded as compute passes instead of uploaded (0 = uploaded): lightMatrix.comp after the depth pyramid */
     uint32_t run_light_matrix; float volumetrics_max_distance;
     uint32_t taa_use_separate_supersampling, taa_supersample_use_tonemapping; /* TAASettings::useSeparateSupersampling (off), supersampleUseTonemapping */
@@ -68,7 +77,7 @@ enum plrf_exchange_id { PLRF_EXCHANGE_HISTOGRAM = 0, PLRF_EXCHANGE_GI_TRACE = 1,
                          * depth pyramid; a band has none). plrf_get_depth_apex_exchange names two floats {min, max} in device memory holding the band's
                          * range: replace them IN PLACE by the minimum of all bands' first and the maximum of all bands' second float (exact: the result
                          * equals the unpartitioned pyramid's apex bit for bit) */
-                        PLRF_EXCHANGE_DEPTH_APEX = 5, PLRF_EXCHANGE_COUNT = 6 };
+                        PLRF_EXCHANGE_DEPTH_APEX = 5, PLRF_EXCHANGE_GI_REQUESTS = 6, PLRF_EXCHANGE_COUNT = 7 };
 /* phase bits or-ed into exchange_id when band_overlap_exchange is on (ids 1..4; the histogram is always one call): after the producer's
  * edge rows are launched the callback gets id | PLRF_EXCHANGE_BEGIN and must only START the transfers (stream-ordered after what is already
  * on hip_stream); the producer's interior rows are launched next and run beside the transfers; before the first consumer of the halo rows
@@ -90,6 +99,19 @@ int plrf_set_exchange_callback(void* pipeline, plrf_exchange_callback callback, 
 /* items of the frame being launched (valid inside the callback and until the next plrf_frame); *inout_count = capacity in, count out */
 int plrf_get_exchange_items(void* pipeline, int exchange_id, plrf_exchange_item* out_items, uint32_t* inout_count);
 int plrf_get_histogram_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes);
+/* the request-list exchange (band_gi_halo = PLRF_HALO_REQUESTED): the trace image's size, this rank's rectangle in trace texels, and per spatial filter pass (0: its
+ * input is the traced GI, exchanged at PLRF_EXCHANGE_GI_TRACE; 1: the temporally filtered GI, PLRF_EXCHANGE_GI_TEMPORAL) the request bitmap (row_words 32-bit words
+ * per texel row; bit x % 32 of word x / 32) and the input images; depth = the filters' R16F depth texture. enabled = 0: the pipeline does not use request lists. */
+typedef struct plrf_gi_request {
+    int32_t enabled;
+    uint32_t image_cols, image_rows, row_words;
+    uint32_t x0, y0, x1, y1;
+    void* bitmap[2];
+    void* ysh[2];
+    void* cocg[2];
+    void* depth;
+} plrf_gi_request;
+int plrf_get_gi_request_exchange(void* pipeline, plrf_gi_request* out);
 /* non-zero: this pipeline records rows-first producers (band_overlap_exchange 2): a BEGIN callback may wait for plr_get_edge_signal */
 int plrf_band_rows_first(void* pipeline);
 int plrf_get_depth_apex_exchange(void* pipeline, void** out_device_ptr, size_t* out_bytes); /* 8 bytes: float min, float max */

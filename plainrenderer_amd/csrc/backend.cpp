@@ -41,7 +41,7 @@ static bool shaderTakesColumns(const std::string& shader) {
     static const char* const names[] = {"histogramPerTile.comp", "histogramCombineTiles.comp", "depthHiZPyramid.comp", "depthPyramidApex.comp", "depthDownscale.comp",
                                         "sdfCameraTileCulling.comp", "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp", "filterIndirectDiffuseTemporal.comp",
                                         "indirectLightUpscale.comp", "deferredShading.comp", "temporalFilter.comp", "bloomDownsample.comp", "bloomUpsample.comp",
-                                        "applyBloom.comp", "tonemapping.comp"};
+                                        "applyBloom.comp", "tonemapping.comp", "giSampleRequests.comp"};
     for (const char* n : names) if (shader == n) return true;
     return false;
 }

@@ -185,6 +185,57 @@ __global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
     }
 }
 
+// ---------------------------------------------------------------- request lists (plr_frame.h PLRF_HALO_REQUESTED)
+// A SLICE is the part of a request bitmap over one rank's rectangle, tightly packed: `rows` texel rows of `wordsPerRow` words, word (0, 0) = texel (x0, y0) of
+// the rectangle (x0 a multiple of 32: rectangle edges are multiples of 64 pixels = 32 trace texels). Both sides of a request walk the same slice - the requester's
+// copy and the copy it sent - in the same order: word by word, bit by bit; offsets[w] = set bits in front of word w, so texel number offsets[w] + (set bits of
+// word w below bit b) of the response belongs to bit b of word w.
+struct RequestSlice { const uint32_t* bits; uint32_t* offsets; uint32_t* count; uint32_t words; };
+constexpr int kMaxSlices = 64;
+struct SliceTable { int n; RequestSlice s[kMaxSlices]; };
+// one block per slice: exclusive prefix sum of the words' population counts, the total into *count
+__global__ __launch_bounds__(1024) void requestScanKernel(SliceTable t) {
+    __shared__ uint32_t partial[1024];
+    const RequestSlice sl = t.s[blockIdx.x];
+    const uint32_t per = (sl.words + 1023u) / 1024u, begin = threadIdx.x * per, end = min(begin + per, sl.words);
+    uint32_t sum = 0;
+    for (uint32_t w = begin; w < end; w++) sum += (uint32_t)__popc(sl.bits[w]);
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? partial[threadIdx.x - d] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[threadIdx.x] - sum;
+    for (uint32_t w = begin; w < end; w++) { sl.offsets[w] = run; run += (uint32_t)__popc(sl.bits[w]); }
+    if (threadIdx.x == 1023u) *sl.count = partial[1023];
+}
+// the texels one peer asked this rank for (GATHER: images -> buffer, 16 bytes each: Y_SH, CoCg, the R16F depth) / the texels this rank asked one peer for
+// (scatter: buffer -> images); (x0, y0) = the rectangle the slice covers, in trace texels
+struct RequestWalk { const uint32_t* bits; const uint32_t* offsets; uint4* buffer; uint32_t words, wordsPerRow, x0, y0; };
+constexpr int kMaxWalks = 16;
+struct WalkTable { int n; RequestWalk w[kMaxWalks]; uint2* ysh; uint32_t* cocg; uint16_t* depth; uint32_t imageCols; };
+template <bool GATHER>
+__global__ __launch_bounds__(256) void requestWalkKernel(WalkTable t) {
+    const RequestWalk k = t.w[blockIdx.y];
+    for (uint32_t wi = blockIdx.x * 256u + threadIdx.x; wi < k.words; wi += gridDim.x * 256u) {
+        uint32_t bits = k.bits[wi];
+        if (!bits) continue;
+        const uint32_t row = wi / k.wordsPerRow, col = wi - row * k.wordsPerRow;
+        uint32_t slot = k.offsets[wi];
+        while (bits) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            const size_t idx = (size_t)(k.y0 + row) * t.imageCols + (k.x0 + col * 32u + b);
+            if (GATHER) { const uint2 y = t.ysh[idx]; k.buffer[slot] = make_uint4(y.x, y.y, t.cocg[idx], (uint32_t)t.depth[idx]); }
+            else { const uint4 v = k.buffer[slot]; t.ysh[idx] = make_uint2(v.x, v.y); t.cocg[idx] = v.z; t.depth[idx] = (uint16_t)v.w; }
+            slot++;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- waiting for the producer's edge signal on the communication stream
 // hipStreamWaitValue32 does it in the command processor - and a PENDING value wait on one stream slows every kernel the chip runs meanwhile: with the host a frame
 // ahead the communication stream's head is such a wait nearly all the time, and the kernels of a band measured 5 - 20 % longer (trace 116 -> 141 us, shade 215 -> 227,
@@ -212,7 +263,7 @@ struct Watchdog {
     uint32_t graceMs = 60000, graceArms = 64, arms = 0;
     static const char* phaseName(int phase) { return phase == PLRF_EXCHANGE_BEGIN ? "BEGIN (transfers posted, completion pending)" : (phase == PLRF_EXCHANGE_END ? "END" : "in line on the launch stream"); }
     static const char* idName(int id) {
-        static const char* names[PLRF_EXCHANGE_COUNT] = {"histogram all-reduce", "traced GI halo", "temporally filtered GI halo", "GI history halo", "resolved colour + TAA history halo", "depth range all-reduce"};
+        static const char* names[PLRF_EXCHANGE_COUNT] = {"histogram all-reduce", "traced GI halo", "temporally filtered GI halo", "GI history halo", "resolved colour + TAA history halo", "depth range all-reduce", "GI sample requests"};
         return id >= 0 && id < PLRF_EXCHANGE_COUNT ? names[id] : "?";
     }
     void arm(int rank, int id, int phase, plrf_watchdog_query query, void* user) {
@@ -322,6 +373,21 @@ struct RcclExchange {
     uint32_t doneSerial[PLRF_EXCHANGE_COUNT] = {};
     StageArena sendArena[PLRF_EXCHANGE_COUNT], recvArena[PLRF_EXCHANGE_COUNT];
     uint64_t bytesSent = 0, bytesReceived = 0, exchanges = 0; // of the last frame (reset by the histogram exchange, the first of a frame)
+    // request lists (PLRF_HALO_REQUESTED): per peer one buffer of request slices going out (the peer's rectangle, both spatial filter passes) and one coming in (this
+    // rank's rectangle, both passes), their per-word offsets, the totals (device, and a pinned copy the host reads behind countsReady)
+    struct RequestState {
+        bool ready = false;
+        plrf_gi_request info{};
+        struct Peer { uint32_t outWords = 0, outWordsPerRow = 0, inWords = 0; uint32_t* out = nullptr; uint32_t* in = nullptr; uint32_t* outOff = nullptr; uint32_t* inOff = nullptr; Rect rect{}; };
+        std::vector<Peer> peers;          // [world]; the entry of this rank is empty
+        uint32_t inWordsPerRow = 0;
+        Rect mine{};
+        uint8_t* arena = nullptr;
+        uint32_t* countsDev = nullptr;    // [2 points][world][2: out, in]
+        uint32_t* countsHost = nullptr;   // pinned
+        hipEvent_t countsReady = nullptr;
+        StageArena send[2], recv[2];
+    } req;
     int lastOverlapMode = 0;
     bool packedRegions = false;
     int streamWaitValueSupported = 0;
@@ -356,6 +422,12 @@ struct RcclExchange {
         for (auto& a : recvArena) if (a.ptr) hipFree(a.ptr);
         if (commStream) hipStreamDestroy(commStream);
         if (cancelWord) hipHostFree(cancelWord);
+        if (req.arena) hipFree(req.arena);
+        if (req.countsDev) hipFree(req.countsDev);
+        if (req.countsHost) hipHostFree(req.countsHost);
+        if (req.countsReady) hipEventDestroy(req.countsReady);
+        for (auto& a : req.send) if (a.ptr) hipFree(a.ptr);
+        for (auto& a : req.recv) if (a.ptr) hipFree(a.ptr);
     }
 
     int nccl(ncclResult_t r, const char* what) { return r == ncclSuccess ? 0 : xfail(PLR_ERR_HIP, std::string(what) + ": " + ncclGetErrorString(r)); }
@@ -574,6 +646,155 @@ struct RcclExchange {
         return launchCopies<false>(unpacks, stream);
     }
 
+    // ---- request lists (plr_frame.h PLRF_HALO_REQUESTED). moves `ops` (posting order; the peers post the mirror image) through the communicator or the in-process transport
+    int transfer(int id, const std::vector<LocalGroup::Op>& ops, hipStream_t stream) {
+        for (const LocalGroup::Op& o : ops) (o.send ? bytesSent : bytesReceived) += o.bytes;
+        exchanges++;
+        if (local) return localTransfer(id, ops, stream);
+        if (loopback) return 0; // (one rank on its own: nothing to ask anybody for)
+        if (int rc = nccl(ncclGroupStart(), "ncclGroupStart")) return rc;
+        int rc = 0;
+        for (size_t k = 0; k < ops.size() && !rc; k++)
+            rc = ops[k].send ? nccl(ncclSend(ops[k].ptr, ops[k].bytes, ncclUint8, ops[k].peer, comm, stream), "ncclSend") : nccl(ncclRecv(ops[k].ptr, ops[k].bytes, ncclUint8, ops[k].peer, comm, stream), "ncclRecv");
+        const int grc = nccl(ncclGroupEnd(), "ncclGroupEnd");
+        return rc ? rc : grc;
+    }
+    Rect traceRect(int p) const { // rank p's rectangle in trace texels
+        Rect full;
+        if (!rects.empty()) full = rects[(size_t)p];
+        else { uint32_t b0, b1; if (bounds.empty()) bandRowsOf(frameHeight, (uint32_t)world, (uint32_t)p, &b0, &b1); else { b0 = bounds[(size_t)p]; b1 = bounds[(size_t)p + 1]; } full = {0u, b0, frameWidth, b1}; }
+        return scaleRect(full, frameWidth, frameHeight, req.info.image_cols, req.info.image_rows);
+    }
+    int prepareRequests(hipStream_t stream) {
+        plrf_gi_request info;
+        if (int rc = plrf_get_gi_request_exchange(fp, &info)) return xfail(rc, plrf_last_error());
+        if (!info.enabled) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: a request exchange for a pipeline without band_gi_halo = PLRF_HALO_REQUESTED");
+        if (req.ready && std::memcmp(&info, &req.info, sizeof(info)) == 0) return 0;
+        if (req.ready) return xfail(PLR_ERR_UNSUPPORTED, "exchange: the request buffers of the pipeline changed");
+        req.info = info;
+        req.mine = traceRect(rank);
+        if (req.mine.x0 != info.x0 || req.mine.y0 != info.y0 || req.mine.x1 != info.x1 || req.mine.y1 != info.y1) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: the pipeline's rectangle is not this rank's");
+        auto wordsPerRow = [](const Rect& r) { return (r.x1 + 31u) / 32u - r.x0 / 32u; };
+        req.inWordsPerRow = wordsPerRow(req.mine);
+        const uint32_t inWords = 2u * req.inWordsPerRow * (req.mine.y1 - req.mine.y0);
+        req.peers.assign((size_t)world, RequestState::Peer{});
+        size_t total = 0;
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            RequestState::Peer& pe = req.peers[(size_t)p];
+            pe.rect = traceRect(p);
+            if (pe.rect.x0 % 32u || req.mine.x0 % 32u) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists need rectangle edges on multiples of 32 trace texels");
+            pe.outWordsPerRow = wordsPerRow(pe.rect);
+            pe.outWords = 2u * pe.outWordsPerRow * (pe.rect.y1 - pe.rect.y0);
+            pe.inWords = inWords;
+            total += 2 * ((size_t)pe.outWords + pe.inWords) * 4 + 4 * 256;
+        }
+        // (cleared ON THE STREAM the exchange runs on: hipMemset goes to the null stream, which does not order against non-blocking streams - the clear could land on
+        //  top of the first frame's slices)
+        if (int rc = hip(hipMalloc((void**)&req.arena, std::max<size_t>(total, 256)), "hipMalloc(request slices)")) return rc;
+        if (int rc = hip(hipMemsetAsync(req.arena, 0, std::max<size_t>(total, 256), stream), "hipMemsetAsync(request slices)")) return rc;
+        uint8_t* at = req.arena;
+        auto take = [&](uint32_t words) { uint32_t* p0 = (uint32_t*)at; at += (((size_t)words * 4 + 255) & ~(size_t)255); return p0; };
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            RequestState::Peer& pe = req.peers[(size_t)p];
+            pe.out = take(pe.outWords); pe.in = take(pe.inWords); pe.outOff = take(pe.outWords); pe.inOff = take(pe.inWords);
+        }
+        const size_t countBytes = (size_t)2 * (size_t)world * 2 * sizeof(uint32_t);
+        if (int rc = hip(hipMalloc((void**)&req.countsDev, countBytes), "hipMalloc(request counts)")) return rc;
+        if (int rc = hip(hipMemsetAsync(req.countsDev, 0, countBytes, stream), "hipMemsetAsync(request counts)")) return rc;
+        if (int rc = hip(hipHostMalloc((void**)&req.countsHost, countBytes, hipHostMallocDefault), "hipHostMalloc(request counts)")) return rc;
+        std::memset(req.countsHost, 0, countBytes);
+        if (int rc = hip(hipEventCreateWithFlags(&req.countsReady, hipEventDisableTiming), "hipEventCreateWithFlags")) return rc;
+        req.ready = true;
+        return 0;
+    }
+    uint32_t* countSlot(uint32_t* base, int point, int peer, int in) const { return base + (((size_t)point * (size_t)world + (size_t)peer) * 2 + (size_t)in); }
+    // PLRF_EXCHANGE_GI_REQUESTS: the marks of both spatial filter passes are in the bitmaps (the launch stream is behind the giSampleRequests passes); every peer gets the
+    // part over its rectangle, this rank the parts over its own, and the totals go to the host
+    int postRequests(hipStream_t stream) {
+        if (int rc = prepareRequests(stream)) return rc;
+        std::vector<CopyRegion> packs;
+        std::vector<LocalGroup::Op> ops;
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            const RequestState::Peer& pe = req.peers[(size_t)p];
+            for (int q = 0; q < 2; q++) {
+                CopyRegion r;
+                r.image = (uint8_t*)req.info.bitmap[q] + ((size_t)pe.rect.y0 * req.info.row_words + pe.rect.x0 / 32u) * 4;
+                r.buffer = (uint8_t*)(pe.out + (size_t)q * (pe.outWords / 2));
+                r.pitch = req.info.row_words * 4; r.widthBytes = pe.outWordsPerRow * 4; r.rows = pe.rect.y1 - pe.rect.y0; r.unit = 4u;
+                packs.push_back(r);
+            }
+            ops.push_back({p, true, (uint8_t*)pe.out, (size_t)pe.outWords * 4});
+            ops.push_back({p, false, (uint8_t*)pe.in, (size_t)pe.inWords * 4});
+        }
+        if (int rc = launchCopies<true>(packs, stream)) return rc;
+        if (int rc = transfer(PLRF_EXCHANGE_GI_REQUESTS, ops, stream)) return rc;
+        SliceTable t{};
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            const RequestState::Peer& pe = req.peers[(size_t)p];
+            for (int q = 0; q < 2; q++) {
+                if (t.n + 2 > kMaxSlices) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists for more than 16 peers");
+                t.s[t.n++] = {pe.out + (size_t)q * (pe.outWords / 2), pe.outOff + (size_t)q * (pe.outWords / 2), countSlot(req.countsDev, q, p, 0), pe.outWords / 2};
+                t.s[t.n++] = {pe.in + (size_t)q * (pe.inWords / 2), pe.inOff + (size_t)q * (pe.inWords / 2), countSlot(req.countsDev, q, p, 1), pe.inWords / 2};
+            }
+        }
+        if (t.n) {
+            requestScanKernel<<<(unsigned)t.n, 1024, 0, stream>>>(t);
+            if (int rc = hip(hipGetLastError(), "requestScanKernel")) return rc;
+        }
+        if (int rc = hip(hipMemcpyAsync(req.countsHost, req.countsDev, (size_t)2 * (size_t)world * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(request counts)")) return rc;
+        return hip(hipEventRecord(req.countsReady, stream), "hipEventRecord(request counts)");
+    }
+    // PLRF_EXCHANGE_GI_TRACE / _GI_TEMPORAL with request lists: this rank's input images of spatial filter pass `point` are complete on its rectangle (the launch stream is
+    // behind their producer): gather what the peers asked for, trade, scatter what this rank asked for into the images and the depth texture
+    int postRequested(int id, int point, hipStream_t stream) {
+        if (!req.ready) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: requested texels before the request exchange of the frame");
+        if (int rc = hip(hipEventSynchronize(req.countsReady), "hipEventSynchronize(request counts)")) return rc; // the host needs the sizes; the GPU is long past this point
+        size_t sendTotal = 0, recvTotal = 0;
+        std::vector<size_t> sendAt((size_t)world, 0), recvAt((size_t)world, 0);
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            sendAt[(size_t)p] = sendTotal; sendTotal += (size_t)*countSlot(req.countsHost, point, p, 1) * 16;
+            recvAt[(size_t)p] = recvTotal; recvTotal += (size_t)*countSlot(req.countsHost, point, p, 0) * 16;
+        }
+        if (int rc = arena(req.send[point], std::max<size_t>(sendTotal, 16))) return rc;
+        if (int rc = arena(req.recv[point], std::max<size_t>(recvTotal, 16))) return rc;
+        WalkTable gather{}, scatter{};
+        gather.ysh = scatter.ysh = (uint2*)req.info.ysh[point]; gather.cocg = scatter.cocg = (uint32_t*)req.info.cocg[point]; gather.depth = scatter.depth = (uint16_t*)req.info.depth;
+        gather.imageCols = scatter.imageCols = req.info.image_cols;
+        std::vector<LocalGroup::Op> ops;
+        uint32_t maxGather = 1, maxScatter = 1;
+        for (int p = 0; p < world; p++) {
+            if (p == rank) continue;
+            const RequestState::Peer& pe = req.peers[(size_t)p];
+            const uint32_t nIn = *countSlot(req.countsHost, point, p, 1), nOut = *countSlot(req.countsHost, point, p, 0);
+            if (gather.n >= kMaxWalks) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists for more than 16 peers");
+            if (nIn) {
+                gather.w[gather.n++] = {pe.in + (size_t)point * (pe.inWords / 2), pe.inOff + (size_t)point * (pe.inWords / 2), (uint4*)(req.send[point].ptr + sendAt[(size_t)p]), pe.inWords / 2, req.inWordsPerRow, req.mine.x0, req.mine.y0};
+                maxGather = std::max(maxGather, pe.inWords / 2);
+                ops.push_back({p, true, req.send[point].ptr + sendAt[(size_t)p], (size_t)nIn * 16});
+            }
+            if (nOut) {
+                scatter.w[scatter.n++] = {pe.out + (size_t)point * (pe.outWords / 2), pe.outOff + (size_t)point * (pe.outWords / 2), (uint4*)(req.recv[point].ptr + recvAt[(size_t)p]), pe.outWords / 2, pe.outWordsPerRow, pe.rect.x0, pe.rect.y0};
+                maxScatter = std::max(maxScatter, pe.outWords / 2);
+                ops.push_back({p, false, req.recv[point].ptr + recvAt[(size_t)p], (size_t)nOut * 16});
+            }
+        }
+        if (gather.n) {
+            requestWalkKernel<true><<<dim3(std::min((maxGather + 255u) / 256u, 256u), (unsigned)gather.n), 256, 0, stream>>>(gather);
+            if (int rc = hip(hipGetLastError(), "requestWalkKernel(gather)")) return rc;
+        }
+        if (int rc = transfer(id, ops, stream)) return rc;
+        if (scatter.n) {
+            requestWalkKernel<false><<<dim3(std::min((maxScatter + 255u) / 256u, 256u), (unsigned)scatter.n), 256, 0, stream>>>(scatter);
+            if (int rc = hip(hipGetLastError(), "requestWalkKernel(scatter)")) return rc;
+        }
+        return 0;
+    }
+
     // all transfers of exchange `id`, one ncclGroup, on `stream`
     int post(int id, hipStream_t stream) {
         plrf_exchange_item items[16];
@@ -651,6 +872,14 @@ struct RcclExchange {
             const int r1 = nccl(ncclAllReduce(f + 1, f + 1, 1, ncclFloat, ncclMax, comm, launchStream), "ncclAllReduce(depth max)");
             const int grc = nccl(ncclGroupEnd(), "ncclGroupEnd");
             if (r0 || r1 || grc) return r0 ? r0 : (r1 ? r1 : grc);
+            return watch(id, 0, launchStream);
+        }
+        if (id == PLRF_EXCHANGE_GI_REQUESTS) {
+            if (int rc = postRequests(launchStream)) return rc;
+            return watch(id, 0, launchStream);
+        }
+        if ((id == PLRF_EXCHANGE_GI_TRACE || id == PLRF_EXCHANGE_GI_TEMPORAL) && phase == 0 && req.ready) {
+            if (int rc = postRequested(id, id == PLRF_EXCHANGE_GI_TRACE ? 0 : 1, launchStream)) return rc;
             return watch(id, 0, launchStream);
         }
         if (phase == PLRF_EXCHANGE_BEGIN) {
@@ -892,7 +1121,7 @@ int plrf_local_attach_rects(void* pipeline, void* group, int rank, int world, ui
         if (g->device != device) return xfail(PLR_ERR_UNSUPPORTED, "plrf_local_attach_rects: the in-process transport copies device to device on ONE GPU; ranks on several GPUs use the communicator (plrf_rccl_attach_rects)");
         if (!g->slots) {
             if (hipMalloc((void**)&g->slots, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMalloc(all-reduce slots)");
-            if (hipMemset(g->slots, 0, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMemset(all-reduce slots)");
+            if (hipMemset(g->slots, 0, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return xfail(PLR_ERR_HIP, "hipMemset(all-reduce slots)");
         }
     }
     void* exchange = nullptr;

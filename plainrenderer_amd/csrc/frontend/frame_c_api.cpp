@@ -142,6 +142,28 @@ int plrf_get_histogram_exchange(void* p, void** outPtr, size_t* outBytes) {
         *outBytes = 128 * sizeof(uint32_t);
     })
 }
+int plrf_get_gi_request_exchange(void* p, plrf_gi_request* out) {
+    PLRF_TRY({
+        FramePipeline* fp = (FramePipeline*)p;
+        std::memset(out, 0, sizeof(*out));
+        const BandSettings& b = fp->settings.band;
+        out->enabled = b.enabled() && b.giRequested ? 1 : 0;
+        if (!out->enabled) return PLR_OK;
+        const SDFGI& gi = fp->sdfGi();
+        const ImageDescription td = fp->backend().getImageDescription(gi.m_indirectDiffuse_Y_SH[0]);
+        const uint32_t div = fp->settings.sdfTrace.halfResTrace ? 2u : 1u;
+        out->image_cols = td.width; out->image_rows = td.height; out->row_words = gi.m_giRequestRowWords;
+        out->x0 = b.tiled() ? b.colBegin / div : 0u; out->x1 = b.tiled() ? std::min((b.colEnd + div - 1) / div, td.width) : td.width;
+        out->y0 = b.rowBegin / div; out->y1 = std::min((b.rowEnd + div - 1) / div, td.height);
+        size_t bytes = 0;
+        auto imagePtr = [&](ImageHandle h) { void* ptr = nullptr; fp->backend().getImageDevicePointer(h, 0, &ptr, &bytes); return ptr; };
+        for (int i = 0; i < 2; i++)
+            if (plr_get_storage_buffer_device_pointer(gi.m_giRequestBitmap[i].index, &out->bitmap[i], &bytes) != PLR_OK) throw std::runtime_error(plr_last_error());
+        out->ysh[0] = imagePtr(gi.m_indirectDiffuse_Y_SH[0]); out->cocg[0] = imagePtr(gi.m_indirectDiffuse_CoCg[0]);
+        out->ysh[1] = imagePtr(gi.m_indirectDiffuseHistory_Y_SH[1]); out->cocg[1] = imagePtr(gi.m_indirectDiffuseHistory_CoCg[1]);
+        out->depth = imagePtr(fp->depthHalfRes());
+    })
+}
 int plrf_band_rows_first(void* p) {
     const FramePipeline* fp = (const FramePipeline*)p;
     return fp && fp->settings.band.enabled() && fp->settings.band.overlapExchange && fp->settings.band.rowsFirst ? 1 : 0;

@@ -409,6 +409,19 @@ void SDFGI::init(RenderBackend& be, int screenW, int screenH, const SDFTraceSett
         m_diffuseSDFTracePass = be.createComputePass(d);
     }
     for (int i = 0; i < 2; i++) {
+        // the request-list exchange of a partitioned frame (GiBand::requested; no reference counterpart): which texels outside this GPU's rectangle do the disc samples
+        // of spatial filter pass i land on?
+        ComputePassDescription d;
+        d.name = i == 0 ? "Indirect diffuse sample requests (filter 0)" : "Indirect diffuse sample requests (filter 1)";
+        d.shaderDescription.srcPathRelative = "giSampleRequests.comp";
+        d.shaderDescription.specialisationConstants = {spec(0, i)};
+        m_giSampleRequestPass[i] = be.createComputePass(d);
+        m_giRequestRowWords = (tw + 31u) / 32u;
+        StorageBufferDescription rb;
+        rb.size = (size_t)m_giRequestRowWords * th * sizeof(uint32_t);
+        m_giRequestBitmap[i] = be.createStorageBuffer(rb);
+    }
+    for (int i = 0; i < 2; i++) {
         ComputePassDescription d;
         d.name = "Indirect diffuse spatial filter";
         d.shaderDescription.srcPathRelative = "filterIndirectDiffuseSpatial.comp";
@@ -448,7 +461,28 @@ SDFGI::IndirectLightingImages SDFGI::getIndirectLightingResults(bool tracedHalfR
     return {m_indirectDiffuseHistory_Y_SH[0], m_indirectDiffuseHistory_CoCg[0]};
 }
 
+void SDFGI::sampleRequests(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const {
+    // recorded like the spatial filter executions they precede: the same rectangle; what is "valid" is the rectangle itself, every sample beyond it is a request
+    const ImageDescription td = be.getImageDescription(m_indirectDiffuse_Y_SH[1]);
+    for (int i = 0; i < 2; i++) {
+        ComputePassExecution exe;
+        exe.genericInfo.handle = m_giSampleRequestPass[i];
+        exe.genericInfo.resources.sampledImages = {ImageResource(s.halfResTrace ? deps.depthHalfRes : deps.currentFrame.depthBuffer, 0, 4)};
+        exe.genericInfo.resources.storageBuffers = {StorageBufferResource(m_giRequestBitmap[i], false, 6)};
+        dispatch8(exe, td.width, td.height, band->traceRows, band->traceCols);
+        exe.validRows[0] = std::min(band->traceRows.begin, td.height); exe.validRows[1] = std::min(band->traceRows.end, td.height);
+        const uint32_t c0 = std::min(band->traceCols.begin, td.width), c1 = std::min(band->traceCols.end, td.width);
+        if (c0 > 0 || c1 < td.width) { exe.validCols[0] = c0; exe.validCols[1] = c1; }
+        be.setComputePassExecution(exe);
+    }
+}
+
 void SDFGI::computeIndirectLighting(RenderBackend& be, const FrameIndexCounter&, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const {
+    if (band && band->requested) {
+        // where the two spatial filter passes' samples land depends on depth, camera and frame index only: asked for now, traded while the trace runs
+        sampleRequests(be, deps, s, band);
+        band->exchangePoint(band->user, ExchangeGiRequests);
+    }
     diffuseSDFTrace(be, deps, s, band);
     filterIndirectDiffuse(be, deps, s, band);
 }
@@ -542,8 +576,12 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
     const ColRange cols = band ? band->traceCols : ColRange{};
     // band rendering: the spatial filter's inputs are valid on the band's rows and the giHalo rows received from each neighbour; a disc sample
     // beyond them is treated like an off-screen sample (ComputePassExecution::validRows, plr.h) instead of reading rows nobody sent
-    auto setValidRows = [&](ComputePassExecution& exe) {
+    auto setValidRows = [&](ComputePassExecution& exe, int filterIndex) {
         if (!band) return;
+        if (band->requested) { // every texel a sample can land on is either this rectangle's or has been requested and received: nothing is masked (plr.h: {0, 0} = all valid)
+            exe.genericInfo.resources.storageBuffers.push_back(StorageBufferResource(m_giRequestBitmap[filterIndex], true, 6));
+            return;
+        }
         const uint32_t r0 = std::min(rows.begin, td.height), r1 = std::min(rows.end, td.height);
         exe.validRows[0] = r0 > band->giHalo ? r0 - band->giHalo : 0u;
         exe.validRows[1] = std::min(r1 + band->giHalo, td.height);
@@ -561,7 +599,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[0], 0, 2), ImageResource(m_indirectDiffuse_CoCg[0], 0, 3), ImageResource(depthSrc, 0, 4),
                                                    ImageResource(deps.worldSpaceNormals, 0, 5)};
         dispatch8(exe, td.width, td.height, rows, cols);
-        setValidRows(exe);
+        setValidRows(exe, 0);
         be.setComputePassExecution(exe);
     }
     {
@@ -583,7 +621,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.storageImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 0), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 1)};
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
-        setValidRows(exe);
+        setValidRows(exe, 1);
         recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols);
     }
     // (this exchange is small - 16 rows - and its producer launches a packing pre-pass per dispatch: it is not split / overlapped)
@@ -636,6 +674,11 @@ FramePipeline::FramePipeline(const FramePipelineSettings& s) : settings(s) {
     } else if (s.band.tiled()) throw std::runtime_error("tile columns without band rows: set rowBegin / rowEnd too");
     // a halo never needs to be larger than the image (PLRF_HALO_WHOLE_IMAGE: the exact mode of a partitioned frame, every GI texel a denoiser sample can
     // reach is exchanged); clamping here keeps the row arithmetic below in 32 bits
+    if (settings.band.giHalo == 0xfffffffeu) { // PLRF_HALO_REQUESTED
+        if (!s.sdfTrace.halfResTrace) throw std::runtime_error("band_gi_halo = PLRF_HALO_REQUESTED needs the half-resolution trace (the packed-texel spatial filter)");
+        settings.band.giRequested = true;
+        settings.band.giHalo = 0;
+    }
     settings.band.giHalo = std::min(settings.band.giHalo, std::max(W, H));
     settings.band.giHistoryHalo = std::min(settings.band.giHistoryHalo, std::max(W, H));
     for (int i = 0; i < ExchangeCount; i++) {
@@ -1231,7 +1274,12 @@ void FramePipeline::exchangePoint(int id, const char* label) {
     std::vector<ImageHandle> images;
     std::vector<StorageBufferHandle> buffers;
     if ((id & ExchangeIdMask) == ExchangeHistogram) buffers.push_back(m_histogramBuffer);
+    else if ((id & ExchangeIdMask) == ExchangeGiRequests) { buffers.push_back(m_sdfGi.m_giRequestBitmap[0]); buffers.push_back(m_sdfGi.m_giRequestBitmap[1]); }
     else for (const ExchangeItem& it : m_exchangeItems[id & ExchangeIdMask]) images.push_back(it.image);
+    if (settings.band.giRequested && ((id & ExchangeIdMask) == ExchangeGiTrace || (id & ExchangeIdMask) == ExchangeGiTemporal)) {
+        images.push_back(m_depthHalfRes); // the requested texels arrive with their depth
+        buffers.push_back(m_sdfGi.m_giRequestBitmap[(id & ExchangeIdMask) == ExchangeGiTrace ? 0 : 1]);
+    }
     m_be.setHostCallbackExecution(&FramePipeline::exchangeTrampoline, &m_exchangeCtx[phase * ExchangeCount + (id & ExchangeIdMask)], label, images, buffers);
 }
 
@@ -1308,6 +1356,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
             gb.user = this;
             gb.giHalo = settings.band.giHalo; gb.giHistoryHalo = settings.band.giHistoryHalo;
             gb.rowsFirst = settings.band.rowsFirst;
+            gb.requested = settings.band.giRequested;
             // registers the images of a GI exchange and records its callback: phase 0 = whole exchange, ExchangeBegin after the producer's
             // edge rows, ExchangeEnd (items already registered) before the consumer
             static const auto giExchange = [](FramePipeline* self, int id, int phase) {
@@ -1316,7 +1365,9 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
                 const BandSettings& b = self->settings.band;
                 const bool reg = phase != ExchangeEnd;
                 const char* what = phase == ExchangeBegin ? " (start)" : (phase == ExchangeEnd ? " (wait)" : "");
-                if (id == ExchangeGiTrace) {
+                if (id == ExchangeGiRequests) {
+                    self->exchangePoint(id, "Exchange: GI sample requests");
+                } else if (id == ExchangeGiTrace) {
                     if (reg) { self->addExchangeItem(id, gi.m_indirectDiffuse_Y_SH[0], d, b.giHalo); self->addExchangeItem(id, gi.m_indirectDiffuse_CoCg[0], d, b.giHalo); }
                     self->exchangePoint(id | phase, (std::string("Exchange: traced GI halo rows") + what).c_str());
                 } else if (id == ExchangeGiTemporal) {
@@ -1327,7 +1378,7 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
                     self->exchangePoint(id | phase, (std::string("Exchange: GI history halo rows") + what).c_str());
                 }
             };
-            const bool overlap = settings.band.overlapExchange && m_exchangeFn;
+            const bool overlap = settings.band.overlapExchange && m_exchangeFn && !settings.band.giRequested; // (a requested texel can be anywhere in its owner's rectangle: no edges-first producers)
             if (overlap) {
                 gb.exchangeBegin = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeBegin); };
                 gb.exchangePoint = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeEnd); };

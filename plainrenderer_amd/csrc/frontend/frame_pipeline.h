@@ -69,6 +69,11 @@ struct BandSettings {
     uint32_t colBegin = 0, colEnd = 0;
     bool tiled() const { return colEnd > colBegin; }
     uint32_t giHalo = 64;               // trace-resolution rows of the GI images exchanged before each spatial filter pass
+    // REQUEST LISTS instead of a halo in front of the two spatial filter passes (round 6; plr_frame.h PLRF_HALO_REQUESTED): a giSampleRequests pass per filter marks
+    // the texels outside this rectangle its disc samples land on (they depend on depth, camera and frame index only), the exchange callback ExchangeGiRequests
+    // trades the bitmaps, and at ExchangeGiTrace / ExchangeGiTemporal every owner sends exactly the requested texels. The partitioned frame then equals the
+    // unpartitioned one bit for bit, as with a whole-image halo, for 6 - 27 MB per rank and frame at 8K instead of 200 (profiles/r06_gi_request_count.txt)
+    bool giRequested = false;
     uint32_t giHistoryHalo = 16;        // trace-resolution rows of the filtered GI exchanged for the upscale / next frame's reprojection
     uint32_t colorHalo = 8;             // full-resolution rows shaded beyond the band (3x3 neighbourhood of the temporal filter)
     uint32_t postHalo = 224;            // full-resolution rows of the temporal filter's result exchanged for the bloom chain: the chain's dependency cone
@@ -89,7 +94,9 @@ struct BandSettings {
 // phase bits or-ed into the exchange id a callback receives (0: start the exchange and wait for it)
 enum ExchangePhase : int { ExchangeBegin = 0x100, ExchangeEnd = 0x200, ExchangeIdMask = 0xff };
 // ExchangeDepthApex (only with runLightMatrix): all-reduce of the band's depth range, min on .r / max on .g of a 1 x 1 RG32F image (depthApexImage())
-enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeDepthApex = 5, ExchangeCount = 6 };
+// ExchangeGiRequests (only with BandSettings::giRequested): the request bitmaps of both spatial filter passes (FramePipeline::giRequestExchange)
+enum ExchangeId : int { ExchangeHistogram = 0, ExchangeGiTrace = 1, ExchangeGiTemporal = 2, ExchangeGiHistory = 3, ExchangePost = 4, ExchangeDepthApex = 5, ExchangeGiRequests = 6,
+                        ExchangeCount = 7 };
 // one image whose rows next to the band must be refreshed from the neighbours: this band sends its first / last haloRows owned
 // rows up / down and receives [rowBegin - haloRows, rowBegin) and [rowEnd, rowEnd + haloRows) (clipped to the image)
 // tile rendering: the owned rectangle is columns [colBegin, colEnd) of those rows (imageCols texels of texelBytes bytes per row), the halo is haloRows texels wide
@@ -191,6 +198,7 @@ struct GiBand {
     void (*exchangeWhole)(void* user, int exchangeId) = nullptr; // overlap: an exchange that is not split (start and wait in one callback)
     uint32_t giHalo = 0, giHistoryHalo = 0;                      // trace-resolution halo rows of exchanges 1/2 and 3
     bool rowsFirst = false;                                      // BandSettings::rowsFirst
+    bool requested = false;                                      // BandSettings::giRequested: request lists instead of a halo in front of the spatial filters
 };
 // records exe over `rows` of a w x h image; with edgesDone the first / last `halo` rows are recorded first, then edgesDone(), then the rest
 // rowsFirst: ONE execution over all the rows with first_rows = the edges (plr.h), then edgesDone()
@@ -220,7 +228,11 @@ public:
     ImageHandle m_indirectDiffuse_Y_SH[2], m_indirectDiffuse_CoCg[2], m_indirectDiffuseHistory_Y_SH[2], m_indirectDiffuseHistory_CoCg[2];
     ImageHandle m_indirectLightingFullRes_Y_SH, m_indirectLightingFullRes_CoCg;
     StorageBufferHandle m_sdfInstanceBuffer, m_sdfCameraFrustumCulledInstances, m_sdfInstanceWorldBBBuffer, m_sdfCameraCulledTiles;
+    // request-list exchange (GiBand::requested): per spatial filter pass the bitmap of requested texels, ceil(trace width / 32) words per trace row
+    StorageBufferHandle m_giRequestBitmap[2];
+    uint32_t m_giRequestRowWords = 0;
 private:
+    void sampleRequests(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const;
     void sdfInstanceCulling(RenderBackend& be, const SDFTraceDependencies& deps, int targetW, int targetH, float influenceRadius, bool hiZCulling, const GiBand* band) const;
     void diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const;
     void filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies& deps, const SDFTraceSettings& s, const GiBand* band) const;
@@ -229,7 +241,7 @@ public:
 private:
     uint32_t m_sdfInstanceCount = 0;
     RenderPassHandle m_diffuseSDFTracePass, m_indirectDiffuseFilterSpatialPass[2], m_indirectDiffuseFilterTemporalPass, m_indirectLightingUpscale,
-        m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ, m_sdfDebugVisualisationPass;
+        m_sdfCameraFrustumCulling, m_sdfCameraTileCulling, m_sdfCameraTileCullingHiZ, m_sdfDebugVisualisationPass, m_giSampleRequestPass[2];
 };
 
 // Techniques/Sky.h:6-15 (everything in km); laid out as the std140 block of sky.inc:1-10 (56 bytes)
@@ -305,6 +317,8 @@ public:
     void setExchangeCallback(ExchangeCallback fn, void* user) { m_exchangeFn = fn; m_exchangeUser = user; }
     const std::vector<ExchangeItem>& exchangeItems(int exchangeId) const { return m_exchangeItems[exchangeId]; }
     StorageBufferHandle histogramBuffer() const { return m_histogramBuffer; }
+    const SDFGI& sdfGi() const { return m_sdfGi; }
+    ImageHandle depthHalfRes() const { return m_depthHalfRes; }
     ImageHandle depthApexImage() const { return m_bandDepthApex; }
     RenderBackend& backend() { return m_be; }
     FramePipelineSettings settings;

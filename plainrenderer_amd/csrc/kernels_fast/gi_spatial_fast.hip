@@ -84,6 +84,26 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
     packed[idx] = packGiTexel(yt, ct, dep, g->nearPlane, g->farPlane);
 }
 
+// the request-list exchange (MARK above): the texels a rank's samples land on outside its own rectangle arrive one by one (the owners send them, the exchange scatters
+// them into the input images and the depth texture); this packs exactly those - one thread per word of the request bitmap
+template <int DEPTH_FMT>
+__global__ __launch_bounds__(256) void spatialSparsePackKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
+                                                               const uint32_t* __restrict__ bitmap, uint32_t rowWords, uint32_t words) {
+    const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
+    if (wi >= words) return;
+    uint32_t bits = bitmap[wi];
+    if (!bits) return;
+    const uint32_t y = wi / rowWords, xw = wi - y * rowWords;
+    while (bits) {
+        const uint32_t b = (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1u;
+        const uint32_t x = xw * 32u + b;
+        if (x >= (uint32_t)inYSH.w) continue;
+        const size_t idx = (size_t)y * (size_t)inYSH.w + x;
+        packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
+    }
+}
+
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
 // Per-launch constants the launcher works out on the host: this chip has no scalar float unit, so uniform float arithmetic (image sizes as floats, their
 // correctly rounded reciprocals, the norms of three rows of viewProjection: three square roots) is otherwise repeated by every lane
@@ -93,12 +113,16 @@ struct SpatialFrameConsts {
     float nW, nH;      // normal texture size
     float3 vpRowNorms; // |x row|, |y row|, |w row| of the xyz part of viewProjection
 };
-template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG>
+// MARK (round 6, the request-list GI exchange of a partitioned frame; plr_frame.h PLRF_HALO_REQUESTED): the kernel gathers nothing and writes no image - every
+// sample that lands on screen but OUTSIDE the valid rectangle (the rank's own rows / columns) sets its texel's bit in requestBitmap (bitmapRowWords 32-bit words
+// per texel row). Same block -> pixel mapping, same per-pixel frame, same position statements as the filter launch that follows: the sample positions are
+// evaluated in one place (below, contraction off, explicit fused multiply-adds) so that both instantiations land on the same texels, bit for bit.
+template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG, bool MARK = false>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
                                                                int coverW, int coverH, int yBase, int xBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
                                                                uint32_t validY0, uint32_t validRowCount, uint32_t validX0, uint32_t validColCount, int rowMissShrinks,
-                                                               SpatialFrameConsts fc) {
+                                                               SpatialFrameConsts fc, uint32_t* __restrict__ requestBitmap = nullptr, uint32_t bitmapRowWords = 0) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
@@ -155,8 +179,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         B = radiusWorld * unit(pCenter - pUp);
     }
     const int nwi = normalTexture.w, nhi = normalTexture.h;
-    vec3 N;
-    {
+    vec3 N(0.f, 0.f, 1.f);
+    if (!MARK) {
         const int x = clampTo(floorToInt(u0 * fc.nW), nwi - 1), y = clampTo(floorToInt(v0 * fc.nH), nhi - 1);
         const uint32_t t = ((const uint32_t*)normalTexture.ptr)[__umul24((uint32_t)y, (uint32_t)nwi) + (uint32_t)x];
         // c / 255 as the three-instruction form (this file is built with IEEE division: ten instructions per channel otherwise; the same values, device/image.h)
@@ -243,37 +267,49 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             bool off[4];
     #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float ox, oy;
-                if (SAFE) { ox = samples[96 + i0 + k]; oy = samples[128 + i0 + k]; }
-                else { const float d = samples[i0 + k] * lengthModifier; ox = samples[32 + i0 + k] * d; oy = samples[64 + i0 + k] * d; }
-                const float clipX = P0.x + ox * PT.x + oy * PB.x, clipY = P0.y + ox * PT.y + oy * PB.y, clipW = P0.z + ox * PT.z + oy * PB.z;
-                const float invW = rcpf(clipW);
-                float cu = clipX * invW, cv = clipY * invW;
-                off[k] = false;
+                // ---- WHERE the sample lands: every operation spelled out (no contraction left to the compiler), so that the MARK instantiation of this kernel
+                // and the filtering one compute the same texel from the same inputs
+                float cu, cv;
                 uint32_t tx, ty;
-                if (SAFE) {
-                    // `safe` leaves a margin of 1e-3 of the screen: cu * halfW + halfW lies strictly inside (0, width) - no clamp, and trunc == floor
-                    tx = (uint32_t)(int)(cu * halfW + halfW); ty = (uint32_t)(int)(cv * halfH + halfH);
-                    if (!INSIDE) off[k] = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount;
-                } else {
-                    // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
-                    cu = fabsf(cu) > 1.f ? su0 - 2.f * ox : cu;
-                    cv = fabsf(cv) > 1.f ? sv0 - 2.f * oy : cv;
-                    off[k] = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 1.f; // still off-screen: weight 0, shrink the disc (:100-105)
-                    // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
-                    tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfW + halfW, 0.f, yWm1); ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfH + halfH, 0.f, yHm1);
-                    // a row no neighbouring band has sent (band rendering) gets weight 0 like an off-screen sample; whether it also shrinks the disc for the
-                    // samples after it, as an off-screen one does (:100-105), is the launcher's choice (rowMissShrinks; measured in profiles/r04_config5_series.txt)
-                    const bool rowMiss = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount; // (or a column: tile rendering)
-                    lengthModifier = (off[k] || (rowMiss && rowMissShrinks)) ? lengthModifier * 0.98f : lengthModifier;
-                    off[k] = off[k] || rowMiss;
+                bool offScreen = false, miss = false;
+                {
+#pragma clang fp contract(off)
+                    float ox, oy;
+                    if (SAFE) { ox = samples[96 + i0 + k]; oy = samples[128 + i0 + k]; }
+                    else { const float d = samples[i0 + k] * lengthModifier; ox = samples[32 + i0 + k] * d; oy = samples[64 + i0 + k] * d; }
+                    const float clipX = __builtin_fmaf(oy, PB.x, __builtin_fmaf(ox, PT.x, P0.x)), clipY = __builtin_fmaf(oy, PB.y, __builtin_fmaf(ox, PT.y, P0.y));
+                    const float clipW = __builtin_fmaf(oy, PB.z, __builtin_fmaf(ox, PT.z, P0.z));
+                    const float invW = rcpf(clipW);
+                    cu = clipX * invW; cv = clipY * invW;
+                    if (SAFE) {
+                        // `safe` leaves a margin of 1e-3 of the screen: cu * halfW + halfW lies strictly inside (0, width) - no clamp, and trunc == floor
+                        tx = (uint32_t)(int)__builtin_fmaf(cu, halfW, halfW); ty = (uint32_t)(int)__builtin_fmaf(cv, halfH, halfH);
+                        if (!INSIDE) miss = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount;
+                    } else {
+                        // mirror at the borders (:86-89): a coordinate outside [0,1] is replaced by uv - offset
+                        cu = fabsf(cu) > 1.f ? __builtin_fmaf(-2.f, ox, su0) : cu;
+                        cv = fabsf(cv) > 1.f ? __builtin_fmaf(-2.f, oy, sv0) : cv;
+                        offScreen = __builtin_fmaxf(fabsf(cu), fabsf(cv)) > 1.f; // still off-screen: weight 0, shrink the disc (:100-105)
+                        // nearest texel: trunc == floor for non-negative coordinates, negative ones clamp to 0 either way
+                        tx = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(cu, halfW, halfW), 0.f, yWm1); ty = (uint32_t)(int)__builtin_amdgcn_fmed3f(__builtin_fmaf(cv, halfH, halfH), 0.f, yHm1);
+                        // a row no neighbouring band has sent (band rendering) gets weight 0 like an off-screen sample; whether it also shrinks the disc for the
+                        // samples after it, as an off-screen one does (:100-105), is the launcher's choice (rowMissShrinks; measured in profiles/r04_config5_series.txt)
+                        miss = (ty - validY0) >= validRowCount || (tx - validX0) >= validColCount; // (or a column: tile rendering)
+                        lengthModifier = (offScreen || (miss && rowMissShrinks)) ? lengthModifier * 0.98f : lengthModifier;
+                    }
                 }
+                if (MARK) {
+                    if (miss && !offScreen) __hip_atomic_fetch_or(requestBitmap + (size_t)ty * bitmapRowWords + (tx >> 5), 1u << (tx & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
+                off[k] = offScreen || miss;
                 su[k] = cu; sv[k] = cv;
                 ti[k] = __umul24(ty, ywi) + tx; // image sides stay below 2^24
                 if (SIG) { const uint32_t o = off[k] ? 1u : 0u; sampleParityX |= ((tx + o) & 1u) << (i0 + k); sampleParityY |= ((ty + o) & 1u) << (i0 + k); }
                 di[k] = SAME_GRID ? ti[k]
                                   : (uint32_t)(int)__builtin_amdgcn_fmed3f(cv * halfDH + halfDH, 0.f, dHm1) * (uint32_t)dwi + (uint32_t)(int)__builtin_amdgcn_fmed3f(cu * halfDW + halfDW, 0.f, dWm1);
             }
+            if (MARK) continue;
             if (PACKED) {
                 uint4 t4[4];
     #pragma unroll
@@ -326,6 +362,12 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             }
         }
     };
+    if (MARK) {
+        // a wave whose discs provably stay inside the rank's own rectangle requests nothing; the others walk the samples with the copy the filter will take
+        if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
+        else if (__builtin_amdgcn_ballot_w64(!safeInside) != 0ull) sampleLoop(std::true_type{}, std::false_type{});
+        return;
+    }
     if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
     else if (__builtin_amdgcn_ballot_w64(!safeInside) == 0ull) sampleLoop(std::true_type{}, std::true_type{});
     else if (rowMissShrinks == 0) sampleLoop(std::true_type{}, std::false_type{});
@@ -455,6 +497,13 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     int validLo, validHi, validLoX, validHiX;
     c.validRowRange(c.sampled[2].h, &validLo, &validHi);
     c.validColRange(c.sampled[2].w, &validLoX, &validHiX);
+    // the request-list exchange (plr_frame.h PLRF_HALO_REQUESTED): storage buffer 6 = the bitmap of the texels outside the dispatched rectangle this execution's samples land
+    // on (written by giSampleRequests.comp over the same rectangle, filled in by the exchange). Everything is valid then; what has to be packed is the rectangle itself
+    // and those texels
+    const bool requested = c.hasSbuf(6);
+    const uint32_t bitmapRowWords = ((uint32_t)c.sampled[2].w + 31u) / 32u;
+    if (requested && (!sameGrid || c.sbuf[6].size < (size_t)bitmapRowWords * (size_t)c.sampled[2].h * 4u))
+        return c.fail(-4, "filterIndirectDiffuseSpatial: the request bitmap (storage buffer 6) needs inputs on the depth texture's grid and ceil(width / 32) words per texel row");
     if (sameGrid) {
         // what the filter can read: the dispatched rows and a margin (samples further away read whatever an earlier frame packed there, exactly like
         // the stale image rows they would read unpacked), inside the rows declared valid (band rendering: a sample on any other row has weight 0);
@@ -462,10 +511,10 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         // (the margin follows the declared valid rows: a band's GI halo grows with the frame height, 64 trace rows per 2160 - ADVICE r03: with a fixed 128
         //  a frame taller than 4320 rows read stale packed texels on valid halo rows beyond it)
         // (and the declared valid rows may be the whole image while the dispatch is a band: a GI halo as large as the image, the exact mode of tools/config5_series.sh)
-        const int margin = std::max({128, y0 - validLo, validHi - h});
+        const int margin = requested ? 0 : std::max({128, y0 - validLo, validHi - h});
         const int p0 = std::max({y0 - margin, 0, validLo}), p1 = std::min({h + margin, (int)c.sampled[2].h, validHi});
-        const bool tiled = validLoX > 0 || validHiX < (int)c.sampled[2].w || x0 > 0 || w < (int)c.sampled[2].w;
-        const int marginX = std::max({128, x0 - validLoX, validHiX - w});
+        const bool tiled = requested || validLoX > 0 || validHiX < (int)c.sampled[2].w || x0 > 0 || w < (int)c.sampled[2].w;
+        const int marginX = requested ? 0 : std::max({128, x0 - validLoX, validHiX - w});
         const int q0 = tiled ? std::max({x0 - marginX, 0, validLoX}) : 0, q1 = tiled ? std::min({w + marginX, (int)c.sampled[2].w, validHiX}) : (int)c.sampled[2].w;
         PackRect todo[4];
         const int nTodo = p1 > p0 && q1 > q0 ? unpackedRects(c, packed, PackRect{q0, p0, q1, p1}, todo) : 0;
@@ -484,6 +533,13 @@ static int launchSpatialFilterFast(const PassCtx& c) {
             PLR_CHECK_LAUNCH(c);
             c.splitTiming("texel packing");
         } else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
+        if (requested) {
+            const uint32_t words = bitmapRowWords * (uint32_t)c.sampled[2].h;
+            if (c.sampled[4].fmt == F_R16F) spatialSparsePackKernel<F_R16F><<<divUp(words, 256u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
+            else spatialSparsePackKernel<F_D32><<<divUp(words, 256u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
+            PLR_CHECK_LAUNCH(c);
+            c.splitTiming("requested texels");
+        }
     }
     uint32_t* sig = c.sigFor(2u * (size_t)out.w * (size_t)out.h); // two words per pixel
     // per-frame constants of the "can a sample of this pixel leave the screen" test, from the host's copy of the global buffer (a host the backend cannot read
@@ -514,6 +570,59 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     return 0;
 }
 PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseSpatial.comp", launchSpatialFilterFast);
+
+// ---- giSampleRequests.comp (no reference counterpart; the request-list GI exchange of a partitioned frame, plr_frame.h PLRF_HALO_REQUESTED): for the rectangle of
+// trace pixels it is dispatched over - recorded like the spatial filter execution it precedes: same dispatch, valid_rows / valid_cols = the rank's own rectangle - sets
+// the bit of every texel OUTSIDE that rectangle a disc sample of filterIndirectDiffuseSpatial.comp (specialisation constant 0 = its filterIndex) lands on.
+//   sampled image 4: the filter's depthTexture (the trace resolution); storage buffer 6: the bitmap, ceil(width / 32) words per texel row, cleared here.
+// The sample positions depend on depth, camera and frame index only (filterIndirectDiffuseSpatial.comp:53-105), so this runs before the trace.
+static int launchGiSampleRequests(const PassCtx& c) {
+    if (int rc = c.needGlobal()) return rc;
+    if (int rc = c.needSampled(4, -1, "giSampleRequests depthTexture")) return rc;
+    if (int rc = c.needSbuf(6, 4, "giSampleRequests bitmap")) return rc;
+    const ImgView& depth = c.sampled[4];
+    if (depth.fmt != F_R16F && depth.fmt != F_D32) return c.fail(-4, "giSampleRequests: depthTexture must be R16_sFloat or Depth32");
+    const uint32_t rowWords = ((uint32_t)depth.w + 31u) / 32u;
+    const size_t bitmapBytes = (size_t)rowWords * (size_t)depth.h * 4u;
+    if (c.sbuf[6].size < bitmapBytes) return c.fail(-4, "giSampleRequests: the bitmap needs ceil(width / 32) words per texel row of the depth texture");
+    if (!c.globalHost) return c.fail(-4, "giSampleRequests: the global uniform block must have been filled through plr_set_uniform_buffer_data");
+    static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0;
+    if (rowMissShrinks) return c.fail(-4, "giSampleRequests: PLR_BAND_ROW_MISS_SHRINKS changes where samples land depending on what is valid; not with request lists");
+    const int filterIndex = c.specInt(0, 0);
+    const PassCtx::RowSpan rs = c.rowSpan(depth.h);
+    const PassCtx::ColSpan cs = c.colSpan(depth.w);
+    const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
+    if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
+    if (w <= x0 || h <= y0) return 0;
+    constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
+    const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
+    const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544);
+    const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
+    const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
+    uint8_t* scratch = spatialScratch(c, false); // the sample tables
+    if (!scratch) return c.fail(-2, "giSampleRequests: cannot allocate scratch memory");
+    PLR_CHECK_LAUNCH(c);
+    int validLo, validHi, validLoX, validHiX;
+    c.validRowRange(depth.h, &validLo, &validHi);
+    c.validColRange(depth.w, &validLoX, &validHiX);
+    const float* hvp = c.globalHost->viewProjection;
+    auto rowNorm = [&](int r) { return (float)std::sqrt((double)hvp[r] * hvp[r] + (double)hvp[4 + r] * hvp[4 + r] + (double)hvp[8 + r] * hvp[8 + r]); };
+    SpatialFrameConsts fc;
+    fc.tsx = 1.f / (float)depth.w; fc.tsy = 1.f / (float)depth.h;
+    fc.dW = (float)depth.w; fc.dH = (float)depth.h; fc.nW = fc.dW; fc.nH = fc.dH;
+    fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
+    ImgView gi = depth; // the GI images share the depth texture's grid: only their size is used
+#define PLR_MARK_ARGS gi, gi, gi, gi, depth, depth, c.global, (const float*)scratch, (const uint4*)nullptr, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, (uint32_t*)nullptr, \
+                      (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), 0, fc, (uint32_t*)c.sbuf[6].ptr, rowWords
+    if (depth.fmt == F_R16F) spatialFilterFastKernel<F_R16F, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
+    else spatialFilterFastKernel<F_D32, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
+#undef PLR_MARK_ARGS
+    PLR_CHECK_LAUNCH(c);
+    return 0;
+}
+// PLR_MATH_FAST only: the marks are the texels THIS file's filter kernel lands on; the exact set's filter orders its arithmetic differently and a sample on a texel
+// boundary may land next door (plr_set_math_mode(PLR_MATH_EXACT) + request lists fails loudly: no exact kernel for this shader)
+PLR_REGISTER_SHADER_FAST("giSampleRequests.comp", launchGiSampleRequests);
 
 // ---- the producers of the filter's input write the packed texels of the rows they produce (PassCtx::consumer; fused_gi.h)
 PLR_REGISTER_CONSUMER_LINK(trace_spatial, "sdfDiffuseTrace.comp", "filterIndirectDiffuseSpatial.comp");

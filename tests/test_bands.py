@@ -182,7 +182,8 @@ def _run(inputs, exact, band=None, group=None, halos=None, out=None, half_res=1,
                                hist=be.downloadStorageBuffer(fp.storage_buffer("histogram"), 512, dtype=np.uint32).copy(),
                                light=be.downloadStorageBuffer(fp.storage_buffer("light"), 20, dtype=np.uint8).tobytes(),
                                shadow=be.downloadStorageBuffer(fp.storage_buffer("sunShadowInfo"), 304, dtype=np.uint8).tobytes()))
-        res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1], edge_signal=be.getEdgeSignal())
+        res = dict(frames=frames, calls=list(ex.calls) if ex else [], fused=be.getPassFusion()[1], edge_signal=be.getEdgeSignal(),
+                   exchange=(fp.rccl_stats(), fp.rccl_info()) if (band is not None and transport == "native") else None)
         fp.destroy()
         be.shutdown()
         out[band[0] if band is not None else "full"] = res
@@ -732,6 +733,27 @@ def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res, transport)
     expected = [0, 1 | B, 1 | E, 2 | B, 2 | E, 3, 4 | B, 4 | E] if half_res else [0, 1, 2, 3, 4]
     if transport == "python":
         assert tiles[0]["calls"][:len(expected)] == expected
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [(2, 2), (1, 3), (4, 3), (2, 1)])
+def test_gpu_request_lists_reproduce_the_full_frame_bit_exact(grid):
+    """band_gi_halo = PLRF_HALO_REQUESTED (round 6): in front of the two spatial GI filter passes no halo is exchanged at all - every rank asks the
+    owners for exactly the texels its disc samples land on (giSampleRequests passes -> bitmaps -> ExchangeGiRequests; then Y_SH, CoCg and depth of the marked texels at
+    the two GI exchange points), through the native exchange over its in-process transport. With the other halos as large as the image the partitioned frame must
+    equal the unpartitioned one in every bit (benchmarked kernel set: the requests are the fast filter kernel's own sample positions), over three frames of feedback."""
+    inputs = _make_inputs()
+    full = _run_full(inputs, False)
+    rects = _tile_rects(*grid)
+    n = len(rects)
+    big = max(W, H)
+    halos = dict(band_gi_halo=0xfffffffe, band_gi_history_halo=big, band_post_halo=big, band_taa_history_halo=big)
+    tiles = _run_bands(inputs, n, False, halos, rects=rects, transport="native")
+    mism = _compare(full, tiles, n, rects=rects)
+    bad = {k: v for k, v in mism.items() if v != 0.0}
+    assert not bad, bad
+    sent, received, groups = tiles[0]["exchange"][0]
+    assert groups >= 5 and received > 0, tiles[0]["exchange"]
 
 
 @pytest.mark.gpu
