@@ -310,12 +310,18 @@ def main():
     ap.add_argument("--allow-replicas", action="store_true", help="N > 1 only: if the band frame cannot run, fall back to N independent 4K replicas (said so in the JSON line) instead of failing")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: keep the equal partition instead of balancing the rectangles' sizes from measured times")
     ap.add_argument("--partition", choices=["auto", "tiles", "bands"], default="auto", help="N > 1: screen tiles (2 x N/2 grid; N = 4: BASELINE config 5's 2 x 2) or row bands; "
-                    "auto = row bands, the faster of the two in the single-GPU replay (profiles/r05_tile_vs_band.txt)")
-    ap.add_argument("--exact-partition", action="store_true", help="N > 1: exchange every GI texel with every rank (band_gi_halo = PLRF_HALO_WHOLE_IMAGE): the partitioned frame equals the "
-                    "unpartitioned one bit for bit (tests/test_config5_8k.py); default: a halo of 64 trace rows per 2160 frame rows, whose deviation is stated in profiles/r05_config5_series.txt")
+                    "auto (N even): BOTH are timed in this run (a short run each), the faster one is the headline, the other is reported under alt_partition")
+    ap.add_argument("--gi-exchange", choices=["requested", "exact", "halo"], default="requested", help="N > 1: what the spatial GI filters get from the other ranks. requested (default): "
+                    "request lists, band_gi_halo = PLRF_HALO_REQUESTED - every rank asks the owners for exactly the texels its samples land on; the partitioned frame EQUALS the unpartitioned one "
+                    "bit for bit (tests/test_config5_8k.py). exact: every GI texel to every rank (PLRF_HALO_WHOLE_IMAGE), also bit-identical, 10 x the bytes. halo: 64 trace rows per 2160 frame "
+                    "rows - NOT the same frame: samples beyond the halo get weight 0 and the deviation grows with the frame count (profiles/r05_config5_series.txt)")
+    ap.add_argument("--exact-partition", action="store_true", help="the same as --gi-exchange exact")
     ap.add_argument("--no-strong-scaling", action="store_true", help="N > 1: skip the single-GPU run of the same frame (rank 0) the strong-scaling figure is taken against")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when --gpus N spawns its own ranks (0: derived from the pid)")
     args = ap.parse_args()
+    if args.exact_partition:
+        args.gi_exchange = "exact"
+    args.exact_partition = args.gi_exchange != "halo"  # "the partitioned frame is byte-identical": whole-frame inputs on every rank (the denoiser's samples may land anywhere)
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -360,10 +366,14 @@ def main():
     band_partition = {"bounds": None, "calibration": []}
     # auto = the measured winner of the single-GPU replay of both partitions from one build (profiles/r05_tile_vs_band.txt: slowest of four row bands 0.88 ms, slowest of
     # 2 x 2 tiles 0.91 ms of the 2.72 ms 8K frame): row bands. Config 5's own 2 x 2 tiles: --partition tiles. Neither has been measured on more than one GPU.
-    use_tiles = world > 1 and world % 2 == 0 and args.partition == "tiles"
     if args.partition == "tiles" and world > 1 and world % 2:
         raise SystemExit("bench.py: --partition tiles needs an even number of GPUs (2 x N/2 grid)")
-    grid_x, grid_y = (2, world // 2) if use_tiles else (1, world)
+    geometry = {"tiles": world > 1 and world % 2 == 0 and args.partition == "tiles"}  # the geometry make() builds; "auto" tries both below
+
+    calibrated = {}
+
+    def grid():
+        return (2, world // 2) if geometry["tiles"] else (1, world)
 
     def band_frame_size():
         # N GPUs render ONE frame of N x the pixels, partitioned by rows: 7680 x (1080 * N) (N = 4: the 8K frame of BASELINE config 5).
@@ -375,8 +385,10 @@ def main():
         kw = dict(band_row_begin=rect[1], band_row_end=rect[3])
         if rect[0] != 0 or rect[2] != w_:
             kw.update(band_col_begin=rect[0], band_col_end=rect[2])
-        if args.exact_partition:
+        if args.gi_exchange == "exact":
             kw.update(band_gi_halo=0xffffffff)  # PLRF_HALO_WHOLE_IMAGE
+        elif args.gi_exchange == "requested":
+            kw.update(band_gi_halo=0xfffffffe)  # PLRF_HALO_REQUESTED
         return kw
 
     def calibrate_partition():
@@ -384,6 +396,7 @@ def main():
         show the slowest rank's time), the per-rank times are gathered and the row / column boundaries re-cut so that every rectangle costs the same
         (tiling.balanced_tile_bounds). Two rounds; the same partition on every rank."""
         w_, h_ = band_frame_size()
+        grid_x, grid_y = grid()
         cols, rows = tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)
         best = None  # (slowest time, cols, rows) of the partitions MEASURED so far: the cost density inside a rectangle is not flat (sky above ground), so a re-cut
         # overshoots or undershoots; up to four rounds, and the partition returned is the best one that was actually timed, not the last proposal
@@ -429,13 +442,23 @@ def main():
         rects_ = None
         if mode == "bands":
             w_, h_ = band_frame_size()
-            cols_, rows_ = (tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)) if args.no_balance else calibrate_partition()
+            grid_x, grid_y = grid()
+            band_partition["calibration"] = []
+            if args.no_balance:
+                cols_, rows_ = tiling.equal_bounds(w_, grid_x), tiling.equal_bounds(h_, grid_y)
+            else:  # (calibrated once per geometry: the short run that chooses the geometry and the headline run use the same partition)
+                if geometry["tiles"] not in calibrated:
+                    calibrated[geometry["tiles"]] = (calibrate_partition(), list(band_partition["calibration"]))
+                (cols_, rows_), band_partition["calibration"] = calibrated[geometry["tiles"]]
             rects_ = tiling.tile_rects(w_, h_, grid_x, grid_y, cols_, rows_)
             band_ = (rects_[rank][1], rects_[rank][3])
             band_partition["bounds"] = rows_
             band_partition.update(kind="tiles %dx%d" % (grid_x, grid_y) if grid_x > 1 else "row bands", col_bounds=cols_, row_bounds=rows_, rects=[list(r) for r in rects_],
-                                  gi_halo="whole image: the partitioned frame equals the unpartitioned one bit for bit" if args.exact_partition else
-                                          "default (64 trace rows per 2160 frame rows): deviation from the unpartitioned frame stated in profiles/r05_config5_series.txt")
+                                  gi_halo={"requested": "request lists (PLRF_HALO_REQUESTED): every rank receives exactly the texels its spatial-filter samples land on; the partitioned "
+                                                        "frame equals the unpartitioned one bit for bit (tests/test_config5_8k.py)",
+                                           "exact": "whole image (PLRF_HALO_WHOLE_IMAGE): the partitioned frame equals the unpartitioned one bit for bit",
+                                           "halo": "64 trace rows per 2160 frame rows: NOT the same frame - its deviation from the unpartitioned frame grows with the frame count "
+                                                   "(profiles/r05_config5_series.txt); strong_scaling_vs_1gpu_same_frame compares different images"}[args.gi_exchange])
             tile_rect[0] = rects_[rank]
         be_ = RenderBackend(w_, h_, device=local_rank)
         if band_ is not None:
@@ -486,6 +509,49 @@ def main():
             del inputs1
             torch.cuda.empty_cache()
         dist.barrier()
+
+    # ---- which geometry? With --partition auto and an even N both are timed in THIS run - a short run each, same scene, same exchange mode, every
+    # rank's clock, the slowest rank counts - and the faster one becomes the headline run below; the other one's time is reported under alt_partition. A geometry
+    # that cannot run is reported as such and the other one is taken.
+    alt_partition = None
+    if world > 1 and world % 2 == 0 and args.partition == "auto":
+        quick = {}
+        for tiles in (False, True):
+            geometry["tiles"] = tiles
+            ok, ms_q, err = 1, float("inf"), None
+            be_q = fp_q = None
+            try:
+                be_q, fp_q, (_, cams_q, _), _, _, _ = make("bands")
+                for i in range(6):
+                    fp_q.frame(cams_q[i + 1], 1.0 / 60.0, 0.5)
+                be_q.waitForGPUIdle()
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                n_q = max(10, min(args.steps, 60))
+                dist.barrier()
+                tq = time.perf_counter()
+                for i in range(n_q):
+                    fp_q.frame(cams_q[(i % 20) + 1], 1.0 / 60.0, 0.5)
+                be_q.waitForGPUIdle()
+                tt = torch.tensor([(time.perf_counter() - tq) * 1e3 / n_q], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms_q = float(tt.item())
+            quick[tiles] = {"kind": "tiles %dx%d" % grid() if tiles else "row bands", "ms_per_step": round(ms_q, 4) if ms_q != float("inf") else None,
+                            "steps": max(10, min(args.steps, 60)), "rects": band_partition.get("rects"), "error": err if int(flag.item()) == 0 else None}
+            try:
+                if fp_q is not None:
+                    fp_q.destroy()
+                if be_q is not None:
+                    be_q.shutdown()
+            except Exception:  # noqa: BLE001
+                pass
+            torch.cuda.empty_cache()
+        geometry["tiles"] = (quick[True]["ms_per_step"] or float("inf")) < (quick[False]["ms_per_step"] or float("inf"))
+        alt_partition = dict(quick[not geometry["tiles"]], note="the geometry NOT taken for the headline: a short run of the same frame in this invocation")
+        band_partition["chosen_from"] = {"row bands": quick[False]["ms_per_step"], "tiles": quick[True]["ms_per_step"]}
 
     parallelism_note = None
     if world > 1 or args.force_bands:
@@ -661,7 +727,7 @@ def main():
                        "input_producers_as_compute": bool(args.producers), "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
                        "general_kernel_executions_in_last_timed_frame": general_count,
                        "parallelism": ("one %dx%d frame in %s (one per GPU), halos exchanged over RCCL point-to-point (%s) "
-                                       "+ one 512 B histogram all-reduce per frame" % (w, h, ("%d x %d screen tiles of ~%dx%d" % (grid_x, grid_y, w // grid_x, h // grid_y)) if grid_x > 1 else
+                                       "+ one 512 B histogram all-reduce per frame" % (w, h, ("%d x %d screen tiles of ~%dx%d" % (grid()[0], grid()[1], w // grid()[0], h // grid()[1])) if grid()[0] > 1 else
                                                                                         ("%d row bands of ~%d rows" % (world, h // world)),
                                                                                         "torch.distributed from Python" if args.python_exchange else "ncclSend/ncclRecv from the C++ host")) if (world > 1 and not replicas) else
                                       ("replicas: one independent %dx%d frame per GPU (band rendering unavailable: %s)" % (w, h, parallelism_note) if replicas else "single GPU")},
@@ -672,6 +738,7 @@ def main():
                                     "ms_at_60pct_of_8TBs": round(frame_bytes / (0.6 * HBM_PEAK_GBS * 1e9) * 1e3, 4)},
                                    **((frame_valu_floor() or {}) if (w, h, args.grid, args.sdf_res, args.shadow_res) == (3840, 2160, 16, 64, 2048) and band is None else {})),
             "band_partition": band_partition if band is not None else None,
+            "alt_partition": alt_partition,
             # strong scaling against the SAME frame on one GPU (rank 0, same run): the figure BASELINE's ">= 3.5x at 4 GPUs on 8K" is written in. Measured on
             # one node only when the driver's scaling run has N GPUs; null at N = 1
             "single_gpu_same_frame_ms": round(single_gpu_same_frame_ms, 4) if single_gpu_same_frame_ms else None,

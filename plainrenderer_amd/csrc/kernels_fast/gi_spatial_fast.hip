@@ -89,19 +89,31 @@ __global__ __launch_bounds__(256) void spatialPackKernel(ImgView inYSH, ImgView 
 template <int DEPTH_FMT>
 __global__ __launch_bounds__(256) void spatialSparsePackKernel(ImgView inYSH, ImgView inCoCg, ImgView depthTexture, const GlobalUbo* __restrict__ g, uint4* __restrict__ packed,
                                                                const uint32_t* __restrict__ bitmap, uint32_t rowWords, uint32_t words) {
+    // a lane per TEXEL (bit): 8 words per block; a lane per word with a loop over its bits took 31 us per pass at 8K / 4 (divergent, serial), this is bandwidth of 1 MB
+    const uint32_t wi = blockIdx.x * 8u + (threadIdx.x >> 5), b = threadIdx.x & 31u;
+    if (wi >= words) return;
+    if (!((bitmap[wi] >> b) & 1u)) return;
+    const uint32_t y = wi / rowWords, x = (wi - y * rowWords) * 32u + b;
+    if (x >= (uint32_t)inYSH.w) return;
+    const size_t idx = (size_t)y * (size_t)inYSH.w + x;
+    packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
+}
+// the request pass's byte map (one byte per texel, row pitch `pitch` bytes) -> the bitmap: a lane per word, 32 bytes = two 16-byte loads
+__global__ __launch_bounds__(256) void requestBytesToBitsKernel(const uint8_t* __restrict__ bytes, uint32_t pitch, uint32_t* __restrict__ bitmap, uint32_t rowWords, uint32_t words) {
     const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
     if (wi >= words) return;
-    uint32_t bits = bitmap[wi];
-    if (!bits) return;
     const uint32_t y = wi / rowWords, xw = wi - y * rowWords;
-    while (bits) {
-        const uint32_t b = (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1u;
-        const uint32_t x = xw * 32u + b;
-        if (x >= (uint32_t)inYSH.w) continue;
-        const size_t idx = (size_t)y * (size_t)inYSH.w + x;
-        packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
+    const uint4* src = (const uint4*)(bytes + (size_t)y * pitch + (size_t)xw * 32u);
+    const uint4 a = src[0], c = src[1];
+    const uint32_t d[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // non-zero bytes of a dword -> 4 bits
+        const uint32_t v = d[k];
+        bits |= (((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) | ((v & 0xff000000u) ? 8u : 0u)) << (4 * k);
     }
+    bitmap[wi] = bits;
 }
 
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
@@ -114,8 +126,8 @@ struct SpatialFrameConsts {
     float3 vpRowNorms; // |x row|, |y row|, |w row| of the xyz part of viewProjection
 };
 // MARK (round 6, the request-list GI exchange of a partitioned frame; plr_frame.h PLRF_HALO_REQUESTED): the kernel gathers nothing and writes no image - every
-// sample that lands on screen but OUTSIDE the valid rectangle (the rank's own rows / columns) sets its texel's bit in requestBitmap (bitmapRowWords 32-bit words
-// per texel row). Same block -> pixel mapping, same per-pixel frame, same position statements as the filter launch that follows: the sample positions are
+// sample that lands on screen but OUTSIDE the valid rectangle (the rank's own rows / columns) sets its texel's BYTE in requestBitmap (here: a byte map,
+// bitmapRowWords = bytes per texel row). Same block -> pixel mapping, same per-pixel frame, same position statements as the filter launch that follows: the sample positions are
 // evaluated in one place (below, contraction off, explicit fused multiply-adds) so that both instantiations land on the same texels, bit for bit.
 template <int DEPTH_FMT, int TX, bool SAME_GRID, bool PACKED, bool SIG, bool MARK = false>
 __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, ImgView outCoCg, ImgView inYSH, ImgView inCoCg, ImgView depthTexture, ImgView normalTexture,
@@ -139,6 +151,24 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const int dwi = depthTexture.w, dhi = depthTexture.h;
 
     const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
+    if (MARK) {
+        // Most waves of a rank's rectangle request nothing: their discs stay inside it. Decided here from the centre texel's depth alone, with the bound `safe` /
+        // `safeInside` use below (clip.w of the centre is its linear depth) and 5 % + two texels to spare - before the three exact world positions of the frame,
+        // which are most of what such a wave would otherwise pay (the request passes took 55 us each at 8K / 4, profiles/r06_band_cost.txt)
+        const int cx = clampTo(px, depthTexture.w - 1), cy = clampTo(py, depthTexture.h - 1);
+        const float dq = Texel<DEPTH_FMT>::load(depthTexture.ptr, __umul24((uint32_t)cy, (uint32_t)depthTexture.w) + (uint32_t)cx).x;
+        const float lin = nf * rcpf(farP + (1.f - dq) * nmf);
+        const float dm = radiusWorld * 1.4143f * 1.01f * 1.05f;
+        const float sx = fc.vpRowNorms.x, sy = fc.vpRowNorms.y, sw = fc.vpRowNorms.z;
+        const float wMin = (lin - sw * dm) * 0.99f;
+        const float su = fabsf(2.f * ((float)px + 0.5f) * fc.tsx - 1.f), sv = fabsf(2.f * ((float)py + 0.5f) * fc.tsy - 1.f);
+        bool inside = wMin > 0.f && su * lin + sx * dm <= wMin && sv * lin + sy * dm <= wMin; // on screen: no mirrored sample
+        const float inv = rcpf(__builtin_fmaxf(wMin, 1e-20f));
+        const float reachY = 0.5f * (sy + sw) * dm * inv * (float)inYSH.h + 3.f, reachX = 0.5f * (sx + sw) * dm * inv * (float)inYSH.w + 3.f;
+        inside = inside && (float)py - reachY >= (float)validY0 && (float)py + reachY < (float)(validY0 + validRowCount) &&
+                 (float)px - reachX >= (float)validX0 && (float)px + reachX < (float)(validX0 + validColCount);
+        if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) return;
+    }
     float tsx, tsy, u0, v0;
     vec3 pCenter, T, B;
     {
@@ -299,7 +329,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                     }
                 }
                 if (MARK) {
-                    if (miss && !offScreen) __hip_atomic_fetch_or(requestBitmap + (size_t)ty * bitmapRowWords + (tx >> 5), 1u << (tx & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // one BYTE per texel, plain stores (every writer stores the same 1): millions of atomic ORs on words shared by 32 texels made this pass take 2.4 x
+                    // the filter it precedes (profiles/r06_band_cost.txt); requestBytesToBitsKernel folds the bytes into the bitmap the exchange trades
+                    if (miss && !offScreen) ((uint8_t*)requestBitmap)[(size_t)ty * bitmapRowWords + tx] = 1u;
                     continue;
                 }
                 off[k] = offScreen || miss;
@@ -535,8 +567,8 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         } else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
         if (requested) {
             const uint32_t words = bitmapRowWords * (uint32_t)c.sampled[2].h;
-            if (c.sampled[4].fmt == F_R16F) spatialSparsePackKernel<F_R16F><<<divUp(words, 256u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
-            else spatialSparsePackKernel<F_D32><<<divUp(words, 256u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
+            if (c.sampled[4].fmt == F_R16F) spatialSparsePackKernel<F_R16F><<<divUp(words, 8u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
+            else spatialSparsePackKernel<F_D32><<<divUp(words, 8u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
             PLR_CHECK_LAUNCH(c);
             c.splitTiming("requested texels");
         }
@@ -592,19 +624,32 @@ static int launchGiSampleRequests(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.rowSpan(depth.h);
     const PassCtx::ColSpan cs = c.colSpan(depth.w);
     const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
-    if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
-    if (w <= x0 || h <= y0) return 0;
+    // scratch: [sample tables | byte map: one byte per texel, rows of rowWords * 32 bytes]
+    const uint32_t bytePitch = rowWords * 32u;
+    const size_t byteMapBytes = (size_t)bytePitch * (size_t)depth.h;
+    const bool freshScratch = c.scratchSize && *c.scratchSize < kSpatialTableBytes + byteMapBytes;
+    uint8_t* scratch = (uint8_t*)c.scratch(kSpatialTableBytes + byteMapBytes);
+    if (!scratch) return c.fail(-2, "giSampleRequests: cannot allocate scratch memory");
+    if (freshScratch) spatialSampleTableKernel<<<1, 256, 0, c.stream>>>((float*)scratch);
+    uint8_t* byteMap = scratch + kSpatialTableBytes;
+    if (hipMemsetAsync(byteMap, 0, byteMapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
+    if (w <= x0 || h <= y0) {
+        if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
+        return 0;
+    }
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544);
     const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
     const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
-    uint8_t* scratch = spatialScratch(c, false); // the sample tables
-    if (!scratch) return c.fail(-2, "giSampleRequests: cannot allocate scratch memory");
     PLR_CHECK_LAUNCH(c);
     int validLo, validHi, validLoX, validHiX;
     c.validRowRange(depth.h, &validLo, &validHi);
     c.validColRange(depth.w, &validLoX, &validHiX);
+    if (validLo <= 0 && validHi >= depth.h && validLoX <= 0 && validHiX >= depth.w) { // the rectangle is the image: nothing lies outside it
+        if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
+        return 0;
+    }
     const float* hvp = c.globalHost->viewProjection;
     auto rowNorm = [&](int r) { return (float)std::sqrt((double)hvp[r] * hvp[r] + (double)hvp[4 + r] * hvp[4 + r] + (double)hvp[8 + r] * hvp[8 + r]); };
     SpatialFrameConsts fc;
@@ -613,10 +658,13 @@ static int launchGiSampleRequests(const PassCtx& c) {
     fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
     ImgView gi = depth; // the GI images share the depth texture's grid: only their size is used
 #define PLR_MARK_ARGS gi, gi, gi, gi, depth, depth, c.global, (const float*)scratch, (const uint4*)nullptr, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, (uint32_t*)nullptr, \
-                      (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), 0, fc, (uint32_t*)c.sbuf[6].ptr, rowWords
+                      (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), 0, fc, (uint32_t*)byteMap, bytePitch
     if (depth.fmt == F_R16F) spatialFilterFastKernel<F_R16F, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
     else spatialFilterFastKernel<F_D32, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
 #undef PLR_MARK_ARGS
+    PLR_CHECK_LAUNCH(c);
+    const uint32_t words = rowWords * (uint32_t)depth.h;
+    requestBytesToBitsKernel<<<divUp(words, 256u), 256, 0, c.stream>>>(byteMap, bytePitch, (uint32_t*)c.sbuf[6].ptr, rowWords, words);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

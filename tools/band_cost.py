@@ -1,9 +1,11 @@
 """Redundant compute of a partitioned frame, measured on ONE GPU: the N partitions of the 7680 x (1080 N) frame - row bands, or a grid of screen tiles (BASELINE
-config 5: 2 x 2) - are rendered one after the other, each with the halo it recomputes and the native exchange in LOOPBACK (csrc/frontend/band_exchange.cpp: no
-communicator; a tile's pack / unpack kernels run and a device copy stands in for the links, a band sends straight from its images and has nothing local to
-run), producers recorded edges-first as the overlapped exchange records them. Their times are summed and compared with the time of the unpartitioned frame.
-    python tools/band_cost.py [N] [--tiles GXxGY] [--passes] [--balance]
-default N = 4: the 8K frame; --tiles 2x2: config 5's partition (GX * GY = N); --balance: rectangle sizes from measured times, as bench.py does"""
+config 5: 2 x 2) - are timed one after the other, each with the halo it recomputes and the NATIVE exchange (csrc/frontend/band_exchange.cpp) over its in-process
+transport: all ranks render the warm-up frames together (every exchange moves what a multi-GPU run moves), then the group is frozen and each rank is timed alone
+with its neighbours' last frame in its halos (measure_all). Their times are summed and compared with the time of the unpartitioned frame.
+    python tools/band_cost.py [N] [--tiles GXxGY] [--passes] [--balance] [--requested | --exact] [--loopback]
+default N = 4: the 8K frame; --tiles 2x2: config 5's partition (GX * GY = N); --balance: rectangle sizes from measured times, as bench.py does;
+--requested: band_gi_halo = PLRF_HALO_REQUESTED (request lists: byte-identical to the unpartitioned frame), --exact: PLRF_HALO_WHOLE_IMAGE, default: the bounded halo;
+--loopback: the replay of rounds 3 - 5 (every partition on its own with the exchange in loopback: a tile's halos are its own texels, a band's halos nothing)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,8 +25,11 @@ w, h = 7680, 1080 * n
 kind = "tiles %dx%d" % (gx, gy) if gx > 1 else "%d bands" % n
 
 
-def measure(rects, index):
-    """index None: the unpartitioned frame"""
+MODE = {"halo": None, "exact": 0xffffffff, "requested": 0xfffffffe}[os.environ.get("PLR_BAND_COST_MODE", "requested" if "--requested" in sys.argv else ("exact" if "--exact" in sys.argv else "halo"))]
+LOOPBACK = "--loopback" in sys.argv  # the old replay: every partition on its own, the exchange in loopback (a tile's halos are its own texels, a band's halos nothing)
+
+
+def make_pipeline(rects, index, group=None):
     be = RenderBackend(w, h, device=0)
     kw, band = {}, None
     if index is not None:
@@ -33,20 +38,27 @@ def measure(rects, index):
         if x0 != 0 or x1 != w:
             kw.update(band_col_begin=x0, band_col_end=x1)
         band = (y0, y1)
+        if MODE is not None:
+            kw.update(band_gi_halo=MODE)
     if index is not None and "PLR_BAND_COST_GI_HALO" in os.environ:  # experiment hook: trace texels of GI exchanged with each neighbour (tools/config5_series.sh: the exact mode)
         kw.update(band_gi_halo=int(os.environ["PLR_BAND_COST_GI_HALO"]))
     if index is not None and "PLR_BAND_COST_OVERLAP" in os.environ:  # experiment hook: band_overlap_exchange (plr_frame.h; 2 = edges first in one launch, the default)
         kw.update(band_overlap_exchange=int(os.environ["PLR_BAND_COST_OVERLAP"]))
     fp = FramePipeline(be, w, h, shadow_map_res=2048, **kw)
     if index is not None:
-        fp.attach_rccl_rects(None, index, len(rects), w, h, rects)  # loopback: the recording is the multi-GPU one, the local work of the exchange runs
+        if group is not None:
+            fp.attach_local_rects(group, index, len(rects), w, h, rects)  # the native exchange over its in-process transport: real neighbours
+        else:
+            fp.attach_rccl_rects(None, index, len(rects), w, h, rects)  # loopback: the recording is the multi-GPU one, the local work of the exchange runs
     # (a halo beyond the default needs the inputs of rows beyond bench.input_halo: the whole frame's then)
-    scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, None if "PLR_BAND_COST_GI_HALO" in os.environ else band)
+    whole_inputs = MODE is not None or "PLR_BAND_COST_GI_HALO" in os.environ
+    scene, cams, inputs = bench.build_scene(args, "cuda:0", w, h, None if whole_inputs else band)
     inputs.upload(fp)
     be.waitForGPUIdle()
-    for i in range(args.warmup):
-        fp.frame(cams[i + 1], 1 / 60, 0.5)
-    be.waitForGPUIdle()
+    return be, fp, cams
+
+
+def timed(be, fp, cams, index):
     t0 = time.perf_counter()
     for i in range(args.steps):
         fp.frame(cams[i + 6], 1 / 60, 0.5)
@@ -61,9 +73,78 @@ def measure(rects, index):
         fp.frame(cams[i + 20], 1 / 60, 0.5)
         for name, t in be.getRenderpassTimings():
             acc[name] = acc.get(name, 0.0) + t / 8
+    be.setPassTiming(False)
+    return ms, acc
+
+
+def measure(rects, index):
+    """one partition (index None: the unpartitioned frame) on its own, the exchange in loopback"""
+    be, fp, cams = make_pipeline(rects, index)
+    for i in range(args.warmup):
+        fp.frame(cams[i + 1], 1 / 60, 0.5)
+    be.waitForGPUIdle()
+    out = timed(be, fp, cams, index)
     fp.destroy()
     be.shutdown()
-    return ms, acc
+    return out
+
+
+def measure_all(rects):
+    """Every partition timed ALONE on the GPU with REAL neighbour data in its halos (round 6): all ranks live in this process (a thread, backend,
+    pipeline and native exchange each, over the in-process transport), render the warm-up frames together - every exchange moves what a multi-GPU run moves -, then the
+    group is FROZEN: a rank no longer waits for its peers and copies from what they posted last (their buffers keep their last frame), and the ranks are timed one
+    after the other. -> [(ms, pass times)] per rank"""
+    if LOOPBACK:
+        return [measure(rects, i) for i in range(len(rects))]
+    import threading
+    from plainrenderer_amd.frame import LocalExchangeGroup
+    nr = len(rects)
+    group = LocalExchangeGroup(nr)
+    warm, go, done = threading.Barrier(nr + 1), [threading.Event() for _ in range(nr)], [threading.Event() for _ in range(nr)]
+    results, errors = [None] * nr, []
+
+    def rank(i):
+        try:
+            be, fp, cams = make_pipeline(rects, i, group)
+            for f in range(args.warmup):
+                fp.frame(cams[f + 1], 1 / 60, 0.5)
+            be.waitForGPUIdle()
+            warm.wait()
+            go[i].wait()
+            results[i] = timed(be, fp, cams, i)
+            done[i].set()
+            go[i].clear(); go[i].wait()  # the pipelines stay alive until every rank has been timed: the others copy from this one's buffers
+            fp.destroy()
+            be.shutdown()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            group.abort()
+            try:
+                warm.abort()
+            except Exception:  # noqa: BLE001
+                pass
+            done[i].set()
+            raise
+
+    threads = [threading.Thread(target=rank, args=(i,)) for i in range(nr)]
+    for t in threads:
+        t.start()
+    try:
+        warm.wait(timeout=900)
+    except threading.BrokenBarrierError:
+        raise SystemExit("band_cost: a rank failed during the warm-up frames: %s" % (errors[:1],))
+    group.freeze(True)
+    for i in range(nr):
+        go[i].set()
+        done[i].wait(timeout=900)
+        if errors:
+            raise SystemExit("band_cost: rank %d failed: %s" % (i, errors[0]))
+    for i in range(nr):
+        go[i].set()
+    for t in threads:
+        t.join(timeout=300)
+    group.destroy()
+    return results
 
 
 measure(None, None)  # (the first measurement of a process reads up to 30 % high on some boxes: taken twice, the second is reported)
@@ -75,7 +156,7 @@ if "--balance" in sys.argv:
     # what bench.py --gpus N does before its timed region (static load balancing from measured times), here with the partitions one after the other
     best, seen = None, []
     for it in range(4):  # up to four rounds; the partition used is the best one MEASURED (bench.calibrate_partition)
-        times = [measure(rects, i)[0] for i in range(n)]
+        times = [r[0] for r in measure_all(rects)]
         print("partition %s: times %s ms, slowest / mean = %.3f" % (rects, ["%.3f" % t for t in times], max(times) / (sum(times) / n)))
         seen.append((list(cols), list(rows)))
         if best is None or max(times) < best[0]:
@@ -88,8 +169,9 @@ if "--balance" in sys.argv:
     cols, rows = best[1], best[2]
     rects = tiling.tile_rects(w, h, gx, gy, cols, rows)
 total, band_passes, slowest = 0.0, {}, 0.0
+final = measure_all(rects)
 for i in range(n):
-    ms, acc = measure(rects, i)
+    ms, acc = final[i]
     total += ms
     slowest = max(slowest, ms)
     for k, v in acc.items():
