@@ -803,6 +803,7 @@ struct RcclExchange {
 
     // all transfers of exchange `id`, one ncclGroup, on `stream`
     int post(int id, hipStream_t stream) {
+        if (req.ready && (id == PLRF_EXCHANGE_GI_TRACE || id == PLRF_EXCHANGE_GI_TEMPORAL)) return postRequested(id, id == PLRF_EXCHANGE_GI_TRACE ? 0 : 1, stream);
         plrf_exchange_item items[16];
         uint32_t count = 16;
         if (int rc = plrf_get_exchange_items(fp, id, items, &count)) return xfail(rc, plrf_last_error());
@@ -888,10 +889,6 @@ struct RcclExchange {
             if (int rc = postRequests(commStream)) return rc;
             if (dog.deadlineMs) { if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc; dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]); }
             return 0;
-        }
-        if ((id == PLRF_EXCHANGE_GI_TRACE || id == PLRF_EXCHANGE_GI_TEMPORAL) && phase == 0 && req.ready) {
-            if (int rc = postRequested(id, id == PLRF_EXCHANGE_GI_TRACE ? 0 : 1, launchStream)) return rc;
-            return watch(id, 0, launchStream);
         }
         if (phase == PLRF_EXCHANGE_BEGIN) {
             // When may the transfers start? Edges-first producers (band_overlap_exchange 2): as soon as the launch that is still running has written its edge

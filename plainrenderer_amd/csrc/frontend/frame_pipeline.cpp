@@ -563,6 +563,11 @@ void SDFGI::diffuseSDFTrace(RenderBackend& be, const SDFTraceDependencies& deps,
     exe.genericInfo.resources.storageBuffers = {StorageBufferResource(deps.lightBuffer, true, 5), StorageBufferResource(m_sdfInstanceBuffer, true, 6),
                                                 StorageBufferResource(m_sdfCameraCulledTiles, true, 7), StorageBufferResource(deps.sunShadowInfoBuffer, true, 9)};
     exe.genericInfo.resources.uniformBuffers = {UniformBufferResource(m_sdfTraceInfluenceRangeBuffer, 8)};
+    if (band && band->requested && band->requestedBegin) {
+        recordRows(be, exe, td.width, td.height, band->traceRows, 0, nullptr, false, band->traceCols);
+        band->requestedBegin(band->user, ExchangeGiTrace); // the owners gather what was asked of them as soon as their trace is done
+        return;
+    }
     if (band && band->exchangeBegin)
         recordRows(be, exe, td.width, td.height, band->traceRows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTrace); }, band->rowsFirst, band->traceCols);
     else recordRows(be, exe, td.width, td.height, band ? band->traceRows : RowRange{}, 0, nullptr, false, band ? band->traceCols : ColRange{});
@@ -576,6 +581,19 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
     const ColRange cols = band ? band->traceCols : ColRange{};
     // band rendering: the spatial filter's inputs are valid on the band's rows and the giHalo rows received from each neighbour; a disc sample
     // beyond them is treated like an off-screen sample (ComputePassExecution::validRows, plr.h) instead of reading rows nobody sent
+    // a spatial filter execution; with request lists + overlap: the waves that need no requested texel, the wait for the exchange, the others (push constant: the phase)
+    auto recordSpatial = [&](ComputePassExecution& exe, int exchangeId) {
+        if (band && band->requested && band->requestedEnd) {
+            const int32_t phase1 = 1, phase2 = 2;
+            exe.pushConstants = dataToCharArray(&phase1, sizeof(phase1));
+            be.setComputePassExecution(exe);
+            band->requestedEnd(band->user, exchangeId);
+            exe.pushConstants = dataToCharArray(&phase2, sizeof(phase2));
+            be.setComputePassExecution(exe);
+            return;
+        }
+        be.setComputePassExecution(exe);
+    };
     auto setValidRows = [&](ComputePassExecution& exe, int filterIndex) {
         if (!band) return;
         if (band->requested) { // every texel a sample can land on is either this rectangle's or has been requested and received: nothing is masked (plr.h: {0, 0} = all valid)
@@ -600,7 +618,7 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
                                                    ImageResource(deps.worldSpaceNormals, 0, 5)};
         dispatch8(exe, td.width, td.height, rows, cols);
         setValidRows(exe, 0);
-        be.setComputePassExecution(exe);
+        recordSpatial(exe, ExchangeGiTrace);
     }
     {
         // always History[0] -> History[1]; the reference computes historySrc/DstIndex but never uses them (SDFGI.cpp:457-458)
@@ -611,10 +629,11 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuse_Y_SH[1], 0, 4), ImageResource(m_indirectDiffuse_CoCg[1], 0, 5),
                                                    ImageResource(m_indirectDiffuseHistory_Y_SH[0], 0, 6), ImageResource(m_indirectDiffuseHistory_CoCg[0], 0, 7),
                                                    ImageResource(deps.currentFrame.motionBuffer, 0, 8), ImageResource(deps.previousFrame.motionBuffer, 0, 9)};
-        if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); }, band->rowsFirst, cols);
+        if (band && band->requested && band->requestedBegin) { recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols); band->requestedBegin(band->user, ExchangeGiTemporal); }
+        else if (band && band->exchangeBegin) recordRows(be, exe, td.width, td.height, rows, band->giHalo, [&] { band->exchangeBegin(band->user, ExchangeGiTemporal); }, band->rowsFirst, cols);
         else recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols);
     }
-    if (band && band->exchangePoint) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
+    if (band && band->exchangePoint && !(band->requested && band->requestedBegin)) band->exchangePoint(band->user, ExchangeGiTemporal); // spatial pass 1 reads neighbouring rows of History[1]
     {
         ComputePassExecution exe;
         exe.genericInfo.handle = m_indirectDiffuseFilterSpatialPass[1];
@@ -622,7 +641,8 @@ void SDFGI::filterIndirectDiffuse(RenderBackend& be, const SDFTraceDependencies&
         exe.genericInfo.resources.sampledImages = {ImageResource(m_indirectDiffuseHistory_Y_SH[1], 0, 2), ImageResource(m_indirectDiffuseHistory_CoCg[1], 0, 3),
                                                    ImageResource(depthSrc, 0, 4), ImageResource(deps.worldSpaceNormals, 0, 5)};
         setValidRows(exe, 1);
-        recordRows(be, exe, td.width, td.height, rows, 0, nullptr, false, cols);
+        dispatch8(exe, td.width, td.height, rows, cols);
+        recordSpatial(exe, ExchangeGiTemporal);
     }
     // (this exchange is small - 16 rows - and its producer launches a packing pre-pass per dispatch: it is not split / overlapped)
     if (band && band->exchangeWhole) band->exchangeWhole(band->user, ExchangeGiHistory);
@@ -1379,6 +1399,10 @@ void FramePipeline::prepareRenderpasses() { // RenderFrontend.cpp:313-406
                 }
             };
             const bool overlap = settings.band.overlapExchange && m_exchangeFn && !settings.band.giRequested; // (a requested texel can be anywhere in its owner's rectangle: no edges-first producers)
+            if (settings.band.giRequested && settings.band.overlapExchange && m_exchangeFn) {
+                gb.requestedBegin = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeBegin); };
+                gb.requestedEnd = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeEnd); };
+            }
             if (overlap) {
                 gb.exchangeBegin = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeBegin); };
                 gb.exchangePoint = [](void* user, int id) { giExchange((FramePipeline*)user, id, ExchangeEnd); };

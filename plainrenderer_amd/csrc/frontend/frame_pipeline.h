@@ -199,6 +199,10 @@ struct GiBand {
     uint32_t giHalo = 0, giHistoryHalo = 0;                      // trace-resolution halo rows of exchanges 1/2 and 3
     bool rowsFirst = false;                                      // BandSettings::rowsFirst
     bool requested = false;                                      // BandSettings::giRequested: request lists instead of a halo in front of the spatial filters
+    // requested + overlap: the response exchange starts behind the producer (requestedBegin), the spatial filter runs the waves that need nothing from it meanwhile
+    // (request phase 1), waits (requestedEnd) and runs the rest (phase 2); null: one exchange callback and one filter execution
+    void (*requestedBegin)(void* user, int exchangeId) = nullptr;
+    void (*requestedEnd)(void* user, int exchangeId) = nullptr;
 };
 // records exe over `rows` of a w x h image; with edgesDone the first / last `halo` rows are recorded first, then edgesDone(), then the rest
 // rowsFirst: ONE execution over all the rows with first_rows = the edges (plr.h), then edgesDone()

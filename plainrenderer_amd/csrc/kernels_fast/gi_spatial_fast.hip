@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
                                                                int coverW, int coverH, int yBase, int xBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
                                                                uint32_t validY0, uint32_t validRowCount, uint32_t validX0, uint32_t validColCount, int rowMissShrinks,
-                                                               SpatialFrameConsts fc, uint32_t* __restrict__ requestBitmap = nullptr, uint32_t bitmapRowWords = 0) {
+                                                               SpatialFrameConsts fc, uint32_t* __restrict__ requestBitmap = nullptr, uint32_t bitmapRowWords = 0, int requestPhase = 0) {
     const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
@@ -151,7 +151,12 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const int dwi = depthTexture.w, dhi = depthTexture.h;
 
     const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
-    if (MARK) {
+    // requestPhase (the filter with request lists, push constant of the execution): 1 = only the waves whose discs provably stay inside the dispatched rectangle (they
+    // need nothing from another GPU: this launch runs WHILE the requested texels travel), 2 = the other waves (behind the exchange). The test is MARK's, below.
+    if (MARK || requestPhase != 0) {
+        // the rectangle: MARK - what is declared valid (the rank's own rows / columns); a filter launch - what it is dispatched over (the same rectangle)
+        const uint32_t rY0 = MARK ? validY0 : (uint32_t)yBase, rYn = MARK ? validRowCount : (uint32_t)(coverH - yBase);
+        const uint32_t rX0 = MARK ? validX0 : (uint32_t)xBase, rXn = MARK ? validColCount : (uint32_t)(coverW - xBase);
         // Most waves of a rank's rectangle request nothing: their discs stay inside it. Decided here from the centre texel's depth alone, with the bound `safe` /
         // `safeInside` use below (clip.w of the centre is its linear depth) and 5 % + two texels to spare - before the three exact world positions of the frame,
         // which are most of what such a wave would otherwise pay (the request passes took 55 us each at 8K / 4, profiles/r06_band_cost.txt)
@@ -165,9 +170,10 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         bool inside = wMin > 0.f && su * lin + sx * dm <= wMin && sv * lin + sy * dm <= wMin; // on screen: no mirrored sample
         const float inv = rcpf(__builtin_fmaxf(wMin, 1e-20f));
         const float reachY = 0.5f * (sy + sw) * dm * inv * (float)inYSH.h + 3.f, reachX = 0.5f * (sx + sw) * dm * inv * (float)inYSH.w + 3.f;
-        inside = inside && (float)py - reachY >= (float)validY0 && (float)py + reachY < (float)(validY0 + validRowCount) &&
-                 (float)px - reachX >= (float)validX0 && (float)px + reachX < (float)(validX0 + validColCount);
-        if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) return;
+        inside = inside && (float)py - reachY >= (float)rY0 && (float)py + reachY < (float)(rY0 + rYn) &&
+                 (float)px - reachX >= (float)rX0 && (float)px + reachX < (float)(rX0 + rXn);
+        const bool allInside = __builtin_amdgcn_ballot_w64(!inside) == 0ull;
+        if (MARK ? allInside : (requestPhase == 1 ? !allInside : allInside)) return;
     }
     float tsx, tsy, u0, v0;
     vec3 pCenter, T, B;
@@ -533,6 +539,9 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     // on (written by giSampleRequests.comp over the same rectangle, filled in by the exchange). Everything is valid then; what has to be packed is the rectangle itself
     // and those texels
     const bool requested = c.hasSbuf(6);
+    int requestPhase = 0; // push constant (4 bytes, optional): 0 = every wave, 1 = the waves that need no requested texel, 2 = the others (see the kernel)
+    if (requested && c.push.size() >= 4) std::memcpy(&requestPhase, c.push.data(), 4);
+    if (requestPhase < 0 || requestPhase > 2) return c.fail(-1, "filterIndirectDiffuseSpatial: request phase out of range");
     const uint32_t bitmapRowWords = ((uint32_t)c.sampled[2].w + 31u) / 32u;
     if (requested && (!sameGrid || c.sbuf[6].size < (size_t)bitmapRowWords * (size_t)c.sampled[2].h * 4u))
         return c.fail(-4, "filterIndirectDiffuseSpatial: the request bitmap (storage buffer 6) needs inputs on the depth texture's grid and ceil(width / 32) words per texel row");
@@ -549,7 +558,7 @@ static int launchSpatialFilterFast(const PassCtx& c) {
         const int marginX = requested ? 0 : std::max({128, x0 - validLoX, validHiX - w});
         const int q0 = tiled ? std::max({x0 - marginX, 0, validLoX}) : 0, q1 = tiled ? std::min({w + marginX, (int)c.sampled[2].w, validHiX}) : (int)c.sampled[2].w;
         PackRect todo[4];
-        const int nTodo = p1 > p0 && q1 > q0 ? unpackedRects(c, packed, PackRect{q0, p0, q1, p1}, todo) : 0;
+        const int nTodo = p1 > p0 && q1 > q0 && requestPhase != 2 ? unpackedRects(c, packed, PackRect{q0, p0, q1, p1}, todo) : 0; // (phase 2: phase 1 packed the rectangle)
         if (c.sampled[4].fmt != F_R16F && c.sampled[4].fmt != F_D32) return c.fail(-4, "filterIndirectDiffuseSpatial: depthTexture must be R16_sFloat or Depth32");
         if (nTodo) {
             PackRects pr{};
@@ -564,8 +573,8 @@ static int launchSpatialFilterFast(const PassCtx& c) {
             else spatialPackKernel<F_D32><<<pgrid, 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, pr);
             PLR_CHECK_LAUNCH(c);
             c.splitTiming("texel packing");
-        } else if (p1 > p0) countFusedExecutions(1); // the producer did all of it
-        if (requested) {
+        } else if (p1 > p0 && requestPhase != 2) countFusedExecutions(1); // the producer did all of it
+        if (requested && requestPhase != 1) { // (phase 1 runs while the requested texels are still on their way)
             const uint32_t words = bitmapRowWords * (uint32_t)c.sampled[2].h;
             if (c.sampled[4].fmt == F_R16F) spatialSparsePackKernel<F_R16F><<<divUp(words, 8u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
             else spatialSparsePackKernel<F_D32><<<divUp(words, 8u), 256, 0, c.stream>>>(c.sampled[2], c.sampled[3], c.sampled[4], c.global, packed, (const uint32_t*)c.sbuf[6].ptr, bitmapRowWords, words);
@@ -585,7 +594,7 @@ static int launchSpatialFilterFast(const PassCtx& c) {
     fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
     static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0; // experiment hook; 0 = the exact kernel's rule (kernels_exact/gi_filters.hip)
 #define PLR_SPATIAL_ARGS out, c.storage[1], c.sampled[2], c.sampled[3], c.sampled[4], c.sampled[5], c.global, tables, packed, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, sig, \
-                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), rowMissShrinks, fc
+                         (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), rowMissShrinks, fc, (uint32_t*)nullptr, 0u, requestPhase
 #define PLR_SPATIAL_LAUNCH(FMT, SG, PK)                                                                             \
     do {                                                                                                            \
         if (sig) spatialFilterFastKernel<FMT, TXv, SG, PK, true><<<grid, 256, 0, c.stream>>>(PLR_SPATIAL_ARGS);     \
