@@ -190,31 +190,40 @@ __global__ __launch_bounds__(256) void exchangeCopyKernel(CopyTable t) {
 // the rectangle (x0 a multiple of 32: rectangle edges are multiples of 64 pixels = 32 trace texels). Both sides of a request walk the same slice - the requester's
 // copy and the copy it sent - in the same order: word by word, bit by bit; offsets[w] = set bits in front of word w, so texel number offsets[w] + (set bits of
 // word w below bit b) of the response belongs to bit b of word w.
-struct RequestSlice { const uint32_t* bits; uint32_t* offsets; uint32_t* count; uint32_t words; };
+// offsets[w] counts within the word's 1024-word BLOCK; blockBase[w / 1024] = set bits in front of that block (two small kernels: a block of 1024 lanes per 1024
+// words, then one wave per slice over the <= 128 block sums; ONE 1024-thread block per slice walking 64 words per thread serially took 127 us beside the trace)
+struct RequestSlice { const uint32_t* bits; uint32_t* offsets; uint32_t* blockBase; uint32_t* count; uint32_t words; };
 constexpr int kMaxSlices = 64;
+constexpr uint32_t kScanBlock = 1024, kMaxScanBlocks = 128; // <= 131072 words = 4 M texels per slice
 struct SliceTable { int n; RequestSlice s[kMaxSlices]; };
-// one block per slice: exclusive prefix sum of the words' population counts, the total into *count
-__global__ __launch_bounds__(1024) void requestScanKernel(SliceTable t) {
-    __shared__ uint32_t partial[1024];
-    const RequestSlice sl = t.s[blockIdx.x];
-    const uint32_t per = (sl.words + 1023u) / 1024u, begin = threadIdx.x * per, end = min(begin + per, sl.words);
-    uint32_t sum = 0;
-    for (uint32_t w = begin; w < end; w++) sum += (uint32_t)__popc(sl.bits[w]);
-    partial[threadIdx.x] = sum;
+__global__ __launch_bounds__(1024) void requestScanBlocksKernel(SliceTable t) {
+    __shared__ uint32_t waveSum[16];
+    const RequestSlice sl = t.s[blockIdx.y];
+    const uint32_t w = blockIdx.x * kScanBlock + threadIdx.x;
+    if (blockIdx.x * kScanBlock >= sl.words) return;
+    const uint32_t n = w < sl.words ? (uint32_t)__popc(sl.bits[w]) : 0u;
+    uint32_t incl = n; // inclusive scan inside the wave
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63u) waveSum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) { // Hillis-Steele inclusive scan
-        const uint32_t v = threadIdx.x >= d ? partial[threadIdx.x - d] : 0u;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = partial[threadIdx.x] - sum;
-    for (uint32_t w = begin; w < end; w++) { sl.offsets[w] = run; run += (uint32_t)__popc(sl.bits[w]); }
-    if (threadIdx.x == 1023u) *sl.count = partial[1023];
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) base += waveSum[k];
+    if (w < sl.words) sl.offsets[w] = base + incl - n;
+    if (threadIdx.x == 1023u) sl.blockBase[blockIdx.x] = base + incl; // the block's total, turned into a base by the kernel below
+}
+__global__ __launch_bounds__(64) void requestScanSlicesKernel(SliceTable t) {
+    const RequestSlice sl = t.s[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    const uint32_t blocks = (sl.words + kScanBlock - 1) / kScanBlock;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < blocks; b++) { const uint32_t v = sl.blockBase[b]; sl.blockBase[b] = run; run += v; }
+    *sl.count = run;
 }
 // the texels one peer asked this rank for (GATHER: images -> buffer, 16 bytes each: Y_SH, CoCg, the R16F depth) / the texels this rank asked one peer for
 // (scatter: buffer -> images); (x0, y0) = the rectangle the slice covers, in trace texels
-struct RequestWalk { const uint32_t* bits; const uint32_t* offsets; uint4* buffer; uint32_t words, wordsPerRow, x0, y0; };
+struct RequestWalk { const uint32_t* bits; const uint32_t* offsets; const uint32_t* blockBase; uint4* buffer; uint32_t words, wordsPerRow, x0, y0; };
 constexpr int kMaxWalks = 16;
 struct WalkTable { int n; RequestWalk w[kMaxWalks]; uint2* ysh; uint32_t* cocg; uint16_t* depth; uint32_t imageCols; };
 template <bool GATHER>
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void requestWalkKernel(WalkTable t) {
         uint32_t bits = k.bits[wi];
         if (!bits) continue;
         const uint32_t row = wi / k.wordsPerRow, col = wi - row * k.wordsPerRow;
-        uint32_t slot = k.offsets[wi];
+        uint32_t slot = k.blockBase[wi / kScanBlock] + k.offsets[wi];
         while (bits) {
             const uint32_t b = (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
@@ -339,6 +348,22 @@ struct LocalGroup {
         return true;
     }
 };
+// every receive of one exchange in ONE launch (a device copy per transfer is a blit launch of ~10 us each: three peers made an exchange take 100 us on the launch stream,
+// where a communicator's group is one kernel): blockIdx.y = transfer, 16-byte units where both addresses allow it, else words (sizes are multiples of 4)
+struct LocalCopy { uint8_t* dst; const uint8_t* src; size_t bytes; };
+constexpr int kMaxLocalCopies = 32;
+struct LocalCopyTable { int n; LocalCopy c[kMaxLocalCopies]; };
+__global__ __launch_bounds__(256) void localCopyKernel(LocalCopyTable t) {
+    const LocalCopy c = t.c[blockIdx.y];
+    const bool wide = (((uintptr_t)c.dst | (uintptr_t)c.src) & 15u) == 0u;
+    if (wide) {
+        const size_t units = c.bytes / 16;
+        for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < units; i += (size_t)gridDim.x * 256u) ((uint4*)c.dst)[i] = ((const uint4*)c.src)[i];
+        for (size_t i = units * 4 + (size_t)blockIdx.x * 256u + threadIdx.x; i < c.bytes / 4; i += (size_t)gridDim.x * 256u) ((uint32_t*)c.dst)[i] = ((const uint32_t*)c.src)[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < c.bytes / 4; i += (size_t)gridDim.x * 256u) ((uint32_t*)c.dst)[i] = ((const uint32_t*)c.src)[i];
+    }
+}
 // dst[i] = reduction over the ranks' slots; op 0: uint32 sum (histogram bins), 1: {min, max} of two floats (depth range)
 __global__ __launch_bounds__(128) void localAllReduceKernel(const uint8_t* __restrict__ slots, int world, int op, uint32_t words, uint32_t* __restrict__ dst) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -378,7 +403,8 @@ struct RcclExchange {
     struct RequestState {
         bool ready = false;
         plrf_gi_request info{};
-        struct Peer { uint32_t outWords = 0, outWordsPerRow = 0, inWords = 0; uint32_t* out = nullptr; uint32_t* in = nullptr; uint32_t* outOff = nullptr; uint32_t* inOff = nullptr; Rect rect{}; };
+        struct Peer { uint32_t outWords = 0, outWordsPerRow = 0, inWords = 0; uint32_t* out = nullptr; uint32_t* in = nullptr; uint32_t* outOff = nullptr; uint32_t* inOff = nullptr;
+                      uint32_t* outBase = nullptr; uint32_t* inBase = nullptr; /* [2 points][kMaxScanBlocks] */ Rect rect{}; };
         std::vector<Peer> peers;          // [world]; the entry of this rank is empty
         uint32_t inWordsPerRow = 0;
         Rect mine{};
@@ -528,6 +554,11 @@ struct RcclExchange {
                 return xfail(PLR_ERR_HIP, g.error);
         }
         // my k-th receive from p <- p's k-th send to me
+        std::vector<LocalCopy> copies;
+        auto copy = [&](uint8_t* dst, const uint8_t* src, size_t bytes) -> int {
+            if (bytes % 4 == 0 && bytes > 0) { copies.push_back({dst, src, bytes}); return 0; }
+            return bytes ? hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(in-process transfer)") : 0;
+        };
         for (int p : from) {
             const LocalGroup::Post& theirs = g.posts[(size_t)p][(size_t)id];
             if (!theirs.posted || theirs.generation == 0) return xfail(PLR_ERR_HIP, "in-process exchange: peer " + std::to_string(p) + " has never posted exchange " + std::to_string(id));
@@ -538,17 +569,25 @@ struct RcclExchange {
             for (const LocalGroup::Op& o : ops) {
                 if (o.send || o.peer != p) continue;
                 if (g.frozen) { // timing replay: the peer's buffers hold its LAST frame - as many bytes as both sides have (request lists change size from frame to frame)
-                    if (k < sends.size()) if (int rc = hip(hipMemcpyAsync(o.ptr, sends[k]->ptr, std::min(o.bytes, sends[k]->bytes), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(in-process transfer)")) return rc;
+                    if (k < sends.size()) if (int rc = copy(o.ptr, sends[k]->ptr, std::min(o.bytes, sends[k]->bytes))) return rc;
                     k++;
                     continue;
                 }
                 if (k >= sends.size() || sends[k]->bytes != o.bytes)
                     return xfail(PLR_ERR_HIP, "in-process exchange " + std::to_string(id) + ": rank " + std::to_string(rank) + " expects " + std::to_string(o.bytes) + " bytes from rank " + std::to_string(p) +
                                                   ", which posted " + (k < sends.size() ? std::to_string(sends[k]->bytes) + " bytes" : std::string("fewer sends")) + " (the plans of the two ranks disagree)");
-                if (int rc = hip(hipMemcpyAsync(o.ptr, sends[k]->ptr, o.bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(in-process transfer)")) return rc;
+                if (int rc = copy(o.ptr, sends[k]->ptr, o.bytes)) return rc;
                 k++;
             }
             if (k != sends.size() && !g.frozen) return xfail(PLR_ERR_HIP, "in-process exchange " + std::to_string(id) + ": rank " + std::to_string(p) + " posted more sends to rank " + std::to_string(rank) + " than it receives");
+        }
+        for (size_t first = 0; first < copies.size(); first += kMaxLocalCopies) {
+            LocalCopyTable t{};
+            t.n = (int)std::min<size_t>(kMaxLocalCopies, copies.size() - first);
+            size_t largest = 16;
+            for (int i = 0; i < t.n; i++) { t.c[i] = copies[first + i]; largest = std::max(largest, t.c[i].bytes); }
+            localCopyKernel<<<dim3((unsigned)std::min<size_t>((largest / 16 + 1023) / 1024, 512), (unsigned)t.n), 256, 0, stream>>>(t);
+            if (int rc = hip(hipGetLastError(), "localCopyKernel")) return rc;
         }
         if (int rc = hip(hipEventRecord(mine.copied, stream), "hipEventRecord(copied)")) return rc;
         mine.received = gen;
@@ -692,7 +731,8 @@ struct RcclExchange {
             pe.outWordsPerRow = wordsPerRow(pe.rect);
             pe.outWords = 2u * pe.outWordsPerRow * (pe.rect.y1 - pe.rect.y0);
             pe.inWords = inWords;
-            total += 2 * ((size_t)pe.outWords + pe.inWords) * 4 + 4 * 256;
+            if (pe.outWords / 2 > kScanBlock * kMaxScanBlocks || pe.inWords / 2 > kScanBlock * kMaxScanBlocks) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists over rectangles of more than 4 M trace texels");
+            total += 2 * ((size_t)pe.outWords + pe.inWords) * 4 + 4 * 256 + 2 * (2 * kMaxScanBlocks * 4 + 256);
         }
         // (cleared ON THE STREAM the exchange runs on: hipMemset goes to the null stream, which does not order against non-blocking streams - the clear could land on
         //  top of the first frame's slices)
@@ -704,6 +744,7 @@ struct RcclExchange {
             if (p == rank) continue;
             RequestState::Peer& pe = req.peers[(size_t)p];
             pe.out = take(pe.outWords); pe.in = take(pe.inWords); pe.outOff = take(pe.outWords); pe.inOff = take(pe.inWords);
+            pe.outBase = take(2 * kMaxScanBlocks); pe.inBase = take(2 * kMaxScanBlocks);
         }
         const size_t countBytes = (size_t)2 * (size_t)world * 2 * sizeof(uint32_t);
         if (int rc = hip(hipMalloc((void**)&req.countsDev, countBytes), "hipMalloc(request counts)")) return rc;
@@ -742,13 +783,17 @@ struct RcclExchange {
             const RequestState::Peer& pe = req.peers[(size_t)p];
             for (int q = 0; q < 2; q++) {
                 if (t.n + 2 > kMaxSlices) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists for more than 16 peers");
-                t.s[t.n++] = {pe.out + (size_t)q * (pe.outWords / 2), pe.outOff + (size_t)q * (pe.outWords / 2), countSlot(req.countsDev, q, p, 0), pe.outWords / 2};
-                t.s[t.n++] = {pe.in + (size_t)q * (pe.inWords / 2), pe.inOff + (size_t)q * (pe.inWords / 2), countSlot(req.countsDev, q, p, 1), pe.inWords / 2};
+                t.s[t.n++] = {pe.out + (size_t)q * (pe.outWords / 2), pe.outOff + (size_t)q * (pe.outWords / 2), pe.outBase + (size_t)q * kMaxScanBlocks, countSlot(req.countsDev, q, p, 0), pe.outWords / 2};
+                t.s[t.n++] = {pe.in + (size_t)q * (pe.inWords / 2), pe.inOff + (size_t)q * (pe.inWords / 2), pe.inBase + (size_t)q * kMaxScanBlocks, countSlot(req.countsDev, q, p, 1), pe.inWords / 2};
             }
         }
         if (t.n) {
-            requestScanKernel<<<(unsigned)t.n, 1024, 0, stream>>>(t);
-            if (int rc = hip(hipGetLastError(), "requestScanKernel")) return rc;
+            uint32_t maxWords = 1;
+            for (int i = 0; i < t.n; i++) maxWords = std::max(maxWords, t.s[i].words);
+            requestScanBlocksKernel<<<dim3((maxWords + kScanBlock - 1) / kScanBlock, (unsigned)t.n), 1024, 0, stream>>>(t);
+            if (int rc = hip(hipGetLastError(), "requestScanBlocksKernel")) return rc;
+            requestScanSlicesKernel<<<(unsigned)t.n, 64, 0, stream>>>(t);
+            if (int rc = hip(hipGetLastError(), "requestScanSlicesKernel")) return rc;
         }
         if (int rc = hip(hipMemcpyAsync(req.countsHost, req.countsDev, (size_t)2 * (size_t)world * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(request counts)")) return rc;
         return hip(hipEventRecord(req.countsReady, stream), "hipEventRecord(request counts)");
@@ -779,12 +824,12 @@ struct RcclExchange {
             const uint32_t nIn = *countSlot(req.countsHost, point, p, 1), nOut = *countSlot(req.countsHost, point, p, 0);
             if (gather.n >= kMaxWalks) return xfail(PLR_ERR_UNSUPPORTED, "exchange: request lists for more than 16 peers");
             if (nIn) {
-                gather.w[gather.n++] = {pe.in + (size_t)point * (pe.inWords / 2), pe.inOff + (size_t)point * (pe.inWords / 2), (uint4*)(req.send[point].ptr + sendAt[(size_t)p]), pe.inWords / 2, req.inWordsPerRow, req.mine.x0, req.mine.y0};
+                gather.w[gather.n++] = {pe.in + (size_t)point * (pe.inWords / 2), pe.inOff + (size_t)point * (pe.inWords / 2), pe.inBase + (size_t)point * kMaxScanBlocks, (uint4*)(req.send[point].ptr + sendAt[(size_t)p]), pe.inWords / 2, req.inWordsPerRow, req.mine.x0, req.mine.y0};
                 maxGather = std::max(maxGather, pe.inWords / 2);
                 ops.push_back({p, true, req.send[point].ptr + sendAt[(size_t)p], (size_t)nIn * 16});
             }
             if (nOut) {
-                scatter.w[scatter.n++] = {pe.out + (size_t)point * (pe.outWords / 2), pe.outOff + (size_t)point * (pe.outWords / 2), (uint4*)(req.recv[point].ptr + recvAt[(size_t)p]), pe.outWords / 2, pe.outWordsPerRow, pe.rect.x0, pe.rect.y0};
+                scatter.w[scatter.n++] = {pe.out + (size_t)point * (pe.outWords / 2), pe.outOff + (size_t)point * (pe.outWords / 2), pe.outBase + (size_t)point * kMaxScanBlocks, (uint4*)(req.recv[point].ptr + recvAt[(size_t)p]), pe.outWords / 2, pe.outWordsPerRow, pe.rect.x0, pe.rect.y0};
                 maxScatter = std::max(maxScatter, pe.outWords / 2);
                 ops.push_back({p, false, req.recv[point].ptr + recvAt[(size_t)p], (size_t)nOut * 16});
             }
