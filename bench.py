@@ -229,10 +229,17 @@ def build_scene(args, device, w, h, band=None):
     from plainrenderer_amd import synth
     from plainrenderer_amd.frame import SyntheticInputs
     from plainrenderer_amd.scene import Camera
-    scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
-    span = args.grid * 8.0
-    x0 = span * 0.35
-    cams = [Camera.look((x0 + 0.002 * i, -9.0, -10.0 + 0.004 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(args.steps + args.warmup + args.profile_frames + 28)]
+    n_cams = args.steps + args.warmup + args.profile_frames + 28
+    if getattr(args, "scene", "default") == "dense":
+        # --scene dense: the instances packed one metre apart (they overlap: 0.8 - 2.5 m half extents), the camera looking along the field - culling
+        # tiles carry tens of instances up to the list's cap of 100 (sdfCameraTileCulling.comp:42-99), the generator of tests/test_sdfgi.py dense_scene at the bench's size
+        scene = synth.SynthScene(grid=args.grid, cell=1.0, seed_id=301, device=device)
+        cams = [Camera.look((args.grid * 0.5 + 0.002 * i, -5.0, -6.0 + 0.004 * i), (0.0, 0.35, 1.0), aspect=w / h) for i in range(n_cams)]
+    else:
+        scene = synth.SynthScene(grid=args.grid, cell=8.0, seed_id=700, device=device)
+        span = args.grid * 8.0
+        x0 = span * 0.35
+        cams = [Camera.look((x0 + 0.002 * i, -9.0, -10.0 + 0.004 * i), (0.02, 0.17, 1.0), aspect=w / h) for i in range(n_cams)]
     rows = depth_range = None
     if band is not None:
         # every band must fit the same shadow cascades: depth range of the whole frame from a 1/8-resolution G-buffer (same on all ranks)
@@ -304,6 +311,8 @@ def main():
     ap.add_argument("--pass-table", action="store_true", help="print the per-pass table to stderr")
     ap.add_argument("--producers", action="store_true", help="NOT the headline workload: also run the input producers as compute passes every frame (sun light matrices, "
                     "the three sky LUTs, the four froxel passes: SURVEY 8 f3) instead of reading uploaded LUTs / matrices; single GPU only")
+    ap.add_argument("--scene", choices=["default", "dense"], default="default", help="NOT the headline workload: dense = the same 256 instances packed one metre apart, the camera looking "
+                    "along the field - culling tiles carry tens of instances, up to the cap of 100 (the trace where the shader is stressed); the JSON line carries trace samples/s and the tile counts")
     ap.add_argument("--exact", action="store_true", help="diagnostic: run the bit-exact kernel set (PLR_MATH_EXACT) instead of the default fast set")
     ap.add_argument("--force-bands", action="store_true", help="diagnostic: run the N=1 frame through the band path (one band, RCCL group of size 1)")
     ap.add_argument("--python-exchange", action="store_true", help="diagnostic: drive the halo exchange from Python (torch.distributed) instead of the C++ host's RCCL exchange")
@@ -696,6 +705,23 @@ def main():
             sys.stderr.write("%-36s %9.4f %7.1f %9.1f %8.1f\n" % (name, avg, launches, nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0, 100 * avg * launches / tot))
         sys.stderr.write("sum of pass times %.3f ms; frame (wall) %.3f ms\n" % (tot, ms_per_step))
 
+    # ---- the SDF trace as a line of its own: rays (= trace pixels) per second, and how many instances the culling tiles carry (sdfCameraTileCulling.comp: 32 x 32 trace
+    # pixels per tile, at most 100 instances each) - the default scene has a median of one instance per tile, --scene dense tens
+    trace_line = None
+    if band is None:
+        try:
+            tile_uints = 101
+            raw = be.downloadStorageBuffer(fp.storage_buffer("sdfCulledTiles"), math.ceil(w / 32) * math.ceil((h // 2) / 32) * tile_uints * 4, dtype=np.uint32).reshape(-1, tile_uints)
+            tw_tiles, th_tiles = math.ceil((w // 2) / 32), math.ceil((h // 2) / 32)
+            counts = raw.reshape(th_tiles, math.ceil(w / 32), tile_uints)[:, :tw_tiles, 0].reshape(-1)  # the buffer's row stride is the FULL-resolution tile count (sdfCulling.inc:17-20)
+            t_ms = sum(v for k, v in ((n, float(np.mean(x))) for n, x in pass_ms.items()) if "SDF trace" in k)
+            trace_line = {"rays_per_frame": (w // 2) * (h // 2), "trace_ms": round(t_ms, 4) if t_ms else None,
+                          "rays_per_s": round((w // 2) * (h // 2) / (t_ms * 1e-3), 1) if t_ms else None,
+                          "instances_per_culling_tile": {"median": float(np.median(counts)), "mean": round(float(counts.mean()), 2), "max": int(counts.max()),
+                                                         "tiles_at_the_cap_of_100": int((counts >= 100).sum()), "tiles": int(counts.size)}}
+        except Exception as e:  # noqa: BLE001
+            trace_line = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+
     exchange_stats = None
     if band is not None and not args.python_exchange:
         sent, received, groups = fp.rccl_stats()
@@ -720,8 +746,8 @@ def main():
             "host_ms_per_frame_idle_gpu": round(host_idle_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "full frame (exposure + HiZ + SDF GI trace/denoise + deferred shade + TAA + bloom + tonemap) %dx%d, %d SDF instances x %d^3, "
-                                   "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res),
-                       "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "kernel_set": "exact" if args.exact else "fast",
+                                   "half-res trace, reference default settings" % (w, h, args.grid ** 2, args.sdf_res) + (" - DENSE scene (instances 1 m apart, tens of instances per culling tile): not the headline workload" if args.scene == "dense" else ""),
+                       "scene": args.scene, "resolution": [w, h], "sdf_instances": args.grid ** 2, "sdf_resolution": args.sdf_res, "kernel_set": "exact" if args.exact else "fast",
                        # what the timed frames do besides the workload's size: camera translation per frame (static G-buffer, moving view for the reprojections),
                        # backend scheduling switches (include/plr.h): pass fusion level, asynchronous frame tail (bloom chain + tonemap beside the next frame)
                        "input_producers_as_compute": bool(args.producers), "camera_step_per_frame": [0.002, 0.0, 0.004], "pass_fusion": be.getPassFusion()[0], "async_tail": be.getAsyncTail()[0],
@@ -744,6 +770,7 @@ def main():
             "single_gpu_same_frame_ms": round(single_gpu_same_frame_ms, 4) if single_gpu_same_frame_ms else None,
             "strong_scaling_vs_1gpu_same_frame": round(single_gpu_same_frame_ms / ms_per_step, 4) if (single_gpu_same_frame_ms and not replicas) else None,
             "roofline": roofline,
+            "sdf_trace": trace_line,
             "cpu_baseline": cpu,
             "exchange": exchange_stats,
             "passes_ms": {name: round(avg * launches, 4) for name, avg, launches, _ in table},
