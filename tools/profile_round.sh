@@ -42,16 +42,20 @@ cd $REPO
   python -m pytest tests/test_parity_fullsize.py -m gpu -q -s 2>&1 | grep -E "^\.?PARITY|passed|failed" | sed 's/^\.//'; } > $OUT/parity_4k.txt
 { echo "# kernel source digest: $DIGEST"; echo "# python -m pytest tests/test_config5_8k.py -m gpu -s   (7680x4320 as 2 x 2 tiles and as 4 row bands on one GPU, exact mode and default halos, 64 frames, vs the unpartitioned frame and the oracle)";
   python -m pytest tests/test_config5_8k.py -m gpu -q -s 2>&1 | grep -E "CONFIG5 .*(summary|partition:|oracle|halos)|passed|failed" | sed 's/^\.*//'; } > $OUT/config5_8k.txt
-# tiles against bands, measured: the single-GPU replay of both partitions of the 8K frame from this build (loopback exchange, edges-first producers, balanced), then
-# the bands without the edges-first machinery (what the overlap costs when there is no link time to hide)
-{ echo "# kernel source digest: $DIGEST"; echo "# ---- python tools/band_cost.py 4 --tiles 2x2 --passes --balance"; python tools/band_cost.py 4 --tiles 2x2 --passes --balance 2>&1 | grep -v amdgpu.ids;
-  echo "# ---- python tools/band_cost.py 4 --passes --balance"; python tools/band_cost.py 4 --passes --balance 2>&1 | grep -v amdgpu.ids;
-  echo "# ---- PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance   (band_overlap_exchange 0: producers not split, exchanges whole)"; PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids;
-  echo "# ---- PLRF_EXCHANGE_END_BY_VALUE=1 python tools/band_cost.py 4 --balance   (the END of an exchange as a stream value wait instead of an event wait)"; PLRF_EXCHANGE_END_BY_VALUE=1 python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids;
-  echo "# ---- PLRF_EXCHANGE_BEGIN_WAIT=value python tools/band_cost.py 4 --balance   (the BEGIN's wait for the edge signal as hipStreamWaitValue32, as until the middle of round 5, instead of a sleeping one-wave kernel)"; PLRF_EXCHANGE_BEGIN_WAIT=value python tools/band_cost.py 4 --balance 2>&1 | grep -v amdgpu.ids; } > $OUT/tile_vs_band.txt
-bash tools/config5_series.sh 256 > $OUT/config5_series.txt 2>&1
+# tiles against bands in the three GI exchange modes, measured: the single-GPU replay from this build - every rank timed alone with its neighbours' real data in its
+# halos (tools/band_cost.py over the native exchange's in-process transport, round 6); then the requested mode without the two-phase filter, and the loopback replay
+# of rounds 3 - 5 for continuity
+{ echo "# kernel source digest: $DIGEST";
+  for M in "--requested" "" "--exact"; do for G in "--tiles 2x2" ""; do echo "# ---- python tools/band_cost.py 4 $G --balance --passes $M"; python tools/band_cost.py 4 $G --balance --passes $M 2>&1 | grep -v amdgpu.ids | grep -vE "^    partition [0-9]"; done; done
+  echo "# ---- PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --tiles 2x2 --balance --requested   (one exchange callback and one filter execution per point)"; PLR_BAND_COST_OVERLAP=0 python tools/band_cost.py 4 --tiles 2x2 --balance --requested 2>&1 | grep -v amdgpu.ids | grep -vE "^    partition [0-9]";
+  echo "# ---- python tools/band_cost.py 4 --tiles 2x2 --balance --loopback   (the replay of rounds 3 - 5: every partition with its own texels in its halos)"; python tools/band_cost.py 4 --tiles 2x2 --balance --loopback 2>&1 | grep -v amdgpu.ids | grep -vE "^    partition [0-9]"; } > $OUT/tile_vs_band.txt
+# the 256-frame series of the bounded-halo mode's deviation (profiles/r05g_config5_series.txt): unchanged since round 5, re-taken only on request
+[ -n "${PLR_PROFILE_SERIES:-}" ] && bash tools/config5_series.sh 256 > $OUT/config5_series.txt 2>&1
 { echo "# kernel source digest: $DIGEST"; python tools/tail_cost.py 2>&1 | grep -v amdgpu.ids; } > $OUT/tail_cost.txt
 NOW=$(python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_digest())")
 if [ "$NOW" != "$DIGEST" ]; then echo "kernel sources changed during the profile run ($DIGEST -> $NOW): evidence is inconsistent" >&2; exit 1; fi
-grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt $OUT/config5_series.txt && { echo "parity suite failed" >&2; exit 1; }
+grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt && { echo "parity suite failed" >&2; exit 1; }
+# the dense scene (tens of instances per culling tile, up to the cap): bench line + culling / trace parity at the benchmark's size
+python $REPO/bench.py --scene dense --no-cpu-baseline > $OUT/bench_dense.json 2>> $OUT/bench.err
+{ echo "# kernel source digest: $DIGEST"; python tools/parity_dense.py 2>&1 | grep -v amdgpu.ids; } > $OUT/parity_dense.txt
 ls -la $OUT
