@@ -607,7 +607,9 @@ struct RcclExchange {
         if (!mine.filled) if (int rc = hip(hipEventCreateWithFlags(&mine.filled, hipEventDisableTiming), "hipEventCreateWithFlags")) return rc;
         std::unique_lock<std::mutex> lock(g.m);
         const uint64_t gen = mine.generation + 1;
-        uint8_t* base = g.slots + (size_t)(gen & 1u) * (size_t)g.world * LocalGroup::kSlotBytes; // two sets of slots: a rank one exchange ahead does not overwrite what a peer still reads
+        // two sets of slots PER EXCHANGE ID: a rank one exchange ahead does not overwrite what a peer still reads - and the depth-range all-reduce does not land in the
+        // histogram's slots (one shared set: a rank already at the depth range overwrote bins another rank was still summing; found by the tile light-matrix test)
+        uint8_t* base = g.slots + ((size_t)id * 2u + (size_t)(gen & 1u)) * (size_t)g.world * LocalGroup::kSlotBytes;
         lock.unlock();
         if (int rc = hip(hipMemcpyAsync(base + (size_t)rank * LocalGroup::kSlotBytes, ptr, bytes, hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(all-reduce slot)")) return rc;
         if (int rc = hip(hipEventRecord(mine.filled, stream), "hipEventRecord(filled)")) return rc;
@@ -1173,8 +1175,9 @@ int plrf_local_attach_rects(void* pipeline, void* group, int rank, int world, ui
         if (g->device < 0) g->device = device;
         if (g->device != device) return xfail(PLR_ERR_UNSUPPORTED, "plrf_local_attach_rects: the in-process transport copies device to device on ONE GPU; ranks on several GPUs use the communicator (plrf_rccl_attach_rects)");
         if (!g->slots) {
-            if (hipMalloc((void**)&g->slots, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMalloc(all-reduce slots)");
-            if (hipMemset(g->slots, 0, 2 * (size_t)world * LocalGroup::kSlotBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return xfail(PLR_ERR_HIP, "hipMemset(all-reduce slots)");
+            const size_t slotBytes = 2 * (size_t)PLRF_EXCHANGE_COUNT * (size_t)world * LocalGroup::kSlotBytes;
+            if (hipMalloc((void**)&g->slots, slotBytes) != hipSuccess) return xfail(PLR_ERR_HIP, "hipMalloc(all-reduce slots)");
+            if (hipMemset(g->slots, 0, slotBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return xfail(PLR_ERR_HIP, "hipMemset(all-reduce slots)");
         }
     }
     void* exchange = nullptr;

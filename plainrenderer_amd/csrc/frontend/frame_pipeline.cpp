@@ -1123,7 +1123,8 @@ void FramePipeline::computeDepthApexOfTiles() {
         cols.end = std::min(cols.end, levelCols);
         exe.dispatchBase[0] = cols.begin;
         exe.dispatchCount[0] = cols.end - cols.begin;
-        // (a one-column tile from column 0 would read as "whole rows": only possible when the level has one column, where it IS whole rows)
+        const int32_t columnRange = 1; // the x range is a range of texel columns, also when it is one column from column 0
+        exe.pushConstants = dataToCharArray(&columnRange, sizeof(columnRange));
     }
     exe.genericInfo.resources.sampledImages = {ImageResource(m_minMaxDepthPyramid, top, 0)};
     exe.genericInfo.resources.storageImages = {ImageResource(m_bandDepthApex, 0, 1)};

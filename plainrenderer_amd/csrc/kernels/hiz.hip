@@ -56,8 +56,12 @@ static int launchDepthPyramidApex(const PassCtx& c) {
     const ImgView& level = c.sampled[0];
     const PassCtx::RowSpan rs = c.rowSpan(level.h, 1);
     if (rs.y1 <= rs.y0) return c.fail(-1, "depthPyramidApex: no rows to reduce");
-    // columns: the dispatch's x range in texels of the level (tile rendering); the band renderer's dispatch of ONE workgroup from column 0 means whole rows
-    const PassCtx::ColSpan cs = c.base[0] == 0 && c.dispatch[0] <= 1 ? PassCtx::ColSpan{0, level.w} : c.colSpan(level.w, 1);
+    // columns: whole rows, unless the execution says that its x range is a range of texel columns of the level (tile rendering; push constant, 4 bytes, non-zero).
+    // (Until round 5 "base 0, count <= 1" was read as whole rows: a tile one texel of the level wide - 64 pixels - at column 0 of a wider frame reduced texels the
+    //  GPU never built. ADVICE r05)
+    int columnRange = 0;
+    if (c.push.size() >= 4) std::memcpy(&columnRange, c.push.data(), 4);
+    const PassCtx::ColSpan cs = columnRange ? c.colSpan(level.w, 1) : PassCtx::ColSpan{0, level.w};
     if (cs.x1 <= cs.x0) return c.fail(-1, "depthPyramidApex: no columns to reduce");
     depthPyramidApexKernel<<<1, 256, 0, c.stream>>>(level, rs.y0, rs.y1, cs.x0, cs.x1, (float2*)c.storage[1].ptr);
     PLR_CHECK_LAUNCH(c);

@@ -134,8 +134,11 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                                                                const GlobalUbo* __restrict__ g, const float* __restrict__ sampleTables, const uint4* __restrict__ packed, int filterIndex,
                                                                int coverW, int coverH, int yBase, int xBase, int tilesX, int tilesY, int chunkRows, uint32_t* __restrict__ sig,
                                                                uint32_t validY0, uint32_t validRowCount, uint32_t validX0, uint32_t validColCount, int rowMissShrinks,
-                                                               SpatialFrameConsts fc, uint32_t* __restrict__ requestBitmap = nullptr, uint32_t bitmapRowWords = 0, int requestPhase = 0) {
-    const float* __restrict__ samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
+                                                               SpatialFrameConsts fc, uint32_t* __restrict__ requestBitmap = nullptr, uint32_t bitmapRowWords = 0, int requestPhase = 0,
+                                                               uint32_t* __restrict__ requestBitmap2 = nullptr) {
+    // (MARK with requestBitmap2: BOTH spatial filter passes' requests in one launch - filterIndex's pass into requestBitmap, then filter 1's into requestBitmap2; the
+    //  per-pixel frame is the same for both, only the disc's radius and the sample table change: `samples`, `radiusWorld`, T, B, PT, PB and the safety flags are re-set)
+    const float* samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
     if (!xcdWalk(tilesX, tilesY, chunkRows, tileX, tileY)) return; // device/xcd.h: the note on the XCDs' L2s above
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float dW = fc.dW, dH = fc.dH;
     const int dwi = depthTexture.w, dhi = depthTexture.h;
 
-    const float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
+    float radiusWorld = filterIndex == 1 ? 1.f : 1.5f;
     // requestPhase (the filter with request lists, push constant of the execution): 1 = only the waves whose discs provably stay inside the dispatched rectangle (they
     // need nothing from another GPU: this launch runs WHILE the requested texels travel), 2 = the other waves (behind the exchange). The test is MARK's, below.
     if (MARK || requestPhase != 0) {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         if (MARK ? allInside : (requestPhase == 1 ? !allInside : allInside)) return;
     }
     float tsx, tsy, u0, v0;
-    vec3 pCenter, T, B;
+    vec3 pCenter, T, B, uT, uB;
     {
         // the shader's own sequence (:33-41), bit for bit: see the note at the top of this file
 #pragma clang fp contract(off)
@@ -211,8 +214,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         // uv + vec2(1, 0) * texelSize and uv + vec2(0, 1) * texelSize (:37-38): 1 * t = t and v + 0 * t = v exactly for the positive finite values here
         const vec3 pRight = pixelToWorldExact(u0 + tsx, v0);
         const vec3 pUp = pixelToWorldExact(u0, v0 + tsy);
-        T = radiusWorld * unit(pCenter - pRight);
-        B = radiusWorld * unit(pCenter - pUp);
+        uT = unit(pCenter - pRight); uB = unit(pCenter - pUp);
+        T = radiusWorld * uT;
+        B = radiusWorld * uB;
     }
     const int nwi = normalTexture.w, nhi = normalTexture.h;
     vec3 N(0.f, 0.f, 1.f);
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
         return vec3(vp[0] * p.x + vp[4] * p.y + vp[8] * p.z + vp[12] * w, vp[1] * p.x + vp[5] * p.y + vp[9] * p.z + vp[13] * w,
                     vp[3] * p.x + vp[7] * p.y + vp[11] * p.z + vp[15] * w);
     };
-    const vec3 P0 = projXYW(pCenter, 1.f), PT = projXYW(T, 0.f), PB = projXYW(B, 0.f);
+    const vec3 P0 = projXYW(pCenter, 1.f);
+    vec3 PT = projXYW(T, 0.f), PB = projXYW(B, 0.f);
     // dot(N, pixelWorld - pCenter) = c0 + lin * (nF + ndcY * nU + ndcX * nR)
     const float c0 = dot(N, camPos - pCenter);
     const float nF = dot(N, fwd), nU = -tanH * dot(N, up), nR = tanA * dot(N, right);
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     // Can a sample of this pixel leave the screen? Its world offset is ox * T + oy * B with |ox| + |oy| <= sqrt(2) and |T| = |B| = radiusWorld,
     // so |offset| <= dm; the clip coordinates move by at most (row norm) * dm, and |x'| <= w', |y'| <= w' is what "on screen" means.
     bool safe, safeInside = true; // safeInside: the disc provably stays inside the valid rows / columns too (band / tile rendering)
-    {
+    auto computeSafety = [&]() {
+        safeInside = true;
         const float dm = radiusWorld * 1.4143f * 1.01f;
         // norms of the x, y and w rows of viewProjection: per-frame constants, from the launcher (three square roots and a dozen multiply-adds per LANE otherwise -
         // this chip has no scalar float unit to take uniform arithmetic)
@@ -257,7 +263,9 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
             const float reach = 0.5f * (sx + sw) * dm * rcpf(__builtin_fmaxf(wMin, 1e-20f)) * (float)inYSH.w + 1.f; // columns
             safeInside = safeInside && (float)px - reach >= (float)validX0 && (float)px + reach < (float)(validX0 + validColCount);
         }
-    }
+    };
+    computeSafety();
+    uint8_t* markBytes = (uint8_t*)requestBitmap;
     float resCo = 0.f, resCg = 0.f;
     float weightTotal = 0.f;
     float lengthModifier = 1.f;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
                 if (MARK) {
                     // one BYTE per texel, plain stores (every writer stores the same 1): millions of atomic ORs on words shared by 32 texels made this pass take 2.4 x
                     // the filter it precedes (profiles/r06_band_cost.txt); requestBytesToBitsKernel folds the bytes into the bitmap the exchange trades
-                    if (miss && !offScreen) ((uint8_t*)requestBitmap)[(size_t)ty * bitmapRowWords + tx] = 1u;
+                    if (miss && !offScreen) markBytes[(size_t)ty * bitmapRowWords + tx] = 1u;
                     continue;
                 }
                 off[k] = offScreen || miss;
@@ -402,8 +410,22 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     };
     if (MARK) {
         // a wave whose discs provably stay inside the rank's own rectangle requests nothing; the others walk the samples with the copy the filter will take
-        if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
-        else if (__builtin_amdgcn_ballot_w64(!safeInside) != 0ull) sampleLoop(std::true_type{}, std::false_type{});
+        auto markPass = [&]() {
+            if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
+            else if (__builtin_amdgcn_ballot_w64(!safeInside) != 0ull) sampleLoop(std::true_type{}, std::false_type{});
+        };
+        markPass();
+        if (requestBitmap2) { // the second spatial filter pass (filterIndex 1: its own sample table, a disc of 1 m): same frame, same statements
+#pragma clang fp contract(off)
+            samples = sampleTables + min(g->frameIndexMod4 + 1u, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
+            radiusWorld = 1.f;
+            T = radiusWorld * uT; B = radiusWorld * uB;
+            PT = projXYW(T, 0.f); PB = projXYW(B, 0.f);
+            computeSafety();
+            lengthModifier = 1.f;
+            markBytes = (uint8_t*)requestBitmap2;
+            markPass();
+        }
         return;
     }
     if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) sampleLoop(std::false_type{}, std::true_type{});
@@ -617,7 +639,8 @@ PLR_REGISTER_SHADER_FAST("filterIndirectDiffuseSpatial.comp", launchSpatialFilte
 // the bit of every texel OUTSIDE that rectangle a disc sample of filterIndirectDiffuseSpatial.comp (specialisation constant 0 = its filterIndex) lands on.
 //   sampled image 4: the filter's depthTexture (the trace resolution); storage buffer 6: the bitmap, ceil(width / 32) words per texel row, cleared here.
 // The sample positions depend on depth, camera and frame index only (filterIndirectDiffuseSpatial.comp:53-105), so this runs before the trace.
-static int launchGiSampleRequests(const PassCtx& c) {
+// `second`: the execution of the OTHER spatial filter pass over the same rectangle (pass fusion: both passes' requests in one launch), or null
+static int launchGiSampleRequestsImpl(const PassCtx& c, const PassCtx* second) {
     if (int rc = c.needGlobal()) return rc;
     if (int rc = c.needSampled(4, -1, "giSampleRequests depthTexture")) return rc;
     if (int rc = c.needSbuf(6, 4, "giSampleRequests bitmap")) return rc;
@@ -625,7 +648,7 @@ static int launchGiSampleRequests(const PassCtx& c) {
     if (depth.fmt != F_R16F && depth.fmt != F_D32) return c.fail(-4, "giSampleRequests: depthTexture must be R16_sFloat or Depth32");
     const uint32_t rowWords = ((uint32_t)depth.w + 31u) / 32u;
     const size_t bitmapBytes = (size_t)rowWords * (size_t)depth.h * 4u;
-    if (c.sbuf[6].size < bitmapBytes) return c.fail(-4, "giSampleRequests: the bitmap needs ceil(width / 32) words per texel row of the depth texture");
+    if (c.sbuf[6].size < bitmapBytes || (second && second->sbuf[6].size < bitmapBytes)) return c.fail(-4, "giSampleRequests: the bitmap needs ceil(width / 32) words per texel row of the depth texture");
     if (!c.globalHost) return c.fail(-4, "giSampleRequests: the global uniform block must have been filled through plr_set_uniform_buffer_data");
     static const int rowMissShrinks = std::getenv("PLR_BAND_ROW_MISS_SHRINKS") ? std::atoi(std::getenv("PLR_BAND_ROW_MISS_SHRINKS")) : 0;
     if (rowMissShrinks) return c.fail(-4, "giSampleRequests: PLR_BAND_ROW_MISS_SHRINKS changes where samples land depending on what is valid; not with request lists");
@@ -633,19 +656,21 @@ static int launchGiSampleRequests(const PassCtx& c) {
     const PassCtx::RowSpan rs = c.rowSpan(depth.h);
     const PassCtx::ColSpan cs = c.colSpan(depth.w);
     const int w = cs.x1, x0 = cs.x0, h = rs.y1, y0 = rs.y0;
-    // scratch: [sample tables | byte map: one byte per texel, rows of rowWords * 32 bytes]
+    // scratch: [sample tables | byte map: one byte per texel, rows of rowWords * 32 bytes | a second byte map (two passes in one launch)]
     const uint32_t bytePitch = rowWords * 32u;
     const size_t byteMapBytes = (size_t)bytePitch * (size_t)depth.h;
-    const bool freshScratch = c.scratchSize && *c.scratchSize < kSpatialTableBytes + byteMapBytes;
-    uint8_t* scratch = (uint8_t*)c.scratch(kSpatialTableBytes + byteMapBytes);
+    const size_t scratchBytes = kSpatialTableBytes + 2 * byteMapBytes;
+    const bool freshScratch = c.scratchSize && *c.scratchSize < scratchBytes;
+    uint8_t* scratch = (uint8_t*)c.scratch(scratchBytes);
     if (!scratch) return c.fail(-2, "giSampleRequests: cannot allocate scratch memory");
     if (freshScratch) spatialSampleTableKernel<<<1, 256, 0, c.stream>>>((float*)scratch);
     uint8_t* byteMap = scratch + kSpatialTableBytes;
-    if (hipMemsetAsync(byteMap, 0, byteMapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
-    if (w <= x0 || h <= y0) {
-        if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
-        return 0;
-    }
+    uint8_t* byteMap2 = second ? byteMap + byteMapBytes : nullptr;
+    auto clearBitmaps = [&]() {
+        if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return false;
+        return !second || hipMemsetAsync(second->sbuf[6].ptr, 0, bitmapBytes, c.stream) == hipSuccess;
+    };
+    if (w <= x0 || h <= y0) return clearBitmaps() ? 0 : c.fail(-2, "giSampleRequests: hipMemsetAsync");
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544);
@@ -655,10 +680,9 @@ static int launchGiSampleRequests(const PassCtx& c) {
     int validLo, validHi, validLoX, validHiX;
     c.validRowRange(depth.h, &validLo, &validHi);
     c.validColRange(depth.w, &validLoX, &validHiX);
-    if (validLo <= 0 && validHi >= depth.h && validLoX <= 0 && validHiX >= depth.w) { // the rectangle is the image: nothing lies outside it
-        if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
-        return 0;
-    }
+    if (validLo <= 0 && validHi >= depth.h && validLoX <= 0 && validHiX >= depth.w) // the rectangle is the image: nothing lies outside it
+        return clearBitmaps() ? 0 : c.fail(-2, "giSampleRequests: hipMemsetAsync");
+    if (hipMemsetAsync(byteMap, 0, (second ? 2 : 1) * byteMapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
     const float* hvp = c.globalHost->viewProjection;
     auto rowNorm = [&](int r) { return (float)std::sqrt((double)hvp[r] * hvp[r] + (double)hvp[4 + r] * hvp[4 + r] + (double)hvp[8 + r] * hvp[8 + r]); };
     SpatialFrameConsts fc;
@@ -667,16 +691,30 @@ static int launchGiSampleRequests(const PassCtx& c) {
     fc.vpRowNorms = make_float3(rowNorm(0), rowNorm(1), rowNorm(3));
     ImgView gi = depth; // the GI images share the depth texture's grid: only their size is used
 #define PLR_MARK_ARGS gi, gi, gi, gi, depth, depth, c.global, (const float*)scratch, (const uint4*)nullptr, filterIndex, w, h, y0, x0, tilesX, tilesY, chunkRows, (uint32_t*)nullptr, \
-                      (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), 0, fc, (uint32_t*)byteMap, bytePitch
+                      (uint32_t)validLo, (uint32_t)std::max(validHi - validLo, 0), (uint32_t)validLoX, (uint32_t)std::max(validHiX - validLoX, 0), 0, fc, (uint32_t*)byteMap, bytePitch, 0, (uint32_t*)byteMap2
     if (depth.fmt == F_R16F) spatialFilterFastKernel<F_R16F, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
     else spatialFilterFastKernel<F_D32, TXv, true, true, false, true><<<grid, 256, 0, c.stream>>>(PLR_MARK_ARGS);
 #undef PLR_MARK_ARGS
     PLR_CHECK_LAUNCH(c);
     const uint32_t words = rowWords * (uint32_t)depth.h;
     requestBytesToBitsKernel<<<divUp(words, 256u), 256, 0, c.stream>>>(byteMap, bytePitch, (uint32_t*)c.sbuf[6].ptr, rowWords, words);
+    if (second) requestBytesToBitsKernel<<<divUp(words, 256u), 256, 0, c.stream>>>(byteMap2, bytePitch, (uint32_t*)second->sbuf[6].ptr, rowWords, words);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }
+static int launchGiSampleRequests(const PassCtx& c) { return launchGiSampleRequestsImpl(c, nullptr); }
+// pass fusion: the request passes of filter 0 and filter 1, recorded back to back over the same rectangle and depth texture, as ONE launch (they share the per-pixel
+// frame - three exact world positions - which is most of what a wave pays before its samples)
+static int launchGiSampleRequestsPair(const PassCtx* const* ctxs, size_t count) {
+    if (count != 2) return kUseGeneralKernel;
+    const PassCtx &a = *ctxs[0], &b = *ctxs[1];
+    if (a.specInt(0, 0) != 0 || b.specInt(0, 0) != 1 || !a.hasSampled(4) || !b.hasSampled(4) || !a.hasSbuf(6) || !b.hasSbuf(6)) return kUseGeneralKernel;
+    if (a.sampled[4].ptr != b.sampled[4].ptr || a.sbuf[6].ptr == b.sbuf[6].ptr || std::memcmp(a.base, b.base, sizeof(a.base)) || std::memcmp(a.dispatch, b.dispatch, sizeof(a.dispatch)) ||
+        std::memcmp(a.validRows, b.validRows, sizeof(a.validRows)) || std::memcmp(a.validCols, b.validCols, sizeof(a.validCols)))
+        return kUseGeneralKernel;
+    return launchGiSampleRequestsImpl(a, &b);
+}
+PLR_REGISTER_FUSION("giSampleRequests x 2", launchGiSampleRequestsPair, "giSampleRequests.comp", "giSampleRequests.comp");
 // PLR_MATH_FAST only: the marks are the texels THIS file's filter kernel lands on; the exact set's filter orders its arithmetic differently and a sample on a texel
 // boundary may land next door (plr_set_math_mode(PLR_MATH_EXACT) + request lists fails loudly: no exact kernel for this shader)
 PLR_REGISTER_SHADER_FAST("giSampleRequests.comp", launchGiSampleRequests);
