@@ -615,6 +615,9 @@ def test_rect_plan_of_bands_equals_the_band_plan_and_the_cpp_plan():
         assert sum((r[2] - r[0]) * (r[3] - r[1]) for r in rects) == fw * fh
         for div in (1, 2):
             cols, rows = fw // div, fh // div
+            # PLRF_HALO_WHOLE_IMAGE passed straight to the public plan function saturates (it used to wrap in 32 bits: ADVICE r05): the plan of a halo as large as the image
+            for k in range(gx * gy):
+                assert cpp_plan(fw, fh, rects, k, cols, rows, 0xffffffff) == cpp_plan(fw, fh, rects, k, cols, rows, max(cols, rows)) == tiling.rect_plan(rects, k, fw, fh, cols, rows, max(cols, rows))
             for halo in (8, 16, 128, 224):
                 plans = [tiling.rect_plan(rects, k, fw, fh, cols, rows, halo) for k in range(gx * gy)]
                 for k, plan in enumerate(plans):

@@ -20,7 +20,13 @@ for line in open("profiles/%s_big_kernel_counters.txt" % prev).read().splitlines
         out.append(line.replace(prev, tag).replace(prev_digest, digest))
         continue
     key = line[:60].strip()
-    r = [r for r in rows if r[0].replace(",", ";").startswith(key)][0]
+    match = [r for r in rows if r[0].replace(",", ";").startswith(key)]
+    if not match:  # the kernel's template arguments changed since the previous set: the same kernel by its name in front of them, the launch with the most waves
+        match = sorted([r for r in rows if r[0].split("<")[0] == key.split("<")[0]], key=lambda r: -float(dict(zip(hdr, r))["SQ_WAVES"]))
+        key = match[0][0].replace(",", ";") if match else key
+    if not match:
+        continue
+    r = match[0]
     d = dict(zip(hdr, r)); f = lambda k: float(d[k]); waves = f("SQ_WAVES"); cyc = f("GRBM_GUI_ACTIVE") / 8
     out.append("%-60s %7.1f %8d %9d %9.1f %9.1f %6.0f %% %8.2f %6.0f %% %6.0f %%" % (
         key[:58], cyc / 2400.0, waves, round(f("SQ_INSTS_VALU") / waves), f("SQ_INSTS_VMEM_RD") / waves, f("SQ_INSTS_LDS") / waves, 100 * f("TA_TA_BUSY_sum") / 256 / cyc,
