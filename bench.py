@@ -330,7 +330,9 @@ def main():
     args = ap.parse_args()
     if args.exact_partition:
         args.gi_exchange = "exact"
-    args.exact_partition = args.gi_exchange != "halo"  # "the partitioned frame is byte-identical": whole-frame inputs on every rank (the denoiser's samples may land anywhere)
+    # the byte-identical modes get the G-buffer inputs of the WHOLE frame on every rank (whole-image halo: the denoiser weighs samples anywhere in the frame; request lists:
+    # kept the same so that both parity-true modes are measured on the same inputs - the requested texels arrive with their depth, so the rectangle + halo would do)
+    args.whole_frame_inputs = args.gi_exchange != "halo"
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -415,7 +417,7 @@ def main():
             be_ = RenderBackend(w_, h_, device=local_rank)
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **rect_settings(rects_[rank], w_))
             fp_.set_exchange_callback(lambda exchange_id, stream: None)
-            _, cams_, inputs_ = build_scene(args, device, w_, h_, None if args.exact_partition else (b0, b1))
+            _, cams_, inputs_ = build_scene(args, device, w_, h_, None if args.whole_frame_inputs else (b0, b1))
             inputs_.upload(fp_)
             for i in range(4):
                 fp_.frame(cams_[i + 1], 1.0 / 60.0, 0.5)
@@ -487,7 +489,7 @@ def main():
             extra = dict(run_sky_luts=1, run_volumetrics=1, run_light_matrix=1) if args.producers else {}
             fp_ = FramePipeline(be_, w_, h_, shadow_map_res=args.shadow_res, **extra)
         # (the exact partition's denoiser weighs samples anywhere in the frame: depth and normals of the whole frame are inputs of every rank then)
-        sc = build_scene(args, device, w_, h_, None if args.exact_partition else band_)
+        sc = build_scene(args, device, w_, h_, None if args.whole_frame_inputs else band_)
         sc[2].upload(fp_)
         be_.waitForGPUIdle()
         return be_, fp_, sc, w_, h_, band_
