@@ -679,9 +679,7 @@ int plr_setup(int device_ordinal, uint32_t width, uint32_t height) {
     HIP_TRY(hipEventCreate(&g->frameEnd));
     for (auto& slot : g->pinnedSlots) HIP_TRY(hipEventCreateWithFlags(&slot.free, hipEventDisableTiming));
     for (auto& st : g->sideStreams) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    static const int tailPriority = std::getenv("PLR_TAIL_PRIORITY") ? std::atoi(std::getenv("PLR_TAIL_PRIORITY")) : 0; // experiment hook: 1 = the tail stream at the least priority
-    if (tailPriority) HIP_TRY(hipStreamCreateWithPriority(&g->tailStream, hipStreamNonBlocking, leastPriority));
-    else HIP_TRY(hipStreamCreateWithFlags(&g->tailStream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g->tailStream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g->tailDone, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&g->tailStart, hipEventDisableTiming));
     if (earlyPriority) HIP_TRY(hipStreamCreateWithPriority(&g->earlyStream, hipStreamNonBlocking, leastPriority));
