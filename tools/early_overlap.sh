@@ -11,7 +11,7 @@ d = json.loads(sys.stdin.read()); print('%-58s frame %.4f ms' % ('$3', d['ms_per
 for ROUND in 1 2; do
   run 0 "" "one launch (early parts off)"
   run 2 "self" "two launches back to back (direct, then upscale + combine)"
-  run 1 "" "direct from the frame's start (beside front .. spatial 2)"
+  run 1 "" "direct from the start of the frame (beside front .. spatial 2)"
   run 1 "SDF trace" "direct beside trace .. spatial 2"
   run 1 "spatial filter" "direct beside spatial 1 .. spatial 2"
   run 1 "temporal filter" "direct beside temporal GI .. spatial 2"
@@ -23,6 +23,6 @@ trace() {
 }
 trace 0 "" "one launch (early parts off)"
 trace 2 "self" "two launches back to back"
-trace 1 "" "direct from the frame's start"
+trace 1 "" "direct from the start of the frame"
 trace 1 "SDF trace" "direct beside trace .. spatial 2"
 trace 1 "spatial filter" "direct beside spatial 1 .. spatial 2"
