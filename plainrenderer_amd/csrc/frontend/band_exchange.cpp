@@ -226,24 +226,56 @@ __global__ __launch_bounds__(64) void requestScanSlicesKernel(SliceTable t) {
 struct RequestWalk { const uint32_t* bits; const uint32_t* offsets; const uint32_t* blockBase; uint4* buffer; uint32_t words, wordsPerRow, x0, y0; };
 constexpr int kMaxWalks = 16;
 struct WalkTable { int n; RequestWalk w[kMaxWalks]; uint2* ysh; uint32_t* cocg; uint16_t* depth; uint32_t imageCols; };
+// One lane per BIT: a wave takes kWalkWords = 8 words of the slice, two per step (the halves of the wave), four steps unrolled - the words, their offsets and then the
+// texels of all four steps are independent loads, a wave's life is two memory latencies whatever its words hold. (One thread per word walked a dense word's 32 texels
+// one after the other: the words along a rectangle's edge are dense, and the gather / scatter of 0.4 M texels took 27 - 52 us, on the responses' critical path:
+// profiles/r06c_band_timeline.txt.)
+constexpr uint32_t kWalkWords = 8;
 template <bool GATHER>
 __global__ __launch_bounds__(256) void requestWalkKernel(WalkTable t) {
     const RequestWalk k = t.w[blockIdx.y];
-    for (uint32_t wi = blockIdx.x * 256u + threadIdx.x; wi < k.words; wi += gridDim.x * 256u) {
-        uint32_t bits = k.bits[wi];
-        if (!bits) continue;
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, bit = lane & 31u;
+    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kWalkWords; // wave-uniform
+    if (w0 >= k.words) return;
+    uint32_t word[4];
+    bool any = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t wi = w0 + 2u * i + half;
+        word[i] = wi < k.words ? k.bits[wi] : 0u;
+        any = any || word[i] != 0u;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+    uint32_t slot[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t wi = w0 + 2u * i + half;
+        slot[i] = word[i] ? k.blockBase[wi / kScanBlock] + k.offsets[wi] + (uint32_t)__popc(word[i] & ((1u << bit) - 1u)) : 0u;
+    }
+    size_t idx[4];
+    bool on[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t wi = w0 + 2u * i + half;
         const uint32_t row = wi / k.wordsPerRow, col = wi - row * k.wordsPerRow;
-        uint32_t slot = k.blockBase[wi / kScanBlock] + k.offsets[wi];
-        while (bits) {
-            const uint32_t b = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1u;
-            const size_t idx = (size_t)(k.y0 + row) * t.imageCols + (k.x0 + col * 32u + b);
-            if (GATHER) { const uint2 y = t.ysh[idx]; k.buffer[slot] = make_uint4(y.x, y.y, t.cocg[idx], (uint32_t)t.depth[idx]); }
-            else { const uint4 v = k.buffer[slot]; t.ysh[idx] = make_uint2(v.x, v.y); t.cocg[idx] = v.z; t.depth[idx] = (uint16_t)v.w; }
-            slot++;
-        }
+        on[i] = ((word[i] >> bit) & 1u) != 0u;
+        idx[i] = (size_t)(k.y0 + row) * t.imageCols + (k.x0 + col * 32u + bit);
+    }
+    if (GATHER) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) if (on[i]) { const uint2 y = t.ysh[idx[i]]; v[i] = make_uint4(y.x, y.y, t.cocg[idx[i]], (uint32_t)t.depth[idx[i]]); }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) if (on[i]) k.buffer[slot[i]] = v[i];
+    } else {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) if (on[i]) v[i] = k.buffer[slot[i]];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) if (on[i]) { t.ysh[idx[i]] = make_uint2(v[i].x, v[i].y); t.cocg[idx[i]] = v[i].z; t.depth[idx[i]] = (uint16_t)v[i].w; }
     }
 }
+static unsigned walkBlocks(uint32_t words) { return (words + 4u * kWalkWords - 1u) / (4u * kWalkWords); }
 
 // ---------------------------------------------------------------- waiting for the producer's edge signal on the communication stream
 // hipStreamWaitValue32 does it in the command processor - and a PENDING value wait on one stream slows every kernel the chip runs meanwhile: with the host a frame
@@ -415,6 +447,7 @@ struct RcclExchange {
         StageArena send[2], recv[2];
     } req;
     int lastOverlapMode = 0;
+    bool deferredPost[PLRF_EXCHANGE_COUNT] = {}; // request lists: a BEGIN whose transfers are posted from its END (run())
     bool packedRegions = false;
     int streamWaitValueSupported = 0;
     // watchdog: entries are completion events; a background thread reports (and aborts) when the frame loop itself is stuck
@@ -837,12 +870,12 @@ struct RcclExchange {
             }
         }
         if (gather.n) {
-            requestWalkKernel<true><<<dim3(std::min((maxGather + 255u) / 256u, 256u), (unsigned)gather.n), 256, 0, stream>>>(gather);
+            requestWalkKernel<true><<<dim3(walkBlocks(maxGather), (unsigned)gather.n), 256, 0, stream>>>(gather);
             if (int rc = hip(hipGetLastError(), "requestWalkKernel(gather)")) return rc;
         }
         if (int rc = transfer(id, ops, stream)) return rc;
         if (scatter.n) {
-            requestWalkKernel<false><<<dim3(std::min((maxScatter + 255u) / 256u, 256u), (unsigned)scatter.n), 256, 0, stream>>>(scatter);
+            requestWalkKernel<false><<<dim3(walkBlocks(maxScatter), (unsigned)scatter.n), 256, 0, stream>>>(scatter);
             if (int rc = hip(hipGetLastError(), "requestWalkKernel(scatter)")) return rc;
         }
         return 0;
@@ -937,6 +970,17 @@ struct RcclExchange {
             if (dog.deadlineMs) { if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc; dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]); }
             return 0;
         }
+        if (phase == PLRF_EXCHANGE_BEGIN && req.ready && (id == PLRF_EXCHANGE_GI_TRACE || id == PLRF_EXCHANGE_GI_TEMPORAL)) {
+            // Request lists: the sizes of the responses are the counts of the request exchange, which the HOST must have read (postRequested) - a wait of the launch
+            // thread for the GPU. Here, right behind the producer's launch, the launch stream would run dry behind that wait (54 us between the trace and the filter's first
+            // phase, profiles/r06c_band_timeline.txt). So the BEGIN only marks the point on the launch stream; the responses are posted from the END, which the launch thread
+            // reaches with the filter's first phase - the waves that need no requested texel - already enqueued: the GPU works through it while the host waits.
+            lastOverlapMode = 1;
+            if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
+            if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
+            deferredPost[id] = true;
+            return 0;
+        }
         if (phase == PLRF_EXCHANGE_BEGIN) {
             // When may the transfers start? Edges-first producers (band_overlap_exchange 2): as soon as the launch that is still running has written its edge
             // rows / columns - the communication stream waits for the backend's edge signal (a word the kernel's last edge block stores, hipStreamWaitValue32),
@@ -957,19 +1001,24 @@ struct RcclExchange {
                 if (int rc = hip(hipEventRecord(ready[id], launchStream), "hipEventRecord")) return rc;
                 if (int rc = hip(hipStreamWaitEvent(commStream, ready[id], 0), "hipStreamWaitEvent")) return rc;
             }
-            if (int rc = post(id, commStream)) return rc;
-            if (doneFlag[id]) if (int rc = hip(hipStreamWriteValue32(commStream, doneFlag[id], ++doneSerial[id], 0), "hipStreamWriteValue32")) return rc;
-            // (the event stays: it is what the watchdog queries, and the END's order when there are no stream memory operations)
-            if (!doneFlag[id] || dog.deadlineMs) if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc;
-            dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]);
-            return 0;
+            return postBehindBegin(id);
         }
         if (phase == PLRF_EXCHANGE_END) {
+            if (deferredPost[id]) { deferredPost[id] = false; if (int rc = postBehindBegin(id)) return rc; }
             if (doneFlag[id]) return hip(hipStreamWaitValue32(launchStream, doneFlag[id], doneSerial[id], hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32(END)");
             return hip(hipStreamWaitEvent(launchStream, done[id], 0), "hipStreamWaitEvent");
         }
         if (int rc = post(id, launchStream)) return rc;
         return watch(id, 0, launchStream);
+    }
+    // the transfers of exchange `id` on the communication stream (which is behind the BEGIN's wait), their completion flag / event, the watchdog's entry
+    int postBehindBegin(int id) {
+        if (int rc = post(id, commStream)) return rc;
+        if (doneFlag[id]) if (int rc = hip(hipStreamWriteValue32(commStream, doneFlag[id], ++doneSerial[id], 0), "hipStreamWriteValue32")) return rc;
+        // (the event stays: it is what the watchdog queries, and the END's order when there are no stream memory operations)
+        if (!doneFlag[id] || dog.deadlineMs) if (int rc = hip(hipEventRecord(done[id], commStream), "hipEventRecord")) return rc;
+        dog.arm(rank, id, PLRF_EXCHANGE_BEGIN, &RcclExchange::eventDone, &dogArgs[id]);
+        return 0;
     }
     // an exchange enqueued on the launch stream itself gets no completion event by default: an event record is a barrier packet of ~6 us on the launch stream,
     // and a launch stream parked in such an exchange shows up anyway - the next overlapped exchange's producer never runs, its edge signal is never raised, and
