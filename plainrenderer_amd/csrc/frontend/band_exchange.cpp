@@ -837,7 +837,14 @@ struct RcclExchange {
     // behind their producer): gather what the peers asked for, trade, scatter what this rank asked for into the images and the depth texture
     int postRequested(int id, int point, hipStream_t stream) {
         if (!req.ready) return xfail(PLR_ERR_INVALID_ARGUMENT, "exchange: requested texels before the request exchange of the frame");
+        static const bool debugWait = std::getenv("PLRF_EXCHANGE_DEBUG_WAIT") != nullptr; // how long does the launch thread wait for the counts? (0: it is the GPU that waits for the host)
+        const auto w0 = std::chrono::steady_clock::now();
         if (int rc = hip(hipEventSynchronize(req.countsReady), "hipEventSynchronize(request counts)")) return rc; // the host needs the sizes; the GPU is long past this point
+        if (debugWait && point == 0) {
+            static thread_local double total = 0; static thread_local int n = 0;
+            total += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+            if (++n % 20 == 0) { fprintf(stderr, "[exchange rank %d] launch thread waited %.1f us per frame for the request counts (last 20 frames)\n", rank, total / 20); total = 0; }
+        }
         if (int rc = hip(hipStreamWaitEvent(stream, req.countsReady, 0), "hipStreamWaitEvent(request counts)")) return rc; // (the slices and their offsets were made on the communication stream)
         size_t sendTotal = 0, recvTotal = 0;
         std::vector<size_t> sendAt((size_t)world, 0), recvAt((size_t)world, 0);
