@@ -58,4 +58,8 @@ grep -q failed $OUT/parity_4k.txt $OUT/config5_8k.txt && { echo "parity suite fa
 # the dense scene (tens of instances per culling tile, up to the cap): bench line + culling / trace parity at the benchmark's size
 python $REPO/bench.py --scene dense --no-cpu-baseline > $OUT/bench_dense.json 2>> $OUT/bench.err
 { echo "# kernel source digest: $DIGEST"; python tools/parity_dense.py 2>&1 | grep -v amdgpu.ids; } > $OUT/parity_dense.txt
+# one rank's frame of the partitioned 8K frame (request lists, 2 x 2 tiles) as a kernel timeline: what runs when on which queue (tools/band_timeline.sh)
+bash tools/band_timeline.sh > /dev/null 2>&1
+{ echo "# kernel source digest: $DIGEST"; echo "# bash tools/band_timeline.sh   (rocprofv3 --kernel-trace around tools/band_cost.py 4 --tiles 2x2 --requested; start, end, duration, queue, kernel)";
+  cat $REPO/gpurun_out/band_timeline/timeline.txt; } > $OUT/band_timeline.txt
 ls -la $OUT
