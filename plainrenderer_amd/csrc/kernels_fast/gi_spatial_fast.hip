@@ -98,12 +98,17 @@ __global__ __launch_bounds__(256) void spatialSparsePackKernel(ImgView inYSH, Im
     const size_t idx = (size_t)y * (size_t)inYSH.w + x;
     packed[idx] = packGiTexel(((const uint2*)inYSH.ptr)[idx], ((const uint32_t*)inCoCg.ptr)[idx], Texel<DEPTH_FMT>::load(depthTexture.ptr, idx).x, g->nearPlane, g->farPlane);
 }
-// the request pass's byte map (one byte per texel, row pitch `pitch` bytes) -> the bitmap: a lane per word, 32 bytes = two 16-byte loads
-__global__ __launch_bounds__(256) void requestBytesToBitsKernel(const uint8_t* __restrict__ bytes, uint32_t pitch, uint32_t* __restrict__ bitmap, uint32_t rowWords, uint32_t words) {
+// the request pass's byte map (one byte per texel, row pitch `pitch` bytes) -> the bitmap: a lane per word, 32 bytes = two 16-byte loads. blockIdx.y: the map (two passes'
+// requests in one launch). The bytes that were set are cleared again here - the map is all zero when the next frame's request pass starts, without a 2 x 2 MB memset
+// launch in front of it every frame (r06c_band_timeline.txt: fillBufferAligned 5 - 10 us + the gap of a dependent launch)
+__global__ __launch_bounds__(256) void requestBytesToBitsKernel(uint8_t* __restrict__ bytes0, uint32_t* __restrict__ bitmap0, uint8_t* __restrict__ bytes1, uint32_t* __restrict__ bitmap1,
+                                                                uint32_t pitch, uint32_t rowWords, uint32_t words) {
     const uint32_t wi = blockIdx.x * 256u + threadIdx.x;
     if (wi >= words) return;
+    uint8_t* bytes = blockIdx.y ? bytes1 : bytes0;
+    uint32_t* bitmap = blockIdx.y ? bitmap1 : bitmap0;
     const uint32_t y = wi / rowWords, xw = wi - y * rowWords;
-    const uint4* src = (const uint4*)(bytes + (size_t)y * pitch + (size_t)xw * 32u);
+    uint4* src = (uint4*)(bytes + (size_t)y * pitch + (size_t)xw * 32u);
     const uint4 a = src[0], c = src[1];
     const uint32_t d[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
     uint32_t bits = 0u;
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(256) void requestBytesToBitsKernel(const uint8_t* _
         bits |= (((v & 0xffu) ? 1u : 0u) | ((v & 0xff00u) ? 2u : 0u) | ((v & 0xff0000u) ? 4u : 0u) | ((v & 0xff000000u) ? 8u : 0u)) << (4 * k);
     }
     bitmap[wi] = bits;
+    if (bits) { src[0] = make_uint4(0u, 0u, 0u, 0u); src[1] = make_uint4(0u, 0u, 0u, 0u); }
 }
 
 // SIG: also write the decision signature: two words per pixel, bit i = x / y parity of sample i's nearest texel (both toggled when off screen; oracle/oracle.h)
@@ -666,6 +672,8 @@ static int launchGiSampleRequestsImpl(const PassCtx& c, const PassCtx* second) {
     if (freshScratch) spatialSampleTableKernel<<<1, 256, 0, c.stream>>>((float*)scratch);
     uint8_t* byteMap = scratch + kSpatialTableBytes;
     uint8_t* byteMap2 = second ? byteMap + byteMapBytes : nullptr;
+    // (both maps are zero between frames: requestBytesToBitsKernel clears what a pass set)
+    if (freshScratch && hipMemsetAsync(byteMap, 0, 2 * byteMapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
     auto clearBitmaps = [&]() {
         if (hipMemsetAsync(c.sbuf[6].ptr, 0, bitmapBytes, c.stream) != hipSuccess) return false;
         return !second || hipMemsetAsync(second->sbuf[6].ptr, 0, bitmapBytes, c.stream) == hipSuccess;
@@ -682,7 +690,6 @@ static int launchGiSampleRequestsImpl(const PassCtx& c, const PassCtx* second) {
     c.validColRange(depth.w, &validLoX, &validHiX);
     if (validLo <= 0 && validHi >= depth.h && validLoX <= 0 && validHiX >= depth.w) // the rectangle is the image: nothing lies outside it
         return clearBitmaps() ? 0 : c.fail(-2, "giSampleRequests: hipMemsetAsync");
-    if (hipMemsetAsync(byteMap, 0, (second ? 2 : 1) * byteMapBytes, c.stream) != hipSuccess) return c.fail(-2, "giSampleRequests: hipMemsetAsync");
     const float* hvp = c.globalHost->viewProjection;
     auto rowNorm = [&](int r) { return (float)std::sqrt((double)hvp[r] * hvp[r] + (double)hvp[4 + r] * hvp[4 + r] + (double)hvp[8 + r] * hvp[8 + r]); };
     SpatialFrameConsts fc;
@@ -697,8 +704,8 @@ static int launchGiSampleRequestsImpl(const PassCtx& c, const PassCtx* second) {
 #undef PLR_MARK_ARGS
     PLR_CHECK_LAUNCH(c);
     const uint32_t words = rowWords * (uint32_t)depth.h;
-    requestBytesToBitsKernel<<<divUp(words, 256u), 256, 0, c.stream>>>(byteMap, bytePitch, (uint32_t*)c.sbuf[6].ptr, rowWords, words);
-    if (second) requestBytesToBitsKernel<<<divUp(words, 256u), 256, 0, c.stream>>>(byteMap2, bytePitch, (uint32_t*)second->sbuf[6].ptr, rowWords, words);
+    requestBytesToBitsKernel<<<dim3(divUp(words, 256u), second ? 2u : 1u), 256, 0, c.stream>>>(byteMap, (uint32_t*)c.sbuf[6].ptr, byteMap2, second ? (uint32_t*)second->sbuf[6].ptr : nullptr,
+                                                                                              bytePitch, rowWords, words);
     PLR_CHECK_LAUNCH(c);
     return 0;
 }

@@ -172,6 +172,27 @@ static int launch(const PassCtx& c) {
     return 0;
 }
 
+// The frame's pending fills (backend.h PassCtx::pendingFillSlot) ride in launch 1 of a front when it touches none of their destinations (uniform / storage buffers the
+// host writes per frame: the frustum, the culled-instance count, filter weights, the rotating copy of the global buffer ... - launch 1 reads the colour and depth images
+// and the light buffer): *fillSlot = the table for one more block of the launch, or null after the fills went out as a launch of their own (a dependent launch of
+// ~ 10 us and its two gaps in front of every frame: profiles/r06c_band_timeline.txt, applyFillsKernel - the band front did not take them until round 6c)
+static int takeFillsIfDisjoint(const PassCtx& c, const HistParams& hp, uint8_t** fillSlot) {
+    *fillSlot = nullptr;
+    if (!c.pendingFillSlot) return 0;
+    const uint8_t* slot = c.pendingFillSlot;
+    const uint32_t nFills = *(const uint32_t*)slot;
+    const FillEntry* entries = (const FillEntry*)(slot + kFillTableHeader); // pinned host memory: readable here
+    auto touches = [&](const void* base, size_t bytes) {
+        for (uint32_t i = 0; i < nFills; i++)
+            if (entries[i].dst < (uint64_t)(uintptr_t)base + bytes && (uint64_t)(uintptr_t)base < entries[i].dst + entries[i].size) return true;
+        return false;
+    };
+    const bool disjoint = !touches(hp.light, sizeof(LightBuffer)) && !touches(hp.perTile, (size_t)hp.tilesX * (hp.tileY0 + hp.gridY) * kBins * 4u) &&
+                          !touches(hp.thresholds, kBins * 4u);
+    if (disjoint) { *fillSlot = c.pendingFillSlot; c.pendingFillsTaken = true; return 0; }
+    return c.applyPendingFillsNow();
+}
+
 // the six passes of the frame front - eight with the camera culling's two behind them - as two launches (fused_front.h)
 static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     if (count != 6 && count != 8) return kUseGeneralKernel;
@@ -194,9 +215,10 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
         if (int rc = prepareFusedCulling(*ctxs[6], *ctxs[7], &cull, &useHiZ, &hiz)) return rc;
         const fasthiz::TileTailParams& t = zp.tileTail;
         if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel;
-        if (ctxs[0]->pendingFillSlot) if (int rc = ctxs[0]->applyPendingFillsNow()) return rc;
+        uint8_t* fillSlotT = nullptr;
+        if (int rc = takeFillsIfDisjoint(*ctxs[0], hp, &fillSlotT)) return rc;
         const uint32_t histBlocksT = hp.gridX * hp.gridY, hizBlocksT = (uint32_t)(zp.gridX * zp.gridY);
-        histogramAndPyramidKernel<true><<<histBlocksT + hizBlocksT, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocksT, hizBlocksT, (uint32_t)zp.gridX, nullptr);
+        histogramAndPyramidKernel<true><<<histBlocksT + hizBlocksT + (fillSlotT ? 1u : 0u), 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocksT, hizBlocksT, (uint32_t)zp.gridX, fillSlotT);
         PLR_CHECK_LAUNCH(*ctxs[0]);
         return launchTileFrontSecondWithExposure(zp, cull, ep, ctxs[0]->stream);
     }
@@ -212,23 +234,8 @@ static int launchFusedFront(const PassCtx* const* ctxs, size_t count) {
     }
     // the pyramid's inputs are not outputs of the exposure chain (and vice versa): nothing else orders the two chains
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
-    // the frame's pending fills ride in launch 1 when it touches none of their destinations (uniform / storage buffers the host writes per frame: the frustum, the
-    // culled-instance count, filter weights, the rotating copy of the global buffer ... - launch 1 reads the colour and depth images and the light buffer)
     uint8_t* fillSlot = nullptr;
-    if (ctxs[0]->pendingFillSlot) {
-        const uint8_t* slot = ctxs[0]->pendingFillSlot;
-        const uint32_t nFills = *(const uint32_t*)slot;
-        const FillEntry* entries = (const FillEntry*)(slot + kFillTableHeader); // pinned host memory: readable here
-        auto touches = [&](const void* base, size_t bytes) {
-            for (uint32_t i = 0; i < nFills; i++)
-                if (entries[i].dst < (uint64_t)(uintptr_t)base + bytes && (uint64_t)(uintptr_t)base < entries[i].dst + entries[i].size) return true;
-            return false;
-        };
-        const bool disjoint = !touches(hp.light, sizeof(LightBuffer)) && !touches(hp.perTile, (size_t)hp.tilesX * (hp.tileY0 + hp.gridY) * kBins * 4u) &&
-                              !touches(hp.thresholds, kBins * 4u);
-        if (disjoint) { fillSlot = ctxs[0]->pendingFillSlot; ctxs[0]->pendingFillsTaken = true; }
-        else if (int rc = ctxs[0]->applyPendingFillsNow()) return rc;
-    }
+    if (int rc = takeFillsIfDisjoint(*ctxs[0], hp, &fillSlot)) return rc;
     histogramAndPyramidKernel<true><<<histBlocks + hizBlocks + (fillSlot ? 1u : 0u), 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX, fillSlot);
     PLR_CHECK_LAUNCH(*ctxs[0]);
     return launchExposureChainAndPyramidTail(ep, zp, ctxs[0]->stream, count == 8 ? &cull : nullptr, cullLevel);
@@ -253,9 +260,10 @@ static int launchBandFront(const PassCtx* const* ctxs, size_t count) {
     if (int rc = prepareFusedCulling(*ctxs[5], *ctxs[6], &cull, &useHiZ, &hiz)) return rc;
     const fasthiz::TileTailParams& t = zp.tileTail;
     if (!useHiZ || hiz.ptr != (const void*)t.level4 || hiz.w != t.w4 || hiz.h != t.h4) return kUseGeneralKernel; // the tiles must sample the level launch 2 finishes
-    if (ctxs[0]->pendingFillSlot) if (int rc = ctxs[0]->applyPendingFillsNow()) return rc; // (not registered for the frame's fills: the backend applies them first)
+    uint8_t* fillSlot = nullptr;
+    if (int rc = takeFillsIfDisjoint(*ctxs[0], hp, &fillSlot)) return rc;
     const uint32_t histBlocks = hp.gridX * hp.gridY, hizBlocks = (uint32_t)(zp.gridX * zp.gridY);
-    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks, 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX, nullptr);
+    histogramAndPyramidKernel<true><<<histBlocks + hizBlocks + (fillSlot ? 1u : 0u), 256, 0, ctxs[0]->stream>>>(hp, zp.quad, histBlocks, hizBlocks, (uint32_t)zp.gridX, fillSlot);
     PLR_CHECK_LAUNCH(*ctxs[0]);
     return launchBandFrontSecond(zp, cull, rp, ctxs[0]->stream);
 }
@@ -277,7 +285,7 @@ static int fasthist_launch(const PassCtx& c) { return fasthist::launch(c); }
 PLR_REGISTER_SHADER_FAST("histogramPerTile.comp", fasthist_launch);
 static int fused_frame_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
 static int fused_band_front(const PassCtx* const* ctxs, size_t count) { return fasthist::launchBandFront(ctxs, count); }
-PLR_REGISTER_FUSION("band front: histogram + reset + combine || per-tile depth pyramid || camera culling", fused_band_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
+PLR_REGISTER_FUSION_TAKES_FILLS("band front: histogram + reset + combine || per-tile depth pyramid || camera culling", fused_band_front, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",
                     "depthHiZPyramid.comp", "depthDownscale.comp", "sdfCameraFrustumCulling.comp", "sdfCameraTileCulling.comp");
 static int fused_frame_front_and_culling(const PassCtx* const* ctxs, size_t count) { return fasthist::launchFusedFront(ctxs, count); }
 PLR_REGISTER_FUSION_TAKES_FILLS("frame front: histogram + exposure chain || depth pyramid || camera culling", fused_frame_front_and_culling, "histogramPerTile.comp", "histogramReset.comp", "histogramCombineTiles.comp",

@@ -13,6 +13,20 @@ rows.sort()
 # the third quarter of the histogram launches that belong to partitioned frames (rank 2 of 4 at the default arguments)
 starts = [i for i, r in enumerate(rows) if "histogramAndPyramid" in r[3]]
 print("# %d kernel dispatches, %d frames" % (len(rows), len(starts)))
+# which hardware queue do a rank's launch stream, asynchronous tail and communication stream sit on? (the four ranks and the unpartitioned pipeline of this one process share
+# the device's hardware queues; a rank per process has three streams in use and a queue for each.) Runs of consecutive frames with the same triple:
+def queue_of(k, k1, what):
+    qs = [rows[i][2] for i in range(k, k1) if what in rows[i][3]]
+    return max(set(qs), key=qs.count) if qs else "-"
+runs = []
+for a, b in zip(starts, starts[1:]):
+    key = (queue_of(a, b, "histogramAndPyramid"), queue_of(a, b, "bloomDownsample"), queue_of(a, b, "requestScan"))
+    us = (rows[b][0] - rows[a][0]) / 1e3
+    if runs and runs[-1][0] == key: runs[-1][1].append(us)
+    else: runs.append([key, [us]])
+print("# frames by (launch queue, tail queue, communication queue): count, median us from frame start to frame start")
+for key, v in runs:
+    if len(v) >= 8: print("#   launch q%s tail q%s comm q%s: %3d frames, median %7.1f us%s" % (key[0], key[1], key[2], len(v), sorted(v)[len(v) // 2], "   <- the tail shares the launch stream's queue: no overlap" if key[0] == key[1] else ""))
 for frac in (0.45, 0.55, 0.65):
     k = starts[int(len(starts) * frac)]
     k1 = [i for i in starts if i > k][0]
