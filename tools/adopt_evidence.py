@@ -34,6 +34,11 @@ for line in open("profiles/%s_big_kernel_counters.txt" % prev).read().splitlines
 open("profiles/%s_big_kernel_counters.txt" % tag, "w").write("\n".join(out) + "\n")
 with open("profiles/%s_pytest_gpu.txt" % tag, "w") as fh:
     fh.write("# python -m pytest tests -m gpu -q   (kernel source digest %s, MI355X box)\n" % digest + open("gpurun_out/final/pytest_gpu.txt").read())
+# the reports the profile round wrote as they are
+import shutil
+for f in ("config5_8k.txt", "kernel_stats.csv", "parity_4k.txt", "parity_dense.txt", "pass_table.txt", "pass_table_producers.txt", "pass_table_producers_exact.txt", "tail_cost.txt",
+          "tile_vs_band.txt", "band_timeline.txt", "bench_dense.json"):
+    if os.path.exists("gpurun_out/prof_%s/%s" % (tag, f)): shutil.copy("gpurun_out/prof_%s/%s" % (tag, f), "profiles/%s_%s" % (tag, f))
 same_round = tag[:3] == prev[:3]  # a previous ROUND's final set stays (the documents' history cites it); an earlier build of this round is replaced
 for f in glob.glob("profiles/%s_*" % prev) if same_round else []:
     subprocess.check_call(["git", "rm", "-q", "-f", f])
