@@ -26,4 +26,24 @@ PLR_DI bool xcdWalk(int tilesX, int tilesY, int chunkRows, int& tileX, int& tile
     return tileY < tilesY;
 }
 
+// The same walk with the image cut in BOTH directions: splitX (1, 2, 4 or 8) columns of XCDs, 8 / splitX rows of them; XCD k works on column k % splitX, and on
+// the chunks (k / splitX), (k / splitX) + 8 / splitX, ... of that column (interleaved as above). A chunk is then splitX times narrower and, for the same number of
+// chunks per XCD, splitX times taller: what an XCD's L2 fetches beyond its own tiles - the discs' reach r around every chunk - is (1 + 2r / height)(1 + 2r / width)
+// of the chunk instead of 1 + 2r / height of a full-width one, and the height is what was small. splitX = 1 is xcdWalk.
+inline int xcdChunkRows2(int tilesY, int chunksPerXcd, int splitX) { const int v = (8 / splitX) * chunksPerXcd; return (tilesY + v - 1) / v; }
+inline int xcdBlockTilesX(int tilesX, int splitX) { return (tilesX + splitX - 1) / splitX; }
+inline dim3 xcdWalkGrid2(int tilesX, int tilesY, int chunksPerXcd, int splitX) {
+    return dim3((unsigned)(xcdBlockTilesX(tilesX, splitX) * xcdChunkRows2(tilesY, chunksPerXcd, splitX) * chunksPerXcd) * 8u);
+}
+PLR_DI bool xcdWalk2(int tilesX, int tilesY, int chunkRows, int splitX, int& tileX, int& tileY) {
+    const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3);
+    const int cx = xcd % splitX, ry = xcd / splitX, rowsSplit = 8 / splitX;
+    const int bw = (tilesX + splitX - 1) / splitX, perChunk = bw * chunkRows;
+    const int turn = local / perChunk, within = local - turn * perChunk;
+    const int lx = within / chunkRows;
+    tileX = cx * bw + lx;
+    tileY = (turn * rowsSplit + ry) * chunkRows + (within - lx * chunkRows);
+    return tileX < tilesX && tileY < tilesY;
+}
+
 } // namespace plr

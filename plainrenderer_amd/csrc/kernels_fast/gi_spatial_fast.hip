@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void spatialFilterFastKernel(ImgView outYSH, I
     const float* samples = sampleTables + min(g->frameIndexMod4 + (uint32_t)filterIndex, (uint32_t)(kSampleKeys - 1)) * kSampleTableFloats;
     constexpr int TY = 256 / TX;
     int tileX, tileY;
-    if (!xcdWalk(tilesX, tilesY, chunkRows, tileX, tileY)) return; // device/xcd.h: the note on the XCDs' L2s above
+    if (!xcdWalk2(tilesX, tilesY, chunkRows & 0xffff, chunkRows >> 16, tileX, tileY)) return; // device/xcd.h: the note on the XCDs' L2s above (chunkRows: rows | splitX << 16)
     const int px = xBase + tileX * TX + (int)(threadIdx.x % TX); // columns [xBase, coverW) (tile rendering: PassCtx::colSpan), rows [yBase, coverH)
     const int py = yBase + tileY * TY + (int)(threadIdx.x / TX);
     if (px >= coverW || py >= coverH) return;
@@ -549,10 +549,20 @@ static int launchSpatialFilterFast(const PassCtx& c) {
 #endif
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
-    // chunks of ~17 tile rows (68 pixel rows) measured best at 4K (2 per XCD: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
-    const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544); // chunks of ~68 pixel rows
-    const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
-    const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
+    // XCD columns (device/xcd.h xcdWalk2): at the 4K frame's 1920 x 1080 filter image two columns of XCDs - chunks of ~68 rows x 960 texels, four per XCD - measure
+    // 184 - 186 us for the two passes against 188 - 190 with full-width chunks (the frame 0.697 - 0.699 against 0.704 - 0.705 ms, three alternating pairs); at 8K
+    // (3840 x 2160) two columns are neutral and four cost 3 %, at 1080p (960 x 540) two cost 4 %: one column there (profiles/r06e_spatial_walk.txt).
+    // PLR_SPATIAL_SPLIT_X / PLR_SPATIAL_CHUNKS: the hooks of tools/spatial_walk_ab.sh
+    static const int splitXEnv = std::getenv("PLR_SPATIAL_SPLIT_X") ? std::atoi(std::getenv("PLR_SPATIAL_SPLIT_X")) : 0;
+    static const int chunksEnv = std::getenv("PLR_SPATIAL_CHUNKS") ? std::atoi(std::getenv("PLR_SPATIAL_CHUNKS")) : 0;
+    const int widthPx = tilesX * TXv, heightPx = tilesY * TYv;
+    int splitX = splitXEnv ? splitXEnv : (widthPx >= 1536 && widthPx < 3072 ? 2 : 1);
+    if ((splitX != 2 && splitX != 4 && splitX != 8) || tilesX < 2 * splitX) splitX = 1;
+    // chunks of ~68 pixel rows: measured best at 4K (2 per XCD of full-width chunks: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
+    const int xcdRows = 8 / splitX;
+    const int chunksPerXcd = chunksEnv > 0 ? chunksEnv : std::max(1, (heightPx + 34 * xcdRows) / (68 * xcdRows));
+    const int chunkRows = xcdChunkRows2(tilesY, chunksPerXcd, splitX) | (splitX << 16);
+    const dim3 grid = xcdWalkGrid2(tilesX, tilesY, chunksPerXcd, splitX);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
     const bool sameGrid = c.sampled[4].w == c.sampled[2].w && c.sampled[4].h == c.sampled[2].h;
     uint8_t* scratch = spatialScratch(c, sameGrid);
@@ -682,7 +692,7 @@ static int launchGiSampleRequestsImpl(const PassCtx& c, const PassCtx* second) {
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
     const int chunksPerXcd = std::max(1, (tilesY * TYv + 272) / 544);
-    const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd);
+    const int chunkRows = xcdChunkRows(tilesY, chunksPerXcd) | (1 << 16); // (rows | splitX << 16: the kernel's xcdWalk2)
     const dim3 grid = xcdWalkGrid(tilesX, tilesY, chunksPerXcd);
     PLR_CHECK_LAUNCH(c);
     int validLo, validHi, validLoX, validHiX;
