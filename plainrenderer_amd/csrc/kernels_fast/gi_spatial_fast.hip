@@ -549,18 +549,19 @@ static int launchSpatialFilterFast(const PassCtx& c) {
 #endif
     constexpr int TXv = PLR_SPATIAL_TX, TYv = 256 / TXv;
     const int tilesX = (int)divUp((unsigned)(w - x0), (unsigned)TXv), tilesY = (int)divUp((unsigned)(h - y0), (unsigned)TYv);
-    // XCD columns (device/xcd.h xcdWalk2): at the 4K frame's 1920 x 1080 filter image two columns of XCDs - chunks of ~68 rows x 960 texels, four per XCD - measure
-    // 184 - 186 us for the two passes against 188 - 190 with full-width chunks (the frame 0.697 - 0.699 against 0.704 - 0.705 ms, three alternating pairs); at 8K
-    // (3840 x 2160) two columns are neutral and four cost 3 %, at 1080p (960 x 540) two cost 4 %: one column there (profiles/r06e_spatial_walk.txt).
+    // XCD columns (device/xcd.h xcdWalk2): at the 4K frame's 1920 x 1080 filter image two columns of XCDs - chunks of 960 texels x ~90 rows, three per XCD - measure
+    // 184 - 187 us for the two passes against 188 - 190 with full-width chunks of 68 rows (the frame 0.699 - 0.702 against 0.704 - 0.705 ms) and 1.77 x the
+    // algorithmic HBM bytes against 1.87 x (four chunks of 68 rows: the same time, 1.94 x; two of 135: 1.60 x and the old time); at 8K (3840 x 2160) two columns
+    // are neutral and four cost 3 %, at 1080p (960 x 540) two cost 4 %: one column there (profiles/r06_spatial_walk.txt).
     // PLR_SPATIAL_SPLIT_X / PLR_SPATIAL_CHUNKS: the hooks of tools/spatial_walk_ab.sh
     static const int splitXEnv = std::getenv("PLR_SPATIAL_SPLIT_X") ? std::atoi(std::getenv("PLR_SPATIAL_SPLIT_X")) : 0;
     static const int chunksEnv = std::getenv("PLR_SPATIAL_CHUNKS") ? std::atoi(std::getenv("PLR_SPATIAL_CHUNKS")) : 0;
     const int widthPx = tilesX * TXv, heightPx = tilesY * TYv;
     int splitX = splitXEnv ? splitXEnv : (widthPx >= 1536 && widthPx < 3072 ? 2 : 1);
     if ((splitX != 2 && splitX != 4 && splitX != 8) || tilesX < 2 * splitX) splitX = 1;
-    // chunks of ~68 pixel rows: measured best at 4K (2 per XCD of full-width chunks: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
-    const int xcdRows = 8 / splitX;
-    const int chunksPerXcd = chunksEnv > 0 ? chunksEnv : std::max(1, (heightPx + 34 * xcdRows) / (68 * xcdRows));
+    // one column: chunks of ~68 pixel rows measured best at 4K (2 per XCD of full-width chunks: 222 -> 199 us for the two passes) and 8K (4 per XCD: 1472 -> 827 us)
+    const int xcdRows = 8 / splitX, chunkPx = splitX == 1 ? 68 : 90;
+    const int chunksPerXcd = chunksEnv > 0 ? chunksEnv : std::max(1, (heightPx + chunkPx * xcdRows / 2) / (chunkPx * xcdRows));
     const int chunkRows = xcdChunkRows2(tilesY, chunksPerXcd, splitX) | (splitX << 16);
     const dim3 grid = xcdWalkGrid2(tilesX, tilesY, chunksPerXcd, splitX);
     // half-res trace: depth and GI images share the texel grid (one texel index serves all gathers, and the packed path applies)
