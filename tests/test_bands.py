@@ -761,8 +761,8 @@ def test_gpu_tiles_reproduce_the_full_frame_bit_exact(grid, half_res, transport)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid", [(2, 2), (1, 3), (4, 3), (2, 1)])
-def test_gpu_request_lists_reproduce_the_full_frame_bit_exact(grid):
+@pytest.mark.parametrize("grid,overlap", [((2, 2), None), ((1, 3), None), ((4, 3), None), ((2, 1), None), ((2, 2), 0), ((1, 3), 0)])
+def test_gpu_request_lists_reproduce_the_full_frame_bit_exact(grid, overlap):
     """band_gi_halo = PLRF_HALO_REQUESTED (round 6): in front of the two spatial GI filter passes no halo is exchanged at all - every rank asks the
     owners for exactly the texels its disc samples land on (giSampleRequests passes -> bitmaps -> ExchangeGiRequests; then Y_SH, CoCg and depth of the marked texels at
     the two GI exchange points), through the native exchange over its in-process transport. With the other halos as large as the image the partitioned frame must
@@ -773,6 +773,8 @@ def test_gpu_request_lists_reproduce_the_full_frame_bit_exact(grid):
     n = len(rects)
     big = max(W, H)
     halos = dict(band_gi_halo=0xfffffffe, band_gi_history_halo=big, band_post_halo=big, band_taa_history_halo=big)
+    if overlap is not None:  # band_overlap_exchange 0: one exchange callback and ONE filter execution per point (default: BEGIN / END around the filter's first phase)
+        halos["band_overlap_exchange"] = overlap
     tiles = _run_bands(inputs, n, False, halos, rects=rects, transport="native")
     mism = _compare(full, tiles, n, rects=rects)
     bad = {k: v for k, v in mism.items() if v != 0.0}
